@@ -1,0 +1,194 @@
+/*
+ * rama_hip.h -- C ABI of the MI355X (gfx950) backend for oliverhu/rama's decode path.
+ *
+ * This is the drop-in boundary: exactly what a Rust `impl Device<HipSlice> for Hip`
+ * (reference trait: engine/src/device/device.rs:3-24) would bind over `extern "C"`,
+ * in place of the reference's cudarc/NVRTC/cuBLAS backend (engine/src/device/gpu.rs,
+ * engine/src/device/math.cu, engine/src/transformer/hbm.rs).  Plain pointers and
+ * sizes only; no C++ / torch types.  See INTEGRATION.md for the Rust-side stub.
+ *
+ * Conventions
+ *  - Every `float*` / `const float*` argument is a DEVICE pointer already offset by
+ *    the caller's View.range.start (reference: `cudaview()`, gpu.rs:51-69), except
+ *    where the name says `host`.
+ *  - All work is enqueued on the context's HIP stream and is asynchronous unless the
+ *    function copies to host memory (those synchronise, like cudarc's *_sync_* calls).
+ *  - Return value: 0 = ok; > 0 = a hipError_t; < 0 = RAMA_E*.  The reference trait has
+ *    no Result and unwraps every driver call (panic); a host wrapper that wants that
+ *    behaviour aborts on non-zero.  rama_last_error() gives a message for the calling
+ *    thread's last failure.
+ *  - Thread-safety: one context = one stream; calls on one context must be serialised
+ *    by the caller.  Distinct contexts / run states may be used from distinct threads
+ *    over shared read-only weights (reference: one RunState per request, lib.rs:134-147).
+ */
+#ifndef RAMA_HIP_H
+#define RAMA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAMA_OK        0
+#define RAMA_EINVAL   (-1)  /* bad argument (null pointer, width % 4 != 0, pos >= seq_len ...) */
+#define RAMA_EUNSUP   (-2)  /* shape the reference path does not support (n_kv_heads != n_heads) */
+#define RAMA_EIO      (-3)  /* checkpoint file problem */
+#define RAMA_ENOMEM   (-4)
+
+typedef struct rama_ctx rama_ctx;
+typedef struct rama_model rama_model;
+
+/* ---------------------------------------------------------------- lifecycle
+ * replaces GPU::new (gpu.rs:213-234: device 0, NVRTC compile, cuBLAS handle).
+ * `hip_stream` may be NULL (the context creates its own non-blocking stream) or an
+ * existing hipStream_t to adopt (e.g. a framework's current stream). */
+int  rama_ctx_create(int device, void *hip_stream, rama_ctx **out);
+int  rama_ctx_destroy(rama_ctx *ctx);
+int  rama_sync(rama_ctx *ctx);                       /* hipStreamSynchronize */
+const char *rama_last_error(void);
+/* name (<= 63 chars), compute units, total HBM bytes of the context's device */
+int  rama_device_info(rama_ctx *ctx, char name[64], int *compute_units, size_t *hbm_bytes);
+
+/* ---------------------------------------------------------------- memory
+ * replaces hbm.rs:14-16 `allocate` (= htod_sync_copy) and dtoh_sync_copy_into
+ * (gpu.rs:196-209 to_cpu, hbm.rs:38-51 into_state). */
+int  rama_alloc_f32(rama_ctx *ctx, size_t n, float **out);            /* zero-filled, cf. ram.rs:10-21 */
+int  rama_upload_f32(rama_ctx *ctx, const float *host, size_t n, float **out);  /* alloc + H2D */
+int  rama_copy_h2d_f32(rama_ctx *ctx, float *dst, const float *host, size_t n);
+int  rama_download_f32(rama_ctx *ctx, const float *src, size_t n, float *host);
+int  rama_free(rama_ctx *ctx, void *device_ptr);
+
+/* ---------------------------------------------------------------- Device<T> ops, 1:1
+ * engine/src/device/device.rs:3-24; arithmetic follows the CPU backend
+ * (engine/src/device/cpu.rs), never math.cu (which is buggy: SURVEY.md section 2.1). */
+int  rama_array_add(rama_ctx *ctx, float *target, const float *source, size_t n);   /* device.rs:4  cpu.rs:16-21 */
+int  rama_array_mult(rama_ctx *ctx, float *target, const float *source, size_t n);  /* device.rs:5  cpu.rs:59-64 */
+int  rama_sinu(rama_ctx *ctx, float *o, size_t n);                                   /* device.rs:6  cpu.rs:54-57 */
+int  rama_copy_from_slice(rama_ctx *ctx, float *target, const float *source, size_t n); /* device.rs:9 cpu.rs:66-72 */
+int  rama_rmsnorm(rama_ctx *ctx, float *o, const float *x, const float *weight, size_t n); /* device.rs:10 cpu.rs:99-117 */
+/* device.rs:12 cpu.rs:74-97: one head of q and k rotated in place by (pos_real[i], pos_img[i]) */
+int  rama_apply_position(rama_ctx *ctx, float *q, float *k, const float *pos_real,
+                         const float *pos_img, size_t head_size);
+/* device.rs:13 cpu.rs:127-153: o[r*o_cols + c] = sum_k a[r*width + k] * b[k*o_cols + c];
+ * a = weight matrix [o_rows, width] row-major, b = activations.  width % 4 != 0 ->
+ * RAMA_EINVAL (the reference CPU body panics there). */
+int  rama_matmul(rama_ctx *ctx, float *o, const float *a, const float *b,
+                 size_t width, size_t o_rows, size_t o_cols);
+int  rama_softmax(rama_ctx *ctx, float *x, size_t n);                                /* device.rs:14 cpu.rs:119-125 */
+/* device.rs:7-8 cpu.rs:23-52; flat argument list as math.cu:94 calculate_attention +
+ * math.cu:72 update_xb take it.  key_cache/value_cache are the full [L, seq_len, dim] buffers. */
+int  rama_multi_head_attention(rama_ctx *ctx, float *xb, float *att, const float *q,
+                               const float *key_cache, const float *value_cache,
+                               int layer, int dim, int pos, int head_size, int seq_len, int n_heads);
+/* device.rs:16 Device::sample, T == 0 leg (cpu.rs:163-167): argmax on the device, ties ->
+ * last maximal index; only the 4-byte result crosses PCIe (reference GPU path clones and
+ * downloads all logits per token, gpu.rs:153). */
+int  rama_sample_argmax(rama_ctx *ctx, const float *logits, size_t n, int32_t *next_host);
+/* T != 0 leg (cpu.rs:168-177, infer.rs:55-85): temperature scale (only if T < 1), softmax,
+ * top-p.  `u` = the uniform draw; the reference re-seeds ChaCha20 every call (cpu.rs:161-162,
+ * gpu.rs:151-152) so its draw is one constant.  Runs on the host after one logits download,
+ * as the reference's GPU path does. */
+int  rama_sample_topp(rama_ctx *ctx, const float *logits, size_t n, float temperature,
+                      float topp, float u, int32_t *next_host);
+
+/* ---------------------------------------------------------------- model + state
+ * engine/src/transformer/mod.rs:128-138 */
+typedef struct {
+    int32_t dim, hidden_dim, n_layers, n_heads, n_kv_heads, vocab_size, seq_len;
+    int32_t shared_weight;
+} rama_config;
+
+/* engine/src/transformer/state.rs:53-74; device pointers.  For a pipeline stage the
+ * per-layer tensors hold only layers [layer_begin, layer_end) (index = layer - layer_begin);
+ * tensors a stage does not own are NULL. */
+typedef struct {
+    const float *token_embedding_table;
+    const float *rms_att_weight, *rms_ffn_weight;
+    const float *wq, *wk, *wv, *wo, *w1, *w2, *w3;
+    const float *rms_final_weight;
+    const float *freq_cis_real, *freq_cis_imag;
+    const float *wcls;            /* == token_embedding_table when shared (state.rs:111-117) */
+} rama_weights;
+
+/* engine/src/transformer/state.rs:3-17, sized as ram.rs:7-23 (caches: [n_local_layers, seq_len, dim]) */
+typedef struct {
+    float *x, *xb, *xb2, *hb, *hb2, *q, *k, *v, *att, *logits, *key_cache, *value_cache;
+} rama_run_state;
+
+typedef struct {
+    int32_t layer_begin, layer_end;   /* this stage's layers */
+    int32_t do_embed;                 /* 1: gather x from token_embedding_table (infer.rs:13) */
+    int32_t do_cls;                   /* 1: final rmsnorm + classifier (infer.rs:49-51) */
+} rama_stage;
+
+/* llama2.c v0 checkpoint (header mod.rs:141-166, tensor order ram.rs:28-51): mmap the file,
+ * one hipMalloc for the tensor blob, one staged H2D copy (replaces 6.7 G four-byte reads,
+ * utils/read.rs:25-33, + 14 htod_sync_copy, hbm.rs:55-90). */
+int  rama_model_load(rama_ctx *ctx, const char *path, rama_model **out);
+/* Synthetic weights of a given shape, generated in HBM by an integer-hash fill kernel
+ * (bit-identical to oracle_fill_synth); only layers of `stage` are materialised.
+ * rope_real/rope_imag: host tables [seq_len, head_size/2] or NULL (computed here). */
+int  rama_model_synth(rama_ctx *ctx, const rama_config *cfg, uint64_t seed, const rama_stage *stage,
+                      const float *rope_real_host, const float *rope_imag_host, rama_model **out);
+int  rama_model_config(const rama_model *m, rama_config *cfg);
+int  rama_model_weights(const rama_model *m, rama_weights *w);
+size_t rama_model_bytes(const rama_model *m);
+int  rama_model_free(rama_ctx *ctx, rama_model *m);
+
+int  rama_state_create(rama_ctx *ctx, const rama_config *cfg, int n_local_layers, rama_run_state *out);
+int  rama_state_free(rama_ctx *ctx, rama_run_state *s);
+
+/* bit-exact device twin of oracle_fill_synth: dst[i] = bias + (float)(ih4(i+offset) - 131070) * scale */
+int  rama_fill_synth(rama_ctx *ctx, float *dst, size_t n, uint64_t seed, uint64_t tag,
+                     uint64_t offset, float scale, float bias);
+
+/* ---------------------------------------------------------------- fused decode path
+ * engine/src/transformer/infer.rs:8-53 forward(cfg, wv, rsv, token, pos, device): the same
+ * values in logits / key_cache / value_cache / x (per-layer residual), computed with fused
+ * launches (rmsnorm folded into the following matvec, RoPE + cache append into the QKV
+ * epilogue, SiLU*gate into W1/W3, residual adds into Wo / W2).  Scratch buffers the fusion
+ * makes dead (xb2, hb2, and x/xb after the final norm) are not written; the 1:1 ops above
+ * reproduce the full choreography. */
+int  rama_forward(rama_ctx *ctx, const rama_config *cfg, const rama_weights *w,
+                  rama_run_state *s, int token, int pos);
+int  rama_forward_stage(rama_ctx *ctx, const rama_config *cfg, const rama_weights *w,
+                        rama_run_state *s, int token, int pos, const rama_stage *stage);
+
+/* generate() loop of mod.rs:169-206 at temperature 0, chained on the device: token = 1 (BOS)
+ * at pos 0; while pos < steps: forward; next = pos < n_prompt ? prompt[pos] : argmax(logits);
+ * out[pos] = next.  No per-token host round trip; out_tokens_host receives `steps` ids. */
+int  rama_generate_greedy(rama_ctx *ctx, const rama_config *cfg, const rama_weights *w,
+                          rama_run_state *s, const int32_t *prompt_tokens_host, int n_prompt,
+                          int steps, int32_t *out_tokens_host);
+/* The same loop in pieces, for timing: begin sets (token, pos) and the forced-token list;
+ * each decode_steps call enqueues n more (forward + argmax + advance) steps. */
+int  rama_decode_begin(rama_ctx *ctx, int token, int pos, const int32_t *forced_tokens_host, int n_forced);
+int  rama_decode_steps(rama_ctx *ctx, const rama_config *cfg, const rama_weights *w,
+                       rama_run_state *s, int n_steps);
+/* tokens produced since rama_decode_begin (synchronises) */
+int  rama_decode_tokens(rama_ctx *ctx, int32_t *out_tokens_host, int max_tokens, int *n_out);
+/* 1: capture each decode step into a hipGraph and replay it (default 0 = eager launches) */
+int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
+
+/* ---------------------------------------------------------------- measurement
+ * HIP events on the context's stream (the stream the kernels are launched on). */
+int  rama_timer_start(rama_ctx *ctx);
+int  rama_timer_stop(rama_ctx *ctx, float *elapsed_ms);      /* synchronises */
+/* Per-kernel timing: while enabled, every launch of kernel class `kernel_id` on the fused
+ * path is bracketed by an event pair (eager mode only).  Classes: */
+#define RAMA_K_QKV   0   /* rmsnorm + Wq|Wk|Wv matvec + RoPE + cache append */
+#define RAMA_K_ATTN  1   /* multi-head attention */
+#define RAMA_K_WO    2   /* Wo matvec + residual */
+#define RAMA_K_W13   3   /* rmsnorm + W1|W3 matvec + SiLU*gate */
+#define RAMA_K_W2    4   /* W2 matvec + residual */
+#define RAMA_K_CLS   5   /* final rmsnorm + classifier matvec */
+#define RAMA_K_COUNT 6
+int  rama_kprof_enable(rama_ctx *ctx, int kernel_id, int max_records);
+int  rama_kprof_read(rama_ctx *ctx, int *n_launches, double *total_ms);  /* synchronises, disables */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAMA_HIP_H */

@@ -1,0 +1,542 @@
+// kernels.hpp -- hand-written HIP kernels for gfx950 (CDNA4, wave64) of rama's fp32
+// decode path.  Arithmetic follows the reference CPU backend (engine/src/device/cpu.rs);
+// the op order follows engine/src/transformer/infer.rs:8-53.
+//
+// Design (DESIGN.md has the numbers):
+//  * The W.x matvecs are >99 % of the bytes and HBM-bound (0.5 FLOP/B).  Weight rows are
+//    streamed once with 16-byte-per-lane `buffer_load_dwordx4 ... nt` straight into VGPRs
+//    (no LDS round trip: nothing is shared between waves), all loads of a step issued
+//    before the first use.  A 256-thread workgroup owns R consecutive rows and splits K
+//    across its four waves (contiguous K-quarters), so a [4096]-wide row group is ONE
+//    burst of 16 outstanding loads per lane; partial sums are reduced with DPP inside a
+//    wave and through 80 bytes of LDS across the four waves.
+//  * Buffer (SRSRC) addressing gives hardware bounds checking: out-of-range lanes/chunks
+//    get offset 0x80000000 and return 0 without touching memory, so ragged widths
+//    (288 = 256 + 32) and row tails need no branches in the load stream.
+//  * rmsnorm is folded into the consuming matvec (sum x^2 rides along the same K split),
+//    RoPE + KV-cache append into the QKV epilogue, SiLU*gate into W1|W3, residual adds
+//    into Wo / W2: five launches per layer.
+//  * (token, pos) live in device memory (`Ctl`) so a decode step can be replayed from a
+//    hipGraph and chained to the device-side argmax with no host round trip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rama {
+
+typedef __attribute__((ext_vector_type(4))) float f4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+
+struct Ctl {          // device-resident decode cursor
+    int token;        // token fed to the next forward
+    int pos;          // its position
+    int n_forced;     // forced (prompt) tokens: next = forced[pos] while pos < n_forced
+    int n_out;        // tokens written to `out` so far
+};
+
+constexpr unsigned kOOB = 0x80000000u;   // >= any num_records we build: load returns 0
+constexpr int kWG = 256;                 // 4 waves
+
+// ---------------------------------------------------------------- small device helpers
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+// streamed-once weights: non-temporal (aux bit 1)
+__device__ __forceinline__ f4 ld_nt(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 2));
+}
+// shared activations: default policy (L2 resident)
+__device__ __forceinline__ f4 ld_c(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+        0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// sum over the 16 lanes of a DPP row; every lane of the row gets the sum
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);   // row_half_mirror
+    v += dpp_mov<0x140>(v);   // row_mirror
+    return v;
+}
+// sum over all 64 lanes, fixed order, wave-uniform result
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ float dot4(f4 a, f4 b, float acc) {
+    acc = fmaf(a.x, b.x, acc);
+    acc = fmaf(a.y, b.y, acc);
+    acc = fmaf(a.z, b.z, acc);
+    acc = fmaf(a.w, b.w, acc);
+    return acc;
+}
+
+// ---------------------------------------------------------------- the streaming core
+// S weight streams (rows) of width K against one activation vector; K is split over the
+// workgroup's 4 waves in 256-float chunks.  On return acc[s] / ss hold this WAVE's
+// (wave-reduced, wave-uniform) partial sums.
+//   NM   : streams alternate over NM matrices (s % NM): 1, or 2 for W1|W3
+//   NORM : activations are nw[k]*x[k]; ss accumulates sum x[k]^2 (rmsnorm folded in)
+template <int S, int NM, int CH, bool NORM>
+__device__ __forceinline__ void stream_dots(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb,
+                                            const unsigned (&rowoff)[S],
+                                            __amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t rn,
+                                            int K, float (&acc)[S], float& ss) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nch = (K + 255) >> 8;          // 256-float chunks in a row
+    const int cpw = (nch + 3) >> 2;          // chunks per wave
+    const int c0 = wave * cpw;
+    const int c1 = min(c0 + cpw, nch);
+    const unsigned kbytes = (unsigned)K * 4u;
+#pragma unroll
+    for (int s = 0; s < S; s++) acc[s] = 0.0f;
+    ss = 0.0f;
+    for (int c = c0; c < c1; c += CH) {
+        f4 w[S][CH];
+        f4 xv[CH];
+        f4 nv[CH];
+        unsigned kb[CH];
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            unsigned b = (unsigned)((c + j) * 1024 + lane * 16);
+            kb[j] = ((c + j) < c1 && b < kbytes) ? b : kOOB;
+        }
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+#pragma unroll
+            for (int s = 0; s < S; s++) {
+                unsigned o = (kb[j] == kOOB) ? kOOB : rowoff[s] + kb[j];
+                w[s][j] = ld_nt((NM == 2 && (s & 1)) ? rb : ra, o);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            xv[j] = ld_c(rx, kb[j]);
+            if (NORM) nv[j] = ld_c(rn, kb[j]);
+        }
+        // every load of the step is in flight before the first FMA: without this fence
+        // hipcc's max-occupancy scheduler interleaves loads with uses to save VGPRs and
+        // leaves only ~8 of the S*CH + 2*CH loads outstanding.
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            f4 xe = xv[j];
+            if (NORM) {
+                ss = dot4(xv[j], xv[j], ss);
+                xe = xv[j] * nv[j];
+            }
+#pragma unroll
+            for (int s = 0; s < S; s++) acc[s] = dot4(w[s][j], xe, acc[s]);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < S; s++) acc[s] = wave_sum(acc[s]);
+    if (NORM) ss = wave_sum(ss);
+}
+
+// cross-wave combine through LDS: part[wave][0..S-1] = acc, part[wave][S] = ss
+template <int S>
+__device__ __forceinline__ void publish_partials(float (*part)[S + 1], const float (&acc)[S], float ss) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int s = 0; s < S; s++) part[wave][s] = acc[s];
+        part[wave][S] = ss;
+    }
+    __syncthreads();
+}
+template <int S>
+__device__ __forceinline__ float combined(float (*part)[S + 1], int s) {
+    return (part[0][s] + part[1][s]) + (part[2][s] + part[3][s]);
+}
+// cpu.rs:110-113: v = 1/sqrt(sum(x^2)/len + 1e-5)
+__device__ __forceinline__ float rms_scale(float ss, int n) {
+    return 1.0f / sqrtf(ss / (float)n + 1e-5f);
+}
+
+// ---------------------------------------------------------------- matvec kernels
+
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_QKV = 2 };
+
+struct GemvParams {
+    const float* w[3];     // nmat matrices, each [rows, K] row-major
+    const float* x;        // [K]
+    const float* nw;       // [K] rmsnorm gain (NORM)
+    float* o[3];           // outputs per matrix (EPI_STORE: o[0]; EPI_RESID: o[0] += ; EPI_QKV: q,k,v)
+    int K, rows, nmat;
+    // EPI_QKV
+    const Ctl* ctl;        // device cursor, or NULL -> pos_val
+    int pos_val;
+    const float* fr;       // freq_cis_real [seq, hs/2]
+    const float* fi;
+    int head_size;
+    float* kc;             // this layer's key cache   [seq, dim]
+    float* vc;             // this layer's value cache [seq, dim]
+};
+
+// R rows per workgroup; grid = nmat*rows/R (rows % R need not be 0: tail rows read as 0)
+template <int R, int CH, bool NORM, int EPI>
+__global__ __launch_bounds__(kWG) void gemv_rows(GemvParams p) {
+    __shared__ float part[4][R + 1];
+    const int groups_per_mat = (p.rows + R - 1) / R;
+    const int m = blockIdx.x / groups_per_mat;
+    const int r0 = (blockIdx.x - m * groups_per_mat) * R;
+    const float* W = (m == 0) ? p.w[0] : (m == 1 ? p.w[1] : p.w[2]);
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(W, (unsigned)p.rows * (unsigned)p.K * 4u);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (unsigned)p.K * 4u);
+    const __amdgpu_buffer_rsrc_t rn = make_rsrc(NORM ? p.nw : p.x, (unsigned)p.K * 4u);
+    unsigned rowoff[R];
+#pragma unroll
+    for (int s = 0; s < R; s++)
+        rowoff[s] = (r0 + s < p.rows) ? (unsigned)(r0 + s) * (unsigned)p.K * 4u : kOOB;
+    float acc[R], ss;
+    stream_dots<R, 1, CH, NORM>(ra, ra, rowoff, rx, rn, p.K, acc, ss);
+    publish_partials<R>(part, acc, ss);
+
+    const int t = threadIdx.x;
+    if (EPI == EPI_STORE || EPI == EPI_RESID) {
+        if (t < R && r0 + t < p.rows) {
+            float d = combined<R>(part, t);
+            if (NORM) d *= rms_scale(combined<R>(part, R), p.K);
+            float* o = (m == 0) ? p.o[0] : (m == 1 ? p.o[1] : p.o[2]);
+            if (EPI == EPI_RESID) d = o[r0 + t] + d;     // infer.rs:37,47  x[i] += y[i]
+            o[r0 + t] = d;
+        }
+    } else {   // EPI_QKV: rows are (even, odd) pairs of one head (R even, head_size even)
+        if (t < R / 2) {
+            const int r = r0 + 2 * t;
+            float a = combined<R>(part, 2 * t), b = combined<R>(part, 2 * t + 1);
+            if (NORM) {
+                const float v = rms_scale(combined<R>(part, R), p.K);
+                a *= v; b *= v;
+            }
+            const int pos = p.ctl ? p.ctl->pos : p.pos_val;
+            if (m < 2) {   // cpu.rs:87-96 rotate (q, k); table row pos, entry (r % hs)/2
+                const int i = (r % p.head_size) >> 1;
+                const float c = p.fr[(size_t)pos * (p.head_size >> 1) + i];
+                const float s = p.fi[(size_t)pos * (p.head_size >> 1) + i];
+                const float ra_ = a * c - b * s;
+                const float rb_ = a * s + b * c;
+                a = ra_; b = rb_;
+            }
+            float* o = (m == 0) ? p.o[0] : (m == 1 ? p.o[1] : p.o[2]);
+            o[r] = a; o[r + 1] = b;
+            if (m == 1) {          // infer.rs:32  key_cache[lo + pos*dim ..] = k
+                p.kc[(size_t)pos * p.rows + r] = a; p.kc[(size_t)pos * p.rows + r + 1] = b;
+            } else if (m == 2) {   // infer.rs:33
+                p.vc[(size_t)pos * p.rows + r] = a; p.vc[(size_t)pos * p.rows + r + 1] = b;
+            }
+        }
+    }
+}
+
+struct SwigluParams {
+    const float* w1;   // [rows, K]
+    const float* w3;   // [rows, K]
+    const float* x;    // [K]
+    const float* nw;   // [K]
+    float* hb;         // [rows]
+    int K, rows;
+};
+
+// hb[r] = silu(w1[r].xs) * (w3[r].xs), xs = rmsnorm(x) * nw   (infer.rs:39-45, cpu.rs:54-64)
+template <int R2, int CH>
+__global__ __launch_bounds__(kWG) void gemv_swiglu(SwigluParams p) {
+    constexpr int S = 2 * R2;
+    __shared__ float part[4][S + 1];
+    const int r0 = blockIdx.x * R2;
+    const unsigned mbytes = (unsigned)p.rows * (unsigned)p.K * 4u;
+    const __amdgpu_buffer_rsrc_t r1 = make_rsrc(p.w1, mbytes);
+    const __amdgpu_buffer_rsrc_t r3 = make_rsrc(p.w3, mbytes);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (unsigned)p.K * 4u);
+    const __amdgpu_buffer_rsrc_t rn = make_rsrc(p.nw, (unsigned)p.K * 4u);
+    unsigned rowoff[S];
+#pragma unroll
+    for (int s = 0; s < S; s++)
+        rowoff[s] = (r0 + (s >> 1) < p.rows) ? (unsigned)(r0 + (s >> 1)) * (unsigned)p.K * 4u : kOOB;
+    float acc[S], ss;
+    stream_dots<S, 2, CH, true>(r1, r3, rowoff, rx, rn, p.K, acc, ss);
+    publish_partials<S>(part, acc, ss);
+    const int t = threadIdx.x;
+    if (t < R2 && r0 + t < p.rows) {
+        const float v = rms_scale(combined<S>(part, S), p.K);
+        float a = combined<S>(part, 2 * t) * v;
+        const float b = combined<S>(part, 2 * t + 1) * v;
+        a = a * (1.0f / (1.0f + expf(-a)));   // cpu.rs:56
+        p.hb[r0 + t] = a * b;                 // cpu.rs:59-64
+    }
+}
+
+// generic o_cols > 1 product of the trait signature (never used by forward): one thread per output
+__global__ void matmul_generic(float* o, const float* a, const float* b, int width, int o_rows, int o_cols) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= o_rows * o_cols) return;
+    int r = idx / o_cols, c = idx % o_cols;
+    float acc = 0.0f;
+    for (int k = 0; k < width; k++) acc = fmaf(a[(size_t)r * width + k], b[(size_t)k * o_cols + c], acc);
+    o[idx] = acc;
+}
+// unaligned-view fallback of the o_cols == 1 product (16-byte alignment not given): one wave per row
+__global__ __launch_bounds__(kWG) void matvec_unaligned(float* o, const float* a, const float* x, int width, int rows) {
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    int lane = threadIdx.x & 63;
+    float acc = 0.0f;
+    for (int k = lane; k < width; k += 64) acc = fmaf(a[(size_t)row * width + k], x[k], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) o[row] = acc;
+}
+
+// ---------------------------------------------------------------- attention (cpu.rs:23-52)
+// One workgroup per head.  G lanes cooperate on one cached row segment (head_size floats =
+// G x float4), so a wave covers 64/G timesteps per load instruction.
+struct AttnParams {
+    const float* q;       // [dim]
+    const float* kc;      // this layer's key cache   [seq, dim]
+    const float* vc;      // this layer's value cache [seq, dim]
+    float* att;           // [n_heads, seq_len] scores / probabilities (reference scratch)
+    float* xb;            // [dim] output
+    const Ctl* ctl;
+    int pos_val;
+    int dim, head_size, seq_len;
+};
+
+template <int G>
+__global__ __launch_bounds__(kWG) void attention_kernel(AttnParams p) {
+    extern __shared__ float sm[];            // [16 + 16*G] reduction scratch, then [seq_len] scores
+    float* s_red = sm;
+    float* s_att = sm + 16 + 16 * G;
+    const int h = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pos = p.ctl ? p.ctl->pos : p.pos_val;
+    const int hs = p.head_size;
+    constexpr int TPW = 64 / G;              // timesteps per wave-instruction
+    const int li = lane % G;                 // my float4 within the head segment
+    const int tg = lane / G;                 // my timestep slot within the wave
+    const bool lane_ok = li * 4 < hs;
+    const size_t hoff = (size_t)h * hs + (size_t)li * 4;
+
+    f4 q4 = {0.f, 0.f, 0.f, 0.f};
+    if (lane_ok) q4 = *reinterpret_cast<const f4*>(p.q + hoff);
+    const float inv_div = sqrtf((float)hs);
+
+    // scores: att[t] = (q . k_t) / sqrt(hs)
+    for (int t0 = wave * TPW; t0 <= pos; t0 += 4 * TPW) {
+        const int t = t0 + tg;
+        float d = 0.0f;
+        if (lane_ok && t <= pos) {
+            f4 k4 = *reinterpret_cast<const f4*>(p.kc + (size_t)t * p.dim + hoff);
+            d = dot4(q4, k4, 0.0f);
+        }
+        d = row16_sum(d);
+        if (G == 32) d += __shfl_xor(d, 16);
+        if (G == 64) { d += __shfl_xor(d, 16); d += __shfl_xor(d, 32); }
+        if (li == 0 && t <= pos) s_att[t] = d / inv_div;
+    }
+    __syncthreads();
+
+    // softmax over 0..=pos (cpu.rs:187-192): max, exp(a - max), sum, divide
+    float mx = -INFINITY;
+    for (int t = tid; t <= pos; t += kWG) mx = fmaxf(mx, s_att[t]);
+    mx = wave_max(mx);
+    if (lane == 0) s_red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    float sum = 0.0f;
+    for (int t = tid; t <= pos; t += kWG) {
+        float e = expf(s_att[t] - mx);
+        s_att[t] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) s_red[8 + wave] = sum;
+    __syncthreads();
+    sum = (s_red[8] + s_red[9]) + (s_red[10] + s_red[11]);
+    for (int t = tid; t <= pos; t += kWG) {
+        float a = s_att[t] / sum;
+        s_att[t] = a;
+        p.att[(size_t)h * p.seq_len + t] = a;
+    }
+    __syncthreads();
+
+    // xb[i] = sum_t att[t] * v_t[i]
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int t0 = wave * TPW; t0 <= pos; t0 += 4 * TPW) {
+        const int t = t0 + tg;
+        if (lane_ok && t <= pos) {
+            f4 v4 = *reinterpret_cast<const f4*>(p.vc + (size_t)t * p.dim + hoff);
+            const float a = s_att[t];
+            acc.x = fmaf(a, v4.x, acc.x); acc.y = fmaf(a, v4.y, acc.y);
+            acc.z = fmaf(a, v4.z, acc.z); acc.w = fmaf(a, v4.w, acc.w);
+        }
+    }
+    // fold the TPW timestep slots of the wave, then the 4 waves
+#pragma unroll
+    for (int m = G; m < 64; m <<= 1) {
+        acc.x += __shfl_xor(acc.x, m); acc.y += __shfl_xor(acc.y, m);
+        acc.z += __shfl_xor(acc.z, m); acc.w += __shfl_xor(acc.w, m);
+    }
+    if (lane < G) *reinterpret_cast<f4*>(s_red + 16 + (wave * G + lane) * 4) = acc;
+    __syncthreads();
+    if (tid < G && tid * 4 < hs) {
+        f4 a0 = *reinterpret_cast<f4*>(s_red + 16 + (0 * G + tid) * 4);
+        f4 a1 = *reinterpret_cast<f4*>(s_red + 16 + (1 * G + tid) * 4);
+        f4 a2 = *reinterpret_cast<f4*>(s_red + 16 + (2 * G + tid) * 4);
+        f4 a3 = *reinterpret_cast<f4*>(s_red + 16 + (3 * G + tid) * 4);
+        f4 r = (a0 + a1) + (a2 + a3);
+        *reinterpret_cast<f4*>(p.xb + (size_t)h * hs + (size_t)tid * 4) = r;
+    }
+}
+
+// ---------------------------------------------------------------- small ops
+
+// infer.rs:13: x = token_embedding_table[token*dim .. (token+1)*dim]
+__global__ void embed_kernel(float* x, const float* emb, const Ctl* ctl, int token_val, int dim) {
+    const int token = ctl ? ctl->token : token_val;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < dim; i += gridDim.x * blockDim.x)
+        x[i] = emb[(size_t)token * dim + i];
+}
+
+__global__ void set_ctl_kernel(Ctl* ctl, int token, int pos, int n_forced, int n_out) {
+    ctl->token = token; ctl->pos = pos; ctl->n_forced = n_forced; ctl->n_out = n_out;
+}
+
+__global__ void array_add_kernel(float* t, const float* s, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) t[i] += s[i];
+}
+__global__ void array_mult_kernel(float* t, const float* s, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) t[i] *= s[i];
+}
+__global__ void sinu_kernel(float* o, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float a = o[i];
+        o[i] = a * (1.0f / (1.0f + expf(-a)));
+    }
+}
+__global__ void copy_kernel(float* t, const float* s, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) t[i] = s[i];
+}
+
+// block-wide sum / max helpers for the single-workgroup ops (1024 threads = 16 waves)
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float s = 0.0f;
+    for (int i = 0; i < nw; i++) s += red[i];
+    return s;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    v = wave_max(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float s = red[0];
+    for (int i = 1; i < nw; i++) s = fmaxf(s, red[i]);
+    return s;
+}
+
+// cpu.rs:99-117, one workgroup
+__global__ __launch_bounds__(1024) void rmsnorm_kernel(float* o, const float* x, const float* w, int n) {
+    __shared__ float red[16];
+    float ss = 0.0f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) ss = fmaf(x[i], x[i], ss);
+    ss = block_sum(ss, red);
+    const float v = rms_scale(ss, n);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) o[i] = w[i] * (v * x[i]);
+}
+
+// cpu.rs:74-97, one head
+__global__ void apply_position_kernel(float* q, float* k, const float* pr, const float* pi, int head_size) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= head_size / 2) return;
+    float c = pr[i], s = pi[i];
+    float q0 = q[2 * i], q1 = q[2 * i + 1];
+    q[2 * i] = q0 * c - q1 * s; q[2 * i + 1] = q0 * s + q1 * c;
+    float k0 = k[2 * i], k1 = k[2 * i + 1];
+    k[2 * i] = k0 * c - k1 * s; k[2 * i + 1] = k0 * s + k1 * c;
+}
+
+// cpu.rs:119-125, one workgroup
+__global__ __launch_bounds__(1024) void softmax_kernel(float* x, int n) {
+    __shared__ float red[16];
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) mx = fmaxf(mx, x[i]);
+    mx = block_max(mx, red);
+    float sum = 0.0f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { float e = expf(x[i] - mx); x[i] = e; sum += e; }
+    sum = block_sum(sum, red);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) x[i] /= sum;
+}
+
+// Device::sample T == 0 (cpu.rs:163-167): max value, ties -> LAST index.  One workgroup.
+// With `ctl` set it also advances the decode cursor (generate loop, mod.rs:190-203):
+// next = pos < n_forced ? forced[pos] : argmax; out[n_out++] = next; token = next; pos += 1.
+__global__ __launch_bounds__(1024) void argmax_kernel(const float* logits, int n, int* result,
+                                                      Ctl* ctl, const int* forced, int* out, int out_cap) {
+    __shared__ float s_v[16];
+    __shared__ int s_i[16];
+    float bv = -INFINITY; int bi = -1;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        float v = logits[i];
+        if (bi < 0 || !(bv > v)) { bv = v; bi = i; }   // ascending i per thread: last max wins
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        float ov = __shfl_xor(bv, m); int oi = __shfl_xor(bi, m);
+        bool take = (bi < 0) || (oi >= 0 && (ov > bv || (ov == bv && oi > bi)));
+        if (take) { bv = ov; bi = oi; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_v[wave] = bv; s_i[wave] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bv = s_v[0]; bi = s_i[0];
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++) {
+            float ov = s_v[w]; int oi = s_i[w];
+            if ((bi < 0) || (oi >= 0 && (ov > bv || (ov == bv && oi > bi)))) { bv = ov; bi = oi; }
+        }
+        if (result) *result = bi;
+        if (ctl) {
+            const int pos = ctl->pos;
+            const int next = (pos < ctl->n_forced) ? forced[pos] : bi;
+            if (ctl->n_out < out_cap) out[ctl->n_out] = next;
+            ctl->n_out += 1;
+            ctl->token = next;
+            ctl->pos = pos + 1;
+        }
+    }
+}
+
+// bit-exact twin of oracle_fill_synth (integer hash, Irwin-Hall(4), one multiply, one add)
+__global__ void fill_synth_kernel(float* dst, size_t n, uint64_t base, float scale, float bias) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint64_t z = (uint64_t)i + base;
+        z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL;
+        z ^= z >> 27; z *= 0x94D049BB133111EBULL;
+        z ^= z >> 31;
+        int sum = (int)(z & 0xFFFF) + (int)((z >> 16) & 0xFFFF) + (int)((z >> 32) & 0xFFFF) + (int)(z >> 48);
+        dst[i] = __fadd_rn(bias, __fmul_rn((float)(sum - 131070), scale));   // no FMA contraction
+    }
+}
+
+}  // namespace rama

@@ -1,0 +1,200 @@
+// model.hip -- weights in HBM: llama2.c v0 checkpoint loader (mmap + one staged H2D copy)
+// and the synthetic-weight generator.  Replaces engine/src/transformer/ram.rs:27-52
+// (TransformerWeights::from_file, 4-byte read_exact loop of utils/read.rs:25-33) and
+// hbm.rs:55-90 (14 htod_sync_copy calls).
+#include "../../include/rama_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fcntl.h>
+#include <string>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <vector>
+
+extern "C" int rama_fill_synth(rama_ctx*, float*, size_t, uint64_t, uint64_t, uint64_t, float, float);
+
+struct rama_model {
+    rama_config cfg{};
+    rama_weights w{};
+    float* blob = nullptr;      // one allocation holding every tensor
+    size_t blob_floats = 0;
+    rama_stage stage{};
+};
+
+namespace {
+
+thread_local std::string g_model_err;
+
+struct TensorSpec { const char* name; size_t n; size_t per_layer; int tag; double std; float bias; };
+
+// tensor order of the v0 file = struct-literal order in ram.rs:31-49
+std::vector<TensorSpec> v0_layout(const rama_config& c) {
+    const size_t L = c.n_layers, d = c.dim, h = c.hidden_dim, V = c.vocab_size, S = c.seq_len;
+    const size_t hs = d / c.n_heads;
+    const double res = 0.02 / std::sqrt(2.0 * (double)L);   // model.py:232-236
+    std::vector<TensorSpec> t = {
+        {"token_embedding_table", V * d, 0, 1, 0.02, 0.f},
+        {"rms_att_weight", L * d, d, 2, 0.05, 1.f},
+        {"wq", L * d * d, d * d, 3, 0.02, 0.f},
+        {"wk", L * d * d, d * d, 4, 0.02, 0.f},
+        {"wv", L * d * d, d * d, 5, 0.02, 0.f},
+        {"wo", L * d * d, d * d, 6, res, 0.f},
+        {"rms_ffn_weight", L * d, d, 7, 0.05, 1.f},
+        {"w1", L * h * d, h * d, 8, 0.02, 0.f},
+        {"w2", L * d * h, d * h, 9, 0.02, 0.f},
+        {"w3", L * h * d, h * d, 10, res, 0.f},
+        {"rms_final_weight", d, 0, 11, 0.05, 1.f},
+        {"freq_cis_real", S * (hs / 2), 0, -1, 0, 0.f},
+        {"freq_cis_imag", S * (hs / 2), 0, -1, 0, 0.f},
+    };
+    if (!c.shared_weight) t.push_back({"wcls", V * d, 0, 12, 0.02, 0.f});
+    return t;
+}
+
+const float** field(rama_weights& w, const char* name) {
+#define F(n) if (!strcmp(name, #n)) return &w.n;
+    F(token_embedding_table) F(rms_att_weight) F(rms_ffn_weight) F(wq) F(wk) F(wv) F(wo) F(w1) F(w2) F(w3)
+    F(rms_final_weight) F(freq_cis_real) F(freq_cis_imag) F(wcls)
+#undef F
+    return nullptr;
+}
+
+int bad(int code, const char* msg) { fprintf(stderr, "rama_model: %s\n", msg); return code; }
+
+size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }
+
+}  // namespace
+
+extern "C" int rama_model_load(rama_ctx* ctx, const char* path, rama_model** out) {
+    if (!ctx || !path || !out) return bad(RAMA_EINVAL, "rama_model_load: NULL argument");
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return bad(RAMA_EIO, "cannot open checkpoint");
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || sb.st_size < 28) { close(fd); return bad(RAMA_EIO, "checkpoint too small"); }
+    void* map = mmap(nullptr, sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (map == MAP_FAILED) return bad(RAMA_EIO, "mmap failed");
+    int32_t hdr[7];
+    memcpy(hdr, map, 28);
+    rama_config c{};
+    // mod.rs:141-166: six fields as-is; the sign of vocab_size carries the shared flag
+    c.dim = hdr[0]; c.hidden_dim = hdr[1]; c.n_layers = hdr[2]; c.n_heads = hdr[3]; c.n_kv_heads = hdr[4];
+    c.vocab_size = hdr[5] > 0 ? hdr[5] : -hdr[5];
+    c.shared_weight = hdr[5] > 0;
+    c.seq_len = hdr[6];
+    if (hdr[0] == 0x616b3432) {   // "ak42": llama2.c v1/v2 header (export.py:132-260), which the engine cannot read
+        munmap(map, sb.st_size);
+        return bad(RAMA_EUNSUP, "checkpoint is llama2.c v1/v2 (ak42 header); rama reads the v0 legacy format only");
+    }
+    if (c.dim <= 0 || c.hidden_dim <= 0 || c.n_layers <= 0 || c.n_heads <= 0 || c.vocab_size <= 0 || c.seq_len <= 0 ||
+        c.dim % c.n_heads != 0) {
+        munmap(map, sb.st_size);
+        return bad(RAMA_EIO, "implausible v0 header");
+    }
+    auto layout = v0_layout(c);
+    size_t total = 0;
+    for (auto& t : layout) total += t.n;
+    if ((size_t)sb.st_size != 28 + total * 4) {
+        munmap(map, sb.st_size);
+        return bad(RAMA_EIO, "checkpoint size does not match its header (ram.rs:28-51 layout)");
+    }
+    rama_model* m = new rama_model();
+    m->cfg = c;
+    m->stage = rama_stage{0, c.n_layers, 1, 1};
+    m->blob_floats = total;
+    int rc = rama_alloc_f32(ctx, total, &m->blob);
+    if (rc) { munmap(map, sb.st_size); delete m; return rc; }
+    // 28-byte header => the tensor blob starts 12 bytes off a 16-byte boundary in the file,
+    // but lands 256-byte aligned in HBM; every tensor size is a multiple of 4 floats.
+    rc = rama_copy_h2d_f32(ctx, m->blob, (const float*)((const char*)map + 28), total);
+    munmap(map, sb.st_size);
+    if (rc) { rama_free(ctx, m->blob); delete m; return rc; }
+    size_t off = 0;
+    for (auto& t : layout) { *field(m->w, t.name) = m->blob + off; off += t.n; }
+    if (c.shared_weight) m->w.wcls = m->w.token_embedding_table;   // state.rs:111-117
+    *out = m;
+    return 0;
+}
+
+extern "C" int rama_model_synth(rama_ctx* ctx, const rama_config* cfg, uint64_t seed, const rama_stage* stage,
+                                const float* rope_real_host, const float* rope_imag_host, rama_model** out) {
+    if (!ctx || !cfg || !out) return bad(RAMA_EINVAL, "rama_model_synth: NULL argument");
+    rama_stage st = stage ? *stage : rama_stage{0, cfg->n_layers, 1, 1};
+    if (st.layer_begin < 0 || st.layer_begin > st.layer_end || st.layer_end > cfg->n_layers)
+        return bad(RAMA_EINVAL, "rama_model_synth: bad layer range");
+    if (cfg->dim <= 0 || cfg->n_heads <= 0 || cfg->dim % cfg->n_heads) return bad(RAMA_EINVAL, "rama_model_synth: bad config");
+    const size_t nl = (size_t)(st.layer_end - st.layer_begin);
+    auto layout = v0_layout(*cfg);
+    const double ih4_std = std::sqrt(4.0 * (65536.0 * 65536.0 - 1.0) / 12.0);
+    const bool need_emb = st.do_embed || (st.do_cls && cfg->shared_weight);
+
+    // which tensors this stage owns, and how many floats of each
+    struct Piece { TensorSpec t; size_t n; size_t src_off; };
+    std::vector<Piece> pieces;
+    size_t total = 0;
+    for (auto& t : layout) {
+        size_t n = 0, src = 0;
+        if (t.per_layer) { n = nl * t.per_layer; src = (size_t)st.layer_begin * t.per_layer; }
+        else if (!strcmp(t.name, "token_embedding_table")) n = need_emb ? t.n : 0;
+        else if (!strcmp(t.name, "rms_final_weight") || !strcmp(t.name, "wcls")) n = st.do_cls ? t.n : 0;
+        else n = t.n;   // RoPE tables: replicated, they are KBs
+        if (n) { pieces.push_back({t, n, src}); total += align64(n); }
+    }
+    rama_model* m = new rama_model();
+    m->cfg = *cfg; m->stage = st; m->blob_floats = total;
+    int rc = rama_alloc_f32(ctx, total, &m->blob);
+    if (rc) { delete m; return rc; }
+    size_t off = 0;
+    const size_t hs = cfg->dim / cfg->n_heads;
+    for (auto& p : pieces) {
+        float* dst = m->blob + off;
+        *field(m->w, p.t.name) = dst;
+        if (p.t.tag >= 0) {
+            rc = rama_fill_synth(ctx, dst, p.n, seed, (uint64_t)p.t.tag, (uint64_t)p.src_off,
+                                 (float)(p.t.std / ih4_std), p.t.bias);
+        } else {
+            const bool real = !strcmp(p.t.name, "freq_cis_real");
+            const float* given = real ? rope_real_host : rope_imag_host;
+            std::vector<float> tab;
+            if (!given) {   // model.py:41-47: cos/sin(t * 10000^(-2i/hs))
+                tab.resize(p.n);
+                for (size_t t = 0; t < (size_t)cfg->seq_len; t++)
+                    for (size_t i = 0; i < hs / 2; i++) {
+                        double f = 1.0 / std::pow(10000.0, (double)(2 * i) / (double)hs);
+                        tab[t * (hs / 2) + i] = (float)(real ? std::cos((double)t * f) : std::sin((double)t * f));
+                    }
+                given = tab.data();
+            }
+            rc = rama_copy_h2d_f32(ctx, dst, given, p.n);
+        }
+        if (rc) { rama_free(ctx, m->blob); delete m; return rc; }
+        off += align64(p.n);
+    }
+    if (cfg->shared_weight && st.do_cls) m->w.wcls = m->w.token_embedding_table;
+    if (!st.do_embed && !(st.do_cls && cfg->shared_weight)) m->w.token_embedding_table = nullptr;
+    *out = m;
+    return 0;
+}
+
+extern "C" int rama_model_config(const rama_model* m, rama_config* cfg) {
+    if (!m || !cfg) return RAMA_EINVAL;
+    *cfg = m->cfg;
+    return 0;
+}
+extern "C" int rama_model_weights(const rama_model* m, rama_weights* w) {
+    if (!m || !w) return RAMA_EINVAL;
+    *w = m->w;
+    return 0;
+}
+extern "C" size_t rama_model_bytes(const rama_model* m) { return m ? m->blob_floats * sizeof(float) : 0; }
+extern "C" int rama_model_free(rama_ctx* ctx, rama_model* m) {
+    if (!m) return 0;
+    int rc = rama_free(ctx, m->blob);
+    delete m;
+    return rc;
+}

@@ -1,0 +1,617 @@
+// rama_api.hip -- the C ABI of include/rama_hip.h: context, memory, the 1:1 Device<T>
+// ops, the fused decode path, measurement.  Kernels are in kernels.hpp.
+#include "../../include/rama_hip.h"
+#include "kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace rama;
+
+// ---------------------------------------------------------------- error plumbing
+
+static thread_local std::string g_err;
+
+const char* rama_last_error(void) { return g_err.c_str(); }
+
+static int fail(int code, const char* what, const char* file, int line) {
+    char buf[512];
+    if (code > 0)
+        snprintf(buf, sizeof buf, "%s: %s (hipError %d) at %s:%d", what, hipGetErrorString((hipError_t)code), code, file, line);
+    else
+        snprintf(buf, sizeof buf, "%s (rama error %d) at %s:%d", what, code, file, line);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail((int)e_, #expr, __FILE__, __LINE__); } while (0)
+#define REQUIRE(cond, code, msg) do { if (!(cond)) return fail((code), msg, __FILE__, __LINE__); } while (0)
+#define LAUNCHCHK() HIPCHK(hipGetLastError())
+
+// ---------------------------------------------------------------- context
+
+struct KProf {
+    int kernel_id = -1;
+    int max_records = 0;
+    int used = 0;
+    std::vector<hipEvent_t> ev;   // 2 per record
+};
+
+struct GraphCache {
+    hipGraphExec_t exec = nullptr;
+    hipGraph_t graph = nullptr;
+    // identity of what was captured
+    rama_config cfg{};
+    rama_weights w{};
+    rama_run_state s{};
+    bool valid = false;
+};
+
+struct rama_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    Ctl* ctl = nullptr;          // device cursor
+    int* forced = nullptr;       // device forced-token list
+    int forced_cap = 0;
+    int* out = nullptr;          // device produced-token list
+    int out_cap = 0;
+    int* argmax_result = nullptr;   // device int for rama_sample_argmax
+    int* pinned_int = nullptr;      // host pinned
+    bool graph_mode = false;
+    GraphCache gc;
+    KProf kp;
+    int cu_count = 0;
+};
+
+static int set_device(rama_ctx* c) { HIPCHK(hipSetDevice(c->device)); return 0; }
+
+int rama_ctx_create(int device, void* hip_stream, rama_ctx** out) {
+    REQUIRE(out, RAMA_EINVAL, "rama_ctx_create: out is NULL");
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    REQUIRE(device >= 0 && device < n, RAMA_EINVAL, "rama_ctx_create: no such device");
+    HIPCHK(hipSetDevice(device));
+    rama_ctx* c = new rama_ctx();
+    c->device = device;
+    if (hip_stream) {
+        c->stream = (hipStream_t)hip_stream;
+    } else {
+        HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    HIPCHK(hipEventCreate(&c->t0));
+    HIPCHK(hipEventCreate(&c->t1));
+    HIPCHK(hipMalloc(&c->ctl, sizeof(Ctl)));
+    HIPCHK(hipMemset(c->ctl, 0, sizeof(Ctl)));
+    c->out_cap = 1 << 16;
+    HIPCHK(hipMalloc(&c->out, sizeof(int) * c->out_cap));
+    c->forced_cap = 1 << 16;
+    HIPCHK(hipMalloc(&c->forced, sizeof(int) * c->forced_cap));
+    HIPCHK(hipMalloc(&c->argmax_result, sizeof(int)));
+    HIPCHK(hipHostMalloc(&c->pinned_int, sizeof(int) * 4));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    c->cu_count = prop.multiProcessorCount;
+    *out = c;
+    return 0;
+}
+
+static void drop_graph(rama_ctx* c) {
+    if (c->gc.exec) hipGraphExecDestroy(c->gc.exec);
+    if (c->gc.graph) hipGraphDestroy(c->gc.graph);
+    c->gc = GraphCache();
+}
+
+int rama_ctx_destroy(rama_ctx* c) {
+    if (!c) return 0;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    drop_graph(c);
+    for (auto e : c->kp.ev) hipEventDestroy(e);
+    hipFree(c->ctl); hipFree(c->out); hipFree(c->forced); hipFree(c->argmax_result);
+    hipHostFree(c->pinned_int);
+    hipEventDestroy(c->t0); hipEventDestroy(c->t1);
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+int rama_sync(rama_ctx* c) {
+    REQUIRE(c, RAMA_EINVAL, "rama_sync: ctx is NULL");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int rama_device_info(rama_ctx* c, char name[64], int* cus, size_t* hbm) {
+    REQUIRE(c, RAMA_EINVAL, "ctx is NULL");
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, c->device));
+    if (name) { strncpy(name, prop.name, 63); name[63] = 0; }
+    if (cus) *cus = prop.multiProcessorCount;
+    if (hbm) *hbm = prop.totalGlobalMem;
+    return 0;
+}
+
+// ---------------------------------------------------------------- memory
+
+int rama_alloc_f32(rama_ctx* c, size_t n, float** out) {
+    REQUIRE(c && out, RAMA_EINVAL, "rama_alloc_f32: NULL argument");
+    if (set_device(c)) return 1;
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(float)));
+    HIPCHK(hipMemsetAsync(p, 0, std::max<size_t>(n, 1) * sizeof(float), c->stream));
+    *out = (float*)p;
+    return 0;
+}
+
+int rama_copy_h2d_f32(rama_ctx* c, float* dst, const float* host, size_t n) {
+    REQUIRE(c && (n == 0 || (dst && host)), RAMA_EINVAL, "rama_copy_h2d_f32: NULL argument");
+    if (n == 0) return 0;
+    HIPCHK(hipMemcpyAsync(dst, host, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));   // htod_sync_copy semantics (hbm.rs:14-16)
+    return 0;
+}
+
+int rama_upload_f32(rama_ctx* c, const float* host, size_t n, float** out) {
+    int rc = rama_alloc_f32(c, n, out);
+    if (rc) return rc;
+    return rama_copy_h2d_f32(c, *out, host, n);
+}
+
+int rama_download_f32(rama_ctx* c, const float* src, size_t n, float* host) {
+    REQUIRE(c && (n == 0 || (src && host)), RAMA_EINVAL, "rama_download_f32: NULL argument");
+    if (n == 0) return 0;
+    HIPCHK(hipMemcpyAsync(host, src, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int rama_free(rama_ctx* c, void* p) {
+    REQUIRE(c, RAMA_EINVAL, "ctx is NULL");
+    if (!p) return 0;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipFree(p));
+    return 0;
+}
+
+// ---------------------------------------------------------------- launch helpers
+
+static inline int ew_grid(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 2048); }
+static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+constexpr int kR = 4;      // rows per workgroup of the matvec kernels
+constexpr int kCH = 4;     // 256-float chunks in flight per wave per step
+constexpr int kR2 = 2;     // (w1,w3) row pairs per workgroup of the SwiGLU kernel
+
+struct KTimer {   // brackets a launch with events when that kernel class is being profiled
+    rama_ctx* c; bool on;
+    KTimer(rama_ctx* c_, int kid) : c(c_), on(false) {
+        KProf& k = c->kp;
+        if (k.kernel_id == kid && k.used < k.max_records) {
+            on = true;
+            hipEventRecord(k.ev[2 * k.used], c->stream);
+        }
+    }
+    ~KTimer() {
+        if (on) { KProf& k = c->kp; hipEventRecord(k.ev[2 * k.used + 1], c->stream); k.used++; }
+    }
+};
+
+static int check_matvec_shape(size_t width, size_t rows) {
+    REQUIRE(width % 4 == 0, RAMA_EINVAL, "matmul: width % 4 != 0 (the reference CPU body panics here, cpu.rs:142-143)");
+    REQUIRE(width > 0 && rows > 0, RAMA_EINVAL, "matmul: empty shape");
+    REQUIRE((double)width * (double)rows * 4.0 < 2147483648.0, RAMA_EINVAL, "matmul: matrix >= 2 GiB, split it by layer");
+    return 0;
+}
+
+// plain W.x (EPI_STORE) or x += W.y (EPI_RESID)
+template <bool NORM, int EPI>
+static int launch_rows(rama_ctx* c, float* o, const float* W, const float* x, const float* nw, int K, int rows) {
+    int rc = check_matvec_shape(K, rows);
+    if (rc) return rc;
+    GemvParams p{};
+    p.w[0] = W; p.x = x; p.nw = nw; p.o[0] = o; p.K = K; p.rows = rows; p.nmat = 1;
+    int grid = (rows + kR - 1) / kR;
+    hipLaunchKernelGGL((gemv_rows<kR, kCH, NORM, EPI>), dim3(grid), dim3(kWG), 0, c->stream, p);
+    LAUNCHCHK();
+    return 0;
+}
+
+// ---------------------------------------------------------------- Device<T> ops, 1:1
+
+int rama_array_add(rama_ctx* c, float* t, const float* s, size_t n) {
+    REQUIRE(c && (n == 0 || (t && s)), RAMA_EINVAL, "array_add: NULL argument");
+    if (!n) return 0;
+    hipLaunchKernelGGL(array_add_kernel, dim3(ew_grid(n)), dim3(256), 0, c->stream, t, s, n);
+    LAUNCHCHK(); return 0;
+}
+int rama_array_mult(rama_ctx* c, float* t, const float* s, size_t n) {
+    REQUIRE(c && (n == 0 || (t && s)), RAMA_EINVAL, "array_mult: NULL argument");
+    if (!n) return 0;
+    hipLaunchKernelGGL(array_mult_kernel, dim3(ew_grid(n)), dim3(256), 0, c->stream, t, s, n);
+    LAUNCHCHK(); return 0;
+}
+int rama_sinu(rama_ctx* c, float* o, size_t n) {
+    REQUIRE(c && (n == 0 || o), RAMA_EINVAL, "sinu: NULL argument");
+    if (!n) return 0;
+    hipLaunchKernelGGL(sinu_kernel, dim3(ew_grid(n)), dim3(256), 0, c->stream, o, n);
+    LAUNCHCHK(); return 0;
+}
+int rama_copy_from_slice(rama_ctx* c, float* t, const float* s, size_t n) {
+    REQUIRE(c && (n == 0 || (t && s)), RAMA_EINVAL, "copy_from_slice: NULL argument");
+    if (!n) return 0;
+    hipLaunchKernelGGL(copy_kernel, dim3(ew_grid(n)), dim3(256), 0, c->stream, t, s, n);
+    LAUNCHCHK(); return 0;
+}
+int rama_rmsnorm(rama_ctx* c, float* o, const float* x, const float* w, size_t n) {
+    REQUIRE(c && o && x && w && n > 0, RAMA_EINVAL, "rmsnorm: bad argument");
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3(1), dim3(1024), 0, c->stream, o, x, w, (int)n);
+    LAUNCHCHK(); return 0;
+}
+int rama_apply_position(rama_ctx* c, float* q, float* k, const float* pr, const float* pi, size_t head_size) {
+    REQUIRE(c && q && k && pr && pi && head_size >= 2, RAMA_EINVAL, "apply_position: bad argument");
+    int n = (int)(head_size / 2);
+    hipLaunchKernelGGL(apply_position_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, q, k, pr, pi, (int)head_size);
+    LAUNCHCHK(); return 0;
+}
+int rama_matmul(rama_ctx* c, float* o, const float* a, const float* b, size_t width, size_t o_rows, size_t o_cols) {
+    REQUIRE(c && o && a && b, RAMA_EINVAL, "matmul: NULL argument");
+    REQUIRE(o_cols >= 1, RAMA_EINVAL, "matmul: o_cols == 0");
+    int rc = check_matvec_shape(width, o_rows);
+    if (rc) return rc;
+    if (o_cols != 1) {   // forward() never takes this path (o_cols is always 1, infer.rs:20-51)
+        size_t n = o_rows * o_cols;
+        hipLaunchKernelGGL(matmul_generic, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, o, a, b, (int)width, (int)o_rows, (int)o_cols);
+        LAUNCHCHK(); return 0;
+    }
+    if (!aligned16(a) || !aligned16(b)) {   // a view that does not start on a 16-byte boundary
+        hipLaunchKernelGGL(matvec_unaligned, dim3((unsigned)((o_rows + 3) / 4)), dim3(kWG), 0, c->stream, o, a, b, (int)width, (int)o_rows);
+        LAUNCHCHK(); return 0;
+    }
+    return launch_rows<false, EPI_STORE>(c, o, a, b, nullptr, (int)width, (int)o_rows);
+}
+int rama_softmax(rama_ctx* c, float* x, size_t n) {
+    REQUIRE(c && x && n > 0, RAMA_EINVAL, "softmax: bad argument");
+    hipLaunchKernelGGL(softmax_kernel, dim3(1), dim3(1024), 0, c->stream, x, (int)n);
+    LAUNCHCHK(); return 0;
+}
+
+static int launch_attention(rama_ctx* c, float* xb, float* att, const float* q, const float* kc_layer,
+                            const float* vc_layer, const Ctl* ctl, int pos, int dim, int head_size,
+                            int seq_len, int n_heads) {
+    REQUIRE(head_size % 4 == 0 && head_size >= 4 && head_size <= 256, RAMA_EUNSUP, "attention: head_size must be a multiple of 4 in [4, 256]");
+    REQUIRE(aligned16(q) && aligned16(kc_layer) && aligned16(vc_layer) && aligned16(xb) && dim % 4 == 0, RAMA_EINVAL, "attention: buffers must be 16-byte aligned");
+    AttnParams p{};
+    p.q = q; p.kc = kc_layer; p.vc = vc_layer; p.att = att; p.xb = xb; p.ctl = ctl; p.pos_val = pos;
+    p.dim = dim; p.head_size = head_size; p.seq_len = seq_len;
+    const int G = head_size <= 64 ? 16 : (head_size <= 128 ? 32 : 64);
+    size_t shm = (size_t)(16 + 16 * G + seq_len) * sizeof(float);
+    REQUIRE(shm <= 160 * 1024, RAMA_EUNSUP, "attention: seq_len too long for the single-workgroup kernel");
+    if (G == 16) hipLaunchKernelGGL((attention_kernel<16>), dim3(n_heads), dim3(kWG), shm, c->stream, p);
+    else if (G == 32) hipLaunchKernelGGL((attention_kernel<32>), dim3(n_heads), dim3(kWG), shm, c->stream, p);
+    else hipLaunchKernelGGL((attention_kernel<64>), dim3(n_heads), dim3(kWG), shm, c->stream, p);
+    LAUNCHCHK();
+    return 0;
+}
+
+int rama_multi_head_attention(rama_ctx* c, float* xb, float* att, const float* q, const float* key_cache,
+                              const float* value_cache, int layer, int dim, int pos, int head_size,
+                              int seq_len, int n_heads) {
+    REQUIRE(c && xb && att && q && key_cache && value_cache, RAMA_EINVAL, "multi_head_attention: NULL argument");
+    REQUIRE(pos >= 0 && pos < seq_len && layer >= 0 && n_heads > 0 && n_heads * head_size == dim, RAMA_EINVAL, "multi_head_attention: bad shape");
+    const size_t lo = (size_t)layer * seq_len * dim;   // cpu.rs:28
+    return launch_attention(c, xb, att, q, key_cache + lo, value_cache + lo, nullptr, pos, dim, head_size, seq_len, n_heads);
+}
+
+int rama_sample_argmax(rama_ctx* c, const float* logits, size_t n, int32_t* next_host) {
+    REQUIRE(c && logits && next_host && n > 0, RAMA_EINVAL, "sample_argmax: bad argument");
+    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, c->stream, logits, (int)n, c->argmax_result,
+                       (Ctl*)nullptr, (const int*)nullptr, (int*)nullptr, 0);
+    LAUNCHCHK();
+    HIPCHK(hipMemcpyAsync(c->pinned_int, c->argmax_result, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *next_host = c->pinned_int[0];
+    return 0;
+}
+
+int rama_sample_topp(rama_ctx* c, const float* logits, size_t n, float temperature, float topp, float u, int32_t* next_host) {
+    REQUIRE(c && logits && next_host && n > 1, RAMA_EINVAL, "sample_topp: bad argument");
+    if (temperature == 0.0f) return rama_sample_argmax(c, logits, n, next_host);
+    std::vector<float> p(n);
+    int rc = rama_download_f32(c, logits, n, p.data());   // as gpu.rs:153 does
+    if (rc) return rc;
+    if (temperature < 1.0f) for (auto& z : p) z /= temperature;           // cpu.rs:170-172
+    float mx = p[0];
+    for (size_t i = 1; i < n; i++) mx = p[i] > mx ? p[i] : mx;            // cpu.rs:187-192
+    float sum = 0.0f;
+    for (auto& z : p) { z = expf(z - mx); }
+    for (auto z : p) sum += z;
+    for (auto& z : p) z /= sum;
+    const float cutoff = (1.0f - topp) / (float)(n - 1);                   // infer.rs:56
+    std::vector<std::pair<float, int>> pi;
+    for (size_t i = 0; i < n; i++) if (p[i] > cutoff) pi.emplace_back(p[i], (int)i);
+    REQUIRE(!pi.empty(), RAMA_EINVAL, "sample_topp: no candidate above the cutoff (the reference underflows here)");
+    std::stable_sort(pi.begin(), pi.end(), [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.first > b.first; });
+    float cum = 0.0f; size_t last = pi.size() - 1;
+    for (size_t i = 0; i < pi.size(); i++) { cum += pi[i].first; if (cum > topp) { last = i; break; } }
+    const float r = u * cum;
+    float cdf = 0.0f; int pick = pi[last].second;
+    for (size_t i = 0; i < last; i++) { cdf += pi[i].first; if (r < cdf) { pick = pi[i].second; break; } }
+    *next_host = pick;
+    return 0;
+}
+
+// ---------------------------------------------------------------- synthetic fill
+
+int rama_fill_synth(rama_ctx* c, float* dst, size_t n, uint64_t seed, uint64_t tag, uint64_t offset, float scale, float bias) {
+    REQUIRE(c && (n == 0 || dst), RAMA_EINVAL, "fill_synth: NULL argument");
+    if (!n) return 0;
+    const uint64_t base = offset + tag * 0x9E3779B97F4A7C15ULL + seed * 0xD1B54A32D192ED03ULL;
+    int grid = (int)std::min<size_t>((n + 255) / 256, 1 << 16);
+    hipLaunchKernelGGL(fill_synth_kernel, dim3(grid), dim3(256), 0, c->stream, dst, n, base, scale, bias);
+    LAUNCHCHK();
+    return 0;
+}
+
+// ---------------------------------------------------------------- fused decode path
+
+static int check_cfg(const rama_config* cfg) {
+    REQUIRE(cfg, RAMA_EINVAL, "config is NULL");
+    REQUIRE(cfg->dim > 0 && cfg->hidden_dim > 0 && cfg->n_layers > 0 && cfg->n_heads > 0 && cfg->vocab_size > 0 && cfg->seq_len > 0, RAMA_EINVAL, "config: non-positive field");
+    REQUIRE(cfg->n_kv_heads == cfg->n_heads, RAMA_EUNSUP, "config: n_kv_heads != n_heads (the reference indexes the cache with stride dim, infer.rs:31-33)");
+    REQUIRE(cfg->dim % cfg->n_heads == 0, RAMA_EINVAL, "config: dim % n_heads != 0");
+    REQUIRE(cfg->dim % 4 == 0 && cfg->hidden_dim % 4 == 0, RAMA_EINVAL, "config: dim and hidden_dim must be multiples of 4 (cpu.rs:142-143)");
+    const int hs = cfg->dim / cfg->n_heads;
+    REQUIRE(hs % 4 == 0 && hs <= 256, RAMA_EUNSUP, "config: head_size must be a multiple of 4, <= 256");
+    return 0;
+}
+
+// one (token, pos) step over a layer range; ctl on the device holds token/pos
+static int enqueue_stage(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s,
+                         const rama_stage* st) {
+    const int dim = cfg->dim, hidden = cfg->hidden_dim, hs = dim / cfg->n_heads;
+    const size_t dd = (size_t)dim * dim, hd = (size_t)hidden * dim;
+    if (st->do_embed) {
+        hipLaunchKernelGGL(embed_kernel, dim3((dim + 255) / 256), dim3(256), 0, c->stream, s->x, w->token_embedding_table, (const Ctl*)c->ctl, 0, dim);
+        LAUNCHCHK();
+    }
+    for (int layer = st->layer_begin; layer < st->layer_end; layer++) {
+        const size_t li = (size_t)(layer - st->layer_begin);
+        float* kc = s->key_cache + li * cfg->seq_len * dim;
+        float* vc = s->value_cache + li * cfg->seq_len * dim;
+        {   // infer.rs:19-33: rmsnorm, Wq|Wk|Wv, RoPE, cache append
+            KTimer kt(c, RAMA_K_QKV);
+            GemvParams p{};
+            p.w[0] = w->wq + li * dd; p.w[1] = w->wk + li * dd; p.w[2] = w->wv + li * dd;
+            p.x = s->x; p.nw = w->rms_att_weight + li * dim;
+            p.o[0] = s->q; p.o[1] = s->k; p.o[2] = s->v;
+            p.K = dim; p.rows = dim; p.nmat = 3;
+            p.ctl = c->ctl; p.fr = w->freq_cis_real; p.fi = w->freq_cis_imag; p.head_size = hs;
+            p.kc = kc; p.vc = vc;
+            hipLaunchKernelGGL((gemv_rows<kR, kCH, true, EPI_QKV>), dim3(3 * (dim / kR)), dim3(kWG), 0, c->stream, p);
+            LAUNCHCHK();
+        }
+        {   // infer.rs:34
+            KTimer kt(c, RAMA_K_ATTN);
+            int rc = launch_attention(c, s->xb, s->att, s->q, kc, vc, c->ctl, 0, dim, hs, cfg->seq_len, cfg->n_heads);
+            if (rc) return rc;
+        }
+        {   // infer.rs:35-37: x += Wo . xb
+            KTimer kt(c, RAMA_K_WO);
+            int rc = launch_rows<false, EPI_RESID>(c, s->x, w->wo + li * dd, s->xb, nullptr, dim, dim);
+            if (rc) return rc;
+        }
+        {   // infer.rs:39-45: rmsnorm, W1|W3, SiLU * gate
+            KTimer kt(c, RAMA_K_W13);
+            SwigluParams p{};
+            p.w1 = w->w1 + li * hd; p.w3 = w->w3 + li * hd; p.x = s->x; p.nw = w->rms_ffn_weight + li * dim;
+            p.hb = s->hb; p.K = dim; p.rows = hidden;
+            hipLaunchKernelGGL((gemv_swiglu<kR2, kCH>), dim3((hidden + kR2 - 1) / kR2), dim3(kWG), 0, c->stream, p);
+            LAUNCHCHK();
+        }
+        {   // infer.rs:46-47: x += W2 . hb
+            KTimer kt(c, RAMA_K_W2);
+            int rc = launch_rows<false, EPI_RESID>(c, s->x, w->w2 + li * hd, s->hb, nullptr, hidden, dim);
+            if (rc) return rc;
+        }
+    }
+    if (st->do_cls) {   // infer.rs:49-51
+        KTimer kt(c, RAMA_K_CLS);
+        int rc = launch_rows<true, EPI_STORE>(c, s->logits, w->wcls, s->x, w->rms_final_weight, dim, cfg->vocab_size);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+static int check_stage(const rama_config* cfg, const rama_weights* w, const rama_run_state* s, const rama_stage* st) {
+    REQUIRE(w && s && st, RAMA_EINVAL, "forward: NULL argument");
+    REQUIRE(st->layer_begin >= 0 && st->layer_begin <= st->layer_end && st->layer_end <= cfg->n_layers, RAMA_EINVAL, "forward: bad layer range");
+    REQUIRE(cfg->dim % kR == 0, RAMA_EINVAL, "forward: dim % 4 != 0");
+    if (st->layer_end > st->layer_begin)
+        REQUIRE(w->wq && w->wk && w->wv && w->wo && w->w1 && w->w2 && w->w3 && w->rms_att_weight && w->rms_ffn_weight && w->freq_cis_real && w->freq_cis_imag, RAMA_EINVAL, "forward: missing layer weights");
+    if (st->do_embed) REQUIRE(w->token_embedding_table, RAMA_EINVAL, "forward: missing embedding table");
+    if (st->do_cls) REQUIRE(w->wcls && w->rms_final_weight && s->logits, RAMA_EINVAL, "forward: missing classifier weights");
+    REQUIRE(s->x && s->xb && s->hb && s->q && s->k && s->v && s->att && s->key_cache && s->value_cache, RAMA_EINVAL, "forward: missing state buffer");
+    return 0;
+}
+
+int rama_forward_stage(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s,
+                       int token, int pos, const rama_stage* st) {
+    REQUIRE(c, RAMA_EINVAL, "ctx is NULL");
+    int rc = check_cfg(cfg); if (rc) return rc;
+    rc = check_stage(cfg, w, s, st); if (rc) return rc;
+    REQUIRE(pos >= 0 && pos < cfg->seq_len, RAMA_EINVAL, "forward: pos outside [0, seq_len)");
+    REQUIRE(token >= 0 && token < cfg->vocab_size, RAMA_EINVAL, "forward: token outside the vocabulary");
+    hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(1), 0, c->stream, c->ctl, token, pos, 0, 0);
+    LAUNCHCHK();
+    return enqueue_stage(c, cfg, w, s, st);
+}
+
+int rama_forward(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s, int token, int pos) {
+    REQUIRE(cfg, RAMA_EINVAL, "config is NULL");
+    rama_stage st{0, cfg->n_layers, 1, 1};
+    return rama_forward_stage(c, cfg, w, s, token, pos, &st);
+}
+
+// ---- device-chained greedy decode (generate() at T == 0, mod.rs:169-206)
+
+int rama_decode_begin(rama_ctx* c, int token, int pos, const int32_t* forced_host, int n_forced) {
+    REQUIRE(c, RAMA_EINVAL, "ctx is NULL");
+    REQUIRE(n_forced >= 0 && n_forced <= c->forced_cap, RAMA_EINVAL, "decode_begin: too many forced tokens");
+    REQUIRE(n_forced == 0 || forced_host, RAMA_EINVAL, "decode_begin: forced list is NULL");
+    if (n_forced) {
+        HIPCHK(hipMemcpyAsync(c->forced, forced_host, sizeof(int) * n_forced, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(1), 0, c->stream, c->ctl, token, pos, n_forced, 0);
+    LAUNCHCHK();
+    return 0;
+}
+
+static int enqueue_decode_step(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s) {
+    rama_stage st{0, cfg->n_layers, 1, 1};
+    int rc = enqueue_stage(c, cfg, w, s, &st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, c->stream, (const float*)s->logits, cfg->vocab_size,
+                       (int*)nullptr, c->ctl, (const int*)c->forced, c->out, c->out_cap);
+    LAUNCHCHK();
+    return 0;
+}
+
+static bool same_capture(const GraphCache& g, const rama_config* cfg, const rama_weights* w, const rama_run_state* s) {
+    return g.valid && !memcmp(&g.cfg, cfg, sizeof *cfg) && !memcmp(&g.w, w, sizeof *w) && !memcmp(&g.s, s, sizeof *s);
+}
+
+int rama_decode_steps(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s, int n_steps) {
+    REQUIRE(c, RAMA_EINVAL, "ctx is NULL");
+    int rc = check_cfg(cfg); if (rc) return rc;
+    rama_stage st{0, cfg->n_layers, 1, 1};
+    rc = check_stage(cfg, w, s, &st); if (rc) return rc;
+    REQUIRE(n_steps >= 0, RAMA_EINVAL, "decode_steps: n_steps < 0");
+    if (c->graph_mode && c->kp.kernel_id < 0) {
+        if (!same_capture(c->gc, cfg, w, s)) {
+            drop_graph(c);
+            HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            rc = enqueue_decode_step(c, cfg, w, s);
+            hipError_t e = hipStreamEndCapture(c->stream, &c->gc.graph);
+            if (rc) return rc;
+            HIPCHK(e);
+            HIPCHK(hipGraphInstantiate(&c->gc.exec, c->gc.graph, nullptr, nullptr, 0));
+            c->gc.cfg = *cfg; c->gc.w = *w; c->gc.s = *s; c->gc.valid = true;
+        }
+        for (int i = 0; i < n_steps; i++) HIPCHK(hipGraphLaunch(c->gc.exec, c->stream));
+        return 0;
+    }
+    for (int i = 0; i < n_steps; i++) {
+        rc = enqueue_decode_step(c, cfg, w, s);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int rama_decode_tokens(rama_ctx* c, int32_t* out_host, int max_tokens, int* n_out) {
+    REQUIRE(c && n_out, RAMA_EINVAL, "decode_tokens: NULL argument");
+    Ctl h;
+    HIPCHK(hipMemcpyAsync(&h, c->ctl, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int n = std::min(std::min(h.n_out, c->out_cap), max_tokens);
+    if (n > 0 && out_host) {
+        HIPCHK(hipMemcpyAsync(out_host, c->out, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    *n_out = n;
+    return 0;
+}
+
+int rama_generate_greedy(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s,
+                         const int32_t* prompt_host, int n_prompt, int steps, int32_t* out_host) {
+    REQUIRE(c && cfg && out_host, RAMA_EINVAL, "generate_greedy: NULL argument");
+    REQUIRE(steps >= 0 && steps <= cfg->seq_len, RAMA_EINVAL, "generate_greedy: steps > seq_len (the reference does not bound-check, SURVEY section 5)");
+    REQUIRE(steps <= c->out_cap, RAMA_EINVAL, "generate_greedy: too many steps");
+    int rc = rama_decode_begin(c, /*BOS*/ 1, 0, prompt_host, std::min(n_prompt, c->forced_cap));
+    if (rc) return rc;
+    rc = rama_decode_steps(c, cfg, w, s, steps);
+    if (rc) return rc;
+    int n = 0;
+    return rama_decode_tokens(c, out_host, steps, &n);
+}
+
+int rama_set_graph_mode(rama_ctx* c, int enabled) {
+    REQUIRE(c, RAMA_EINVAL, "ctx is NULL");
+    c->graph_mode = enabled != 0;
+    if (!enabled) { hipStreamSynchronize(c->stream); drop_graph(c); }
+    return 0;
+}
+
+// ---------------------------------------------------------------- measurement
+
+int rama_timer_start(rama_ctx* c) {
+    REQUIRE(c, RAMA_EINVAL, "ctx is NULL");
+    HIPCHK(hipEventRecord(c->t0, c->stream));
+    return 0;
+}
+int rama_timer_stop(rama_ctx* c, float* ms) {
+    REQUIRE(c && ms, RAMA_EINVAL, "timer_stop: NULL argument");
+    HIPCHK(hipEventRecord(c->t1, c->stream));
+    HIPCHK(hipEventSynchronize(c->t1));
+    HIPCHK(hipEventElapsedTime(ms, c->t0, c->t1));
+    return 0;
+}
+
+int rama_kprof_enable(rama_ctx* c, int kernel_id, int max_records) {
+    REQUIRE(c && kernel_id >= 0 && kernel_id < RAMA_K_COUNT && max_records > 0, RAMA_EINVAL, "kprof_enable: bad argument");
+    KProf& k = c->kp;
+    while ((int)k.ev.size() < 2 * max_records) {
+        hipEvent_t e; HIPCHK(hipEventCreate(&e)); k.ev.push_back(e);
+    }
+    k.kernel_id = kernel_id; k.max_records = max_records; k.used = 0;
+    return 0;
+}
+int rama_kprof_read(rama_ctx* c, int* n_launches, double* total_ms) {
+    REQUIRE(c && n_launches && total_ms, RAMA_EINVAL, "kprof_read: NULL argument");
+    KProf& k = c->kp;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    double tot = 0.0;
+    for (int i = 0; i < k.used; i++) {
+        float ms = 0.0f;
+        HIPCHK(hipEventElapsedTime(&ms, k.ev[2 * i], k.ev[2 * i + 1]));
+        tot += ms;
+    }
+    *n_launches = k.used; *total_ms = tot;
+    k.kernel_id = -1; k.used = 0;
+    return 0;
+}
+
+// ---------------------------------------------------------------- state
+
+int rama_state_create(rama_ctx* c, const rama_config* cfg, int n_local_layers, rama_run_state* out) {
+    REQUIRE(c && out, RAMA_EINVAL, "state_create: NULL argument");
+    int rc = check_cfg(cfg); if (rc) return rc;
+    REQUIRE(n_local_layers >= 0 && n_local_layers <= cfg->n_layers, RAMA_EINVAL, "state_create: bad layer count");
+    // one blob, every buffer 256-byte aligned; sizes as ram.rs:7-23 (kv_dim == dim here)
+    auto al = [](size_t n) { return (n + 63) & ~(size_t)63; };
+    const size_t d = cfg->dim, h = cfg->hidden_dim;
+    const size_t kv = (size_t)std::max(n_local_layers, 1) * cfg->seq_len * d;
+    size_t sizes[12] = {d, d, d, h, h, d, d, d, (size_t)cfg->n_heads * cfg->seq_len, (size_t)cfg->vocab_size, kv, kv};
+    size_t total = 0;
+    for (size_t z : sizes) total += al(z);
+    float* blob = nullptr;
+    rc = rama_alloc_f32(c, total, &blob);
+    if (rc) return rc;
+    float** fields[12] = {&out->x, &out->xb, &out->xb2, &out->hb, &out->hb2, &out->q, &out->k, &out->v, &out->att, &out->logits, &out->key_cache, &out->value_cache};
+    size_t off = 0;
+    for (int i = 0; i < 12; i++) { *fields[i] = blob + off; off += al(sizes[i]); }
+    return 0;
+}
+
+int rama_state_free(rama_ctx* c, rama_run_state* s) {
+    REQUIRE(c && s, RAMA_EINVAL, "state_free: NULL argument");
+    int rc = rama_free(c, s->x);   // x is the blob base
+    memset(s, 0, sizeof *s);
+    return rc;
+}

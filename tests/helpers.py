@@ -35,3 +35,35 @@ def load_case(name):
         cfg = cfg_from_array(g["cfg"])
         w = S.synth_weights(cfg, int(g["seed"]), rope=(g["freq_cis_real"], g["freq_cis_imag"]))
     return cfg, w, g
+
+
+# ------------------------------------------------------------------ GPU-side helpers
+
+def to_rama_cfg(cfg: O.Config):
+    import rama_amd
+    return rama_amd.Config(cfg.dim, cfg.hidden_dim, cfg.n_layers, cfg.n_heads, cfg.n_kv_heads,
+                           cfg.vocab_size, cfg.seq_len, cfg.shared_weight)
+
+
+def gpu_views(dev, cfg: O.Config, w: dict):
+    """Upload numpy weights tensor by tensor (hbm.rs:55-90) and allocate a zeroed RunState."""
+    import rama_amd
+    rcfg = to_rama_cfg(cfg)
+    ws = rama_amd.TransformerWeights.from_numpy(rcfg, w, dev)
+    rs = rama_amd.RunState.from_config(rcfg, dev)
+    return rcfg, ws, rama_amd.TransformerWeightsView.from_gpu_ws(ws), rs, rama_amd.RunStateView.from_rs(rs)
+
+
+def synth_at(indices, seed, tag, scale, bias=0.0):
+    """oracle synthetic generator evaluated at arbitrary flat indices (numpy restatement)."""
+    idx = np.asarray(indices, dtype=np.uint64)
+    M = (1 << 64) - 1
+    base = np.uint64((tag * 0x9E3779B97F4A7C15 + seed * 0xD1B54A32D192ED03) & M)
+    with np.errstate(over="ignore"):
+        z = idx + base
+        z ^= z >> np.uint64(30); z *= np.uint64(0xBF58476D1CE4E5B9)
+        z ^= z >> np.uint64(27); z *= np.uint64(0x94D049BB133111EB)
+        z ^= z >> np.uint64(31)
+    m = np.uint64(0xFFFF)
+    s = ((z & m) + ((z >> np.uint64(16)) & m) + ((z >> np.uint64(32)) & m) + (z >> np.uint64(48))).astype(np.int64)
+    return (np.float32(bias) + (s - 131070).astype(np.float32) * np.float32(scale)).astype(np.float32)

@@ -1,0 +1,258 @@
+"""-m gpu: every Device<T> op (device.rs:3-24) through the C ABI against the CPU oracle on
+the same seeded inputs.  Elementwise / copy ops must be bit-exact; reductions are held to
+a few fp32 ulps of the magnitude involved (tolerances written at each check)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from oracle import synth as S
+from tests.helpers import synth_at
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import rama_amd
+    d = rama_amd.Hip(0)
+    yield d
+    d.close()
+
+
+def up(dev, a):
+    import rama_amd
+    return rama_amd.MutView(dev.allocate(a))
+
+
+def rnd(n, seed, scale=1.0):
+    return (np.random.default_rng(seed).standard_normal(n) * scale).astype(np.float32)
+
+
+# ------------------------------------------------------------------ elementwise (bit-exact)
+
+@pytest.mark.parametrize("n", [1, 4, 288, 1000, 11008, 70001])
+def test_array_add_mult_copy_exact(dev, n):
+    a, b = rnd(n, 1), rnd(n, 2)
+    ta = up(dev, a); tb = up(dev, b)
+    dev.array_add(ta, tb.as_view(), n)
+    ea = a.copy(); O.array_add(ea, b, n)
+    assert np.array_equal(dev.download(ta), ea)
+    dev.array_mult(ta, tb.as_view(), n)
+    O.array_mult(ea, b, n)
+    assert np.array_equal(dev.download(ta), ea)
+    tc = up(dev, np.zeros(n, np.float32))
+    dev.copy_from_slice(tc, ta.as_view(), n)
+    assert np.array_equal(dev.download(tc), ea)
+
+
+def test_elementwise_n_zero_is_noop(dev):
+    a = rnd(8, 3)
+    ta = up(dev, a)
+    dev.array_add(ta, ta.as_view(), 0)
+    dev.sinu(ta, 0)
+    assert np.array_equal(dev.download(ta), a)
+
+
+@pytest.mark.parametrize("n", [5, 768, 11008])
+def test_sinu(dev, n):
+    a = rnd(n, 4, 3.0)
+    a[:3] = [0.0, -30.0, 30.0][:min(3, n)]
+    ta = up(dev, a)
+    dev.sinu(ta, n)
+    e = a.copy(); O.sinu(e, n)
+    # expf differs by <= 2 ulp between libm and the device; silu amplifies by |a| <= 30
+    np.testing.assert_allclose(dev.download(ta), e, rtol=3e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("hs", [2, 16, 48, 64, 128])
+def test_apply_position(dev, hs):
+    q, k = rnd(hs, 5), rnd(hs, 6)
+    ang = np.random.default_rng(7).uniform(0, 6.28, hs // 2)
+    pr, pi = np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32)
+    tq, tk, tpr, tpi = up(dev, q), up(dev, k), up(dev, pr), up(dev, pi)
+    dev.apply_position(tq, tk, tpr.as_view(), tpi.as_view(), hs)
+    eq, ek = q.copy(), k.copy()
+    O.apply_position(eq, ek, pr, pi, hs)
+    # a*c - b*s may contract to one FMA on the device: <= 1 ulp of the larger product
+    np.testing.assert_allclose(dev.download(tq), eq, rtol=0, atol=4e-7)
+    np.testing.assert_allclose(dev.download(tk), ek, rtol=0, atol=4e-7)
+
+
+@pytest.mark.parametrize("n", [4, 288, 768, 4096])
+def test_rmsnorm(dev, n):
+    x, w = rnd(n, 8), (1.0 + rnd(n, 9, 0.1)).astype(np.float32)
+    to = up(dev, np.zeros(n, np.float32))
+    dev.rmsnorm(to, up(dev, x).as_view(), up(dev, w).as_view(), n)
+    e = np.zeros(n, np.float32); O.rmsnorm(e, x, w, n)
+    np.testing.assert_allclose(dev.download(to), e, rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("n", [1, 7, 256, 32000])
+def test_softmax(dev, n):
+    x = rnd(n, 10, 4.0)
+    tx = up(dev, x)
+    dev.softmax(tx, n)
+    e = x.copy(); O.softmax(e, n)
+    got = dev.download(tx)
+    np.testing.assert_allclose(got, e, rtol=1e-5, atol=1e-9)
+    assert abs(float(got.astype(np.float64).sum()) - 1.0) < 1e-5
+
+
+# ------------------------------------------------------------------ matmul
+
+MATVEC_SHAPES = [   # (rows, width): reference shapes + ragged tails
+    (288, 288), (768, 288), (288, 768), (32000, 288),      # stories15M (width 288 = 256 + 32)
+    (768, 768), (2048, 768), (768, 2048),                  # stories110M
+    (4096, 4096), (11008, 4096), (4096, 11008),            # llama2-7B layer
+    (5, 4), (3, 260), (1, 1024), (7, 1028), (9, 12),       # row tails / tiny widths
+]
+
+
+@pytest.mark.parametrize("rows,width", MATVEC_SHAPES)
+def test_matmul_vs_oracle(dev, rows, width):
+    W = rnd(rows * width, rows + width, 0.05)
+    x = rnd(width, 11)
+    to = up(dev, np.full(rows, 7.0, np.float32))
+    dev.matmul(to, up(dev, W).as_view(), up(dev, x).as_view(), width, rows, 1)
+    e = np.zeros(rows, np.float32); O.matmul(e, W, x, width, rows, 1)
+    # both are fp32 sums of `width` products in different orders; bound: ~ sqrt(width) * eps * |W||x|
+    tol = 4e-7 * np.sqrt(width) * float(np.abs(W).max() * np.abs(x).max()) * 8 + 1e-7
+    got = dev.download(to)
+    assert np.abs(got - e).max() <= tol, (np.abs(got - e).max(), tol)
+    # and against exact arithmetic
+    ex = (W.reshape(rows, width).astype(np.float64) @ x.astype(np.float64))
+    assert np.abs(got - ex).max() <= tol
+
+
+def test_matmul_one_hot_is_exact_column(dev):
+    """W . e_j is column j bit for bit (every other product is an exact 0)."""
+    rows, width = 1000, 1028
+    W = rnd(rows * width, 12)
+    for j in (0, 255, 256, 1027):
+        x = np.zeros(width, np.float32); x[j] = 1.0
+        to = up(dev, np.zeros(rows, np.float32))
+        dev.matmul(to, up(dev, W).as_view(), up(dev, x).as_view(), width, rows, 1)
+        assert np.array_equal(dev.download(to), W.reshape(rows, width)[:, j])
+
+
+def test_matmul_known_answer_and_ocols(dev):
+    """gpu.rs:249-288 test_blas data (k zero-padded to 4): the o_cols = 2 product."""
+    l = np.array([3, 3, 3, 0, 3, 5, 3, 0, 3, 3, 3, 0, 3, 3, 3, 0], dtype=np.float32)
+    r = np.array([2, 2, 2, 2, 2, 2, 0, 0], dtype=np.float32)
+    to = up(dev, np.ones(8, np.float32))
+    dev.matmul(to, up(dev, l).as_view(), up(dev, r).as_view(), 4, 4, 2)
+    assert dev.download(to).tolist() == [18, 18, 22, 22, 18, 18, 18, 18]
+
+
+def test_matmul_width_not_multiple_of_4_is_an_error(dev):
+    import rama_amd
+    to = up(dev, np.zeros(4, np.float32))
+    with pytest.raises(rama_amd.RamaError):   # reference CPU body panics (cpu.rs:142-143)
+        dev.matmul(to, up(dev, rnd(12, 1)).as_view(), up(dev, rnd(3, 2)).as_view(), 3, 4, 1)
+
+
+def test_matmul_unaligned_view(dev):
+    """a View that starts 4 bytes into its storage (legal in the trait) takes the scalar path"""
+    import rama_amd
+    rows, width = 6, 16
+    W = rnd(rows * width + 1, 13); x = rnd(width + 1, 14)
+    sw, sx = dev.allocate(W), dev.allocate(x)
+    to = up(dev, np.zeros(rows, np.float32))
+    dev.matmul(to, rama_amd.View(sw).slice(1), rama_amd.View(sx).slice(1), width, rows, 1)
+    e = np.zeros(rows, np.float32); O.matmul(e, W[1:].copy(), x[1:].copy(), width, rows, 1)
+    np.testing.assert_allclose(dev.download(to), e, rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------ attention
+
+@pytest.mark.parametrize("n_heads,hs,seq_len,positions", [
+    (4, 16, 32, [0, 1, 5, 31]),
+    (6, 48, 256, [0, 3, 17, 255]),
+    (12, 64, 64, [0, 2, 63]),
+    (2, 128, 300, [0, 1, 64, 299]),
+    (1, 128, 16, [0, 15]),
+    (3, 4, 8, [0, 7]),
+])
+def test_multi_head_attention(dev, n_heads, hs, seq_len, positions):
+    import rama_amd
+    dim, L = n_heads * hs, 2
+    cfg = O.Config(dim, 4 * dim, L, n_heads, n_heads, 8, seq_len, True)
+    rcfg = rama_amd.Config(dim, 4 * dim, L, n_heads, n_heads, 8, seq_len, True)
+    orc = O.Oracle(cfg, dict(token_embedding_table=np.zeros((8, dim), np.float32), rms_att_weight=np.zeros((L, dim), np.float32),
+                             rms_ffn_weight=np.zeros((L, dim), np.float32), wq=np.zeros(1, np.float32), wk=np.zeros(1, np.float32),
+                             wv=np.zeros(1, np.float32), wo=np.zeros(1, np.float32), w1=np.zeros(1, np.float32), w2=np.zeros(1, np.float32),
+                             w3=np.zeros(1, np.float32), rms_final_weight=np.zeros(dim, np.float32),
+                             freq_cis_real=np.zeros(1, np.float32), freq_cis_imag=np.zeros(1, np.float32)))
+    kc = rnd(L * seq_len * dim, 20); vc = rnd(L * seq_len * dim, 21); q = rnd(dim, 22, 2.0)
+    rs = rama_amd.RunState.from_config(rcfg, dev)
+    rsv = rama_amd.RunStateView.from_rs(rs)
+    dev.upload_into(rsv.key_cache, kc); dev.upload_into(rsv.value_cache, vc); dev.upload_into(rsv.q, q)
+    for layer in (0, 1):
+        for pos in positions:
+            orc.s["key_cache"][:] = kc; orc.s["value_cache"][:] = vc; orc.s["q"][:] = q
+            orc.multi_head_attention(layer, pos)
+            dev.multi_head_attention(rsv, rcfg, layer, pos)
+            got = dev.download(rsv.xb)
+            np.testing.assert_allclose(got, orc.s["xb"], rtol=2e-5, atol=3e-6)
+            att = dev.download(rsv.att).reshape(n_heads, seq_len)[:, :pos + 1]
+            np.testing.assert_allclose(att, orc.s["att"].reshape(n_heads, seq_len)[:, :pos + 1], rtol=2e-5, atol=1e-7)
+            np.testing.assert_allclose(att.sum(axis=1), 1.0, atol=1e-5)
+    rs.free()
+
+
+def test_attention_uniform_keys_average_values(dev):
+    """property: identical keys => uniform softmax => output = mean of the cached values"""
+    import rama_amd
+    n_heads, hs, seq_len = 2, 64, 128
+    dim = n_heads * hs
+    rcfg = rama_amd.Config(dim, dim, 1, n_heads, n_heads, 8, seq_len, True)
+    rs = rama_amd.RunState.from_config(rcfg, dev); rsv = rama_amd.RunStateView.from_rs(rs)
+    k = np.tile(rnd(dim, 30), seq_len); v = rnd(seq_len * dim, 31)
+    dev.upload_into(rsv.key_cache, k); dev.upload_into(rsv.value_cache, v); dev.upload_into(rsv.q, rnd(dim, 32))
+    pos = 99
+    dev.multi_head_attention(rsv, rcfg, 0, pos)
+    want = v.reshape(seq_len, dim)[:pos + 1].astype(np.float64).mean(axis=0)
+    np.testing.assert_allclose(dev.download(rsv.xb), want, atol=2e-6)
+    rs.free()
+
+
+# ------------------------------------------------------------------ sampling
+
+def test_sample_argmax_ties_last_index(dev):
+    import rama_amd
+    n = 32000
+    x = rnd(n, 40)
+    x[123] = x[31999] = x[17000] = 9.0
+    cfg = rama_amd.Config(4, 4, 1, 1, 1, n, 4, True)
+    rs = rama_amd.RunState.from_config(cfg, dev); rsv = rama_amd.RunStateView.from_rs(rs)
+    dev.upload_into(rsv.logits, x)
+    assert dev.sample(cfg, rsv, 0.0, 0.9) == 31999 == O.argmax(x)
+    x[31999] = 0.0
+    dev.upload_into(rsv.logits, x)
+    assert dev.sample(cfg, rsv, 0.0, 0.9) == 17000 == O.argmax(x)
+    rs.free()
+
+
+@pytest.mark.parametrize("temperature,topp,u", [(1.0, 0.9, 0.2721174359321594), (0.7, 0.9, 0.5), (1.5, 0.5, 0.03743588924407959), (1.0, 1.0, 0.999)])
+def test_sample_topp_matches_oracle(dev, temperature, topp, u):
+    import rama_amd
+    n = 4096
+    x = rnd(n, 41, 3.0)
+    cfg = rama_amd.Config(4, 4, 1, 1, 1, n, 4, True)
+    rs = rama_amd.RunState.from_config(cfg, dev); rsv = rama_amd.RunStateView.from_rs(rs)
+    dev.upload_into(rsv.logits, x)
+    assert dev.sample(cfg, rsv, temperature, topp, u) == O.sample(x.copy(), temperature, topp, u)
+    rs.free()
+
+
+# ------------------------------------------------------------------ synthetic fill (bit-exact)
+
+@pytest.mark.parametrize("n,seed,tag,offset,bias", [(1, 0, 1, 0, 0.0), (1000, 3, 5, 0, 0.0), (70001, 9, 12, 1 << 33, 0.0), (4096, 2, 7, 12345, 1.0)])
+def test_fill_synth_bit_exact(dev, n, seed, tag, offset, bias):
+    sc = np.float32(0.02 / S.IH4_STD)
+    s = dev.alloc(n)
+    import rama_amd
+    rama_amd._lib.check(dev.lib.rama_fill_synth(dev.ctx, s.ptr, n, seed, tag, offset, sc, np.float32(bias)))
+    assert np.array_equal(dev.download(s), O.fill_synth(n, seed, tag, sc, bias, offset))
