@@ -70,7 +70,12 @@ def cpu_baseline(shape_name, n_tokens, n_layers_sample):
         tag, scale, bias = spec[name]
         w[name] = O.fill_synth(int(np.prod(shp)), 0, tag, scale, bias).reshape(shp)
     w["freq_cis_real"], w["freq_cis_imag"] = S.rope_tables(cfg.seq_len, cfg.head_size)
-    cores = os.cpu_count() or 1
+    # the GPU box shows 256 CPUs but a 1-GPU job owns a 16-CPU share
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(16, avail))
     orc = O.Oracle(cfg, w, threads=cores)
     toks = [1] + PROMPT
     t_layers = t_cls = 0.0

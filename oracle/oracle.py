@@ -86,6 +86,13 @@ def lib() -> C.CDLL:
     L.oracle_forward_range.argtypes = L.oracle_forward.argtypes + [C.c_int] * 4
     L.oracle_forward_f64.argtypes = L.oracle_forward.argtypes
     L.oracle_fill_synth.argtypes = [_f32p, sz, C.c_uint64, C.c_uint64, C.c_uint64, C.c_float, C.c_float]
+    # The GPU box reports 256 CPUs but a 1-GPU job owns a 16-CPU share: an OpenMP team of
+    # 256 on that share makes every tiny parallel region crawl.  Callers may override.
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    L.oracle_set_threads(max(1, min(16, ncpu)))
     _lib = L
     return L
 

@@ -91,8 +91,10 @@ int oracle_matmul(float *o, const float *a, const float *b,
                   size_t width, size_t o_rows, size_t o_cols) {
     if (width % 4 != 0 || o_cols == 0) return -1;
     size_t n_out = o_rows * o_cols;
+    /* tiny products stay on the calling thread (fork/join costs more than the work) */
+    const int par = (n_out * width) >= ((size_t)1 << 17);
     if (o_cols == 1) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (par)
         for (size_t r = 0; r < n_out; r++) {
             const float *ar = a + r * width;
             float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
@@ -106,7 +108,7 @@ int oracle_matmul(float *o, const float *a, const float *b,
         }
         return 0;
     }
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (par)
     for (size_t idx = 0; idx < n_out; idx++) {
         size_t r = idx / o_cols, c = idx % o_cols;
         const float *ar = a + r * width;
@@ -144,7 +146,8 @@ void oracle_multi_head_attention(const oracle_config *cfg, oracle_state *s,
     const size_t hs = dim / (size_t)cfg->n_heads;
     const size_t lo = (size_t)layer * (size_t)cfg->seq_len * dim;
     const float scale_div = sqrtf((float)hs);
-#pragma omp parallel for schedule(static)
+    const int par = ((size_t)(pos + 1) * dim) >= ((size_t)1 << 15);
+#pragma omp parallel for schedule(static) if (par)
     for (int h = 0; h < cfg->n_heads; h++) {
         float *att = s->att + (size_t)h * (size_t)cfg->seq_len;
         const float *q = s->q + (size_t)h * hs;
@@ -277,7 +280,7 @@ void oracle_forward(const oracle_config *cfg, const oracle_weights *w,
 /* ---------------- fp64 arbiter (same network, double accumulation) ------------- */
 
 static void mv64(float *o, const float *a, const float *b, size_t width, size_t rows) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (rows * width >= ((size_t)1 << 17))
     for (size_t r = 0; r < rows; r++) {
         double acc = 0.0;
         const float *ar = a + r * width;
@@ -317,7 +320,7 @@ void oracle_forward_f64(const oracle_config *cfg, const oracle_weights *w,
         const size_t lo = l * (size_t)cfg->seq_len * dim;
         memcpy(s->key_cache + lo + (size_t)pos * dim, s->k, dim * sizeof(float));
         memcpy(s->value_cache + lo + (size_t)pos * dim, s->v, dim * sizeof(float));
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (((size_t)(pos + 1) * dim) >= ((size_t)1 << 15))
         for (int h = 0; h < cfg->n_heads; h++) {
             float *att = s->att + (size_t)h * (size_t)cfg->seq_len;
             const float *q = s->q + (size_t)h * hs;
@@ -370,7 +373,7 @@ static inline uint64_t splitmix64(uint64_t z) {
 void oracle_fill_synth(float *dst, size_t n, uint64_t seed, uint64_t tag,
                        uint64_t offset, float scale, float bias) {
     const uint64_t base = offset + tag * 0x9E3779B97F4A7C15ULL + seed * 0xD1B54A32D192ED03ULL;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n >= ((size_t)1 << 16))
     for (size_t i = 0; i < n; i++) {
         uint64_t z = splitmix64((uint64_t)i + base);
         int32_t sum = (int32_t)(z & 0xFFFF) + (int32_t)((z >> 16) & 0xFFFF) +

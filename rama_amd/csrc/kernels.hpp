@@ -535,7 +535,9 @@ __global__ void fill_synth_kernel(float* dst, size_t n, uint64_t base, float sca
         z ^= z >> 27; z *= 0x94D049BB133111EBULL;
         z ^= z >> 31;
         int sum = (int)(z & 0xFFFF) + (int)((z >> 16) & 0xFFFF) + (int)((z >> 32) & 0xFFFF) + (int)(z >> 48);
-        dst[i] = __fadd_rn(bias, __fmul_rn((float)(sum - 131070), scale));   // no FMA contraction
+        float prod = (float)(sum - 131070) * scale;
+        asm volatile("" : "+v"(prod));   // opaque: bias + prod must round twice like the CPU generator, never one FMA
+        dst[i] = bias + prod;
     }
 }
 

@@ -131,7 +131,10 @@ int rama_device_info(rama_ctx* c, char name[64], int* cus, size_t* hbm) {
     REQUIRE(c, RAMA_EINVAL, "ctx is NULL");
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, c->device));
-    if (name) { strncpy(name, prop.name, 63); name[63] = 0; }
+    if (name) {   // marketing name needs amdgpu.ids, absent on some boxes: fall back to the ISA name
+        strncpy(name, prop.name[0] ? prop.name : prop.gcnArchName, 63);
+        name[63] = 0;
+    }
     if (cus) *cus = prop.multiProcessorCount;
     if (hbm) *hbm = prop.totalGlobalMem;
     return 0;

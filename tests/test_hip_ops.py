@@ -96,7 +96,11 @@ def test_softmax(dev, n):
     dev.softmax(tx, n)
     e = x.copy(); O.softmax(e, n)
     got = dev.download(tx)
-    np.testing.assert_allclose(got, e, rtol=1e-5, atol=1e-9)
+    # the oracle's (= reference's) SEQUENTIAL fp32 sum of n positive terms is itself off by
+    # ~sqrt(n)*eps relative; the device tree sum is closer to exact
+    np.testing.assert_allclose(got, e, rtol=max(1e-5, 4e-7 * n ** 0.5), atol=1e-12)
+    ex = np.exp(x.astype(np.float64) - float(x.max())); ex /= ex.sum()
+    np.testing.assert_allclose(got, ex, rtol=5e-6, atol=1e-12)
     assert abs(float(got.astype(np.float64).sum()) - 1.0) < 1e-5
 
 
