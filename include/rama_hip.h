@@ -171,6 +171,10 @@ int  rama_decode_steps(rama_ctx *ctx, const rama_config *cfg, const rama_weights
 int  rama_decode_tokens(rama_ctx *ctx, int32_t *out_tokens_host, int max_tokens, int *n_out);
 /* 1: capture each decode step into a hipGraph and replay it (default 0 = eager launches) */
 int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
+/* Performance knobs (results are unaffected up to fp32 summation order).  Keys:
+ *   "geom" = 0..3 : matvec workgroup geometry (rows per workgroup, waves, chunks per step);
+ *                   0 is the shipping choice, see rama_api.hip DISPATCH_GEOM */
+int  rama_set_tuning(rama_ctx *ctx, const char *key, int value);
 
 /* ---------------------------------------------------------------- measurement
  * HIP events on the context's stream (the stream the kernels are launched on). */

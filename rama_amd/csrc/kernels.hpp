@@ -5,11 +5,13 @@
 // Design (DESIGN.md has the numbers):
 //  * The W.x matvecs are >99 % of the bytes and HBM-bound (0.5 FLOP/B).  Weight rows are
 //    streamed once with 16-byte-per-lane `buffer_load_dwordx4 ... nt` straight into VGPRs
-//    (no LDS round trip: nothing is shared between waves), all loads of a step issued
-//    before the first use.  A 256-thread workgroup owns R consecutive rows and splits K
-//    across its four waves (contiguous K-quarters), so a [4096]-wide row group is ONE
-//    burst of 16 outstanding loads per lane; partial sums are reduced with DPP inside a
-//    wave and through 80 bytes of LDS across the four waves.
+//    (no LDS round trip: nothing is shared between waves), every load of a step issued
+//    before the first use.  A workgroup of NW waves owns R consecutive rows and splits K
+//    across its waves in 256-float (1 KiB) chunks, chunk c going to wave c mod NW, so the
+//    workgroup as a whole sweeps each row front to back in NW-KiB contiguous pieces
+//    (measured: +10-14 % over giving each wave a contiguous K range; tools/gemv_bench.hip).
+//    Partial sums are reduced with DPP inside a wave and through a few bytes of LDS across
+//    the waves.  Shipping geometry: NW = 8, R = 2, CH = 2 (small workgroups, high occupancy).
 //  * Buffer (SRSRC) addressing gives hardware bounds checking: out-of-range lanes/chunks
 //    get offset 0x80000000 and return 0 without touching memory, so ragged widths
 //    (288 = 256 + 32) and row tails need no branches in the load stream.
@@ -35,7 +37,7 @@ struct Ctl {          // device-resident decode cursor
 };
 
 constexpr unsigned kOOB = 0x80000000u;   // >= any num_records we build: load returns 0
-constexpr int kWG = 256;                 // 4 waves
+constexpr int kWG = 256;                 // workgroup size of the non-matvec kernels
 
 // ---------------------------------------------------------------- small device helpers
 
@@ -56,6 +58,13 @@ __device__ __forceinline__ float dpp_mov(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
         0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
+template <int CTRL>
+__device__ __forceinline__ int dpp_movi(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+__device__ __forceinline__ float lane_f(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
 // sum over the 16 lanes of a DPP row; every lane of the row gets the sum
 __device__ __forceinline__ float row16_sum(float v) {
     v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
@@ -67,16 +76,22 @@ __device__ __forceinline__ float row16_sum(float v) {
 // sum over all 64 lanes, fixed order, wave-uniform result
 __device__ __forceinline__ float wave_sum(float v) {
     v = row16_sum(v);
-    float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
-    float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
-    float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
-    float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
-    return (r0 + r1) + (r2 + r3);
+    return (lane_f(v, 0) + lane_f(v, 16)) + (lane_f(v, 32) + lane_f(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
-    return v;
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    return fmaxf(fmaxf(lane_f(v, 0), lane_f(v, 16)), fmaxf(lane_f(v, 32), lane_f(v, 48)));
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+    v = max(v, dpp_movi<0xB1>(v));
+    v = max(v, dpp_movi<0x4E>(v));
+    v = max(v, dpp_movi<0x141>(v));
+    v = max(v, dpp_movi<0x140>(v));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 __device__ __forceinline__ float dot4(f4 a, f4 b, float acc) {
     acc = fmaf(a.x, b.x, acc);
@@ -87,12 +102,13 @@ __device__ __forceinline__ float dot4(f4 a, f4 b, float acc) {
 }
 
 // ---------------------------------------------------------------- the streaming core
-// S weight streams (rows) of width K against one activation vector; K is split over the
-// workgroup's 4 waves in 256-float chunks.  On return acc[s] / ss hold this WAVE's
+// S weight streams (rows) of width K against one activation vector; the row's 256-float
+// chunks are dealt round-robin to the workgroup's NW waves (chunk c -> wave c mod NW) and a
+// wave takes CH of its chunks per step.  On return acc[s] / ss hold this WAVE's
 // (wave-reduced, wave-uniform) partial sums.
 //   NM   : streams alternate over NM matrices (s % NM): 1, or 2 for W1|W3
 //   NORM : activations are nw[k]*x[k]; ss accumulates sum x[k]^2 (rmsnorm folded in)
-template <int S, int NM, int CH, bool NORM>
+template <int S, int NM, int CH, int NW, bool NORM>
 __device__ __forceinline__ void stream_dots(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb,
                                             const unsigned (&rowoff)[S],
                                             __amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t rn,
@@ -100,28 +116,26 @@ __device__ __forceinline__ void stream_dots(__amdgpu_buffer_rsrc_t ra, __amdgpu_
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nch = (K + 255) >> 8;          // 256-float chunks in a row
-    const int cpw = (nch + 3) >> 2;          // chunks per wave
-    const int c0 = wave * cpw;
-    const int c1 = min(c0 + cpw, nch);
     const unsigned kbytes = (unsigned)K * 4u;
 #pragma unroll
     for (int s = 0; s < S; s++) acc[s] = 0.0f;
     ss = 0.0f;
-    for (int c = c0; c < c1; c += CH) {
+    for (int c = wave; c < nch; c += CH * NW) {
         f4 w[S][CH];
         f4 xv[CH];
         f4 nv[CH];
         unsigned kb[CH];
 #pragma unroll
         for (int j = 0; j < CH; j++) {
-            unsigned b = (unsigned)((c + j) * 1024 + lane * 16);
-            kb[j] = ((c + j) < c1 && b < kbytes) ? b : kOOB;
+            const int ci = c + j * NW;
+            const unsigned b = (unsigned)(ci * 1024 + lane * 16);
+            kb[j] = (ci < nch && b < kbytes) ? b : kOOB;
         }
 #pragma unroll
         for (int j = 0; j < CH; j++) {
 #pragma unroll
             for (int s = 0; s < S; s++) {
-                unsigned o = (kb[j] == kOOB) ? kOOB : rowoff[s] + kb[j];
+                const unsigned o = (kb[j] == kOOB) ? kOOB : rowoff[s] + kb[j];
                 w[s][j] = ld_nt((NM == 2 && (s & 1)) ? rb : ra, o);
             }
         }
@@ -131,8 +145,8 @@ __device__ __forceinline__ void stream_dots(__amdgpu_buffer_rsrc_t ra, __amdgpu_
             if (NORM) nv[j] = ld_c(rn, kb[j]);
         }
         // every load of the step is in flight before the first FMA: without this fence
-        // hipcc's max-occupancy scheduler interleaves loads with uses to save VGPRs and
-        // leaves only ~8 of the S*CH + 2*CH loads outstanding.
+        // hipcc's max-occupancy scheduler sinks loads next to their uses to save VGPRs
+        // and leaves only a few outstanding.
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < CH; j++) {
@@ -151,7 +165,7 @@ __device__ __forceinline__ void stream_dots(__amdgpu_buffer_rsrc_t ra, __amdgpu_
 }
 
 // cross-wave combine through LDS: part[wave][0..S-1] = acc, part[wave][S] = ss
-template <int S>
+template <int S, int NW>
 __device__ __forceinline__ void publish_partials(float (*part)[S + 1], const float (&acc)[S], float ss) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) {
@@ -161,9 +175,16 @@ __device__ __forceinline__ void publish_partials(float (*part)[S + 1], const flo
     }
     __syncthreads();
 }
-template <int S>
+template <int S, int NW>
 __device__ __forceinline__ float combined(float (*part)[S + 1], int s) {
-    return (part[0][s] + part[1][s]) + (part[2][s] + part[3][s]);
+    float t[NW];
+#pragma unroll
+    for (int w = 0; w < NW; w++) t[w] = part[w][s];
+#pragma unroll
+    for (int n = NW; n > 1; n >>= 1)      // fixed pairwise tree
+#pragma unroll
+        for (int w = 0; w < n / 2; w++) t[w] = t[2 * w] + t[2 * w + 1];
+    return t[0];
 }
 // cpu.rs:110-113: v = 1/sqrt(sum(x^2)/len + 1e-5)
 __device__ __forceinline__ float rms_scale(float ss, int n) {
@@ -190,14 +211,16 @@ struct GemvParams {
     float* vc;             // this layer's value cache [seq, dim]
 };
 
-// R rows per workgroup; grid = nmat*rows/R (rows % R need not be 0: tail rows read as 0)
-template <int R, int CH, bool NORM, int EPI>
-__global__ __launch_bounds__(kWG) void gemv_rows(GemvParams p) {
-    __shared__ float part[4][R + 1];
+// R rows per workgroup of NW waves; grid = nmat * ceil(rows/R) (tail rows read as 0)
+template <int R, int CH, int NW, bool NORM, int EPI>
+__global__ __launch_bounds__(NW * 64) void gemv_rows(GemvParams p) {
+    __shared__ float part[NW][R + 1];
     const int groups_per_mat = (p.rows + R - 1) / R;
     const int m = blockIdx.x / groups_per_mat;
     const int r0 = (blockIdx.x - m * groups_per_mat) * R;
+    const int t = threadIdx.x;
     const float* W = (m == 0) ? p.w[0] : (m == 1 ? p.w[1] : p.w[2]);
+    float* o = (m == 0) ? p.o[0] : (m == 1 ? p.o[1] : p.o[2]);
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(W, (unsigned)p.rows * (unsigned)p.K * 4u);
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (unsigned)p.K * 4u);
     const __amdgpu_buffer_rsrc_t rn = make_rsrc(NORM ? p.nw : p.x, (unsigned)p.K * 4u);
@@ -205,37 +228,45 @@ __global__ __launch_bounds__(kWG) void gemv_rows(GemvParams p) {
 #pragma unroll
     for (int s = 0; s < R; s++)
         rowoff[s] = (r0 + s < p.rows) ? (unsigned)(r0 + s) * (unsigned)p.K * 4u : kOOB;
-    float acc[R], ss;
-    stream_dots<R, 1, CH, NORM>(ra, ra, rowoff, rx, rn, p.K, acc, ss);
-    publish_partials<R>(part, acc, ss);
 
-    const int t = threadIdx.x;
+    // epilogue operands are fetched up front so their latency hides behind the weight stream
+    float resid = 0.0f, rc = 1.0f, rs = 0.0f;
+    int pos = 0;
+    if (EPI == EPI_RESID) {
+        if (t < R && r0 + t < p.rows) resid = o[r0 + t];
+    } else if (EPI == EPI_QKV) {
+        pos = p.ctl ? p.ctl->pos : p.pos_val;
+        if (t < R / 2 && m < 2) {   // table row pos, entry (r % hs)/2  (infer.rs:15-16)
+            const int i = ((r0 + 2 * t) % p.head_size) >> 1;
+            rc = p.fr[(size_t)pos * (p.head_size >> 1) + i];
+            rs = p.fi[(size_t)pos * (p.head_size >> 1) + i];
+        }
+    }
+
+    float acc[R], ss;
+    stream_dots<R, 1, CH, NW, NORM>(ra, ra, rowoff, rx, rn, p.K, acc, ss);
+    publish_partials<R, NW>(part, acc, ss);
+
     if (EPI == EPI_STORE || EPI == EPI_RESID) {
         if (t < R && r0 + t < p.rows) {
-            float d = combined<R>(part, t);
-            if (NORM) d *= rms_scale(combined<R>(part, R), p.K);
-            float* o = (m == 0) ? p.o[0] : (m == 1 ? p.o[1] : p.o[2]);
-            if (EPI == EPI_RESID) d = o[r0 + t] + d;     // infer.rs:37,47  x[i] += y[i]
+            float d = combined<R, NW>(part, t);
+            if (NORM) d *= rms_scale(combined<R, NW>(part, R), p.K);
+            if (EPI == EPI_RESID) d = resid + d;     // infer.rs:37,47  x[i] += y[i]
             o[r0 + t] = d;
         }
     } else {   // EPI_QKV: rows are (even, odd) pairs of one head (R even, head_size even)
         if (t < R / 2) {
             const int r = r0 + 2 * t;
-            float a = combined<R>(part, 2 * t), b = combined<R>(part, 2 * t + 1);
+            float a = combined<R, NW>(part, 2 * t), b = combined<R, NW>(part, 2 * t + 1);
             if (NORM) {
-                const float v = rms_scale(combined<R>(part, R), p.K);
+                const float v = rms_scale(combined<R, NW>(part, R), p.K);
                 a *= v; b *= v;
             }
-            const int pos = p.ctl ? p.ctl->pos : p.pos_val;
-            if (m < 2) {   // cpu.rs:87-96 rotate (q, k); table row pos, entry (r % hs)/2
-                const int i = (r % p.head_size) >> 1;
-                const float c = p.fr[(size_t)pos * (p.head_size >> 1) + i];
-                const float s = p.fi[(size_t)pos * (p.head_size >> 1) + i];
-                const float ra_ = a * c - b * s;
-                const float rb_ = a * s + b * c;
+            if (m < 2) {   // cpu.rs:87-96 rotate (q, k)
+                const float ra_ = a * rc - b * rs;
+                const float rb_ = a * rs + b * rc;
                 a = ra_; b = rb_;
             }
-            float* o = (m == 0) ? p.o[0] : (m == 1 ? p.o[1] : p.o[2]);
             o[r] = a; o[r + 1] = b;
             if (m == 1) {          // infer.rs:32  key_cache[lo + pos*dim ..] = k
                 p.kc[(size_t)pos * p.rows + r] = a; p.kc[(size_t)pos * p.rows + r + 1] = b;
@@ -256,10 +287,10 @@ struct SwigluParams {
 };
 
 // hb[r] = silu(w1[r].xs) * (w3[r].xs), xs = rmsnorm(x) * nw   (infer.rs:39-45, cpu.rs:54-64)
-template <int R2, int CH>
-__global__ __launch_bounds__(kWG) void gemv_swiglu(SwigluParams p) {
+template <int R2, int CH, int NW>
+__global__ __launch_bounds__(NW * 64) void gemv_swiglu(SwigluParams p) {
     constexpr int S = 2 * R2;
-    __shared__ float part[4][S + 1];
+    __shared__ float part[NW][S + 1];
     const int r0 = blockIdx.x * R2;
     const unsigned mbytes = (unsigned)p.rows * (unsigned)p.K * 4u;
     const __amdgpu_buffer_rsrc_t r1 = make_rsrc(p.w1, mbytes);
@@ -271,13 +302,13 @@ __global__ __launch_bounds__(kWG) void gemv_swiglu(SwigluParams p) {
     for (int s = 0; s < S; s++)
         rowoff[s] = (r0 + (s >> 1) < p.rows) ? (unsigned)(r0 + (s >> 1)) * (unsigned)p.K * 4u : kOOB;
     float acc[S], ss;
-    stream_dots<S, 2, CH, true>(r1, r3, rowoff, rx, rn, p.K, acc, ss);
-    publish_partials<S>(part, acc, ss);
+    stream_dots<S, 2, CH, NW, true>(r1, r3, rowoff, rx, rn, p.K, acc, ss);
+    publish_partials<S, NW>(part, acc, ss);
     const int t = threadIdx.x;
     if (t < R2 && r0 + t < p.rows) {
-        const float v = rms_scale(combined<S>(part, S), p.K);
-        float a = combined<S>(part, 2 * t) * v;
-        const float b = combined<S>(part, 2 * t + 1) * v;
+        const float v = rms_scale(combined<S, NW>(part, S), p.K);
+        float a = combined<S, NW>(part, 2 * t) * v;
+        const float b = combined<S, NW>(part, 2 * t + 1) * v;
         a = a * (1.0f / (1.0f + expf(-a)));   // cpu.rs:56
         p.hb[r0 + t] = a * b;                 // cpu.rs:59-64
     }
@@ -490,40 +521,69 @@ __global__ __launch_bounds__(1024) void softmax_kernel(float* x, int n) {
 
 // Device::sample T == 0 (cpu.rs:163-167): max value, ties -> LAST index.  One workgroup.
 // With `ctl` set it also advances the decode cursor (generate loop, mod.rs:190-203):
-// next = pos < n_forced ? forced[pos] : argmax; out[n_out++] = next; token = next; pos += 1.
-__global__ __launch_bounds__(1024) void argmax_kernel(const float* logits, int n, int* result,
-                                                      Ctl* ctl, const int* forced, int* out, int out_cap) {
+//   next = pos < n_forced ? forced[pos] : argmax; out[n_out++] = next; token = next; pos += 1
+// and, when `emb` is given, gathers the next step's embedding row into x (infer.rs:13), so a
+// chained decode step needs no separate gather launch.
+struct ArgmaxParams {
+    const float* logits; int n;
+    int* result;          // optional device int
+    Ctl* ctl;             // optional cursor to advance
+    const int* forced; int* out; int out_cap;
+    const float* emb; float* x; int dim;   // optional next-token embedding gather
+};
+
+__global__ __launch_bounds__(1024) void argmax_kernel(ArgmaxParams p) {
     __shared__ float s_v[16];
     __shared__ int s_i[16];
+    __shared__ int s_next;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // cursor reads go out first; their latency overlaps the logits sweep
+    int pos = 0, n_forced = 0, n_out = 0, forced_tok = -1;
+    if (p.ctl && tid == 0) {
+        pos = p.ctl->pos; n_forced = p.ctl->n_forced; n_out = p.ctl->n_out;
+        if (pos < n_forced) forced_tok = p.forced[pos];
+    }
     float bv = -INFINITY; int bi = -1;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        float v = logits[i];
-        if (bi < 0 || !(bv > v)) { bv = v; bi = i; }   // ascending i per thread: last max wins
+    // 16-byte loads when the view is aligned; every thread visits its indices in ascending
+    // order, so "replace unless strictly smaller" keeps the LAST maximum (cpu.rs:165-167)
+    const int n4 = (((uintptr_t)p.logits & 15) == 0) ? (p.n >> 2) : 0;
+    const f4* l4 = reinterpret_cast<const f4*>(p.logits);
+    for (int i = tid; i < n4; i += 1024) {
+        const f4 v = l4[i];
+        if (!(bv > v.x)) { bv = v.x; bi = 4 * i; }
+        if (!(bv > v.y)) { bv = v.y; bi = 4 * i + 1; }
+        if (!(bv > v.z)) { bv = v.z; bi = 4 * i + 2; }
+        if (!(bv > v.w)) { bv = v.w; bi = 4 * i + 3; }
     }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        float ov = __shfl_xor(bv, m); int oi = __shfl_xor(bi, m);
-        bool take = (bi < 0) || (oi >= 0 && (ov > bv || (ov == bv && oi > bi)));
-        if (take) { bv = ov; bi = oi; }
+    for (int i = 4 * n4 + tid; i < p.n; i += 1024) {
+        const float v = p.logits[i];
+        if (!(bv > v)) { bv = v; bi = i; }
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { s_v[wave] = bv; s_i[wave] = bi; }
+    const float wm = wave_max(bv);
+    const int wi = wave_max_i(bv == wm ? bi : -1);
+    if (lane == 0) { s_v[wave] = wm; s_i[wave] = wi; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        bv = s_v[0]; bi = s_i[0];
-        for (int w = 1; w < (int)(blockDim.x >> 6); w++) {
-            float ov = s_v[w]; int oi = s_i[w];
-            if ((bi < 0) || (oi >= 0 && (ov > bv || (ov == bv && oi > bi)))) { bv = ov; bi = oi; }
+    if (tid == 0) {
+        float v = s_v[0]; int idx = s_i[0];
+        for (int w = 1; w < 16; w++) {
+            const float ov = s_v[w]; const int oi = s_i[w];
+            if (oi >= 0 && (idx < 0 || ov > v || (ov == v && oi > idx))) { v = ov; idx = oi; }
         }
-        if (result) *result = bi;
-        if (ctl) {
-            const int pos = ctl->pos;
-            const int next = (pos < ctl->n_forced) ? forced[pos] : bi;
-            if (ctl->n_out < out_cap) out[ctl->n_out] = next;
-            ctl->n_out += 1;
-            ctl->token = next;
-            ctl->pos = pos + 1;
+        if (p.result) *p.result = idx;
+        int next = idx;
+        if (p.ctl) {
+            if (forced_tok >= 0) next = forced_tok;
+            if (n_out < p.out_cap) p.out[n_out] = next;
+            p.ctl->n_out = n_out + 1;
+            p.ctl->token = next;
+            p.ctl->pos = pos + 1;
         }
+        s_next = next;
+    }
+    if (p.emb) {
+        __syncthreads();
+        const size_t base = (size_t)s_next * p.dim;
+        for (int i = tid; i < p.dim; i += 1024) p.x[i] = p.emb[base + i];
     }
 }
 

@@ -66,6 +66,8 @@ struct rama_ctx {
     GraphCache gc;
     KProf kp;
     int cu_count = 0;
+    int tune_geom = 3;
+    const float* embedded_x = nullptr;   // run-state x that already holds emb[ctl.token] (chained decode)
 };
 
 static int set_device(rama_ctx* c) { HIPCHK(hipSetDevice(c->device)); return 0; }
@@ -187,9 +189,19 @@ int rama_free(rama_ctx* c, void* p) {
 static inline int ew_grid(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 2048); }
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-constexpr int kR = 4;      // rows per workgroup of the matvec kernels
-constexpr int kCH = 4;     // 256-float chunks in flight per wave per step
-constexpr int kR2 = 2;     // (w1,w3) row pairs per workgroup of the SwiGLU kernel
+// Matvec workgroup geometry: R_ rows (R2_ (w1,w3) row pairs) per workgroup of NW_ waves, CH_
+// 1-KiB chunks per wave per step.  Geometry 3 (4 rows x 8 waves x 2 chunks) ships: in the
+// full llama2-7B decode it gives 233 tok/s vs 223 / 221 / 231 for 0 / 1 / 2 (tools/tune.py).
+// The bare-matvec sweep (tools/gemv_bench.hip) prefers 2 rows per workgroup, but the kernels
+// with rmsnorm folded in re-read x and the norm gain per workgroup, which 4 rows amortise.
+// The others stay selectable for A/B runs through rama_set_tuning(ctx, "geom", g).
+#define DISPATCH_GEOM(c, KERNEL_CALL)                                                                          \
+    switch ((c)->tune_geom) {                                                                                  \
+        case 1: { constexpr int R_ = 2, R2_ = 1, CH_ = 4, NW_ = 4; (void)R_; (void)R2_; KERNEL_CALL; } break;  \
+        case 2: { constexpr int R_ = 4, R2_ = 2, CH_ = 4, NW_ = 4; (void)R_; (void)R2_; KERNEL_CALL; } break;  \
+        case 0: { constexpr int R_ = 2, R2_ = 1, CH_ = 2, NW_ = 8; (void)R_; (void)R2_; KERNEL_CALL; } break;  \
+        default: { constexpr int R_ = 4, R2_ = 2, CH_ = 2, NW_ = 8; (void)R_; (void)R2_; KERNEL_CALL; } break; \
+    }
 
 struct KTimer {   // brackets a launch with events when that kernel class is being profiled
     rama_ctx* c; bool on;
@@ -219,8 +231,7 @@ static int launch_rows(rama_ctx* c, float* o, const float* W, const float* x, co
     if (rc) return rc;
     GemvParams p{};
     p.w[0] = W; p.x = x; p.nw = nw; p.o[0] = o; p.K = K; p.rows = rows; p.nmat = 1;
-    int grid = (rows + kR - 1) / kR;
-    hipLaunchKernelGGL((gemv_rows<kR, kCH, NORM, EPI>), dim3(grid), dim3(kWG), 0, c->stream, p);
+    DISPATCH_GEOM(c, hipLaunchKernelGGL((gemv_rows<R_, CH_, NW_, NORM, EPI>), dim3((rows + R_ - 1) / R_), dim3(NW_ * 64), 0, c->stream, p));
     LAUNCHCHK();
     return 0;
 }
@@ -313,8 +324,9 @@ int rama_multi_head_attention(rama_ctx* c, float* xb, float* att, const float* q
 
 int rama_sample_argmax(rama_ctx* c, const float* logits, size_t n, int32_t* next_host) {
     REQUIRE(c && logits && next_host && n > 0, RAMA_EINVAL, "sample_argmax: bad argument");
-    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, c->stream, logits, (int)n, c->argmax_result,
-                       (Ctl*)nullptr, (const int*)nullptr, (int*)nullptr, 0);
+    ArgmaxParams ap{};
+    ap.logits = logits; ap.n = (int)n; ap.result = c->argmax_result;
+    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, c->stream, ap);
     LAUNCHCHK();
     HIPCHK(hipMemcpyAsync(c->pinned_int, c->argmax_result, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -396,7 +408,7 @@ static int enqueue_stage(rama_ctx* c, const rama_config* cfg, const rama_weights
             p.K = dim; p.rows = dim; p.nmat = 3;
             p.ctl = c->ctl; p.fr = w->freq_cis_real; p.fi = w->freq_cis_imag; p.head_size = hs;
             p.kc = kc; p.vc = vc;
-            hipLaunchKernelGGL((gemv_rows<kR, kCH, true, EPI_QKV>), dim3(3 * (dim / kR)), dim3(kWG), 0, c->stream, p);
+            DISPATCH_GEOM(c, hipLaunchKernelGGL((gemv_rows<R_, CH_, NW_, true, EPI_QKV>), dim3(3 * (dim / R_)), dim3(NW_ * 64), 0, c->stream, p));
             LAUNCHCHK();
         }
         {   // infer.rs:34
@@ -414,7 +426,7 @@ static int enqueue_stage(rama_ctx* c, const rama_config* cfg, const rama_weights
             SwigluParams p{};
             p.w1 = w->w1 + li * hd; p.w3 = w->w3 + li * hd; p.x = s->x; p.nw = w->rms_ffn_weight + li * dim;
             p.hb = s->hb; p.K = dim; p.rows = hidden;
-            hipLaunchKernelGGL((gemv_swiglu<kR2, kCH>), dim3((hidden + kR2 - 1) / kR2), dim3(kWG), 0, c->stream, p);
+            DISPATCH_GEOM(c, hipLaunchKernelGGL((gemv_swiglu<R2_, CH_, NW_>), dim3((hidden + R2_ - 1) / R2_), dim3(NW_ * 64), 0, c->stream, p));
             LAUNCHCHK();
         }
         {   // infer.rs:46-47: x += W2 . hb
@@ -434,7 +446,7 @@ static int enqueue_stage(rama_ctx* c, const rama_config* cfg, const rama_weights
 static int check_stage(const rama_config* cfg, const rama_weights* w, const rama_run_state* s, const rama_stage* st) {
     REQUIRE(w && s && st, RAMA_EINVAL, "forward: NULL argument");
     REQUIRE(st->layer_begin >= 0 && st->layer_begin <= st->layer_end && st->layer_end <= cfg->n_layers, RAMA_EINVAL, "forward: bad layer range");
-    REQUIRE(cfg->dim % kR == 0, RAMA_EINVAL, "forward: dim % 4 != 0");
+    REQUIRE(cfg->dim % 4 == 0, RAMA_EINVAL, "forward: dim % 4 != 0");
     if (st->layer_end > st->layer_begin)
         REQUIRE(w->wq && w->wk && w->wv && w->wo && w->w1 && w->w2 && w->w3 && w->rms_att_weight && w->rms_ffn_weight && w->freq_cis_real && w->freq_cis_imag, RAMA_EINVAL, "forward: missing layer weights");
     if (st->do_embed) REQUIRE(w->token_embedding_table, RAMA_EINVAL, "forward: missing embedding table");
@@ -452,6 +464,7 @@ int rama_forward_stage(rama_ctx* c, const rama_config* cfg, const rama_weights* 
     REQUIRE(token >= 0 && token < cfg->vocab_size, RAMA_EINVAL, "forward: token outside the vocabulary");
     hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(1), 0, c->stream, c->ctl, token, pos, 0, 0);
     LAUNCHCHK();
+    c->embedded_x = nullptr;
     return enqueue_stage(c, cfg, w, s, st);
 }
 
@@ -473,15 +486,21 @@ int rama_decode_begin(rama_ctx* c, int token, int pos, const int32_t* forced_hos
     }
     hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(1), 0, c->stream, c->ctl, token, pos, n_forced, 0);
     LAUNCHCHK();
+    c->embedded_x = nullptr;   // the first decode step must gather x = emb[token] itself
     return 0;
 }
 
+// One chained step: layers + classifier + (argmax, cursor advance, next token's embedding
+// gather).  x already holds emb[token] on entry (rama_decode_steps primes it once).
 static int enqueue_decode_step(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s) {
-    rama_stage st{0, cfg->n_layers, 1, 1};
+    rama_stage st{0, cfg->n_layers, 0, 1};
     int rc = enqueue_stage(c, cfg, w, s, &st);
     if (rc) return rc;
-    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, c->stream, (const float*)s->logits, cfg->vocab_size,
-                       (int*)nullptr, c->ctl, (const int*)c->forced, c->out, c->out_cap);
+    ArgmaxParams ap{};
+    ap.logits = s->logits; ap.n = cfg->vocab_size;
+    ap.ctl = c->ctl; ap.forced = c->forced; ap.out = c->out; ap.out_cap = c->out_cap;
+    ap.emb = w->token_embedding_table; ap.x = s->x; ap.dim = cfg->dim;
+    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, c->stream, ap);
     LAUNCHCHK();
     return 0;
 }
@@ -496,6 +515,12 @@ int rama_decode_steps(rama_ctx* c, const rama_config* cfg, const rama_weights* w
     rama_stage st{0, cfg->n_layers, 1, 1};
     rc = check_stage(cfg, w, s, &st); if (rc) return rc;
     REQUIRE(n_steps >= 0, RAMA_EINVAL, "decode_steps: n_steps < 0");
+    if (n_steps == 0) return 0;
+    if (c->embedded_x != s->x) {   // infer.rs:13 for the first step; later steps get it from the argmax kernel
+        hipLaunchKernelGGL(embed_kernel, dim3((cfg->dim + 255) / 256), dim3(256), 0, c->stream, s->x, w->token_embedding_table, (const Ctl*)c->ctl, 0, cfg->dim);
+        LAUNCHCHK();
+        c->embedded_x = s->x;
+    }
     if (c->graph_mode && c->kp.kernel_id < 0) {
         if (!same_capture(c->gc, cfg, w, s)) {
             drop_graph(c);
@@ -542,6 +567,18 @@ int rama_generate_greedy(rama_ctx* c, const rama_config* cfg, const rama_weights
     if (rc) return rc;
     int n = 0;
     return rama_decode_tokens(c, out_host, steps, &n);
+}
+
+int rama_set_tuning(rama_ctx* c, const char* key, int value) {
+    REQUIRE(c && key, RAMA_EINVAL, "set_tuning: NULL argument");
+    if (!strcmp(key, "geom")) {
+        REQUIRE(value >= 0 && value <= 3, RAMA_EINVAL, "set_tuning: geom must be 0..3");
+        c->tune_geom = value;
+        hipStreamSynchronize(c->stream);
+        drop_graph(c);
+        return 0;
+    }
+    return fail(RAMA_EINVAL, "set_tuning: unknown key", __FILE__, __LINE__);
 }
 
 int rama_set_graph_mode(rama_ctx* c, int enabled) {

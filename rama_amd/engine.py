@@ -130,6 +130,9 @@ class Engine:
     def set_graph_mode(self, on: bool):
         check(self.device.lib.rama_set_graph_mode(self.device.ctx, int(on)))
 
+    def set_tuning(self, key: str, value: int):
+        check(self.device.lib.rama_set_tuning(self.device.ctx, key.encode(), value), "rama_set_tuning")
+
     # -- measurement (HIP events on the launch stream)
     def timer_start(self):
         check(self.device.lib.rama_timer_start(self.device.ctx))
