@@ -116,7 +116,9 @@ def main():
     cfg = rama_amd.Config(d, h, L, H, H, V, seq, shared)
     torch.cuda.set_device(local_rank)
 
-    if args.gpus > 1:
+    # RAMA_FORCE_PIPELINE=1 rehearses the N > 1 code path (process group, HipStage, the
+    # grouped exchanges' bookkeeping) with a single rank on a 1-GPU box
+    if args.gpus > 1 or os.environ.get("RAMA_FORCE_PIPELINE"):
         from rama_amd.pipeline import run_pipeline_bench
         line = run_pipeline_bench(args, cfg, rank, world, local_rank)
         if rank == 0:

@@ -156,6 +156,15 @@ int  rama_forward(rama_ctx *ctx, const rama_config *cfg, const rama_weights *w,
 int  rama_forward_stage(rama_ctx *ctx, const rama_config *cfg, const rama_weights *w,
                         rama_run_state *s, int token, int pos, const rama_stage *stage);
 
+/* Layer-pipeline stage variants (no reference counterpart: the reference is single-device).
+ * The token id is read from / written to DEVICE memory, so a stage boundary is one RCCL
+ * send/recv of x[dim] (and of one int32 from the last stage back to the first) with no host
+ * round trip.  token_dev may be NULL for a stage that does not embed. */
+int  rama_forward_stage_devtok(rama_ctx *ctx, const rama_config *cfg, const rama_weights *w,
+                               rama_run_state *s, const int32_t *token_dev, int pos,
+                               const rama_stage *stage);
+int  rama_argmax_dev(rama_ctx *ctx, const float *logits, size_t n, int32_t *result_dev);
+
 /* generate() loop of mod.rs:169-206 at temperature 0, chained on the device: token = 1 (BOS)
  * at pos 0; while pos < steps: forward; next = pos < n_prompt ? prompt[pos] : argmax(logits);
  * out[pos] = next.  No per-token host round trip; out_tokens_host receives `steps` ids. */

@@ -448,6 +448,14 @@ __global__ void set_ctl_kernel(Ctl* ctl, int token, int pos, int n_forced, int n
     ctl->token = token; ctl->pos = pos; ctl->n_forced = n_forced; ctl->n_out = n_out;
 }
 
+// cursor from a token id that lives in device memory (pipeline stages); an id outside the
+// vocabulary is clamped so a corrupted hand-off cannot turn into a wild embedding read
+__global__ void set_ctl_dev_kernel(Ctl* ctl, const int* token_dev, int pos, int vocab) {
+    int t = token_dev ? *token_dev : 0;
+    t = t < 0 ? 0 : (t >= vocab ? vocab - 1 : t);
+    ctl->token = t; ctl->pos = pos; ctl->n_forced = 0; ctl->n_out = 0;
+}
+
 __global__ void array_add_kernel(float* t, const float* s, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) t[i] += s[i];
 }

@@ -468,6 +468,29 @@ int rama_forward_stage(rama_ctx* c, const rama_config* cfg, const rama_weights* 
     return enqueue_stage(c, cfg, w, s, st);
 }
 
+// pipeline-stage variants: the token id stays in device memory end to end
+int rama_forward_stage_devtok(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s,
+                              const int32_t* token_dev, int pos, const rama_stage* st) {
+    REQUIRE(c, RAMA_EINVAL, "ctx is NULL");
+    int rc = check_cfg(cfg); if (rc) return rc;
+    rc = check_stage(cfg, w, s, st); if (rc) return rc;
+    REQUIRE(pos >= 0 && pos < cfg->seq_len, RAMA_EINVAL, "forward: pos outside [0, seq_len)");
+    REQUIRE(token_dev || !st->do_embed, RAMA_EINVAL, "forward: an embedding stage needs a token");
+    hipLaunchKernelGGL(set_ctl_dev_kernel, dim3(1), dim3(1), 0, c->stream, c->ctl, (const int*)token_dev, pos, cfg->vocab_size);
+    LAUNCHCHK();
+    c->embedded_x = nullptr;
+    return enqueue_stage(c, cfg, w, s, st);
+}
+
+int rama_argmax_dev(rama_ctx* c, const float* logits, size_t n, int32_t* result_dev) {
+    REQUIRE(c && logits && result_dev && n > 0, RAMA_EINVAL, "argmax_dev: bad argument");
+    ArgmaxParams ap{};
+    ap.logits = logits; ap.n = (int)n; ap.result = (int*)result_dev;
+    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, c->stream, ap);
+    LAUNCHCHK();
+    return 0;
+}
+
 int rama_forward(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s, int token, int pos) {
     REQUIRE(cfg, RAMA_EINVAL, "config is NULL");
     rama_stage st{0, cfg->n_layers, 1, 1};

@@ -1,0 +1,240 @@
+"""Layer pipeline over N ranks (one process per GPU, torch.distributed; backend "nccl" is RCCL
+over xGMI on ROCm, "gloo" on CPU for tests).  New functionality: the reference is single-device
+(SURVEY.md section 8e).
+
+Partition: rank r owns layers [r*L/N, (r+1)*L/N) with their weights and KV slabs; rank 0 also owns
+the embedding table, the last rank the final norm + classifier.  The only exchanges are
+point-to-point: the residual x[dim] (16 KiB at llama2-7B) from rank r to r+1 and the sampled token
+id (4 bytes) from the last rank back to rank 0 -- no collective.
+
+Batch-1 decode is sequential in the layers, so ONE sequence gains nothing from a pipeline.  The
+schedule therefore keeps N sequences in flight: work item j = (sequence j % N, position j // N);
+rank r processes item tau - r at tick tau, so in steady state every rank is busy every tick and one
+token leaves the pipe per tick.  After computing, a rank posts ONE grouped exchange
+(batch_isend_irecv: its output to the next rank + the receive of its next input), which is
+deadlock-free for any N including N = 2, where both directions share one peer.
+
+`Schedule` is pure bookkeeping and `run_pipeline` only needs a backend object with
+x_buffers / tok_buffers / compute(); tests drive it with gloo and the CPU oracle as the backend.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import time
+from dataclasses import dataclass
+from typing import List, Optional
+
+BOS = 1
+
+
+@dataclass
+class Item:
+    seq: int
+    pos: int
+
+
+class Schedule:
+    """Which item a rank computes at a tick, and what it sends / receives afterwards."""
+
+    def __init__(self, world: int, n_seq: int, n_pos: int):
+        assert n_seq >= 1 and world >= 1 and n_pos >= 1
+        # item j leaves the last rank at tick j + world - 1 and its successor j + n_seq enters
+        # rank 0 at tick j + n_seq: the sampled token exists in time iff n_seq >= world
+        assert n_seq >= world, "a pipeline of `world` stages needs at least `world` sequences in flight"
+        self.world, self.n_seq, self.n_pos = world, n_seq, n_pos
+        self.total = n_seq * n_pos
+        self.ticks = self.total + world - 1
+
+    def item(self, rank: int, tick: int) -> Optional[Item]:
+        j = tick - rank
+        if 0 <= j < self.total:
+            return Item(j % self.n_seq, j // self.n_seq)
+        return None
+
+    def sends(self, rank: int, tick: int):
+        """-> list of (kind, seq, peer): what `rank` sends after computing at `tick`."""
+        it = self.item(rank, tick)
+        if it is None or self.world == 1:
+            return []
+        if rank < self.world - 1:
+            return [("x", it.seq, rank + 1)]
+        return [("tok", it.seq, 0)]
+
+    def recvs(self, rank: int, tick: int):
+        """-> list of (kind, seq, peer): what `rank` receives in the exchange of `tick`."""
+        if self.world == 1:
+            return []
+        src = rank - 1 if rank > 0 else self.world - 1
+        it = self.item(src, tick)
+        if it is None:
+            return []
+        return [("x" if rank > 0 else "tok", it.seq, src)]
+
+
+def split_layers(n_layers: int, world: int, rank: int):
+    """contiguous, as even as possible; earlier ranks get the remainder"""
+    base, rem = divmod(n_layers, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def run_ticks(sched: Schedule, rank: int, backend, tick_from: int, tick_to: int, prompts, dist=None):
+    """Run ticks [tick_from, tick_to).  backend.compute(seq, pos, token) runs this rank's stage:
+    token is an int (BOS / forced prompt token, rank 0 only) or None (= use tok_buffers[seq] on
+    rank 0; ignored elsewhere).  After the last rank's compute tok_buffers[seq] holds the argmax."""
+    for tick in range(tick_from, tick_to):
+        it = sched.item(rank, tick)
+        if it is not None:
+            token = None
+            if rank == 0:
+                p = prompts[it.seq]
+                if it.pos == 0:
+                    token = BOS                       # mod.rs:182
+                elif it.pos <= len(p):
+                    token = p[it.pos - 1]             # mod.rs:190-191 forced prompt token
+            backend.compute(it.seq, it.pos, token)
+        if dist is None or sched.world == 1:
+            if sched.world == 1 and it is not None:
+                pass   # single rank: tok_buffers[seq] already holds the next token
+            continue
+        ops = []
+        for kind, seq, peer in sched.sends(rank, tick):
+            buf = backend.x_buffers[seq] if kind == "x" else backend.tok_buffers[seq]
+            ops.append(dist.P2POp(dist.isend, buf, peer))
+        for kind, seq, peer in sched.recvs(rank, tick):
+            buf = backend.x_buffers[seq] if kind == "x" else backend.tok_buffers[seq]
+            ops.append(dist.P2POp(dist.irecv, buf, peer))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+
+
+# ------------------------------------------------------------------ the HIP backend
+
+class HipStage:
+    """This rank's layer range on its GPU, one run state per in-flight sequence."""
+
+    def __init__(self, cfg, rank: int, world: int, local_rank: int, n_seq: int, seed: int = 0, rope=None):
+        import torch
+        import rama_amd
+        from rama_amd._lib import check, rama_run_state, rama_stage
+        self.torch, self.check = torch, check
+        self.cfg, self.rank, self.world = cfg, rank, world
+        torch.cuda.set_device(local_rank)
+        # adopt torch's current stream: RCCL ops issued through torch order against it
+        self.dev = rama_amd.Hip(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+        lo, hi = split_layers(cfg.n_layers, world, rank)
+        self.stage = rama_stage(lo, hi, int(rank == 0), int(rank == world - 1))
+        self.model = rama_amd.Model.synth(self.dev, cfg, seed, self.stage, rope)
+        device = torch.device("cuda", local_rank)
+        self.x_buffers = [torch.zeros(cfg.dim, dtype=torch.float32, device=device) for _ in range(n_seq)]
+        self.tok_buffers = [torch.zeros(1, dtype=torch.int32, device=device) for _ in range(n_seq)]
+        self.states, self._blob = [], []
+        for s in range(n_seq):
+            st = rama_run_state()
+            check(self.dev.lib.rama_state_create(self.dev.ctx, C.byref(self.model.ccfg), hi - lo, C.byref(st)))
+            self._blob.append(st.x)                       # blob base, needed to free
+            st.x = self.x_buffers[s].data_ptr()           # the hand-off buffer IS the stage's x
+            self.states.append(st)
+        self.dev.sync()
+
+    def compute(self, seq: int, pos: int, token):
+        L, st = self.dev.lib, self.states[seq]
+        if token is not None:
+            self.check(L.rama_forward_stage(self.dev.ctx, C.byref(self.model.ccfg), C.byref(self.model.weights),
+                                            C.byref(st), int(token), pos, C.byref(self.stage)), "rama_forward_stage")
+        else:
+            tok_ptr = self.tok_buffers[seq].data_ptr() if self.rank == 0 else None
+            self.check(L.rama_forward_stage_devtok(self.dev.ctx, C.byref(self.model.ccfg), C.byref(self.model.weights),
+                                                   C.byref(st), tok_ptr, pos, C.byref(self.stage)),
+                       "rama_forward_stage_devtok")
+        if self.rank == self.world - 1:
+            self.check(L.rama_argmax_dev(self.dev.ctx, st.logits, self.cfg.vocab_size,
+                                         self.tok_buffers[seq].data_ptr()), "rama_argmax_dev")
+
+    def free(self):
+        for st, blob in zip(self.states, self._blob):
+            st.x = blob
+            self.dev.lib.rama_state_free(self.dev.ctx, C.byref(st))
+        self.model.free()
+        self.dev.close()
+
+
+def run_pipeline_bench(args, cfg, rank: int, world: int, local_rank: int) -> dict:
+    """bench.py --gpus N > 1: N sequences in flight, a step = N ticks (every sequence advances
+    one token, every rank does one full-stage pass per sequence: per-GPU work is fixed -> weak)."""
+    import torch
+    import torch.distributed as dist
+    import rama_amd
+    from bench import HBM_PEAK_GBPS, PROMPT
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    if not dist.is_initialized():
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    n_seq = world
+    n_pos = args.warmup + args.steps
+    if n_pos > cfg.seq_len:
+        raise SystemExit(f"--warmup + --steps = {n_pos} exceeds seq_len {cfg.seq_len}")
+    backend = HipStage(cfg, rank, world, local_rank, n_seq, seed=0)
+    sched = Schedule(world, n_seq, n_pos)
+    prompts = [PROMPT for _ in range(n_seq)]
+    t_warm = args.warmup * n_seq                     # ticks; >= world - 1 fills the pipe
+    t_end = t_warm + args.steps * n_seq
+    assert t_warm >= world - 1, "warm-up too short to fill the pipeline"
+    run_ticks(sched, rank, backend, 0, t_warm, prompts, dist)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_ticks(sched, rank, backend, t_warm, t_end, prompts, dist)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    run_ticks(sched, rank, backend, t_end, sched.ticks, prompts, dist)   # drain, untimed
+    torch.cuda.synchronize()
+    tmax = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", local_rank))
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    tokens = args.steps * n_seq
+    tok_s = tokens / dt
+    bytes_ = rama_amd.algorithmic_bytes(cfg)
+    # dominant kernel (W1|W3 SwiGLU matvec) on this rank's stage, event-bracketed per launch
+    roofline = None
+    n_local = backend.stage.layer_end - backend.stage.layer_begin
+    if n_local > 0 and not args.no_kprof:
+        L = backend.dev.lib
+        reps = 8
+        backend.check(L.rama_kprof_enable(backend.dev.ctx, 3, reps * n_local))
+        for _ in range(reps):
+            backend.compute(0, n_pos - 1, BOS if rank == 0 else None)
+        n, tot = C.c_int(), C.c_double()
+        backend.check(L.rama_kprof_read(backend.dev.ctx, C.byref(n), C.byref(tot)))
+        if n.value:
+            avg_ms = tot.value / n.value
+            a = bytes_["w13"] / (avg_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": "gemv_swiglu (rmsnorm + W1|W3 matvec + SiLU*gate), rank 0's stage",
+                        "achieved": round(a, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": round(a / HBM_PEAK_GBPS, 4), "traffic": None,
+                        "algorithmic_bytes_per_launch": bytes_["w13"], "avg_launch_us": round(avg_ms * 1e3, 2)}
+    line = {
+        "metric": "tokens/sec decode + matvec achieved-HBM-GB/s vs roofline, llama2-7B fp32 1xMI355X",
+        "value": round(tok_s, 3), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.config} fp32 decode, layer pipeline over {world} GPUs, {n_seq} sequences in flight, greedy",
+                   "dim": cfg.dim, "hidden_dim": cfg.hidden_dim, "n_layers": cfg.n_layers, "n_heads": cfg.n_heads,
+                   "vocab_size": cfg.vocab_size, "seq_len": cfg.seq_len, "sequences_in_flight": n_seq,
+                   "parallelism": f"pp{world} (RCCL send/recv of x[dim] and the token id)", "hipgraph": False},
+        "token_level": {"algorithmic_bytes_per_token": bytes_["token"],
+                        "achieved_GBps_aggregate": round(bytes_["token"] * tok_s / 1e9, 1),
+                        "frac_of_aggregate_8TBps": round(bytes_["token"] * tok_s / 1e9 / (HBM_PEAK_GBPS * world), 4)},
+        "roofline": roofline, "cpu_baseline": None,   # cpu_baseline: rank 0 at N = 1 only (bench.py)
+    }
+    backend.free()
+    dist.barrier()
+    dist.destroy_process_group()
+    return line
