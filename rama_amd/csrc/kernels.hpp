@@ -11,7 +11,7 @@
 //    workgroup as a whole sweeps each row front to back in NW-KiB contiguous pieces
 //    (measured: +10-14 % over giving each wave a contiguous K range; tools/gemv_bench.hip).
 //    Partial sums are reduced with DPP inside a wave and through a few bytes of LDS across
-//    the waves.  Shipping geometry: NW = 8, R = 2, CH = 2 (small workgroups, high occupancy).
+//    the waves.  Shipping geometry: NW = 8, R = 4, CH = 2 (rama_api.hip DISPATCH_GEOM).
 //  * Buffer (SRSRC) addressing gives hardware bounds checking: out-of-range lanes/chunks
 //    get offset 0x80000000 and return 0 without touching memory, so ragged widths
 //    (288 = 256 + 32) and row tails need no branches in the load stream.
@@ -335,103 +335,155 @@ __global__ __launch_bounds__(kWG) void matvec_unaligned(float* o, const float* a
 }
 
 // ---------------------------------------------------------------- attention (cpu.rs:23-52)
-// One workgroup per head.  G lanes cooperate on one cached row segment (head_size floats =
-// G x float4), so a wave covers 64/G timesteps per load instruction.
+// One workgroup of 16 waves per head.  G lanes cooperate on one cached row segment (head_size
+// floats = G x float4), so a wave covers TPW = 64/G timesteps per load instruction and the
+// workgroup a tile of 16*TPW*U timesteps per round (256 at head_size 128), U = 8 independent
+// 16-byte loads in flight per lane: decode attention is latency-bound (a few MB of cache per
+// layer against 255 idle CUs), so what matters is how few dependent memory round trips the
+// chain has, not bandwidth.  Cache rows are read through a buffer descriptor: timesteps beyond
+// pos and the padding lanes of head_size 48 get offset 0x80000000 and read as 0 -- no branches
+// in the load stream.  The first V tile is requested before the softmax, which does not need
+// it, so its latency hides behind the exp/sum phase.
 struct AttnParams {
     const float* q;       // [dim]
     const float* kc;      // this layer's key cache   [seq, dim]
     const float* vc;      // this layer's value cache [seq, dim]
-    float* att;           // [n_heads, seq_len] scores / probabilities (reference scratch)
+    float* att;           // [n_heads, seq_len] probabilities (reference scratch) or NULL
     float* xb;            // [dim] output
     const Ctl* ctl;
     int pos_val;
     int dim, head_size, seq_len;
 };
 
+constexpr int kAttnWaves = 16;
+constexpr int kAttnThreads = kAttnWaves * 64;
+// LDS floats: [2 * kAttnWaves] max / sum, [kAttnWaves * G * 4] partial outputs, [seq_len] scores
+__host__ __device__ constexpr int attn_scratch_floats(int G) { return 2 * kAttnWaves + kAttnWaves * G * 4; }
+
 template <int G>
-__global__ __launch_bounds__(kWG) void attention_kernel(AttnParams p) {
-    extern __shared__ float sm[];            // [16 + 16*G] reduction scratch, then [seq_len] scores
-    float* s_red = sm;
-    float* s_att = sm + 16 + 16 * G;
+__global__ __launch_bounds__(kAttnThreads) void attention_kernel(AttnParams p) {
+    extern __shared__ float sm[];
+    float* s_max = sm;
+    float* s_sum = sm + kAttnWaves;
+    float* s_acc = sm + 2 * kAttnWaves;
+    float* s_att = sm + attn_scratch_floats(G);
+    constexpr int U = 8;
+    constexpr int TPW = 64 / G;                       // timesteps per wave-instruction
+    constexpr int TILE = kAttnWaves * TPW * U;        // timesteps per workgroup round
     const int h = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pos = p.ctl ? p.ctl->pos : p.pos_val;
     const int hs = p.head_size;
-    constexpr int TPW = 64 / G;              // timesteps per wave-instruction
     const int li = lane % G;                 // my float4 within the head segment
     const int tg = lane / G;                 // my timestep slot within the wave
     const bool lane_ok = li * 4 < hs;
-    const size_t hoff = (size_t)h * hs + (size_t)li * 4;
+    const unsigned cache_bytes = (unsigned)p.seq_len * (unsigned)p.dim * 4u;
+    const __amdgpu_buffer_rsrc_t rk = make_rsrc(p.kc, cache_bytes);
+    const __amdgpu_buffer_rsrc_t rv = make_rsrc(p.vc, cache_bytes);
+    const unsigned col = (unsigned)(h * hs + li * 4) * 4u;
+    const unsigned rowb = (unsigned)p.dim * 4u;
+    // timestep of slot u in the round starting at `base`
+    auto t_of = [&](int base, int u) { return base + (u * kAttnWaves + wave) * TPW + tg; };
+    auto off_of = [&](int t) { return (lane_ok && t <= pos) ? (unsigned)t * rowb + col : kOOB; };
 
     f4 q4 = {0.f, 0.f, 0.f, 0.f};
-    if (lane_ok) q4 = *reinterpret_cast<const f4*>(p.q + hoff);
-    const float inv_div = sqrtf((float)hs);
+    if (lane_ok) q4 = *reinterpret_cast<const f4*>(p.q + (size_t)h * hs + (size_t)li * 4);
+    const float div = sqrtf((float)hs);
 
-    // scores: att[t] = (q . k_t) / sqrt(hs)
-    for (int t0 = wave * TPW; t0 <= pos; t0 += 4 * TPW) {
-        const int t = t0 + tg;
-        float d = 0.0f;
-        if (lane_ok && t <= pos) {
-            f4 k4 = *reinterpret_cast<const f4*>(p.kc + (size_t)t * p.dim + hoff);
-            d = dot4(q4, k4, 0.0f);
+    f4 kt[U], vt[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) kt[u] = ld_c(rk, off_of(t_of(0, u)));
+#pragma unroll
+    for (int u = 0; u < U; u++) vt[u] = ld_c(rv, off_of(t_of(0, u)));     // needed only after the softmax
+    __builtin_amdgcn_sched_barrier(0);
+
+    // scores: att[t] = (q . k_t) / sqrt(hs)     (cpu.rs:34-41)
+    for (int base = 0; base <= pos; base += TILE) {
+        if (base > 0) {
+#pragma unroll
+            for (int u = 0; u < U; u++) kt[u] = ld_c(rk, off_of(t_of(base, u)));
+            __builtin_amdgcn_sched_barrier(0);
         }
-        d = row16_sum(d);
-        if (G == 32) d += __shfl_xor(d, 16);
-        if (G == 64) { d += __shfl_xor(d, 16); d += __shfl_xor(d, 32); }
-        if (li == 0 && t <= pos) s_att[t] = d / inv_div;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            float d = dot4(q4, kt[u], 0.0f);
+            d = row16_sum(d);
+            if (G == 32) d += __shfl_xor(d, 16);
+            if (G == 64) { d += __shfl_xor(d, 16); d += __shfl_xor(d, 32); }
+            const int t = t_of(base, u);
+            if (li == 0 && t <= pos) s_att[t] = d / div;
+        }
     }
     __syncthreads();
 
     // softmax over 0..=pos (cpu.rs:187-192): max, exp(a - max), sum, divide
     float mx = -INFINITY;
-    for (int t = tid; t <= pos; t += kWG) mx = fmaxf(mx, s_att[t]);
+    for (int t = tid; t <= pos; t += kAttnThreads) mx = fmaxf(mx, s_att[t]);
     mx = wave_max(mx);
-    if (lane == 0) s_red[wave] = mx;
+    if (lane == 0) s_max[wave] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    mx = s_max[0];
+#pragma unroll
+    for (int w = 1; w < kAttnWaves; w++) mx = fmaxf(mx, s_max[w]);
     float sum = 0.0f;
-    for (int t = tid; t <= pos; t += kWG) {
+    for (int t = tid; t <= pos; t += kAttnThreads) {
         float e = expf(s_att[t] - mx);
         s_att[t] = e;
         sum += e;
     }
     sum = wave_sum(sum);
-    if (lane == 0) s_red[8 + wave] = sum;
+    if (lane == 0) s_sum[wave] = sum;
     __syncthreads();
-    sum = (s_red[8] + s_red[9]) + (s_red[10] + s_red[11]);
-    for (int t = tid; t <= pos; t += kWG) {
+    {
+        float t8[kAttnWaves];
+#pragma unroll
+        for (int w = 0; w < kAttnWaves; w++) t8[w] = s_sum[w];
+#pragma unroll
+        for (int n = kAttnWaves; n > 1; n >>= 1)
+#pragma unroll
+            for (int w = 0; w < n / 2; w++) t8[w] = t8[2 * w] + t8[2 * w + 1];
+        sum = t8[0];
+    }
+    for (int t = tid; t <= pos; t += kAttnThreads) {
         float a = s_att[t] / sum;
         s_att[t] = a;
-        p.att[(size_t)h * p.seq_len + t] = a;
+        if (p.att) p.att[(size_t)h * p.seq_len + t] = a;
     }
     __syncthreads();
 
-    // xb[i] = sum_t att[t] * v_t[i]
+    // xb[i] = sum_t att[t] * v_t[i]     (cpu.rs:43-49)
     f4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int t0 = wave * TPW; t0 <= pos; t0 += 4 * TPW) {
-        const int t = t0 + tg;
-        if (lane_ok && t <= pos) {
-            f4 v4 = *reinterpret_cast<const f4*>(p.vc + (size_t)t * p.dim + hoff);
-            const float a = s_att[t];
-            acc.x = fmaf(a, v4.x, acc.x); acc.y = fmaf(a, v4.y, acc.y);
-            acc.z = fmaf(a, v4.z, acc.z); acc.w = fmaf(a, v4.w, acc.w);
+    for (int base = 0; base <= pos; base += TILE) {
+        if (base > 0) {
+#pragma unroll
+            for (int u = 0; u < U; u++) vt[u] = ld_c(rv, off_of(t_of(base, u)));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int t = t_of(base, u);
+            const float a = (t <= pos) ? s_att[t] : 0.0f;
+            acc.x = fmaf(a, vt[u].x, acc.x); acc.y = fmaf(a, vt[u].y, acc.y);
+            acc.z = fmaf(a, vt[u].z, acc.z); acc.w = fmaf(a, vt[u].w, acc.w);
         }
     }
-    // fold the TPW timestep slots of the wave, then the 4 waves
+    // fold the TPW timestep slots of the wave, then the waves (fixed pairwise tree)
 #pragma unroll
     for (int m = G; m < 64; m <<= 1) {
         acc.x += __shfl_xor(acc.x, m); acc.y += __shfl_xor(acc.y, m);
         acc.z += __shfl_xor(acc.z, m); acc.w += __shfl_xor(acc.w, m);
     }
-    if (lane < G) *reinterpret_cast<f4*>(s_red + 16 + (wave * G + lane) * 4) = acc;
+    if (lane < G) *reinterpret_cast<f4*>(s_acc + (wave * G + lane) * 4) = acc;
     __syncthreads();
     if (tid < G && tid * 4 < hs) {
-        f4 a0 = *reinterpret_cast<f4*>(s_red + 16 + (0 * G + tid) * 4);
-        f4 a1 = *reinterpret_cast<f4*>(s_red + 16 + (1 * G + tid) * 4);
-        f4 a2 = *reinterpret_cast<f4*>(s_red + 16 + (2 * G + tid) * 4);
-        f4 a3 = *reinterpret_cast<f4*>(s_red + 16 + (3 * G + tid) * 4);
-        f4 r = (a0 + a1) + (a2 + a3);
-        *reinterpret_cast<f4*>(p.xb + (size_t)h * hs + (size_t)tid * 4) = r;
+        f4 t8[kAttnWaves];
+#pragma unroll
+        for (int w = 0; w < kAttnWaves; w++) t8[w] = *reinterpret_cast<f4*>(s_acc + (w * G + tid) * 4);
+#pragma unroll
+        for (int n = kAttnWaves; n > 1; n >>= 1)
+#pragma unroll
+            for (int w = 0; w < n / 2; w++) t8[w] = t8[2 * w] + t8[2 * w + 1];
+        *reinterpret_cast<f4*>(p.xb + (size_t)h * hs + (size_t)tid * 4) = t8[0];
     }
 }
 

@@ -304,11 +304,11 @@ static int launch_attention(rama_ctx* c, float* xb, float* att, const float* q, 
     p.q = q; p.kc = kc_layer; p.vc = vc_layer; p.att = att; p.xb = xb; p.ctl = ctl; p.pos_val = pos;
     p.dim = dim; p.head_size = head_size; p.seq_len = seq_len;
     const int G = head_size <= 64 ? 16 : (head_size <= 128 ? 32 : 64);
-    size_t shm = (size_t)(16 + 16 * G + seq_len) * sizeof(float);
-    REQUIRE(shm <= 160 * 1024, RAMA_EUNSUP, "attention: seq_len too long for the single-workgroup kernel");
-    if (G == 16) hipLaunchKernelGGL((attention_kernel<16>), dim3(n_heads), dim3(kWG), shm, c->stream, p);
-    else if (G == 32) hipLaunchKernelGGL((attention_kernel<32>), dim3(n_heads), dim3(kWG), shm, c->stream, p);
-    else hipLaunchKernelGGL((attention_kernel<64>), dim3(n_heads), dim3(kWG), shm, c->stream, p);
+    size_t shm = (size_t)(attn_scratch_floats(G) + seq_len) * sizeof(float);
+    REQUIRE(shm <= 64 * 1024, RAMA_EUNSUP, "attention: seq_len too long for the single-workgroup kernel");
+    if (G == 16) hipLaunchKernelGGL((attention_kernel<16>), dim3(n_heads), dim3(kAttnThreads), shm, c->stream, p);
+    else if (G == 32) hipLaunchKernelGGL((attention_kernel<32>), dim3(n_heads), dim3(kAttnThreads), shm, c->stream, p);
+    else hipLaunchKernelGGL((attention_kernel<64>), dim3(n_heads), dim3(kAttnThreads), shm, c->stream, p);
     LAUNCHCHK();
     return 0;
 }

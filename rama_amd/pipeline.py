@@ -115,15 +115,22 @@ def run_ticks(sched: Schedule, rank: int, backend, tick_from: int, tick_to: int,
 class HipStage:
     """This rank's layer range on its GPU, one run state per in-flight sequence."""
 
-    def __init__(self, cfg, rank: int, world: int, local_rank: int, n_seq: int, seed: int = 0, rope=None):
+    def __init__(self, cfg, rank: int, world: int, local_rank: int, n_seq: int, seed: int = 0, rope=None,
+                 torch_stream=None):
         import torch
         import rama_amd
         from rama_amd._lib import check, rama_run_state, rama_stage
         self.torch, self.check = torch, check
         self.cfg, self.rank, self.world = cfg, rank, world
         torch.cuda.set_device(local_rank)
-        # adopt torch's current stream: RCCL ops issued through torch order against it
-        self.dev = rama_amd.Hip(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+        # Kernels, tensor copies and the RCCL ops torch issues must share ONE stream order.  The
+        # legacy default stream has handle 0, which rama_ctx_create reads as "make your own", so
+        # run on an explicit torch stream, make it current (ProcessGroupNCCL orders its p2p ops
+        # against the current stream) and let the context adopt its handle.
+        self.stream = torch_stream if torch_stream is not None else torch.cuda.Stream(torch.device("cuda", local_rank))
+        torch.cuda.set_stream(self.stream)
+        assert self.stream.cuda_stream != 0
+        self.dev = rama_amd.Hip(local_rank, stream=self.stream.cuda_stream)
         lo, hi = split_layers(cfg.n_layers, world, rank)
         self.stage = rama_stage(lo, hi, int(rank == 0), int(rank == world - 1))
         self.model = rama_amd.Model.synth(self.dev, cfg, seed, self.stage, rope)

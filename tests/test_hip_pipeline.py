@@ -46,7 +46,9 @@ def test_hipstage_pipeline_tokens(name, world, n_seq):
     n_pos = min(cfg.seq_len, 12)
     toks = g["tokens"].tolist()
     prompts = [toks[1 + s:1 + s + (s % 3)] for s in range(n_seq)]
-    stages = [HipStage(rcfg, r, world, 0, n_seq, seed=int(g["seed"]), rope=rope) for r in range(world)]
+    stream = torch.cuda.Stream()      # all stages of this one-process rehearsal share a stream
+    stages = [HipStage(rcfg, r, world, 0, n_seq, seed=int(g["seed"]), rope=rope, torch_stream=stream)
+              for r in range(world)]
     produced = drive(stages, Schedule(world, n_seq, n_pos), prompts)
     torch.cuda.synchronize()
     for s in range(n_seq):
