@@ -50,6 +50,22 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(kernel_substr):
+    """HBM read bytes per launch of the dominant kernel from the committed PMC pass (a run of
+    its own: rocprofv3 --pmc FETCH_SIZE cannot ride along with a timed run), already carrying
+    the guide's gfx950 correction (FETCH_SIZE counts 128-B requests at 64 B: x2)."""
+    import glob
+    files = sorted(glob.glob(str(REPO / "profiles" / "r*_bench_7b_pmc_fetch_size.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        rows = json.load(f)["rows"]
+    for r in rows:
+        if kernel_substr in r["kernel"] and r["counter"] == "FETCH_SIZE":
+            return r["hbm_read_bytes_corrected"], f"profiles/{Path(files[-1]).name}"
+    return None, None
+
+
 def cpu_baseline(shape_name, n_tokens, n_layers_sample):
     """Time the oracle (reference-algorithm CPU restatement, OpenMP over rows/heads like the
     reference's rayon) on a bounded sample of the same workload: `n_layers_sample` of the L
@@ -162,9 +178,11 @@ def main():
                 kernels[k] = {"avg_us": round(avg_ms * 1e3, 2), "launches": n,
                               "GBps": round(b / (avg_ms * 1e-3) / 1e9, 1) if b else None}
             a = kernels["w13"]["GBps"]
-            roofline = {"bound": "hbm", "kernel": "gemv_swiglu<2,4> (rmsnorm + W1|W3 matvec + SiLU*gate)",
+            traffic, traffic_src = pmc_traffic("gemv_swiglu") if args.config == "llama2-7B" else (None, None)
+            roofline = {"bound": "hbm", "kernel": "gemv_swiglu<2,2,8> (rmsnorm + W1|W3 matvec + SiLU*gate)",
                         "achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBPS, 4),
-                        "traffic": None, "algorithmic_bytes_per_launch": bytes_["w13"],
+                        "traffic": traffic, "traffic_source": traffic_src,
+                        "algorithmic_bytes_per_launch": bytes_["w13"],
                         "avg_launch_us": kernels["w13"]["avg_us"]}
 
     cpu = None

@@ -1,0 +1,289 @@
+// engine.hpp -- C++17 host side above the C ABI (include/rama_hip.h), mirroring the reference's
+// engine crate for the decode path, name for name:
+//   engine/src/transformer/mod.rs    Storage / View / MutView / range_from / Config / generate
+//   engine/src/transformer/state.rs  RunState(+View), TransformerWeights(+View)
+//   engine/src/transformer/hbm.rs    allocate / from_state / from_weight / from_gpu_ws
+//   engine/src/device/device.rs      trait Device<T>            -> struct Device (abstract)
+//   engine/src/device/gpu.rs         impl Device for GPU        -> struct Hip
+//   engine/src/transformer/infer.rs  forward()
+// The reference is Rust; no Rust toolchain exists in this image, so the host is C++ where the
+// reference is compiled code (INTEGRATION.md has the Rust binding).  Every driver error aborts,
+// like the reference's unwrap().  No CPU fallback: every op is a HIP kernel behind the ABI.
+#pragma once
+#include "../../../include/rama_hip.h"
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <string>
+#include <vector>
+
+namespace rama_host {
+
+[[noreturn]] inline void panic(const std::string& what) {
+    std::fprintf(stderr, "panic: %s: %s\n", what.c_str(), rama_last_error());
+    std::abort();
+}
+inline void ck(int rc, const char* what) { if (rc != 0) panic(what); }
+
+// ---- mod.rs:128-167
+struct Config {
+    size_t dim = 0, hidden_dim = 0, n_layers = 0, n_heads = 0, n_kv_heads = 0, vocab_size = 0, seq_len = 0;
+    bool shared_weight = false;
+
+    static Config from_file(std::ifstream& f) {      // 7 x i32; vocab_size > 0 => shared classifier
+        int32_t h[7];
+        f.read(reinterpret_cast<char*>(h), sizeof h);
+        if (!f) panic("error reading file");         // utils/read.rs:27
+        Config c;
+        c.dim = h[0]; c.hidden_dim = h[1]; c.n_layers = h[2]; c.n_heads = h[3]; c.n_kv_heads = h[4];
+        c.shared_weight = h[5] > 0;
+        c.vocab_size = (size_t)(h[5] > 0 ? h[5] : -h[5]);
+        c.seq_len = h[6];
+        return c;
+    }
+    rama_config c() const {
+        return rama_config{(int32_t)dim, (int32_t)hidden_dim, (int32_t)n_layers, (int32_t)n_heads, (int32_t)n_kv_heads,
+                           (int32_t)vocab_size, (int32_t)seq_len, (int32_t)shared_weight};
+    }
+};
+
+// ---- Storage bound to device memory (hbm.rs:6-10 `impl Storage for CudaSlice<f32>`)
+struct HipSlice {
+    rama_ctx* ctx = nullptr;
+    float* ptr = nullptr;
+    size_t len = 0;
+    HipSlice() = default;
+    HipSlice(rama_ctx* c, float* p, size_t n) : ctx(c), ptr(p), len(n) {}
+    HipSlice(const HipSlice&) = delete;
+    HipSlice& operator=(const HipSlice&) = delete;
+    HipSlice(HipSlice&& o) noexcept : ctx(o.ctx), ptr(o.ptr), len(o.len) { o.ptr = nullptr; }
+    HipSlice& operator=(HipSlice&& o) noexcept { std::swap(ctx, o.ctx); std::swap(ptr, o.ptr); std::swap(len, o.len); return *this; }
+    ~HipSlice() { if (ptr) rama_free(ctx, ptr); }
+    size_t length() const { return len; }
+};
+
+struct Range { size_t start, end; };
+constexpr size_t OPEN = (size_t)-1;
+// mod.rs:26-41: an open end means the STORAGE length
+inline Range range_from(size_t start, size_t end, size_t max_len) { return Range{start, end == OPEN ? max_len : end}; }
+
+// ---- mod.rs:16-19,43-59: `range` is ABSOLUTE in the backing storage
+struct View {
+    const HipSlice* data;
+    Range range;
+    explicit View(const HipSlice& s) : data(&s), range{0, s.length()} {}
+    View(const HipSlice* d, Range r) : data(d), range(r) {}
+    View slice(size_t start, size_t end = OPEN) const { return View(data, range_from(start, end, data->length())); }
+    const float* ptr() const { return data->ptr + range.start; }       // cudaview(), gpu.rs:51-69
+};
+// ---- mod.rs:21-24,65-96
+struct MutView {
+    HipSlice* data;
+    Range range;
+    explicit MutView(HipSlice& s) : data(&s), range{0, s.length()} {}
+    MutView(HipSlice* d, Range r) : data(d), range(r) {}
+    View as_view() const { return View(data, range); }
+    View slice(size_t start, size_t end = OPEN) const { return View(data, range_from(start, end, data->length())); }
+    MutView mut_slice(size_t start, size_t end = OPEN) { return MutView(data, range_from(start, end, data->length())); }
+    float* ptr() const { return data->ptr + range.start; }
+};
+
+// ---- state.rs:3-17 / ram.rs:7-23
+struct RunState {
+    HipSlice x, xb, xb2, hb, hb2, q, k, v, att, logits, key_cache, value_cache;
+};
+struct RunStateView {      // state.rs:19-51
+    MutView x, xb, xb2, hb, hb2, q, k, v, att, logits, key_cache, value_cache;
+    static RunStateView from_rs(RunState& rs) {
+        return RunStateView{MutView(rs.x), MutView(rs.xb), MutView(rs.xb2), MutView(rs.hb), MutView(rs.hb2), MutView(rs.q),
+                            MutView(rs.k), MutView(rs.v), MutView(rs.att), MutView(rs.logits), MutView(rs.key_cache),
+                            MutView(rs.value_cache)};
+    }
+    rama_run_state c() const {
+        return rama_run_state{x.ptr(), xb.ptr(), xb2.ptr(), hb.ptr(), hb2.ptr(), q.ptr(), k.ptr(), v.ptr(), att.ptr(),
+                              logits.ptr(), key_cache.ptr(), value_cache.ptr()};
+    }
+};
+
+// ---- state.rs:53-74
+struct TransformerWeights {
+    HipSlice token_embedding_table, rms_att_weight, rms_ffn_weight, wq, wk, wv, wo, w1, w2, w3, rms_final_weight,
+        freq_cis_real, freq_cis_imag, wcls;
+    bool wcls_exists = false;
+};
+struct TransformerWeightsView {   // state.rs:76-122 / hbm.rs:95-120
+    View token_embedding_table, rms_att_weight, rms_ffn_weight, wq, wk, wv, wo, w1, w2, w3, rms_final_weight,
+        freq_cis_real, freq_cis_imag, wcls;
+    bool wcls_exists;
+    static TransformerWeightsView from_gpu_ws(const TransformerWeights& ws) {
+        return TransformerWeightsView{View(ws.token_embedding_table), View(ws.rms_att_weight), View(ws.rms_ffn_weight),
+                                      View(ws.wq), View(ws.wk), View(ws.wv), View(ws.wo), View(ws.w1), View(ws.w2), View(ws.w3),
+                                      View(ws.rms_final_weight), View(ws.freq_cis_real), View(ws.freq_cis_imag),
+                                      ws.wcls_exists ? View(ws.wcls) : View(ws.token_embedding_table),   // state.rs:111-117
+                                      ws.wcls_exists};
+    }
+    rama_weights c() const {
+        return rama_weights{token_embedding_table.ptr(), rms_att_weight.ptr(), rms_ffn_weight.ptr(), wq.ptr(), wk.ptr(),
+                            wv.ptr(), wo.ptr(), w1.ptr(), w2.ptr(), w3.ptr(), rms_final_weight.ptr(), freq_cis_real.ptr(),
+                            freq_cis_imag.ptr(), wcls.ptr()};
+    }
+};
+
+// ---- device.rs:3-24
+struct Device {
+    virtual ~Device() = default;
+    virtual void array_add(MutView& target, const View& source, size_t n) const = 0;
+    virtual void array_mult(MutView& target, const View& source, size_t n) const = 0;
+    virtual void sinu(MutView& o, size_t n) const = 0;
+    virtual void multi_head_attention(RunStateView& rsv, const Config& cfg, size_t layer, size_t pos) const = 0;
+    virtual void copy_from_slice(MutView& target, const View& source, size_t n) const = 0;
+    virtual void rmsnorm(MutView& o, const View& x, const View& weight, size_t n) const = 0;
+    virtual void apply_position(MutView& q, MutView& k, const View& pos_real, const View& pos_img, size_t head_size) const = 0;
+    virtual void matmul(MutView& o, const View& a, const View& b, size_t width, size_t o_rows, size_t o_cols) const = 0;
+    virtual void softmax(MutView& x, size_t n) const = 0;
+    virtual size_t sample(const Config& cfg, RunStateView& rsv, float temperature, float topp) const = 0;
+    virtual void to_cpu(const RunStateView& state, std::vector<std::vector<float>>& cpu_state) const = 0;
+};
+
+// ---- the MI355X backend (replaces gpu.rs's GPU)
+struct Hip final : Device {
+    rama_ctx* ctx = nullptr;
+    // The reference re-seeds ChaCha20 with 100 on every sample() call (cpu.rs:161-162), so its
+    // "random" draw is one constant.  Value derived from the published rand_core/ChaCha20
+    // algorithms; provisional until checked against a Rust build.
+    float topp_draw = 0.2721174359321594f;
+
+    explicit Hip(int device = 0) { ck(rama_ctx_create(device, nullptr, &ctx), "rama_ctx_create"); }   // GPU::new, gpu.rs:213-234
+    ~Hip() override { rama_ctx_destroy(ctx); }
+
+    HipSlice allocate(const std::vector<float>& data) const {     // hbm.rs:14-16 (htod_sync_copy)
+        float* p = nullptr;
+        ck(rama_upload_f32(ctx, data.data(), data.size(), &p), "rama_upload_f32");
+        return HipSlice(ctx, p, data.size());
+    }
+    HipSlice zeros(size_t n) const {
+        float* p = nullptr;
+        ck(rama_alloc_f32(ctx, n, &p), "rama_alloc_f32");
+        return HipSlice(ctx, p, n);
+    }
+    std::vector<float> download(const HipSlice& s) const {
+        std::vector<float> h(s.len);
+        ck(rama_download_f32(ctx, s.ptr, s.len, h.data()), "rama_download_f32");
+        return h;
+    }
+
+    void array_add(MutView& t, const View& s, size_t n) const override { ck(rama_array_add(ctx, t.ptr(), s.ptr(), n), "array_add"); }
+    void array_mult(MutView& t, const View& s, size_t n) const override { ck(rama_array_mult(ctx, t.ptr(), s.ptr(), n), "array_mult"); }
+    void sinu(MutView& o, size_t n) const override { ck(rama_sinu(ctx, o.ptr(), n), "sinu"); }
+    void multi_head_attention(RunStateView& rsv, const Config& cfg, size_t layer, size_t pos) const override {
+        ck(rama_multi_head_attention(ctx, rsv.xb.ptr(), rsv.att.ptr(), rsv.q.ptr(), rsv.key_cache.ptr(), rsv.value_cache.ptr(),
+                                     (int)layer, (int)cfg.dim, (int)pos, (int)(cfg.dim / cfg.n_heads), (int)cfg.seq_len,
+                                     (int)cfg.n_heads), "multi_head_attention");
+    }
+    void copy_from_slice(MutView& t, const View& s, size_t n) const override { ck(rama_copy_from_slice(ctx, t.ptr(), s.ptr(), n), "copy_from_slice"); }
+    void rmsnorm(MutView& o, const View& x, const View& w, size_t n) const override { ck(rama_rmsnorm(ctx, o.ptr(), x.ptr(), w.ptr(), n), "rmsnorm"); }
+    void apply_position(MutView& q, MutView& k, const View& pr, const View& pi, size_t head_size) const override {
+        ck(rama_apply_position(ctx, q.ptr(), k.ptr(), pr.ptr(), pi.ptr(), head_size), "apply_position");
+    }
+    void matmul(MutView& o, const View& a, const View& b, size_t width, size_t o_rows, size_t o_cols) const override {
+        ck(rama_matmul(ctx, o.ptr(), a.ptr(), b.ptr(), width, o_rows, o_cols), "matmul");
+    }
+    void softmax(MutView& x, size_t n) const override { ck(rama_softmax(ctx, x.ptr(), n), "softmax"); }
+    size_t sample(const Config& cfg, RunStateView& rsv, float temperature, float topp) const override {
+        int32_t next = 0;
+        if (temperature == 0.0f) ck(rama_sample_argmax(ctx, rsv.logits.ptr(), cfg.vocab_size, &next), "sample");
+        else ck(rama_sample_topp(ctx, rsv.logits.ptr(), cfg.vocab_size, temperature, topp, topp_draw, &next), "sample");
+        return (size_t)next;
+    }
+    void to_cpu(const RunStateView& s, std::vector<std::vector<float>>& out) const override {   // gpu.rs:196-209
+        const MutView* f[12] = {&s.x, &s.xb, &s.xb2, &s.hb, &s.hb2, &s.q, &s.k, &s.v, &s.att, &s.logits, &s.key_cache, &s.value_cache};
+        out.clear();
+        for (auto* m : f) out.push_back(download(*m->data));
+    }
+};
+
+// ---- ram.rs:7-23 + hbm.rs:19-34 (zero-initialised device state)
+inline RunState run_state_from_config(const Config& cfg, const Hip& dev) {
+    const size_t kv_dim = cfg.dim * cfg.n_kv_heads / cfg.n_heads;
+    RunState s;
+    s.x = dev.zeros(cfg.dim); s.xb = dev.zeros(cfg.dim); s.xb2 = dev.zeros(cfg.dim);
+    s.hb = dev.zeros(cfg.hidden_dim); s.hb2 = dev.zeros(cfg.hidden_dim);
+    s.q = dev.zeros(cfg.dim); s.k = dev.zeros(cfg.dim); s.v = dev.zeros(cfg.dim);
+    s.att = dev.zeros(cfg.n_heads * cfg.seq_len); s.logits = dev.zeros(cfg.vocab_size);
+    s.key_cache = dev.zeros(cfg.n_layers * cfg.seq_len * kv_dim);
+    s.value_cache = dev.zeros(cfg.n_layers * cfg.seq_len * kv_dim);
+    return s;
+}
+
+// ---- ram.rs:27-52 + hbm.rs:55-90: read each tensor (bulk read, not 4 bytes at a time) and upload it
+inline TransformerWeights weights_from_file(std::ifstream& f, const Config& c, const Hip& dev) {
+    const size_t hs = c.dim / c.n_heads;
+    auto rd = [&](size_t n) {
+        std::vector<float> v(n);
+        f.read(reinterpret_cast<char*>(v.data()), (std::streamsize)(n * sizeof(float)));
+        if (!f) panic("error reading file");
+        return dev.allocate(v);
+    };
+    TransformerWeights w;
+    w.token_embedding_table = rd(c.vocab_size * c.dim);
+    w.rms_att_weight = rd(c.n_layers * c.dim);
+    w.wq = rd(c.n_layers * c.dim * c.dim); w.wk = rd(c.n_layers * c.dim * c.dim);
+    w.wv = rd(c.n_layers * c.dim * c.dim); w.wo = rd(c.n_layers * c.dim * c.dim);
+    w.rms_ffn_weight = rd(c.n_layers * c.dim);
+    w.w1 = rd(c.n_layers * c.dim * c.hidden_dim); w.w2 = rd(c.n_layers * c.dim * c.hidden_dim);
+    w.w3 = rd(c.n_layers * c.dim * c.hidden_dim);
+    w.rms_final_weight = rd(c.dim);
+    w.freq_cis_real = rd(c.seq_len * hs / 2); w.freq_cis_imag = rd(c.seq_len * hs / 2);
+    w.wcls_exists = !c.shared_weight;
+    w.wcls = c.shared_weight ? dev.allocate(std::vector<float>{1.0f}) : rd(c.vocab_size * c.dim);   // ram.rs:44-48
+    return w;
+}
+
+// ---- infer.rs:8-53, op for op through the Device trait (the Wq product of :20-21 issued once)
+inline void forward(const Config& cfg, const TransformerWeightsView& wv, RunStateView& rsv, size_t token, size_t pos, const Device& device) {
+    const size_t dim = cfg.dim, hidden_dim = cfg.hidden_dim, head_size = dim / cfg.n_heads;
+    device.copy_from_slice(rsv.x, wv.token_embedding_table.slice(token * dim, (token + 1) * dim), dim);
+    const View pos_real = wv.freq_cis_real.slice(pos * (head_size / 2));
+    const View pos_img = wv.freq_cis_imag.slice(pos * (head_size / 2));
+    for (size_t layer = 0; layer < cfg.n_layers; layer++) {
+        device.rmsnorm(rsv.xb, rsv.x.as_view(), wv.rms_att_weight.slice(layer * dim), dim);
+        device.matmul(rsv.q, wv.wq.slice(layer * dim * dim), rsv.xb.as_view(), dim, dim, 1);
+        device.matmul(rsv.k, wv.wk.slice(layer * dim * dim), rsv.xb.as_view(), dim, dim, 1);
+        device.matmul(rsv.v, wv.wv.slice(layer * dim * dim), rsv.xb.as_view(), dim, dim, 1);
+        for (size_t h = 0; h < cfg.n_heads; h++) {
+            MutView q = rsv.q.mut_slice(h * head_size);
+            MutView k = rsv.k.mut_slice(h * head_size);
+            device.apply_position(q, k, pos_real, pos_img, head_size);
+        }
+        const size_t lo = layer * cfg.seq_len * dim;
+        MutView kc = rsv.key_cache.mut_slice(lo + pos * dim, lo + (pos + 1) * dim);
+        MutView vc = rsv.value_cache.mut_slice(lo + pos * dim, lo + (pos + 1) * dim);
+        device.copy_from_slice(kc, rsv.k.as_view(), dim);
+        device.copy_from_slice(vc, rsv.v.as_view(), dim);
+        device.multi_head_attention(rsv, cfg, layer, pos);
+        device.matmul(rsv.xb2, wv.wo.slice(layer * dim * dim), rsv.xb.as_view(), dim, dim, 1);
+        device.array_add(rsv.x, rsv.xb2.as_view(), dim);
+        device.rmsnorm(rsv.xb, rsv.x.as_view(), wv.rms_ffn_weight.slice(layer * dim), dim);
+        device.matmul(rsv.hb, wv.w1.slice(layer * hidden_dim * dim), rsv.xb.as_view(), dim, hidden_dim, 1);
+        device.matmul(rsv.hb2, wv.w3.slice(layer * hidden_dim * dim), rsv.xb.as_view(), dim, hidden_dim, 1);
+        device.sinu(rsv.hb, hidden_dim);
+        device.array_mult(rsv.hb, rsv.hb2.as_view(), hidden_dim);
+        device.matmul(rsv.xb, wv.w2.slice(layer * dim * hidden_dim), rsv.hb.as_view(), hidden_dim, dim, 1);
+        device.array_add(rsv.x, rsv.xb.as_view(), dim);
+    }
+    device.copy_from_slice(rsv.xb, rsv.x.as_view(), dim);
+    device.rmsnorm(rsv.x, rsv.xb.as_view(), wv.rms_final_weight, dim);
+    device.matmul(rsv.logits, wv.wcls, rsv.x.as_view(), dim, cfg.vocab_size, 1);
+}
+
+// same contract as forward() (logits, caches, residual x) through the fused entry
+inline void forward_fused(const Config& cfg, const TransformerWeightsView& wv, RunStateView& rsv, size_t token, size_t pos, const Hip& device) {
+    rama_config c = cfg.c();
+    rama_weights w = wv.c();
+    rama_run_state s = rsv.c();
+    ck(rama_forward(device.ctx, &c, &w, &s, (int)token, (int)pos), "rama_forward");
+}
+
+}  // namespace rama_host

@@ -630,7 +630,9 @@ int rama_kprof_enable(rama_ctx* c, int kernel_id, int max_records) {
     REQUIRE(c && kernel_id >= 0 && kernel_id < RAMA_K_COUNT && max_records > 0, RAMA_EINVAL, "kprof_enable: bad argument");
     KProf& k = c->kp;
     while ((int)k.ev.size() < 2 * max_records) {
-        hipEvent_t e; HIPCHK(hipEventCreate(&e)); k.ev.push_back(e);
+        // no system-scope fence per record: the brackets sit between dependent kernels and a
+        // host-visible flush at each one would inflate the very interval being measured
+        hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableSystemFence)); k.ev.push_back(e);
     }
     k.kernel_id = kernel_id; k.max_records = max_records; k.used = 0;
     return 0;

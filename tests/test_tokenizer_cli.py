@@ -1,0 +1,139 @@
+"""Host-side string code: the C++ tokenizer (rama_amd/csrc/host/tokenizer.hpp)
+against the Python restatement of bpe.rs (oracle/tokenizer.py) on synthetic vocabularies (CPU),
+and -- marked gpu -- the engine CLI's printed text against oracle generate() + decode."""
+import random
+import struct
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from oracle.tokenizer import Tokenizer, decode
+from tests.helpers import GOLDEN, load_case
+
+REPO = Path(__file__).resolve().parent.parent
+TOOL = REPO / "rama_amd" / "bin" / "tokenizer_tool"
+ENGINE = REPO / "rama_amd" / "bin" / "engine"
+REF_TOK = Path("/root/reference/engine/tokenizer.bin")
+
+
+def write_tokenizer(path, entries):
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", max(len(s.encode()) for s, _ in entries)))
+        for s, score in entries:
+            b = s.encode()
+            f.write(struct.pack("<fi", score, len(b)))
+            f.write(b)
+
+
+def synthetic_vocab(n, seed):
+    """<unk>, <s>, </s>, byte tokens, single chars (incl. a 2-byte one), then scored merges"""
+    rng = random.Random(seed)
+    entries = [("<unk>", 0.0), ("<s>", 0.0), ("</s>", 0.0), ("<0x0A>", 0.0), ("<0xE9>", 0.0)]
+    chars = list("abcdefgh ") + ["é"]
+    entries += [(c, -1.0 - i) for i, c in enumerate(chars)]
+    seen = {s for s, _ in entries}
+    pool = [c for c in chars]
+    while len(entries) < n:
+        a, b = rng.choice(pool), rng.choice(pool)
+        m = a + b
+        if m in seen or len(m) > 6:
+            continue
+        seen.add(m)
+        pool.append(m)
+        entries.append((m, rng.uniform(-10, 0)))
+    return entries
+
+
+def run_tool(*args):
+    return subprocess.run([str(TOOL), *map(str, args)], capture_output=True, text=True)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_cpp_tokenizer_matches_restatement(tmp_path, seed):
+    entries = synthetic_vocab(64, seed)
+    p = tmp_path / "tok.bin"
+    write_tokenizer(p, entries)
+    tok = Tokenizer(p, len(entries))
+    rng = random.Random(100 + seed)
+    for _ in range(60):
+        text = "".join(rng.choice("abcdefgh é") for _ in range(rng.randint(1, 24)))
+        if not text.strip():
+            continue
+        r = run_tool(p, len(entries), "encode", text)
+        assert r.returncode == 0, r.stderr
+        assert [int(v) for v in r.stdout.split()] == tok.encode(text), text
+    ids = list(range(3, len(entries)))
+    r = run_tool(p, len(entries), "decode", *ids)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.rstrip("\n") == "".join(decode(tok.vocab[i]) for i in ids).rstrip("\n")
+
+
+def test_tokenizer_edge_cases(tmp_path):
+    entries = synthetic_vocab(40, 3)
+    p = tmp_path / "tok.bin"
+    write_tokenizer(p, entries)
+    tok = Tokenizer(p, len(entries))
+    assert run_tool(p, len(entries), "encode", "  abc\n").stdout.split() == [str(v) for v in tok.encode("  abc\n")]
+    assert tok.encode("a\nb") == tok.encode("ab")                       # bpe.rs:54 skips '\n'
+    assert run_tool(p, len(entries), "encode", "xyz").returncode == 101   # unknown char: reference panics (bpe.rs:55)
+    with pytest.raises(KeyError):
+        tok.encode("xyz")
+    assert run_tool(p, len(entries), "encode", "   ").returncode == 101   # trims to nothing: bpe.rs:66 underflow
+    assert run_tool(p, len(entries), "decode", 1).stdout == "\n"          # "<s>" -> ""
+    assert run_tool(p, len(entries), "decode", 0).returncode == 101       # "<unk>": from_str_radix panics
+    assert run_tool(p, len(entries), "decode", 4).stdout.encode() == "é\n".encode()   # <0xE9> -> U+00E9
+    assert run_tool(tmp_path / "missing.bin", 4, "encode", "a").returncode == 101
+
+
+@pytest.mark.skipif(not REF_TOK.exists(), reason="reference tokenizer.bin only exists in the build container")
+def test_reference_tokenizer_prompt_ids():
+    """'once upon a time' -> [10646, 2501, 263, 931] (no sentencepiece dummy prefix)"""
+    assert run_tool(REF_TOK, 32000, "encode", "once upon a time").stdout.split() == ["10646", "2501", "263", "931"]
+    assert Tokenizer(REF_TOK, 32000).encode("once upon a time") == [10646, 2501, 263, 931]
+
+
+# ------------------------------------------------------------------ the CLI on the GPU
+
+def cli_vocab(vocab_size):
+    base = [("<unk>", 0.0), ("<s>", 0.0), ("</s>", 0.0)]
+    chars = "abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789 .,!?"
+    return (base + [(c, -float(i)) for i, c in enumerate(chars)])[:vocab_size]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", ["fused", "ops", "chained"])
+def test_engine_cli_text_parity(tmp_path, path):
+    name = "ckpt_untied"
+    cfg, w, g = load_case(name)
+    entries = cli_vocab(cfg.vocab_size)
+    assert len(entries) == cfg.vocab_size
+    tokp = tmp_path / "tok.bin"
+    write_tokenizer(tokp, entries)
+    tok = Tokenizer(tokp, cfg.vocab_size)
+    prompt, steps = "hi b", 12
+    want_ids = O.Oracle(cfg, w).generate_greedy(tok.encode(prompt), steps)
+    # "<unk>" would make decode panic like the reference; the expected text must not contain it
+    want_text = "".join(decode(tok.vocab[i]) if i != 0 else None for i in want_ids) if 0 not in want_ids else None
+    import os
+    env = dict(os.environ, RAMA_PATH=path)
+    r = subprocess.run([str(ENGINE), "-m", str(GOLDEN / f"{name}.bin"), "-t", str(tokp), "-p", prompt, "-s", str(steps), "-r", "0"],
+                       capture_output=True, text=True, env=env, timeout=120)
+    if want_text is None:
+        assert r.returncode == 101
+        return
+    assert r.returncode == 0, r.stderr
+    body, _, tail = r.stdout.partition("\n--------------------------------\n")
+    assert body == want_text, (body, want_text)
+    assert tail.startswith("elapsed: ") and "avg tok/s: " in tail
+
+
+@pytest.mark.gpu
+def test_engine_cli_rejects_too_many_steps(tmp_path):
+    tokp = tmp_path / "tok.bin"
+    write_tokenizer(tokp, cli_vocab(64))
+    r = subprocess.run([str(ENGINE), "-m", str(GOLDEN / "ckpt_tied.bin"), "-t", str(tokp), "-s", "17", "-r", "0"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "seq_len" in r.stderr
