@@ -99,7 +99,7 @@ def test_reference_tokenizer_prompt_ids():
 
 def cli_vocab(vocab_size):
     base = [("<unk>", 0.0), ("<s>", 0.0), ("</s>", 0.0)]
-    chars = "abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789 .,!?"
+    chars = " .,!?abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789"
     return (base + [(c, -float(i)) for i, c in enumerate(chars)])[:vocab_size]
 
 
