@@ -182,7 +182,11 @@ int  rama_decode_tokens(rama_ctx *ctx, int32_t *out_tokens_host, int max_tokens,
 int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
 /* Performance knobs (results are unaffected up to fp32 summation order).  Keys:
  *   "geom" = 0..3 : matvec workgroup geometry (rows per workgroup, waves, chunks per step);
- *                   0 is the shipping choice, see rama_api.hip DISPATCH_GEOM */
+ *                   3 is the shipping choice, see rama_api.hip DISPATCH_GEOM
+ *   "persist" = 0|1 : 1 runs each chained decode step as ONE persistent launch (persist.hpp:
+ *                   one resident workgroup per CU, phases separated by a counter barrier hidden
+ *                   behind weight prefetch).  Same results; measured slower than the launch
+ *                   path in round 1 (170 vs 235 tok/s at llama2-7B), so it is off by default. */
 int  rama_set_tuning(rama_ctx *ctx, const char *key, int value);
 
 /* ---------------------------------------------------------------- measurement

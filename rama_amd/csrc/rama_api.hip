@@ -2,6 +2,7 @@
 // ops, the fused decode path, measurement.  Kernels are in kernels.hpp.
 #include "../../include/rama_hip.h"
 #include "kernels.hpp"
+#include "persist.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -67,6 +68,10 @@ struct rama_ctx {
     KProf kp;
     int cu_count = 0;
     int tune_geom = 3;
+    int tune_persist = 0;                  // 1: decode steps run as one persistent launch (persist.hpp)
+    unsigned long long* pbar = nullptr;    // device: [0] barrier counter, [1] error word, [2] epoch
+    size_t persist_lds = 0;
+    const void* persist_fn = nullptr;
     const float* embedded_x = nullptr;   // run-state x that already holds emb[ctl.token] (chained decode)
 };
 
@@ -95,6 +100,8 @@ int rama_ctx_create(int device, void* hip_stream, rama_ctx** out) {
     c->forced_cap = 1 << 16;
     HIPCHK(hipMalloc(&c->forced, sizeof(int) * c->forced_cap));
     HIPCHK(hipMalloc(&c->argmax_result, sizeof(int)));
+    HIPCHK(hipMalloc(&c->pbar, 4 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(c->pbar, 0, 4 * sizeof(unsigned long long)));
     HIPCHK(hipHostMalloc(&c->pinned_int, sizeof(int) * 4));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
@@ -115,7 +122,7 @@ int rama_ctx_destroy(rama_ctx* c) {
     hipStreamSynchronize(c->stream);
     drop_graph(c);
     for (auto e : c->kp.ev) hipEventDestroy(e);
-    hipFree(c->ctl); hipFree(c->out); hipFree(c->forced); hipFree(c->argmax_result);
+    hipFree(c->ctl); hipFree(c->out); hipFree(c->forced); hipFree(c->argmax_result); hipFree(c->pbar);
     hipHostFree(c->pinned_int);
     hipEventDestroy(c->t0); hipEventDestroy(c->t1);
     if (c->own_stream) hipStreamDestroy(c->stream);
@@ -515,7 +522,41 @@ int rama_decode_begin(rama_ctx* c, int token, int pos, const int32_t* forced_hos
 
 // One chained step: layers + classifier + (argmax, cursor advance, next token's embedding
 // gather).  x already holds emb[token] on entry (rama_decode_steps primes it once).
+// the same step as ONE persistent launch (persist.hpp): one resident workgroup per CU
+static int enqueue_decode_step_persistent(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s) {
+    PersistParams p{};
+    p.dim = cfg->dim; p.hidden = cfg->hidden_dim; p.n_heads = cfg->n_heads; p.vocab = cfg->vocab_size; p.seq_len = cfg->seq_len;
+    p.n_layers = cfg->n_layers; p.do_cls = 1; p.do_argmax = 1;
+    p.emb = w->token_embedding_table; p.rms_att = w->rms_att_weight; p.rms_ffn = w->rms_ffn_weight;
+    p.wq = w->wq; p.wk = w->wk; p.wv = w->wv; p.wo = w->wo; p.w1 = w->w1; p.w2 = w->w2; p.w3 = w->w3;
+    p.rms_final = w->rms_final_weight; p.fr = w->freq_cis_real; p.fi = w->freq_cis_imag; p.wcls = w->wcls;
+    p.x = s->x; p.xb = s->xb; p.hb = s->hb; p.q = s->q; p.k = s->k; p.v = s->v; p.logits = s->logits;
+    p.kc = s->key_cache; p.vc = s->value_cache;
+    p.ctl = c->ctl; p.forced = c->forced; p.out = c->out; p.out_cap = c->out_cap;
+    p.bar = c->pbar; p.epoch = c->pbar + 2;
+    p.nwg = c->cu_count;
+    REQUIRE(cfg->n_heads <= p.nwg, RAMA_EUNSUP, "persistent step: more heads than compute units");
+    const int hs = cfg->dim / cfg->n_heads;
+    const int G = hs <= 64 ? 16 : (hs <= 128 ? 32 : 64);
+    size_t xfloats = (size_t)std::max(std::max(cfg->dim, cfg->hidden_dim), p_attn_lds_floats(G, cfg->seq_len));
+    // > 80 KiB so that at most ONE workgroup fits a CU's 160 KiB: with grid = #CUs every
+    // workgroup is resident, which the in-kernel barrier relies on
+    size_t lds = std::max<size_t>((2 * kPWaves * kPS + 16 + 256 + ((cfg->dim + 3) & ~3) + xfloats) * sizeof(float), 82 * 1024);
+    REQUIRE(lds <= 160 * 1024, RAMA_EUNSUP, "persistent step: activation vector does not fit LDS");
+    const void* fn = G == 16 ? (const void*)decode_step_kernel<16> : (G == 32 ? (const void*)decode_step_kernel<32> : (const void*)decode_step_kernel<64>);
+    if (lds != c->persist_lds || fn != c->persist_fn) {
+        HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        c->persist_lds = lds; c->persist_fn = fn;
+    }
+    if (G == 16) hipLaunchKernelGGL(decode_step_kernel<16>, dim3(p.nwg), dim3(kPThreads), lds, c->stream, p);
+    else if (G == 32) hipLaunchKernelGGL(decode_step_kernel<32>, dim3(p.nwg), dim3(kPThreads), lds, c->stream, p);
+    else hipLaunchKernelGGL(decode_step_kernel<64>, dim3(p.nwg), dim3(kPThreads), lds, c->stream, p);
+    LAUNCHCHK();
+    return 0;
+}
+
 static int enqueue_decode_step(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s) {
+    if (c->tune_persist && c->kp.kernel_id < 0) return enqueue_decode_step_persistent(c, cfg, w, s);
     rama_stage st{0, cfg->n_layers, 0, 1};
     int rc = enqueue_stage(c, cfg, w, s, &st);
     if (rc) return rc;
@@ -569,7 +610,13 @@ int rama_decode_tokens(rama_ctx* c, int32_t* out_host, int max_tokens, int* n_ou
     REQUIRE(c && n_out, RAMA_EINVAL, "decode_tokens: NULL argument");
     Ctl h;
     HIPCHK(hipMemcpyAsync(&h, c->ctl, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long perr = 0;
+    HIPCHK(hipMemcpyAsync(&perr, c->pbar + 1, sizeof perr, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (perr != 0) {   // a bounded spin of the persistent step gave up: its results are invalid
+        hipMemsetAsync(c->pbar, 0, 4 * sizeof(unsigned long long), c->stream);   // counter, error word, base: start over
+        return fail(RAMA_EINVAL, "persistent decode step: barrier timed out", __FILE__, __LINE__);
+    }
     int n = std::min(std::min(h.n_out, c->out_cap), max_tokens);
     if (n > 0 && out_host) {
         HIPCHK(hipMemcpyAsync(out_host, c->out, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
@@ -594,6 +641,13 @@ int rama_generate_greedy(rama_ctx* c, const rama_config* cfg, const rama_weights
 
 int rama_set_tuning(rama_ctx* c, const char* key, int value) {
     REQUIRE(c && key, RAMA_EINVAL, "set_tuning: NULL argument");
+    if (!strcmp(key, "persist")) {
+        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: persist must be 0 or 1");
+        c->tune_persist = value;
+        hipStreamSynchronize(c->stream);
+        drop_graph(c);
+        return 0;
+    }
     if (!strcmp(key, "geom")) {
         REQUIRE(value >= 0 && value <= 3, RAMA_EINVAL, "set_tuning: geom must be 0..3");
         c->tune_geom = value;
