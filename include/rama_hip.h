@@ -183,6 +183,9 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
 /* Performance knobs (results are unaffected up to fp32 summation order).  Keys:
  *   "geom" = 0..3 : matvec workgroup geometry (rows per workgroup, waves, chunks per step);
  *                   3 is the shipping choice, see rama_api.hip DISPATCH_GEOM
+ *   "merge" = 0|1   : 1 runs attention and the Wo matvec as one launch when the occupancy API says
+ *                   its whole grid is resident (Wo's weights stream while attention runs).
+ *                   Measured +0.9 % at short and -2.5 % at 1000-token contexts: off by default
  *   "persist" = 0|1 : 1 runs each chained decode step as ONE persistent launch (persist.hpp:
  *                   one resident workgroup per CU, phases separated by a counter barrier hidden
  *                   behind weight prefetch).  Same results; measured slower than the launch

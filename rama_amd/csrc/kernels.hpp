@@ -209,6 +209,7 @@ struct GemvParams {
     int head_size;
     float* kc;             // this layer's key cache   [seq, dim]
     float* vc;             // this layer's value cache [seq, dim]
+    unsigned* zero_me;     // optional: a counter the NEXT launch uses, cleared here (stream order publishes it)
 };
 
 // R rows per workgroup of NW waves; grid = nmat * ceil(rows/R) (tail rows read as 0)
@@ -235,6 +236,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_rows(GemvParams p) {
     if (EPI == EPI_RESID) {
         if (t < R && r0 + t < p.rows) resid = o[r0 + t];
     } else if (EPI == EPI_QKV) {
+        if (p.zero_me && blockIdx.x == 0 && t == 0) *p.zero_me = 0u;
         pos = p.ctl ? p.ctl->pos : p.pos_val;
         if (t < R / 2 && m < 2) {   // table row pos, entry (r % hs)/2  (infer.rs:15-16)
             const int i = ((r0 + 2 * t) % p.head_size) >> 1;
@@ -353,6 +355,10 @@ struct AttnParams {
     const Ctl* ctl;
     int pos_val;
     int dim, head_size, seq_len;
+    // split-T mode (long contexts): grid (n_heads, nsplit); workgroup (h, s) covers timesteps
+    // [s*chunk, (s+1)*chunk) and writes an un-normalised partial {max, sum, acc[hs]} to part
+    float* part;          // [n_heads, nsplit, head_size + 4]
+    int nsplit;
 };
 
 constexpr int kAttnWaves = 16;
@@ -360,7 +366,7 @@ constexpr int kAttnThreads = kAttnWaves * 64;
 // LDS floats: [2 * kAttnWaves] max / sum, [kAttnWaves * G * 4] partial outputs, [seq_len] scores
 __host__ __device__ constexpr int attn_scratch_floats(int G) { return 2 * kAttnWaves + kAttnWaves * G * 4; }
 
-template <int G>
+template <int G, bool SPLIT>
 __global__ __launch_bounds__(kAttnThreads) void attention_kernel(AttnParams p) {
     extern __shared__ float sm[];
     float* s_max = sm;
@@ -374,6 +380,13 @@ __global__ __launch_bounds__(kAttnThreads) void attention_kernel(AttnParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pos = p.ctl ? p.ctl->pos : p.pos_val;
     const int hs = p.head_size;
+    // timesteps [t0, t1) of this workgroup: everything, or one slice in split-T mode
+    int t0 = 0, t1 = pos + 1;
+    if (SPLIT) {
+        const int chunk = (pos + 1 + p.nsplit - 1) / p.nsplit;
+        t0 = (int)blockIdx.y * chunk;
+        t1 = min(t0 + chunk, pos + 1);
+    }
     const int li = lane % G;                 // my float4 within the head segment
     const int tg = lane / G;                 // my timestep slot within the wave
     const bool lane_ok = li * 4 < hs;
@@ -384,7 +397,7 @@ __global__ __launch_bounds__(kAttnThreads) void attention_kernel(AttnParams p) {
     const unsigned rowb = (unsigned)p.dim * 4u;
     // timestep of slot u in the round starting at `base`
     auto t_of = [&](int base, int u) { return base + (u * kAttnWaves + wave) * TPW + tg; };
-    auto off_of = [&](int t) { return (lane_ok && t <= pos) ? (unsigned)t * rowb + col : kOOB; };
+    auto off_of = [&](int t) { return (lane_ok && t < t1) ? (unsigned)t * rowb + col : kOOB; };
 
     f4 q4 = {0.f, 0.f, 0.f, 0.f};
     if (lane_ok) q4 = *reinterpret_cast<const f4*>(p.q + (size_t)h * hs + (size_t)li * 4);
@@ -392,14 +405,14 @@ __global__ __launch_bounds__(kAttnThreads) void attention_kernel(AttnParams p) {
 
     f4 kt[U], vt[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) kt[u] = ld_c(rk, off_of(t_of(0, u)));
+    for (int u = 0; u < U; u++) kt[u] = ld_c(rk, off_of(t_of(t0, u)));
 #pragma unroll
-    for (int u = 0; u < U; u++) vt[u] = ld_c(rv, off_of(t_of(0, u)));     // needed only after the softmax
+    for (int u = 0; u < U; u++) vt[u] = ld_c(rv, off_of(t_of(t0, u)));     // needed only after the softmax
     __builtin_amdgcn_sched_barrier(0);
 
-    // scores: att[t] = (q . k_t) / sqrt(hs)     (cpu.rs:34-41)
-    for (int base = 0; base <= pos; base += TILE) {
-        if (base > 0) {
+    // scores: att[t] = (q . k_t) / sqrt(hs)     (cpu.rs:34-41); s_att is indexed from t0
+    for (int base = t0; base < t1; base += TILE) {
+        if (base > t0) {
 #pragma unroll
             for (int u = 0; u < U; u++) kt[u] = ld_c(rk, off_of(t_of(base, u)));
             __builtin_amdgcn_sched_barrier(0);
@@ -411,14 +424,15 @@ __global__ __launch_bounds__(kAttnThreads) void attention_kernel(AttnParams p) {
             if (G == 32) d += __shfl_xor(d, 16);
             if (G == 64) { d += __shfl_xor(d, 16); d += __shfl_xor(d, 32); }
             const int t = t_of(base, u);
-            if (li == 0 && t <= pos) s_att[t] = d / div;
+            if (li == 0 && t < t1) s_att[t - t0] = d / div;
         }
     }
     __syncthreads();
 
-    // softmax over 0..=pos (cpu.rs:187-192): max, exp(a - max), sum, divide
+    // softmax over the slice (cpu.rs:187-192): max, exp(a - max), sum, divide
+    const int nt = t1 - t0;
     float mx = -INFINITY;
-    for (int t = tid; t <= pos; t += kAttnThreads) mx = fmaxf(mx, s_att[t]);
+    for (int t = tid; t < nt; t += kAttnThreads) mx = fmaxf(mx, s_att[t]);
     mx = wave_max(mx);
     if (lane == 0) s_max[wave] = mx;
     __syncthreads();
@@ -426,7 +440,7 @@ __global__ __launch_bounds__(kAttnThreads) void attention_kernel(AttnParams p) {
 #pragma unroll
     for (int w = 1; w < kAttnWaves; w++) mx = fmaxf(mx, s_max[w]);
     float sum = 0.0f;
-    for (int t = tid; t <= pos; t += kAttnThreads) {
+    for (int t = tid; t < nt; t += kAttnThreads) {
         float e = expf(s_att[t] - mx);
         s_att[t] = e;
         sum += e;
@@ -444,17 +458,19 @@ __global__ __launch_bounds__(kAttnThreads) void attention_kernel(AttnParams p) {
             for (int w = 0; w < n / 2; w++) t8[w] = t8[2 * w] + t8[2 * w + 1];
         sum = t8[0];
     }
-    for (int t = tid; t <= pos; t += kAttnThreads) {
-        float a = s_att[t] / sum;
-        s_att[t] = a;
-        if (p.att) p.att[(size_t)h * p.seq_len + t] = a;
+    if (!SPLIT) {       // a slice keeps exp(a - slice max); the combine kernel rescales and divides
+        for (int t = tid; t < nt; t += kAttnThreads) {
+            float a = s_att[t] / sum;
+            s_att[t] = a;
+            if (p.att) p.att[(size_t)h * p.seq_len + t] = a;
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
     // xb[i] = sum_t att[t] * v_t[i]     (cpu.rs:43-49)
     f4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int base = 0; base <= pos; base += TILE) {
-        if (base > 0) {
+    for (int base = t0; base < t1; base += TILE) {
+        if (base > t0) {
 #pragma unroll
             for (int u = 0; u < U; u++) vt[u] = ld_c(rv, off_of(t_of(base, u)));
             __builtin_amdgcn_sched_barrier(0);
@@ -462,7 +478,7 @@ __global__ __launch_bounds__(kAttnThreads) void attention_kernel(AttnParams p) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int t = t_of(base, u);
-            const float a = (t <= pos) ? s_att[t] : 0.0f;
+            const float a = (t < t1) ? s_att[t - t0] : 0.0f;
             acc.x = fmaf(a, vt[u].x, acc.x); acc.y = fmaf(a, vt[u].y, acc.y);
             acc.z = fmaf(a, vt[u].z, acc.z); acc.w = fmaf(a, vt[u].w, acc.w);
         }
@@ -483,8 +499,34 @@ __global__ __launch_bounds__(kAttnThreads) void attention_kernel(AttnParams p) {
         for (int n = kAttnWaves; n > 1; n >>= 1)
 #pragma unroll
             for (int w = 0; w < n / 2; w++) t8[w] = t8[2 * w] + t8[2 * w + 1];
-        *reinterpret_cast<f4*>(p.xb + (size_t)h * hs + (size_t)tid * 4) = t8[0];
+        if (SPLIT) {
+            float* o = p.part + ((size_t)h * p.nsplit + blockIdx.y) * (size_t)(hs + 4);
+            *reinterpret_cast<f4*>(o + 4 + (size_t)tid * 4) = t8[0];
+            if (tid == 0) { o[0] = mx; o[1] = sum; }
+        } else {
+            *reinterpret_cast<f4*>(p.xb + (size_t)h * hs + (size_t)tid * 4) = t8[0];
+        }
     }
+}
+
+// split-T combine: xb[h] = sum_s e^(m_s - M) acc_s / sum_s e^(m_s - M) l_s,  M = max_s m_s
+// (algebraically the softmax over all timesteps; an empty slice has l = 0 and drops out)
+__global__ void attention_combine_kernel(const float* part, float* xb, int head_size, int nsplit) {
+    const int h = blockIdx.x, i = threadIdx.x;
+    const size_t ps = (size_t)(head_size + 4);
+    const float* ph = part + (size_t)h * nsplit * ps;
+    float M = -INFINITY;
+    for (int s = 0; s < nsplit; s++) if (ph[s * ps + 1] > 0.0f) M = fmaxf(M, ph[s * ps]);
+    float L = 0.0f, o = 0.0f;
+    for (int s = 0; s < nsplit; s++) {
+        const float l = ph[s * ps + 1];
+        if (l > 0.0f) {
+            const float sc = expf(ph[s * ps] - M);
+            L += sc * l;
+            if (i < head_size) o += sc * ph[s * ps + 4 + i];
+        }
+    }
+    if (i < head_size) xb[(size_t)h * head_size + i] = o / L;
 }
 
 // ---------------------------------------------------------------- small ops

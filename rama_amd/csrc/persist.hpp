@@ -558,4 +558,138 @@ __global__ __launch_bounds__(kPThreads) void decode_step_kernel(PersistParams p)
     }
 }
 
+// ---------------------------------------------------------------- attention + Wo in one launch
+// Decode attention keeps 32 of 256 CUs busy for ~5.6 us while HBM idles, and the Wo matvec that
+// follows pays its own ramp.  Here the grid is Wo's grid (dim/4 workgroups of 8 waves): every
+// workgroup requests its Wo weight tiles FIRST (weights do not depend on activations), workgroups
+// 0..n_heads-1 run attention for one head each (they request their tiles afterwards: they are the
+// critical path), and everyone then waits for the n_heads arrivals before reading xb.
+//  * Hand-off = the same sc1 protocol as above: xb is written with sc1 stores by wave 0 of the
+//    attention workgroups, `s_waitcnt vmcnt(0)`, one agent-scope add; consumers poll from one lane,
+//    pass a workgroup barrier and read xb with sc1 loads only.
+//  * No deadlock: the host launches this kernel only when the occupancy API says the WHOLE grid is
+//    resident at once (else it falls back to the two separate launches), so the attention
+//    workgroups always run.  The spin is bounded anyway.
+//  * The counter is zeroed by the QKV launch that precedes this one in the stream.
+struct AttnWoParams {
+    int dim, n_heads, seq_len;
+    const float* q; const float* kc; const float* vc;   // this layer's cache slabs
+    float* xb; float* x;
+    const float* wo;                                    // this layer's [dim, dim]
+    const Ctl* ctl;
+    unsigned* counter;                                  // arrivals of the attention workgroups
+    unsigned long long* err;
+};
+
+// launch bound: 8 waves per SIMD = 4 workgroups per CU, so the 1024-workgroup grid of llama2-7B
+// (dim 4096 / 4 rows) is resident at once on 256 CUs; it caps the kernel at 64 VGPRs.
+template <int G>
+__global__ __launch_bounds__(kPThreads, 8) void attn_wo_kernel(AttnWoParams a) {
+    extern __shared__ float lds[];
+    constexpr int R = 4, CH = 2, NW = kPWaves;
+    float (*part)[R] = reinterpret_cast<float (*)[R]>(lds);     // [NW][R]
+    float* scratch = lds + NW * R;                              // attention scratch
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = a.dim, rows = a.dim;
+    const int r0 = b * R;
+    const int nch = (K + 255) >> 8;
+    const unsigned kbytes = (unsigned)K * 4u;
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wo, (unsigned)rows * kbytes);
+    unsigned rowoff[R];
+#pragma unroll
+    for (int s = 0; s < R; s++) rowoff[s] = (r0 + s < rows) ? (unsigned)(r0 + s) * kbytes : kOOB;
+    unsigned kb[CH];
+#pragma unroll
+    for (int j = 0; j < CH; j++) {
+        const int c = wave + j * NW;
+        const unsigned o = (unsigned)(c * 1024 + lane * 16);
+        kb[j] = (c < nch && o < kbytes) ? o : kOOB;
+    }
+    f4 w[R][CH];
+    auto issue_first = [&]() {
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+#pragma unroll
+            for (int s = 0; s < R; s++) w[s][j] = ld_nt(rw, (kb[j] == kOOB || rowoff[s] == kOOB) ? kOOB : rowoff[s] + kb[j]);
+    };
+    float resid = 0.0f;
+    if (tid < R && r0 + tid < rows) resid = a.x[r0 + tid];      // x: complete since the previous launch
+
+    if (b < a.n_heads) {
+        PersistParams p{};
+        p.dim = a.dim; p.n_heads = a.n_heads; p.seq_len = a.seq_len; p.q = const_cast<float*>(a.q); p.xb = a.xb;
+        p_attention<G>(p, a.kc, a.vc, b, a.ctl->pos, scratch);
+        if (tid < 64) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // wave 0's sc1 stores of xb have left
+            if (tid == 0) __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        issue_first();
+    } else {
+        issue_first();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (tid == 0) {
+        long spins = 0;
+        while (__hip_atomic_load(a.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)a.n_heads) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1L << 22)) {
+                __hip_atomic_store(a.err, 0x2000ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.xb, kbytes);
+    float acc[R] = {0.f, 0.f, 0.f, 0.f};
+    {
+        f4 xv[CH];
+#pragma unroll
+        for (int j = 0; j < CH; j++) xv[j] = ld4_sc1(rx, kb[j]);
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+#pragma unroll
+            for (int s = 0; s < R; s++) acc[s] = dot4(w[s][j], xv[j], acc[s]);
+    }
+    for (int c0 = wave + CH * NW; c0 < nch; c0 += CH * NW) {    // rows wider than 16 chunks: the rest, un-prefetched
+        f4 ww[R][CH], xv[CH];
+        unsigned kk[CH];
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            const int c = c0 + j * NW;
+            const unsigned o = (unsigned)(c * 1024 + lane * 16);
+            kk[j] = (c < nch && o < kbytes) ? o : kOOB;
+        }
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+#pragma unroll
+            for (int s = 0; s < R; s++) ww[s][j] = ld_nt(rw, (kk[j] == kOOB || rowoff[s] == kOOB) ? kOOB : rowoff[s] + kk[j]);
+#pragma unroll
+        for (int j = 0; j < CH; j++) xv[j] = ld4_sc1(rx, kk[j]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+#pragma unroll
+            for (int s = 0; s < R; s++) acc[s] = dot4(ww[s][j], xv[j], acc[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < R; s++) acc[s] = wave_sum(acc[s]);
+    if (lane == 0) {
+#pragma unroll
+        for (int s = 0; s < R; s++) part[wave][s] = acc[s];
+    }
+    __syncthreads();
+    if (tid < R && r0 + tid < rows) {
+        float t8[NW];
+#pragma unroll
+        for (int q = 0; q < NW; q++) t8[q] = part[q][tid];
+#pragma unroll
+        for (int n = NW; n > 1; n >>= 1)
+#pragma unroll
+            for (int q = 0; q < n / 2; q++) t8[q] = t8[2 * q] + t8[2 * q + 1];
+        a.x[r0 + tid] = resid + t8[0];      // infer.rs:37
+    }
+}
+
 }  // namespace rama

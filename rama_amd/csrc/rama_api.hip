@@ -64,11 +64,19 @@ struct rama_ctx {
     int* argmax_result = nullptr;   // device int for rama_sample_argmax
     int* pinned_int = nullptr;      // host pinned
     bool graph_mode = false;
-    GraphCache gc;
+    GraphCache gc[2];                  // [0]: single-workgroup attention, [1]: split-T attention (long contexts)
     KProf kp;
     int cu_count = 0;
     int tune_geom = 3;
     int tune_persist = 0;                  // 1: decode steps run as one persistent launch (persist.hpp)
+    int tune_merge = 0;                    // 1: attention + Wo in one launch when the whole grid is resident (+0.9 % short, -2.5 % long contexts: off)
+    int merge_blocks_per_cu[3] = {-1, -1, -1};   // occupancy of attn_wo_kernel<16|32|64> at the LDS size below
+    size_t merge_lds[3] = {0, 0, 0};
+    unsigned* attn_counter = nullptr;      // device: arrivals of the attention workgroups
+    float* attn_part = nullptr;            // split-T partials [n_heads, nsplit, head_size + 4]
+    size_t attn_part_floats = 0;
+    int host_pos = -1;                     // position of the next chained decode step (mirrors the device cursor)
+    bool split_attn = false;               // variant the steps being enqueued / captured use
     unsigned long long* pbar = nullptr;    // device: [0] barrier counter, [1] error word, [2] epoch
     size_t persist_lds = 0;
     const void* persist_fn = nullptr;
@@ -100,6 +108,8 @@ int rama_ctx_create(int device, void* hip_stream, rama_ctx** out) {
     c->forced_cap = 1 << 16;
     HIPCHK(hipMalloc(&c->forced, sizeof(int) * c->forced_cap));
     HIPCHK(hipMalloc(&c->argmax_result, sizeof(int)));
+    HIPCHK(hipMalloc(&c->attn_counter, sizeof(unsigned)));
+    HIPCHK(hipMemset(c->attn_counter, 0, sizeof(unsigned)));
     HIPCHK(hipMalloc(&c->pbar, 4 * sizeof(unsigned long long)));
     HIPCHK(hipMemset(c->pbar, 0, 4 * sizeof(unsigned long long)));
     HIPCHK(hipHostMalloc(&c->pinned_int, sizeof(int) * 4));
@@ -111,9 +121,11 @@ int rama_ctx_create(int device, void* hip_stream, rama_ctx** out) {
 }
 
 static void drop_graph(rama_ctx* c) {
-    if (c->gc.exec) hipGraphExecDestroy(c->gc.exec);
-    if (c->gc.graph) hipGraphDestroy(c->gc.graph);
-    c->gc = GraphCache();
+    for (auto& g : c->gc) {
+        if (g.exec) hipGraphExecDestroy(g.exec);
+        if (g.graph) hipGraphDestroy(g.graph);
+        g = GraphCache();
+    }
 }
 
 int rama_ctx_destroy(rama_ctx* c) {
@@ -122,7 +134,7 @@ int rama_ctx_destroy(rama_ctx* c) {
     hipStreamSynchronize(c->stream);
     drop_graph(c);
     for (auto e : c->kp.ev) hipEventDestroy(e);
-    hipFree(c->ctl); hipFree(c->out); hipFree(c->forced); hipFree(c->argmax_result); hipFree(c->pbar);
+    hipFree(c->ctl); hipFree(c->out); hipFree(c->forced); hipFree(c->argmax_result); hipFree(c->pbar); hipFree(c->attn_counter); hipFree(c->attn_part);
     hipHostFree(c->pinned_int);
     hipEventDestroy(c->t0); hipEventDestroy(c->t1);
     if (c->own_stream) hipStreamDestroy(c->stream);
@@ -302,20 +314,54 @@ int rama_softmax(rama_ctx* c, float* x, size_t n) {
     LAUNCHCHK(); return 0;
 }
 
+static int attn_nsplit(const rama_ctx* c, int n_heads) { return std::max(1, std::min(16, c->cu_count / std::max(n_heads, 1))); }
+
+// scratch for the split-T partials; called outside any stream capture (no allocation inside one)
+static int ensure_attn_part(rama_ctx* c, const rama_config* cfg) {
+    const int hs = cfg->dim / cfg->n_heads;
+    const size_t need = (size_t)cfg->n_heads * attn_nsplit(c, cfg->n_heads) * (hs + 4);
+    if (need > c->attn_part_floats) {
+        if (c->attn_part) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->attn_part)); c->attn_part = nullptr; }
+        HIPCHK(hipMalloc(&c->attn_part, need * sizeof(float)));
+        c->attn_part_floats = need;
+    }
+    return 0;
+}
+
+// Split-T attention is worth its extra (combine) launch once a head's cache no longer fits a
+// couple of single-workgroup rounds; below the threshold one workgroup per head is faster.
+constexpr int kSplitTPos = 384;
+
 static int launch_attention(rama_ctx* c, float* xb, float* att, const float* q, const float* kc_layer,
                             const float* vc_layer, const Ctl* ctl, int pos, int dim, int head_size,
-                            int seq_len, int n_heads) {
+                            int seq_len, int n_heads, bool split = false) {
     REQUIRE(head_size % 4 == 0 && head_size >= 4 && head_size <= 256, RAMA_EUNSUP, "attention: head_size must be a multiple of 4 in [4, 256]");
     REQUIRE(aligned16(q) && aligned16(kc_layer) && aligned16(vc_layer) && aligned16(xb) && dim % 4 == 0, RAMA_EINVAL, "attention: buffers must be 16-byte aligned");
     AttnParams p{};
     p.q = q; p.kc = kc_layer; p.vc = vc_layer; p.att = att; p.xb = xb; p.ctl = ctl; p.pos_val = pos;
     p.dim = dim; p.head_size = head_size; p.seq_len = seq_len;
     const int G = head_size <= 64 ? 16 : (head_size <= 128 ? 32 : 64);
+    if (split) {
+        const int nsplit = attn_nsplit(c, n_heads);
+        REQUIRE((size_t)n_heads * nsplit * (head_size + 4) <= c->attn_part_floats, RAMA_EINVAL, "attention: split-T scratch not prepared");
+        p.part = c->attn_part; p.nsplit = nsplit; p.att = nullptr;
+        const int chunk_max = (seq_len + nsplit - 1) / nsplit;
+        size_t shm = (size_t)(attn_scratch_floats(G) + chunk_max) * sizeof(float);
+        dim3 grid(n_heads, nsplit);
+        if (G == 16) hipLaunchKernelGGL((attention_kernel<16, true>), grid, dim3(kAttnThreads), shm, c->stream, p);
+        else if (G == 32) hipLaunchKernelGGL((attention_kernel<32, true>), grid, dim3(kAttnThreads), shm, c->stream, p);
+        else hipLaunchKernelGGL((attention_kernel<64, true>), grid, dim3(kAttnThreads), shm, c->stream, p);
+        LAUNCHCHK();
+        hipLaunchKernelGGL(attention_combine_kernel, dim3(n_heads), dim3(((head_size + 63) / 64) * 64), 0, c->stream,
+                           (const float*)c->attn_part, xb, head_size, nsplit);
+        LAUNCHCHK();
+        return 0;
+    }
     size_t shm = (size_t)(attn_scratch_floats(G) + seq_len) * sizeof(float);
     REQUIRE(shm <= 64 * 1024, RAMA_EUNSUP, "attention: seq_len too long for the single-workgroup kernel");
-    if (G == 16) hipLaunchKernelGGL((attention_kernel<16>), dim3(n_heads), dim3(kAttnThreads), shm, c->stream, p);
-    else if (G == 32) hipLaunchKernelGGL((attention_kernel<32>), dim3(n_heads), dim3(kAttnThreads), shm, c->stream, p);
-    else hipLaunchKernelGGL((attention_kernel<64>), dim3(n_heads), dim3(kAttnThreads), shm, c->stream, p);
+    if (G == 16) hipLaunchKernelGGL((attention_kernel<16, false>), dim3(n_heads), dim3(kAttnThreads), shm, c->stream, p);
+    else if (G == 32) hipLaunchKernelGGL((attention_kernel<32, false>), dim3(n_heads), dim3(kAttnThreads), shm, c->stream, p);
+    else hipLaunchKernelGGL((attention_kernel<64, false>), dim3(n_heads), dim3(kAttnThreads), shm, c->stream, p);
     LAUNCHCHK();
     return 0;
 }
@@ -393,6 +439,41 @@ static int check_cfg(const rama_config* cfg) {
     return 0;
 }
 
+// attention + Wo as one launch (persist.hpp attn_wo_kernel) -- only if the WHOLE grid is resident at
+// once according to the occupancy API, which is what makes its in-kernel wait deadlock-free.
+// Returns 1 if launched, 0 if the caller must use the two separate launches, < 0 / > 0 on error.
+static int try_launch_attn_wo(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s,
+                              size_t li, float* kc, float* vc, bool* launched) {
+    *launched = false;
+    const int dim = cfg->dim, hs = dim / cfg->n_heads;
+    const int G = hs <= 64 ? 16 : (hs <= 128 ? 32 : 64);
+    const int gi = G == 16 ? 0 : (G == 32 ? 1 : 2);
+    const int grid = (dim + 3) / 4;
+    if (cfg->n_heads > grid || !aligned16(s->q) || !aligned16(s->xb) || !aligned16(kc) || !aligned16(vc)) return 0;
+    const size_t lds = (size_t)(kPWaves * 4 + p_attn_lds_floats(G, cfg->seq_len)) * sizeof(float);
+    if (lds > 64 * 1024) return 0;
+    const void* fn = G == 16 ? (const void*)attn_wo_kernel<16> : (G == 32 ? (const void*)attn_wo_kernel<32> : (const void*)attn_wo_kernel<64>);
+    if (c->merge_blocks_per_cu[gi] < 0 || c->merge_lds[gi] != lds) {
+        int nb = 0;
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, kPThreads, lds));
+        c->merge_blocks_per_cu[gi] = nb; c->merge_lds[gi] = lds;
+    }
+    // The occupancy API over-reports by one block per CU only for kernels with > 80 SGPRs
+    // (MI355X_MICROARCH.md, Residency); this kernel uses 58 (build remark), so its answer is
+    // taken as is.  Should the grid not fit, the two separate launches are used instead.
+    if ((long)c->merge_blocks_per_cu[gi] * c->cu_count < grid) return 0;
+    AttnWoParams a{};
+    a.dim = dim; a.n_heads = cfg->n_heads; a.seq_len = cfg->seq_len;
+    a.q = s->q; a.kc = kc; a.vc = vc; a.xb = s->xb; a.x = s->x; a.wo = w->wo + li * (size_t)dim * dim;
+    a.ctl = c->ctl; a.counter = c->attn_counter; a.err = c->pbar + 1;
+    if (G == 16) hipLaunchKernelGGL(attn_wo_kernel<16>, dim3(grid), dim3(kPThreads), lds, c->stream, a);
+    else if (G == 32) hipLaunchKernelGGL(attn_wo_kernel<32>, dim3(grid), dim3(kPThreads), lds, c->stream, a);
+    else hipLaunchKernelGGL(attn_wo_kernel<64>, dim3(grid), dim3(kPThreads), lds, c->stream, a);
+    LAUNCHCHK();
+    *launched = true;
+    return 0;
+}
+
 // one (token, pos) step over a layer range; ctl on the device holds token/pos
 static int enqueue_stage(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s,
                          const rama_stage* st) {
@@ -415,18 +496,26 @@ static int enqueue_stage(rama_ctx* c, const rama_config* cfg, const rama_weights
             p.K = dim; p.rows = dim; p.nmat = 3;
             p.ctl = c->ctl; p.fr = w->freq_cis_real; p.fi = w->freq_cis_imag; p.head_size = hs;
             p.kc = kc; p.vc = vc;
+            p.zero_me = c->attn_counter;
             DISPATCH_GEOM(c, hipLaunchKernelGGL((gemv_rows<R_, CH_, NW_, true, EPI_QKV>), dim3(3 * (dim / R_)), dim3(NW_ * 64), 0, c->stream, p));
             LAUNCHCHK();
         }
-        {   // infer.rs:34
-            KTimer kt(c, RAMA_K_ATTN);
-            int rc = launch_attention(c, s->xb, s->att, s->q, kc, vc, c->ctl, 0, dim, hs, cfg->seq_len, cfg->n_heads);
+        bool merged = false;
+        if (c->tune_merge && !c->split_attn && c->kp.kernel_id < 0) {   // infer.rs:34-37 as one launch (per-kernel timing keeps them apart)
+            int rc = try_launch_attn_wo(c, cfg, w, s, li, kc, vc, &merged);
             if (rc) return rc;
         }
-        {   // infer.rs:35-37: x += Wo . xb
-            KTimer kt(c, RAMA_K_WO);
-            int rc = launch_rows<false, EPI_RESID>(c, s->x, w->wo + li * dd, s->xb, nullptr, dim, dim);
-            if (rc) return rc;
+        if (!merged) {
+            {   // infer.rs:34
+                KTimer kt(c, RAMA_K_ATTN);
+                int rc = launch_attention(c, s->xb, s->att, s->q, kc, vc, c->ctl, 0, dim, hs, cfg->seq_len, cfg->n_heads, c->split_attn);
+                if (rc) return rc;
+            }
+            {   // infer.rs:35-37: x += Wo . xb
+                KTimer kt(c, RAMA_K_WO);
+                int rc = launch_rows<false, EPI_RESID>(c, s->x, w->wo + li * dd, s->xb, nullptr, dim, dim);
+                if (rc) return rc;
+            }
         }
         {   // infer.rs:39-45: rmsnorm, W1|W3, SiLU * gate
             KTimer kt(c, RAMA_K_W13);
@@ -469,9 +558,12 @@ int rama_forward_stage(rama_ctx* c, const rama_config* cfg, const rama_weights* 
     rc = check_stage(cfg, w, s, st); if (rc) return rc;
     REQUIRE(pos >= 0 && pos < cfg->seq_len, RAMA_EINVAL, "forward: pos outside [0, seq_len)");
     REQUIRE(token >= 0 && token < cfg->vocab_size, RAMA_EINVAL, "forward: token outside the vocabulary");
+    rc = ensure_attn_part(c, cfg); if (rc) return rc;
     hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(1), 0, c->stream, c->ctl, token, pos, 0, 0);
     LAUNCHCHK();
     c->embedded_x = nullptr;
+    c->host_pos = -1;
+    c->split_attn = pos >= kSplitTPos;
     return enqueue_stage(c, cfg, w, s, st);
 }
 
@@ -483,9 +575,12 @@ int rama_forward_stage_devtok(rama_ctx* c, const rama_config* cfg, const rama_we
     rc = check_stage(cfg, w, s, st); if (rc) return rc;
     REQUIRE(pos >= 0 && pos < cfg->seq_len, RAMA_EINVAL, "forward: pos outside [0, seq_len)");
     REQUIRE(token_dev || !st->do_embed, RAMA_EINVAL, "forward: an embedding stage needs a token");
+    rc = ensure_attn_part(c, cfg); if (rc) return rc;
     hipLaunchKernelGGL(set_ctl_dev_kernel, dim3(1), dim3(1), 0, c->stream, c->ctl, (const int*)token_dev, pos, cfg->vocab_size);
     LAUNCHCHK();
     c->embedded_x = nullptr;
+    c->host_pos = -1;
+    c->split_attn = pos >= kSplitTPos;
     return enqueue_stage(c, cfg, w, s, st);
 }
 
@@ -517,6 +612,7 @@ int rama_decode_begin(rama_ctx* c, int token, int pos, const int32_t* forced_hos
     hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(1), 0, c->stream, c->ctl, token, pos, n_forced, 0);
     LAUNCHCHK();
     c->embedded_x = nullptr;   // the first decode step must gather x = emb[token] itself
+    c->host_pos = pos;         // the chained loop advances pos by one per step: the host can mirror it
     return 0;
 }
 
@@ -585,23 +681,33 @@ int rama_decode_steps(rama_ctx* c, const rama_config* cfg, const rama_weights* w
         LAUNCHCHK();
         c->embedded_x = s->x;
     }
-    if (c->graph_mode && c->kp.kernel_id < 0) {
-        if (!same_capture(c->gc, cfg, w, s)) {
-            drop_graph(c);
-            HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-            rc = enqueue_decode_step(c, cfg, w, s);
-            hipError_t e = hipStreamEndCapture(c->stream, &c->gc.graph);
-            if (rc) return rc;
-            HIPCHK(e);
-            HIPCHK(hipGraphInstantiate(&c->gc.exec, c->gc.graph, nullptr, nullptr, 0));
-            c->gc.cfg = *cfg; c->gc.w = *w; c->gc.s = *s; c->gc.valid = true;
-        }
-        for (int i = 0; i < n_steps; i++) HIPCHK(hipGraphLaunch(c->gc.exec, c->stream));
-        return 0;
-    }
+    REQUIRE(c->host_pos >= 0, RAMA_EINVAL, "decode_steps: call rama_decode_begin first");
+    rc = ensure_attn_part(c, cfg); if (rc) return rc;
+    REQUIRE(c->host_pos + n_steps <= cfg->seq_len, RAMA_EINVAL, "decode_steps: would run past seq_len");
+    const bool graphs = c->graph_mode && c->kp.kernel_id < 0;
     for (int i = 0; i < n_steps; i++) {
-        rc = enqueue_decode_step(c, cfg, w, s);
-        if (rc) return rc;
+        // the attention variant depends on the position, which the host mirrors step by step
+        c->split_attn = c->host_pos >= kSplitTPos;
+        if (graphs) {
+            GraphCache& g = c->gc[c->split_attn ? 1 : 0];
+            if (!same_capture(g, cfg, w, s)) {
+                if (g.exec) hipGraphExecDestroy(g.exec);
+                if (g.graph) hipGraphDestroy(g.graph);
+                g = GraphCache();
+                HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+                rc = enqueue_decode_step(c, cfg, w, s);
+                hipError_t e = hipStreamEndCapture(c->stream, &g.graph);
+                if (rc) return rc;
+                HIPCHK(e);
+                HIPCHK(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+                g.cfg = *cfg; g.w = *w; g.s = *s; g.valid = true;
+            }
+            HIPCHK(hipGraphLaunch(g.exec, c->stream));
+        } else {
+            rc = enqueue_decode_step(c, cfg, w, s);
+            if (rc) return rc;
+        }
+        c->host_pos += 1;
     }
     return 0;
 }
@@ -641,6 +747,13 @@ int rama_generate_greedy(rama_ctx* c, const rama_config* cfg, const rama_weights
 
 int rama_set_tuning(rama_ctx* c, const char* key, int value) {
     REQUIRE(c && key, RAMA_EINVAL, "set_tuning: NULL argument");
+    if (!strcmp(key, "merge")) {
+        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: merge must be 0 or 1");
+        c->tune_merge = value;
+        hipStreamSynchronize(c->stream);
+        drop_graph(c);
+        return 0;
+    }
     if (!strcmp(key, "persist")) {
         REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: persist must be 0 or 1");
         c->tune_persist = value;

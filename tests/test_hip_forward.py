@@ -285,3 +285,80 @@ def test_persistent_step_equals_launch_path(dev, name, graph):
     for buf in ("key_cache", "value_cache"):
         assert np.abs(dev.download(getattr(rsv, buf)) - orc.s[buf]).max() <= STATE_ATOL
     rs.free(); ws.free()
+
+
+# ------------------------------------------------------------------ long contexts: split-T attention
+
+def _long_ctx_case(n_heads, hs, seq_len=2048, seed=11):
+    """one-layer synthetic model with a pre-filled KV cache (random, O(1) entries)"""
+    dim = n_heads * hs
+    cfg = O.Config(dim, 2 * dim, 1, n_heads, n_heads, 64, seq_len, False)
+    w = S.synth_weights(cfg, seed)
+    rng = np.random.default_rng(seed)
+    kc = rng.standard_normal(seq_len * dim).astype(np.float32)
+    vc = rng.standard_normal(seq_len * dim).astype(np.float32)
+    return cfg, w, kc, vc
+
+
+@pytest.mark.parametrize("n_heads,hs", [(2, 128), (4, 64), (6, 48)])
+def test_split_t_attention_long_context(dev, n_heads, hs):
+    """positions at and beyond the split-T threshold (384): n_heads x nsplit workgroups + combine
+    must give the oracle's logits (which soft-max over ALL timesteps at once)."""
+    import rama_amd
+    cfg, w, kc, vc = _long_ctx_case(n_heads, hs)
+    orc = O.Oracle(cfg, w)
+    rcfg, ws, wv, rs, rsv = gpu_views(dev, cfg, w)
+    for pos in (383, 384, 385, 1000, 2047):
+        orc.s["key_cache"][:] = kc; orc.s["value_cache"][:] = vc
+        dev.upload_into(rsv.key_cache, kc); dev.upload_into(rsv.value_cache, vc)
+        lo = orc.forward(5, pos).copy()
+        rama_amd.forward_fused(rcfg, wv, rsv, 5, pos, dev)
+        lg = dev.download(rsv.logits)
+        assert np.abs(lg - lo).max() <= LOGIT_ATOL, (pos, float(np.abs(lg - lo).max()))
+        # the freshly appended cache rows agree too
+        d = cfg.dim
+        assert np.abs(dev.download(rsv.key_cache)[pos * d:(pos + 1) * d] - orc.s["key_cache"][pos * d:(pos + 1) * d]).max() <= STATE_ATOL
+    rs.free(); ws.free()
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_decode_across_split_threshold(dev, graph):
+    """a chained greedy run from pos 370 to 400 switches attention variant (and hipGraph) at 384"""
+    import ctypes as C
+    import rama_amd
+    from rama_amd._lib import S_FIELDS, check, rama_run_state
+    cfg, w, kc, vc = _long_ctx_case(2, 128)
+    start, steps = 370, 30
+    orc = O.Oracle(cfg, w)
+    orc.s["key_cache"][:] = kc; orc.s["value_cache"][:] = vc
+    token, want = 7, []
+    for pos in range(start, start + steps):
+        token = O.argmax(orc.forward(token, pos))
+        want.append(int(token))
+    rcfg, ws, wv, rs, rsv = gpu_views(dev, cfg, w)
+    dev.upload_into(rsv.key_cache, kc); dev.upload_into(rsv.value_cache, vc)
+    rstate = rama_run_state(*[getattr(rsv, k).ptr for k in S_FIELDS])
+    dev.lib.rama_set_graph_mode(dev.ctx, int(graph))
+    try:
+        check(dev.lib.rama_decode_begin(dev.ctx, 7, start, None, 0))
+        check(dev.lib.rama_decode_steps(dev.ctx, C.byref(rcfg.c()), C.byref(wv.c()), C.byref(rstate), steps))
+        out = (C.c_int32 * steps)(); n = C.c_int()
+        check(dev.lib.rama_decode_tokens(dev.ctx, out, steps, C.byref(n)))
+    finally:
+        dev.lib.rama_set_graph_mode(dev.ctx, 0)
+    assert [int(v) for v in out[:n.value]] == want
+    assert np.abs(dev.download(rsv.logits) - orc.s["logits"]).max() <= LOGIT_ATOL
+    rs.free(); ws.free()
+
+
+def test_decode_steps_needs_begin_and_bounds(dev):
+    import ctypes as C
+    import rama_amd
+    from rama_amd._lib import S_FIELDS, check, rama_run_state
+    cfg, w, g = load_case("synth_d64_h4")
+    rcfg, ws, wv, rs, rsv = gpu_views(dev, cfg, w)
+    rstate = rama_run_state(*[getattr(rsv, k).ptr for k in S_FIELDS])
+    check(dev.lib.rama_decode_begin(dev.ctx, 1, cfg.seq_len - 2, None, 0))
+    with pytest.raises(rama_amd.RamaError):      # 3 steps from seq_len - 2 would overrun the cache
+        check(dev.lib.rama_decode_steps(dev.ctx, C.byref(rcfg.c()), C.byref(wv.c()), C.byref(rstate), 3))
+    rs.free(); ws.free()
