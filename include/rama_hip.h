@@ -192,6 +192,11 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *                   path in round 1 (170 vs 235 tok/s at llama2-7B), so it is off by default. */
 int  rama_set_tuning(rama_ctx *ctx, const char *key, int value);
 
+/* diagnostic (not a product path): one persistent decode step with 100 MHz timestamps of workgroup
+ * `wg`, 8 slots per phase (0 start, 1 activations staged, 2 steps done, 3 arrived, 4 barrier passed) */
+int  rama_persist_stamps(rama_ctx *ctx, const rama_config *cfg, const rama_weights *w, rama_run_state *s,
+                         int wg, unsigned long long *out_host, int max_phases, int *n_phases);
+
 /* ---------------------------------------------------------------- measurement
  * HIP events on the context's stream (the stream the kernels are launched on). */
 int  rama_timer_start(rama_ctx *ctx);

@@ -45,6 +45,8 @@ struct PersistParams {
     Ctl* ctl;
     const int* forced; int* out; int out_cap;
     unsigned long long* bar;           // [0] arrival counter (monotonic over launches), [1] error word
+    unsigned long long* stamps;        // diagnostic only (NULL in production): 100 MHz timestamps of workgroup `stamp_wg`
+    int stamp_wg;
     unsigned long long* epoch;         // arrivals all completed launches have added to bar[0] (device word);
                                        // = this launch's barrier base, advanced by the last phase
     int nwg;
@@ -418,8 +420,12 @@ __global__ __launch_bounds__(kPThreads) void decode_step_kernel(PersistParams p)
         }
     }
 
+    auto stamp = [&](int ph, int k) {
+        if (p.stamps && wg == p.stamp_wg && tid == 0) p.stamps[ph * 8 + k] = __builtin_amdgcn_s_memrealtime();
+    };
     for (int ph = 0; ph < nph; ph++) {
         const int kind = phase_kind(p, ph);
+        stamp(ph, 0);
         const size_t li = (size_t)(ph / 5);
         // what the ring must hold when this phase ends: the next MATVEC phase's first steps
         // (after QKV comes attention, which has no weights: Wo is requested during attention)
@@ -440,7 +446,9 @@ __global__ __launch_bounds__(kPThreads) void decode_step_kernel(PersistParams p)
                 p_issue_head(ring, nxt, wg, nwg, wave, lane);
                 bar_arrive(bar);
             }
+            stamp(ph, 3);
             bar_wait(bar);
+            stamp(ph, 4);
             cur = nxt;
             continue;
         }
@@ -449,6 +457,7 @@ __global__ __launch_bounds__(kPThreads) void decode_step_kernel(PersistParams p)
         const float* xin = kind == 2 ? p.xb : (kind == 4 ? p.hb : p.x);
         const float* nw = kind == 0 ? p.rms_att + li * p.dim : (kind == 3 ? p.rms_ffn + li * p.dim : (kind == 5 ? p.rms_final : nullptr));
         const float v = stage_x(xin, nw, cur.K, lds_x, red, cur.epi == PE_RESID ? p.x : nullptr, p.dim, lds_r);
+        stamp(ph, 1);
 
         float acc[kPS] = {0.f, 0.f, 0.f, 0.f};
         int par = 0;
@@ -514,9 +523,12 @@ __global__ __launch_bounds__(kPThreads) void decode_step_kernel(PersistParams p)
             }
         }
         if (psteps == 0 && prefetch_next && wave != 0) p_issue_head(ring, nxt, wg, nwg, wave, lane);   // no row group of this phase here
+        stamp(ph, 2);
         bar_arrive(bar);
         if (prefetch_next && wave == 0) p_issue_head(ring, nxt, wg, nwg, wave, lane);
+        stamp(ph, 3);
         bar_wait(bar);
+        stamp(ph, 4);
         cur = nxt;
     }
 

@@ -79,6 +79,9 @@ struct rama_ctx {
     bool split_attn = false;               // variant the steps being enqueued / captured use
     unsigned long long* pbar = nullptr;    // device: [0] barrier counter, [1] error word, [2] epoch
     size_t persist_lds = 0;
+    unsigned long long* pstamps = nullptr; // diagnostic timestamps of the persistent step (rama_persist_stamps)
+    int pstamp_wg = 0;
+    bool pstamp_armed = false;
     const void* persist_fn = nullptr;
     const float* embedded_x = nullptr;   // run-state x that already holds emb[ctl.token] (chained decode)
 };
@@ -219,6 +222,7 @@ static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
         case 1: { constexpr int R_ = 2, R2_ = 1, CH_ = 4, NW_ = 4; (void)R_; (void)R2_; KERNEL_CALL; } break;  \
         case 2: { constexpr int R_ = 4, R2_ = 2, CH_ = 4, NW_ = 4; (void)R_; (void)R2_; KERNEL_CALL; } break;  \
         case 0: { constexpr int R_ = 2, R2_ = 1, CH_ = 2, NW_ = 8; (void)R_; (void)R2_; KERNEL_CALL; } break;  \
+        case 4: { constexpr int R_ = 8, R2_ = 4, CH_ = 2, NW_ = 8; (void)R_; (void)R2_; KERNEL_CALL; } break;  \
         default: { constexpr int R_ = 4, R2_ = 2, CH_ = 2, NW_ = 8; (void)R_; (void)R2_; KERNEL_CALL; } break; \
     }
 
@@ -630,6 +634,7 @@ static int enqueue_decode_step_persistent(rama_ctx* c, const rama_config* cfg, c
     p.kc = s->key_cache; p.vc = s->value_cache;
     p.ctl = c->ctl; p.forced = c->forced; p.out = c->out; p.out_cap = c->out_cap;
     p.bar = c->pbar; p.epoch = c->pbar + 2;
+    p.stamps = c->pstamp_armed ? c->pstamps : nullptr; p.stamp_wg = c->pstamp_wg;
     p.nwg = c->cu_count;
     REQUIRE(cfg->n_heads <= p.nwg, RAMA_EUNSUP, "persistent step: more heads than compute units");
     const int hs = cfg->dim / cfg->n_heads;
@@ -762,13 +767,37 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
         return 0;
     }
     if (!strcmp(key, "geom")) {
-        REQUIRE(value >= 0 && value <= 3, RAMA_EINVAL, "set_tuning: geom must be 0..3");
+        REQUIRE(value >= 0 && value <= 4, RAMA_EINVAL, "set_tuning: geom must be 0..4");
         c->tune_geom = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
         return 0;
     }
     return fail(RAMA_EINVAL, "set_tuning: unknown key", __FILE__, __LINE__);
+}
+
+// diagnostic: run ONE persistent decode step with timestamps of workgroup `wg` recorded, and
+// return them (8 slots per phase: 0 phase start, 1 activations staged, 2 steps done, 3 arrived,
+// 4 barrier passed; 100 MHz ticks).  Not part of the product path.
+int rama_persist_stamps(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s, int wg,
+                        unsigned long long* out_host, int max_phases, int* n_phases) {
+    REQUIRE(c && cfg && w && s && out_host && n_phases, RAMA_EINVAL, "persist_stamps: NULL argument");
+    const int nph = 5 * cfg->n_layers + 1;
+    REQUIRE(max_phases >= nph, RAMA_EINVAL, "persist_stamps: buffer too small");
+    if (!c->pstamps) HIPCHK(hipMalloc(&c->pstamps, (size_t)8 * 4096 * sizeof(unsigned long long)));
+    REQUIRE(nph <= 4096, RAMA_EINVAL, "persist_stamps: too many phases");
+    HIPCHK(hipMemsetAsync(c->pstamps, 0, (size_t)8 * nph * sizeof(unsigned long long), c->stream));
+    c->pstamp_wg = wg;
+    unsigned long long* keep = c->pstamps;
+    c->pstamp_armed = true;
+    int rc = enqueue_decode_step_persistent(c, cfg, w, s);
+    c->pstamp_armed = false;
+    if (rc) return rc;
+    c->host_pos += 1;
+    HIPCHK(hipMemcpyAsync(out_host, keep, (size_t)8 * nph * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *n_phases = nph;
+    return 0;
 }
 
 int rama_set_graph_mode(rama_ctx* c, int enabled) {

@@ -260,12 +260,14 @@ def rnd_vec(n, seed):
 
 # ------------------------------------------------------------------ persistent decode step
 
+@pytest.mark.parametrize("key", [b"persist", b"merge"])
 @pytest.mark.parametrize("name,graph", [("synth_d64_h4", False), ("synth_d288_h6", False), ("synth_d288_h6", True),
                                         ("synth_d768_h12", False), ("ckpt_untied", False), ("synth_d128_h1", False),
                                         ("synth_7bshape_l1", False)])
-def test_persistent_step_equals_launch_path(dev, name, graph):
-    """rama_set_tuning("persist", 1): the whole step as one resident launch (persist.hpp) must
-    give the oracle's greedy tokens, logits within the bar, and the same KV cache."""
+def test_persistent_step_equals_launch_path(dev, name, graph, key):
+    """the opt-in launch structures -- rama_set_tuning("persist", 1): the whole step as one
+    resident launch; ("merge", 1): attention + Wo as one launch (persist.hpp) -- must give the
+    oracle's greedy tokens, logits within the bar, and the same KV cache."""
     import rama_amd
     cfg, w, g = load_case(name)
     prompt = g["tokens"].tolist()[1:4]
@@ -273,13 +275,13 @@ def test_persistent_step_equals_launch_path(dev, name, graph):
     orc = O.Oracle(cfg, w)
     want = orc.generate_greedy(prompt, steps)
     rcfg, ws, wv, rs, rsv = gpu_views(dev, cfg, w)
-    rama_amd._lib.check(dev.lib.rama_set_tuning(dev.ctx, b"persist", 1))
+    rama_amd._lib.check(dev.lib.rama_set_tuning(dev.ctx, key, 1))
     dev.lib.rama_set_graph_mode(dev.ctx, int(graph))
     try:
         got = rama_amd.generate_greedy_device(rcfg, prompt, steps, wv, rsv, dev)
     finally:
         dev.lib.rama_set_graph_mode(dev.ctx, 0)
-        rama_amd._lib.check(dev.lib.rama_set_tuning(dev.ctx, b"persist", 0))
+        rama_amd._lib.check(dev.lib.rama_set_tuning(dev.ctx, key, 0))
     assert got == want
     assert np.abs(dev.download(rsv.logits) - orc.s["logits"]).max() <= LOGIT_ATOL
     for buf in ("key_cache", "value_cache"):
