@@ -4,6 +4,8 @@
 #include "kernels.hpp"
 #include "persist.hpp"
 
+#include <hip/hip_ext.h>   // hipExtLaunchKernelGGL: start/stop events carried by the dispatch itself
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -67,6 +69,7 @@ struct rama_ctx {
     GraphCache gc[2];                  // [0]: single-workgroup attention, [1]: split-T attention (long contexts)
     KProf kp;
     int cu_count = 0;
+    hipEvent_t cur_start = nullptr, cur_stop = nullptr;   // events the next profiled launch carries
     int tune_geom = 3;
     int tune_persist = 0;                  // 1: decode steps run as one persistent launch (persist.hpp)
     int tune_merge = 0;                    // 1: attention + Wo in one launch when the whole grid is resident (+0.9 % short, -2.5 % long contexts: off)
@@ -226,19 +229,32 @@ static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
         default: { constexpr int R_ = 4, R2_ = 2, CH_ = 2, NW_ = 8; (void)R_; (void)R2_; KERNEL_CALL; } break; \
     }
 
-struct KTimer {   // brackets a launch with events when that kernel class is being profiled
+// Per-kernel timing: while a kernel class is being profiled, its next launch carries a start and
+// a stop event ON THE DISPATCH ITSELF (hipExtLaunchKernelGGL), so the interval is the kernel's own
+// begin..end as rocprofv3 sees it -- separate event records around the launch add ~3 us.
+struct KTimer {
     rama_ctx* c; bool on;
     KTimer(rama_ctx* c_, int kid) : c(c_), on(false) {
         KProf& k = c->kp;
         if (k.kernel_id == kid && k.used < k.max_records) {
             on = true;
-            hipEventRecord(k.ev[2 * k.used], c->stream);
+            c->cur_start = k.ev[2 * k.used]; c->cur_stop = k.ev[2 * k.used + 1];
         }
     }
     ~KTimer() {
-        if (on) { KProf& k = c->kp; hipEventRecord(k.ev[2 * k.used + 1], c->stream); k.used++; }
+        if (on) { c->kp.used++; c->cur_start = c->cur_stop = nullptr; }
     }
 };
+// launch on the context's stream; the first launch inside an armed KTimer scope takes the events
+#define RAMA_LAUNCH(c, kernel, grid, block, shm, ...)                                                          \
+    do {                                                                                                        \
+        if ((c)->cur_start) {                                                                                   \
+            hipExtLaunchKernelGGL(kernel, grid, block, shm, (c)->stream, (c)->cur_start, (c)->cur_stop, 0, __VA_ARGS__); \
+            (c)->cur_start = nullptr;                                                                           \
+        } else {                                                                                                \
+            hipLaunchKernelGGL(kernel, grid, block, shm, (c)->stream, __VA_ARGS__);                             \
+        }                                                                                                       \
+    } while (0)
 
 static int check_matvec_shape(size_t width, size_t rows) {
     REQUIRE(width % 4 == 0, RAMA_EINVAL, "matmul: width % 4 != 0 (the reference CPU body panics here, cpu.rs:142-143)");
@@ -254,7 +270,7 @@ static int launch_rows(rama_ctx* c, float* o, const float* W, const float* x, co
     if (rc) return rc;
     GemvParams p{};
     p.w[0] = W; p.x = x; p.nw = nw; p.o[0] = o; p.K = K; p.rows = rows; p.nmat = 1;
-    DISPATCH_GEOM(c, hipLaunchKernelGGL((gemv_rows<R_, CH_, NW_, NORM, EPI>), dim3((rows + R_ - 1) / R_), dim3(NW_ * 64), 0, c->stream, p));
+    DISPATCH_GEOM(c, RAMA_LAUNCH(c, (gemv_rows<R_, CH_, NW_, NORM, EPI>), dim3((rows + R_ - 1) / R_), dim3(NW_ * 64), 0, p));
     LAUNCHCHK();
     return 0;
 }
@@ -352,9 +368,9 @@ static int launch_attention(rama_ctx* c, float* xb, float* att, const float* q, 
         const int chunk_max = (seq_len + nsplit - 1) / nsplit;
         size_t shm = (size_t)(attn_scratch_floats(G) + chunk_max) * sizeof(float);
         dim3 grid(n_heads, nsplit);
-        if (G == 16) hipLaunchKernelGGL((attention_kernel<16, true>), grid, dim3(kAttnThreads), shm, c->stream, p);
-        else if (G == 32) hipLaunchKernelGGL((attention_kernel<32, true>), grid, dim3(kAttnThreads), shm, c->stream, p);
-        else hipLaunchKernelGGL((attention_kernel<64, true>), grid, dim3(kAttnThreads), shm, c->stream, p);
+        if (G == 16) RAMA_LAUNCH(c, (attention_kernel<16, true>), grid, dim3(kAttnThreads), shm, p);
+        else if (G == 32) RAMA_LAUNCH(c, (attention_kernel<32, true>), grid, dim3(kAttnThreads), shm, p);
+        else RAMA_LAUNCH(c, (attention_kernel<64, true>), grid, dim3(kAttnThreads), shm, p);
         LAUNCHCHK();
         hipLaunchKernelGGL(attention_combine_kernel, dim3(n_heads), dim3(((head_size + 63) / 64) * 64), 0, c->stream,
                            (const float*)c->attn_part, xb, head_size, nsplit);
@@ -363,9 +379,9 @@ static int launch_attention(rama_ctx* c, float* xb, float* att, const float* q, 
     }
     size_t shm = (size_t)(attn_scratch_floats(G) + seq_len) * sizeof(float);
     REQUIRE(shm <= 64 * 1024, RAMA_EUNSUP, "attention: seq_len too long for the single-workgroup kernel");
-    if (G == 16) hipLaunchKernelGGL((attention_kernel<16, false>), dim3(n_heads), dim3(kAttnThreads), shm, c->stream, p);
-    else if (G == 32) hipLaunchKernelGGL((attention_kernel<32, false>), dim3(n_heads), dim3(kAttnThreads), shm, c->stream, p);
-    else hipLaunchKernelGGL((attention_kernel<64, false>), dim3(n_heads), dim3(kAttnThreads), shm, c->stream, p);
+    if (G == 16) RAMA_LAUNCH(c, (attention_kernel<16, false>), dim3(n_heads), dim3(kAttnThreads), shm, p);
+    else if (G == 32) RAMA_LAUNCH(c, (attention_kernel<32, false>), dim3(n_heads), dim3(kAttnThreads), shm, p);
+    else RAMA_LAUNCH(c, (attention_kernel<64, false>), dim3(n_heads), dim3(kAttnThreads), shm, p);
     LAUNCHCHK();
     return 0;
 }
@@ -501,7 +517,7 @@ static int enqueue_stage(rama_ctx* c, const rama_config* cfg, const rama_weights
             p.ctl = c->ctl; p.fr = w->freq_cis_real; p.fi = w->freq_cis_imag; p.head_size = hs;
             p.kc = kc; p.vc = vc;
             p.zero_me = c->attn_counter;
-            DISPATCH_GEOM(c, hipLaunchKernelGGL((gemv_rows<R_, CH_, NW_, true, EPI_QKV>), dim3(3 * (dim / R_)), dim3(NW_ * 64), 0, c->stream, p));
+            DISPATCH_GEOM(c, RAMA_LAUNCH(c, (gemv_rows<R_, CH_, NW_, true, EPI_QKV>), dim3(3 * (dim / R_)), dim3(NW_ * 64), 0, p));
             LAUNCHCHK();
         }
         bool merged = false;
@@ -526,7 +542,7 @@ static int enqueue_stage(rama_ctx* c, const rama_config* cfg, const rama_weights
             SwigluParams p{};
             p.w1 = w->w1 + li * hd; p.w3 = w->w3 + li * hd; p.x = s->x; p.nw = w->rms_ffn_weight + li * dim;
             p.hb = s->hb; p.K = dim; p.rows = hidden;
-            DISPATCH_GEOM(c, hipLaunchKernelGGL((gemv_swiglu<R2_, CH_, NW_>), dim3((hidden + R2_ - 1) / R2_), dim3(NW_ * 64), 0, c->stream, p));
+            DISPATCH_GEOM(c, RAMA_LAUNCH(c, (gemv_swiglu<R2_, CH_, NW_>), dim3((hidden + R2_ - 1) / R2_), dim3(NW_ * 64), 0, p));
             LAUNCHCHK();
         }
         {   // infer.rs:46-47: x += W2 . hb
@@ -826,9 +842,7 @@ int rama_kprof_enable(rama_ctx* c, int kernel_id, int max_records) {
     REQUIRE(c && kernel_id >= 0 && kernel_id < RAMA_K_COUNT && max_records > 0, RAMA_EINVAL, "kprof_enable: bad argument");
     KProf& k = c->kp;
     while ((int)k.ev.size() < 2 * max_records) {
-        // no system-scope fence per record: the brackets sit between dependent kernels and a
-        // host-visible flush at each one would inflate the very interval being measured
-        hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableSystemFence)); k.ev.push_back(e);
+        hipEvent_t e; HIPCHK(hipEventCreate(&e)); k.ev.push_back(e);
     }
     k.kernel_id = kernel_id; k.max_records = max_records; k.used = 0;
     return 0;
