@@ -364,3 +364,40 @@ def test_decode_steps_needs_begin_and_bounds(dev):
     with pytest.raises(rama_amd.RamaError):      # 3 steps from seq_len - 2 would overrun the cache
         check(dev.lib.rama_decode_steps(dev.ctx, C.byref(rcfg.c()), C.byref(wv.c()), C.byref(rstate), 3))
     rs.free(); ws.free()
+
+
+# ------------------------------------------------------------------ BASELINE.json shapes (full width, full vocab)
+
+FULL_SHAPES = {   # dim, hidden, layers, heads, vocab, seq_len, shared classifier
+    "stories15M": (288, 768, 6, 6, 32000, 256, True),
+    "stories110M": (768, 2048, 12, 12, 32000, 1024, True),
+    "llama2-7B-2layers": (4096, 11008, 2, 32, 32000, 2048, False),
+}
+
+
+@pytest.mark.parametrize("shape", list(FULL_SHAPES))
+def test_full_shape_logits_vs_oracle(dev, shape):
+    """BASELINE.json configs at their real widths and vocabulary (synthetic weights generated in
+    HBM, bit-identical to the oracle's): the generate() loop on 'once upon a time', logits of
+    every step within 1e-4 of the oracle, greedy tokens identical."""
+    import rama_amd
+    d, h, L, H, V, seq, shared = FULL_SHAPES[shape]
+    cfg = O.Config(d, h, L, H, H, V, seq, shared)
+    rope = S.rope_tables(seq, d // H)
+    w = S.synth_weights(cfg, 0, rope=rope)
+    orc = O.Oracle(cfg, w)
+    rcfg = to_rama_cfg(cfg)
+    model = rama_amd.Model.synth(dev, rcfg, 0, rope=rope)
+    eng = rama_amd.Engine(dev, model)
+    prompt = [10646, 2501, 263, 931]          # Rama-BPE of 'once upon a time'
+    steps = 10 if d < 4096 else 6
+    token, worst = 1, 0.0
+    for pos in range(steps):
+        lo = orc.forward(token, pos)
+        eng.forward(token, pos)
+        worst = max(worst, float(np.abs(eng.logits() - lo).max()))
+        token = prompt[pos] if pos < len(prompt) else O.argmax(lo)
+    assert worst <= LOGIT_ATOL, f"{shape}: {worst:.3e}"
+    eng2 = rama_amd.Engine(dev, model)
+    assert eng2.generate_greedy(prompt, steps) == O.Oracle(cfg, w).generate_greedy(prompt, steps)
+    eng.free(); eng2.free(); model.free()
