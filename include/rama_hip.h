@@ -156,6 +156,12 @@ int  rama_forward(rama_ctx *ctx, const rama_config *cfg, const rama_weights *w,
 int  rama_forward_stage(rama_ctx *ctx, const rama_config *cfg, const rama_weights *w,
                         rama_run_state *s, int token, int pos, const rama_stage *stage);
 
+/* Batched-prompt prefill (no reference counterpart): the same state as
+ * n_tokens calls rama_forward(tokens[i], pos0 + i) -- KV-cache rows pos0..pos0+n-1 of every layer,
+ * residual x and logits of the LAST position -- with the weights streamed once per 8 positions. */
+int  rama_prefill(rama_ctx *ctx, const rama_config *cfg, const rama_weights *w, rama_run_state *s,
+                  const int32_t *tokens_host, int n_tokens, int pos0);
+
 /* Layer-pipeline stage variants (no reference counterpart: the reference is single-device).
  * The token id is read from / written to DEVICE memory, so a stage boundary is one RCCL
  * send/recv of x[dim] (and of one int32 from the last stage back to the first) with no host
@@ -183,6 +189,8 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
 /* Performance knobs (results are unaffected up to fp32 summation order).  Keys:
  *   "geom" = 0..3 : matvec workgroup geometry (rows per workgroup, waves, chunks per step);
  *                   3 is the shipping choice, see rama_api.hip DISPATCH_GEOM
+ *   "prefill" = 0|1 : 1 (default) lets rama_generate_greedy push the forced prompt positions through
+ *                   rama_prefill (8 positions per weight pass) instead of one forward per token
  *   "merge" = 0|1   : 1 runs attention and the Wo matvec as one launch when the occupancy API says
  *                   its whole grid is resident (Wo's weights stream while attention runs).
  *                   Measured +0.9 % at short and -2.5 % at 1000-token contexts: off by default

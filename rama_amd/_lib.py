@@ -81,6 +81,7 @@ SIGNATURES = {
     "rama_fill_synth": (_int, [_vp, _vp, _sz, C.c_uint64, C.c_uint64, C.c_uint64, C.c_float, C.c_float]),
     "rama_forward": (_int, [_vp, _cfgp, _wp, _sp, _int, _int]),
     "rama_forward_stage": (_int, [_vp, _cfgp, _wp, _sp, _int, _int, _stp]),
+    "rama_prefill": (_int, [_vp, _cfgp, _wp, _sp, i32p, _int, _int]),
     "rama_forward_stage_devtok": (_int, [_vp, _cfgp, _wp, _sp, _vp, _int, _stp]),
     "rama_argmax_dev": (_int, [_vp, _vp, _sz, _vp]),
     "rama_generate_greedy": (_int, [_vp, _cfgp, _wp, _sp, i32p, _int, _int, i32p]),

@@ -359,6 +359,8 @@ struct AttnParams {
     // [s*chunk, (s+1)*chunk) and writes an un-normalised partial {max, sum, acc[hs]} to part
     float* part;          // [n_heads, nsplit, head_size + 4]
     int nsplit;
+    // batched queries (prefill): blockIdx.z = query index; query z sits at position pos + z
+    int q_stride, xb_stride;
 };
 
 constexpr int kAttnWaves = 16;
@@ -378,7 +380,8 @@ __global__ __launch_bounds__(kAttnThreads) void attention_kernel(AttnParams p) {
     constexpr int TILE = kAttnWaves * TPW * U;        // timesteps per workgroup round
     const int h = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pos = p.ctl ? p.ctl->pos : p.pos_val;
+    const int zq = (int)blockIdx.z;
+    const int pos = (p.ctl ? p.ctl->pos : p.pos_val) + zq;
     const int hs = p.head_size;
     // timesteps [t0, t1) of this workgroup: everything, or one slice in split-T mode
     int t0 = 0, t1 = pos + 1;
@@ -400,7 +403,7 @@ __global__ __launch_bounds__(kAttnThreads) void attention_kernel(AttnParams p) {
     auto off_of = [&](int t) { return (lane_ok && t < t1) ? (unsigned)t * rowb + col : kOOB; };
 
     f4 q4 = {0.f, 0.f, 0.f, 0.f};
-    if (lane_ok) q4 = *reinterpret_cast<const f4*>(p.q + (size_t)h * hs + (size_t)li * 4);
+    if (lane_ok) q4 = *reinterpret_cast<const f4*>(p.q + (size_t)zq * p.q_stride + (size_t)h * hs + (size_t)li * 4);
     const float div = sqrtf((float)hs);
 
     f4 kt[U], vt[U];
@@ -504,7 +507,7 @@ __global__ __launch_bounds__(kAttnThreads) void attention_kernel(AttnParams p) {
             *reinterpret_cast<f4*>(o + 4 + (size_t)tid * 4) = t8[0];
             if (tid == 0) { o[0] = mx; o[1] = sum; }
         } else {
-            *reinterpret_cast<f4*>(p.xb + (size_t)h * hs + (size_t)tid * 4) = t8[0];
+            *reinterpret_cast<f4*>(p.xb + (size_t)zq * p.xb_stride + (size_t)h * hs + (size_t)tid * 4) = t8[0];
         }
     }
 }

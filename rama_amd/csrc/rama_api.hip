@@ -3,6 +3,7 @@
 #include "../../include/rama_hip.h"
 #include "kernels.hpp"
 #include "persist.hpp"
+#include "prefill.hpp"
 
 #include <hip/hip_ext.h>   // hipExtLaunchKernelGGL: start/stop events carried by the dispatch itself
 
@@ -72,12 +73,15 @@ struct rama_ctx {
     hipEvent_t cur_start = nullptr, cur_stop = nullptr;   // events the next profiled launch carries
     int tune_geom = 3;
     int tune_persist = 0;                  // 1: decode steps run as one persistent launch (persist.hpp)
+    int tune_prefill = 1;                  // 1: rama_generate_greedy runs the forced prompt positions through rama_prefill
     int tune_merge = 0;                    // 1: attention + Wo in one launch when the whole grid is resident (+0.9 % short, -2.5 % long contexts: off)
     int merge_blocks_per_cu[3] = {-1, -1, -1};   // occupancy of attn_wo_kernel<16|32|64> at the LDS size below
     size_t merge_lds[3] = {0, 0, 0};
     unsigned* attn_counter = nullptr;      // device: arrivals of the attention workgroups
     float* attn_part = nullptr;            // split-T partials [n_heads, nsplit, head_size + 4]
     size_t attn_part_floats = 0;
+    float* pf_blob = nullptr;              // prefill scratch: X, Q, K, V, XB [PB, dim], HB [PB, hidden], tokens [PB]
+    size_t pf_floats = 0;
     int host_pos = -1;                     // position of the next chained decode step (mirrors the device cursor)
     bool split_attn = false;               // variant the steps being enqueued / captured use
     unsigned long long* pbar = nullptr;    // device: [0] barrier counter, [1] error word, [2] epoch
@@ -140,7 +144,7 @@ int rama_ctx_destroy(rama_ctx* c) {
     hipStreamSynchronize(c->stream);
     drop_graph(c);
     for (auto e : c->kp.ev) hipEventDestroy(e);
-    hipFree(c->ctl); hipFree(c->out); hipFree(c->forced); hipFree(c->argmax_result); hipFree(c->pbar); hipFree(c->attn_counter); hipFree(c->attn_part);
+    hipFree(c->ctl); hipFree(c->out); hipFree(c->forced); hipFree(c->argmax_result); hipFree(c->pbar); hipFree(c->attn_counter); hipFree(c->attn_part); hipFree(c->pf_blob);
     hipHostFree(c->pinned_int);
     hipEventDestroy(c->t0); hipEventDestroy(c->t1);
     if (c->own_stream) hipStreamDestroy(c->stream);
@@ -619,6 +623,82 @@ int rama_forward(rama_ctx* c, const rama_config* cfg, const rama_weights* w, ram
     return rama_forward_stage(c, cfg, w, s, token, pos, &st);
 }
 
+// ---- batched-prompt prefill (prefill.hpp): n positions pos0..pos0+n-1 through the layers PB at a time
+int rama_prefill(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s,
+                 const int32_t* tokens_host, int n_tokens, int pos0) {
+    REQUIRE(c && tokens_host, RAMA_EINVAL, "prefill: NULL argument");
+    int rc = check_cfg(cfg); if (rc) return rc;
+    rama_stage st{0, cfg->n_layers, 1, 1};
+    rc = check_stage(cfg, w, s, &st); if (rc) return rc;
+    REQUIRE(n_tokens >= 1 && pos0 >= 0 && pos0 + n_tokens <= cfg->seq_len, RAMA_EINVAL, "prefill: positions outside [0, seq_len)");
+    for (int i = 0; i < n_tokens; i++) REQUIRE(tokens_host[i] >= 0 && tokens_host[i] < cfg->vocab_size, RAMA_EINVAL, "prefill: token outside the vocabulary");
+    const int dim = cfg->dim, hidden = cfg->hidden_dim, hs = dim / cfg->n_heads;
+    const size_t dd = (size_t)dim * dim, hd = (size_t)hidden * dim;
+    const size_t need = (size_t)kPB * (5 * (size_t)dim + hidden) + 64;
+    if (need > c->pf_floats) {
+        if (c->pf_blob) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->pf_blob)); c->pf_blob = nullptr; }
+        HIPCHK(hipMalloc(&c->pf_blob, need * sizeof(float)));
+        c->pf_floats = need;
+    }
+    float* X = c->pf_blob; float* Q = X + (size_t)kPB * dim; float* KS = Q + (size_t)kPB * dim; float* VS = KS + (size_t)kPB * dim;
+    float* XB = VS + (size_t)kPB * dim; float* HB = XB + (size_t)kPB * dim; int* toks = reinterpret_cast<int*>(HB + (size_t)kPB * hidden);
+    c->embedded_x = nullptr; c->host_pos = -1;
+    int last_nt = 0;
+    for (int c0 = 0; c0 < n_tokens; c0 += kPB) {
+        const int nt = std::min(kPB, n_tokens - c0), p0 = pos0 + c0;
+        last_nt = nt;
+        HIPCHK(hipMemcpyAsync(toks, tokens_host + c0, sizeof(int) * nt, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(embed_mt_kernel, dim3((dim + 255) / 256, nt), dim3(256), 0, c->stream, X, w->token_embedding_table, (const int*)toks, nt, dim);
+        LAUNCHCHK();
+        for (int layer = 0; layer < cfg->n_layers; layer++) {
+            const size_t li = (size_t)layer;
+            float* kc = s->key_cache + li * cfg->seq_len * dim;
+            float* vc = s->value_cache + li * cfg->seq_len * dim;
+            MtParams p{};
+            p.n_tok = nt; p.pos0 = p0; p.fr = w->freq_cis_real; p.fi = w->freq_cis_imag; p.head_size = hs; p.kc = kc; p.vc = vc;
+            // infer.rs:19-33 for PB positions
+            p.w[0] = w->wq + li * dd; p.w[1] = w->wk + li * dd; p.w[2] = w->wv + li * dd;
+            p.x = X; p.x_stride = dim; p.nw = w->rms_att_weight + li * dim;
+            p.o[0] = Q; p.o[1] = KS; p.o[2] = VS; p.o_stride = dim; p.K = dim; p.rows = dim; p.nmat = 3; p.epi = EPI_QKV;
+            hipLaunchKernelGGL((gemm_mt_rows<true, EPI_QKV>), dim3(3 * ((dim + 3) / 4)), dim3(kMtThreads), 0, c->stream, p);
+            LAUNCHCHK();
+            {   // infer.rs:34 for PB queries: query z attends to positions 0..p0+z
+                AttnParams a{};
+                a.q = Q; a.kc = kc; a.vc = vc; a.att = nullptr; a.xb = XB; a.ctl = nullptr; a.pos_val = p0;
+                a.dim = dim; a.head_size = hs; a.seq_len = cfg->seq_len; a.q_stride = dim; a.xb_stride = dim;
+                const int G = hs <= 64 ? 16 : (hs <= 128 ? 32 : 64);
+                size_t shm = (size_t)(attn_scratch_floats(G) + cfg->seq_len) * sizeof(float);
+                REQUIRE(shm <= 64 * 1024, RAMA_EUNSUP, "prefill: seq_len too long for the single-workgroup attention kernel");
+                dim3 grid(cfg->n_heads, 1, nt);
+                if (G == 16) hipLaunchKernelGGL((attention_kernel<16, false>), grid, dim3(kAttnThreads), shm, c->stream, a);
+                else if (G == 32) hipLaunchKernelGGL((attention_kernel<32, false>), grid, dim3(kAttnThreads), shm, c->stream, a);
+                else hipLaunchKernelGGL((attention_kernel<64, false>), grid, dim3(kAttnThreads), shm, c->stream, a);
+                LAUNCHCHK();
+            }
+            // infer.rs:35-37
+            p.w[0] = w->wo + li * dd; p.x = XB; p.x_stride = dim; p.nw = nullptr; p.o[0] = X; p.o_stride = dim;
+            p.K = dim; p.rows = dim; p.nmat = 1; p.epi = EPI_RESID;
+            hipLaunchKernelGGL((gemm_mt_rows<false, EPI_RESID>), dim3((dim + 3) / 4), dim3(kMtThreads), 0, c->stream, p);
+            LAUNCHCHK();
+            // infer.rs:39-45
+            p.w[0] = w->w1 + li * hd; p.w[1] = w->w3 + li * hd; p.x = X; p.x_stride = dim; p.nw = w->rms_ffn_weight + li * dim;
+            p.o[0] = HB; p.o_stride = hidden; p.K = dim; p.rows = hidden; p.nmat = 1; p.epi = 3;
+            hipLaunchKernelGGL((gemm_mt_rows<true, 3>), dim3((hidden + 1) / 2), dim3(kMtThreads), 0, c->stream, p);
+            LAUNCHCHK();
+            // infer.rs:46-47
+            p.w[0] = w->w2 + li * hd; p.x = HB; p.x_stride = hidden; p.nw = nullptr; p.o[0] = X; p.o_stride = dim;
+            p.K = hidden; p.rows = dim; p.nmat = 1; p.epi = EPI_RESID;
+            hipLaunchKernelGGL((gemm_mt_rows<false, EPI_RESID>), dim3((dim + 3) / 4), dim3(kMtThreads), 0, c->stream, p);
+            LAUNCHCHK();
+        }
+    }
+    // the last position's residual stream, then infer.rs:49-51 for it only (generate() ignores the
+    // logits of the forced positions before it)
+    hipLaunchKernelGGL(copy_kernel, dim3(ew_grid(dim)), dim3(256), 0, c->stream, s->x, (const float*)(X + (size_t)(last_nt - 1) * dim), (size_t)dim);
+    LAUNCHCHK();
+    return launch_rows<true, EPI_STORE>(c, s->logits, w->wcls, s->x, w->rms_final_weight, dim, cfg->vocab_size);
+}
+
 // ---- device-chained greedy decode (generate() at T == 0, mod.rs:169-206)
 
 int rama_decode_begin(rama_ctx* c, int token, int pos, const int32_t* forced_host, int n_forced) {
@@ -758,16 +838,49 @@ int rama_generate_greedy(rama_ctx* c, const rama_config* cfg, const rama_weights
     REQUIRE(c && cfg && out_host, RAMA_EINVAL, "generate_greedy: NULL argument");
     REQUIRE(steps >= 0 && steps <= cfg->seq_len, RAMA_EINVAL, "generate_greedy: steps > seq_len (the reference does not bound-check, SURVEY section 5)");
     REQUIRE(steps <= c->out_cap, RAMA_EINVAL, "generate_greedy: too many steps");
-    int rc = rama_decode_begin(c, /*BOS*/ 1, 0, prompt_host, std::min(n_prompt, c->forced_cap));
-    if (rc) return rc;
-    rc = rama_decode_steps(c, cfg, w, s, steps);
-    if (rc) return rc;
+    REQUIRE(n_prompt >= 0 && (n_prompt == 0 || prompt_host), RAMA_EINVAL, "generate_greedy: bad prompt");
+    n_prompt = std::min(n_prompt, c->forced_cap);
+    int rc;
+    if (c->tune_prefill && n_prompt >= 3 && steps > n_prompt && !c->tune_persist) {
+        // Positions 0..n_prompt carry known tokens (BOS, then the prompt; mod.rs:182-191) and their
+        // `next` is forced, so they go through the layers together (rama_prefill); the logits of
+        // position n_prompt give the first sampled token and the chained loop takes over.
+        std::vector<int32_t> toks(n_prompt + 1);
+        toks[0] = 1;
+        for (int i = 0; i < n_prompt; i++) toks[i + 1] = prompt_host[i];
+        for (int i = 0; i < n_prompt; i++) REQUIRE(prompt_host[i] >= 0 && prompt_host[i] < cfg->vocab_size, RAMA_EINVAL, "generate_greedy: prompt token outside the vocabulary");
+        rc = rama_prefill(c, cfg, w, s, toks.data(), n_prompt + 1, 0);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(c->out, prompt_host, sizeof(int) * n_prompt, hipMemcpyHostToDevice, c->stream));   // forced `next`s
+        hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(1), 0, c->stream, c->ctl, toks[n_prompt], n_prompt, 0, n_prompt);
+        LAUNCHCHK();
+        ArgmaxParams ap{};
+        ap.logits = s->logits; ap.n = cfg->vocab_size;
+        ap.ctl = c->ctl; ap.forced = c->forced; ap.out = c->out; ap.out_cap = c->out_cap;
+        ap.emb = w->token_embedding_table; ap.x = s->x; ap.dim = cfg->dim;
+        hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, c->stream, ap);     // out[n_prompt], cursor -> n_prompt + 1, next x
+        LAUNCHCHK();
+        c->embedded_x = s->x;
+        c->host_pos = n_prompt + 1;
+        rc = rama_decode_steps(c, cfg, w, s, steps - n_prompt - 1);
+        if (rc) return rc;
+    } else {
+        rc = rama_decode_begin(c, /*BOS*/ 1, 0, prompt_host, n_prompt);
+        if (rc) return rc;
+        rc = rama_decode_steps(c, cfg, w, s, steps);
+        if (rc) return rc;
+    }
     int n = 0;
     return rama_decode_tokens(c, out_host, steps, &n);
 }
 
 int rama_set_tuning(rama_ctx* c, const char* key, int value) {
     REQUIRE(c && key, RAMA_EINVAL, "set_tuning: NULL argument");
+    if (!strcmp(key, "prefill")) {
+        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: prefill must be 0 or 1");
+        c->tune_prefill = value;
+        return 0;
+    }
     if (!strcmp(key, "merge")) {
         REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: merge must be 0 or 1");
         c->tune_merge = value;
