@@ -660,7 +660,7 @@ int rama_prefill(rama_ctx* c, const rama_config* cfg, const rama_weights* w, ram
             p.w[0] = w->wq + li * dd; p.w[1] = w->wk + li * dd; p.w[2] = w->wv + li * dd;
             p.x = X; p.x_stride = dim; p.nw = w->rms_att_weight + li * dim;
             p.o[0] = Q; p.o[1] = KS; p.o[2] = VS; p.o_stride = dim; p.K = dim; p.rows = dim; p.nmat = 3; p.epi = EPI_QKV;
-            hipLaunchKernelGGL((gemm_mt_rows<true, EPI_QKV>), dim3(3 * ((dim + 3) / 4)), dim3(kMtThreads), 0, c->stream, p);
+            if (p.K <= kMtOneStepK) { hipLaunchKernelGGL((gemm_mt_rows<true, EPI_QKV, kMtSub, true>), dim3(3 * ((dim + mt_rows_per_wg(false) - 1) / mt_rows_per_wg(false))), dim3(kMtThreads), 0, c->stream, p); } else { hipLaunchKernelGGL((gemm_mt_rows<true, EPI_QKV, kMtSub, false>), dim3(3 * ((dim + mt_rows_per_wg(false) - 1) / mt_rows_per_wg(false))), dim3(kMtThreads), 0, c->stream, p); }
             LAUNCHCHK();
             {   // infer.rs:34 for PB queries: query z attends to positions 0..p0+z
                 AttnParams a{};
@@ -678,17 +678,17 @@ int rama_prefill(rama_ctx* c, const rama_config* cfg, const rama_weights* w, ram
             // infer.rs:35-37
             p.w[0] = w->wo + li * dd; p.x = XB; p.x_stride = dim; p.nw = nullptr; p.o[0] = X; p.o_stride = dim;
             p.K = dim; p.rows = dim; p.nmat = 1; p.epi = EPI_RESID;
-            hipLaunchKernelGGL((gemm_mt_rows<false, EPI_RESID>), dim3((dim + 3) / 4), dim3(kMtThreads), 0, c->stream, p);
+            if (p.K <= kMtOneStepK) { hipLaunchKernelGGL((gemm_mt_rows<false, EPI_RESID, kMtSub, true>), dim3((dim + mt_rows_per_wg(false) - 1) / mt_rows_per_wg(false)), dim3(kMtThreads), 0, c->stream, p); } else { hipLaunchKernelGGL((gemm_mt_rows<false, EPI_RESID, kMtSub, false>), dim3((dim + mt_rows_per_wg(false) - 1) / mt_rows_per_wg(false)), dim3(kMtThreads), 0, c->stream, p); }
             LAUNCHCHK();
             // infer.rs:39-45
             p.w[0] = w->w1 + li * hd; p.w[1] = w->w3 + li * hd; p.x = X; p.x_stride = dim; p.nw = w->rms_ffn_weight + li * dim;
             p.o[0] = HB; p.o_stride = hidden; p.K = dim; p.rows = hidden; p.nmat = 1; p.epi = 3;
-            hipLaunchKernelGGL((gemm_mt_rows<true, 3>), dim3((hidden + 1) / 2), dim3(kMtThreads), 0, c->stream, p);
+            if (p.K <= kMtOneStepK) { hipLaunchKernelGGL((gemm_mt_rows<true, 3, kMtSub, true>), dim3((hidden + mt_rows_per_wg(true) - 1) / mt_rows_per_wg(true)), dim3(kMtThreads), 0, c->stream, p); } else { hipLaunchKernelGGL((gemm_mt_rows<true, 3, kMtSub, false>), dim3((hidden + mt_rows_per_wg(true) - 1) / mt_rows_per_wg(true)), dim3(kMtThreads), 0, c->stream, p); }
             LAUNCHCHK();
             // infer.rs:46-47
             p.w[0] = w->w2 + li * hd; p.x = HB; p.x_stride = hidden; p.nw = nullptr; p.o[0] = X; p.o_stride = dim;
             p.K = hidden; p.rows = dim; p.nmat = 1; p.epi = EPI_RESID;
-            hipLaunchKernelGGL((gemm_mt_rows<false, EPI_RESID>), dim3((dim + 3) / 4), dim3(kMtThreads), 0, c->stream, p);
+            if (p.K <= kMtOneStepK) { hipLaunchKernelGGL((gemm_mt_rows<false, EPI_RESID, kMtSub, true>), dim3((dim + mt_rows_per_wg(false) - 1) / mt_rows_per_wg(false)), dim3(kMtThreads), 0, c->stream, p); } else { hipLaunchKernelGGL((gemm_mt_rows<false, EPI_RESID, kMtSub, false>), dim3((dim + mt_rows_per_wg(false) - 1) / mt_rows_per_wg(false)), dim3(kMtThreads), 0, c->stream, p); }
             LAUNCHCHK();
         }
     }
