@@ -191,6 +191,8 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *                   3 is the shipping choice, see rama_api.hip DISPATCH_GEOM
  *   "prefill" = 0|1 : 1 (default) lets rama_generate_greedy push the forced prompt positions through
  *                   rama_prefill (8 positions per weight pass) instead of one forward per token
+ *   "prefill_rounds" = 1..64 : rama_prefill cuts each matrix launch into this many even rounds
+ *                   over the CUs (default 1, the measured best: 42 ms vs 50 ms at 8 rounds)
  *   "merge" = 0|1   : 1 runs attention and the Wo matvec as one launch when the occupancy API says
  *                   its whole grid is resident (Wo's weights stream while attention runs).
  *                   Measured +0.9 % at short and -2.5 % at 1000-token contexts: off by default

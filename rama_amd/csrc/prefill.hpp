@@ -27,6 +27,7 @@ struct MtParams {
     float* o[3];           // outputs [PB, o_stride] (QKV: q, k-scratch, v-scratch)
     int o_stride;
     int K, rows, nmat, n_tok;
+    int nsub;              // sub-groups (4 rows / 2 (w1,w3) pairs each) per workgroup, >= 1
     int epi;               // EPI_STORE / EPI_RESID / EPI_QKV, or 3 = SwiGLU (w[0] = w1, w[1] = w3)
     int pos0;              // position of token 0 (EPI_QKV)
     const float* fr; const float* fi; int head_size;
@@ -83,27 +84,25 @@ __device__ __forceinline__ void wave_sum32(float (&v)[32]) {
 }
 __device__ __forceinline__ int mt_value_of_lane(int lane) { return (lane >> 1) & 31; }
 
-// One workgroup = NSUB sub-groups of 4 rows (2 (w1,w3) pairs) x PB tokens.  When a row fits one
-// step (K <= 16 chunks) each wave keeps ITS chunks of the PB activation vectors in registers across
-// the sub-groups, so they are read from L2 once per 4*NSUB rows instead of once per 4 rows; wider
-// rows (W2: K = hidden) re-read them per step.
-template <bool NORM, int EPI, int NSUB, bool ONE>
+// One workgroup = p.nsub consecutive sub-groups of 4 rows (2 (w1,w3) pairs) x PB tokens; sub-groups
+// are numbered across the launch's matrices (Q, K, V), so the host can cut any launch into one even
+// round over the CUs.  When a row fits one step (K <= 16 chunks, ONE) each wave keeps ITS chunks of
+// the PB activation vectors in registers across its sub-groups, so they are read from L2 once per
+// workgroup instead of once per 4 rows; wider rows (W2: K = hidden) re-read them per step.
+template <bool NORM, int EPI, bool ONE>
 __global__ __launch_bounds__(kMtThreads) void gemm_mt_rows(MtParams p) {
     constexpr int S = 4, CH = 2;
     constexpr bool PAIR = EPI == 3;
     __shared__ float part[2][kMtWaves][S][kPB];
     __shared__ float part_ss[kMtWaves][kPB];
     const int rows_per_sub = PAIR ? 2 : 4;
-    const int rows_per_wg = rows_per_sub * NSUB;
-    const int gpm = (p.rows + rows_per_wg - 1) / rows_per_wg;
-    const int m = PAIR ? 0 : blockIdx.x / gpm;
-    const int rbase = (blockIdx.x - m * gpm) * rows_per_wg;
+    const int spm = (p.rows + rows_per_sub - 1) / rows_per_sub;     // sub-groups per matrix
+    const int total = (PAIR ? 1 : p.nmat) * spm;
+    const int g0 = blockIdx.x * p.nsub;
+    const int nsub = min(p.nsub, total - g0);                        // uniform, >= 1 (host sizes the grid)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nch = (p.K + 255) >> 8;
     const unsigned kbytes = (unsigned)p.K * 4u, mbytes = (unsigned)p.rows * kbytes;
-    const float* Wa = PAIR ? p.w[0] : (m == 0 ? p.w[0] : (m == 1 ? p.w[1] : p.w[2]));
-    const float* Wb = PAIR ? p.w[1] : Wa;
-    const __amdgpu_buffer_rsrc_t ra = make_rsrc(Wa, mbytes), rb = make_rsrc(Wb, mbytes);
     const __amdgpu_buffer_rsrc_t rn = make_rsrc(NORM ? p.nw : p.x, kbytes);
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (unsigned)(p.n_tok * p.x_stride) * 4u);
     constexpr bool one_step = ONE;          // host guarantees nch <= CH * kMtWaves when set
@@ -134,10 +133,13 @@ __global__ __launch_bounds__(kMtThreads) void gemm_mt_rows(MtParams p) {
     // free the w registers and BEFORE that sub-group's reduction / epilogue, which then overlap
     // the HBM latency even with one resident workgroup per CU
     const int nsteps = one_step ? 1 : (nch + CH * kMtWaves - 1) / (CH * kMtWaves);
-    const int nsub = min(NSUB, (p.rows - rbase + rows_per_sub - 1) / rows_per_sub);   // uniform, >= 1
     f4 w[S][CH];
     auto load_w = [&](int sub, int st) {
-        const int r0 = rbase + sub * rows_per_sub;
+        const int g = g0 + sub;
+        const int m = PAIR ? 0 : g / spm;
+        const int r0 = (g - m * spm) * rows_per_sub;
+        const float* Wa = PAIR ? p.w[0] : (m == 0 ? p.w[0] : (m == 1 ? p.w[1] : p.w[2]));
+        const __amdgpu_buffer_rsrc_t ra = make_rsrc(Wa, mbytes), rb = make_rsrc(PAIR ? p.w[1] : Wa, mbytes);
 #pragma unroll
         for (int j = 0; j < CH; j++) {
             const int ci = wave + (st * CH + j) * kMtWaves;
@@ -153,7 +155,8 @@ __global__ __launch_bounds__(kMtThreads) void gemm_mt_rows(MtParams p) {
     load_w(0, 0);
 #pragma unroll 1
     for (int sub = 0; sub < nsub; sub++) {
-        const int r0 = rbase + sub * rows_per_sub;
+        const int m = PAIR ? 0 : (g0 + sub) / spm;
+        const int r0 = (g0 + sub - m * spm) * rows_per_sub;
         f2 acc[S][kPB];                 // .x sums the even elements of a float4, .y the odd ones (v_pk_fma_f32)
 #pragma unroll
         for (int s = 0; s < S; s++)
@@ -262,9 +265,7 @@ __global__ __launch_bounds__(kMtThreads) void gemm_mt_rows(MtParams p) {
     }
 }
 
-constexpr int kMtSub = 4;
 constexpr int kMtOneStepK = 2 * kMtWaves * 256;   // widest row (floats) the register-resident-activation variant takes
-__host__ __device__ constexpr int mt_rows_per_wg(bool pair) { return (pair ? 2 : 4) * kMtSub; }
 
 // X[t] = token_embedding_table[tokens[t]]   (infer.rs:13 per prompt position)
 __global__ void embed_mt_kernel(float* X, const float* emb, const int* tokens, int n_tok, int dim) {

@@ -73,6 +73,7 @@ struct rama_ctx {
     hipEvent_t cur_start = nullptr, cur_stop = nullptr;   // events the next profiled launch carries
     int tune_geom = 3;
     int tune_persist = 0;                  // 1: decode steps run as one persistent launch (persist.hpp)
+    int tune_pf_rounds = 1;                // prefill launches are cut into this many even rounds over the CUs
     int tune_prefill = 1;                  // 1: rama_generate_greedy runs the forced prompt positions through rama_prefill
     int tune_merge = 0;                    // 1: attention + Wo in one launch when the whole grid is resident (+0.9 % short, -2.5 % long contexts: off)
     int merge_blocks_per_cu[3] = {-1, -1, -1};   // occupancy of attn_wo_kernel<16|32|64> at the LDS size below
@@ -623,6 +624,22 @@ int rama_forward(rama_ctx* c, const rama_config* cfg, const rama_weights* w, ram
     return rama_forward_stage(c, cfg, w, s, token, pos, &st);
 }
 
+// One prefill launch: cut the launch's sub-groups (4 rows x PB tokens each) into `tune_pf_rounds`
+// even rounds over the CUs -- the kernels hold one workgroup per CU (register-resident activations),
+// so a grid that is not a multiple of the CU count idles part of the chip for a whole round.
+template <bool NORM, int EPI>
+static int launch_mt(rama_ctx* c, MtParams& p) {
+    const int rows_per_sub = EPI == 3 ? 2 : 4;
+    const int total = (EPI == 3 ? 1 : p.nmat) * ((p.rows + rows_per_sub - 1) / rows_per_sub);
+    const int slots = std::max(1, c->cu_count) * std::max(1, c->tune_pf_rounds);
+    p.nsub = std::max(1, (total + slots - 1) / slots);
+    const int grid = (total + p.nsub - 1) / p.nsub;
+    if (p.K <= kMtOneStepK) hipLaunchKernelGGL((gemm_mt_rows<NORM, EPI, true>), dim3(grid), dim3(kMtThreads), 0, c->stream, p);
+    else hipLaunchKernelGGL((gemm_mt_rows<NORM, EPI, false>), dim3(grid), dim3(kMtThreads), 0, c->stream, p);
+    LAUNCHCHK();
+    return 0;
+}
+
 // ---- batched-prompt prefill (prefill.hpp): n positions pos0..pos0+n-1 through the layers PB at a time
 int rama_prefill(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s,
                  const int32_t* tokens_host, int n_tokens, int pos0) {
@@ -660,8 +677,7 @@ int rama_prefill(rama_ctx* c, const rama_config* cfg, const rama_weights* w, ram
             p.w[0] = w->wq + li * dd; p.w[1] = w->wk + li * dd; p.w[2] = w->wv + li * dd;
             p.x = X; p.x_stride = dim; p.nw = w->rms_att_weight + li * dim;
             p.o[0] = Q; p.o[1] = KS; p.o[2] = VS; p.o_stride = dim; p.K = dim; p.rows = dim; p.nmat = 3; p.epi = EPI_QKV;
-            if (p.K <= kMtOneStepK) { hipLaunchKernelGGL((gemm_mt_rows<true, EPI_QKV, kMtSub, true>), dim3(3 * ((dim + mt_rows_per_wg(false) - 1) / mt_rows_per_wg(false))), dim3(kMtThreads), 0, c->stream, p); } else { hipLaunchKernelGGL((gemm_mt_rows<true, EPI_QKV, kMtSub, false>), dim3(3 * ((dim + mt_rows_per_wg(false) - 1) / mt_rows_per_wg(false))), dim3(kMtThreads), 0, c->stream, p); }
-            LAUNCHCHK();
+            rc = launch_mt<true, EPI_QKV>(c, p); if (rc) return rc;
             {   // infer.rs:34 for PB queries: query z attends to positions 0..p0+z
                 AttnParams a{};
                 a.q = Q; a.kc = kc; a.vc = vc; a.att = nullptr; a.xb = XB; a.ctl = nullptr; a.pos_val = p0;
@@ -678,18 +694,15 @@ int rama_prefill(rama_ctx* c, const rama_config* cfg, const rama_weights* w, ram
             // infer.rs:35-37
             p.w[0] = w->wo + li * dd; p.x = XB; p.x_stride = dim; p.nw = nullptr; p.o[0] = X; p.o_stride = dim;
             p.K = dim; p.rows = dim; p.nmat = 1; p.epi = EPI_RESID;
-            if (p.K <= kMtOneStepK) { hipLaunchKernelGGL((gemm_mt_rows<false, EPI_RESID, kMtSub, true>), dim3((dim + mt_rows_per_wg(false) - 1) / mt_rows_per_wg(false)), dim3(kMtThreads), 0, c->stream, p); } else { hipLaunchKernelGGL((gemm_mt_rows<false, EPI_RESID, kMtSub, false>), dim3((dim + mt_rows_per_wg(false) - 1) / mt_rows_per_wg(false)), dim3(kMtThreads), 0, c->stream, p); }
-            LAUNCHCHK();
+            rc = launch_mt<false, EPI_RESID>(c, p); if (rc) return rc;
             // infer.rs:39-45
             p.w[0] = w->w1 + li * hd; p.w[1] = w->w3 + li * hd; p.x = X; p.x_stride = dim; p.nw = w->rms_ffn_weight + li * dim;
             p.o[0] = HB; p.o_stride = hidden; p.K = dim; p.rows = hidden; p.nmat = 1; p.epi = 3;
-            if (p.K <= kMtOneStepK) { hipLaunchKernelGGL((gemm_mt_rows<true, 3, kMtSub, true>), dim3((hidden + mt_rows_per_wg(true) - 1) / mt_rows_per_wg(true)), dim3(kMtThreads), 0, c->stream, p); } else { hipLaunchKernelGGL((gemm_mt_rows<true, 3, kMtSub, false>), dim3((hidden + mt_rows_per_wg(true) - 1) / mt_rows_per_wg(true)), dim3(kMtThreads), 0, c->stream, p); }
-            LAUNCHCHK();
+            rc = launch_mt<true, 3>(c, p); if (rc) return rc;
             // infer.rs:46-47
             p.w[0] = w->w2 + li * hd; p.x = HB; p.x_stride = hidden; p.nw = nullptr; p.o[0] = X; p.o_stride = dim;
             p.K = hidden; p.rows = dim; p.nmat = 1; p.epi = EPI_RESID;
-            if (p.K <= kMtOneStepK) { hipLaunchKernelGGL((gemm_mt_rows<false, EPI_RESID, kMtSub, true>), dim3((dim + mt_rows_per_wg(false) - 1) / mt_rows_per_wg(false)), dim3(kMtThreads), 0, c->stream, p); } else { hipLaunchKernelGGL((gemm_mt_rows<false, EPI_RESID, kMtSub, false>), dim3((dim + mt_rows_per_wg(false) - 1) / mt_rows_per_wg(false)), dim3(kMtThreads), 0, c->stream, p); }
-            LAUNCHCHK();
+            rc = launch_mt<false, EPI_RESID>(c, p); if (rc) return rc;
         }
     }
     // the last position's residual stream, then infer.rs:49-51 for it only (generate() ignores the
@@ -876,6 +889,11 @@ int rama_generate_greedy(rama_ctx* c, const rama_config* cfg, const rama_weights
 
 int rama_set_tuning(rama_ctx* c, const char* key, int value) {
     REQUIRE(c && key, RAMA_EINVAL, "set_tuning: NULL argument");
+    if (!strcmp(key, "prefill_rounds")) {
+        REQUIRE(value >= 1 && value <= 64, RAMA_EINVAL, "set_tuning: prefill_rounds must be in 1..64");
+        c->tune_pf_rounds = value;
+        return 0;
+    }
     if (!strcmp(key, "prefill")) {
         REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: prefill must be 0 or 1");
         c->tune_prefill = value;
