@@ -138,6 +138,315 @@ __global__ __launch_bounds__(256) void gemv_waverow(const float* W, const float*
     }
 }
 
+
+// ---- variant C: one round of resident workgroups pulling R-row groups from an atomic queue.
+//   The first D groups of a workgroup are static (blockIdx + s * gridDim), later ones come from
+//   the counter; a group's weight loads are issued D iterations before its FMAs (register ring),
+//   the id of the group to fetch next travels through LDS behind the reduction's barrier.
+//   K must fit one step (K <= CH * NW * 256).  ctr[0] = queue head, ctr[1] = finished workgroups;
+//   the last workgroup to leave resets both.
+template <int R, int CH, int NW, int D>
+__global__ __launch_bounds__(NW * 64) void gemv_queue(const float* W, const float* x, float* o, int K, int rows, unsigned* ctr) {
+    __shared__ float part[2][NW][R];
+    __shared__ int ids[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(W, (unsigned)rows * (unsigned)K * 4u);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (unsigned)K * 4u);
+    const int nch = (K + 255) >> 8;
+    const unsigned kbytes = (unsigned)K * 4u;
+    const int ngroups = (rows + R - 1) / R;
+    const int nwg = gridDim.x;
+    unsigned kb[CH]; f4 xv[CH];
+#pragma unroll
+    for (int j = 0; j < CH; j++) {
+        const int ci = wave + j * NW;
+        const unsigned b = (unsigned)(ci * 1024 + lane * 16);
+        kb[j] = (ci < nch && b < kbytes) ? b : kOOB;
+        xv[j] = ldw<0>(rx, kb[j]);
+    }
+    f4 w[D][R][CH];
+    int gid[D];
+    auto issue = [&](int s, int g) {
+        gid[s] = g;
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int row = g * R + r;
+                w[s][r][j] = ldw<2>(ra, (g >= ngroups || row >= rows || kb[j] == kOOB) ? kOOB : (unsigned)row * kbytes + kb[j]);
+            }
+    };
+    int next_id = 0;
+    if (threadIdx.x == 0) next_id = (int)atomicAdd(&ctr[0], 1u) + D * nwg;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < D; s++) issue(s, blockIdx.x + s * nwg);
+    int par = 0;
+    bool live = true;
+    while (live) {
+#pragma unroll
+        for (int s = 0; s < D; s++) {
+            const int g = gid[s];
+            if (g >= ngroups) { live = false; break; }
+            float acc[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = 0.f;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < CH; j++)
+#pragma unroll
+                for (int r = 0; r < R; r++) acc[r] = dot4(w[s][r][j], xv[j], acc[r]);
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = wave_sum(acc[r]);
+            if (lane == 0) {
+#pragma unroll
+                for (int r = 0; r < R; r++) part[par][wave][r] = acc[r];
+            }
+            if (threadIdx.x == 0) ids[par] = next_id;
+            __syncthreads();
+            const int nid = ids[par];
+            if (threadIdx.x == 0) next_id = (int)atomicAdd(&ctr[0], 1u) + D * nwg;
+            __builtin_amdgcn_sched_barrier(0);
+            issue(s, nid);
+            __builtin_amdgcn_sched_barrier(0);
+            if (threadIdx.x < R && g * R + threadIdx.x < rows) {
+                float d = 0.f;
+#pragma unroll
+                for (int q = 0; q < NW; q++) d += part[par][q][threadIdx.x];
+                o[g * R + threadIdx.x] = d;
+            }
+            par ^= 1;
+        }
+    }
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        if (next_id == -12345) o[0] = 0.f;             // keeps the last atomic's return alive
+        if (atomicAdd(&ctr[1], 1u) == (unsigned)nwg - 1) { ctr[0] = 0; ctr[1] = 0; }
+    }
+}
+
+
+// ---- variant D: one round of resident workgroups pulling R-row groups from 8 atomic queues
+//   (groups cut into 8 contiguous ranges, one head per 128-byte line; a workgroup uses queue
+//   blockIdx & 7 = its XCD under round-robin dispatch).  The first D groups of a workgroup are
+//   static, later ones are tickets.  Register ring of depth D: the weight loads AND the ticket
+//   atomic of a slot are issued D iterations before they are consumed.
+//   All vector-memory traffic inside the loop is inline asm with MANUAL s_waitcnt: hipcc's waitcnt
+//   insertion drains vmcnt to 0 in this loop shape (and always does once a store is pending next
+//   to loads), which collapses the ring to depth 1.  Per slot the issue order is
+//   [ticket atomic, R*CH loads], so "slot s has landed" == vmcnt <= (D-1) * (R*CH + 1).
+//   Results stay in LDS until the queue is dry (no store inside the loop).
+//   ctr[q * 32] = head of queue q, ctr[8 * 32] = finished workgroups (last one resets all).
+// s_waitcnt vmcnt(N) only (expcnt / lgkmcnt left at their maxima); the builtin form is an S_WAITCNT the
+// compiler's own waitcnt pass accounts for
+template <int N> __device__ __forceinline__ void wait_vm() {
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | (((N >> 4) & 3) << 14));
+}
+__device__ __forceinline__ f4 asm_load_nt(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    f4 v;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen nt" : "=v"(v) : "v"(off), "s"(r) : "memory");
+    return v;
+}
+__device__ __forceinline__ unsigned asm_ticket(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    unsigned v = 1;
+    asm volatile("buffer_atomic_add %0, %1, %2, 0 offen sc0" : "+v"(v) : "v"(off), "s"(r) : "memory");
+    return v;
+}
+template <int R, int CH, int NW, int D, bool STATIC = false>
+__global__ __launch_bounds__(NW * 64) void gemv_queue8(const float* W, const float* x, float* o, int K, int rows, unsigned* ctr) {
+    __shared__ float part[2][NW][R];
+    __shared__ int ids[2];
+    constexpr int kOutCap = 128;
+    __shared__ float out_val[kOutCap][R];
+    __shared__ int out_gid[kOutCap];
+    int n_out = 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(W, (unsigned)rows * (unsigned)K * 4u);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (unsigned)K * 4u);
+    const int nch = (K + 255) >> 8;
+    const unsigned kbytes = (unsigned)K * 4u;
+    const int ngroups = (rows + R - 1) / R;
+    const int per_q = (ngroups + 7) >> 3;
+    unsigned kb[CH]; f4 xv[CH];
+#pragma unroll
+    for (int j = 0; j < CH; j++) {
+        const int ci = wave + j * NW;
+        const unsigned b = (unsigned)(ci * 1024 + lane * 16);
+        kb[j] = (ci < nch && b < kbytes) ? b : kOOB;
+        xv[j] = ldw<0>(rx, kb[j]);
+    }
+    const int q = blockIdx.x & 7, rank = blockIdx.x >> 3, nwg_q = gridDim.x >> 3;
+    const int q_lim = (ngroups - q + 7) >> 3;      // queue q hands out groups q, q + 8, q + 16, ... (the chip sweeps ONE window)
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(ctr + q * 32, 4u);
+    const unsigned tk_off = threadIdx.x == 0 ? 0u : kOOB;
+    // xv must have landed before the manual waits start counting
+    wait_vm<0>();
+    f4 w[D][R][CH];
+    unsigned pending[D];
+    int gid[D];
+    // branch-free addressing: an exhausted slot (g clamped to ngroups) and a chunk beyond K both
+    // land at or above the descriptor's size, where buffer loads return 0
+    auto issue = [&](int s, int g) {
+        gid[s] = g;
+        pending[s] = STATIC ? 0u : asm_ticket(rq, tk_off);
+        const unsigned gbase = (unsigned)min(g, ngroups) * (unsigned)R * kbytes;
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+#pragma unroll
+            for (int r = 0; r < R; r++) w[s][r][j] = asm_load_nt(ra, gbase + (unsigned)r * kbytes + kb[j]);
+    };
+    auto resolve = [&](unsigned ticket) -> int {
+        const int t = D * nwg_q + (int)ticket;
+        return t < q_lim ? t * 8 + q : 0x7fffffff;
+    };
+#pragma unroll
+    for (int s = 0; s < D; s++) {
+        const int t = s * nwg_q + rank;
+        issue(s, t < q_lim ? t * 8 + q : 0x7fffffff);
+    }
+    int par = 0;
+    bool live = true;
+    while (live) {
+#pragma unroll
+        for (int s = 0; s < D; s++) {
+            const int g = gid[s];
+            if (g >= ngroups) { live = false; break; }
+            wait_vm<(D - 1) * (R * CH + (STATIC ? 0 : 1))>();
+            // tie the slot's registers to the wait so no use can be scheduled above it
+#pragma unroll
+            for (int j = 0; j < CH; j++)
+#pragma unroll
+                for (int r = 0; r < R; r++) asm volatile("" : "+v"(w[s][r][j]));
+            asm volatile("" : "+v"(pending[s]));
+            float acc[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = 0.f;
+#pragma unroll
+            for (int j = 0; j < CH; j++)
+#pragma unroll
+                for (int r = 0; r < R; r++) acc[r] = dot4(w[s][r][j], xv[j], acc[r]);
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = wave_sum(acc[r]);
+            if (lane == 0) {
+#pragma unroll
+                for (int r = 0; r < R; r++) part[par][wave][r] = acc[r];
+            }
+            int nid;
+            if (STATIC) { __syncthreads(); const int t = (n_out + D) * nwg_q + rank; nid = t < q_lim ? t * 8 + q : 0x7fffffff; }
+            else { if (threadIdx.x == 0) ids[par] = resolve(pending[s]); __syncthreads(); nid = ids[par]; }
+            issue(s, nid);
+            if (threadIdx.x < R) {
+                float d = 0.f;
+#pragma unroll
+                for (int qq = 0; qq < NW; qq++) d += part[par][qq][threadIdx.x];
+                out_val[n_out][threadIdx.x] = d;
+                if (threadIdx.x == 0) out_gid[n_out] = g;
+            }
+            n_out++;
+            par ^= 1;
+            if (n_out == kOutCap) { live = false; break; }      // bench only: never reached at these sizes
+        }
+    }
+    wait_vm<0>();
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_out * R; i += NW * 64) {
+        const int row = out_gid[i / R] * R + (i % R);
+        if (row < rows) o[row] = out_val[i / R][i % R];
+    }
+    if (threadIdx.x == 0) {
+        if (atomicAdd(&ctr[8 * 32], 1u) == gridDim.x - 1) {
+            for (int i = 0; i <= 8; i++) ctr[i * 32] = 0;
+        }
+    }
+}
+
+// ---- variant E: two DEPENDENT matvecs (o1 = A.x, o2 = B.o1[0:K]) as one launch.  The workgroups of
+//   B come after those of A in blockIdx order, so (in-order dispatch per XCD) they only take slots
+//   that A no longer needs; each streams its 64 KiB of B FIRST (weights never depend on
+//   activations), then waits for the "A done" flag, then reads o1 with sc1 loads.  HBM never drains
+//   between the two matvecs.  Producer side: o1 rows are written with sc1 (write-through) stores,
+//   wave 0 drains vmcnt and takes a ticket on one of 16 arrival counters; the last arrival of a
+//   counter takes a ticket on the top counter, the last of those raises the flag.  sync[] layout
+//   (unsigned, one 128-byte line each): [0..15] arrival counters, [16] top, [17] flag, [18] error.
+//   Counters are monotonic over launches: launch number `epoch` (1, 2, ...) is a kernel argument.
+__device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <int R, int CH, int NW>
+__global__ __launch_bounds__(NW * 64) void gemv_chain(const float* A, const float* B, const float* x, float* o1, float* o2,
+                                                      int K, int rowsA, int rowsB, unsigned* sync, unsigned epoch) {
+    __shared__ float part[NW][R];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nA = (rowsA + R - 1) / R;
+    const bool second = (int)blockIdx.x >= nA;
+    const int g = second ? blockIdx.x - nA : blockIdx.x;
+    const float* W = second ? B : A;
+    const int rows = second ? rowsB : rowsA;
+    const int r0 = g * R;
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(W, (unsigned)rows * (unsigned)K * 4u);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(second ? o1 : x, (unsigned)K * 4u);
+    const int nch = (K + 255) >> 8;
+    const unsigned kbytes = (unsigned)K * 4u;
+    unsigned kb[CH]; f4 w[R][CH]; f4 xv[CH];
+#pragma unroll
+    for (int j = 0; j < CH; j++) {
+        const int ci = wave + j * NW;
+        const unsigned b = (unsigned)(ci * 1024 + lane * 16);
+        kb[j] = (ci < nch && b < kbytes) ? b : kOOB;
+    }
+#pragma unroll
+    for (int j = 0; j < CH; j++)
+#pragma unroll
+        for (int r = 0; r < R; r++) w[r][j] = ldw<2>(ra, (r0 + r < rows && kb[j] != kOOB) ? (unsigned)(r0 + r) * kbytes + kb[j] : kOOB);
+    __builtin_amdgcn_sched_barrier(0);
+    if (second) {
+        if (threadIdx.x == 0) {
+            long spins = 0;
+            while (__hip_atomic_load(&sync[17 * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1L << 20)) { sync[18 * 32] = 1u; break; }      // never hang the GPU
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < CH; j++) xv[j] = ldw<16>(rx, kb[j]);                 // sc1: written by other XCDs
+    } else {
+#pragma unroll
+        for (int j = 0; j < CH; j++) xv[j] = ldw<0>(rx, kb[j]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < CH; j++)
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] = dot4(w[r][j], xv[j], acc[r]);
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = wave_sum(acc[r]);
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < R; r++) part[wave][r] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        if (lane < R && r0 + lane < rows) {
+            float d = 0.f;
+#pragma unroll
+            for (int q = 0; q < NW; q++) d += part[q][lane];
+            if (second) o2[r0 + lane] = d; else st_sc1(&o1[r0 + lane], d);
+        }
+        if (!second) {
+            __builtin_amdgcn_s_waitcnt(0);                   // this wave's sc1 stores have left
+            if (lane == 0) {
+                const int c = blockIdx.x & 15;
+                const unsigned n_c = (unsigned)((nA - c + 15) >> 4);
+                if (atomicAdd(&sync[c * 32], 1u) == epoch * n_c - 1u)
+                    if (atomicAdd(&sync[16 * 32], 1u) == epoch * 16u - 1u)
+                        __hip_atomic_store(&sync[17 * 32], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
 // ---- pure read bandwidth probe: every workgroup streams a contiguous slab, sums it
 template <int CH, int AUX>
 __global__ __launch_bounds__(256) void read_probe(const float* W, float* o, size_t n_f4_per_block) {
@@ -166,6 +475,19 @@ void launch_waverow(const float* W, const float* x, float* o, int K, int rows, h
     hipLaunchKernelGGL((gemv_waverow<R, CH, AUX>), dim3((rows + 4 * R - 1) / (4 * R)), dim3(256), 0, s, W, x, o, K, rows);
 }
 
+static unsigned* g_ctr = nullptr;
+template <int R, int CH, int NW, int D, int WGPC>
+void launch_queue(const float* W, const float* x, float* o, int K, int rows, hipStream_t s) {
+    if (K > CH * NW * 256) return;
+    hipLaunchKernelGGL((gemv_queue<R, CH, NW, D>), dim3(256 * WGPC), dim3(NW * 64), 0, s, W, x, o, K, rows, g_ctr);
+}
+
+template <int R, int CH, int NW, int D, int WGPC, bool STATIC = false>
+void launch_queue8(const float* W, const float* x, float* o, int K, int rows, hipStream_t s) {
+    if (K > CH * NW * 256) return;
+    hipLaunchKernelGGL((gemv_queue8<R, CH, NW, D, STATIC>), dim3(256 * WGPC), dim3(NW * 64), 0, s, W, x, o, K, rows, g_ctr);
+}
+
 int main(int argc, char** argv) {
     int iters = argc > 1 ? atoi(argv[1]) : 40;
     CK(hipSetDevice(0));
@@ -191,7 +513,22 @@ int main(int argc, char** argv) {
         {"ksplit R2 CH4 NW2 inter  nt", launch_ksplit<2, 4, 2, 1, 2>},
         {"ksplit R2 CH8 NW2 inter  nt", launch_ksplit<2, 8, 2, 1, 2>},
         {"ksplit R2 CH4 NW16 inter nt", launch_ksplit<2, 4, 16, 1, 2>},
+        {"queue R4 CH2 NW8 D2 x1", launch_queue<4, 2, 8, 2, 1>},
+        {"queue8 R4 CH2 NW8 D2 x1", launch_queue8<4, 2, 8, 2, 1>},
+        {"queue8 R4 CH2 NW8 D3 x1", launch_queue8<4, 2, 8, 3, 1>},
+        {"queue8 R4 CH2 NW8 D4 x1", launch_queue8<4, 2, 8, 4, 1>},
+        {"queue8 R4 CH2 NW8 D2 x2", launch_queue8<4, 2, 8, 2, 2>},
+        {"queue8 R4 CH2 NW8 D3 x2", launch_queue8<4, 2, 8, 3, 2>},
+        {"static8 R4 CH2 NW8 D2 x1", launch_queue8<4, 2, 8, 2, 1, true>},
+        {"static8 R4 CH2 NW8 D3 x1", launch_queue8<4, 2, 8, 3, 1, true>},
+        {"static8 R4 CH2 NW8 D2 x2", launch_queue8<4, 2, 8, 2, 2, true>},
+        {"static8 R4 CH2 NW8 D1 x4", launch_queue8<4, 2, 8, 1, 4, true>},
+        {"queue8 R4 CH2 NW8 D1 x4", launch_queue8<4, 2, 8, 1, 4>},
+        {"queue8 R4 CH2 NW8 D1 x3", launch_queue8<4, 2, 8, 1, 3>},
+        {"queue8 R4 CH2 NW8 D2 x3", launch_queue8<4, 2, 8, 2, 3>},
+        {"queue8 R2 CH2 NW8 D2 x4", launch_queue8<2, 2, 8, 2, 4>},
     };
+    CK(hipMalloc(&g_ctr, 4096)); CK(hipMemset(g_ctr, 0, 4096));
     struct Shape { const char* name; int rows, K; } shapes[] = {
         {"wo    4096x4096 ", 4096, 4096}, {"w2    4096x11008", 4096, 11008},
         {"w1    11008x4096", 11008, 4096}, {"qkv  12288x4096 ", 12288, 4096}, {"cls  32000x4096 ", 32000, 4096},
@@ -199,8 +536,8 @@ int main(int argc, char** argv) {
     const size_t max_bytes = (size_t)32000 * 4096 * 4;
     const int nbuf = 6;   // 6 x 524 MB = 3.1 GB rotation
     std::vector<float*> W(nbuf);
-    for (auto& p : W) { CK(hipMalloc(&p, max_bytes)); CK(hipMemset(p, 0x11, max_bytes)); }
-    float *x, *o; CK(hipMalloc(&x, 11008 * 4)); CK(hipMemset(x, 0, 11008 * 4)); CK(hipMalloc(&o, 32000 * 4));
+    for (auto& p : W) { CK(hipMalloc(&p, max_bytes)); CK(hipMemset(p, 0x3c, max_bytes)); }
+    float *x, *o; CK(hipMalloc(&x, 11008 * 4)); { std::vector<float> ones(11008, 1.0f); CK(hipMemcpy(x, ones.data(), 11008 * 4, hipMemcpyHostToDevice)); } CK(hipMalloc(&o, 32000 * 4));
     // read-bandwidth probe
     {
         size_t total = max_bytes / 16;   // f4 count
@@ -239,8 +576,48 @@ int main(int argc, char** argv) {
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1));
                 if (rep) { best = std::min(best, ms); sum += ms; cnt++; }
             }
+            // every row is the same sum of K equal weights: a row the variant skipped stays 0
+            CK(hipMemsetAsync(o, 0, 32000 * 4, st));
+            v.launch(W[0], x, o, sh.K, sh.rows, st);
+            std::vector<float> ho(sh.rows);
+            CK(hipMemcpyAsync(ho.data(), o, sh.rows * 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+            int bad = 0; float wv; unsigned bits = 0x3c3c3c3cu; memcpy(&wv, &bits, 4);
+            for (int r = 0; r < sh.rows; r++) if (!(fabsf(ho[r] - wv * sh.K) <= 1e-3f * wv * sh.K)) bad++;
             double us = best * 1e3 / iters;
+            if (bad) printf("  !! %d rows wrong in the next variant\n", bad);
             printf("  %-30s %8.2f us  %7.0f GB/s  (avg %.2f us)\n", v.name.c_str(), us, bytes / (us * 1e-6) / 1e9, sum / cnt * 1e3 / iters);
+        }
+    }
+    {   // dependent pair: qkv-shaped A (12288 x 4096) then wo-shaped B (4096 x 4096) on A's first 4096 outputs
+        const int K = 4096, rowsA = 12288, rowsB = 4096;
+        float* o1; CK(hipMalloc(&o1, rowsA * 4));
+        unsigned* sync; CK(hipMalloc(&sync, 32 * 32 * 4)); CK(hipMemset(sync, 0, 32 * 32 * 4)); unsigned epoch = 0;
+        size_t fa = (size_t)rowsA * K, fb = (size_t)rowsB * K;
+        for (int mode = 0; mode < 2; mode++) {
+            float best = 1e9;
+            for (int rep = 0; rep < 4; rep++) {
+                CK(hipEventRecord(e0, st));
+                for (int i = 0; i < iters; i++) {
+                    const float* A = W[i % nbuf]; const float* B = W[(i + 3) % nbuf] + fa;
+                    if (mode == 0) {
+                        launch_ksplit<4, 2, 8, 1, 2>(A, x, o1, K, rowsA, st);
+                        launch_ksplit<4, 2, 8, 1, 2>(B, o1, o, K, rowsB, st);
+                    } else {
+                        hipLaunchKernelGGL((gemv_chain<4, 2, 8>), dim3(rowsA / 4 + rowsB / 4), dim3(512), 0, st, A, B, x, o1, o, K, rowsA, rowsB, sync, ++epoch);
+                    }
+                }
+                CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                if (rep) best = std::min(best, ms);
+            }
+            std::vector<float> ho(rowsB); unsigned herr = 0;
+            CK(hipMemcpy(ho.data(), o, rowsB * 4, hipMemcpyDeviceToHost));
+            if (mode) CK(hipMemcpy(&herr, sync + 18 * 32, 4, hipMemcpyDeviceToHost));
+            float wv; unsigned bits = 0x3c3c3c3cu; memcpy(&wv, &bits, 4);
+            const float expect = wv * K * (wv * K) ;
+            int bad = 0; for (int r = 0; r < rowsB; r++) if (!(fabsf(ho[r] - expect) <= 1e-3f * expect)) bad++;
+            printf("dependent pair %s: %.2f us per pair (bytes %.1f MB -> %.0f GB/s)  bad rows %d  spin timeout %u\n", mode ? "one chained launch" : "two launches", best * 1e3 / iters,
+                   (fa + fb) * 4 / 1e6, (fa + fb) * 4.0 / (best * 1e-3 / iters) / 1e9, bad, herr);
         }
     }
     CK(hipGetLastError());
