@@ -132,6 +132,10 @@ int  rama_model_load(rama_ctx *ctx, const char *path, rama_model **out);
  * rope_real/rope_imag: host tables [seq_len, head_size/2] or NULL (computed here). */
 int  rama_model_synth(rama_ctx *ctx, const rama_config *cfg, uint64_t seed, const rama_stage *stage,
                       const float *rope_real_host, const float *rope_imag_host, rama_model **out);
+/* Write a whole model as a llama2.c v0 file -- the format engine/export/export.py:75-127
+ * (legacy_export) produces and transformer/ram.rs:28-51 reads, so upstream Rama loads it too
+ * (SURVEY section 8 row f2).  RAMA_EINVAL for a model that holds only a pipeline stage. */
+int  rama_model_save(rama_ctx *ctx, const rama_model *model, const char *path);
 int  rama_model_config(const rama_model *m, rama_config *cfg);
 int  rama_model_weights(const rama_model *m, rama_weights *w);
 size_t rama_model_bytes(const rama_model *m);

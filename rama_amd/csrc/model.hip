@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -178,6 +179,38 @@ extern "C" int rama_model_synth(rama_ctx* ctx, const rama_config* cfg, uint64_t 
     if (cfg->shared_weight && st.do_cls) m->w.wcls = m->w.token_embedding_table;
     if (!st.do_embed && !(st.do_cls && cfg->shared_weight)) m->w.token_embedding_table = nullptr;
     *out = m;
+    return 0;
+}
+
+// Write the model as a llama2.c v0 file (export.py:75-127 legacy_export = the layout ram.rs:28-51 reads):
+// 7 x i32 header with vocab_size negated when the classifier is not shared, then the tensors in
+// v0 order.  Only a whole model (every layer, embedding and classifier on this device) can be saved.
+extern "C" int rama_model_save(rama_ctx* ctx, const rama_model* m, const char* path) {
+    if (!ctx || !m || !path) return bad(RAMA_EINVAL, "rama_model_save: NULL argument");
+    const rama_config& c = m->cfg;
+    if (m->stage.layer_begin != 0 || m->stage.layer_end != c.n_layers || !m->stage.do_embed || !m->stage.do_cls)
+        return bad(RAMA_EINVAL, "rama_model_save: the model holds only a pipeline stage");
+    FILE* f = fopen(path, "wb");
+    if (!f) return bad(RAMA_EIO, "rama_model_save: cannot open the output file");
+    const int32_t hdr[7] = {c.dim, c.hidden_dim, c.n_layers, c.n_heads, c.n_kv_heads,
+                            c.shared_weight ? c.vocab_size : -c.vocab_size, c.seq_len};
+    bool ok = fwrite(hdr, sizeof(hdr), 1, f) == 1;
+    rama_weights w = m->w;
+    std::vector<float> buf;
+    const size_t chunk = (size_t)16 << 20;     // floats per D2H piece
+    for (auto& t : v0_layout(c)) {
+        const float* src = *field(w, t.name);
+        if (!src) { ok = false; break; }
+        for (size_t off = 0; ok && off < t.n; off += chunk) {
+            const size_t n = std::min(chunk, t.n - off);
+            buf.resize(n);
+            if (rama_download_f32(ctx, src + off, n, buf.data()) != 0) { ok = false; break; }
+            ok = fwrite(buf.data(), sizeof(float), n, f) == n;
+        }
+        if (!ok) break;
+    }
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) { remove(path); return bad(RAMA_EIO, "rama_model_save: write failed"); }
     return 0;
 }
 

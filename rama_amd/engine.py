@@ -59,6 +59,10 @@ class Model:
               "rama_model_synth")
         return Model(device, h, st)
 
+    def save(self, path):
+        """write the model as a llama2.c v0 .bin (export.py legacy layout; upstream Rama loads it)"""
+        check(self.device.lib.rama_model_save(self.device.ctx, self.handle, str(path).encode()), "rama_model_save")
+
     @property
     def bytes(self) -> int:
         return self.device.lib.rama_model_bytes(self.handle)
