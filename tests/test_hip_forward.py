@@ -500,3 +500,39 @@ def test_prefill_argument_errors(dev):
     with pytest.raises(rama_amd.RamaError):
         _prefill(dev, rcfg, wv, rsv, [cfg.vocab_size], 0)           # token outside the vocabulary
     rs.free(); ws.free()
+
+
+def test_concurrent_contexts_share_weights(dev):
+    """the server pattern (Threading): several host threads, one context (= one HIP
+    stream) and one run state each, the SAME read-only weights; every thread must produce the
+    tokens a lone run produces"""
+    import threading
+    import rama_amd
+    cfg, w, g = load_case("synth_d288_h6")
+    model = rama_amd.Model.synth(dev, to_rama_cfg(cfg), int(g["seed"]), rope=(g["freq_cis_real"], g["freq_cis_imag"]))
+    prompts = [[5, 9, 2], [17], [], [3, 3, 3, 3, 40, 41], [100, 7]]
+    steps = 24
+    solo = rama_amd.Engine(dev, model)
+    want = [solo.generate_greedy(p, steps) for p in prompts]
+    solo.free()
+    ctxs = [rama_amd.Hip(0) for _ in prompts]
+    engines = [rama_amd.Engine(c, model) for c in ctxs]
+    for i, e in enumerate(engines):
+        e.set_graph_mode(i % 2 == 0)          # graph replay and eager launches side by side
+    got, errs = [None] * len(prompts), []
+    start = threading.Barrier(len(prompts))
+
+    def run(i):
+        try:
+            start.wait()
+            for _ in range(3):
+                got[i] = engines[i].generate_greedy(prompts[i], steps)
+        except Exception as e:        # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=run, args=(i,)) for i in range(len(prompts))]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errs, errs
+    assert got == want
+    for e in engines: e.free()
+    model.free()
