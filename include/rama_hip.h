@@ -193,6 +193,8 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
 /* Performance knobs (results are unaffected up to fp32 summation order).  Keys:
  *   "geom" = 0..3 : matvec workgroup geometry (rows per workgroup, waves, chunks per step);
  *                   3 is the shipping choice, see rama_api.hip DISPATCH_GEOM
+ *   "resid_r2" = 0|1 : 1 (default) gives the two residual matvecs (Wo, W2) 2-row workgroups under
+ *                   geometry 3; measured +0.45 % tokens/s at llama2-7B, same tokens
  *   "prefill" = 0|1 : 1 (default) lets rama_generate_greedy push the forced prompt positions through
  *                   rama_prefill (8 positions per weight pass) instead of one forward per token
  *   "prefill_rounds" = 1..64 : rama_prefill cuts each matrix launch into this many even rounds

@@ -73,6 +73,7 @@ struct rama_ctx {
     hipEvent_t cur_start = nullptr, cur_stop = nullptr;   // events the next profiled launch carries
     int tune_geom = 3;
     int tune_persist = 0;                  // 1: decode steps run as one persistent launch (persist.hpp)
+    int tune_resid_r2 = 1;                 // 1: Wo / W2 use 2-row workgroups under the default geometry (+0.45 %)
     int tune_pf_rounds = 1;                // prefill launches are cut into this many even rounds over the CUs
     int tune_prefill = 1;                  // 1: rama_generate_greedy runs the forced prompt positions through rama_prefill
     int tune_merge = 0;                    // 1: attention + Wo in one launch when the whole grid is resident (+0.9 % short, -2.5 % long contexts: off)
@@ -275,6 +276,13 @@ static int launch_rows(rama_ctx* c, float* o, const float* W, const float* x, co
     if (rc) return rc;
     GemvParams p{};
     p.w[0] = W; p.x = x; p.nw = nw; p.o[0] = o; p.K = K; p.rows = rows; p.nmat = 1;
+    if (!NORM && EPI == EPI_RESID && c->tune_geom == 3 && c->tune_resid_r2) {
+        // the residual matvecs (Wo, W2) read no rmsnorm gain, so a 2-row workgroup's re-read of
+        // x is cheap and the finer grain balances better
+        RAMA_LAUNCH(c, (gemv_rows<2, 2, 8, NORM, EPI>), dim3((rows + 1) / 2), dim3(8 * 64), 0, p);
+        LAUNCHCHK();
+        return 0;
+    }
     DISPATCH_GEOM(c, RAMA_LAUNCH(c, (gemv_rows<R_, CH_, NW_, NORM, EPI>), dim3((rows + R_ - 1) / R_), dim3(NW_ * 64), 0, p));
     LAUNCHCHK();
     return 0;
@@ -889,6 +897,13 @@ int rama_generate_greedy(rama_ctx* c, const rama_config* cfg, const rama_weights
 
 int rama_set_tuning(rama_ctx* c, const char* key, int value) {
     REQUIRE(c && key, RAMA_EINVAL, "set_tuning: NULL argument");
+    if (!strcmp(key, "resid_r2")) {
+        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: resid_r2 must be 0 or 1");
+        c->tune_resid_r2 = value;
+        hipStreamSynchronize(c->stream);
+        drop_graph(c);
+        return 0;
+    }
     if (!strcmp(key, "prefill_rounds")) {
         REQUIRE(value >= 1 && value <= 64, RAMA_EINVAL, "set_tuning: prefill_rounds must be in 1..64");
         c->tune_pf_rounds = value;
