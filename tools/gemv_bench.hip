@@ -470,6 +470,14 @@ template <int R, int CH, int NW, int ASSIGN, int AUX>
 void launch_ksplit(const float* W, const float* x, float* o, int K, int rows, hipStream_t s) {
     hipLaunchKernelGGL((gemv_ksplit<R, CH, NW, ASSIGN, AUX>), dim3((rows + R - 1) / R), dim3(NW * 64), 0, s, W, x, o, K, rows);
 }
+// same kernel, occupancy capped by an unused dynamic-LDS reservation (160 KiB per CU)
+template <int R, int CH, int NW, int WGPC>
+void launch_ksplit_occ(const float* W, const float* x, float* o, int K, int rows, hipStream_t s) {
+    const size_t lds = WGPC == 3 ? 52 * 1024 : (WGPC == 2 ? 72 * 1024 : (WGPC == 1 ? 100 * 1024 : 0));
+    static bool once = [] { hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_ksplit<R, CH, NW, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); return true; }();
+    (void)once;
+    hipLaunchKernelGGL((gemv_ksplit<R, CH, NW, 1, 2>), dim3((rows + R - 1) / R), dim3(NW * 64), lds, s, W, x, o, K, rows);
+}
 template <int R, int CH, int AUX>
 void launch_waverow(const float* W, const float* x, float* o, int K, int rows, hipStream_t s) {
     hipLaunchKernelGGL((gemv_waverow<R, CH, AUX>), dim3((rows + 4 * R - 1) / (4 * R)), dim3(256), 0, s, W, x, o, K, rows);
@@ -513,6 +521,17 @@ int main(int argc, char** argv) {
         {"ksplit R2 CH4 NW2 inter  nt", launch_ksplit<2, 4, 2, 1, 2>},
         {"ksplit R2 CH8 NW2 inter  nt", launch_ksplit<2, 8, 2, 1, 2>},
         {"ksplit R2 CH4 NW16 inter nt", launch_ksplit<2, 4, 16, 1, 2>},
+        {"ksplit R4 CH2 NW8 occ3", launch_ksplit_occ<4, 2, 8, 3>},
+        {"ksplit R4 CH2 NW8 occ2", launch_ksplit_occ<4, 2, 8, 2>},
+        {"ksplit R6 CH2 NW8 occ2", launch_ksplit_occ<6, 2, 8, 2>},
+        {"ksplit R8 CH2 NW8 occ2", launch_ksplit_occ<8, 2, 8, 2>},
+        {"ksplit R2 CH2 NW8 occ3", launch_ksplit_occ<2, 2, 8, 3>},
+        {"ksplit R4 CH1 NW16 inter nt", launch_ksplit<4, 1, 16, 1, 2>},
+        {"ksplit R2 CH1 NW16 inter nt", launch_ksplit<2, 1, 16, 1, 2>},
+        {"ksplit R8 CH1 NW16 inter nt", launch_ksplit<8, 1, 16, 1, 2>},
+        {"ksplit R1 CH2 NW8 inter  nt", launch_ksplit<1, 2, 8, 1, 2>},
+        {"ksplit R3 CH2 NW8 inter  nt", launch_ksplit<3, 2, 8, 1, 2>},
+        {"ksplit R2 CH2 NW8 inter  --", launch_ksplit<2, 2, 8, 1, 0>},
         {"queue R4 CH2 NW8 D2 x1", launch_queue<4, 2, 8, 2, 1>},
         {"queue8 R4 CH2 NW8 D2 x1", launch_queue8<4, 2, 8, 2, 1>},
         {"queue8 R4 CH2 NW8 D3 x1", launch_queue8<4, 2, 8, 3, 1>},
