@@ -498,6 +498,7 @@ void launch_queue8(const float* W, const float* x, float* o, int K, int rows, hi
 
 int main(int argc, char** argv) {
     int iters = argc > 1 ? atoi(argv[1]) : 40;
+    const bool same_buf = argc > 2 && atoi(argv[2]) == 1;
     CK(hipSetDevice(0));
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -589,6 +590,7 @@ int main(int argc, char** argv) {
                 CK(hipEventRecord(e0, st));
                 for (int i = 0; i < iters; i++) {
                     int b = i % nbuf, sub = (i / nbuf) % per_buf;
+                    if (same_buf) { b = 0; sub = 0; }     // every launch re-reads ONE matrix: Infinity-Cache-resident if it fits
                     v.launch(W[b] + (size_t)sub * mat_floats, x, o, sh.K, sh.rows, st);
                 }
                 CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
