@@ -142,37 +142,49 @@ def main():
         return
 
     need = args.warmup + args.steps
-    if need > seq:
-        raise SystemExit(f"--warmup + --steps = {need} exceeds seq_len {seq}")
     dev = rama_amd.Hip(local_rank)
     model = rama_amd.Model.synth(dev, cfg, seed=0)
     eng = rama_amd.Engine(dev, model)
     dev.sync()
     bytes_ = rama_amd.algorithmic_bytes(cfg)
 
+    def run_steps(n, pos):
+        """n decode steps from position pos; a generation that reaches seq_len is followed by a new
+        one (BOS + prompt at position 0), so a run may be longer than the model's context"""
+        while n > 0:
+            if pos == seq:
+                eng.decode_begin(1, 0, PROMPT)
+                pos = 0
+            m = min(n, seq - pos)
+            eng.decode_steps(m)
+            n -= m
+            pos += m
+        return pos
+
     eng.set_graph_mode(bool(args.graph))
     eng.decode_begin(1, 0, PROMPT)
-    eng.decode_steps(args.warmup)
+    pos = run_steps(args.warmup, 0)
     dev.sync()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     eng.timer_start()
-    eng.decode_steps(args.steps)
+    pos = run_steps(args.steps, pos)
     ev_ms = eng.timer_stop()
     dev.sync()
     torch.cuda.synchronize()
     wall_ms = (time.perf_counter() - t0) * 1e3
     ms_per_step = wall_ms / args.steps
     tokens = eng.decode_tokens()
-    assert len(tokens) == need, (len(tokens), need)
+    assert len(tokens) == (need if need <= seq else pos), (len(tokens), need, pos)
 
     roofline, kernels = None, {}
     if not args.no_kprof:
         eng.set_graph_mode(False)   # per-launch event brackets need eager launches
-        ksteps = min(16, seq - need) if seq - need > 0 else 0
-        if ksteps:
+        ksteps = 16
+        kpos = min(pos, seq - ksteps)
+        if kpos >= 0:
             for k in ("qkv", "attn", "wo", "w13", "w2", "cls"):
-                eng.decode_begin(tokens[-1], need, [])
+                eng.decode_begin(tokens[-1] if tokens else 1, kpos, [])
                 avg_ms, n = eng.kprof(k, ksteps)
                 b = bytes_.get(k)
                 kernels[k] = {"avg_us": round(avg_ms * 1e3, 2), "launches": n,
@@ -195,7 +207,7 @@ def main():
         "value": round(tok_s, 3), "unit": "tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.config} fp32 decode, weights resident in HBM, greedy, pos {args.warmup}..{need - 1}",
+        "config": {"workload": f"{args.config} fp32 decode, weights resident in HBM, greedy, pos {args.warmup}..{need - 1}" + (" (wrapping at seq_len)" if need > seq else ""),
                    "dim": d, "hidden_dim": h, "n_layers": L, "n_heads": H, "vocab_size": V, "seq_len": seq,
                    "sequences_in_flight": 1, "parallelism": "single GPU", "hipgraph": bool(args.graph)},
         "token_level": {"algorithmic_bytes_per_token": bytes_["token"],

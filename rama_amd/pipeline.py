@@ -79,21 +79,24 @@ def split_layers(n_layers: int, world: int, rank: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def run_ticks(sched: Schedule, rank: int, backend, tick_from: int, tick_to: int, prompts, dist=None):
+def run_ticks(sched: Schedule, rank: int, backend, tick_from: int, tick_to: int, prompts, dist=None, wrap: int = 0):
     """Run ticks [tick_from, tick_to).  backend.compute(seq, pos, token) runs this rank's stage:
     token is an int (BOS / forced prompt token, rank 0 only) or None (= use tok_buffers[seq] on
-    rank 0; ignored elsewhere).  After the last rank's compute tok_buffers[seq] holds the argmax."""
+    rank 0; ignored elsewhere).  After the last rank's compute tok_buffers[seq] holds the argmax.
+    wrap > 0: a sequence that reaches position `wrap` (the model's seq_len) starts over at position 0
+    with BOS and its prompt -- a new generation in the same slot, so a run may be longer than seq_len."""
     for tick in range(tick_from, tick_to):
         it = sched.item(rank, tick)
         if it is not None:
+            pos = it.pos % wrap if wrap else it.pos
             token = None
             if rank == 0:
                 p = prompts[it.seq]
-                if it.pos == 0:
+                if pos == 0:
                     token = BOS                       # mod.rs:182
-                elif it.pos <= len(p):
-                    token = p[it.pos - 1]             # mod.rs:190-191 forced prompt token
-            backend.compute(it.seq, it.pos, token)
+                elif pos <= len(p):
+                    token = p[pos - 1]                # mod.rs:190-191 forced prompt token
+            backend.compute(it.seq, pos, token)
         if dist is None or sched.world == 1:
             if sched.world == 1 and it is not None:
                 pass   # single rank: tok_buffers[seq] already holds the next token
@@ -182,26 +185,24 @@ def run_pipeline_bench(args, cfg, rank: int, world: int, local_rank: int) -> dic
         dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
     n_seq = world
-    n_pos = args.warmup + args.steps
-    if n_pos > cfg.seq_len:
-        raise SystemExit(f"--warmup + --steps = {n_pos} exceeds seq_len {cfg.seq_len}")
+    n_pos = args.warmup + args.steps        # longer than seq_len: the slots start new generations (run_ticks wrap)
     backend = HipStage(cfg, rank, world, local_rank, n_seq, seed=0)
     sched = Schedule(world, n_seq, n_pos)
     prompts = [PROMPT for _ in range(n_seq)]
     t_warm = args.warmup * n_seq                     # ticks; >= world - 1 fills the pipe
     t_end = t_warm + args.steps * n_seq
-    assert t_warm >= world - 1, "warm-up too short to fill the pipeline"
-    run_ticks(sched, rank, backend, 0, t_warm, prompts, dist)
+    # t_warm < world - 1 (e.g. --warmup 0): the timed region then includes the pipeline fill
+    run_ticks(sched, rank, backend, 0, t_warm, prompts, dist, wrap=cfg.seq_len)
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run_ticks(sched, rank, backend, t_warm, t_end, prompts, dist)
+    run_ticks(sched, rank, backend, t_warm, t_end, prompts, dist, wrap=cfg.seq_len)
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    run_ticks(sched, rank, backend, t_end, sched.ticks, prompts, dist)   # drain, untimed
+    run_ticks(sched, rank, backend, t_end, sched.ticks, prompts, dist, wrap=cfg.seq_len)   # drain, untimed
     torch.cuda.synchronize()
     tmax = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", local_rank))
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -217,7 +218,7 @@ def run_pipeline_bench(args, cfg, rank: int, world: int, local_rank: int) -> dic
         reps = 8
         backend.check(L.rama_kprof_enable(backend.dev.ctx, 3, reps * n_local))
         for _ in range(reps):
-            backend.compute(0, n_pos - 1, BOS if rank == 0 else None)
+            backend.compute(0, (n_pos - 1) % cfg.seq_len, BOS if rank == 0 else None)
         n, tot = C.c_int(), C.c_double()
         backend.check(L.rama_kprof_read(backend.dev.ctx, C.byref(n), C.byref(tot)))
         if n.value:

@@ -136,3 +136,22 @@ def test_split_layers_covers_everything():
         assert parts[0][0] == 0 and parts[-1][1] == L
         assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
         assert max(h - l for l, h in parts) - min(h - l for l, h in parts) <= 1
+
+
+def test_run_ticks_wraps_at_seq_len():
+    """a run longer than seq_len: every slot starts a NEW generation (BOS, then its prompt) when
+    its position reaches `wrap`, and positions handed to the stage stay inside [0, wrap)"""
+    class Rec:
+        def __init__(self):
+            self.calls = []
+
+        def compute(self, seq, pos, token):
+            self.calls.append((seq, pos, token))
+    be = Rec()
+    sched = Schedule(1, 2, 7)
+    prompts = [[11, 12], []]
+    run_ticks(sched, 0, be, 0, sched.ticks, prompts, None, wrap=3)
+    seq0 = [(p, t) for s, p, t in be.calls if s == 0]
+    seq1 = [(p, t) for s, p, t in be.calls if s == 1]
+    assert seq0 == [(0, BOS), (1, 11), (2, 12), (0, BOS), (1, 11), (2, 12), (0, BOS)]
+    assert seq1 == [(0, BOS), (1, None), (2, None), (0, BOS), (1, None), (2, None), (0, BOS)]
