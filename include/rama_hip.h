@@ -193,6 +193,10 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
 /* Performance knobs (results are unaffected up to fp32 summation order).  Keys:
  *   "geom" = 0..3 : matvec workgroup geometry (rows per workgroup, waves, chunks per step);
  *                   3 is the shipping choice, see rama_api.hip DISPATCH_GEOM
+ *   "split_pos" = -1 | N : attention switches from one workgroup per head to the split-T variant
+ *                   (n_heads x nsplit workgroups + a combine launch) at position N; -1 (default)
+ *                   chooses by model size: 384 when one head's whole K+V cache exceeds 1 MiB
+ *                   (llama2-7B), never below that (stories15M / 110M), as measured
  *   "resid_r2" = 0|1 : 1 (default) gives the two residual matvecs (Wo, W2) 2-row workgroups under
  *                   geometry 3; measured +0.45 % tokens/s at llama2-7B, same tokens
  *   "prefill" = 0|1 : 1 (default) lets rama_generate_greedy push the forced prompt positions through

@@ -73,6 +73,7 @@ struct rama_ctx {
     hipEvent_t cur_start = nullptr, cur_stop = nullptr;   // events the next profiled launch carries
     int tune_geom = 3;
     int tune_persist = 0;                  // 1: decode steps run as one persistent launch (persist.hpp)
+    int tune_split_pos = -1;               // attention runs split-T (+ combine launch) from this position on; -1 = by model size
     int tune_resid_r2 = 1;                 // 1: Wo / W2 use 2-row workgroups under the default geometry (+0.45 %)
     int tune_pf_rounds = 1;                // prefill launches are cut into this many even rounds over the CUs
     int tune_prefill = 1;                  // 1: rama_generate_greedy runs the forced prompt positions through rama_prefill
@@ -364,6 +365,15 @@ static int ensure_attn_part(rama_ctx* c, const rama_config* cfg) {
 // Split-T attention is worth its extra (combine) launch once a head's cache no longer fits a
 // couple of single-workgroup rounds; below the threshold one workgroup per head is faster.
 constexpr int kSplitTPos = 384;
+// Measured (tools/split_sweep.py): at llama2-7B (32 heads x 128) splitting wins from ~position 400 on
+// (209 -> 212 tok/s at 600, 177 -> 205 at 1900); at the stories110M shape (12 heads x 64, 1024
+// positions) the single-workgroup kernel wins everywhere (2 837 vs 2 082 tok/s at 900), because
+// its whole per-head cache is a few rounds of one workgroup and the combine launch costs more.
+static int split_threshold(const rama_ctx* c, const rama_config* cfg) {
+    if (c->tune_split_pos >= 0) return c->tune_split_pos;
+    const long kv_bytes_per_pos = 2L * (cfg->dim / cfg->n_heads) * 4;          // one head's K + V row
+    return kv_bytes_per_pos * cfg->seq_len <= (1L << 20) ? (1 << 30) : kSplitTPos;   // whole head cache <= 1 MiB: never split
+}
 
 static int launch_attention(rama_ctx* c, float* xb, float* att, const float* q, const float* kc_layer,
                             const float* vc_layer, const Ctl* ctl, int pos, int dim, int head_size,
@@ -596,7 +606,7 @@ int rama_forward_stage(rama_ctx* c, const rama_config* cfg, const rama_weights* 
     LAUNCHCHK();
     c->embedded_x = nullptr;
     c->host_pos = -1;
-    c->split_attn = pos >= kSplitTPos;
+    c->split_attn = pos >= split_threshold(c, cfg);
     return enqueue_stage(c, cfg, w, s, st);
 }
 
@@ -613,7 +623,7 @@ int rama_forward_stage_devtok(rama_ctx* c, const rama_config* cfg, const rama_we
     LAUNCHCHK();
     c->embedded_x = nullptr;
     c->host_pos = -1;
-    c->split_attn = pos >= kSplitTPos;
+    c->split_attn = pos >= split_threshold(c, cfg);
     return enqueue_stage(c, cfg, w, s, st);
 }
 
@@ -809,7 +819,7 @@ int rama_decode_steps(rama_ctx* c, const rama_config* cfg, const rama_weights* w
     const bool graphs = c->graph_mode && c->kp.kernel_id < 0;
     for (int i = 0; i < n_steps; i++) {
         // the attention variant depends on the position, which the host mirrors step by step
-        c->split_attn = c->host_pos >= kSplitTPos;
+        c->split_attn = c->host_pos >= split_threshold(c, cfg);
         if (graphs) {
             GraphCache& g = c->gc[c->split_attn ? 1 : 0];
             if (!same_capture(g, cfg, w, s)) {
@@ -897,6 +907,13 @@ int rama_generate_greedy(rama_ctx* c, const rama_config* cfg, const rama_weights
 
 int rama_set_tuning(rama_ctx* c, const char* key, int value) {
     REQUIRE(c && key, RAMA_EINVAL, "set_tuning: NULL argument");
+    if (!strcmp(key, "split_pos")) {
+        REQUIRE(value >= -1, RAMA_EINVAL, "set_tuning: split_pos must be >= -1");
+        c->tune_split_pos = value;
+        hipStreamSynchronize(c->stream);
+        drop_graph(c);
+        return 0;
+    }
     if (!strcmp(key, "resid_r2")) {
         REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: resid_r2 must be 0 or 1");
         c->tune_resid_r2 = value;

@@ -349,24 +349,31 @@ def _long_ctx_case(n_heads, hs, seq_len=2048, seed=11):
     return cfg, w, kc, vc
 
 
+@pytest.mark.parametrize("split_pos", [384, -1, 1 << 30])
 @pytest.mark.parametrize("n_heads,hs", [(2, 128), (4, 64), (6, 48)])
-def test_split_t_attention_long_context(dev, n_heads, hs):
-    """positions at and beyond the split-T threshold (384): n_heads x nsplit workgroups + combine
-    must give the oracle's logits (which soft-max over ALL timesteps at once)."""
+def test_split_t_attention_long_context(dev, n_heads, hs, split_pos):
+    """long contexts through both attention variants: split-T (n_heads x nsplit workgroups +
+    combine) forced from position 384, the default choice by model size (-1), and the
+    single-workgroup kernel only; all must give the oracle's logits (one softmax over ALL timesteps)."""
     import rama_amd
+    from rama_amd._lib import check
     cfg, w, kc, vc = _long_ctx_case(n_heads, hs)
     orc = O.Oracle(cfg, w)
     rcfg, ws, wv, rs, rsv = gpu_views(dev, cfg, w)
-    for pos in (383, 384, 385, 1000, 2047):
-        orc.s["key_cache"][:] = kc; orc.s["value_cache"][:] = vc
-        dev.upload_into(rsv.key_cache, kc); dev.upload_into(rsv.value_cache, vc)
-        lo = orc.forward(5, pos).copy()
-        rama_amd.forward_fused(rcfg, wv, rsv, 5, pos, dev)
-        lg = dev.download(rsv.logits)
-        assert np.abs(lg - lo).max() <= LOGIT_ATOL, (pos, float(np.abs(lg - lo).max()))
-        # the freshly appended cache rows agree too
-        d = cfg.dim
-        assert np.abs(dev.download(rsv.key_cache)[pos * d:(pos + 1) * d] - orc.s["key_cache"][pos * d:(pos + 1) * d]).max() <= STATE_ATOL
+    check(dev.lib.rama_set_tuning(dev.ctx, b"split_pos", split_pos))
+    try:
+        for pos in (383, 384, 385, 1000, 2047):
+            orc.s["key_cache"][:] = kc; orc.s["value_cache"][:] = vc
+            dev.upload_into(rsv.key_cache, kc); dev.upload_into(rsv.value_cache, vc)
+            lo = orc.forward(5, pos).copy()
+            rama_amd.forward_fused(rcfg, wv, rsv, 5, pos, dev)
+            lg = dev.download(rsv.logits)
+            assert np.abs(lg - lo).max() <= LOGIT_ATOL, (pos, float(np.abs(lg - lo).max()))
+            # the freshly appended cache rows agree too
+            d = cfg.dim
+            assert np.abs(dev.download(rsv.key_cache)[pos * d:(pos + 1) * d] - orc.s["key_cache"][pos * d:(pos + 1) * d]).max() <= STATE_ATOL
+    finally:
+        check(dev.lib.rama_set_tuning(dev.ctx, b"split_pos", -1))
     rs.free(); ws.free()
 
 
