@@ -203,9 +203,11 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *                   rama_prefill (8 positions per weight pass) instead of one forward per token
  *   "prefill_rounds" = 1..64 : rama_prefill cuts each matrix launch into this many even rounds
  *                   over the CUs (default 1, the measured best: 42 ms vs 50 ms at 8 rounds)
- *   "merge" = 0|1   : 1 runs attention and the Wo matvec as one launch when the occupancy API says
- *                   its whole grid is resident (Wo's weights stream while attention runs).
- *                   Measured +0.9 % at short and -2.5 % at 1000-token contexts: off by default
+ *   "merge" = -1|0|1 : 1 runs attention and the Wo matvec as one launch when the occupancy API says
+ *                   its whole grid is resident (Wo's weights stream while attention runs); -1
+ *                   (default) turns it on for dim <= 1024 only: measured +4.2 % / +7.7 % tokens/s at
+ *                   the stories110M / stories15M shapes, +0.9 % short and -2.5 % at 1000-token
+ *                   contexts at llama2-7B
  *   "persist" = 0|1 : 1 runs each chained decode step as ONE persistent launch (persist.hpp:
  *                   one resident workgroup per CU, phases separated by a counter barrier hidden
  *                   behind weight prefetch).  Same results; measured slower than the launch

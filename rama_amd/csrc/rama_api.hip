@@ -77,7 +77,8 @@ struct rama_ctx {
     int tune_resid_r2 = 1;                 // 1: Wo / W2 use 2-row workgroups under the default geometry (+0.45 %)
     int tune_pf_rounds = 1;                // prefill launches are cut into this many even rounds over the CUs
     int tune_prefill = 1;                  // 1: rama_generate_greedy runs the forced prompt positions through rama_prefill
-    int tune_merge = 0;                    // 1: attention + Wo in one launch when the whole grid is resident (+0.9 % short, -2.5 % long contexts: off)
+    int tune_merge = -1;                   // attention + Wo in one launch: 1 on, 0 off, -1 by model size (on for dim <= 1024:
+                                           // +4..8 % at the stories shapes; at llama2-7B +0.9 % short / -2.5 % long contexts)
     int merge_blocks_per_cu[3] = {-1, -1, -1};   // occupancy of attn_wo_kernel<16|32|64> at the LDS size below
     size_t merge_lds[3] = {0, 0, 0};
     unsigned* attn_counter = nullptr;      // device: arrivals of the attention workgroups
@@ -544,7 +545,8 @@ static int enqueue_stage(rama_ctx* c, const rama_config* cfg, const rama_weights
             LAUNCHCHK();
         }
         bool merged = false;
-        if (c->tune_merge && !c->split_attn && c->kp.kernel_id < 0) {   // infer.rs:34-37 as one launch (per-kernel timing keeps them apart)
+        const bool want_merge = c->tune_merge < 0 ? dim <= 1024 : c->tune_merge != 0;
+        if (want_merge && !c->split_attn && c->kp.kernel_id < 0) {   // infer.rs:34-37 as one launch (per-kernel timing keeps them apart)
             int rc = try_launch_attn_wo(c, cfg, w, s, li, kc, vc, &merged);
             if (rc) return rc;
         }
@@ -932,7 +934,7 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
         return 0;
     }
     if (!strcmp(key, "merge")) {
-        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: merge must be 0 or 1");
+        REQUIRE(value >= -1 && value <= 1, RAMA_EINVAL, "set_tuning: merge must be -1, 0 or 1");
         c->tune_merge = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
