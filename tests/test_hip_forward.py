@@ -543,3 +543,57 @@ def test_concurrent_contexts_share_weights(dev):
     assert got == want
     for e in engines: e.free()
     model.free()
+
+
+# ------------------------------------------------------------------ randomized shapes
+
+def _random_shapes(n, seed=2024):
+    """(dim, hidden, n_layers, n_heads, vocab, seq_len, shared): head sizes 4..256 (multiples of 4),
+    row widths that are NOT multiples of the 256-float chunk or of the 4-row workgroup, odd vocab"""
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        hs = int(rng.choice([4, 8, 12, 20, 32, 48, 64, 80, 96, 128, 160, 256]))
+        n_heads = int(rng.integers(1, 9))
+        dim = hs * n_heads
+        if dim > 1536:
+            continue
+        hidden = 4 * int(rng.integers(1, 3 * dim // 4 + 2))
+        out.append((dim, hidden, int(rng.integers(1, 4)), n_heads, int(rng.integers(5, 700)),
+                    int(rng.integers(12, 80)), bool(rng.integers(0, 2))))
+    return out
+
+
+@pytest.mark.parametrize("shape", _random_shapes(14), ids=lambda s: "d%d_h%d_L%d_H%d_V%d_S%d_%s" % (s[:6] + ("tied" if s[6] else "untied",)))
+def test_random_shapes_fused_prefill_and_ops_vs_oracle(dev, shape):
+    """shapes nobody tuned for: the fused path, the batched prefill and the 1:1 trait-op path
+    must all give the oracle's logits and caches"""
+    import rama_amd
+    dim, hidden, L, H, V, seq, shared = shape
+    cfg = O.Config(dim, hidden, L, H, H, V, seq, shared)
+    w = S.synth_weights(cfg, seed=dim + hidden)
+    rng = np.random.default_rng(dim * 31 + V)
+    toks = [1 % V] + [int(t) for t in rng.integers(0, V, 10)]
+    orc = O.Oracle(cfg, w)
+    want = [orc.forward(t, p).copy() for p, t in enumerate(toks)]
+    # fused, token by token
+    rcfg, ws, wv, rs, rsv = gpu_views(dev, cfg, w)
+    for p, t in enumerate(toks):
+        rama_amd.forward_fused(rcfg, wv, rsv, t, p, dev)
+        assert np.abs(dev.download(rsv.logits) - want[p]).max() <= LOGIT_ATOL, ("fused", p)
+    for buf in ("key_cache", "value_cache"):
+        assert np.abs(dev.download(getattr(rsv, buf)) - orc.s[buf]).max() <= STATE_ATOL, buf
+    rs.free()
+    # batched prefill of the same positions into a fresh state
+    rs = rama_amd.RunState.from_config(rcfg, dev); rsv = rama_amd.RunStateView.from_rs(rs)
+    _prefill(dev, rcfg, wv, rsv, toks, 0)
+    assert np.abs(dev.download(rsv.logits) - want[-1]).max() <= LOGIT_ATOL, "prefill"
+    for buf in ("key_cache", "value_cache"):
+        assert np.abs(dev.download(getattr(rsv, buf)) - orc.s[buf]).max() <= STATE_ATOL, ("prefill", buf)
+    rs.free()
+    # the reference's own op sequence through the Device trait mirror (first 3 positions)
+    rs = rama_amd.RunState.from_config(rcfg, dev); rsv = rama_amd.RunStateView.from_rs(rs)
+    for p, t in enumerate(toks[:3]):
+        rama_amd.forward(rcfg, wv, rsv, t, p, dev)
+        assert np.abs(dev.download(rsv.logits) - want[p]).max() <= LOGIT_ATOL, ("ops", p)
+    rs.free(); ws.free()
