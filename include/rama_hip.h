@@ -181,6 +181,23 @@ int  rama_argmax_dev(rama_ctx *ctx, const float *logits, size_t n, int32_t *resu
 int  rama_generate_greedy(rama_ctx *ctx, const rama_config *cfg, const rama_weights *w,
                           rama_run_state *s, const int32_t *prompt_tokens_host, int n_prompt,
                           int steps, int32_t *out_tokens_host);
+
+/* Device::sample for temperature != 0 without the logits download (reference: cpu.rs:155-179,
+ * sample_top_q infer.rs:55-85; the reference GPU path copies 128 KB to the host per token,
+ * gpu.rs:149-173): logits (/ T if T < 1) -> softmax -> keep p > (1 - topp) / (n - 1) -> stable
+ * descending sort -> cut where the running sum exceeds topp -> draw with r = u * sum.  `u` is the
+ * uniform draw; the reference re-seeds its generator on every call, so it is the same constant
+ * for every token.  temperature == 0 is the argmax.  Result in device memory;
+ * -1 when no probability exceeds the cutoff (the reference's index arithmetic underflows there). */
+int  rama_sample_topp_dev(rama_ctx *ctx, const float *logits, size_t n, float temperature, float topp,
+                          float u, int32_t *result_dev);
+/* Sampler of the chained decode loop (rama_decode_steps): temperature 0 (default) = argmax. */
+int  rama_decode_sampler(rama_ctx *ctx, float temperature, float topp, float u);
+/* generate() (mod.rs:169-206) for any temperature, chained on the device: no per-token host round
+ * trip; rama_generate_greedy is this with temperature 0. */
+int  rama_generate(rama_ctx *ctx, const rama_config *cfg, const rama_weights *w, rama_run_state *s,
+                   const int32_t *prompt_tokens_host, int n_prompt, int steps, float temperature,
+                   float topp, float u, int32_t *out_tokens_host);
 /* The same loop in pieces, for timing: begin sets (token, pos) and the forced-token list;
  * each decode_steps call enqueues n more (forward + argmax + advance) steps. */
 int  rama_decode_begin(rama_ctx *ctx, int token, int pos, const int32_t *forced_tokens_host, int n_forced);

@@ -8,5 +8,5 @@ ops without the built library raises.
 from ._lib import RamaError, load  # noqa: F401
 from .transformer import (Config, Hip, HipSlice, MutView, RunState, RunStateView,  # noqa: F401
                           TransformerWeights, TransformerWeightsView, View, forward,
-                          forward_fused, generate, generate_greedy_device)
+                          forward_fused, generate, generate_device, generate_greedy_device)
 from .engine import Engine, Model, algorithmic_bytes  # noqa: F401

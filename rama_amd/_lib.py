@@ -86,6 +86,9 @@ SIGNATURES = {
     "rama_forward_stage_devtok": (_int, [_vp, _cfgp, _wp, _sp, _vp, _int, _stp]),
     "rama_argmax_dev": (_int, [_vp, _vp, _sz, _vp]),
     "rama_generate_greedy": (_int, [_vp, _cfgp, _wp, _sp, i32p, _int, _int, i32p]),
+    "rama_generate": (_int, [_vp, _cfgp, _wp, _sp, i32p, _int, _int, C.c_float, C.c_float, C.c_float, i32p]),
+    "rama_sample_topp_dev": (_int, [_vp, _vp, _sz, C.c_float, C.c_float, C.c_float, _vp]),
+    "rama_decode_sampler": (_int, [_vp, C.c_float, C.c_float, C.c_float]),
     "rama_decode_begin": (_int, [_vp, _int, _int, i32p, _int]),
     "rama_decode_steps": (_int, [_vp, _cfgp, _wp, _sp, _int]),
     "rama_decode_tokens": (_int, [_vp, i32p, _int, C.POINTER(_int)]),

@@ -83,10 +83,12 @@ int main(int argc, char** argv) {
     catch (const std::exception& e) { std::fprintf(stderr, "panic: %s\n", e.what()); return 101; }
 
     try {
-        if (path == "chained" && args.temperature == 0.0f) {
+        if (path == "chained") {
+            // the whole generate() loop on the device, argmax or top-p (no per-token host round trip)
             std::vector<int32_t> pt(prompt_tokens.begin(), prompt_tokens.end()), out(steps ? steps : 1);
             rama_config c = config.c(); rama_weights w = wv.c(); rama_run_state s = rsv.c();
-            ck(rama_generate_greedy(device.ctx, &c, &w, &s, pt.data(), (int)pt.size(), (int)steps, out.data()), "rama_generate_greedy");
+            ck(rama_generate(device.ctx, &c, &w, &s, pt.data(), (int)pt.size(), (int)steps, args.temperature, args.topp,
+                             device.topp_draw, out.data()), "rama_generate");
             for (size_t i = 0; i < steps; i++) std::cout << decode(tokenizer.vocab[(size_t)out[i]]);
             std::cout.flush();
         } else {

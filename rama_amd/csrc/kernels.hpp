@@ -93,6 +93,28 @@ __device__ __forceinline__ int wave_max_i(int v) {
     return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
                max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = min(v, __shfl_xor(v, m));
+    return v;
+}
+// minimum over a workgroup of up to 16 waves (one barrier pair; every thread gets the result)
+__device__ __forceinline__ int block_min_i(int v) {
+    __shared__ int s_m[16];
+    v = wave_min_i(v);
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int r = s_m[0];
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 1; w < nw; w++) r = min(r, s_m[w]);
+    __syncthreads();
+    return r;
+}
 __device__ __forceinline__ float dot4(f4 a, f4 b, float acc) {
     acc = fmaf(a.x, b.x, acc);
     acc = fmaf(a.y, b.y, acc);
@@ -637,6 +659,29 @@ struct ArgmaxParams {
     const float* emb; float* x; int dim;   // optional next-token embedding gather
 };
 
+// what ends a chained decode step once the sampled index is known (mod.rs:187-201): the result
+// word, the forced prompt token overriding the sample, the output list and the cursor
+__device__ __forceinline__ int finish_step(const ArgmaxParams& p, int idx, int pos, int n_forced, int n_out, int forced_tok) {
+    if (p.result) *p.result = idx;          // -1: the top-p sampler found no candidate
+    int next = idx < 0 ? 0 : idx;
+    if (p.ctl) {
+        if (forced_tok >= 0) next = forced_tok;
+        if (n_out < p.out_cap) p.out[n_out] = next;
+        p.ctl->n_out = n_out + 1;
+        p.ctl->token = next;
+        p.ctl->pos = pos + 1;
+    }
+    return next;
+}
+// x = emb[next] for the following step (infer.rs:13); *s_next is a __shared__ word thread 0 wrote
+__device__ __forceinline__ void gather_next_embedding(const ArgmaxParams& p, const int* s_next) {
+    if (p.emb) {
+        __syncthreads();
+        const size_t base = (size_t)*s_next * p.dim;
+        for (int i = threadIdx.x; i < p.dim; i += blockDim.x) p.x[i] = p.emb[base + i];
+    }
+}
+
 __global__ __launch_bounds__(1024) void argmax_kernel(ArgmaxParams p) {
     __shared__ float s_v[16];
     __shared__ int s_i[16];
@@ -674,22 +719,150 @@ __global__ __launch_bounds__(1024) void argmax_kernel(ArgmaxParams p) {
             const float ov = s_v[w]; const int oi = s_i[w];
             if (oi >= 0 && (idx < 0 || ov > v || (ov == v && oi > idx))) { v = ov; idx = oi; }
         }
-        if (p.result) *p.result = idx;
-        int next = idx;
-        if (p.ctl) {
-            if (forced_tok >= 0) next = forced_tok;
-            if (n_out < p.out_cap) p.out[n_out] = next;
-            p.ctl->n_out = n_out + 1;
-            p.ctl->token = next;
-            p.ctl->pos = pos + 1;
+        s_next = finish_step(p, idx, pos, n_forced, n_out, forced_tok);
+    }
+    gather_next_embedding(p, &s_next);
+}
+
+// ---------------------------------------------------------------- top-p sampling on the device
+// Device::sample for temperature != 0 (cpu.rs:168-178 + sample_top_q, infer.rs:55-85), without the
+// reference GPU path's 128 KB logits download per token (gpu.rs:153):
+//   topp_prepare_kernel   logits (/ T if T < 1) -> softmax (max, exp, sum, divide) -> keys[i] = p_i
+//                         if p_i > (1 - topp) / (n - 1) else -1, vals[i] = i, *m = #candidates
+//   (stable descending radix sort of the n pairs, hipCUB)      = the reference's stable sort of
+//                         the filtered list: equal probabilities keep ascending index order
+//   topp_pick_kernel      cum += p in sorted order until cum > topp (sequential fp32, one thread,
+//                         staged through LDS); r = u * cum; first i < last with r < cum_i, else last
+// The only arithmetic that differs from the CPU path is the order of the softmax's sum (the
+// reference's own rayon sum has no fixed order either) and the device expf.
+struct ToppParams {
+    const float* logits; int n;
+    float temperature, topp, u;
+    float* keys; int* vals;          // [n] unsorted pairs (prepare) -- sorted pairs (pick)
+    float* prefix;                   // [n] scratch: running sums of the sorted probabilities
+    int* m;                          // number of candidates
+    unsigned* err;                   // set to 1 when no probability exceeds the cutoff
+};
+
+__global__ __launch_bounds__(1024) void topp_prepare_kernel(ToppParams p) {
+    __shared__ float s_r[16];
+    __shared__ int s_c[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool scale = p.temperature < 1.0f;                       // cpu.rs:170-172: T > 1 has no effect
+    auto x_of = [&](int i) { const float v = p.logits[i]; return scale ? v / p.temperature : v; };
+    float mx = -INFINITY;
+    for (int i = tid; i < p.n; i += 1024) mx = fmaxf(mx, x_of(i));
+    mx = wave_max(mx);
+    if (lane == 0) s_r[wave] = mx;
+    __syncthreads();
+    mx = s_r[0];
+#pragma unroll
+    for (int w = 1; w < 16; w++) mx = fmaxf(mx, s_r[w]);
+    __syncthreads();
+    float sum = 0.0f;
+    for (int i = tid; i < p.n; i += 1024) { const float e = expf(x_of(i) - mx); p.keys[i] = e; sum += e; }
+    sum = wave_sum(sum);
+    if (lane == 0) s_r[wave] = sum;
+    __syncthreads();
+    {
+        float t[16];
+#pragma unroll
+        for (int w = 0; w < 16; w++) t[w] = s_r[w];
+#pragma unroll
+        for (int n = 16; n > 1; n >>= 1)
+#pragma unroll
+            for (int w = 0; w < n / 2; w++) t[w] = t[2 * w] + t[2 * w + 1];
+        sum = t[0];
+    }
+    const float cutoff = (1.0f - p.topp) / (float)(p.n - 1);      // infer.rs:56
+    int cnt = 0;
+    for (int i = tid; i < p.n; i += 1024) {
+        const float pr = p.keys[i] / sum;
+        const bool keep = pr > cutoff;
+        p.keys[i] = keep ? pr : -1.0f;
+        p.vals[i] = i;
+        cnt += keep;
+    }
+    cnt = wave_sum_i(cnt);
+    if (lane == 0) s_c[wave] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        int m = 0;
+        for (int w = 0; w < 16; w++) m += s_c[w];
+        *p.m = m;
+        if (m == 0 && p.err) *p.err = 1u;
+    }
+}
+
+constexpr int kToppChunk = 4096;
+__global__ __launch_bounds__(1024) void topp_pick_kernel(ToppParams p, ArgmaxParams fin) {
+    __shared__ float s_p[2][kToppChunk];
+    __shared__ int s_last, s_next, s_pick;
+    __shared__ float s_cum;
+    const int tid = threadIdx.x;
+    int pos = 0, n_forced = 0, n_out = 0, forced_tok = -1;
+    if (fin.ctl && tid == 0) {
+        pos = fin.ctl->pos; n_forced = fin.ctl->n_forced; n_out = fin.ctl->n_out;
+        if (pos < n_forced) forced_tok = fin.forced[pos];
+    }
+    const int m = *p.m;
+    if (tid == 0) { s_last = m > 0 ? m - 1 : 0; s_cum = 0.0f; s_pick = 0; }
+    // Sequential running sum in sorted order (infer.rs:70-73): the fp32 rounding of cum_i depends
+    // on every earlier add, so ONE thread walks the list -- 8 values per step from LDS (two 16-byte
+    // reads, eight dependent adds, running sums written back in place, one threshold test per
+    // step) -- while all threads stage the next chunk (double buffer) and afterwards copy the
+    // running sums out.  Padding zeros leave cum unchanged.
+    const int nchunks = (m + kToppChunk - 1) / kToppChunk;
+    auto stage = [&](int c) {
+        const int base = c * kToppChunk, len = min(kToppChunk, m - base), padded = (len + 7) & ~7;
+        for (int i = tid; i < padded; i += 1024) s_p[c & 1][i] = i < len ? p.keys[base + i] : 0.0f;
+    };
+    if (nchunks > 0) stage(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; c++) {
+        const int base = c * kToppChunk, len = min(kToppChunk, m - base);
+        if (c + 1 < nchunks) stage(c + 1);
+        if (tid == 0) {
+            float cum = s_cum;
+            f4* q = reinterpret_cast<f4*>(s_p[c & 1]);
+            const int nb = (len + 7) >> 3;
+            int hit = -1;
+            for (int b8 = 0; b8 < nb; b8++) {
+                f4 a = q[2 * b8], b = q[2 * b8 + 1];
+                a.x = cum + a.x; a.y = a.x + a.y; a.z = a.y + a.z; a.w = a.z + a.w;
+                b.x = a.w + b.x; b.y = b.x + b.y; b.z = b.y + b.z; b.w = b.z + b.w;
+                q[2 * b8] = a; q[2 * b8 + 1] = b;
+                cum = b.w;
+                if (cum > p.topp) {              // first crossing inside this block of 8
+                    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                    int j = 0;
+                    while (!(v[j] > p.topp)) j++;
+                    hit = b8 * 8 + j; cum = v[j];
+                    break;
+                }
+            }
+            s_cum = cum;
+            if (hit >= 0) { s_last = base + hit; s_pick = 1; }
         }
-        s_next = next;
-    }
-    if (p.emb) {
         __syncthreads();
-        const size_t base = (size_t)s_next * p.dim;
-        for (int i = tid; i < p.dim; i += 1024) p.x[i] = p.emb[base + i];
+        // running sums of this chunk -> global (read again below); only indices < last matter
+        for (int i = tid; i < len; i += 1024) p.prefix[base + i] = s_p[c & 1][i];
+        if (s_pick) break;                                   // uniform
+        __syncthreads();
     }
+    __syncthreads();
+    // r = u * cum; the first i < last whose running sum exceeds r wins, else `last` (infer.rs:75-84);
+    // the running sums of that loop are exactly the ones stored above
+    const int last = s_last;
+    const float r = p.u * s_cum;
+    int best = last;
+    for (int i = tid; i < last; i += 1024) if (r < p.prefix[i]) { best = i; break; }
+    best = block_min_i(best);
+    if (tid == 0) {
+        const int idx = m > 0 ? p.vals[best] : -1;
+        s_next = finish_step(fin, idx, pos, n_forced, n_out, forced_tok);
+    }
+    gather_next_embedding(fin, &s_next);
 }
 
 // bit-exact twin of oracle_fill_synth (integer hash, Irwin-Hall(4), one multiply, one add)

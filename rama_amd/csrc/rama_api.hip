@@ -4,6 +4,7 @@
 #include "kernels.hpp"
 #include "persist.hpp"
 #include "prefill.hpp"
+#include <hipcub/hipcub.hpp>
 
 #include <hip/hip_ext.h>   // hipExtLaunchKernelGGL: start/stop events carried by the dispatch itself
 
@@ -73,6 +74,11 @@ struct rama_ctx {
     hipEvent_t cur_start = nullptr, cur_stop = nullptr;   // events the next profiled launch carries
     int tune_geom = 3;
     int tune_persist = 0;                  // 1: decode steps run as one persistent launch (persist.hpp)
+    // device top-p sampler (Device::sample for temperature != 0); temperature 0 = argmax
+    float samp_T = 0.0f, samp_topp = 0.9f, samp_u = 0.0f;
+    float* topp_keys[2] = {nullptr, nullptr}; int* topp_vals[2] = {nullptr, nullptr};
+    float* topp_prefix = nullptr; int* topp_m = nullptr; unsigned* topp_err = nullptr;
+    void* topp_tmp = nullptr; size_t topp_tmp_bytes = 0; int topp_cap = 0;
     int tune_split_pos = -1;               // attention runs split-T (+ combine launch) from this position on; -1 = by model size
     int tune_resid_r2 = 1;                 // 1: Wo / W2 use 2-row workgroups under the default geometry (+0.45 %)
     int tune_pf_rounds = 1;                // prefill launches are cut into this many even rounds over the CUs
@@ -148,7 +154,9 @@ int rama_ctx_destroy(rama_ctx* c) {
     hipStreamSynchronize(c->stream);
     drop_graph(c);
     for (auto e : c->kp.ev) hipEventDestroy(e);
-    hipFree(c->ctl); hipFree(c->out); hipFree(c->forced); hipFree(c->argmax_result); hipFree(c->pbar); hipFree(c->attn_counter); hipFree(c->attn_part); hipFree(c->pf_blob);
+    hipFree(c->ctl); hipFree(c->out); hipFree(c->forced); hipFree(c->argmax_result); hipFree(c->pbar); hipFree(c->attn_counter); hipFree(c->attn_part);
+    for (int i = 0; i < 2; i++) { hipFree(c->topp_keys[i]); hipFree(c->topp_vals[i]); }
+    hipFree(c->topp_prefix); hipFree(c->topp_m); hipFree(c->topp_err); hipFree(c->topp_tmp); hipFree(c->pf_blob);
     hipHostFree(c->pinned_int);
     hipEventDestroy(c->t0); hipEventDestroy(c->t1);
     if (c->own_stream) hipStreamDestroy(c->stream);
@@ -629,6 +637,71 @@ int rama_forward_stage_devtok(rama_ctx* c, const rama_config* cfg, const rama_we
     return enqueue_stage(c, cfg, w, s, st);
 }
 
+// ---- device top-p sampler (kernels.hpp: topp_prepare_kernel, hipCUB stable radix sort, topp_pick_kernel)
+
+// scratch for n logits; called outside any stream capture
+static int ensure_topp_scratch(rama_ctx* c, int n) {
+    if (n <= c->topp_cap) return 0;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 2; i++) {
+        hipFree(c->topp_keys[i]); hipFree(c->topp_vals[i]);
+        HIPCHK(hipMalloc(&c->topp_keys[i], sizeof(float) * n));
+        HIPCHK(hipMalloc(&c->topp_vals[i], sizeof(int) * n));
+    }
+    hipFree(c->topp_prefix); HIPCHK(hipMalloc(&c->topp_prefix, sizeof(float) * n));
+    if (!c->topp_m) { HIPCHK(hipMalloc(&c->topp_m, sizeof(int))); HIPCHK(hipMalloc(&c->topp_err, sizeof(unsigned))); HIPCHK(hipMemset(c->topp_err, 0, sizeof(unsigned))); }
+    size_t bytes = 0;
+    HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes, c->topp_keys[0], c->topp_keys[1], c->topp_vals[0], c->topp_vals[1], n, 0, 32, c->stream));
+    hipFree(c->topp_tmp); c->topp_tmp = nullptr;
+    HIPCHK(hipMalloc(&c->topp_tmp, bytes ? bytes : 16));
+    c->topp_tmp_bytes = bytes;
+    c->topp_cap = n;
+    return 0;
+}
+
+// the sampling tail of a step: argmax (temperature 0) or top-p, then whatever `fin` asks for
+// (result word, cursor advance, next embedding gather)
+static int enqueue_sample(rama_ctx* c, ArgmaxParams fin, float temperature, float topp, float u) {
+    if (temperature == 0.0f) {
+        hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, c->stream, fin);
+        LAUNCHCHK();
+        return 0;
+    }
+    REQUIRE(fin.n > 1 && fin.n <= c->topp_cap, RAMA_EINVAL, "top-p sampler: scratch not prepared");
+    ToppParams tp{};
+    tp.logits = fin.logits; tp.n = fin.n; tp.temperature = temperature; tp.topp = topp; tp.u = u;
+    tp.keys = c->topp_keys[0]; tp.vals = c->topp_vals[0]; tp.prefix = c->topp_prefix; tp.m = c->topp_m; tp.err = c->topp_err;
+    hipLaunchKernelGGL(topp_prepare_kernel, dim3(1), dim3(1024), 0, c->stream, tp);
+    LAUNCHCHK();
+    size_t bytes = c->topp_tmp_bytes;
+    HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(c->topp_tmp, bytes, c->topp_keys[0], c->topp_keys[1], c->topp_vals[0], c->topp_vals[1],
+                                                        fin.n, 0, 32, c->stream));
+    tp.keys = c->topp_keys[1]; tp.vals = c->topp_vals[1];
+    hipLaunchKernelGGL(topp_pick_kernel, dim3(1), dim3(1024), 0, c->stream, tp, fin);
+    LAUNCHCHK();
+    return 0;
+}
+
+int rama_sample_topp_dev(rama_ctx* c, const float* logits, size_t n, float temperature, float topp, float u, int32_t* result_dev) {
+    REQUIRE(c && logits && result_dev && n > 1 && n < (1u << 30), RAMA_EINVAL, "sample_topp_dev: bad argument");
+    int rc = temperature != 0.0f ? ensure_topp_scratch(c, (int)n) : 0;
+    if (rc) return rc;
+    ArgmaxParams ap{};
+    ap.logits = logits; ap.n = (int)n; ap.result = (int*)result_dev;
+    return enqueue_sample(c, ap, temperature, topp, u);
+}
+
+int rama_decode_sampler(rama_ctx* c, float temperature, float topp, float u) {
+    REQUIRE(c, RAMA_EINVAL, "ctx is NULL");
+    REQUIRE(temperature >= 0.0f && topp >= 0.0f && topp <= 1.0f && u >= 0.0f && u < 1.0f, RAMA_EINVAL, "decode_sampler: temperature >= 0, topp in [0,1], u in [0,1)");
+    if (temperature != c->samp_T || topp != c->samp_topp || u != c->samp_u) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        drop_graph(c);
+        c->samp_T = temperature; c->samp_topp = topp; c->samp_u = u;
+    }
+    return 0;
+}
+
 int rama_argmax_dev(rama_ctx* c, const float* logits, size_t n, int32_t* result_dev) {
     REQUIRE(c && logits && result_dev && n > 0, RAMA_EINVAL, "argmax_dev: bad argument");
     ArgmaxParams ap{};
@@ -794,9 +867,7 @@ static int enqueue_decode_step(rama_ctx* c, const rama_config* cfg, const rama_w
     ap.logits = s->logits; ap.n = cfg->vocab_size;
     ap.ctl = c->ctl; ap.forced = c->forced; ap.out = c->out; ap.out_cap = c->out_cap;
     ap.emb = w->token_embedding_table; ap.x = s->x; ap.dim = cfg->dim;
-    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, c->stream, ap);
-    LAUNCHCHK();
-    return 0;
+    return enqueue_sample(c, ap, c->samp_T, c->samp_topp, c->samp_u);
 }
 
 static bool same_capture(const GraphCache& g, const rama_config* cfg, const rama_weights* w, const rama_run_state* s) {
@@ -817,6 +888,7 @@ int rama_decode_steps(rama_ctx* c, const rama_config* cfg, const rama_weights* w
     }
     REQUIRE(c->host_pos >= 0, RAMA_EINVAL, "decode_steps: call rama_decode_begin first");
     rc = ensure_attn_part(c, cfg); if (rc) return rc;
+    if (c->samp_T != 0.0f) { rc = ensure_topp_scratch(c, cfg->vocab_size); if (rc) return rc; }
     REQUIRE(c->host_pos + n_steps <= cfg->seq_len, RAMA_EINVAL, "decode_steps: would run past seq_len");
     const bool graphs = c->graph_mode && c->kp.kernel_id < 0;
     for (int i = 0; i < n_steps; i++) {
@@ -857,6 +929,14 @@ int rama_decode_tokens(rama_ctx* c, int32_t* out_host, int max_tokens, int* n_ou
         hipMemsetAsync(c->pbar, 0, 4 * sizeof(unsigned long long), c->stream);   // counter, error word, base: start over
         return fail(RAMA_EINVAL, "persistent decode step: barrier timed out", __FILE__, __LINE__);
     }
+    if (c->topp_err) {
+        unsigned terr = 0;
+        HIPCHK(hipMemcpy(&terr, c->topp_err, sizeof terr, hipMemcpyDeviceToHost));
+        if (terr) {
+            hipMemset(c->topp_err, 0, sizeof terr);
+            return fail(RAMA_EINVAL, "top-p sampler: no probability above the cutoff (the reference underflows here, infer.rs:56-84)", __FILE__, __LINE__);
+        }
+    }
     int n = std::min(std::min(h.n_out, c->out_cap), max_tokens);
     if (n > 0 && out_host) {
         HIPCHK(hipMemcpyAsync(out_host, c->out, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
@@ -868,7 +948,14 @@ int rama_decode_tokens(rama_ctx* c, int32_t* out_host, int max_tokens, int* n_ou
 
 int rama_generate_greedy(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s,
                          const int32_t* prompt_host, int n_prompt, int steps, int32_t* out_host) {
+    return rama_generate(c, cfg, w, s, prompt_host, n_prompt, steps, 0.0f, 0.9f, 0.0f, out_host);
+}
+
+int rama_generate(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s,
+                  const int32_t* prompt_host, int n_prompt, int steps, float temperature, float topp, float u,
+                  int32_t* out_host) {
     REQUIRE(c && cfg && out_host, RAMA_EINVAL, "generate_greedy: NULL argument");
+    { int rcs = rama_decode_sampler(c, temperature, topp, u); if (rcs) return rcs; }
     REQUIRE(steps >= 0 && steps <= cfg->seq_len, RAMA_EINVAL, "generate_greedy: steps > seq_len (the reference does not bound-check, SURVEY section 5)");
     REQUIRE(steps <= c->out_cap, RAMA_EINVAL, "generate_greedy: too many steps");
     REQUIRE(n_prompt >= 0 && (n_prompt == 0 || prompt_host), RAMA_EINVAL, "generate_greedy: bad prompt");
@@ -891,8 +978,9 @@ int rama_generate_greedy(rama_ctx* c, const rama_config* cfg, const rama_weights
         ap.logits = s->logits; ap.n = cfg->vocab_size;
         ap.ctl = c->ctl; ap.forced = c->forced; ap.out = c->out; ap.out_cap = c->out_cap;
         ap.emb = w->token_embedding_table; ap.x = s->x; ap.dim = cfg->dim;
-        hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, c->stream, ap);     // out[n_prompt], cursor -> n_prompt + 1, next x
-        LAUNCHCHK();
+        if (c->samp_T != 0.0f) { rc = ensure_topp_scratch(c, cfg->vocab_size); if (rc) return rc; }
+        rc = enqueue_sample(c, ap, c->samp_T, c->samp_topp, c->samp_u);               // out[n_prompt], cursor -> n_prompt + 1, next x
+        if (rc) return rc;
         c->embedded_x = s->x;
         c->host_pos = n_prompt + 1;
         rc = rama_decode_steps(c, cfg, w, s, steps - n_prompt - 1);

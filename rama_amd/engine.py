@@ -117,6 +117,18 @@ class Engine:
               "rama_generate_greedy")
         return [int(v) for v in out[:steps]]
 
+    def generate(self, prompt_tokens, steps: int, temperature: float = 0.0, topp: float = 0.9, u: float = 0.0):
+        """generate() for any temperature, sampled on the device (rama_generate)"""
+        pt = (C.c_int32 * max(len(prompt_tokens), 1))(*prompt_tokens)
+        out = (C.c_int32 * max(steps, 1))()
+        check(self.device.lib.rama_generate(self.device.ctx, C.byref(self.model.ccfg), C.byref(self.model.weights),
+                                            C.byref(self.state), pt, len(prompt_tokens), steps,
+                                            temperature, topp, u, out), "rama_generate")
+        return [int(v) for v in out[:steps]]
+
+    def decode_sampler(self, temperature: float, topp: float = 0.9, u: float = 0.0):
+        check(self.device.lib.rama_decode_sampler(self.device.ctx, temperature, topp, u), "rama_decode_sampler")
+
     def decode_begin(self, token: int, pos: int, forced=()):
         ft = (C.c_int32 * max(len(forced), 1))(*forced)
         check(self.device.lib.rama_decode_begin(self.device.ctx, token, pos, ft, len(forced)), "rama_decode_begin")

@@ -369,6 +369,18 @@ def generate(cfg: Config, prompt_tokens, temperature: float, steps: int, topp: f
     return out
 
 
+def generate_device(cfg: Config, prompt_tokens, temperature: float, steps: int, topp: float,
+                    wv: TransformerWeightsView, rsv: RunStateView, device: Hip, u: float = 0.2721174359321594):
+    """generate() chained on the device for any temperature (rama_generate): argmax or top-p sampling
+    without the per-token logits download; one D2H of the token list at the end."""
+    rs = rama_run_state(*[getattr(rsv, k).ptr for k in S_FIELDS])
+    pt = (C.c_int32 * max(len(prompt_tokens), 1))(*prompt_tokens)
+    out = (C.c_int32 * max(steps, 1))()
+    check(device.lib.rama_generate(device.ctx, C.byref(cfg.c()), C.byref(wv.c()), C.byref(rs),
+                                   pt, len(prompt_tokens), steps, temperature, topp, u, out), "rama_generate")
+    return [int(v) for v in out[:steps]]
+
+
 def generate_greedy_device(cfg: Config, prompt_tokens, steps: int, wv: TransformerWeightsView,
                            rsv: RunStateView, device: Hip):
     """The T == 0 loop chained on the device (rama_generate_greedy): one D2H at the end."""

@@ -222,6 +222,38 @@ def test_generate_with_topp_sampling_matches_oracle(dev):
     rs.free(); ws.free()
 
 
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("name,temperature,topp,u,prompt_len", [("synth_d64_h4", 1.0, 0.9, 0.2721174359321594, 2), ("synth_d288_h6", 0.8, 0.95, 0.6, 0),
+                                                                ("ckpt_untied", 1.0, 0.9, 0.03743588924407959, 5), ("synth_d64_h4", 1.5, 0.5, 0.9, 3)])
+def test_generate_sampled_on_device_matches_oracle(dev, name, temperature, topp, u, prompt_len, graph):
+    """rama_generate with temperature != 0: the whole loop (prefill of the prompt, top-p sampling,
+    cursor advance) stays on the device; tokens must equal forward() + Device::sample of the oracle"""
+    import rama_amd
+    cfg, w, g = load_case(name)
+    steps = min(14, cfg.seq_len)
+    prompt = g["tokens"].tolist()[1:1 + prompt_len]
+    orc = O.Oracle(cfg, w)
+    token, want = 1, []
+    for pos in range(steps):
+        lo = orc.forward(token, pos)
+        nxt = prompt[pos] if pos < len(prompt) else O.sample(lo.copy(), temperature, topp, u)
+        want.append(int(nxt)); token = nxt
+    if name.startswith("ckpt"):
+        m = rama_amd.Model.load(dev, GOLDEN / f"{name}.bin")
+    else:
+        m = rama_amd.Model.synth(dev, to_rama_cfg(cfg), int(g["seed"]), rope=(g["freq_cis_real"], g["freq_cis_imag"]))
+    eng = rama_amd.Engine(dev, m)
+    eng.set_graph_mode(graph)
+    try:
+        assert eng.generate(prompt, steps, temperature, topp, u) == want
+        assert eng.generate(prompt, steps, temperature, topp, u) == want       # replay (graph cache, scratch reuse)
+        assert eng.generate_greedy(prompt, steps) == eng.generate(prompt, steps, 0.0)
+    finally:
+        eng.set_graph_mode(False)
+        eng.decode_sampler(0.0)
+    eng.free(); m.free()
+
+
 def test_stage_split_equals_whole(dev):
     """layer-pipeline stages on one device: [0,1) + [1,L) with x handed over == full forward"""
     import rama_amd

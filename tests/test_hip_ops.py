@@ -260,3 +260,61 @@ def test_fill_synth_bit_exact(dev, n, seed, tag, offset, bias):
     import rama_amd
     rama_amd._lib.check(dev.lib.rama_fill_synth(dev.ctx, s.ptr, n, seed, tag, offset, sc, np.float32(bias)))
     assert np.array_equal(dev.download(s), O.fill_synth(n, seed, tag, sc, bias, offset))
+
+
+# ------------------------------------------------------------------ top-p sampling on the device
+
+def _topp_dev(dev, x, temperature, topp, u):
+    """rama_sample_topp_dev on a host vector -> token id"""
+    import ctypes as C
+    from rama_amd._lib import check
+    d_x = dev.allocate(x)
+    d_r = dev.allocate(np.zeros(1, dtype=np.float32))
+    check(dev.lib.rama_sample_topp_dev(dev.ctx, d_x.ptr, x.size, temperature, topp, u, d_r.ptr))
+    out = dev.download(d_r).view(np.int32)[0]
+    d_x.free(); d_r.free()
+    return int(out)
+
+
+@pytest.mark.parametrize("n,scale,seed", [(32000, 3.0, 1), (32000, 0.05, 2), (32000, 12.0, 3), (4097, 2.0, 4), (13, 1.0, 5), (2, 1.0, 6), (70001, 4.0, 7)])
+@pytest.mark.parametrize("temperature,topp,u", [(1.0, 0.9, 0.2721174359321594), (0.7, 0.9, 0.5), (1.5, 0.5, 0.03743588924407959),
+                                                (1.0, 1.0, 0.999), (0.3, 0.95, 0.0), (1.0, 0.2, 0.75)])
+def test_sample_topp_dev_matches_oracle(dev, n, scale, seed, temperature, topp, u):
+    """device sampler == the oracle's Device::sample restatement on peaked (scale 12), ordinary and
+    nearly flat (scale 0.05: every token is a candidate, 8 LDS chunks of running sums) logits"""
+    x = rnd(n, seed, scale)
+    got, want = _topp_dev(dev, x, temperature, topp, u), O.sample(x.copy(), temperature, topp, u)
+    if got != want:
+        assert got >= 0 and want >= 0, (got, want)     # -1 = no candidate above the cutoff, on both sides or neither
+        # Only legitimate where the draw lands in the far tail: there the fp32 running sum sits on
+        # plateaus (p_i << ulp(cum)), so the index depends on the last bit of the softmax's sum,
+        # whose order the reference itself does not fix (rayon, SURVEY 8c).  The two picks must
+        # then be neighbours in cumulative mass.
+        z = x.astype(np.float64) / (temperature if temperature < 1.0 else 1.0)
+        pr = np.exp(z - z.max()); pr /= pr.sum()
+        order = np.argsort(-pr, kind="stable")
+        cum = np.cumsum(pr[order])
+        rank = {int(t): i for i, t in enumerate(order)}
+        assert abs(cum[rank[got]] - cum[rank[want]]) < 2e-6, (got, want)
+        assert u * min(topp, 1.0) > 0.9, "a mismatch away from the tail is a bug"
+
+
+def test_sample_topp_dev_ties_keep_index_order(dev):
+    """equal probabilities: the reference's stable sort keeps ascending index order among them"""
+    x = np.full(1000, -3.0, dtype=np.float32)
+    x[[17, 400, 401, 999]] = 2.0                      # four equal maxima, p ~ 0.249 each
+    for u in (0.0, 0.26, 0.51, 0.76, 0.99):
+        assert _topp_dev(dev, x, 1.0, 0.9, u) == O.sample(x.copy(), 1.0, 0.9, u)
+
+
+def test_sample_topp_dev_temperature_zero_is_argmax(dev):
+    x = rnd(5000, 9, 2.0)
+    x[[10, 4000]] = 50.0
+    assert _topp_dev(dev, x, 0.0, 0.9, 0.3) == 4000 == O.argmax(x)
+
+
+def test_sample_topp_dev_without_candidates(dev):
+    """uniform logits and topp = 0: every p = 1/n is below the cutoff 1/(n-1); the reference's index
+    arithmetic underflows there (infer.rs:56-84), the oracle and the device sampler both say -1"""
+    x = np.zeros(500, dtype=np.float32)
+    assert _topp_dev(dev, x, 1.0, 0.0, 0.5) == -1 == O.sample(x.copy(), 1.0, 0.0, 0.5)

@@ -131,6 +131,35 @@ def test_engine_cli_text_parity(tmp_path, path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("path", ["fused", "chained"])
+def test_engine_cli_temperature_one_text_parity(tmp_path, path):
+    """`-r 1` (the reference README's bench setting, README.md:80-83): top-p sampling with the
+    re-seeded constant draw; "chained" samples on the device, "fused" through the trait's sample()"""
+    import os
+    name = "ckpt_untied"
+    cfg, w, g = load_case(name)
+    tokp = tmp_path / "tok.bin"
+    write_tokenizer(tokp, cli_vocab(cfg.vocab_size))
+    tok = Tokenizer(tokp, cfg.vocab_size)
+    prompt, steps, u = "hi b", 12, 0.2721174359321594
+    pt = tok.encode(prompt)
+    orc = O.Oracle(cfg, w)
+    token, want_ids = 1, []
+    for pos in range(steps):
+        lo = orc.forward(token, pos)
+        nxt = pt[pos] if pos < len(pt) else O.sample(lo.copy(), 1.0, 0.9, u)
+        want_ids.append(int(nxt)); token = nxt
+    r = subprocess.run([str(ENGINE), "-m", str(GOLDEN / f"{name}.bin"), "-t", str(tokp), "-p", prompt, "-s", str(steps), "-r", "1", "-l", "0.9"],
+                       capture_output=True, text=True, env=dict(os.environ, RAMA_PATH=path), timeout=120)
+    if 0 in want_ids:
+        assert r.returncode == 101
+        return
+    assert r.returncode == 0, r.stderr
+    body = r.stdout.partition("\n--------------------------------\n")[0]
+    assert body == "".join(decode(tok.vocab[i]) for i in want_ids)
+
+
+@pytest.mark.gpu
 def test_engine_cli_rejects_too_many_steps(tmp_path):
     tokp = tmp_path / "tok.bin"
     write_tokenizer(tokp, cli_vocab(64))
