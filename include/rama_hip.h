@@ -88,8 +88,8 @@ int  rama_multi_head_attention(rama_ctx *ctx, float *xb, float *att, const float
 int  rama_sample_argmax(rama_ctx *ctx, const float *logits, size_t n, int32_t *next_host);
 /* T != 0 leg (cpu.rs:168-177, infer.rs:55-85): temperature scale (only if T < 1), softmax,
  * top-p.  `u` = the uniform draw; the reference re-seeds ChaCha20 every call (cpu.rs:161-162,
- * gpu.rs:151-152) so its draw is one constant.  Runs on the host after one logits download,
- * as the reference's GPU path does. */
+ * gpu.rs:151-152) so its draw is one constant.  Runs on the device (rama_sample_topp_dev below);
+ * only the 4-byte result crosses PCIe.  RAMA_EINVAL when no probability exceeds the cutoff. */
 int  rama_sample_topp(rama_ctx *ctx, const float *logits, size_t n, float temperature,
                       float topp, float u, int32_t *next_host);
 

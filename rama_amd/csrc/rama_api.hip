@@ -442,27 +442,15 @@ int rama_sample_argmax(rama_ctx* c, const float* logits, size_t n, int32_t* next
 int rama_sample_topp(rama_ctx* c, const float* logits, size_t n, float temperature, float topp, float u, int32_t* next_host) {
     REQUIRE(c && logits && next_host && n > 1, RAMA_EINVAL, "sample_topp: bad argument");
     if (temperature == 0.0f) return rama_sample_argmax(c, logits, n, next_host);
-    std::vector<float> p(n);
-    int rc = rama_download_f32(c, logits, n, p.data());   // as gpu.rs:153 does
+    // Device::sample (cpu.rs:168-178) on the device; only the 4-byte result crosses PCIe (the
+    // reference's GPU path downloads all n logits and samples on the host, gpu.rs:149-173)
+    int rc = rama_sample_topp_dev(c, logits, n, temperature, topp, u, c->argmax_result);
     if (rc) return rc;
-    if (temperature < 1.0f) for (auto& z : p) z /= temperature;           // cpu.rs:170-172
-    float mx = p[0];
-    for (size_t i = 1; i < n; i++) mx = p[i] > mx ? p[i] : mx;            // cpu.rs:187-192
-    float sum = 0.0f;
-    for (auto& z : p) { z = expf(z - mx); }
-    for (auto z : p) sum += z;
-    for (auto& z : p) z /= sum;
-    const float cutoff = (1.0f - topp) / (float)(n - 1);                   // infer.rs:56
-    std::vector<std::pair<float, int>> pi;
-    for (size_t i = 0; i < n; i++) if (p[i] > cutoff) pi.emplace_back(p[i], (int)i);
-    REQUIRE(!pi.empty(), RAMA_EINVAL, "sample_topp: no candidate above the cutoff (the reference underflows here)");
-    std::stable_sort(pi.begin(), pi.end(), [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.first > b.first; });
-    float cum = 0.0f; size_t last = pi.size() - 1;
-    for (size_t i = 0; i < pi.size(); i++) { cum += pi[i].first; if (cum > topp) { last = i; break; } }
-    const float r = u * cum;
-    float cdf = 0.0f; int pick = pi[last].second;
-    for (size_t i = 0; i < last; i++) { cdf += pi[i].first; if (r < cdf) { pick = pi[i].second; break; } }
-    *next_host = pick;
+    HIPCHK(hipMemcpyAsync(c->pinned_int, c->argmax_result, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    hipMemsetAsync(c->topp_err, 0, sizeof(unsigned), c->stream);
+    REQUIRE(c->pinned_int[0] >= 0, RAMA_EINVAL, "sample_topp: no candidate above the cutoff (the reference underflows here)");
+    *next_host = c->pinned_int[0];
     return 0;
 }
 

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """llama2-7B shape at temperature 1 (the reference README's `-r 1` bench setting): tokens/s with the
-top-p sampler on the device (rama_generate) vs the trait-level path that downloads the logits and
-samples on the host every token (what gpu.rs:149-173 does), vs greedy."""
+top-p sampler on the device inside the chained loop (rama_generate) vs the trait-level loop that
+calls Device::sample per token (rama_sample_topp: device sampler + a 4-byte download and a sync
+every token; the reference's gpu.rs:149-173 downloads all logits and samples on the host), vs greedy."""
 import json, sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -22,7 +23,7 @@ for label, T in (("greedy_device", 0.0), ("topp_device", 1.0)):
     eng.generate(PROMPT, 8, T, 0.9, u); dev.sync()
     t0 = time.perf_counter(); toks = eng.generate(PROMPT, steps, T, 0.9, u); dt = time.perf_counter() - t0
     out[label] = round(steps / dt, 1)
-# host-sampled loop over the same fused forward (Device::sample through the C ABI's host sampler)
+# per-token loop over the same fused forward + Device::sample (one sync per token)
 import ctypes as C
 from rama_amd._lib import check
 eng.decode_sampler(0.0)
@@ -37,5 +38,5 @@ for pos in range(steps):
         check(dev.lib.rama_sample_topp(dev.ctx, eng.state.logits, V, 1.0, 0.9, u, C.byref(nxt)))
         token = nxt.value
 dt = time.perf_counter() - t0
-out["topp_host_sampler"] = round(steps / dt, 1)
+out["topp_trait_loop"] = round(steps / dt, 1)
 print(json.dumps({"config": name, "steps": steps, "tok_s": out}))
