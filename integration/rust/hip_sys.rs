@@ -1,0 +1,77 @@
+//! Raw bindings of include/rama_hip.h (the subset the Device trait and the optional fast path need).
+//! `*mut f32` / `*const f32` are DEVICE pointers; every function returns 0 or an error code and
+//! leaves a message in `rama_last_error()` (thread-local).
+#![allow(non_camel_case_types, dead_code)]
+use core::ffi::{c_char, c_int, c_void};
+
+#[repr(C)] pub struct rama_ctx { _p: [u8; 0] }
+#[repr(C)] pub struct rama_model { _p: [u8; 0] }
+
+/// transformer/mod.rs:128-138 with C ints
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct rama_config {
+    pub dim: i32, pub hidden_dim: i32, pub n_layers: i32, pub n_heads: i32,
+    pub n_kv_heads: i32, pub vocab_size: i32, pub seq_len: i32, pub shared_weight: i32,
+}
+/// transformer/state.rs:53-74 as device pointers
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct rama_weights {
+    pub token_embedding_table: *const f32, pub rms_att_weight: *const f32, pub rms_ffn_weight: *const f32,
+    pub wq: *const f32, pub wk: *const f32, pub wv: *const f32, pub wo: *const f32,
+    pub w1: *const f32, pub w2: *const f32, pub w3: *const f32,
+    pub rms_final_weight: *const f32, pub freq_cis_real: *const f32, pub freq_cis_imag: *const f32,
+    pub wcls: *const f32,
+}
+/// transformer/state.rs:3-17 as device pointers
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct rama_run_state {
+    pub x: *mut f32, pub xb: *mut f32, pub xb2: *mut f32, pub hb: *mut f32, pub hb2: *mut f32,
+    pub q: *mut f32, pub k: *mut f32, pub v: *mut f32, pub att: *mut f32, pub logits: *mut f32,
+    pub key_cache: *mut f32, pub value_cache: *mut f32,
+}
+
+extern "C" {
+    pub fn rama_ctx_create(device: c_int, stream: *mut c_void, out: *mut *mut rama_ctx) -> c_int;
+    pub fn rama_ctx_destroy(ctx: *mut rama_ctx) -> c_int;
+    pub fn rama_sync(ctx: *mut rama_ctx) -> c_int;
+    pub fn rama_last_error() -> *const c_char;
+
+    pub fn rama_alloc_f32(ctx: *mut rama_ctx, n: usize, out: *mut *mut f32) -> c_int;
+    pub fn rama_upload_f32(ctx: *mut rama_ctx, host: *const f32, n: usize, out: *mut *mut f32) -> c_int;
+    pub fn rama_download_f32(ctx: *mut rama_ctx, src: *const f32, n: usize, host: *mut f32) -> c_int;
+    pub fn rama_free(ctx: *mut rama_ctx, p: *mut c_void) -> c_int;
+
+    // one per Device<T> method (device/device.rs:4-21)
+    pub fn rama_array_add(ctx: *mut rama_ctx, target: *mut f32, source: *const f32, n: usize) -> c_int;
+    pub fn rama_array_mult(ctx: *mut rama_ctx, target: *mut f32, source: *const f32, n: usize) -> c_int;
+    pub fn rama_sinu(ctx: *mut rama_ctx, o: *mut f32, n: usize) -> c_int;
+    pub fn rama_copy_from_slice(ctx: *mut rama_ctx, target: *mut f32, source: *const f32, n: usize) -> c_int;
+    pub fn rama_rmsnorm(ctx: *mut rama_ctx, o: *mut f32, x: *const f32, weight: *const f32, n: usize) -> c_int;
+    pub fn rama_apply_position(ctx: *mut rama_ctx, q: *mut f32, k: *mut f32, pos_real: *const f32,
+                               pos_img: *const f32, head_size: usize) -> c_int;
+    pub fn rama_matmul(ctx: *mut rama_ctx, o: *mut f32, a: *const f32, b: *const f32,
+                       width: usize, o_rows: usize, o_cols: usize) -> c_int;
+    pub fn rama_softmax(ctx: *mut rama_ctx, x: *mut f32, n: usize) -> c_int;
+    pub fn rama_multi_head_attention(ctx: *mut rama_ctx, xb: *mut f32, att: *mut f32, q: *const f32,
+                                     key_cache: *const f32, value_cache: *const f32, layer: c_int, dim: c_int,
+                                     pos: c_int, head_size: c_int, seq_len: c_int, n_heads: c_int) -> c_int;
+    pub fn rama_sample_argmax(ctx: *mut rama_ctx, logits: *const f32, n: usize, next: *mut i32) -> c_int;
+    pub fn rama_sample_topp(ctx: *mut rama_ctx, logits: *const f32, n: usize, temperature: f32,
+                            topp: f32, u: f32, next: *mut i32) -> c_int;
+
+    // optional fast path: forward() / generate() as single calls, same observable state
+    pub fn rama_forward(ctx: *mut rama_ctx, cfg: *const rama_config, w: *const rama_weights,
+                        s: *mut rama_run_state, token: c_int, pos: c_int) -> c_int;
+    pub fn rama_prefill(ctx: *mut rama_ctx, cfg: *const rama_config, w: *const rama_weights,
+                        s: *mut rama_run_state, tokens_host: *const i32, n_tokens: c_int, pos0: c_int) -> c_int;
+    pub fn rama_generate(ctx: *mut rama_ctx, cfg: *const rama_config, w: *const rama_weights,
+                         s: *mut rama_run_state, prompt_tokens_host: *const i32, n_prompt: c_int, steps: c_int,
+                         temperature: f32, topp: f32, u: f32, out_tokens_host: *mut i32) -> c_int;
+    pub fn rama_set_graph_mode(ctx: *mut rama_ctx, enabled: c_int) -> c_int;
+
+    // resident model straight from a v0 checkpoint (mmap + one H2D copy)
+    pub fn rama_model_load(ctx: *mut rama_ctx, path: *const c_char, out: *mut *mut rama_model) -> c_int;
+    pub fn rama_model_config(m: *const rama_model, cfg: *mut rama_config) -> c_int;
+    pub fn rama_model_weights(m: *const rama_model, w: *mut rama_weights) -> c_int;
+    pub fn rama_model_free(ctx: *mut rama_ctx, m: *mut rama_model) -> c_int;
+}
