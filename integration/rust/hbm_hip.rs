@@ -1,7 +1,7 @@
 //! Host `Vec<f32>` weights / state -> HBM, and the views over them, for the `hip` feature.
 use crate::device::hip::{Hip, HipSlice};
-use super::state::{RunState, RunStateView, TransformerWeights, TransformerWeightsView};
-use super::{MutView, View};
+use super::state::{RunState, TransformerWeights, TransformerWeightsView};
+use super::View;
 
 macro_rules! upload {
     ($dev:expr, $src:expr, { $($f:ident),* $(,)? } $(, $extra:ident : $val:expr)*) => {
@@ -37,10 +37,4 @@ impl<'a> TransformerWeightsView<'a, HipSlice> {
     }
 }
 
-impl<'a> RunStateView<'a, HipSlice> {
-    /// same shape as the reference's `from_rs` for the CPU/CUDA storages (state.rs:35-50)
-    pub fn from_hip_rs(rs: &'a mut RunState<HipSlice>) -> Self {
-        macro_rules! mv { ($($f:ident),*) => { RunStateView { $($f: MutView::new(&mut rs.$f),)* } } }
-        mv!(x, xb, xb2, hb, hb2, q, k, v, att, logits, key_cache, value_cache)
-    }
-}
+// RunStateView::from_rs (state.rs:35-50) is generic over the storage and needs no HIP twin.

@@ -116,7 +116,7 @@ impl Device<HipSlice> for Hip {
         next as usize
     }
     fn to_cpu(&self, state: &RunStateView<HipSlice>, cpu_state: &mut RunState<Vec<f32>>) {
-        macro_rules! pull { ($($f:ident),*) => { $( self.download_into(state.$f.data, &mut cpu_state.$f); )* } }
+        macro_rules! pull { ($($f:ident),*) => { $( self.download_into(&*state.$f.data, &mut cpu_state.$f); )* } }
         pull!(x, xb, xb2, hb, hb2, q, k, v, att, logits, key_cache, value_cache);
     }
 }
