@@ -115,6 +115,17 @@ __device__ __forceinline__ int block_min_i(int v) {
     __syncthreads();
     return r;
 }
+__device__ __forceinline__ int block_sum_i(int v) {
+    __shared__ int s_s[16];
+    v = wave_sum_i(v);
+    if ((threadIdx.x & 63) == 0) s_s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int r = 0;
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 0; w < nw; w++) r += s_s[w];
+    __syncthreads();
+    return r;
+}
 __device__ __forceinline__ float dot4(f4 a, f4 b, float acc) {
     acc = fmaf(a.x, b.x, acc);
     acc = fmaf(a.y, b.y, acc);
@@ -808,13 +819,15 @@ __global__ __launch_bounds__(1024) void topp_pick_kernel(ToppParams p, ArgmaxPar
     const int m = *p.m;
     if (tid == 0) { s_last = m > 0 ? m - 1 : 0; s_cum = 0.0f; s_pick = 0; }
     // Sequential running sum in sorted order (infer.rs:70-73): the fp32 rounding of cum_i depends
-    // on every earlier add, so ONE thread walks the list -- 8 values per step from LDS (two 16-byte
-    // reads, eight dependent adds, running sums written back in place, one threshold test per
-    // step) -- while all threads stage the next chunk (double buffer) and afterwards copy the
-    // running sums out.  Padding zeros leave cum unchanged.
+    // on every earlier add, so the chain cannot be split.  Wave 0 walks it 64 values at a time with
+    // a lane ripple: lane i holds p_i, lane 0 is seeded with carry + p_0, and 63 identical
+    // `v_add_f32_dpp s, s, p wave_shr:1` steps (lane i: s = s[i-1] + p_i; lane 0 has no source lane
+    // and keeps its value) leave S_i in lane i -- one 4-cycle VALU op (+2 wait states) per element,
+    // no LDS turn inside the chain.  All threads stage the next 4096-value chunk meanwhile (double
+    // buffer) and afterwards copy the running sums out.  Padding zeros leave the sum unchanged.
     const int nchunks = (m + kToppChunk - 1) / kToppChunk;
     auto stage = [&](int c) {
-        const int base = c * kToppChunk, len = min(kToppChunk, m - base), padded = (len + 7) & ~7;
+        const int base = c * kToppChunk, len = min(kToppChunk, m - base), padded = (len + 63) & ~63;
         for (int i = tid; i < padded; i += 1024) s_p[c & 1][i] = i < len ? p.keys[base + i] : 0.0f;
     };
     if (nchunks > 0) stage(0);
@@ -822,27 +835,33 @@ __global__ __launch_bounds__(1024) void topp_pick_kernel(ToppParams p, ArgmaxPar
     for (int c = 0; c < nchunks; c++) {
         const int base = c * kToppChunk, len = min(kToppChunk, m - base);
         if (c + 1 < nchunks) stage(c + 1);
-        if (tid == 0) {
-            float cum = s_cum;
-            f4* q = reinterpret_cast<f4*>(s_p[c & 1]);
-            const int nb = (len + 7) >> 3;
+        if (tid < 64) {
+            float* q = s_p[c & 1];
+            float carry = s_cum;
+            const int nblk = (len + 63) >> 6;
             int hit = -1;
-            for (int b8 = 0; b8 < nb; b8++) {
-                f4 a = q[2 * b8], b = q[2 * b8 + 1];
-                a.x = cum + a.x; a.y = a.x + a.y; a.z = a.y + a.z; a.w = a.z + a.w;
-                b.x = a.w + b.x; b.y = b.x + b.y; b.z = b.y + b.z; b.w = b.z + b.w;
-                q[2 * b8] = a; q[2 * b8 + 1] = b;
-                cum = b.w;
-                if (cum > p.topp) {              // first crossing inside this block of 8
-                    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-                    int j = 0;
-                    while (!(v[j] > p.topp)) j++;
-                    hit = b8 * 8 + j; cum = v[j];
+            float pv = q[tid];
+            for (int blk = 0; blk < nblk; blk++) {
+                const float pn = q[min(blk + 1, nblk - 1) * 64 + tid];      // next block's values: in flight during the ripple
+                float sv = tid == 0 ? carry + pv : pv;
+#pragma unroll
+                for (int k = 0; k < 63; k++)
+                    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(sv) : "v"(pv));
+                q[blk * 64 + tid] = sv;
+                carry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sv), 63));
+                const unsigned long long over = __ballot(sv > p.topp);
+                if (over) {                       // sums are non-decreasing: the first set lane is the crossing
+                    const int l0 = __ffsll((long long)over) - 1;
+                    hit = blk * 64 + l0;
+                    carry = __shfl(sv, l0);
                     break;
                 }
+                pv = pn;
             }
-            s_cum = cum;
-            if (hit >= 0) { s_last = base + hit; s_pick = 1; }
+            if (tid == 0) {
+                s_cum = carry;
+                if (hit >= 0) { s_last = base + hit; s_pick = 1; }
+            }
         }
         __syncthreads();
         // running sums of this chunk -> global (read again below); only indices < last matter
@@ -855,9 +874,11 @@ __global__ __launch_bounds__(1024) void topp_pick_kernel(ToppParams p, ArgmaxPar
     // the running sums of that loop are exactly the ones stored above
     const int last = s_last;
     const float r = p.u * s_cum;
-    int best = last;
-    for (int i = tid; i < last; i += 1024) if (r < p.prefix[i]) { best = i; break; }
-    best = block_min_i(best);
+    // the running sums never decrease, so "first i < last with r < cum_i" = the number of i < last
+    // with cum_i <= r: independent loads, no early exit
+    int below = 0;
+    for (int i = tid; i < last; i += 1024) below += !(r < p.prefix[i]);
+    const int best = min(block_sum_i(below), last);
     if (tid == 0) {
         const int idx = m > 0 ? p.vals[best] : -1;
         s_next = finish_step(fin, idx, pos, n_forced, n_out, forced_tok);
