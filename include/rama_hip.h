@@ -166,6 +166,15 @@ int  rama_forward_stage(rama_ctx *ctx, const rama_config *cfg, const rama_weight
 int  rama_prefill(rama_ctx *ctx, const rama_config *cfg, const rama_weights *w, rama_run_state *s,
                   const int32_t *tokens_host, int n_tokens, int pos0);
 
+/* One decode step for up to 8 INDEPENDENT sequences (the server's concurrent requests), every
+ * weight row streamed once for all of them (no reference counterpart).  states[i] is sequence
+ * i's run state; afterwards it holds what rama_forward(token_i, pos_i) would have left in it:
+ * the appended cache rows and the logits (x / xb / q ... scratch is not maintained).  Sequences may
+ * sit at different positions; two entries must not share a state. */
+int  rama_decode_batch(rama_ctx *ctx, const rama_config *cfg, const rama_weights *w,
+                       const rama_run_state *states, const int32_t *tokens_host,
+                       const int32_t *positions_host, int n_seq);
+
 /* Layer-pipeline stage variants (no reference counterpart: the reference is single-device).
  * The token id is read from / written to DEVICE memory, so a stage boundary is one RCCL
  * send/recv of x[dim] (and of one int32 from the last stage back to the first) with no host

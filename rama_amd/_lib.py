@@ -83,6 +83,7 @@ SIGNATURES = {
     "rama_forward": (_int, [_vp, _cfgp, _wp, _sp, _int, _int]),
     "rama_forward_stage": (_int, [_vp, _cfgp, _wp, _sp, _int, _int, _stp]),
     "rama_prefill": (_int, [_vp, _cfgp, _wp, _sp, i32p, _int, _int]),
+    "rama_decode_batch": (_int, [_vp, _cfgp, _wp, _sp, i32p, i32p, _int]),
     "rama_forward_stage_devtok": (_int, [_vp, _cfgp, _wp, _sp, _vp, _int, _stp]),
     "rama_argmax_dev": (_int, [_vp, _vp, _sz, _vp]),
     "rama_generate_greedy": (_int, [_vp, _cfgp, _wp, _sp, i32p, _int, _int, i32p]),

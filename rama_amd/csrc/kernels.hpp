@@ -379,6 +379,9 @@ __global__ __launch_bounds__(kWG) void matvec_unaligned(float* o, const float* a
 // pos and the padding lanes of head_size 48 get offset 0x80000000 and read as 0 -- no branches
 // in the load stream.  The first V tile is requested before the softmax, which does not need
 // it, so its latency hides behind the exp/sum phase.
+// one independent sequence of a batched decode step (rama_decode_batch): its cache bases and position
+struct SeqSlot { float* kc; float* vc; int pos; int pad; };
+
 struct AttnParams {
     const float* q;       // [dim]
     const float* kc;      // this layer's key cache   [seq, dim]
@@ -394,6 +397,9 @@ struct AttnParams {
     int nsplit;
     // batched queries (prefill): blockIdx.z = query index; query z sits at position pos + z
     int q_stride, xb_stride;
+    // batched sequences (rama_decode_batch): query z belongs to sequence z with its own caches and
+    // position; layer_off = floats from a cache base to this layer's slab
+    const SeqSlot* seqs; size_t layer_off;
 };
 
 constexpr int kAttnWaves = 16;
@@ -414,7 +420,7 @@ __global__ __launch_bounds__(kAttnThreads) void attention_kernel(AttnParams p) {
     const int h = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int zq = (int)blockIdx.z;
-    const int pos = (p.ctl ? p.ctl->pos : p.pos_val) + zq;
+    const int pos = p.seqs ? p.seqs[zq].pos : (p.ctl ? p.ctl->pos : p.pos_val) + zq;
     const int hs = p.head_size;
     // timesteps [t0, t1) of this workgroup: everything, or one slice in split-T mode
     int t0 = 0, t1 = pos + 1;
@@ -427,8 +433,8 @@ __global__ __launch_bounds__(kAttnThreads) void attention_kernel(AttnParams p) {
     const int tg = lane / G;                 // my timestep slot within the wave
     const bool lane_ok = li * 4 < hs;
     const unsigned cache_bytes = (unsigned)p.seq_len * (unsigned)p.dim * 4u;
-    const __amdgpu_buffer_rsrc_t rk = make_rsrc(p.kc, cache_bytes);
-    const __amdgpu_buffer_rsrc_t rv = make_rsrc(p.vc, cache_bytes);
+    const __amdgpu_buffer_rsrc_t rk = make_rsrc(p.seqs ? p.seqs[zq].kc + p.layer_off : p.kc, cache_bytes);
+    const __amdgpu_buffer_rsrc_t rv = make_rsrc(p.seqs ? p.seqs[zq].vc + p.layer_off : p.vc, cache_bytes);
     const unsigned col = (unsigned)(h * hs + li * 4) * 4u;
     const unsigned rowb = (unsigned)p.dim * 4u;
     // timestep of slot u in the round starting at `base`

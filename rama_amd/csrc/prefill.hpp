@@ -32,6 +32,8 @@ struct MtParams {
     int pos0;              // position of token 0 (EPI_QKV)
     const float* fr; const float* fi; int head_size;
     float* kc; float* vc;  // this layer's cache slabs [seq, dim]
+    // batched independent sequences (rama_decode_batch): token t belongs to sequence t
+    const SeqSlot* seqs; size_t layer_off;
 };
 
 // Wave reduction of 32 per-lane values at once: each butterfly step folds the upper half of the
@@ -239,7 +241,9 @@ __global__ __launch_bounds__(kMtThreads) void gemm_mt_rows(MtParams p) {
                 if (u < 2) {
                     const int r = r0 + 2 * u;
                     float a = total(2 * u) * v, b = total(2 * u + 1) * v;
-                    const int pos = p.pos0 + t;
+                    const int pos = p.seqs ? p.seqs[t].pos : p.pos0 + t;
+                    float* kc = p.seqs ? p.seqs[t].kc + p.layer_off : p.kc;
+                    float* vc = p.seqs ? p.seqs[t].vc + p.layer_off : p.vc;
                     if (m < 2) {
                         const int i = (r % p.head_size) >> 1;
                         const float c = p.fr[(size_t)pos * (p.head_size >> 1) + i], sn = p.fi[(size_t)pos * (p.head_size >> 1) + i];
@@ -248,8 +252,8 @@ __global__ __launch_bounds__(kMtThreads) void gemm_mt_rows(MtParams p) {
                     }
                     float* o = (m == 0 ? p.o[0] : (m == 1 ? p.o[1] : p.o[2])) + (size_t)t * p.o_stride;
                     o[r] = a; o[r + 1] = b;
-                    if (m == 1) { p.kc[(size_t)pos * p.rows + r] = a; p.kc[(size_t)pos * p.rows + r + 1] = b; }
-                    if (m == 2) { p.vc[(size_t)pos * p.rows + r] = a; p.vc[(size_t)pos * p.rows + r + 1] = b; }
+                    if (m == 1) { kc[(size_t)pos * p.rows + r] = a; kc[(size_t)pos * p.rows + r + 1] = b; }
+                    if (m == 2) { vc[(size_t)pos * p.rows + r] = a; vc[(size_t)pos * p.rows + r + 1] = b; }
                 }
             } else {
                 if (r0 + u < p.rows) {

@@ -722,6 +722,77 @@ static int launch_mt(rama_ctx* c, MtParams& p) {
 }
 
 // ---- batched-prompt prefill (prefill.hpp): n positions pos0..pos0+n-1 through the layers PB at a time
+// scratch of the token-batch passes: X, Q, KS, VS, XB [kPB, dim], HB [kPB, hidden], token ids,
+// (decode_batch) logits [kPB, vocab] and the sequence table
+struct BatchScratch { float *X, *Q, *KS, *VS, *XB, *HB, *LG; int* toks; SeqSlot* seqs; };
+
+static int ensure_batch_scratch(rama_ctx* c, const rama_config* cfg, bool with_logits, BatchScratch* b) {
+    const size_t dim = cfg->dim, hidden = cfg->hidden_dim;
+    const size_t need = (size_t)kPB * (5 * dim + hidden) + 64 + 64 + (with_logits ? (size_t)kPB * cfg->vocab_size : 0);
+    if (need > c->pf_floats) {
+        if (c->pf_blob) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->pf_blob)); c->pf_blob = nullptr; }
+        HIPCHK(hipMalloc(&c->pf_blob, need * sizeof(float)));
+        c->pf_floats = need;
+    }
+    b->X = c->pf_blob; b->Q = b->X + kPB * dim; b->KS = b->Q + kPB * dim; b->VS = b->KS + kPB * dim;
+    b->XB = b->VS + kPB * dim; b->HB = b->XB + kPB * dim;
+    b->toks = reinterpret_cast<int*>(b->HB + kPB * hidden);
+    b->seqs = reinterpret_cast<SeqSlot*>(b->toks + 64);
+    b->LG = reinterpret_cast<float*>(b->toks + 128);
+    return 0;
+}
+
+// nt <= kPB tokens (already embedded in b.X) through every layer, each weight row streamed once.
+// seqs == nullptr: consecutive positions p0.. of ONE sequence (caches kc0/vc0 = its cache bases);
+// seqs != nullptr: token t belongs to independent sequence t (device table b.seqs).
+static int run_layers_batched(rama_ctx* c, const rama_config* cfg, const rama_weights* w, const BatchScratch& b,
+                              int nt, int p0, float* key_cache, float* value_cache, bool seqs) {
+    const int dim = cfg->dim, hidden = cfg->hidden_dim, hs = dim / cfg->n_heads;
+    const size_t dd = (size_t)dim * dim, hd = (size_t)hidden * dim;
+    int rc;
+    for (int layer = 0; layer < cfg->n_layers; layer++) {
+        const size_t li = (size_t)layer;
+        const size_t layer_off = li * cfg->seq_len * dim;
+        float* kc = key_cache ? key_cache + layer_off : nullptr;
+        float* vc = value_cache ? value_cache + layer_off : nullptr;
+        MtParams p{};
+        p.n_tok = nt; p.pos0 = p0; p.fr = w->freq_cis_real; p.fi = w->freq_cis_imag; p.head_size = hs; p.kc = kc; p.vc = vc;
+        p.seqs = seqs ? b.seqs : nullptr; p.layer_off = layer_off;
+        // infer.rs:19-33 for the batch
+        p.w[0] = w->wq + li * dd; p.w[1] = w->wk + li * dd; p.w[2] = w->wv + li * dd;
+        p.x = b.X; p.x_stride = dim; p.nw = w->rms_att_weight + li * dim;
+        p.o[0] = b.Q; p.o[1] = b.KS; p.o[2] = b.VS; p.o_stride = dim; p.K = dim; p.rows = dim; p.nmat = 3; p.epi = EPI_QKV;
+        rc = launch_mt<true, EPI_QKV>(c, p); if (rc) return rc;
+        {   // infer.rs:34: query z attends to positions 0..pos(z)
+            AttnParams a{};
+            a.q = b.Q; a.kc = kc; a.vc = vc; a.att = nullptr; a.xb = b.XB; a.ctl = nullptr; a.pos_val = p0;
+            a.dim = dim; a.head_size = hs; a.seq_len = cfg->seq_len; a.q_stride = dim; a.xb_stride = dim;
+            a.seqs = seqs ? b.seqs : nullptr; a.layer_off = layer_off;
+            const int G = hs <= 64 ? 16 : (hs <= 128 ? 32 : 64);
+            size_t shm = (size_t)(attn_scratch_floats(G) + cfg->seq_len) * sizeof(float);
+            REQUIRE(shm <= 64 * 1024, RAMA_EUNSUP, "token batch: seq_len too long for the single-workgroup attention kernel");
+            dim3 grid(cfg->n_heads, 1, nt);
+            if (G == 16) hipLaunchKernelGGL((attention_kernel<16, false>), grid, dim3(kAttnThreads), shm, c->stream, a);
+            else if (G == 32) hipLaunchKernelGGL((attention_kernel<32, false>), grid, dim3(kAttnThreads), shm, c->stream, a);
+            else hipLaunchKernelGGL((attention_kernel<64, false>), grid, dim3(kAttnThreads), shm, c->stream, a);
+            LAUNCHCHK();
+        }
+        // infer.rs:35-37
+        p.w[0] = w->wo + li * dd; p.x = b.XB; p.x_stride = dim; p.nw = nullptr; p.o[0] = b.X; p.o_stride = dim;
+        p.K = dim; p.rows = dim; p.nmat = 1; p.epi = EPI_RESID;
+        rc = launch_mt<false, EPI_RESID>(c, p); if (rc) return rc;
+        // infer.rs:39-45
+        p.w[0] = w->w1 + li * hd; p.w[1] = w->w3 + li * hd; p.x = b.X; p.x_stride = dim; p.nw = w->rms_ffn_weight + li * dim;
+        p.o[0] = b.HB; p.o_stride = hidden; p.K = dim; p.rows = hidden; p.nmat = 1; p.epi = 3;
+        rc = launch_mt<true, 3>(c, p); if (rc) return rc;
+        // infer.rs:46-47
+        p.w[0] = w->w2 + li * hd; p.x = b.HB; p.x_stride = hidden; p.nw = nullptr; p.o[0] = b.X; p.o_stride = dim;
+        p.K = hidden; p.rows = dim; p.nmat = 1; p.epi = EPI_RESID;
+        rc = launch_mt<false, EPI_RESID>(c, p); if (rc) return rc;
+    }
+    return 0;
+}
+
 int rama_prefill(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s,
                  const int32_t* tokens_host, int n_tokens, int pos0) {
     REQUIRE(c && tokens_host, RAMA_EINVAL, "prefill: NULL argument");
@@ -730,67 +801,62 @@ int rama_prefill(rama_ctx* c, const rama_config* cfg, const rama_weights* w, ram
     rc = check_stage(cfg, w, s, &st); if (rc) return rc;
     REQUIRE(n_tokens >= 1 && pos0 >= 0 && pos0 + n_tokens <= cfg->seq_len, RAMA_EINVAL, "prefill: positions outside [0, seq_len)");
     for (int i = 0; i < n_tokens; i++) REQUIRE(tokens_host[i] >= 0 && tokens_host[i] < cfg->vocab_size, RAMA_EINVAL, "prefill: token outside the vocabulary");
-    const int dim = cfg->dim, hidden = cfg->hidden_dim, hs = dim / cfg->n_heads;
-    const size_t dd = (size_t)dim * dim, hd = (size_t)hidden * dim;
-    const size_t need = (size_t)kPB * (5 * (size_t)dim + hidden) + 64;
-    if (need > c->pf_floats) {
-        if (c->pf_blob) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->pf_blob)); c->pf_blob = nullptr; }
-        HIPCHK(hipMalloc(&c->pf_blob, need * sizeof(float)));
-        c->pf_floats = need;
-    }
-    float* X = c->pf_blob; float* Q = X + (size_t)kPB * dim; float* KS = Q + (size_t)kPB * dim; float* VS = KS + (size_t)kPB * dim;
-    float* XB = VS + (size_t)kPB * dim; float* HB = XB + (size_t)kPB * dim; int* toks = reinterpret_cast<int*>(HB + (size_t)kPB * hidden);
+    const int dim = cfg->dim;
+    BatchScratch b{};
+    rc = ensure_batch_scratch(c, cfg, false, &b); if (rc) return rc;
     c->embedded_x = nullptr; c->host_pos = -1;
     int last_nt = 0;
     for (int c0 = 0; c0 < n_tokens; c0 += kPB) {
         const int nt = std::min(kPB, n_tokens - c0), p0 = pos0 + c0;
         last_nt = nt;
-        HIPCHK(hipMemcpyAsync(toks, tokens_host + c0, sizeof(int) * nt, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(embed_mt_kernel, dim3((dim + 255) / 256, nt), dim3(256), 0, c->stream, X, w->token_embedding_table, (const int*)toks, nt, dim);
+        HIPCHK(hipMemcpyAsync(b.toks, tokens_host + c0, sizeof(int) * nt, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(embed_mt_kernel, dim3((dim + 255) / 256, nt), dim3(256), 0, c->stream, b.X, w->token_embedding_table, (const int*)b.toks, nt, dim);
         LAUNCHCHK();
-        for (int layer = 0; layer < cfg->n_layers; layer++) {
-            const size_t li = (size_t)layer;
-            float* kc = s->key_cache + li * cfg->seq_len * dim;
-            float* vc = s->value_cache + li * cfg->seq_len * dim;
-            MtParams p{};
-            p.n_tok = nt; p.pos0 = p0; p.fr = w->freq_cis_real; p.fi = w->freq_cis_imag; p.head_size = hs; p.kc = kc; p.vc = vc;
-            // infer.rs:19-33 for PB positions
-            p.w[0] = w->wq + li * dd; p.w[1] = w->wk + li * dd; p.w[2] = w->wv + li * dd;
-            p.x = X; p.x_stride = dim; p.nw = w->rms_att_weight + li * dim;
-            p.o[0] = Q; p.o[1] = KS; p.o[2] = VS; p.o_stride = dim; p.K = dim; p.rows = dim; p.nmat = 3; p.epi = EPI_QKV;
-            rc = launch_mt<true, EPI_QKV>(c, p); if (rc) return rc;
-            {   // infer.rs:34 for PB queries: query z attends to positions 0..p0+z
-                AttnParams a{};
-                a.q = Q; a.kc = kc; a.vc = vc; a.att = nullptr; a.xb = XB; a.ctl = nullptr; a.pos_val = p0;
-                a.dim = dim; a.head_size = hs; a.seq_len = cfg->seq_len; a.q_stride = dim; a.xb_stride = dim;
-                const int G = hs <= 64 ? 16 : (hs <= 128 ? 32 : 64);
-                size_t shm = (size_t)(attn_scratch_floats(G) + cfg->seq_len) * sizeof(float);
-                REQUIRE(shm <= 64 * 1024, RAMA_EUNSUP, "prefill: seq_len too long for the single-workgroup attention kernel");
-                dim3 grid(cfg->n_heads, 1, nt);
-                if (G == 16) hipLaunchKernelGGL((attention_kernel<16, false>), grid, dim3(kAttnThreads), shm, c->stream, a);
-                else if (G == 32) hipLaunchKernelGGL((attention_kernel<32, false>), grid, dim3(kAttnThreads), shm, c->stream, a);
-                else hipLaunchKernelGGL((attention_kernel<64, false>), grid, dim3(kAttnThreads), shm, c->stream, a);
-                LAUNCHCHK();
-            }
-            // infer.rs:35-37
-            p.w[0] = w->wo + li * dd; p.x = XB; p.x_stride = dim; p.nw = nullptr; p.o[0] = X; p.o_stride = dim;
-            p.K = dim; p.rows = dim; p.nmat = 1; p.epi = EPI_RESID;
-            rc = launch_mt<false, EPI_RESID>(c, p); if (rc) return rc;
-            // infer.rs:39-45
-            p.w[0] = w->w1 + li * hd; p.w[1] = w->w3 + li * hd; p.x = X; p.x_stride = dim; p.nw = w->rms_ffn_weight + li * dim;
-            p.o[0] = HB; p.o_stride = hidden; p.K = dim; p.rows = hidden; p.nmat = 1; p.epi = 3;
-            rc = launch_mt<true, 3>(c, p); if (rc) return rc;
-            // infer.rs:46-47
-            p.w[0] = w->w2 + li * hd; p.x = HB; p.x_stride = hidden; p.nw = nullptr; p.o[0] = X; p.o_stride = dim;
-            p.K = hidden; p.rows = dim; p.nmat = 1; p.epi = EPI_RESID;
-            rc = launch_mt<false, EPI_RESID>(c, p); if (rc) return rc;
-        }
+        rc = run_layers_batched(c, cfg, w, b, nt, p0, s->key_cache, s->value_cache, false);
+        if (rc) return rc;
     }
     // the last position's residual stream, then infer.rs:49-51 for it only (generate() ignores the
     // logits of the forced positions before it)
-    hipLaunchKernelGGL(copy_kernel, dim3(ew_grid(dim)), dim3(256), 0, c->stream, s->x, (const float*)(X + (size_t)(last_nt - 1) * dim), (size_t)dim);
+    hipLaunchKernelGGL(copy_kernel, dim3(ew_grid(dim)), dim3(256), 0, c->stream, s->x, (const float*)(b.X + (size_t)(last_nt - 1) * dim), (size_t)dim);
     LAUNCHCHK();
     return launch_rows<true, EPI_STORE>(c, s->logits, w->wcls, s->x, w->rms_final_weight, dim, cfg->vocab_size);
+}
+
+// ---- one decode step for up to kPB INDEPENDENT sequences (the server's concurrent requests,
+// SURVEY 8e): every weight row is streamed once for all of them.  No reference counterpart; the
+// contract is "what forward(token_i, pos_i) leaves in state_i, for every i": cache rows + logits.
+int rama_decode_batch(rama_ctx* c, const rama_config* cfg, const rama_weights* w, const rama_run_state* states,
+                      const int32_t* tokens_host, const int32_t* pos_host, int n_seq) {
+    REQUIRE(c && states && tokens_host && pos_host, RAMA_EINVAL, "decode_batch: NULL argument");
+    REQUIRE(n_seq >= 1 && n_seq <= kPB, RAMA_EINVAL, "decode_batch: 1..8 sequences per call");
+    int rc = check_cfg(cfg); if (rc) return rc;
+    rama_stage st{0, cfg->n_layers, 1, 1};
+    SeqSlot slots[kPB] = {};
+    for (int i = 0; i < n_seq; i++) {
+        rc = check_stage(cfg, w, &states[i], &st); if (rc) return rc;
+        REQUIRE(tokens_host[i] >= 0 && tokens_host[i] < cfg->vocab_size, RAMA_EINVAL, "decode_batch: token outside the vocabulary");
+        REQUIRE(pos_host[i] >= 0 && pos_host[i] < cfg->seq_len, RAMA_EINVAL, "decode_batch: position outside [0, seq_len)");
+        for (int j = 0; j < i; j++) REQUIRE(states[j].key_cache != states[i].key_cache && states[j].logits != states[i].logits, RAMA_EINVAL, "decode_batch: two sequences share a run state");
+        slots[i].kc = states[i].key_cache; slots[i].vc = states[i].value_cache; slots[i].pos = pos_host[i];
+    }
+    const int dim = cfg->dim, V = cfg->vocab_size;
+    BatchScratch b{};
+    rc = ensure_batch_scratch(c, cfg, true, &b); if (rc) return rc;
+    c->embedded_x = nullptr; c->host_pos = -1;
+    HIPCHK(hipMemcpyAsync(b.toks, tokens_host, sizeof(int) * n_seq, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(b.seqs, slots, sizeof(SeqSlot) * n_seq, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(embed_mt_kernel, dim3((dim + 255) / 256, n_seq), dim3(256), 0, c->stream, b.X, w->token_embedding_table, (const int*)b.toks, n_seq, dim);
+    LAUNCHCHK();
+    rc = run_layers_batched(c, cfg, w, b, n_seq, 0, nullptr, nullptr, true);
+    if (rc) return rc;
+    // infer.rs:49-51 for every sequence: final rmsnorm + classifier as one more multi-RHS pass
+    MtParams p{};
+    p.n_tok = n_seq; p.w[0] = w->wcls; p.x = b.X; p.x_stride = dim; p.nw = w->rms_final_weight;
+    p.o[0] = b.LG; p.o_stride = V; p.K = dim; p.rows = V; p.nmat = 1; p.epi = EPI_STORE;
+    rc = launch_mt<true, EPI_STORE>(c, p); if (rc) return rc;
+    for (int i = 0; i < n_seq; i++)
+        HIPCHK(hipMemcpyAsync(states[i].logits, b.LG + (size_t)i * V, sizeof(float) * V, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
 }
 
 // ---- device-chained greedy decode (generate() at T == 0, mod.rs:169-206)

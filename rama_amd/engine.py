@@ -169,3 +169,15 @@ class Engine:
 
     def free(self):
         check(self.device.lib.rama_state_free(self.device.ctx, C.byref(self.state)))
+
+
+def decode_batch(engines: Sequence["Engine"], tokens: Sequence[int], positions: Sequence[int]):
+    """One decode step for up to 8 independent sequences over the same model (rama_decode_batch):
+    engines[i] advances by forward(tokens[i], positions[i]); its logits()/caches are updated."""
+    assert 1 <= len(engines) == len(tokens) == len(positions) <= 8
+    e0 = engines[0]
+    states = (rama_run_state * len(engines))(*[e.state for e in engines])
+    toks = (C.c_int32 * len(engines))(*tokens)
+    poss = (C.c_int32 * len(engines))(*positions)
+    check(e0.device.lib.rama_decode_batch(e0.device.ctx, C.byref(e0.model.ccfg), C.byref(e0.model.weights),
+                                          states, toks, poss, len(engines)), "rama_decode_batch")

@@ -629,3 +629,54 @@ def test_random_shapes_fused_prefill_and_ops_vs_oracle(dev, shape):
         rama_amd.forward(rcfg, wv, rsv, t, p, dev)
         assert np.abs(dev.download(rsv.logits) - want[p]).max() <= LOGIT_ATOL, ("ops", p)
     rs.free(); ws.free()
+
+
+# ------------------------------------------------------------------ batched independent sequences
+
+@pytest.mark.parametrize("name,n_seq", [("synth_d64_h4", 3), ("synth_d288_h6", 8), ("synth_d768_h12", 5), ("ckpt_untied", 2), ("synth_7bshape_l1", 8)])
+def test_decode_batch_equals_independent_forwards(dev, name, n_seq):
+    """rama_decode_batch: n sequences with different histories and positions advance together, one
+    weight pass; every sequence must end up with the logits and cache rows of its own forward()"""
+    import rama_amd
+    cfg, w, g = load_case(name)
+    toks = g["tokens"].tolist()
+    if name.startswith("ckpt"):
+        m = rama_amd.Model.load(dev, GOLDEN / f"{name}.bin")
+    else:
+        m = rama_amd.Model.synth(dev, to_rama_cfg(cfg), int(g["seed"]), rope=(g["freq_cis_real"], g["freq_cis_imag"]))
+    batch = [rama_amd.Engine(dev, m) for _ in range(n_seq)]
+    orcs = [O.Oracle(cfg, w) for _ in range(n_seq)]
+    # sequence i starts with i tokens of its own history (different positions inside one batch)
+    rng = np.random.default_rng(5)
+    hist = [[1] + [int(t) for t in rng.integers(0, cfg.vocab_size, i % 4)] for i in range(n_seq)]
+    for i in range(n_seq):
+        for p_, t in enumerate(hist[i][:-1]):
+            batch[i].forward(t, p_); orcs[i].forward(t, p_)
+    cur = [h[-1] for h in hist]
+    pos = [len(h) - 1 for h in hist]
+    steps = min(4, cfg.seq_len - max(pos) - 1)
+    for _ in range(steps):
+        rama_amd.decode_batch(batch, cur, pos)
+        for i in range(n_seq):
+            lo = orcs[i].forward(cur[i], pos[i])
+            assert np.abs(batch[i].logits() - lo).max() <= LOGIT_ATOL, (i, pos[i])
+            cur[i] = O.argmax(lo); pos[i] += 1
+    for i in range(n_seq):
+        for buf in ("key_cache", "value_cache"):
+            assert np.abs(batch[i].buffer(buf, orcs[i].s[buf].size) - orcs[i].s[buf]).max() <= STATE_ATOL, (i, buf)
+    for e in batch: e.free()
+    m.free()
+
+
+def test_decode_batch_argument_errors(dev):
+    import rama_amd
+    cfg, w, g = load_case("synth_d64_h4")
+    m = rama_amd.Model.synth(dev, to_rama_cfg(cfg), int(g["seed"]), rope=(g["freq_cis_real"], g["freq_cis_imag"]))
+    a, b = rama_amd.Engine(dev, m), rama_amd.Engine(dev, m)
+    with pytest.raises(rama_amd.RamaError):
+        rama_amd.decode_batch([a, a], [1, 1], [0, 0])                 # one state twice
+    with pytest.raises(rama_amd.RamaError):
+        rama_amd.decode_batch([a, b], [1, cfg.vocab_size], [0, 0])    # token outside the vocabulary
+    with pytest.raises(rama_amd.RamaError):
+        rama_amd.decode_batch([a, b], [1, 1], [0, cfg.seq_len])       # position outside the context
+    a.free(); b.free(); m.free()

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Aggregate decode throughput with B independent sequences sharing each weight pass
+(rama_decode_batch, B = 1..8) at the llama2-7B shape; greedy tokens are fed back through the host
+(argmax of each sequence's logits on the device, 4 bytes each).  Prints one JSON line."""
+import ctypes as C
+import json, sys, time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import rama_amd
+from rama_amd._lib import check
+from bench import SHAPES
+name = sys.argv[1] if len(sys.argv) > 1 else "llama2-7B"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 48
+d, h, L, H, V, seq, shared = SHAPES[name]
+cfg = rama_amd.Config(d, h, L, H, H, V, seq, shared)
+dev = rama_amd.Hip(0)
+model = rama_amd.Model.synth(dev, cfg, seed=0)
+out = {}
+for B in (1, 2, 4, 8):
+    engs = [rama_amd.Engine(dev, model) for _ in range(B)]
+    cur = [1 + i for i in range(B)]
+    nxt = C.c_int32()
+    def step(pos):
+        rama_amd.decode_batch(engs, cur, [pos] * B)
+        for i, e in enumerate(engs):
+            check(dev.lib.rama_sample_argmax(dev.ctx, e.state.logits, V, C.byref(nxt)))
+            cur[i] = nxt.value
+    for p in range(4): step(p)
+    dev.sync()
+    t0 = time.perf_counter()
+    for p in range(4, 4 + steps): step(p)
+    dev.sync()
+    dt = time.perf_counter() - t0
+    out[B] = {"ms_per_step": round(dt * 1e3 / steps, 3), "aggregate_tok_s": round(B * steps / dt, 1)}
+    for e in engs: e.free()
+print(json.dumps({"config": name, "steps": steps, "by_batch": out}))
