@@ -64,6 +64,10 @@ extern "C" {
                         s: *mut rama_run_state, token: c_int, pos: c_int) -> c_int;
     pub fn rama_prefill(ctx: *mut rama_ctx, cfg: *const rama_config, w: *const rama_weights,
                         s: *mut rama_run_state, tokens_host: *const i32, n_tokens: c_int, pos0: c_int) -> c_int;
+    /// one decode step for up to 8 independent sequences (states: array of n_seq run states)
+    pub fn rama_decode_batch(ctx: *mut rama_ctx, cfg: *const rama_config, w: *const rama_weights,
+                             states: *const rama_run_state, tokens_host: *const i32, positions_host: *const i32,
+                             n_seq: c_int) -> c_int;
     pub fn rama_generate(ctx: *mut rama_ctx, cfg: *const rama_config, w: *const rama_weights,
                          s: *mut rama_run_state, prompt_tokens_host: *const i32, n_prompt: c_int, steps: c_int,
                          temperature: f32, topp: f32, u: f32, out_tokens_host: *mut i32) -> c_int;
