@@ -913,7 +913,8 @@ static int enqueue_decode_step_persistent(rama_ctx* c, const rama_config* cfg, c
 }
 
 static int enqueue_decode_step(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s) {
-    if (c->tune_persist && c->kp.kernel_id < 0) return enqueue_decode_step_persistent(c, cfg, w, s);
+    // the single-launch step has the argmax built in: any other sampler takes the launch path
+    if (c->tune_persist && c->kp.kernel_id < 0 && c->samp_T == 0.0f) return enqueue_decode_step_persistent(c, cfg, w, s);
     rama_stage st{0, cfg->n_layers, 0, 1};
     int rc = enqueue_stage(c, cfg, w, s, &st);
     if (rc) return rc;
