@@ -28,11 +28,13 @@ rcfg = rama_amd.Config(d, h, L, H, H, V, seq, False)
 eng = rama_amd.Engine(dev, rama_amd.Model.synth(dev, rcfg, 0, rope=rope))
 prompt = [10646, 2501, 263, 931]
 token, diffs, toks_cpu, toks_gpu = 1, [], [], []
+fed, logits_cpu = [], []
 t_cpu = 0.0
 for pos in range(n_pos):
     t1 = time.time()
     lo = orc.forward(token, pos).copy()
     t_cpu += time.time() - t1
+    fed.append(int(token)); logits_cpu.append(lo)
     eng.forward(token, pos)
     lg = eng.logits()
     diffs.append(float(np.abs(lg - lo).max()))
@@ -45,7 +47,28 @@ orc3 = O.Oracle(cfg, w, threads=16)
 l32 = orc3.forward(1, 0).copy()
 eng2 = rama_amd.Engine(dev, eng.model)
 eng2.forward(1, 0)
+# the same positions through the batched-prompt prefill (8 per weight pass) into a fresh state, and
+# the device top-p sampler on those logits against the oracle's Device::sample
+import ctypes as C
+from rama_amd._lib import check
+eng3 = rama_amd.Engine(dev, eng.model)
+npf = min(n_pos, 21)
+arr = (C.c_int32 * npf)(*fed[:npf])
+check(dev.lib.rama_prefill(dev.ctx, C.byref(eng3.model.ccfg), C.byref(eng3.model.weights), C.byref(eng3.state), arr, npf, 0))
+pf_diff = float(np.abs(eng3.logits() - logits_cpu[npf - 1]).max())
+u = 0.2721174359321594
+nxt = C.c_int32()
+check(dev.lib.rama_sample_topp(dev.ctx, eng3.state.logits, V, 1.0, 0.9, u, C.byref(nxt)))
+topp_equal = int(nxt.value) == int(O.sample(logits_cpu[npf - 1].copy(), 1.0, 0.9, u))
+# two independent sequences in one weight pass: sequence A continues the run above at position
+# npf, sequence B starts a new generation at position 0
+engB = rama_amd.Engine(dev, eng.model)
+rama_amd.decode_batch([eng3, engB], [fed[npf] if npf < len(fed) else toks_cpu[npf - 1], 1], [npf, 0])
+batch_diff_b = float(np.abs(engB.logits() - logits_cpu[0]).max())
+batch_diff_a = float(np.abs(eng3.logits() - logits_cpu[npf]).max()) if npf < len(logits_cpu) else None
 print(json.dumps({"shape": "llama2-7B (32 layers)", "positions": n_pos, "max_abs_logit_diff_per_pos": [round(v, 9) for v in diffs],
                   "worst": max(diffs), "bar": 1e-4, "argmax_equal": toks_cpu == toks_gpu,
                   "pos0_cpu32_vs_f64": float(np.abs(l32 - l64).max()), "pos0_hip_vs_f64": float(np.abs(eng2.logits() - l64).max()),
-                  "logit_abs_max": float(np.abs(l64).max()), "weights_gen_s": round(t_gen, 1), "cpu_s_per_token": round(t_cpu / n_pos, 3)}))
+                  "logit_abs_max": float(np.abs(l64).max()),
+                  "prefill_positions": npf, "prefill_last_logit_diff": pf_diff, "topp_token_equal_on_prefill_logits": topp_equal,
+                  "decode_batch_diff_seqA_at_pos_npf": batch_diff_a, "decode_batch_diff_seqB_at_pos0": batch_diff_b, "weights_gen_s": round(t_gen, 1), "cpu_s_per_token": round(t_cpu / n_pos, 3)}))
