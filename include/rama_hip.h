@@ -136,6 +136,13 @@ int  rama_model_synth(rama_ctx *ctx, const rama_config *cfg, uint64_t seed, cons
  * (legacy_export) produces and transformer/ram.rs:28-51 reads, so upstream Rama loads it too
  * (SURVEY section 8 row f2).  RAMA_EINVAL for a model that holds only a pipeline stage. */
 int  rama_model_save(rama_ctx *ctx, const rama_model *model, const char *path);
+/* Placement tuning (optional, once per model): the W1|W3 kernel streams two tensors that sit
+ * gigabytes apart, and how their pages fall onto HBM channels differs from allocation to
+ * allocation (53.5 vs 57 us for the same launch on two boxes).  Tries `tries` (<= 12) placements of
+ * W3 in a second allocation, times the real kernel on each and keeps the fastest, or the original.
+ * before_ms / after_ms (optional) = one pass of that kernel over the model's layers before and
+ * after.  Costs one extra copy of W3 in HBM when it moves; weights' values are untouched. */
+int  rama_model_tune_placement(rama_ctx *ctx, rama_model *model, int tries, float *before_ms, float *after_ms);
 int  rama_model_config(const rama_model *m, rama_config *cfg);
 int  rama_model_weights(const rama_model *m, rama_weights *w);
 size_t rama_model_bytes(const rama_model *m);

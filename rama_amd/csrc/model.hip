@@ -18,12 +18,17 @@
 #include <vector>
 
 extern "C" int rama_fill_synth(rama_ctx*, float*, size_t, uint64_t, uint64_t, uint64_t, float, float);
+// rama_api.hip (internal, not part of the header): average milliseconds of one pass of the W1|W3
+// kernel over n_layers layers with the given tensor bases
+extern "C" int rama_time_swiglu_(rama_ctx*, const rama_config*, const float* w1, const float* w3, const float* nw,
+                                 int n_layers, float* ms_per_pass);
 
 struct rama_model {
     rama_config cfg{};
     rama_weights w{};
     float* blob = nullptr;      // one allocation holding every tensor
     size_t blob_floats = 0;
+    float* arena = nullptr;     // second allocation, owns W3 once rama_model_tune_placement has moved it
     rama_stage stage{};
 };
 
@@ -225,8 +230,50 @@ extern "C" int rama_model_weights(const rama_model* m, rama_weights* w) {
     return 0;
 }
 extern "C" size_t rama_model_bytes(const rama_model* m) { return m ? m->blob_floats * sizeof(float) : 0; }
+// Placement tuning.  The W1|W3 kernel streams two tensors that sit gigabytes apart, and how their
+// pages fall onto HBM channels/banks differs from allocation to allocation: the same binary runs
+// that kernel in 53.5 us on one box and 57 us on another, and shifting W3 by a few KiB moves it
+// anywhere in 53.5-59.6 us.  This tries `tries` placements of W3 in a second
+// allocation, times the real kernel on each and keeps the fastest (or the original).
+extern "C" int rama_model_tune_placement(rama_ctx* ctx, rama_model* m, int tries, float* before_ms, float* after_ms) {
+    if (!ctx || !m) return bad(RAMA_EINVAL, "rama_model_tune_placement: NULL argument");
+    const rama_config& c = m->cfg;
+    const int nl = m->stage.layer_end - m->stage.layer_begin;
+    float base = 0.f;
+    if (before_ms) *before_ms = 0.f;
+    if (after_ms) *after_ms = 0.f;
+    if (nl <= 0 || tries <= 0 || !m->w.w1 || !m->w.w3) return 0;
+    int rc = rama_time_swiglu_(ctx, &c, m->w.w1, m->w.w3, m->w.rms_ffn_weight, nl, &base);
+    if (rc) return rc;
+    if (before_ms) *before_ms = base;
+    if (after_ms) *after_ms = base;
+    if (m->arena) return 0;                                  // already tuned once
+    const size_t n = (size_t)nl * c.hidden_dim * c.dim;
+    static const size_t kOffsets[] = {0, 128, 2048, 32768, 512, 8192 + 64, 131072 + 256, 1048576 + 1024, 256, 65536 + 128, 4096 + 32, 16384 + 512};
+    const size_t slack = (size_t)2 << 20;
+    float* arena = nullptr;
+    rc = rama_alloc_f32(ctx, n + slack, &arena);
+    if (rc) return rc;
+    float best = base; long best_off = -1;
+    const int nt = std::min<int>(tries, (int)(sizeof(kOffsets) / sizeof(kOffsets[0])));
+    for (int k = 0; k < nt; k++) {
+        if (hipMemcpy(arena + kOffsets[k], m->w.w3, n * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess) { rama_free(ctx, arena); return bad(RAMA_EIO, "rama_model_tune_placement: copy failed"); }
+        float ms = 0.f;
+        rc = rama_time_swiglu_(ctx, &c, m->w.w1, arena + kOffsets[k], m->w.rms_ffn_weight, nl, &ms);
+        if (rc) { rama_free(ctx, arena); return rc; }
+        if (ms < best * 0.995f) { best = ms; best_off = (long)kOffsets[k]; }
+    }
+    if (best_off < 0) { rama_free(ctx, arena); return 0; }  // the original placement stays
+    if (hipMemcpy(arena + best_off, m->w.w3, n * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess) { rama_free(ctx, arena); return bad(RAMA_EIO, "rama_model_tune_placement: copy failed"); }
+    m->w.w3 = arena + best_off;                              // the old copy stays allocated inside the blob, unused
+    m->arena = arena;
+    if (after_ms) *after_ms = best;
+    return 0;
+}
+
 extern "C" int rama_model_free(rama_ctx* ctx, rama_model* m) {
     if (!m) return 0;
+    if (m->arena) rama_free(ctx, m->arena);
     int rc = rama_free(ctx, m->blob);
     delete m;
     return rc;

@@ -625,6 +625,39 @@ int rama_forward_stage_devtok(rama_ctx* c, const rama_config* cfg, const rama_we
     return enqueue_stage(c, cfg, w, s, st);
 }
 
+// internal helper of rama_model_tune_placement (model.hip): average ms of one pass of the W1|W3 kernel
+// over n_layers layers with the given tensor bases (events on the context's stream, 1 warm + 3 timed)
+extern "C" int rama_time_swiglu_(rama_ctx* c, const rama_config* cfg, const float* w1, const float* w3, const float* nw,
+                                 int n_layers, float* ms_per_pass) {
+    REQUIRE(c && cfg && w1 && w3 && nw && ms_per_pass && n_layers > 0, RAMA_EINVAL, "time_swiglu: bad argument");
+    const int dim = cfg->dim, hidden = cfg->hidden_dim;
+    const size_t hd = (size_t)hidden * dim;
+    float* x = nullptr; float* hb = nullptr;
+    int rc = rama_alloc_f32(c, dim, &x); if (rc) return rc;
+    rc = rama_alloc_f32(c, hidden, &hb); if (rc) { rama_free(c, x); return rc; }
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    const int reps = 3;
+    for (int r = -1; r < reps; r++) {
+        if (r == 0) HIPCHK(hipEventRecord(e0, c->stream));
+        for (int l = 0; l < n_layers; l++) {
+            SwigluParams p{};
+            p.w1 = w1 + (size_t)l * hd; p.w3 = w3 + (size_t)l * hd; p.x = x; p.nw = nw + (size_t)l * dim;
+            p.hb = hb; p.K = dim; p.rows = hidden;
+            DISPATCH_GEOM(c, hipLaunchKernelGGL((gemv_swiglu<R2_, CH_, NW_>), dim3((hidden + R2_ - 1) / R2_), dim3(NW_ * 64), 0, c->stream, p));
+        }
+    }
+    HIPCHK(hipEventRecord(e1, c->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    rama_free(c, x); rama_free(c, hb);
+    LAUNCHCHK();
+    *ms_per_pass = ms / reps;
+    return 0;
+}
+
 // ---- device top-p sampler (kernels.hpp: topp_prepare_kernel, hipCUB stable radix sort, topp_pick_kernel)
 
 // scratch for n logits; called outside any stream capture

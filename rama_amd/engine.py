@@ -63,6 +63,16 @@ class Model:
         """write the model as a llama2.c v0 .bin (export.py legacy layout; upstream Rama loads it)"""
         check(self.device.lib.rama_model_save(self.device.ctx, self.handle, str(path).encode()), "rama_model_save")
 
+    def tune_placement(self, tries: int = 8) -> dict:
+        """try `tries` placements of W3 and keep the fastest for the W1|W3 kernel (rama_model_tune_placement)"""
+        b, a = C.c_float(), C.c_float()
+        check(self.device.lib.rama_model_tune_placement(self.device.ctx, self.handle, tries, C.byref(b), C.byref(a)),
+              "rama_model_tune_placement")
+        check(self.device.lib.rama_model_weights(self.handle, C.byref(self.weights)))     # W3 may have moved
+        n = max(self.stage.layer_end - self.stage.layer_begin, 1)
+        return {"w13_us_before": round(b.value * 1e3 / n, 2), "w13_us_after": round(a.value * 1e3 / n, 2),
+                "moved": a.value < b.value, "tries": tries}
+
     @property
     def bytes(self) -> int:
         return self.device.lib.rama_model_bytes(self.handle)

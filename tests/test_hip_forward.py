@@ -680,3 +680,28 @@ def test_decode_batch_argument_errors(dev):
     with pytest.raises(rama_amd.RamaError):
         rama_amd.decode_batch([a, b], [1, 1], [0, cfg.seq_len])       # position outside the context
     a.free(); b.free(); m.free()
+
+
+def test_model_tune_placement_keeps_the_weights(dev, tmp_path):
+    """placement tuning may move W3 to another allocation; values, logits and the saved file stay the same"""
+    import rama_amd
+    cfg, w, g = load_case("synth_d288_h6")
+    m = rama_amd.Model.synth(dev, to_rama_cfg(cfg), int(g["seed"]), rope=(g["freq_cis_real"], g["freq_cis_imag"]))
+    eng = rama_amd.Engine(dev, m)
+    toks = g["tokens"].tolist()[:5]
+    before = []
+    for p_, t in enumerate(toks):
+        eng.forward(t, p_); before.append(eng.logits().copy())
+    rep = m.tune_placement(12)
+    assert rep["w13_us_after"] <= rep["w13_us_before"] and rep["tries"] == 12
+    assert np.array_equal(m.tensor("w3", w["w3"].size), np.asarray(w["w3"]).reshape(-1))
+    eng2 = rama_amd.Engine(dev, m)
+    for p_, t in enumerate(toks):
+        eng2.forward(t, p_)
+        assert np.array_equal(eng2.logits(), before[p_])
+    m.tune_placement(4)                                   # a second call measures, never moves again
+    out = tmp_path / "tuned.bin"
+    m.save(out)
+    cfg2, w2 = O.read_checkpoint(out)
+    assert np.array_equal(np.asarray(w2["w3"]).reshape(-1), np.asarray(w["w3"]).reshape(-1))
+    eng.free(); eng2.free(); m.free()
