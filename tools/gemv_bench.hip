@@ -96,6 +96,65 @@ __global__ __launch_bounds__(NW * 64) void gemv_ksplit(const float* W, const flo
     }
 }
 
+// ---- variant A2: as A (chunks interleaved over the waves), but the workgroup's R rows are R/2
+//   consecutive rows from the first half of the matrix plus R/2 from the second half: two distant
+//   streams per workgroup, like the W1|W3 kernel has by construction
+template <int R, int CH, int NW, int AUX>
+__global__ __launch_bounds__(NW * 64) void gemv_ksplit2(const float* W, const float* x, float* o, int K, int rows) {
+    __shared__ float part[NW][R];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int H = R / 2;
+    const int half = ((rows / 2 + H - 1) / H) * H;          // rows of the first half, multiple of H
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(W, (unsigned)rows * (unsigned)K * 4u);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (unsigned)K * 4u);
+    const int nch = (K + 255) >> 8;
+    const unsigned kbytes = (unsigned)K * 4u;
+    int row[R]; unsigned rowoff[R];
+#pragma unroll
+    for (int s = 0; s < R; s++) {
+        row[s] = (s < H ? 0 : half) + (int)blockIdx.x * H + (s % H);
+        const bool ok = s < H ? row[s] < half : row[s] < rows;
+        rowoff[s] = ok ? (unsigned)row[s] * kbytes : kOOB;
+        if (!ok) row[s] = -1;
+    }
+    float acc[R];
+#pragma unroll
+    for (int s = 0; s < R; s++) acc[s] = 0.f;
+    for (int c = wave; c < nch; c += CH * NW) {
+        f4 w[R][CH]; f4 xv[CH]; unsigned kb[CH];
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            int ci = c + j * NW;
+            unsigned b = (unsigned)(ci * 1024 + lane * 16);
+            kb[j] = (ci < nch && b < kbytes) ? b : kOOB;
+        }
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+#pragma unroll
+            for (int s = 0; s < R; s++) w[s][j] = ldw<AUX>(ra, (kb[j] == kOOB || rowoff[s] == kOOB) ? kOOB : rowoff[s] + kb[j]);
+#pragma unroll
+        for (int j = 0; j < CH; j++) xv[j] = ldw<0>(rx, kb[j]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+#pragma unroll
+            for (int s = 0; s < R; s++) acc[s] = dot4(w[s][j], xv[j], acc[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < R; s++) acc[s] = wave_sum(acc[s]);
+    if (lane == 0) {
+#pragma unroll
+        for (int s = 0; s < R; s++) part[wave][s] = acc[s];
+    }
+    __syncthreads();
+    if (threadIdx.x < R && row[threadIdx.x] >= 0) {
+        float d = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; w++) d += part[w][threadIdx.x];
+        o[row[threadIdx.x]] = d;
+    }
+}
+
 // ---- variant B: every wave owns R whole rows (no cross-wave reduce); 4 waves per workgroup
 template <int R, int CH, int AUX>
 __global__ __launch_bounds__(256) void gemv_waverow(const float* W, const float* x, float* o, int K, int rows) {
@@ -478,6 +537,13 @@ void launch_ksplit_occ(const float* W, const float* x, float* o, int K, int rows
     (void)once;
     hipLaunchKernelGGL((gemv_ksplit<R, CH, NW, 1, 2>), dim3((rows + R - 1) / R), dim3(NW * 64), lds, s, W, x, o, K, rows);
 }
+template <int R, int CH, int NW, int AUX>
+void launch_ksplit2(const float* W, const float* x, float* o, int K, int rows, hipStream_t s) {
+    constexpr int H = R / 2;
+    const int half = ((rows / 2 + H - 1) / H) * H;
+    const int groups = std::max(half, rows - half + H - 1) / H + 1;
+    hipLaunchKernelGGL((gemv_ksplit2<R, CH, NW, AUX>), dim3(groups), dim3(NW * 64), 0, s, W, x, o, K, rows);
+}
 template <int R, int CH, int AUX>
 void launch_waverow(const float* W, const float* x, float* o, int K, int rows, hipStream_t s) {
     hipLaunchKernelGGL((gemv_waverow<R, CH, AUX>), dim3((rows + 4 * R - 1) / (4 * R)), dim3(256), 0, s, W, x, o, K, rows);
@@ -522,6 +588,9 @@ int main(int argc, char** argv) {
         {"ksplit R2 CH4 NW2 inter  nt", launch_ksplit<2, 4, 2, 1, 2>},
         {"ksplit R2 CH8 NW2 inter  nt", launch_ksplit<2, 8, 2, 1, 2>},
         {"ksplit R2 CH4 NW16 inter nt", launch_ksplit<2, 4, 16, 1, 2>},
+        {"ksplit2 R4 CH2 NW8 two halves", launch_ksplit2<4, 2, 8, 2>},
+        {"ksplit2 R8 CH2 NW8 two halves", launch_ksplit2<8, 2, 8, 2>},
+        {"ksplit2 R6 CH2 NW8 two halves", launch_ksplit2<6, 2, 8, 2>},
         {"ksplit R4 CH2 NW8 occ3", launch_ksplit_occ<4, 2, 8, 3>},
         {"ksplit R4 CH2 NW8 occ2", launch_ksplit_occ<4, 2, 8, 2>},
         {"ksplit R6 CH2 NW8 occ2", launch_ksplit_occ<6, 2, 8, 2>},
