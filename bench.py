@@ -193,7 +193,7 @@ def main():
                 kernels[k] = {"avg_us": round(avg_ms * 1e3, 2), "launches": n,
                               "GBps": round(b / (avg_ms * 1e-3) / 1e9, 1) if b else None}
             a = kernels["w13"]["GBps"]
-            traffic, traffic_src = pmc_traffic("gemv_swiglu") if args.config == "llama2-7B" else (None, None)
+            traffic, traffic_src = pmc_traffic("gemv_swiglu<") if args.config == "llama2-7B" else (None, None)
             roofline = {"bound": "hbm", "kernel": "gemv_swiglu<2,2,8> (rmsnorm + W1|W3 matvec + SiLU*gate)",
                         "achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBPS, 4),
                         "traffic": traffic, "traffic_source": traffic_src,

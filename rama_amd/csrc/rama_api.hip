@@ -644,7 +644,7 @@ extern "C" int rama_time_swiglu_(rama_ctx* c, const rama_config* cfg, const floa
             SwigluParams p{};
             p.w1 = w1 + (size_t)l * hd; p.w3 = w3 + (size_t)l * hd; p.x = x; p.nw = nw + (size_t)l * dim;
             p.hb = hb; p.K = dim; p.rows = hidden;
-            DISPATCH_GEOM(c, hipLaunchKernelGGL((gemv_swiglu<R2_, CH_, NW_>), dim3((hidden + R2_ - 1) / R2_), dim3(NW_ * 64), 0, c->stream, p));
+            DISPATCH_GEOM(c, hipLaunchKernelGGL((gemv_swiglu_probe<R2_, CH_, NW_>), dim3((hidden + R2_ - 1) / R2_), dim3(NW_ * 64), 0, c->stream, p));
         }
     }
     HIPCHK(hipEventRecord(e1, c->stream));
