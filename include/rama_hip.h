@@ -138,11 +138,16 @@ int  rama_model_synth(rama_ctx *ctx, const rama_config *cfg, uint64_t seed, cons
 int  rama_model_save(rama_ctx *ctx, const rama_model *model, const char *path);
 /* Placement tuning (optional, once per model): the W1|W3 kernel streams two tensors that sit
  * gigabytes apart, and how their pages fall onto HBM channels differs from allocation to
- * allocation (53.5 vs 57 us for the same launch on two boxes).  Tries `tries` (<= 12) placements of
- * W3 in a second allocation, times the real kernel on each and keeps the fastest, or the original.
- * before_ms / after_ms (optional) = one pass of that kernel over the model's layers before and
- * after.  Costs one extra copy of W3 in HBM when it moves; weights' values are untouched. */
-int  rama_model_tune_placement(rama_ctx *ctx, rama_model *model, int tries, float *before_ms, float *after_ms);
+ * allocation (53.5 vs 57 us for the same launch on two boxes).  Copies W3 into up to `tries`
+ * (<= 12) fresh allocations and keeps the one under which a decode step is fastest, or the
+ * original.  `timer` (optional) is the caller's measurement of ITS decode loop with the candidate
+ * weight table -- milliseconds per step, > 0; isolated-kernel or scratch-state timings do not
+ * predict the real loop, measured -- NULL times eager steps over a scratch state instead.
+ * before_ms / after_ms (optional) = that time before and after.  Costs one extra copy of W3 in
+ * HBM when it moves; values are untouched. */
+typedef float (*rama_step_timer)(void *user, const rama_weights *candidate);
+int  rama_model_tune_placement(rama_ctx *ctx, rama_model *model, int tries, rama_step_timer timer, void *user,
+                               float *before_ms, float *after_ms);
 int  rama_model_config(const rama_model *m, rama_config *cfg);
 int  rama_model_weights(const rama_model *m, rama_weights *w);
 size_t rama_model_bytes(const rama_model *m);
@@ -230,8 +235,10 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *                   (n_heads x nsplit workgroups + a combine launch) at position N; -1 (default)
  *                   chooses by model size: 384 when one head's whole K+V cache exceeds 1 MiB
  *                   (llama2-7B), never below that (stories15M / 110M), as measured
- *   "resid_r2" = 0|1 : 1 (default) gives the two residual matvecs (Wo, W2) 2-row workgroups under
- *                   geometry 3; measured +0.45 % tokens/s at llama2-7B, same tokens
+ *   "resid_r2" = 0..3 : geometry of the two residual matvecs (Wo, W2) under geometry 3: 0 = 4-row
+ *                   workgroups like the rest; 1 = 2 rows x 8 waves (+0.45 % tokens/s at llama2-7B);
+ *                   2 (default) = as 1, and rows wider than 8192 floats (W2) spread over 16 waves,
+ *                   one chunk each per step (+1.15 % more); 3 = 16 waves x 4 chunks
  *   "prefill" = 0|1 : 1 (default) lets rama_generate_greedy push the forced prompt positions through
  *                   rama_prefill (8 positions per weight pass) instead of one forward per token
  *   "prefill_rounds" = 1..64 : rama_prefill cuts each matrix launch into this many even rounds

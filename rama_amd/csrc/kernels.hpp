@@ -350,10 +350,6 @@ __device__ __forceinline__ void gemv_swiglu_body(const SwigluParams& p) {
 }
 template <int R2, int CH, int NW>
 __global__ __launch_bounds__(NW * 64) void gemv_swiglu(SwigluParams p) { gemv_swiglu_body<R2, CH, NW>(p); }
-// the same kernel under another name: rama_model_tune_placement's timing launches, kept apart from
-// the decode path's in profiler summaries
-template <int R2, int CH, int NW>
-__global__ __launch_bounds__(NW * 64) void gemv_swiglu_probe(SwigluParams p) { gemv_swiglu_body<R2, CH, NW>(p); }
 
 // generic o_cols > 1 product of the trait signature (never used by forward): one thread per output
 __global__ void matmul_generic(float* o, const float* a, const float* b, int width, int o_rows, int o_cols) {

@@ -80,7 +80,8 @@ struct rama_ctx {
     float* topp_prefix = nullptr; int* topp_m = nullptr; unsigned* topp_err = nullptr;
     void* topp_tmp = nullptr; size_t topp_tmp_bytes = 0; int topp_cap = 0;
     int tune_split_pos = -1;               // attention runs split-T (+ combine launch) from this position on; -1 = by model size
-    int tune_resid_r2 = 1;                 // 1: Wo / W2 use 2-row workgroups under the default geometry (+0.45 %)
+    int tune_resid_r2 = 2;                 // Wo / W2 under geometry 3: 0 = 4-row workgroups, 1 = 2 rows x 8 waves (+0.45 %),
+                                           // 2 = additionally 16 waves for rows wider than 8192 floats (W2: +1.15 % more), 3 = 16 waves x 4 chunks
     int tune_pf_rounds = 1;                // prefill launches are cut into this many even rounds over the CUs
     int tune_prefill = 1;                  // 1: rama_generate_greedy runs the forced prompt positions through rama_prefill
     int tune_merge = -1;                   // attention + Wo in one launch: 1 on, 0 off, -1 by model size (on for dim <= 1024:
@@ -288,8 +289,11 @@ static int launch_rows(rama_ctx* c, float* o, const float* W, const float* x, co
     p.w[0] = W; p.x = x; p.nw = nw; p.o[0] = o; p.K = K; p.rows = rows; p.nmat = 1;
     if (!NORM && EPI == EPI_RESID && c->tune_geom == 3 && c->tune_resid_r2) {
         // the residual matvecs (Wo, W2) read no rmsnorm gain, so a 2-row workgroup's re-read of
-        // x is cheap and the finer grain balances better
-        RAMA_LAUNCH(c, (gemv_rows<2, 2, 8, NORM, EPI>), dim3((rows + 1) / 2), dim3(8 * 64), 0, p);
+        // x is cheap and the finer grain balances better; rows wider than
+        // 8192 floats (W2) can also spread over 16 waves (resid_r2 = 2 / 3)
+        if (K > 8192 && c->tune_resid_r2 == 2) RAMA_LAUNCH(c, (gemv_rows<2, 1, 16, NORM, EPI>), dim3((rows + 1) / 2), dim3(16 * 64), 0, p);
+        else if (K > 8192 && c->tune_resid_r2 == 3) RAMA_LAUNCH(c, (gemv_rows<2, 4, 16, NORM, EPI>), dim3((rows + 1) / 2), dim3(16 * 64), 0, p);
+        else RAMA_LAUNCH(c, (gemv_rows<2, 2, 8, NORM, EPI>), dim3((rows + 1) / 2), dim3(8 * 64), 0, p);
         LAUNCHCHK();
         return 0;
     }
@@ -623,39 +627,6 @@ int rama_forward_stage_devtok(rama_ctx* c, const rama_config* cfg, const rama_we
     c->host_pos = -1;
     c->split_attn = pos >= split_threshold(c, cfg);
     return enqueue_stage(c, cfg, w, s, st);
-}
-
-// internal helper of rama_model_tune_placement (model.hip): average ms of one pass of the W1|W3 kernel
-// over n_layers layers with the given tensor bases (events on the context's stream, 1 warm + 3 timed)
-extern "C" int rama_time_swiglu_(rama_ctx* c, const rama_config* cfg, const float* w1, const float* w3, const float* nw,
-                                 int n_layers, float* ms_per_pass) {
-    REQUIRE(c && cfg && w1 && w3 && nw && ms_per_pass && n_layers > 0, RAMA_EINVAL, "time_swiglu: bad argument");
-    const int dim = cfg->dim, hidden = cfg->hidden_dim;
-    const size_t hd = (size_t)hidden * dim;
-    float* x = nullptr; float* hb = nullptr;
-    int rc = rama_alloc_f32(c, dim, &x); if (rc) return rc;
-    rc = rama_alloc_f32(c, hidden, &hb); if (rc) { rama_free(c, x); return rc; }
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-    const int reps = 3;
-    for (int r = -1; r < reps; r++) {
-        if (r == 0) HIPCHK(hipEventRecord(e0, c->stream));
-        for (int l = 0; l < n_layers; l++) {
-            SwigluParams p{};
-            p.w1 = w1 + (size_t)l * hd; p.w3 = w3 + (size_t)l * hd; p.x = x; p.nw = nw + (size_t)l * dim;
-            p.hb = hb; p.K = dim; p.rows = hidden;
-            DISPATCH_GEOM(c, hipLaunchKernelGGL((gemv_swiglu_probe<R2_, CH_, NW_>), dim3((hidden + R2_ - 1) / R2_), dim3(NW_ * 64), 0, c->stream, p));
-        }
-    }
-    HIPCHK(hipEventRecord(e1, c->stream));
-    HIPCHK(hipEventSynchronize(e1));
-    float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-    hipEventDestroy(e0); hipEventDestroy(e1);
-    rama_free(c, x); rama_free(c, hb);
-    LAUNCHCHK();
-    *ms_per_pass = ms / reps;
-    return 0;
 }
 
 // ---- device top-p sampler (kernels.hpp: topp_prepare_kernel, hipCUB stable radix sort, topp_pick_kernel)
@@ -1093,7 +1064,7 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
         return 0;
     }
     if (!strcmp(key, "resid_r2")) {
-        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: resid_r2 must be 0 or 1");
+        REQUIRE(value >= 0 && value <= 3, RAMA_EINVAL, "set_tuning: resid_r2 must be 0..3");
         c->tune_resid_r2 = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);

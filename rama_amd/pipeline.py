@@ -137,7 +137,6 @@ class HipStage:
         lo, hi = split_layers(cfg.n_layers, world, rank)
         self.stage = rama_stage(lo, hi, int(rank == 0), int(rank == world - 1))
         self.model = rama_amd.Model.synth(self.dev, cfg, seed, self.stage, rope)
-        self.placement = self.model.tune_placement(12) if hi > lo else None     # fastest of 12 placements of W3
         device = torch.device("cuda", local_rank)
         self.x_buffers = [torch.zeros(cfg.dim, dtype=torch.float32, device=device) for _ in range(n_seq)]
         self.tok_buffers = [torch.zeros(1, dtype=torch.int32, device=device) for _ in range(n_seq)]

@@ -693,8 +693,9 @@ def test_model_tune_placement_keeps_the_weights(dev, tmp_path):
     for p_, t in enumerate(toks):
         eng.forward(t, p_); before.append(eng.logits().copy())
     rep = m.tune_placement(12)
-    assert rep["w13_us_after"] <= rep["w13_us_before"] and rep["tries"] == 12
+    assert rep["step_us_after"] <= rep["step_us_before"] and rep["tries"] == 12
     assert np.array_equal(m.tensor("w3", w["w3"].size), np.asarray(w["w3"]).reshape(-1))
+    assert np.array_equal(m.tensor("w1", w["w1"].size), np.asarray(w["w1"]).reshape(-1))
     eng2 = rama_amd.Engine(dev, m)
     for p_, t in enumerate(toks):
         eng2.forward(t, p_)

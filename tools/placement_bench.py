@@ -21,6 +21,13 @@ def rate():
     eng.set_graph_mode(False); eng.free()
     return round(best, 1)
 before = rate()
-rep = model.tune_placement(int(sys.argv[1]) if len(sys.argv) > 1 else 8)
+eng = rama_amd.Engine(dev, model)
+eng.set_graph_mode(True)
+def step_ms():
+    eng.decode_begin(1, 0, PROMPT); eng.decode_steps(6); dev.sync()
+    t = time.perf_counter(); eng.decode_steps(24); dev.sync()
+    return (time.perf_counter() - t) * 1e3 / 24
+rep = model.tune_placement(int(sys.argv[1]) if len(sys.argv) > 1 else 8, timer=step_ms)
+eng.set_graph_mode(False); eng.free()
 after = rate()
 print(json.dumps({"tok_s_before": before, "tok_s_after": after, "tuning": rep}))
