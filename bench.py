@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--graph", type=int, default=1, help="replay each decode step from a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kprof", action="store_true")
+    ap.add_argument("--no-placement-tuning", action="store_true",
+                    help="skip rama_model_tune_placement (profiling runs: its candidate steps would mix into the kernel statistics)")
     ap.add_argument("--cpu-tokens", type=int, default=6)
     ap.add_argument("--cpu-layers", type=int, default=2)
     return ap.parse_args()
@@ -160,7 +162,7 @@ def main():
         eng.decode_steps(24)
         dev.sync()
         return (time.perf_counter() - t) * 1e3 / 24
-    placement = model.tune_placement(8, timer=step_ms) if args.config == "llama2-7B" else None
+    placement = model.tune_placement(8, timer=step_ms) if args.config == "llama2-7B" and not args.no_placement_tuning else None
     if placement:
         # releasing the rejected candidates (tens of GB) is followed by ~0.5 s of slower steps (page-table
         # work, measured 4.38 -> 4.22 -> 4.20 ms over consecutive 64-step runs): let it pass, untimed
