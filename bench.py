@@ -162,7 +162,13 @@ def main():
         eng.decode_steps(24)
         dev.sync()
         return (time.perf_counter() - t) * 1e3 / 24
-    placement = model.tune_placement(8, timer=step_ms) if args.config == "llama2-7B" and not args.no_placement_tuning else None
+    # under rocprofv3 the tuning is skipped: every candidate re-captures the step's hipGraph, and the
+    # profiler (ROCm 7.2) segfaults in hipGraphLaunch once a process has instantiated a second
+    # ~160-node graph (profiles/README.md); its candidate steps would also mix into the statistics
+    profiled = "ROCP_TOOL_LIBRARIES" in os.environ or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+    placement = None
+    if args.config == "llama2-7B" and not args.no_placement_tuning and not profiled:
+        placement = model.tune_placement(8, timer=step_ms)
     if placement:
         # releasing the rejected candidates (tens of GB) is followed by ~0.5 s of slower steps (page-table
         # work, measured 4.38 -> 4.22 -> 4.20 ms over consecutive 64-step runs): let it pass, untimed

@@ -620,7 +620,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&g_ctr, 4096)); CK(hipMemset(g_ctr, 0, 4096));
     struct Shape { const char* name; int rows, K; } shapes[] = {
         {"wo    4096x4096 ", 4096, 4096}, {"w2    4096x11008", 4096, 11008},
-        {"w1    11008x4096", 11008, 4096}, {"qkv  12288x4096 ", 12288, 4096}, {"cls  32000x4096 ", 32000, 4096},
+        {"w1    11008x4096", 11008, 4096}, {"w13i  22016x4096", 22016, 4096}, {"qkv  12288x4096 ", 12288, 4096}, {"cls  32000x4096 ", 32000, 4096},
     };
     const size_t max_bytes = (size_t)32000 * 4096 * 4;
     const int nbuf = 6;   // 6 x 524 MB = 3.1 GB rotation
