@@ -168,7 +168,10 @@ def main():
     profiled = "ROCP_TOOL_LIBRARIES" in os.environ or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
     placement = None
     if args.config == "llama2-7B" and not args.no_placement_tuning and not profiled:
-        placement = model.tune_placement(8, timer=step_ms)
+        try:
+            placement = model.tune_placement(8, timer=step_ms)
+        except rama_amd.RamaError as e:          # tuning is optional: never let it take the bench down
+            placement = {"error": str(e)}
     if placement:
         # releasing the rejected candidates (tens of GB) is followed by ~0.5 s of slower steps (page-table
         # work, measured 4.38 -> 4.22 -> 4.20 ms over consecutive 64-step runs): let it pass, untimed

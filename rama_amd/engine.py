@@ -75,10 +75,12 @@ class Model:
                 C.memmove(C.byref(self.weights), wptr, C.sizeof(rama_weights))
                 return float(timer())
             cb = STEP_TIMER(_cb)
-        check(self.device.lib.rama_model_tune_placement(self.device.ctx, self.handle, tries,
-                                                        C.cast(cb, C.c_void_p) if cb else None, None, C.byref(b), C.byref(a)),
-              "rama_model_tune_placement")
-        check(self.device.lib.rama_model_weights(self.handle, C.byref(self.weights)))     # W3 may have moved
+        try:
+            check(self.device.lib.rama_model_tune_placement(self.device.ctx, self.handle, tries,
+                                                            C.cast(cb, C.c_void_p) if cb else None, None, C.byref(b), C.byref(a)),
+                  "rama_model_tune_placement")
+        finally:    # whatever happened, self.weights must be the model's own table again (W3 / W1 may have moved)
+            check(self.device.lib.rama_model_weights(self.handle, C.byref(self.weights)))
         return {"step_us_before": round(b.value * 1e3, 1), "step_us_after": round(a.value * 1e3, 1),
                 "moved": a.value < b.value, "tries": tries}
 
