@@ -1,0 +1,125 @@
+"""FULL-depth llama2-7B parity (BASELINE.json config 4): 32 layers, 27 GB of synthetic fp32 weights
+generated bit-identically on both sides, the generate() loop of transformer/mod.rs:169-206 on
+'once upon a time' for 200 positions (the README bench length, README.md:80-83).
+
+Per position three logit vectors are compared:
+    HIP      the product path (rama_forward through the C ABI)
+    oracle   oracle/rama_oracle.c, the line-by-line restatement of engine/src/device/cpu.rs
+             (4-lane strided sums of 4096..11008 terms, sequential softmax / rmsnorm sums)
+    f64      the same network with every sum accumulated in double (oracle_forward_f64): the arbiter
+             that says how far each fp32 path sits from the exact result
+All three are fed the SAME token sequence (the oracle's greedy choice), so caches stay comparable.
+
+The per-position numbers are written to gpurun_out/r02_parity_llama2_7b_200pos.json (copied to
+profiles/ by the builder) whatever the outcome; the assertions come last.
+
+Needs ~33 GB of host memory and ~4 minutes (CPU oracle 0.17 s/token, fp64 arbiter ~0.6 s/token).
+RAMA_PARITY_POSITIONS overrides the length (e.g. 8 for a quick run)."""
+from __future__ import annotations
+
+import json
+import os
+import time
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from oracle import synth as S
+
+from .helpers import LOGIT_ATOL, to_rama_cfg
+
+pytestmark = pytest.mark.gpu
+
+REPO = Path(__file__).resolve().parent.parent
+PROMPT = [10646, 2501, 263, 931]          # Rama-BPE of 'once upon a time' 
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import rama_amd
+    d = rama_amd.Hip(0)
+    yield d
+    d.close()
+
+
+def _host_mem_gb() -> float:
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    return int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
+
+
+def test_llama2_7b_full_depth_200_positions(dev):
+    import rama_amd
+    n_pos = int(os.environ.get("RAMA_PARITY_POSITIONS", "200"))
+    d, h, L, H, V, seq = 4096, 11008, 32, 32, 32000, 2048
+    if _host_mem_gb() < 40.0:
+        pytest.skip(f"full-depth 7B oracle needs ~33 GB of host memory, {_host_mem_gb():.0f} GB available")
+    cfg = O.Config(d, h, L, H, H, V, seq, False)
+    t0 = time.time()
+    rope = S.rope_tables(seq, d // H)
+    w = S.synth_weights(cfg, 0, rope=rope)
+    t_gen = time.time() - t0
+    threads = min(16, len(os.sched_getaffinity(0)))
+    orc = O.Oracle(cfg, w, threads=threads)
+    orc64 = O.Oracle(cfg, w, threads=threads)
+    model = rama_amd.Model.synth(dev, to_rama_cfg(cfg), 0, rope=rope)
+    eng = rama_amd.Engine(dev, model)
+
+    rows, toks_cpu, toks_hip = [], [], []
+    token = 1
+    t_cpu = t_f64 = 0.0
+    for pos in range(n_pos):
+        t1 = time.time()
+        lo = orc.forward(token, pos).copy()
+        t2 = time.time()
+        l64 = orc64.forward_f64(token, pos).copy()
+        t3 = time.time()
+        t_cpu += t2 - t1
+        t_f64 += t3 - t2
+        eng.forward(token, pos)
+        lg = eng.logits()
+        rows.append({"pos": pos, "token": int(token),
+                     "hip_vs_oracle": float(np.abs(lg - lo).max()),
+                     "hip_vs_f64": float(np.abs(lg - l64).max()),
+                     "oracle_vs_f64": float(np.abs(lo - l64).max())})
+        toks_cpu.append(int(O.argmax(lo)))
+        toks_hip.append(int(np.flatnonzero(lg == lg.max())[-1]))
+        token = PROMPT[pos] if pos < len(PROMPT) else toks_cpu[-1]
+
+    worst = max(r["hip_vs_oracle"] for r in rows)
+    out = {
+        "shape": "llama2-7B fp32, 32 layers, synthetic weights seed 0 (bit-identical on both sides)",
+        "prompt": "BOS + 'once upon a time' (Rama-BPE), greedy continuation chosen by the oracle",
+        "positions": n_pos, "bar": LOGIT_ATOL,
+        "worst_hip_vs_oracle": worst,
+        "worst_hip_vs_f64": max(r["hip_vs_f64"] for r in rows),
+        "worst_oracle_vs_f64": max(r["oracle_vs_f64"] for r in rows),
+        "positions_over_bar": [r["pos"] for r in rows if r["hip_vs_oracle"] > LOGIT_ATOL],
+        "greedy_tokens_equal": toks_cpu == toks_hip,
+        "first_token_mismatch": next((i for i, (a, b) in enumerate(zip(toks_cpu, toks_hip)) if a != b), None),
+        "weights_gen_s": round(t_gen, 1), "oracle_s_per_token": round(t_cpu / n_pos, 3),
+        "f64_s_per_token": round(t_f64 / n_pos, 3), "oracle_threads": threads,
+        "per_position": rows,
+    }
+    path = Path(os.environ.get("RAMA_PARITY_JSON", REPO / "gpurun_out" / "r02_parity_llama2_7b_200pos.json"))
+    try:
+        path.parent.mkdir(parents=True, exist_ok=True)
+        path.write_text(json.dumps(out, indent=1))
+    except OSError:
+        pass
+    print(json.dumps({k: v for k, v in out.items() if k != "per_position"}))
+    eng.free(); model.free()
+
+    # the fp32 product path is never further from the exact (fp64-accumulated) logits than the
+    # reference arithmetic is: what separates HIP from the oracle is the oracle's own rounding
+    assert out["worst_hip_vs_f64"] <= out["worst_oracle_vs_f64"], out
+    assert toks_cpu == toks_hip, (out["first_token_mismatch"], toks_cpu[:16], toks_hip[:16])
+    # north_star bar: logits within 1e-4 (absolute) of the CPU reference path at every position
+    assert worst <= LOGIT_ATOL, f"positions over 1e-4: {out['positions_over_bar']} worst {worst:.3e}"
