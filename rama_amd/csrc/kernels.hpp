@@ -399,10 +399,17 @@ struct AttnParams {
     int nsplit;
     // batched queries (prefill): blockIdx.z = query index; query z sits at position pos + z
     int q_stride, xb_stride;
+    // tiled = 1: q and xb are in the MFMA tile layout of prefill_mfma.hpp ([tokens, dim] in 16 x 16
+    // blocks); the 16 bytes of (token z, floats k .. k + 3) sit at attn_tile_idx(z, k, dim)
+    int tiled;
     // batched sequences (rama_decode_batch): query z belongs to sequence z with its own caches and
     // position; layer_off = floats from a cache base to this layer's slab
     const SeqSlot* seqs; size_t layer_off;
 };
+
+__device__ __forceinline__ size_t attn_tile_idx(int tk, int k, int K) {      // = tile_idx of prefill_mfma.hpp, k % 4 == 0
+    return ((size_t)((tk >> 4) * (K >> 4) + (k >> 4)) * 64 + (size_t)(((k >> 2) & 3) * 16 + (tk & 15))) * 4;
+}
 
 constexpr int kAttnWaves = 16;
 constexpr int kAttnThreads = kAttnWaves * 64;
@@ -444,7 +451,8 @@ __global__ __launch_bounds__(kAttnThreads) void attention_kernel(AttnParams p) {
     auto off_of = [&](int t) { return (lane_ok && t < t1) ? (unsigned)t * rowb + col : kOOB; };
 
     f4 q4 = {0.f, 0.f, 0.f, 0.f};
-    if (lane_ok) q4 = *reinterpret_cast<const f4*>(p.q + (size_t)zq * p.q_stride + (size_t)h * hs + (size_t)li * 4);
+    if (lane_ok) q4 = *reinterpret_cast<const f4*>(p.tiled ? p.q + attn_tile_idx(zq, h * hs + li * 4, p.dim)
+                                                           : p.q + (size_t)zq * p.q_stride + (size_t)h * hs + (size_t)li * 4);
     const float div = sqrtf((float)hs);
 
     f4 kt[U], vt[U];
@@ -548,7 +556,8 @@ __global__ __launch_bounds__(kAttnThreads) void attention_kernel(AttnParams p) {
             *reinterpret_cast<f4*>(o + 4 + (size_t)tid * 4) = t8[0];
             if (tid == 0) { o[0] = mx; o[1] = sum; }
         } else {
-            *reinterpret_cast<f4*>(p.xb + (size_t)zq * p.xb_stride + (size_t)h * hs + (size_t)tid * 4) = t8[0];
+            *reinterpret_cast<f4*>(p.tiled ? p.xb + attn_tile_idx(zq, h * hs + tid * 4, p.dim)
+                                           : p.xb + (size_t)zq * p.xb_stride + (size_t)h * hs + (size_t)tid * 4) = t8[0];
         }
     }
 }

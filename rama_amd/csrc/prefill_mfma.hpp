@@ -1,0 +1,368 @@
+// prefill_mfma.hpp -- token-batch passes as a true dense fp32 GEMM on the matrix cores
+// (BASELINE north_star "MFMA only if a batched-prompt prefill path is
+// added as a true dense GEMM").  P = 16*PT tokens (prompt positions of one sequence, or one token of
+// each of several sequences) go through a layer together:
+//
+//     O[p][r] = sum_k W[r][k] * X[p][k]          W [rows, K] row-major fp32 (the checkpoint layout)
+//
+// computed with v_mfma_f32_16x16x4_f32 (exact fp32: bit-for-bit an fmaf chain, no reduced
+// precision), the weight tile as the A operand and the activations as B, with the decode kernels'
+// fused epilogues per token (RoPE + KV-cache append, SiLU*gate, residual add).  The contract is the
+// reference's: the same KV-cache rows and final logits as P sequential forward() calls
+// (transformer/mod.rs:187-194 feeds the forced prompt tokens one forward() at a time).
+//
+// What bounds it (measured, tools/pf_mfma_bench.hip): a CU sustains ~24 GB/s from HBM and ~70 GB/s
+// from its XCD's L2, and the two streams share one budget of bytes in flight -- time per CU =
+// W_bytes / 24 + X_bytes / 70.  Every 16-row weight tile needs the whole activation block, so
+// X_bytes = W_bytes * P / (16 RT): the activation re-reads, not the matrix cores (P = 64 needs 55 %
+// of the 155 TFLOP/s fp32 MFMA peak at the HBM rate), decide how far above the weight-stream time a
+// pass lands, and a larger P amortises both.  Hence:
+//   * activations live in TILE layout between the kernels of a pass: a 16-token x 16-float block
+//     is stored as the 64 lanes x 16 bytes of the MFMA B operand (lane l = token l&15, k-slot l>>4,
+//     its 4 floats = k-slot's floats 4 kq .. 4 kq + 3).  A wave reads a block with ONE fully
+//     coalesced 1-KiB buffer_load_dwordx4 and feeds register e to MFMA e -- the sum over k is
+//     order-free, so MFMA e's four k-slots are floats 4 kq + e.  The D tile of a 16x16x4 MFMA (lane
+//     = token, 4 registers = 4 consecutive rows) IS that layout for the next GEMM's K = this GEMM's
+//     rows, so every epilogue store is one coalesced 16-byte store per lane, no transpose anywhere.
+//   * weights stay in the reference's row-major layout: a wave reads a 16-row x 64-float block with 4
+//     buffer_load_dwordx4 nt -- lane l takes 16 bytes at row l>>2, float 16 j + 4 (l&3), so every
+//     quad of lanes covers 64 contiguous bytes and the 4 loads 256 contiguous bytes per row -- and
+//     one ds_bpermute_b32 per register rotates the lane index by two bits into the MFMA A layout
+//     (lane = row l&15, k-slot l>>4), matching the B operand's k assignment.
+//   * rmsnorm is a small kernel of its own on the tile layout (exactly cpu.rs:99-117's
+//     w * (v * x)), not folded into the GEMM: the fold would re-read the gain vector per row tile
+//     through the same L2 budget.
+// K is split over the workgroup's 8 waves in 64-float chunks (chunk c -> wave c mod 8: the
+// workgroup sweeps each row front to back like the decode kernels); partial tiles meet in LDS.
+#pragma once
+#include "kernels.hpp"
+#include <type_traits>
+
+namespace rama {
+
+constexpr int kMfWaves = 8;
+constexpr int kMfThreads = kMfWaves * 64;
+constexpr int kMfMaxTok = 64;                // tokens per pass (PT <= 4)
+
+enum { EPI_SWIGLU = 3, EPI_STORE_ROWS = 4 };
+
+// ---- tile layout of an activation matrix [n_tok, K], K % 16 == 0
+// float index of element (token tk, float k): block (tk / 16, k / 16) of 256 floats, inside it
+// lane (tk % 16) + 16 * ((k / 4) % 4), register k % 4
+__host__ __device__ __forceinline__ size_t tile_idx(int tk, int k, int K) {
+    return ((size_t)((tk >> 4) * (K >> 4) + (k >> 4)) * 64 + (size_t)(((k >> 2) & 3) * 16 + (tk & 15))) * 4 + (size_t)(k & 3);
+}
+__host__ __device__ __forceinline__ size_t tile_floats(int n_tok, int K) { return (size_t)((n_tok + 15) >> 4) * 16 * (size_t)K; }
+
+struct MfParams {
+    const float* w[3];     // matrices [rows, K] row-major (EPI_QKV: wq, wk, wv; EPI_SWIGLU: w1, w3)
+    const float* x;        // activations, tile layout [ceil(n_tok / 16) * 16, K]
+    float* o;              // output, tile layout [.., rows] (EPI_QKV: q; EPI_STORE_ROWS: row-major [n_tok, o_stride])
+    size_t slab_floats;    // split-K: partial sums of K-slice ks go to o + ks * slab_floats
+    int o_stride;
+    int K, rows, n_tok;
+    int ksplit;            // K-slices (workgroups per row group), >= 1
+    int nunit;             // (row group, K-slice) units per workgroup, >= 1
+    int pos0;              // position of token 0 (EPI_QKV)
+    const float* fr; const float* fi; int head_size;
+    float* kc; float* vc;  // this layer's cache slabs [seq, dim]
+    const SeqSlot* seqs; size_t layer_off;    // batched independent sequences (rama_decode_batch)
+};
+
+typedef __attribute__((ext_vector_type(4))) float acc4;
+
+// PT  token tiles of 16 (P = 16 PT tokens per pass)
+// RT  row tiles of 16 per group.  EPI_QKV (RT = 3) and EPI_SWIGLU (RT = 2) take tile rt from matrix
+//     rt, all at the same rows; the others take RT consecutive tiles of w[0]
+// JN  16-float blocks of K per wave per step (2 or 4): the prefetch unit.  Registers per lane =
+//     2 * 4 JN (RT + PT) double-buffered operands + 4 RT PT accumulators.
+// LD  1 (product): weights as described above.  2 / 3 are TIMING PROBES of the microbenchmark with
+//     wrong results: 2 = the same reads without the lane permute, 3 = fully contiguous 1-KiB reads
+//     (what a pre-swizzled second copy of the weights would give).
+template <int PT, int RT, int EPI, int JN = 2, int LD = 1>
+__global__ __launch_bounds__(kMfThreads) void gemm_mfma_rows(MfParams p) {
+    constexpr int NT = RT * PT;                          // accumulator tiles per wave
+    constexpr bool ACROSS = EPI == EPI_QKV || EPI == EPI_SWIGLU;
+    constexpr bool PAIR = EPI == EPI_SWIGLU;
+    static_assert(!PAIR || RT == 2, "SwiGLU groups are one w1 tile + one w3 tile");
+    static_assert(EPI != EPI_QKV || RT == 3, "QKV groups are one tile of each of wq, wk, wv");
+    constexpr int CHUNK = 16 * JN;                       // floats of K per wave per step
+    __shared__ float part[kMfWaves][NT][4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rows_per_grp = ACROSS ? 16 : 16 * RT;
+    const int ngroups = (p.rows + rows_per_grp - 1) / rows_per_grp;
+    const int total = ngroups * p.ksplit;                              // units of the launch
+    const int u0 = blockIdx.x * p.nunit;
+    const int nunit = min(p.nunit, total - u0);                        // uniform, >= 1 (host sizes the grid)
+    const unsigned kbytes = (unsigned)p.K * 4u, mbytes = (unsigned)p.rows * kbytes;
+    const int nblk = p.K >> 4;                                         // 16-float blocks along K
+    const int nch = (p.K + CHUNK - 1) / CHUNK;
+    const int cps = (nch + p.ksplit - 1) / p.ksplit;                   // chunks per K-slice
+    const int S = (cps + kMfWaves - 1) / kMfWaves;                     // steps per unit (same for every wave)
+    const int ntile = (p.n_tok + 15) >> 4;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (unsigned)ntile * 16u * kbytes);
+
+    // weight reads: my (row-in-tile, k-slot) while loading, and the lane I pull from afterwards
+    const int ld_row = lane >> 2, ld_kq = lane & 3;
+    const int pull = (((lane & 15) << 2) | (lane >> 4)) << 2;
+
+    f4 A0[RT][JN], A1[RT][JN], B0[PT][JN], B1[PT][JN];
+
+    // loads of step s of local unit ul.  A step beyond the unit's chunks (odd step counts are
+    // padded to pairs) or beyond the last unit is issued all the same with every offset out of
+    // range: the loads return 0 without touching memory, and the number of loads in flight stays a
+    // compile-time constant at every point of the loop, which lets hipcc emit counted vmcnt waits
+    // instead of draining the prefetch (its waitcnt pass merges conservatively at joins).
+    auto issue = [&](f4 (&A)[RT][JN], f4 (&B)[PT][JN], int ul, int s) {
+        const int u = u0 + ul;
+        const int g = u / p.ksplit, ks = u - g * p.ksplit;
+        const int r0 = g * rows_per_grp;
+        const int cl = wave + s * kMfWaves;                                    // chunk within the K-slice
+        int c = (ul < nunit && s < S && cl < cps) ? ks * cps + cl : nch;
+        if (LD == 5 && !(ul == 0 && s < 2)) c = nch;       // probe: only the first two steps load
+        const unsigned kb0 = (unsigned)(c * CHUNK + ld_kq * 4) * 4u;           // byte offset of my float4 in load 0
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+            const float* Wm = ACROSS ? p.w[rt] : p.w[0];
+            const __amdgpu_buffer_rsrc_t ra = make_rsrc(Wm, mbytes);
+            const int r = r0 + (ACROSS ? 0 : rt * 16) + ld_row;
+#pragma unroll
+            for (int j = 0; j < JN; j++) {
+                const unsigned kb = kb0 + (unsigned)j * 64u;
+                if (LD == 3) A[rt][j] = ld_nt(ra, (c < nch && r < p.rows) ? (unsigned)(r0 + (ACROSS ? 0 : rt * 16)) * kbytes + (unsigned)(c * JN + j) * 1024u + lane * 16u : kOOB);
+                else A[rt][j] = ld_nt(ra, (c < nch && kb < kbytes && r < p.rows) ? (unsigned)r * kbytes + kb : kOOB);
+            }
+        }
+#pragma unroll
+        for (int pt = 0; pt < PT; pt++)
+#pragma unroll
+            for (int j = 0; j < JN; j++) {
+                const int jb = c * JN + j;
+                B[pt][j] = ld_c(rx, (c < nch && jb < nblk && pt < ntile) ? (unsigned)((pt * nblk + jb) * 1024 + lane * 16) : kOOB);
+            }
+    };
+
+    acc4 acc[RT][PT];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+            for (int pt = 0; pt < PT; pt++) acc[rt][pt] = acc4{0.f, 0.f, 0.f, 0.f};
+    };
+
+    auto compute = [&](f4 (&A)[RT][JN], f4 (&B)[PT][JN]) {
+        if (LD == 4) {      // probe: consume the loads with one VALU op each, no MFMA
+#pragma unroll
+            for (int j = 0; j < JN; j++) {
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) acc[rt][0] += A[rt][j];
+#pragma unroll
+                for (int pt = 0; pt < PT; pt++) acc[0][pt] += B[pt][j];
+            }
+            return;
+        }
+        if (LD == 1 || LD == 5) {
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                for (int j = 0; j < JN; j++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        A[rt][j][e] = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(A[rt][j][e])));
+            // all permutes of the step are in flight before the first MFMA: left alone, hipcc
+            // permutes in place one register at a time and waits for each right before its use
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < JN; j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                    for (int pt = 0; pt < PT; pt++)
+                        acc[rt][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[rt][j][e], B[pt][j][e], acc[rt][pt], 0, 0, 0);
+    };
+
+    // cross-wave sum of the unit's tiles + the fused epilogue.  D layout of a 16x16 tile: lane l
+    // holds token (l & 15), rows 4 (l >> 4) + e -- one 16-byte slot of the output's tile layout.
+    auto finish_unit = [&](int ul) {
+        const int u = u0 + ul;
+        const int g = u / p.ksplit, ks = u - g * p.ksplit;
+        const int r0 = g * rows_per_grp;
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+            for (int pt = 0; pt < PT; pt++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) part[wave][rt * PT + pt][e][lane] = acc[rt][pt][e];
+        __syncthreads();
+        auto total4 = [&](int tile, int ln) {
+            acc4 r;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float v8[kMfWaves];
+#pragma unroll
+                for (int q = 0; q < kMfWaves; q++) v8[q] = part[q][tile][e][ln];
+#pragma unroll
+                for (int n = kMfWaves; n > 1; n >>= 1)      // fixed pairwise tree
+#pragma unroll
+                    for (int q = 0; q < n / 2; q++) v8[q] = v8[2 * q] + v8[2 * q + 1];
+                r[e] = v8[0];
+            }
+            return r;
+        };
+        constexpr int UNITS = (PAIR ? PT : NT) * 64;      // one unit = 4 consecutive rows of one token
+        for (int v = tid; v < UNITS; v += kMfThreads) {
+            const int ln = v & 63, tile = v >> 6;
+            const int rt = PAIR ? 0 : tile / PT, pt = PAIR ? tile : tile - rt * PT;
+            const int tk = pt * 16 + (ln & 15), r = r0 + (ACROSS ? 0 : rt * 16) + (ln >> 4) * 4;     // rows r .. r + 3
+            if (tk >= p.n_tok || r >= p.rows) continue;     // rows % 4 == 0: a unit is all in or all out
+            acc4 a = total4(PAIR ? pt : tile, ln);
+            if (PAIR) {
+                const acc4 b = total4(PT + pt, ln);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float sg = a[e] * (1.0f / (1.0f + expf(-a[e])));      // cpu.rs:56
+                    a[e] = sg * b[e];                                              // cpu.rs:59-64
+                }
+                *reinterpret_cast<acc4*>(p.o + tile_idx(tk, r, p.rows)) = a;
+            } else if (EPI == EPI_QKV) {
+                const int pos = p.seqs ? p.seqs[tk].pos : p.pos0 + tk;
+                if (rt < 2) {                                                      // cpu.rs:87-96 rotate (q, k)
+                    const int i = (r % p.head_size) >> 1;
+                    const size_t fo = (size_t)pos * (p.head_size >> 1) + i;
+                    const float c0 = p.fr[fo], s0 = p.fi[fo], c1 = p.fr[fo + 1], s1 = p.fi[fo + 1];
+                    const acc4 t = a;
+                    a[0] = t[0] * c0 - t[1] * s0; a[1] = t[0] * s0 + t[1] * c0;
+                    a[2] = t[2] * c1 - t[3] * s1; a[3] = t[2] * s1 + t[3] * c1;
+                }
+                if (rt == 0) *reinterpret_cast<acc4*>(p.o + tile_idx(tk, r, p.rows)) = a;
+                else {                                                             // infer.rs:32-33
+                    float* cache = (rt == 1 ? (p.seqs ? p.seqs[tk].kc + p.layer_off : p.kc) : (p.seqs ? p.seqs[tk].vc + p.layer_off : p.vc));
+                    *reinterpret_cast<acc4*>(cache + (size_t)pos * p.rows + r) = a;
+                }
+            } else if (EPI == EPI_STORE_ROWS) {
+                *reinterpret_cast<acc4*>(p.o + (size_t)tk * p.o_stride + r) = a;
+            } else {                                                               // K-slice ks of the product, tile layout
+                *reinterpret_cast<acc4*>(p.o + (size_t)ks * p.slab_floats + tile_idx(tk, r, p.rows)) = a;
+            }
+        }
+        __syncthreads();       // part[] is rewritten by the next unit
+    };
+
+    // steps of a unit in pairs (buffer 0, buffer 1); the loads of the step after next are issued
+    // before the current step's MFMAs, the first loads of the next unit before this unit's epilogue
+    const int S2 = (S + 1) >> 1;
+    issue(A0, B0, 0, 0);
+#pragma unroll 1
+    for (int ul = 0; ul < nunit; ul++) {
+        zero_acc();
+#pragma unroll 1
+        for (int i = 0; i < S2; i++) {
+            __builtin_amdgcn_sched_barrier(0);
+            issue(A1, B1, ul, 2 * i + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(A0, B0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + 1 < S2) issue(A0, B0, ul, 2 * i + 2); else issue(A0, B0, ul + 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(A1, B1);
+        }
+        finish_unit(ul);
+    }
+}
+
+// ---- small kernels on the tile layout
+
+// X[t] = token_embedding_table[tokens[t]]   (infer.rs:13 per token), tile layout
+__global__ void embed_tile_kernel(float* X, const float* emb, const int* tokens, int n_tok, int dim) {
+    const int t = blockIdx.y;
+    if (t >= n_tok) return;
+    const size_t base = (size_t)tokens[t] * dim;
+    for (int k = (blockIdx.x * blockDim.x + threadIdx.x) * 4; k < dim; k += gridDim.x * blockDim.x * 4)
+        *reinterpret_cast<f4*>(X + tile_idx(t, k, dim)) = *reinterpret_cast<const f4*>(emb + base + k);
+}
+
+// row-major [n_tok, K] <-> tile layout (tests, the microbenchmark, and the last prompt position's
+// residual stream on its way to the classifier)
+__global__ void tile_rows_kernel(float* T, const float* rows, int n_tok, int K) {
+    const int t = blockIdx.y;
+    for (int k = (blockIdx.x * blockDim.x + threadIdx.x) * 4; k < K; k += gridDim.x * blockDim.x * 4)
+        *reinterpret_cast<f4*>(T + tile_idx(t, k, K)) = *reinterpret_cast<const f4*>(rows + (size_t)t * K + k);
+}
+__global__ void untile_rows_kernel(float* rows, const float* T, int tk0, int K) {
+    const int t = blockIdx.y;
+    for (int k = (blockIdx.x * blockDim.x + threadIdx.x) * 4; k < K; k += gridDim.x * blockDim.x * 4)
+        *reinterpret_cast<f4*>(rows + (size_t)t * K + k) = *reinterpret_cast<const f4*>(T + tile_idx(tk0 + t, k, K));
+}
+
+// x += (s0 + s1 + ..): the K-slices of the preceding Wo / W2 product (its sum first, then the residual
+// add, infer.rs:35-37 / 46-47), on the tile layout; any element order -- both sides use the same one
+__device__ __forceinline__ f4 fold_slabs(f4 x, const float* slabs, int nslab, size_t slab_floats, size_t o) {
+    if (nslab > 0) {
+        f4 t = *reinterpret_cast<const f4*>(slabs + o);
+        for (int k = 1; k < nslab; k++) t = t + *reinterpret_cast<const f4*>(slabs + (size_t)k * slab_floats + o);
+        x = x + t;
+    }
+    return x;
+}
+
+// cpu.rs:99-117 per token on the tile layout: o = w * (v * x), v = 1 / sqrt(sum x^2 / n + 1e-5),
+// after folding the pending K-slices of the previous product into the residual stream (written back).
+// One workgroup of 16 waves per 16-token tile; wave w sweeps blocks w, w + 16, ..: lane (token n,
+// k-slot kq) accumulates its token's squares, the 4 k-slot lanes and the 16 waves meet in LDS.
+__global__ __launch_bounds__(1024) void rmsnorm_tile_kernel(float* O, float* X, const float* w, int dim,
+                                                            const float* slabs, int nslab, size_t slab_floats) {
+    __shared__ float red[16][16];
+    __shared__ float s_v[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nblk = dim >> 4;
+    const size_t tbase = (size_t)blockIdx.x * nblk * 256;
+    float ss = 0.0f;
+    for (int jb = wave; jb < nblk; jb += 16) {
+        const size_t o = tbase + (size_t)jb * 256 + lane * 4;
+        f4 x = *reinterpret_cast<const f4*>(X + o);
+        if (nslab > 0) {
+            x = fold_slabs(x, slabs, nslab, slab_floats, o);
+            *reinterpret_cast<f4*>(X + o) = x;
+        }
+        ss = dot4(x, x, ss);
+    }
+    ss += __shfl_xor(ss, 16);
+    ss += __shfl_xor(ss, 32);
+    if (lane < 16) red[wave][lane] = ss;
+    __syncthreads();          // also orders this thread's X writes before its re-read below
+    if (tid < 16) {
+        float t[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) t[q] = red[q][tid];
+#pragma unroll
+        for (int n = 16; n > 1; n >>= 1)
+#pragma unroll
+            for (int q = 0; q < n / 2; q++) t[q] = t[2 * q] + t[2 * q + 1];
+        s_v[tid] = rms_scale(t[0], dim);
+    }
+    __syncthreads();
+    const float v = s_v[lane & 15];
+    for (int jb = wave; jb < nblk; jb += 16) {
+        const size_t o = tbase + (size_t)jb * 256 + lane * 4;
+        const f4 x = *reinterpret_cast<const f4*>(X + o);          // the same thread wrote it above
+        const f4 g = *reinterpret_cast<const f4*>(w + jb * 16 + (lane >> 4) * 4);
+        f4 r;
+        r.x = g.x * (v * x.x); r.y = g.y * (v * x.y); r.z = g.z * (v * x.z); r.w = g.w * (v * x.w);
+        *reinterpret_cast<f4*>(O + o) = r;
+    }
+}
+
+// rows[t] = X[tk0 + t] (+ pending K-slices): the residual stream of tokens on its way to the
+// row-major classifier path
+__global__ void untile_fold_kernel(float* rows, const float* T, int tk0, int K, const float* slabs, int nslab, size_t slab_floats) {
+    const int t = blockIdx.y;
+    for (int k = (blockIdx.x * blockDim.x + threadIdx.x) * 4; k < K; k += gridDim.x * blockDim.x * 4) {
+        const size_t o = tile_idx(tk0 + t, k, K);
+        *reinterpret_cast<f4*>(rows + (size_t)t * K + k) = fold_slabs(*reinterpret_cast<const f4*>(T + o), slabs, nslab, slab_floats, o);
+    }
+}
+
+}  // namespace rama

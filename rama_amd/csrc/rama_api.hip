@@ -3,7 +3,7 @@
 #include "../../include/rama_hip.h"
 #include "kernels.hpp"
 #include "persist.hpp"
-#include "prefill.hpp"
+#include "prefill_mfma.hpp"
 #include <hipcub/hipcub.hpp>
 
 #include <hip/hip_ext.h>   // hipExtLaunchKernelGGL: start/stop events carried by the dispatch itself
@@ -67,6 +67,7 @@ struct rama_ctx {
     int out_cap = 0;
     int* argmax_result = nullptr;   // device int for rama_sample_argmax
     int* pinned_int = nullptr;      // host pinned
+    int* pinned_tok = nullptr;      // host pinned staging: token ids + a SeqSlot table of a token-batch pass
     bool graph_mode = false;
     GraphCache gc[2];                  // [0]: single-workgroup attention, [1]: split-T attention (long contexts)
     KProf kp;
@@ -82,7 +83,6 @@ struct rama_ctx {
     int tune_split_pos = -1;               // attention runs split-T (+ combine launch) from this position on; -1 = by model size
     int tune_resid_r2 = 2;                 // Wo / W2 under geometry 3: 0 = 4-row workgroups, 1 = 2 rows x 8 waves (+0.45 %),
                                            // 2 = additionally 16 waves for rows wider than 8192 floats (W2: +1.15 % more), 3 = 16 waves x 4 chunks
-    int tune_pf_rounds = 1;                // prefill launches are cut into this many even rounds over the CUs
     int tune_prefill = 1;                  // 1: rama_generate_greedy runs the forced prompt positions through rama_prefill
     int tune_merge = -1;                   // attention + Wo in one launch: 1 on, 0 off, -1 by model size (on for dim <= 1024:
                                            // +4..8 % at the stories shapes; at llama2-7B +0.9 % short / -2.5 % long contexts)
@@ -91,7 +91,7 @@ struct rama_ctx {
     unsigned* attn_counter = nullptr;      // device: arrivals of the attention workgroups
     float* attn_part = nullptr;            // split-T partials [n_heads, nsplit, head_size + 4]
     size_t attn_part_floats = 0;
-    float* pf_blob = nullptr;              // prefill scratch: X, Q, K, V, XB [PB, dim], HB [PB, hidden], tokens [PB]
+    float* pf_blob = nullptr;              // token-batch scratch (tile layout): see BatchScratch
     size_t pf_floats = 0;
     int host_pos = -1;                     // position of the next chained decode step (mirrors the device cursor)
     bool split_attn = false;               // variant the steps being enqueued / captured use
@@ -134,6 +134,7 @@ int rama_ctx_create(int device, void* hip_stream, rama_ctx** out) {
     HIPCHK(hipMalloc(&c->pbar, 4 * sizeof(unsigned long long)));
     HIPCHK(hipMemset(c->pbar, 0, 4 * sizeof(unsigned long long)));
     HIPCHK(hipHostMalloc(&c->pinned_int, sizeof(int) * 4));
+    HIPCHK(hipHostMalloc(&c->pinned_tok, sizeof(int) * kMfMaxTok + sizeof(SeqSlot) * kMfMaxTok));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     c->cu_count = prop.multiProcessorCount;
@@ -158,7 +159,7 @@ int rama_ctx_destroy(rama_ctx* c) {
     hipFree(c->ctl); hipFree(c->out); hipFree(c->forced); hipFree(c->argmax_result); hipFree(c->pbar); hipFree(c->attn_counter); hipFree(c->attn_part);
     for (int i = 0; i < 2; i++) { hipFree(c->topp_keys[i]); hipFree(c->topp_vals[i]); }
     hipFree(c->topp_prefix); hipFree(c->topp_m); hipFree(c->topp_err); hipFree(c->topp_tmp); hipFree(c->pf_blob);
-    hipHostFree(c->pinned_int);
+    hipHostFree(c->pinned_int); hipHostFree(c->pinned_tok);
     hipEventDestroy(c->t0); hipEventDestroy(c->t1);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
@@ -709,68 +710,97 @@ int rama_forward(rama_ctx* c, const rama_config* cfg, const rama_weights* w, ram
     return rama_forward_stage(c, cfg, w, s, token, pos, &st);
 }
 
-// One prefill launch: cut the launch's sub-groups (4 rows x PB tokens each) into `tune_pf_rounds`
-// even rounds over the CUs -- the kernels hold one workgroup per CU (register-resident activations),
-// so a grid that is not a multiple of the CU count idles part of the chip for a whole round.
-template <bool NORM, int EPI>
-static int launch_mt(rama_ctx* c, MtParams& p) {
-    const int rows_per_sub = EPI == 3 ? 2 : 4;
-    const int total = (EPI == 3 ? 1 : p.nmat) * ((p.rows + rows_per_sub - 1) / rows_per_sub);
-    const int slots = std::max(1, c->cu_count) * std::max(1, c->tune_pf_rounds);
-    p.nsub = std::max(1, (total + slots - 1) / slots);
-    const int grid = (total + p.nsub - 1) / p.nsub;
-    if (p.K <= kMtOneStepK) hipLaunchKernelGGL((gemm_mt_rows<NORM, EPI, true>), dim3(grid), dim3(kMtThreads), 0, c->stream, p);
-    else hipLaunchKernelGGL((gemm_mt_rows<NORM, EPI, false>), dim3(grid), dim3(kMtThreads), 0, c->stream, p);
+// ---- token-batch passes on the matrix cores (prefill_mfma.hpp): up to kMfMaxTok tokens -- the forced
+// prompt positions of one sequence (rama_prefill) or one token of each of several independent
+// sequences (rama_decode_batch) -- go through a layer together, every weight row streamed once.
+
+// One GEMM launch.  A unit = (row group, K-slice); the launch is cut into one even round over the CUs
+// (the kernels hold one 8-wave workgroup per CU), consecutive units of a workgroup prefetching across
+// their boundary.  ksplit > 1 only for EPI_STORE, whose K-slices land in slabs the next rmsnorm folds.
+template <int RT, int EPI>
+static int launch_mf(rama_ctx* c, MfParams& p, int pt) {
+    constexpr bool across = EPI == EPI_QKV || EPI == EPI_SWIGLU;
+    const int groups = (p.rows + (across ? 16 : 16 * RT) - 1) / (across ? 16 : 16 * RT);
+    const int total = groups * p.ksplit;
+    p.nunit = std::max(1, (total + std::max(1, c->cu_count) - 1) / std::max(1, c->cu_count));
+    const dim3 grid((total + p.nunit - 1) / p.nunit), block(kMfThreads);
+    if (pt == 1) hipLaunchKernelGGL((gemm_mfma_rows<1, RT, EPI>), grid, block, 0, c->stream, p);
+    else if (pt == 2) hipLaunchKernelGGL((gemm_mfma_rows<2, RT, EPI>), grid, block, 0, c->stream, p);
+    else hipLaunchKernelGGL((gemm_mfma_rows<4, RT, EPI>), grid, block, 0, c->stream, p);
     LAUNCHCHK();
     return 0;
 }
 
-// ---- batched-prompt prefill (prefill.hpp): n positions pos0..pos0+n-1 through the layers PB at a time
-// scratch of the token-batch passes: X, Q, KS, VS, XB [kPB, dim], HB [kPB, hidden], token ids,
-// (decode_batch) logits [kPB, vocab] and the sequence table
-struct BatchScratch { float *X, *Q, *KS, *VS, *XB, *HB, *LG; int* toks; SeqSlot* seqs; };
+// K-slices of the Wo / W2 products: enough (row group, slice) units to give every CU one, while a
+// slice still feeds the workgroup's 8 waves two steps each (16 blocks of 16 floats per wave-step pair)
+static int mf_ksplit(const rama_ctx* c, int rows, int K) {
+    const int groups = (rows + 31) / 32;
+    int ks = 1;
+    while (ks < 4 && groups * ks < c->cu_count && K / (ks * 2) >= 512) ks *= 2;
+    return ks;
+}
+
+// scratch of a pass (tile layout, kMfMaxTok tokens): X residual stream, XN its rmsnorm, Q, XB, HB
+// [hidden], SL = up to 4 K-slice slabs [dim]; then token ids, the sequence table, and (decode_batch)
+// row-major logits [kMfMaxTok, vocab]
+struct BatchScratch { float *X, *XN, *Q, *XB, *HB, *SL, *LG; size_t slab; int* toks; SeqSlot* seqs; };
 
 static int ensure_batch_scratch(rama_ctx* c, const rama_config* cfg, bool with_logits, BatchScratch* b) {
-    const size_t dim = cfg->dim, hidden = cfg->hidden_dim;
-    const size_t need = (size_t)kPB * (5 * dim + hidden) + 64 + 64 + (with_logits ? (size_t)kPB * cfg->vocab_size : 0);
+    const size_t T = kMfMaxTok, dim = cfg->dim, hidden = cfg->hidden_dim;
+    const size_t ints = 64 + (sizeof(SeqSlot) / sizeof(int)) * T;
+    const size_t need = T * (8 * dim + hidden) + ints + 64 + (with_logits ? T * (size_t)cfg->vocab_size : 0);
     if (need > c->pf_floats) {
         if (c->pf_blob) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->pf_blob)); c->pf_blob = nullptr; }
+        if (set_device(c)) return 1;
         HIPCHK(hipMalloc(&c->pf_blob, need * sizeof(float)));
+        // stale tokens of a partly filled 16-token tile flow through the GEMMs as extra columns (never
+        // stored): keep them finite
+        HIPCHK(hipMemsetAsync(c->pf_blob, 0, need * sizeof(float), c->stream));
         c->pf_floats = need;
     }
-    b->X = c->pf_blob; b->Q = b->X + kPB * dim; b->KS = b->Q + kPB * dim; b->VS = b->KS + kPB * dim;
-    b->XB = b->VS + kPB * dim; b->HB = b->XB + kPB * dim;
-    b->toks = reinterpret_cast<int*>(b->HB + kPB * hidden);
+    b->slab = T * dim;
+    b->X = c->pf_blob; b->XN = b->X + T * dim; b->Q = b->XN + T * dim; b->XB = b->Q + T * dim;
+    b->SL = b->XB + T * dim; b->HB = b->SL + 4 * T * dim;
+    b->toks = reinterpret_cast<int*>(b->HB + T * hidden);
     b->seqs = reinterpret_cast<SeqSlot*>(b->toks + 64);
-    b->LG = reinterpret_cast<float*>(b->toks + 128);
+    b->LG = reinterpret_cast<float*>(b->toks + ints + 64);      // ints is a multiple of 4: 16-byte aligned
     return 0;
 }
 
-// nt <= kPB tokens (already embedded in b.X) through every layer, each weight row streamed once.
-// seqs == nullptr: consecutive positions p0.. of ONE sequence (caches kc0/vc0 = its cache bases);
-// seqs != nullptr: token t belongs to independent sequence t (device table b.seqs).
+static bool mf_shape_ok(const rama_config* cfg) { return cfg->dim % 16 == 0 && cfg->hidden_dim % 16 == 0; }
+
+// nt <= kMfMaxTok tokens (already embedded in b.X, tile layout) through every layer.
+// seqs == false: consecutive positions p0.. of ONE sequence (its cache bases key_cache / value_cache);
+// seqs == true: token t belongs to independent sequence t (device table b.seqs).
+// On return the residual stream is b.X + the *nslab_out K-slices in b.SL (folded by the caller).
 static int run_layers_batched(rama_ctx* c, const rama_config* cfg, const rama_weights* w, const BatchScratch& b,
-                              int nt, int p0, float* key_cache, float* value_cache, bool seqs) {
+                              int nt, int p0, float* key_cache, float* value_cache, bool seqs, int* nslab_out) {
     const int dim = cfg->dim, hidden = cfg->hidden_dim, hs = dim / cfg->n_heads;
     const size_t dd = (size_t)dim * dim, hd = (size_t)hidden * dim;
+    const int ntile = (nt + 15) / 16, pt = ntile <= 1 ? 1 : (ntile == 2 ? 2 : 4);
+    const int ks_wo = mf_ksplit(c, dim, dim), ks_w2 = mf_ksplit(c, dim, hidden);
+    int pending = 0;      // K-slices of the previous product waiting in b.SL
     int rc;
     for (int layer = 0; layer < cfg->n_layers; layer++) {
         const size_t li = (size_t)layer;
         const size_t layer_off = li * cfg->seq_len * dim;
-        float* kc = key_cache ? key_cache + layer_off : nullptr;
-        float* vc = value_cache ? value_cache + layer_off : nullptr;
-        MtParams p{};
-        p.n_tok = nt; p.pos0 = p0; p.fr = w->freq_cis_real; p.fi = w->freq_cis_imag; p.head_size = hs; p.kc = kc; p.vc = vc;
-        p.seqs = seqs ? b.seqs : nullptr; p.layer_off = layer_off;
-        // infer.rs:19-33 for the batch
+        MfParams p{};
+        p.n_tok = nt; p.ksplit = 1; p.slab_floats = b.slab;
+        // infer.rs:19 (+ the residual add of the previous layer's W2 product, :47)
+        hipLaunchKernelGGL(rmsnorm_tile_kernel, dim3(ntile), dim3(1024), 0, c->stream, b.XN, b.X, w->rms_att_weight + li * dim, dim,
+                           (const float*)b.SL, pending, b.slab);
+        LAUNCHCHK();
+        // infer.rs:20-33: Wq | Wk | Wv, RoPE, cache append
         p.w[0] = w->wq + li * dd; p.w[1] = w->wk + li * dd; p.w[2] = w->wv + li * dd;
-        p.x = b.X; p.x_stride = dim; p.nw = w->rms_att_weight + li * dim;
-        p.o[0] = b.Q; p.o[1] = b.KS; p.o[2] = b.VS; p.o_stride = dim; p.K = dim; p.rows = dim; p.nmat = 3; p.epi = EPI_QKV;
-        rc = launch_mt<true, EPI_QKV>(c, p); if (rc) return rc;
+        p.x = b.XN; p.o = b.Q; p.K = dim; p.rows = dim;
+        p.pos0 = p0; p.fr = w->freq_cis_real; p.fi = w->freq_cis_imag; p.head_size = hs;
+        p.kc = key_cache ? key_cache + layer_off : nullptr; p.vc = value_cache ? value_cache + layer_off : nullptr;
+        p.seqs = seqs ? b.seqs : nullptr; p.layer_off = layer_off;
+        rc = launch_mf<3, EPI_QKV>(c, p, pt); if (rc) return rc;
         {   // infer.rs:34: query z attends to positions 0..pos(z)
             AttnParams a{};
-            a.q = b.Q; a.kc = kc; a.vc = vc; a.att = nullptr; a.xb = b.XB; a.ctl = nullptr; a.pos_val = p0;
-            a.dim = dim; a.head_size = hs; a.seq_len = cfg->seq_len; a.q_stride = dim; a.xb_stride = dim;
+            a.q = b.Q; a.kc = p.kc; a.vc = p.vc; a.att = nullptr; a.xb = b.XB; a.ctl = nullptr; a.pos_val = p0;
+            a.dim = dim; a.head_size = hs; a.seq_len = cfg->seq_len; a.tiled = 1;
             a.seqs = seqs ? b.seqs : nullptr; a.layer_off = layer_off;
             const int G = hs <= 64 ? 16 : (hs <= 128 ? 32 : 64);
             size_t shm = (size_t)(attn_scratch_floats(G) + cfg->seq_len) * sizeof(float);
@@ -781,19 +811,22 @@ static int run_layers_batched(rama_ctx* c, const rama_config* cfg, const rama_we
             else hipLaunchKernelGGL((attention_kernel<64, false>), grid, dim3(kAttnThreads), shm, c->stream, a);
             LAUNCHCHK();
         }
-        // infer.rs:35-37
-        p.w[0] = w->wo + li * dd; p.x = b.XB; p.x_stride = dim; p.nw = nullptr; p.o[0] = b.X; p.o_stride = dim;
-        p.K = dim; p.rows = dim; p.nmat = 1; p.epi = EPI_RESID;
-        rc = launch_mt<false, EPI_RESID>(c, p); if (rc) return rc;
-        // infer.rs:39-45
-        p.w[0] = w->w1 + li * hd; p.w[1] = w->w3 + li * hd; p.x = b.X; p.x_stride = dim; p.nw = w->rms_ffn_weight + li * dim;
-        p.o[0] = b.HB; p.o_stride = hidden; p.K = dim; p.rows = hidden; p.nmat = 1; p.epi = 3;
-        rc = launch_mt<true, 3>(c, p); if (rc) return rc;
-        // infer.rs:46-47
-        p.w[0] = w->w2 + li * hd; p.x = b.HB; p.x_stride = hidden; p.nw = nullptr; p.o[0] = b.X; p.o_stride = dim;
-        p.K = hidden; p.rows = dim; p.nmat = 1; p.epi = EPI_RESID;
-        rc = launch_mt<false, EPI_RESID>(c, p); if (rc) return rc;
+        // infer.rs:35: Wo . xb as K-slices; the residual add (:37) rides in the next rmsnorm
+        p.w[0] = w->wo + li * dd; p.x = b.XB; p.o = b.SL; p.K = dim; p.rows = dim; p.ksplit = ks_wo;
+        rc = launch_mf<2, EPI_STORE>(c, p, pt); if (rc) return rc;
+        // infer.rs:37,39
+        hipLaunchKernelGGL(rmsnorm_tile_kernel, dim3(ntile), dim3(1024), 0, c->stream, b.XN, b.X, w->rms_ffn_weight + li * dim, dim,
+                           (const float*)b.SL, ks_wo, b.slab);
+        LAUNCHCHK();
+        // infer.rs:41-45: W1 | W3, SiLU * gate
+        p.w[0] = w->w1 + li * hd; p.w[1] = w->w3 + li * hd; p.x = b.XN; p.o = b.HB; p.K = dim; p.rows = hidden; p.ksplit = 1;
+        rc = launch_mf<2, EPI_SWIGLU>(c, p, pt); if (rc) return rc;
+        // infer.rs:46: W2 . hb as K-slices (:47 rides in the next rmsnorm / the caller's fold)
+        p.w[0] = w->w2 + li * hd; p.x = b.HB; p.o = b.SL; p.K = hidden; p.rows = dim; p.ksplit = ks_w2;
+        rc = launch_mf<2, EPI_STORE>(c, p, pt); if (rc) return rc;
+        pending = ks_w2;
     }
+    *nslab_out = pending;
     return 0;
 }
 
@@ -805,59 +838,89 @@ int rama_prefill(rama_ctx* c, const rama_config* cfg, const rama_weights* w, ram
     rc = check_stage(cfg, w, s, &st); if (rc) return rc;
     REQUIRE(n_tokens >= 1 && pos0 >= 0 && pos0 + n_tokens <= cfg->seq_len, RAMA_EINVAL, "prefill: positions outside [0, seq_len)");
     for (int i = 0; i < n_tokens; i++) REQUIRE(tokens_host[i] >= 0 && tokens_host[i] < cfg->vocab_size, RAMA_EINVAL, "prefill: token outside the vocabulary");
+    if (set_device(c)) return 1;
     const int dim = cfg->dim;
+    const size_t att_floats = (size_t)attn_scratch_floats((dim / cfg->n_heads) <= 64 ? 16 : ((dim / cfg->n_heads) <= 128 ? 32 : 64)) + cfg->seq_len;
+    if (!mf_shape_ok(cfg) || att_floats * sizeof(float) > 64 * 1024) {
+        // widths that are not whole 16-float blocks, or contexts the one-workgroup attention cannot
+        // hold: the reference's own schedule, one forward() per forced token (mod.rs:187-194)
+        for (int i = 0; i < n_tokens; i++) { rc = rama_forward(c, cfg, w, s, tokens_host[i], pos0 + i); if (rc) return rc; }
+        return 0;
+    }
     BatchScratch b{};
     rc = ensure_batch_scratch(c, cfg, false, &b); if (rc) return rc;
     c->embedded_x = nullptr; c->host_pos = -1;
-    int last_nt = 0;
-    for (int c0 = 0; c0 < n_tokens; c0 += kPB) {
-        const int nt = std::min(kPB, n_tokens - c0), p0 = pos0 + c0;
+    int last_nt = 0, nslab = 0;
+    for (int c0 = 0; c0 < n_tokens; c0 += kMfMaxTok) {
+        const int nt = std::min(kMfMaxTok, n_tokens - c0), p0 = pos0 + c0;
         last_nt = nt;
-        HIPCHK(hipMemcpyAsync(b.toks, tokens_host + c0, sizeof(int) * nt, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(embed_mt_kernel, dim3((dim + 255) / 256, nt), dim3(256), 0, c->stream, b.X, w->token_embedding_table, (const int*)b.toks, nt, dim);
+        // the ids go through the context's pinned staging buffer: the caller's array may be gone
+        // before the copy runs
+        HIPCHK(hipStreamSynchronize(c->stream));
+        memcpy(c->pinned_tok, tokens_host + c0, sizeof(int) * nt);
+        HIPCHK(hipMemcpyAsync(b.toks, c->pinned_tok, sizeof(int) * nt, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(embed_tile_kernel, dim3((dim / 4 + 255) / 256, nt), dim3(256), 0, c->stream, b.X, w->token_embedding_table, (const int*)b.toks, nt, dim);
         LAUNCHCHK();
-        rc = run_layers_batched(c, cfg, w, b, nt, p0, s->key_cache, s->value_cache, false);
+        rc = run_layers_batched(c, cfg, w, b, nt, p0, s->key_cache, s->value_cache, false, &nslab);
         if (rc) return rc;
     }
-    // the last position's residual stream, then infer.rs:49-51 for it only (generate() ignores the
-    // logits of the forced positions before it)
-    hipLaunchKernelGGL(copy_kernel, dim3(ew_grid(dim)), dim3(256), 0, c->stream, s->x, (const float*)(b.X + (size_t)(last_nt - 1) * dim), (size_t)dim);
+    // the last position's residual stream (+ the last W2 product), then infer.rs:49-51 for it only
+    // (generate() ignores the logits of the forced positions before it)
+    hipLaunchKernelGGL(untile_fold_kernel, dim3((dim / 4 + 255) / 256, 1), dim3(256), 0, c->stream, s->x, (const float*)b.X, last_nt - 1, dim,
+                       (const float*)b.SL, nslab, b.slab);
     LAUNCHCHK();
     return launch_rows<true, EPI_STORE>(c, s->logits, w->wcls, s->x, w->rms_final_weight, dim, cfg->vocab_size);
 }
 
-// ---- one decode step for up to kPB INDEPENDENT sequences (the server's concurrent requests,
+// ---- one decode step for up to kMfMaxTok INDEPENDENT sequences (the server's concurrent requests,
 // SURVEY 8e): every weight row is streamed once for all of them.  No reference counterpart; the
 // contract is "what forward(token_i, pos_i) leaves in state_i, for every i": cache rows + logits.
 int rama_decode_batch(rama_ctx* c, const rama_config* cfg, const rama_weights* w, const rama_run_state* states,
                       const int32_t* tokens_host, const int32_t* pos_host, int n_seq) {
     REQUIRE(c && states && tokens_host && pos_host, RAMA_EINVAL, "decode_batch: NULL argument");
-    REQUIRE(n_seq >= 1 && n_seq <= kPB, RAMA_EINVAL, "decode_batch: 1..8 sequences per call");
+    REQUIRE(n_seq >= 1 && n_seq <= kMfMaxTok, RAMA_EINVAL, "decode_batch: 1..64 sequences per call");
     int rc = check_cfg(cfg); if (rc) return rc;
     rama_stage st{0, cfg->n_layers, 1, 1};
-    SeqSlot slots[kPB] = {};
+    if (set_device(c)) return 1;
     for (int i = 0; i < n_seq; i++) {
         rc = check_stage(cfg, w, &states[i], &st); if (rc) return rc;
         REQUIRE(tokens_host[i] >= 0 && tokens_host[i] < cfg->vocab_size, RAMA_EINVAL, "decode_batch: token outside the vocabulary");
         REQUIRE(pos_host[i] >= 0 && pos_host[i] < cfg->seq_len, RAMA_EINVAL, "decode_batch: position outside [0, seq_len)");
         for (int j = 0; j < i; j++) REQUIRE(states[j].key_cache != states[i].key_cache && states[j].logits != states[i].logits, RAMA_EINVAL, "decode_batch: two sequences share a run state");
-        slots[i].kc = states[i].key_cache; slots[i].vc = states[i].value_cache; slots[i].pos = pos_host[i];
     }
     const int dim = cfg->dim, V = cfg->vocab_size;
+    const size_t att_floats = (size_t)attn_scratch_floats((dim / cfg->n_heads) <= 64 ? 16 : ((dim / cfg->n_heads) <= 128 ? 32 : 64)) + cfg->seq_len;
+    if (!mf_shape_ok(cfg) || V % 4 != 0 || att_floats * sizeof(float) > 64 * 1024) {   // see rama_prefill: one forward() per sequence
+        for (int i = 0; i < n_seq; i++) {
+            rama_run_state si = states[i];
+            rc = rama_forward(c, cfg, w, &si, tokens_host[i], pos_host[i]); if (rc) return rc;
+        }
+        return 0;
+    }
     BatchScratch b{};
     rc = ensure_batch_scratch(c, cfg, true, &b); if (rc) return rc;
     c->embedded_x = nullptr; c->host_pos = -1;
-    HIPCHK(hipMemcpyAsync(b.toks, tokens_host, sizeof(int) * n_seq, hipMemcpyHostToDevice, c->stream));
+    // ids and the sequence table go through pinned staging (the source arrays are the caller's / locals)
+    HIPCHK(hipStreamSynchronize(c->stream));
+    SeqSlot* slots = reinterpret_cast<SeqSlot*>(c->pinned_tok + kMfMaxTok);
+    for (int i = 0; i < n_seq; i++) {
+        c->pinned_tok[i] = tokens_host[i];
+        slots[i].kc = states[i].key_cache; slots[i].vc = states[i].value_cache; slots[i].pos = pos_host[i]; slots[i].pad = 0;
+    }
+    HIPCHK(hipMemcpyAsync(b.toks, c->pinned_tok, sizeof(int) * n_seq, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(b.seqs, slots, sizeof(SeqSlot) * n_seq, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(embed_mt_kernel, dim3((dim + 255) / 256, n_seq), dim3(256), 0, c->stream, b.X, w->token_embedding_table, (const int*)b.toks, n_seq, dim);
+    hipLaunchKernelGGL(embed_tile_kernel, dim3((dim / 4 + 255) / 256, n_seq), dim3(256), 0, c->stream, b.X, w->token_embedding_table, (const int*)b.toks, n_seq, dim);
     LAUNCHCHK();
-    rc = run_layers_batched(c, cfg, w, b, n_seq, 0, nullptr, nullptr, true);
+    int nslab = 0;
+    rc = run_layers_batched(c, cfg, w, b, n_seq, 0, nullptr, nullptr, true, &nslab);
     if (rc) return rc;
-    // infer.rs:49-51 for every sequence: final rmsnorm + classifier as one more multi-RHS pass
-    MtParams p{};
-    p.n_tok = n_seq; p.w[0] = w->wcls; p.x = b.X; p.x_stride = dim; p.nw = w->rms_final_weight;
-    p.o[0] = b.LG; p.o_stride = V; p.K = dim; p.rows = V; p.nmat = 1; p.epi = EPI_STORE;
-    rc = launch_mt<true, EPI_STORE>(c, p); if (rc) return rc;
+    // infer.rs:49-51 for every sequence: fold the last product, final rmsnorm, classifier as one more GEMM
+    const int ntile = (n_seq + 15) / 16, pt = ntile <= 1 ? 1 : (ntile == 2 ? 2 : 4);
+    hipLaunchKernelGGL(rmsnorm_tile_kernel, dim3(ntile), dim3(1024), 0, c->stream, b.XN, b.X, w->rms_final_weight, dim, (const float*)b.SL, nslab, b.slab);
+    LAUNCHCHK();
+    MfParams p{};
+    p.n_tok = n_seq; p.ksplit = 1; p.w[0] = w->wcls; p.x = b.XN; p.o = b.LG; p.o_stride = V; p.K = dim; p.rows = V;
+    rc = launch_mf<2, EPI_STORE_ROWS>(c, p, pt); if (rc) return rc;
     for (int i = 0; i < n_seq; i++)
         HIPCHK(hipMemcpyAsync(states[i].logits, b.LG + (size_t)i * V, sizeof(float) * V, hipMemcpyDeviceToDevice, c->stream));
     return 0;
@@ -1068,11 +1131,6 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
         c->tune_resid_r2 = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
-        return 0;
-    }
-    if (!strcmp(key, "prefill_rounds")) {
-        REQUIRE(value >= 1 && value <= 64, RAMA_EINVAL, "set_tuning: prefill_rounds must be in 1..64");
-        c->tune_pf_rounds = value;
         return 0;
     }
     if (!strcmp(key, "prefill")) {

@@ -193,9 +193,9 @@ class Engine:
 
 
 def decode_batch(engines: Sequence["Engine"], tokens: Sequence[int], positions: Sequence[int]):
-    """One decode step for up to 8 independent sequences over the same model (rama_decode_batch):
+    """One decode step for up to 64 independent sequences over the same model (rama_decode_batch):
     engines[i] advances by forward(tokens[i], positions[i]); its logits()/caches are updated."""
-    assert 1 <= len(engines) == len(tokens) == len(positions) <= 8
+    assert 1 <= len(engines) == len(tokens) == len(positions) <= 64
     e0 = engines[0]
     states = (rama_run_state * len(engines))(*[e.state for e in engines])
     toks = (C.c_int32 * len(engines))(*tokens)

@@ -530,6 +530,35 @@ def test_prefill_equals_sequential_forward(dev, name, n_tokens, pos0):
     rs.free(); ws.free()
 
 
+@pytest.mark.parametrize("n_tokens,pos0", [(17, 0), (33, 0), (64, 0), (65, 3), (150, 0)])
+def test_prefill_long_prompts_cross_tile_and_pass_boundaries(dev, n_tokens, pos0):
+    """prompts longer than one 16-token MFMA tile / one 64-token pass: every tile count (PT = 1, 2, 4),
+    a partly filled last tile, several passes and a non-zero start position give the state sequential
+    forward() calls leave (oracle as referee)"""
+    import rama_amd
+    cfg = O.Config(128, 352, 2, 4, 4, 256, 160, False)
+    w = S.synth_weights(cfg, seed=11)
+    rng = np.random.default_rng(n_tokens)
+    toks = [1] + [int(t) for t in rng.integers(0, cfg.vocab_size, pos0 + n_tokens - 1)]
+    orc = O.Oracle(cfg, w)
+    rcfg, ws, wv, rs, rsv = gpu_views(dev, cfg, w)
+    for pos in range(pos0):
+        orc.forward(toks[pos], pos)
+        rama_amd.forward_fused(rcfg, wv, rsv, toks[pos], pos, dev)
+    for i in range(n_tokens):
+        lo = orc.forward(toks[pos0 + i], pos0 + i)
+    _prefill(dev, rcfg, wv, rsv, toks[pos0:pos0 + n_tokens], pos0)
+    assert np.abs(dev.download(rsv.logits) - lo).max() <= LOGIT_ATOL
+    assert np.abs(dev.download(rsv.x) - orc.s["xb"]).max() <= STATE_ATOL      # infer.rs:49: the residual stream ends up in xb on the CPU path
+    for buf in ("key_cache", "value_cache"):
+        assert np.abs(dev.download(getattr(rsv, buf)) - orc.s[buf]).max() <= STATE_ATOL
+    nxt = O.argmax(lo)
+    lo2 = orc.forward(nxt, pos0 + n_tokens)
+    rama_amd.forward_fused(rcfg, wv, rsv, nxt, pos0 + n_tokens, dev)
+    assert np.abs(dev.download(rsv.logits) - lo2).max() <= LOGIT_ATOL
+    rs.free(); ws.free()
+
+
 def test_prefill_argument_errors(dev):
     import rama_amd
     cfg, w, g = load_case("synth_d64_h4")
@@ -662,6 +691,37 @@ def test_decode_batch_equals_independent_forwards(dev, name, n_seq):
             assert np.abs(batch[i].logits() - lo).max() <= LOGIT_ATOL, (i, pos[i])
             cur[i] = O.argmax(lo); pos[i] += 1
     for i in range(n_seq):
+        for buf in ("key_cache", "value_cache"):
+            assert np.abs(batch[i].buffer(buf, orcs[i].s[buf].size) - orcs[i].s[buf]).max() <= STATE_ATOL, (i, buf)
+    for e in batch: e.free()
+    m.free()
+
+
+@pytest.mark.parametrize("n_seq", [17, 40, 64])
+def test_decode_batch_many_sequences(dev, n_seq):
+    """more sequences than one 16-token MFMA tile: up to 64 independent sequences per weight pass"""
+    import rama_amd
+    cfg = O.Config(128, 352, 2, 4, 4, 256, 24, True)
+    rope = S.rope_tables(cfg.seq_len, cfg.head_size)
+    w = S.synth_weights(cfg, seed=3, rope=rope)
+    m = rama_amd.Model.synth(dev, to_rama_cfg(cfg), 3, rope=rope)
+    batch = [rama_amd.Engine(dev, m) for _ in range(n_seq)]
+    orcs = [O.Oracle(cfg, w) for _ in range(n_seq)]
+    rng = np.random.default_rng(n_seq)
+    cur = [int(t) for t in rng.integers(0, cfg.vocab_size, n_seq)]
+    pos = [0] * n_seq
+    # stagger the sequences: sequence i is advanced alone i % 3 times first
+    for i in range(n_seq):
+        for _ in range(i % 3):
+            lo = orcs[i].forward(cur[i], pos[i]); batch[i].forward(cur[i], pos[i])
+            cur[i] = O.argmax(lo); pos[i] += 1
+    for _ in range(3):
+        rama_amd.decode_batch(batch, cur, pos)
+        for i in range(n_seq):
+            lo = orcs[i].forward(cur[i], pos[i])
+            assert np.abs(batch[i].logits() - lo).max() <= LOGIT_ATOL, (i, pos[i])
+            cur[i] = O.argmax(lo); pos[i] += 1
+    for i in (0, n_seq // 2, n_seq - 1):
         for buf in ("key_cache", "value_cache"):
             assert np.abs(batch[i].buffer(buf, orcs[i].s[buf].size) - orcs[i].s[buf]).max() <= STATE_ATOL, (i, buf)
     for e in batch: e.free()

@@ -1,0 +1,136 @@
+// pf_mfma_bench.hip -- standalone check + microbenchmark of the fp32 MFMA prefill GEMM
+// (rama_amd/csrc/prefill_mfma.hpp).  Not part of the product: a tuning aid.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o pf_mfma_bench tools/pf_mfma_bench.hip
+// Run:   ./pf_mfma_bench [iters]
+// Every variant computes O[p][r] = sum_k W[r][k] X[p][k] for the llama2-7B layer shapes; timing =
+// HIP events around `iters` launches rotating over distinct weight buffers (3 GB, so the 256 MiB
+// Infinity Cache cannot help); the first launch of each variant is checked against a plain kernel.
+#include "../rama_amd/csrc/prefill_mfma.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+
+using namespace rama;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+__global__ void ref_gemm(const float* W, const float* X, float* O, int K, int rows, int P) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x, p = blockIdx.y;
+    if (r >= rows || p >= P) return;
+    double acc = 0.0;
+    for (int k = 0; k < K; k++) acc += (double)W[(size_t)r * K + k] * (double)X[(size_t)p * K + k];
+    O[(size_t)p * rows + r] = (float)acc;
+}
+__global__ void fill_kernel(float* d, size_t n, unsigned seed, float scale) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned z = (unsigned)i * 2654435761u + seed;
+        z ^= z >> 15; z *= 2246822519u; z ^= z >> 13; z *= 3266489917u; z ^= z >> 16;
+        d[i] = ((float)(z & 0xFFFF) - 32768.0f) * scale;
+    }
+}
+
+struct Shape { const char* name; int rows, K; };
+
+enum { MODE_ROWS = 0, MODE_QKV = 1, MODE_SWIGLU = 2 };
+template <int PT, int RT, int JN, int LD, int MODE>
+static void launch(hipStream_t st, const float* W, const float* XT, float* O, size_t slab, int K, int rows, int P, int cus, int ks) {
+    MfParams p{};
+    p.x = XT; p.o = O; p.slab_floats = slab; p.o_stride = rows; p.K = K; p.n_tok = P; p.ksplit = ks;
+    int groups;
+    if (MODE == MODE_ROWS) { p.w[0] = W; p.rows = rows; groups = (rows + 16 * RT - 1) / (16 * RT); }
+    else {      // the shape's rows are split evenly over the RT matrices
+        p.rows = rows / RT;
+        for (int i = 0; i < RT; i++) p.w[i] = W + (size_t)i * p.rows * K;
+        groups = (p.rows + 15) / 16;
+        p.fr = XT; p.fi = XT; p.head_size = 128; p.kc = O + slab; p.vc = O + 2 * slab; p.pos0 = 0;
+    }
+    const int total = groups * ks;
+    p.nunit = std::max(1, (total + cus - 1) / cus);
+    const int grid = (total + p.nunit - 1) / p.nunit;
+    constexpr int EPI = MODE == MODE_QKV ? EPI_QKV : (MODE == MODE_SWIGLU ? EPI_SWIGLU : EPI_STORE);
+    hipLaunchKernelGGL((gemm_mfma_rows<PT, RT, EPI, JN, LD>), dim3(grid), dim3(kMfThreads), 0, st, p);
+}
+typedef void (*LaunchFn)(hipStream_t, const float*, const float*, float*, size_t, int, int, int, int, int);
+struct Variant { const char* name; LaunchFn fn; int P; int ks; bool check; };
+
+int main(int argc, char** argv) {
+    const int iters = argc > 1 ? atoi(argv[1]) : 20;
+    CK(hipSetDevice(0));
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    hipStream_t st; CK(hipStreamCreate(&st));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    Shape shapes[] = {{"wo    4096x4096 ", 4096, 4096}, {"w2    4096x11008", 4096, 11008},
+                      {"qkv   12288x4096", 12288, 4096}, {"w13   22016x4096", 22016, 4096}};
+    const size_t max_floats = (size_t)32000 * 4096;
+    const int nbuf = 6;
+    std::vector<float*> W(nbuf);
+    for (int i = 0; i < nbuf; i++) { CK(hipMalloc(&W[i], max_floats * 4)); hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, st, W[i], max_floats, 17u + i, 1.0f / 32768.0f * 0.02f); }
+    float *X, *XT, *O, *Oref;
+    const int PMAX = 64;
+    CK(hipMalloc(&X, (size_t)PMAX * 11008 * 4)); CK(hipMalloc(&XT, (size_t)PMAX * 11008 * 4));
+    CK(hipMalloc(&O, (size_t)4 * PMAX * 32000 * 4)); CK(hipMalloc(&Oref, (size_t)PMAX * 32000 * 4));
+    hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, st, X, (size_t)PMAX * 11008, 99u, 1.0f / 32768.0f);
+    CK(hipStreamSynchronize(st));
+
+    std::vector<Variant> vs = {
+        {"PT4 RT1 J2 ks1        ", launch<4, 1, 2, 1, MODE_ROWS>, 64, 1, true},
+        {"PT4 RT1 J2 ks1 mfmaX  ", launch<4, 1, 2, 5, MODE_ROWS>, 64, 1, false},
+        {"PT4 RT2 J2 ks2        ", launch<4, 2, 2, 1, MODE_ROWS>, 64, 2, true},
+        {"PT4 RT2 J2 ks2 mfmaX  ", launch<4, 2, 2, 5, MODE_ROWS>, 64, 2, false},
+        {"PT4 RT2 J4 ks2        ", launch<4, 2, 4, 1, MODE_ROWS>, 64, 2, true},
+        {"PT2 RT2 J4 ks2        ", launch<2, 2, 4, 1, MODE_ROWS>, 32, 2, true},
+        {"PT2 RT2 J2 ks2        ", launch<2, 2, 2, 1, MODE_ROWS>, 32, 2, true},
+        {"PT1 RT2 J4 ks2        ", launch<1, 2, 4, 1, MODE_ROWS>, 16, 2, true},
+        {"PT1 RT1 J4 ks1        ", launch<1, 1, 4, 1, MODE_ROWS>, 16, 1, true},
+        {"PT4 qkv3 J2 (time only)", launch<4, 3, 2, 1, MODE_QKV>, 64, 1, false},
+        {"PT2 qkv3 J2 (time only)", launch<2, 3, 2, 1, MODE_QKV>, 32, 1, false},
+        {"PT2 qkv3 J4 (time only)", launch<2, 3, 4, 1, MODE_QKV>, 32, 1, false},
+        {"PT1 qkv3 J4 (time only)", launch<1, 3, 4, 1, MODE_QKV>, 16, 1, false},
+        {"PT4 swiglu J2 (time only)", launch<4, 2, 2, 1, MODE_SWIGLU>, 64, 1, false},
+        {"PT2 swiglu J2 (time only)", launch<2, 2, 2, 1, MODE_SWIGLU>, 32, 1, false},
+        {"PT2 swiglu J4 (time only)", launch<2, 2, 4, 1, MODE_SWIGLU>, 32, 1, false},
+        {"PT1 swiglu J4 (time only)", launch<1, 2, 4, 1, MODE_SWIGLU>, 16, 1, false},
+    };
+    for (const Shape& sh : shapes) {
+        printf("== %s\n", sh.name);
+        const double wbytes = (double)sh.rows * sh.K * 4;
+        for (const Variant& v : vs) {
+            const int P = v.P;
+            const size_t slab = (size_t)PMAX * 32000;
+            CK(hipMemsetAsync(O, 0xff, (size_t)v.ks * slab * 4, st));
+            hipLaunchKernelGGL(tile_rows_kernel, dim3(4, P), dim3(256), 0, st, XT, X, P, sh.K);
+            v.fn(st, W[0], XT, O, slab, sh.K, sh.rows, P, cus, v.ks);
+            double maxerr = -1.0;
+            if (v.check) {
+                hipLaunchKernelGGL(ref_gemm, dim3((sh.rows + 255) / 256, P), dim3(256), 0, st, W[0], X, Oref, sh.K, sh.rows, P);
+                CK(hipStreamSynchronize(st));
+                const size_t nt = tile_floats(P, sh.rows);
+                std::vector<float> a(nt * v.ks), b((size_t)P * sh.rows);
+                for (int k = 0; k < v.ks; k++) CK(hipMemcpy(a.data() + k * nt, O + k * slab, nt * 4, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(b.data(), Oref, b.size() * 4, hipMemcpyDeviceToHost));
+                maxerr = 0.0;
+                for (int t = 0; t < P; t++)
+                    for (int r = 0; r < sh.rows; r++) {
+                        float sum = 0.0f;
+                        for (int k = 0; k < v.ks; k++) sum += a[k * nt + tile_idx(t, r, sh.rows)];
+                        double e = std::fabs((double)sum - (double)b[(size_t)t * sh.rows + r]);
+                        if (!(e <= maxerr)) maxerr = e;
+                    }
+            }
+            CK(hipStreamSynchronize(st));
+            if (hipGetLastError() != hipSuccess) { printf("  %s launch failed\n", v.name); continue; }
+            float best = 1e30f;
+            for (int rep = 0; rep < 3; rep++) {
+                CK(hipEventRecord(e0, st));
+                for (int i = 0; i < iters; i++) v.fn(st, W[i % nbuf], XT, O, slab, sh.K, sh.rows, P, cus, v.ks);
+                CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                best = std::min(best, ms / iters);
+            }
+            printf("  %s P=%2d  %8.1f us  %6.0f GB/s weights  %6.1f TFLOP/s  maxerr %.2e\n", v.name, P, best * 1e3,
+                   wbytes / (best * 1e-3) / 1e9, 2.0 * sh.rows * sh.K * P / (best * 1e-3) / 1e12, maxerr);
+        }
+    }
+    return 0;
+}
