@@ -249,11 +249,20 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *                   (default) turns it on for dim <= 1024 only: measured +4.2 % / +7.7 % tokens/s at
  *                   the stories110M / stories15M shapes, +0.9 % short and -2.5 % at 1000-token
  *                   contexts at llama2-7B
+ *   "ref_order" = 0|1 : 1 computes every op in the REFERENCE'S OWN rounding order (csrc/ref_order.hpp: 4-lane
+ *                   sequential matvec sums with separate multiply and add, sequential rmsnorm / softmax
+ *                   sums, glibc's expf restated) so results can be compared with the reference CPU path
+ *                   bit for bit; ~8 ms per llama2-7B token.  Default 0: the fast path, which differs from
+ *                   the CPU path by the CPU path's own rounding error (1.5e-4 in llama2-7B logits)
  *   "persist" = 0|1 : 1 runs each chained decode step as ONE persistent launch (persist.hpp:
  *                   one resident workgroup per CU, phases separated by a counter barrier hidden
  *                   behind weight prefetch).  Same results; measured slower than the launch
  *                   path in round 1 (170 vs 235 tok/s at llama2-7B), so it is off by default. */
 int  rama_set_tuning(rama_ctx *ctx, const char *key, int value);
+
+/* glibc 2.35 expf (the exp the reference's f32::exp calls on Linux) as the reference-order kernels
+ * evaluate it, elementwise: the bit-exactness test's handle on it */
+int  rama_ref_expf(rama_ctx *ctx, float *o, const float *x, size_t n);
 
 /* diagnostic (not a product path): one persistent decode step with 100 MHz timestamps of workgroup
  * `wg`, 8 slots per phase (0 start, 1 activations staged, 2 steps done, 3 arrived, 4 barrier passed) */

@@ -71,6 +71,7 @@ def lib() -> C.CDLL:
     L.oracle_array_add.argtypes = [_f32p, _f32p, sz]
     L.oracle_array_mult.argtypes = [_f32p, _f32p, sz]
     L.oracle_sinu.argtypes = [_f32p, sz]
+    L.oracle_expf_array.argtypes = [_f32p, _f32p, sz]
     L.oracle_copy_from_slice.argtypes = [_f32p, _f32p, sz]
     L.oracle_rmsnorm.argtypes = [_f32p, _f32p, _f32p, sz]
     L.oracle_apply_position.argtypes = [_f32p, _f32p, _f32p, _f32p, sz]
@@ -107,6 +108,14 @@ def _p(a: np.ndarray):
 def array_add(target, source, n): lib().oracle_array_add(_p(target), _p(source), n)
 def array_mult(target, source, n): lib().oracle_array_mult(_p(target), _p(source), n)
 def sinu(o, n): lib().oracle_sinu(_p(o), n)
+
+
+def expf(x: np.ndarray) -> np.ndarray:
+    out = np.empty_like(x)
+    lib().oracle_expf_array(_p(out), _p(x), x.size)
+    return out
+
+
 def copy_from_slice(target, source, n): lib().oracle_copy_from_slice(_p(target), _p(source), n)
 def rmsnorm(o, x, weight, n): lib().oracle_rmsnorm(_p(o), _p(x), _p(weight), n)
 def softmax(x, n): lib().oracle_softmax(_p(x), n)

@@ -59,6 +59,12 @@ void oracle_copy_from_slice(float *target, const float *source, size_t n) {
     memmove(target, source, n * sizeof(float));
 }
 
+/* the libm exp the restatement (and, through Rust's f32::exp, the reference) evaluates,
+ * elementwise: lets the tests pin the HIP reference-order kernels' expf to it bit for bit */
+void oracle_expf_array(float *o, const float *x, size_t n) {
+    for (size_t i = 0; i < n; i++) o[i] = expf(x[i]);
+}
+
 /* cpu.rs:99-117: v = 1/sqrt(sum(x*x)/len + 1e-5); o[i] = weight[i] * (v * x[i]) */
 void oracle_rmsnorm(float *o, const float *x, const float *weight, size_t n) {
     float ss = 0.0f;

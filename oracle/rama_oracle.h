@@ -77,6 +77,7 @@ int  oracle_get_threads(void);
 /* ---- Device<Vec<f32>> for CPU, engine/src/device/cpu.rs ---- */
 void oracle_array_add(float *target, const float *source, size_t n);          /* cpu.rs:16-21 */
 void oracle_array_mult(float *target, const float *source, size_t n);         /* cpu.rs:59-64 */
+void oracle_expf_array(float *o, const float *x, size_t n);                        /* libm expf = Rust f32::exp on Linux */
 void oracle_sinu(float *o, size_t n);                                          /* cpu.rs:54-57 */
 void oracle_copy_from_slice(float *target, const float *source, size_t n);    /* cpu.rs:66-72 */
 void oracle_rmsnorm(float *o, const float *x, const float *weight, size_t n); /* cpu.rs:99-117 */

@@ -4,6 +4,7 @@
 #include "kernels.hpp"
 #include "persist.hpp"
 #include "prefill_mfma.hpp"
+#include "ref_order.hpp"
 #include <hipcub/hipcub.hpp>
 
 #include <hip/hip_ext.h>   // hipExtLaunchKernelGGL: start/stop events carried by the dispatch itself
@@ -75,6 +76,7 @@ struct rama_ctx {
     hipEvent_t cur_start = nullptr, cur_stop = nullptr;   // events the next profiled launch carries
     int tune_geom = 3;
     int tune_persist = 0;                  // 1: decode steps run as one persistent launch (persist.hpp)
+    int tune_ref_order = 0;                // 1: every op in the reference's own rounding order (ref_order.hpp): bit-comparable, slow
     // device top-p sampler (Device::sample for temperature != 0); temperature 0 = argmax
     float samp_T = 0.0f, samp_topp = 0.9f, samp_u = 0.0f;
     float* topp_keys[2] = {nullptr, nullptr}; int* topp_vals[2] = {nullptr, nullptr};
@@ -303,6 +305,39 @@ static int launch_rows(rama_ctx* c, float* o, const float* W, const float* x, co
     return 0;
 }
 
+// ---------------------------------------------------------------- reference-order launches (ref_order.hpp)
+
+static int launch_matvec_ref(rama_ctx* c, int nmat, float* const o[3], const float* const W[3], const float* x, int K, int rows) {
+    REQUIRE(K % 4 == 0 && K > 0 && rows > 0, RAMA_EINVAL, "matmul: width % 4 != 0 (the reference CPU body panics here, cpu.rs:142-143)");
+    RefMatParams p{};
+    for (int m = 0; m < nmat; m++) { p.w[m] = W[m]; p.o[m] = o[m]; }
+    p.x = x; p.K = K; p.rows = rows;
+    hipLaunchKernelGGL(matvec_ref_kernel, dim3((rows + 63) / 64, nmat), dim3(64), 0, c->stream, p);
+    LAUNCHCHK();
+    return 0;
+}
+static int launch_matvec_ref1(rama_ctx* c, float* o, const float* W, const float* x, int K, int rows) {
+    float* const oo[3] = {o, nullptr, nullptr};
+    const float* const ww[3] = {W, nullptr, nullptr};
+    return launch_matvec_ref(c, 1, oo, ww, x, K, rows);
+}
+static int launch_rmsnorm_ref(rama_ctx* c, float* o, const float* x, const float* w, int n) {
+    REQUIRE((size_t)n * sizeof(float) <= 64 * 1024, RAMA_EUNSUP, "rmsnorm (reference order): vector longer than 16384");
+    hipLaunchKernelGGL(rmsnorm_ref_kernel, dim3(1), dim3(1024), (size_t)n * sizeof(float), c->stream, o, x, w, n);
+    LAUNCHCHK();
+    return 0;
+}
+static int launch_attention_ref(rama_ctx* c, float* xb, float* att, const float* q, const float* kc_layer, const float* vc_layer,
+                                const Ctl* ctl, int pos, int dim, int head_size, int seq_len, int n_heads) {
+    REQUIRE((size_t)seq_len * sizeof(float) <= 64 * 1024, RAMA_EUNSUP, "attention (reference order): seq_len longer than 16384");
+    RefAttnParams p{};
+    p.q = q; p.kc = kc_layer; p.vc = vc_layer; p.att = att; p.xb = xb; p.ctl = ctl; p.pos_val = pos;
+    p.dim = dim; p.head_size = head_size; p.seq_len = seq_len;
+    hipLaunchKernelGGL(attention_ref_kernel, dim3(n_heads), dim3(1024), (size_t)seq_len * sizeof(float), c->stream, p);
+    LAUNCHCHK();
+    return 0;
+}
+
 // ---------------------------------------------------------------- Device<T> ops, 1:1
 
 int rama_array_add(rama_ctx* c, float* t, const float* s, size_t n) {
@@ -320,7 +355,8 @@ int rama_array_mult(rama_ctx* c, float* t, const float* s, size_t n) {
 int rama_sinu(rama_ctx* c, float* o, size_t n) {
     REQUIRE(c && (n == 0 || o), RAMA_EINVAL, "sinu: NULL argument");
     if (!n) return 0;
-    hipLaunchKernelGGL(sinu_kernel, dim3(ew_grid(n)), dim3(256), 0, c->stream, o, n);
+    if (c->tune_ref_order) hipLaunchKernelGGL(sinu_ref_kernel, dim3(ew_grid(n)), dim3(256), 0, c->stream, o, n);
+    else hipLaunchKernelGGL(sinu_kernel, dim3(ew_grid(n)), dim3(256), 0, c->stream, o, n);
     LAUNCHCHK(); return 0;
 }
 int rama_copy_from_slice(rama_ctx* c, float* t, const float* s, size_t n) {
@@ -331,12 +367,18 @@ int rama_copy_from_slice(rama_ctx* c, float* t, const float* s, size_t n) {
 }
 int rama_rmsnorm(rama_ctx* c, float* o, const float* x, const float* w, size_t n) {
     REQUIRE(c && o && x && w && n > 0, RAMA_EINVAL, "rmsnorm: bad argument");
+    if (c->tune_ref_order) return launch_rmsnorm_ref(c, o, x, w, (int)n);
     hipLaunchKernelGGL(rmsnorm_kernel, dim3(1), dim3(1024), 0, c->stream, o, x, w, (int)n);
     LAUNCHCHK(); return 0;
 }
 int rama_apply_position(rama_ctx* c, float* q, float* k, const float* pr, const float* pi, size_t head_size) {
     REQUIRE(c && q && k && pr && pi && head_size >= 2, RAMA_EINVAL, "apply_position: bad argument");
     int n = (int)(head_size / 2);
+    if (c->tune_ref_order) {
+        hipLaunchKernelGGL(rope_ref_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, q, k, (const float*)nullptr, pr, pi, (int)head_size, (int)head_size,
+                           (float*)nullptr, (float*)nullptr);
+        LAUNCHCHK(); return 0;
+    }
     hipLaunchKernelGGL(apply_position_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, q, k, pr, pi, (int)head_size);
     LAUNCHCHK(); return 0;
 }
@@ -345,6 +387,7 @@ int rama_matmul(rama_ctx* c, float* o, const float* a, const float* b, size_t wi
     REQUIRE(o_cols >= 1, RAMA_EINVAL, "matmul: o_cols == 0");
     int rc = check_matvec_shape(width, o_rows);
     if (rc) return rc;
+    if (c->tune_ref_order && o_cols == 1) return launch_matvec_ref1(c, o, a, b, (int)width, (int)o_rows);
     if (o_cols != 1) {   // forward() never takes this path (o_cols is always 1, infer.rs:20-51)
         size_t n = o_rows * o_cols;
         hipLaunchKernelGGL(matmul_generic, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, o, a, b, (int)width, (int)o_rows, (int)o_cols);
@@ -358,6 +401,7 @@ int rama_matmul(rama_ctx* c, float* o, const float* a, const float* b, size_t wi
 }
 int rama_softmax(rama_ctx* c, float* x, size_t n) {
     REQUIRE(c && x && n > 0, RAMA_EINVAL, "softmax: bad argument");
+    if (c->tune_ref_order) { hipLaunchKernelGGL(softmax_ref_kernel, dim3(1), dim3(1024), 0, c->stream, x, (int)n); LAUNCHCHK(); return 0; }
     hipLaunchKernelGGL(softmax_kernel, dim3(1), dim3(1024), 0, c->stream, x, (int)n);
     LAUNCHCHK(); return 0;
 }
@@ -429,6 +473,7 @@ int rama_multi_head_attention(rama_ctx* c, float* xb, float* att, const float* q
     REQUIRE(c && xb && att && q && key_cache && value_cache, RAMA_EINVAL, "multi_head_attention: NULL argument");
     REQUIRE(pos >= 0 && pos < seq_len && layer >= 0 && n_heads > 0 && n_heads * head_size == dim, RAMA_EINVAL, "multi_head_attention: bad shape");
     const size_t lo = (size_t)layer * seq_len * dim;   // cpu.rs:28
+    if (c->tune_ref_order) return launch_attention_ref(c, xb, att, q, key_cache + lo, value_cache + lo, nullptr, pos, dim, head_size, seq_len, n_heads);
     return launch_attention(c, xb, att, q, key_cache + lo, value_cache + lo, nullptr, pos, dim, head_size, seq_len, n_heads);
 }
 
@@ -457,6 +502,13 @@ int rama_sample_topp(rama_ctx* c, const float* logits, size_t n, float temperatu
     REQUIRE(c->pinned_int[0] >= 0, RAMA_EINVAL, "sample_topp: no candidate above the cutoff (the reference underflows here)");
     *next_host = c->pinned_int[0];
     return 0;
+}
+
+int rama_ref_expf(rama_ctx* c, float* o, const float* x, size_t n) {
+    REQUIRE(c && (n == 0 || (o && x)), RAMA_EINVAL, "ref_expf: NULL argument");
+    if (!n) return 0;
+    hipLaunchKernelGGL(expf_glibc_kernel, dim3(ew_grid(n)), dim3(256), 0, c->stream, o, x, n);
+    LAUNCHCHK(); return 0;
 }
 
 // ---------------------------------------------------------------- synthetic fill
@@ -519,9 +571,61 @@ static int try_launch_attn_wo(rama_ctx* c, const rama_config* cfg, const rama_we
     return 0;
 }
 
+// infer.rs:8-53 op by op in the reference's rounding order (ref_order.hpp); leaves EVERY RunState
+// buffer as the CPU path does (x, xb, xb2, hb, hb2, q, k, v, att, logits, caches)
+static int enqueue_stage_ref(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s, const rama_stage* st) {
+    const int dim = cfg->dim, hidden = cfg->hidden_dim, hs = dim / cfg->n_heads;
+    const size_t dd = (size_t)dim * dim, hd = (size_t)hidden * dim;
+    int rc;
+    REQUIRE(s->xb2 && s->hb2 && s->k && s->v, RAMA_EINVAL, "forward (reference order): xb2 / hb2 / k / v buffers are required");
+    if (st->do_embed) {
+        hipLaunchKernelGGL(embed_kernel, dim3((dim + 255) / 256), dim3(256), 0, c->stream, s->x, w->token_embedding_table, (const Ctl*)c->ctl, 0, dim);
+        LAUNCHCHK();
+    }
+    for (int layer = st->layer_begin; layer < st->layer_end; layer++) {
+        const size_t li = (size_t)(layer - st->layer_begin);
+        float* kc = s->key_cache + li * cfg->seq_len * dim;
+        float* vc = s->value_cache + li * cfg->seq_len * dim;
+        rc = launch_rmsnorm_ref(c, s->xb, s->x, w->rms_att_weight + li * dim, dim); if (rc) return rc;          // infer.rs:19
+        {   // :20-23
+            float* const oo[3] = {s->q, s->k, s->v};
+            const float* const ww[3] = {w->wq + li * dd, w->wk + li * dd, w->wv + li * dd};
+            rc = launch_matvec_ref(c, 3, oo, ww, s->xb, dim, dim); if (rc) return rc;
+        }
+        hipLaunchKernelGGL(rope_ref_cursor_kernel, dim3((dim / 2 + 255) / 256), dim3(256), 0, c->stream, s->q, s->k, (const float*)s->v,
+                           w->freq_cis_real, w->freq_cis_imag, dim, hs, kc, vc, (const Ctl*)c->ctl);                                // :25-33
+        LAUNCHCHK();
+        rc = launch_attention_ref(c, s->xb, s->att, s->q, kc, vc, c->ctl, 0, dim, hs, cfg->seq_len, cfg->n_heads); if (rc) return rc;   // :34
+        rc = launch_matvec_ref1(c, s->xb2, w->wo + li * dd, s->xb, dim, dim); if (rc) return rc;                  // :35
+        hipLaunchKernelGGL(array_add_kernel, dim3(ew_grid(dim)), dim3(256), 0, c->stream, s->x, (const float*)s->xb2, (size_t)dim);   // :37
+        LAUNCHCHK();
+        rc = launch_rmsnorm_ref(c, s->xb, s->x, w->rms_ffn_weight + li * dim, dim); if (rc) return rc;            // :39
+        {   // :41-42
+            float* const oo[3] = {s->hb, s->hb2, nullptr};
+            const float* const ww[3] = {w->w1 + li * hd, w->w3 + li * hd, nullptr};
+            rc = launch_matvec_ref(c, 2, oo, ww, s->xb, dim, hidden); if (rc) return rc;
+        }
+        hipLaunchKernelGGL(sinu_ref_kernel, dim3(ew_grid(hidden)), dim3(256), 0, c->stream, s->hb, (size_t)hidden);                  // :44
+        LAUNCHCHK();
+        hipLaunchKernelGGL(array_mult_kernel, dim3(ew_grid(hidden)), dim3(256), 0, c->stream, s->hb, (const float*)s->hb2, (size_t)hidden);   // :45
+        LAUNCHCHK();
+        rc = launch_matvec_ref1(c, s->xb, w->w2 + li * hd, s->hb, hidden, dim); if (rc) return rc;                // :46
+        hipLaunchKernelGGL(array_add_kernel, dim3(ew_grid(dim)), dim3(256), 0, c->stream, s->x, (const float*)s->xb, (size_t)dim);    // :47
+        LAUNCHCHK();
+    }
+    if (st->do_cls) {
+        hipLaunchKernelGGL(copy_kernel, dim3(ew_grid(dim)), dim3(256), 0, c->stream, s->xb, (const float*)s->x, (size_t)dim);         // :49
+        LAUNCHCHK();
+        rc = launch_rmsnorm_ref(c, s->x, s->xb, w->rms_final_weight, dim); if (rc) return rc;                     // :50
+        rc = launch_matvec_ref1(c, s->logits, w->wcls, s->x, dim, cfg->vocab_size); if (rc) return rc;            // :51
+    }
+    return 0;
+}
+
 // one (token, pos) step over a layer range; ctl on the device holds token/pos
 static int enqueue_stage(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s,
                          const rama_stage* st) {
+    if (c->tune_ref_order) return enqueue_stage_ref(c, cfg, w, s, st);
     const int dim = cfg->dim, hidden = cfg->hidden_dim, hs = dim / cfg->n_heads;
     const size_t dd = (size_t)dim * dim, hd = (size_t)hidden * dim;
     if (st->do_embed) {
@@ -841,8 +945,8 @@ int rama_prefill(rama_ctx* c, const rama_config* cfg, const rama_weights* w, ram
     if (set_device(c)) return 1;
     const int dim = cfg->dim;
     const size_t att_floats = (size_t)attn_scratch_floats((dim / cfg->n_heads) <= 64 ? 16 : ((dim / cfg->n_heads) <= 128 ? 32 : 64)) + cfg->seq_len;
-    if (!mf_shape_ok(cfg) || att_floats * sizeof(float) > 64 * 1024) {
-        // widths that are not whole 16-float blocks, or contexts the one-workgroup attention cannot
+    if (c->tune_ref_order || !mf_shape_ok(cfg) || att_floats * sizeof(float) > 64 * 1024) {
+        // reference-order mode; widths that are not whole 16-float blocks, or contexts the one-workgroup attention cannot
         // hold: the reference's own schedule, one forward() per forced token (mod.rs:187-194)
         for (int i = 0; i < n_tokens; i++) { rc = rama_forward(c, cfg, w, s, tokens_host[i], pos0 + i); if (rc) return rc; }
         return 0;
@@ -890,7 +994,7 @@ int rama_decode_batch(rama_ctx* c, const rama_config* cfg, const rama_weights* w
     }
     const int dim = cfg->dim, V = cfg->vocab_size;
     const size_t att_floats = (size_t)attn_scratch_floats((dim / cfg->n_heads) <= 64 ? 16 : ((dim / cfg->n_heads) <= 128 ? 32 : 64)) + cfg->seq_len;
-    if (!mf_shape_ok(cfg) || V % 4 != 0 || att_floats * sizeof(float) > 64 * 1024) {   // see rama_prefill: one forward() per sequence
+    if (c->tune_ref_order || !mf_shape_ok(cfg) || V % 4 != 0 || att_floats * sizeof(float) > 64 * 1024) {   // see rama_prefill: one forward() per sequence
         for (int i = 0; i < n_seq; i++) {
             rama_run_state si = states[i];
             rc = rama_forward(c, cfg, w, &si, tokens_host[i], pos_host[i]); if (rc) return rc;
@@ -981,7 +1085,7 @@ static int enqueue_decode_step_persistent(rama_ctx* c, const rama_config* cfg, c
 
 static int enqueue_decode_step(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s) {
     // the single-launch step has the argmax built in: any other sampler takes the launch path
-    if (c->tune_persist && c->kp.kernel_id < 0 && c->samp_T == 0.0f) return enqueue_decode_step_persistent(c, cfg, w, s);
+    if (c->tune_persist && !c->tune_ref_order && c->kp.kernel_id < 0 && c->samp_T == 0.0f) return enqueue_decode_step_persistent(c, cfg, w, s);
     rama_stage st{0, cfg->n_layers, 0, 1};
     int rc = enqueue_stage(c, cfg, w, s, &st);
     if (rc) return rc;
@@ -1141,6 +1245,13 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
     if (!strcmp(key, "merge")) {
         REQUIRE(value >= -1 && value <= 1, RAMA_EINVAL, "set_tuning: merge must be -1, 0 or 1");
         c->tune_merge = value;
+        hipStreamSynchronize(c->stream);
+        drop_graph(c);
+        return 0;
+    }
+    if (!strcmp(key, "ref_order")) {
+        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: ref_order must be 0 or 1");
+        c->tune_ref_order = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
         return 0;

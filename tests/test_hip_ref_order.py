@@ -1,0 +1,208 @@
+"""-m gpu: the reference-order mode (rama_set_tuning "ref_order" = 1, csrc/ref_order.hpp) must
+reproduce the CPU oracle BIT FOR BIT -- every Device<T> op, every RunState buffer of forward()
+(engine/src/transformer/infer.rs:8-53 over engine/src/device/cpu.rs), the generate() loop.
+
+This is the parity mode: the fast path sums dot products in a different order than the reference
+(a few 1e-5 .. 1.5e-4 apart at llama2-7B depth, all of it the reference's own rounding error, see
+tests/test_hip_parity_7b.py); this mode removes the order difference, so what remains is zero."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from oracle import synth as S
+
+from .helpers import CKPT_CASES, SYNTH_CASES, gpu_views, load_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import rama_amd
+    from rama_amd._lib import check
+    d = rama_amd.Hip(0)
+    check(d.lib.rama_set_tuning(d.ctx, b"ref_order", 1))
+    yield d
+    check(d.lib.rama_set_tuning(d.ctx, b"ref_order", 0))
+    d.close()
+
+
+def up(dev, a):
+    import rama_amd
+    return rama_amd.MutView(dev.allocate(a))
+
+
+def rnd(n, seed, scale=1.0):
+    return (np.random.default_rng(seed).standard_normal(n) * scale).astype(np.float32)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_bits_equal(got, want, what=""):
+    g, w = bits(got), bits(want)
+    if not np.array_equal(g, w):
+        bad = np.flatnonzero(g != w)
+        raise AssertionError(f"{what}: {bad.size} of {g.size} values differ, first at {bad[0]}: "
+                             f"{got.reshape(-1)[bad[0]]!r} vs {want.reshape(-1)[bad[0]]!r}")
+
+
+# ------------------------------------------------------------------ expf
+
+def test_expf_matches_libm_bit_for_bit(dev):
+    """glibc's expf restated in double on the device (ref_order.hpp) against the host libm the
+    oracle -- and Rust's f32::exp -- call: every input class the decode path produces (softmax
+    arguments <= 0 down to underflow, SiLU arguments of either sign) plus the edges"""
+    from rama_amd._lib import check
+    rng = np.random.default_rng(0)
+    parts = [
+        rng.uniform(-110.0, 0.0, 2_000_000), rng.uniform(-20.0, 20.0, 2_000_000), rng.uniform(-1e-3, 1e-3, 200_000),
+        rng.uniform(80.0, 95.0, 100_000), rng.uniform(-105.0, -85.0, 200_000),
+        np.array([0.0, -0.0, 1.0, -1.0, 88.72283, 88.72284, 88.7229, -87.33654, -87.33655, -103.97207, -103.97208, -103.9721,
+                  np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1e38, -1e38, 88.0, -88.0, 87.99999, -87.99999]),
+        np.linspace(-104.0, 89.0, 1_000_003),
+    ]
+    x = np.concatenate(parts).astype(np.float32)
+    want = O.expf(x)
+    tx = up(dev, x); to = up(dev, np.zeros_like(x))
+    check(dev.lib.rama_ref_expf(dev.ctx, to.ptr, tx.ptr, x.size))
+    got = dev.download(to)
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(got), nan)
+    assert_bits_equal(got[~nan], want[~nan], "expf")
+
+
+# ------------------------------------------------------------------ ops
+
+@pytest.mark.parametrize("rows,width", [(1, 4), (7, 8), (288, 288), (768, 288), (333, 772), (4096, 4096), (64, 11008), (1000, 4100)])
+def test_matmul_bit_exact(dev, rows, width):
+    w, x = rnd(rows * width, rows + width, 0.05), rnd(width, 5, 1.5)
+    want = np.empty(rows, np.float32)
+    O.matmul(want, w, x, width, rows)
+    tw = up(dev, w); tx = up(dev, x); to = up(dev, np.zeros(rows, np.float32))
+    dev.matmul(to, tw.as_view(), tx.as_view(), width, rows, 1)
+    assert_bits_equal(dev.download(to), want, "matmul")
+
+
+def test_matmul_unaligned_view_bit_exact(dev):
+    import rama_amd
+    rows, width = 50, 64
+    w, x = rnd(rows * width + 3, 1, 0.1), rnd(width + 1, 2)
+    want = np.empty(rows, np.float32)
+    O.matmul(want, np.ascontiguousarray(w[3:]), np.ascontiguousarray(x[1:]), width, rows)
+    sw = dev.allocate(w); sx = dev.allocate(x); to = up(dev, np.zeros(rows, np.float32))
+    dev.matmul(to, rama_amd.View(sw).slice(3), rama_amd.View(sx).slice(1), width, rows, 1)
+    assert_bits_equal(dev.download(to), want, "matmul (unaligned view)")
+
+
+@pytest.mark.parametrize("n", [4, 288, 768, 4096])
+def test_rmsnorm_sinu_softmax_bit_exact(dev, n):
+    x, w = rnd(n, n, 2.0), rnd(n, n + 1)
+    want = np.empty(n, np.float32)
+    O.rmsnorm(want, x, w, n)
+    tx = up(dev, x); tw = up(dev, w); to = up(dev, np.zeros(n, np.float32))
+    dev.rmsnorm(to, tx.as_view(), tw.as_view(), n)
+    assert_bits_equal(dev.download(to), want, "rmsnorm")
+    a = rnd(n, n + 2, 4.0)
+    ta = up(dev, a)
+    dev.sinu(ta, n)
+    O.sinu(a, n)
+    assert_bits_equal(dev.download(ta), a, "sinu")
+    s = rnd(n, n + 3, 6.0)
+    ts = up(dev, s)
+    dev.softmax(ts, n)
+    O.softmax(s, n)
+    assert_bits_equal(dev.download(ts), s, "softmax")
+
+
+@pytest.mark.parametrize("hs", [4, 48, 64, 128])
+def test_apply_position_bit_exact(dev, hs):
+    q, k = rnd(hs, 1), rnd(hs, 2)
+    pr, pi = rnd(hs // 2, 3), rnd(hs // 2, 4)
+    tq = up(dev, q); tk = up(dev, k); tr = up(dev, pr); ti = up(dev, pi)
+    dev.apply_position(tq, tk, tr.as_view(), ti.as_view(), hs)
+    O.apply_position(q, k, pr, pi, hs)
+    assert_bits_equal(dev.download(tq), q, "rope q")
+    assert_bits_equal(dev.download(tk), k, "rope k")
+
+
+@pytest.mark.parametrize("n_heads,hs,seq_len,positions", [(4, 16, 32, [0, 1, 31]), (6, 48, 256, [0, 17, 255]), (2, 128, 300, [0, 64, 299])])
+def test_multi_head_attention_bit_exact(dev, n_heads, hs, seq_len, positions):
+    import rama_amd
+    dim, L = n_heads * hs, 2
+    cfg = O.Config(dim, 4 * dim, L, n_heads, n_heads, 8, seq_len, True)
+    rcfg = rama_amd.Config(dim, 4 * dim, L, n_heads, n_heads, 8, seq_len, True)
+    z1 = np.zeros(1, np.float32)
+    orc = O.Oracle(cfg, dict(token_embedding_table=np.zeros((8, dim), np.float32), rms_att_weight=np.zeros((L, dim), np.float32),
+                             rms_ffn_weight=np.zeros((L, dim), np.float32), wq=z1, wk=z1, wv=z1, wo=z1, w1=z1, w2=z1, w3=z1,
+                             rms_final_weight=np.zeros(dim, np.float32), freq_cis_real=z1, freq_cis_imag=z1))
+    kc = rnd(L * seq_len * dim, 20); vc = rnd(L * seq_len * dim, 21); q = rnd(dim, 22, 2.0)
+    rs = rama_amd.RunState.from_config(rcfg, dev); rsv = rama_amd.RunStateView.from_rs(rs)
+    dev.upload_into(rsv.key_cache, kc); dev.upload_into(rsv.value_cache, vc); dev.upload_into(rsv.q, q)
+    for layer in (0, 1):
+        for pos in positions:
+            orc.s["key_cache"][:] = kc; orc.s["value_cache"][:] = vc; orc.s["q"][:] = q
+            orc.multi_head_attention(layer, pos)
+            dev.multi_head_attention(rsv, rcfg, layer, pos)
+            assert_bits_equal(dev.download(rsv.xb), orc.s["xb"], f"xb layer {layer} pos {pos}")
+            att = dev.download(rsv.att).reshape(n_heads, seq_len)[:, :pos + 1]
+            assert_bits_equal(att, orc.s["att"].reshape(n_heads, seq_len)[:, :pos + 1], f"att layer {layer} pos {pos}")
+    rs.free()
+
+
+# ------------------------------------------------------------------ forward(): every RunState buffer
+
+STATE_BUFS = ("x", "xb", "xb2", "hb", "hb2", "q", "k", "v", "logits", "key_cache", "value_cache")
+
+
+@pytest.mark.parametrize("name", CKPT_CASES + SYNTH_CASES)
+def test_forward_every_buffer_bit_exact(dev, name):
+    """the fused entry (rama_forward) and the 1:1 trait-op composition, both in reference order,
+    leave the oracle's RunState bit for bit at every position of the fixture"""
+    import rama_amd
+    cfg, w, g = load_case(name)
+    toks = g["tokens"].tolist()[:10]
+    orc = O.Oracle(cfg, w)
+    rcfg, ws, wv, rs, rsv = gpu_views(dev, cfg, w)
+    rs2 = rama_amd.RunState.from_config(rcfg, dev); rsv2 = rama_amd.RunStateView.from_rs(rs2)
+    for pos, t in enumerate(toks):
+        orc.forward(t, pos)
+        rama_amd.forward_fused(rcfg, wv, rsv, t, pos, dev)
+        rama_amd.forward(rcfg, wv, rsv2, t, pos, dev)
+        for buf in STATE_BUFS:
+            assert_bits_equal(dev.download(getattr(rsv, buf)), orc.s[buf], f"{name} fused pos {pos} {buf}")
+            assert_bits_equal(dev.download(getattr(rsv2, buf)), orc.s[buf], f"{name} ops pos {pos} {buf}")
+        att = dev.download(rsv.att).reshape(cfg.n_heads, cfg.seq_len)[:, :pos + 1]
+        assert_bits_equal(att, orc.s["att"].reshape(cfg.n_heads, cfg.seq_len)[:, :pos + 1], f"{name} pos {pos} att")
+    rs.free(); rs2.free(); ws.free()
+
+
+@pytest.mark.parametrize("shape", ["stories15M", "stories110M", "llama2-7B-2layers"])
+def test_full_shape_logits_bit_exact(dev, shape):
+    """BASELINE shapes at full width and vocabulary: logits of the generate() loop on 'once upon a
+    time' identical to the oracle's, bit for bit, device-chained greedy tokens identical"""
+    import rama_amd
+    from .helpers import to_rama_cfg
+    shapes = {"stories15M": (288, 768, 6, 6, 32000, 256, True), "stories110M": (768, 2048, 12, 12, 32000, 1024, True),
+              "llama2-7B-2layers": (4096, 11008, 2, 32, 32000, 2048, False)}
+    d, h, L, H, V, seq, shared = shapes[shape]
+    cfg = O.Config(d, h, L, H, H, V, seq, shared)
+    rope = S.rope_tables(seq, d // H)
+    w = S.synth_weights(cfg, 0, rope=rope)
+    orc = O.Oracle(cfg, w)
+    model = rama_amd.Model.synth(dev, to_rama_cfg(cfg), 0, rope=rope)
+    eng = rama_amd.Engine(dev, model)
+    prompt = [10646, 2501, 263, 931]
+    steps = 12 if d < 4096 else 6
+    token = 1
+    for pos in range(steps):
+        lo = orc.forward(token, pos)
+        eng.forward(token, pos)
+        assert_bits_equal(eng.logits(), lo, f"{shape} pos {pos}")
+        token = prompt[pos] if pos < len(prompt) else O.argmax(lo)
+    eng2 = rama_amd.Engine(dev, model)
+    assert eng2.generate_greedy(prompt, steps) == O.Oracle(cfg, w).generate_greedy(prompt, steps)
+    eng.free(); eng2.free(); model.free()
