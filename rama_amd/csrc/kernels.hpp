@@ -413,16 +413,19 @@ __device__ __forceinline__ size_t attn_tile_idx(int tk, int k, int K) {      // 
 
 constexpr int kAttnWaves = 16;
 constexpr int kAttnThreads = kAttnWaves * 64;
-// LDS floats: [2 * kAttnWaves] max / sum, [kAttnWaves * G * 4] partial outputs, [seq_len] scores
-__host__ __device__ constexpr int attn_scratch_floats(int G) { return 2 * kAttnWaves + kAttnWaves * G * 4; }
+// LDS floats: [2 * W] max / sum, [W * G * 4] partial outputs, [seq_len] scores (W waves, default 16)
+__host__ __device__ constexpr int attn_scratch_floats(int G, int W = kAttnWaves) { return 2 * W + W * G * 4; }
 
-template <int G, bool SPLIT>
-__global__ __launch_bounds__(kAttnThreads) void attention_kernel(AttnParams p) {
+// W = 4: the token-batch passes' short contexts (a few dozen timesteps per query, thousands of
+// (head, query) workgroups): a round of 4 waves already covers 64 timesteps, and 8 such workgroups fit a CU
+template <int G, bool SPLIT, int W = kAttnWaves>
+__global__ __launch_bounds__(W * 64) void attention_kernel(AttnParams p) {
+    constexpr int kAttnWaves = W, kAttnThreads = W * 64;       // shadow the 16-wave defaults
     extern __shared__ float sm[];
     float* s_max = sm;
     float* s_sum = sm + kAttnWaves;
     float* s_acc = sm + 2 * kAttnWaves;
-    float* s_att = sm + attn_scratch_floats(G);
+    float* s_att = sm + attn_scratch_floats(G, W);
     constexpr int U = 8;
     constexpr int TPW = 64 / G;                       // timesteps per wave-instruction
     constexpr int TILE = kAttnWaves * TPW * U;        // timesteps per workgroup round

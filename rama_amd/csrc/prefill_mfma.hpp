@@ -308,19 +308,20 @@ __device__ __forceinline__ f4 fold_slabs(f4 x, const float* slabs, int nslab, si
     return x;
 }
 
-// cpu.rs:99-117 per token on the tile layout: o = w * (v * x), v = 1 / sqrt(sum x^2 / n + 1e-5),
-// after folding the pending K-slices of the previous product into the residual stream (written back).
-// One workgroup of 16 waves per 16-token tile; wave w sweeps blocks w, w + 16, ..: lane (token n,
-// k-slot kq) accumulates its token's squares, the 4 k-slot lanes and the 16 waves meet in LDS.
-__global__ __launch_bounds__(1024) void rmsnorm_tile_kernel(float* O, float* X, const float* w, int dim,
-                                                            const float* slabs, int nslab, size_t slab_floats) {
-    __shared__ float red[16][16];
-    __shared__ float s_v[16];
+// cpu.rs:99-117 per token on the tile layout, as two small launches over (token tile, column part)
+// workgroups so that the ~1 MB of activations is spread over 64 CUs instead of 4:
+//   rms_fold_kernel   x += pending K-slices (written back); partial sum x^2 per (part, token)
+//   rms_scale_kernel  v = 1 / sqrt(sum of the parts (fixed order) / n + 1e-5); o = w * (v * x)
+constexpr int kRmsParts = 16;
+
+__global__ __launch_bounds__(256) void rms_fold_kernel(float* X, float* ssp, int dim, const float* slabs, int nslab, size_t slab_floats) {
+    __shared__ float red[4][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nblk = dim >> 4;
+    const int nblk = dim >> 4, per = (nblk + kRmsParts - 1) / kRmsParts;
+    const int jb0 = blockIdx.y * per, jb1 = min(jb0 + per, nblk);
     const size_t tbase = (size_t)blockIdx.x * nblk * 256;
     float ss = 0.0f;
-    for (int jb = wave; jb < nblk; jb += 16) {
+    for (int jb = jb0 + wave; jb < jb1; jb += 4) {
         const size_t o = tbase + (size_t)jb * 256 + lane * 4;
         f4 x = *reinterpret_cast<const f4*>(X + o);
         if (nslab > 0) {
@@ -332,22 +333,31 @@ __global__ __launch_bounds__(1024) void rmsnorm_tile_kernel(float* O, float* X, 
     ss += __shfl_xor(ss, 16);
     ss += __shfl_xor(ss, 32);
     if (lane < 16) red[wave][lane] = ss;
-    __syncthreads();          // also orders this thread's X writes before its re-read below
+    __syncthreads();
+    if (tid < 16) ssp[((size_t)blockIdx.x * kRmsParts + blockIdx.y) * 16 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+__global__ __launch_bounds__(256) void rms_scale_kernel(float* O, const float* X, const float* w, const float* ssp, int dim) {
+    __shared__ float s_v[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nblk = dim >> 4, per = (nblk + kRmsParts - 1) / kRmsParts;
+    const int jb0 = blockIdx.y * per, jb1 = min(jb0 + per, nblk);
+    const size_t tbase = (size_t)blockIdx.x * nblk * 256;
     if (tid < 16) {
-        float t[16];
+        float t[kRmsParts];
 #pragma unroll
-        for (int q = 0; q < 16; q++) t[q] = red[q][tid];
+        for (int q = 0; q < kRmsParts; q++) t[q] = ssp[((size_t)blockIdx.x * kRmsParts + q) * 16 + tid];
 #pragma unroll
-        for (int n = 16; n > 1; n >>= 1)
+        for (int n = kRmsParts; n > 1; n >>= 1)
 #pragma unroll
             for (int q = 0; q < n / 2; q++) t[q] = t[2 * q] + t[2 * q + 1];
         s_v[tid] = rms_scale(t[0], dim);
     }
     __syncthreads();
     const float v = s_v[lane & 15];
-    for (int jb = wave; jb < nblk; jb += 16) {
+    for (int jb = jb0 + wave; jb < jb1; jb += 4) {
         const size_t o = tbase + (size_t)jb * 256 + lane * 4;
-        const f4 x = *reinterpret_cast<const f4*>(X + o);          // the same thread wrote it above
+        const f4 x = *reinterpret_cast<const f4*>(X + o);
         const f4 g = *reinterpret_cast<const f4*>(w + jb * 16 + (lane >> 4) * 4);
         f4 r;
         r.x = g.x * (v * x.x); r.y = g.y * (v * x.y); r.z = g.z * (v * x.z); r.w = g.w * (v * x.w);

@@ -847,12 +847,13 @@ static int mf_ksplit(const rama_ctx* c, int rows, int K) {
 // scratch of a pass (tile layout, kMfMaxTok tokens): X residual stream, XN its rmsnorm, Q, XB, HB
 // [hidden], SL = up to 4 K-slice slabs [dim]; then token ids, the sequence table, and (decode_batch)
 // row-major logits [kMfMaxTok, vocab]
-struct BatchScratch { float *X, *XN, *Q, *XB, *HB, *SL, *LG; size_t slab; int* toks; SeqSlot* seqs; };
+struct BatchScratch { float *X, *XN, *Q, *XB, *HB, *SL, *LG, *SSP; size_t slab; int* toks; SeqSlot* seqs; };
 
 static int ensure_batch_scratch(rama_ctx* c, const rama_config* cfg, bool with_logits, BatchScratch* b) {
     const size_t T = kMfMaxTok, dim = cfg->dim, hidden = cfg->hidden_dim;
     const size_t ints = 64 + (sizeof(SeqSlot) / sizeof(int)) * T;
-    const size_t need = T * (8 * dim + hidden) + ints + 64 + (with_logits ? T * (size_t)cfg->vocab_size : 0);
+    const size_t ssp = (T / 16) * kRmsParts * 16;        // partial sums of squares per (tile, part, token)
+    const size_t need = T * (8 * dim + hidden) + ssp + ints + 64 + (with_logits ? T * (size_t)cfg->vocab_size : 0);
     if (need > c->pf_floats) {
         if (c->pf_blob) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->pf_blob)); c->pf_blob = nullptr; }
         if (set_device(c)) return 1;
@@ -865,9 +866,19 @@ static int ensure_batch_scratch(rama_ctx* c, const rama_config* cfg, bool with_l
     b->slab = T * dim;
     b->X = c->pf_blob; b->XN = b->X + T * dim; b->Q = b->XN + T * dim; b->XB = b->Q + T * dim;
     b->SL = b->XB + T * dim; b->HB = b->SL + 4 * T * dim;
-    b->toks = reinterpret_cast<int*>(b->HB + T * hidden);
+    b->SSP = b->HB + T * hidden;
+    b->toks = reinterpret_cast<int*>(b->SSP + ssp);
     b->seqs = reinterpret_cast<SeqSlot*>(b->toks + 64);
     b->LG = reinterpret_cast<float*>(b->toks + ints + 64);      // ints is a multiple of 4: 16-byte aligned
+    return 0;
+}
+
+// b.XN = rmsnorm(b.X += the nslab pending K-slices in b.SL) * gain, per token (prefill_mfma.hpp)
+static int launch_rmsnorm_tile(rama_ctx* c, const BatchScratch& b, const float* gain, int dim, int ntile, int nslab) {
+    hipLaunchKernelGGL(rms_fold_kernel, dim3(ntile, kRmsParts), dim3(256), 0, c->stream, b.X, b.SSP, dim, (const float*)b.SL, nslab, b.slab);
+    LAUNCHCHK();
+    hipLaunchKernelGGL(rms_scale_kernel, dim3(ntile, kRmsParts), dim3(256), 0, c->stream, b.XN, (const float*)b.X, gain, (const float*)b.SSP, dim);
+    LAUNCHCHK();
     return 0;
 }
 
@@ -876,9 +887,10 @@ static bool mf_shape_ok(const rama_config* cfg) { return cfg->dim % 16 == 0 && c
 // nt <= kMfMaxTok tokens (already embedded in b.X, tile layout) through every layer.
 // seqs == false: consecutive positions p0.. of ONE sequence (its cache bases key_cache / value_cache);
 // seqs == true: token t belongs to independent sequence t (device table b.seqs).
+// tmax = the longest context any token of the pass attends to (timesteps): sizes the attention scratch.
 // On return the residual stream is b.X + the *nslab_out K-slices in b.SL (folded by the caller).
 static int run_layers_batched(rama_ctx* c, const rama_config* cfg, const rama_weights* w, const BatchScratch& b,
-                              int nt, int p0, float* key_cache, float* value_cache, bool seqs, int* nslab_out) {
+                              int nt, int p0, float* key_cache, float* value_cache, bool seqs, int tmax, int* nslab_out) {
     const int dim = cfg->dim, hidden = cfg->hidden_dim, hs = dim / cfg->n_heads;
     const size_t dd = (size_t)dim * dim, hd = (size_t)hidden * dim;
     const int ntile = (nt + 15) / 16, pt = ntile <= 1 ? 1 : (ntile == 2 ? 2 : 4);
@@ -891,9 +903,7 @@ static int run_layers_batched(rama_ctx* c, const rama_config* cfg, const rama_we
         MfParams p{};
         p.n_tok = nt; p.ksplit = 1; p.slab_floats = b.slab;
         // infer.rs:19 (+ the residual add of the previous layer's W2 product, :47)
-        hipLaunchKernelGGL(rmsnorm_tile_kernel, dim3(ntile), dim3(1024), 0, c->stream, b.XN, b.X, w->rms_att_weight + li * dim, dim,
-                           (const float*)b.SL, pending, b.slab);
-        LAUNCHCHK();
+        rc = launch_rmsnorm_tile(c, b, w->rms_att_weight + li * dim, dim, ntile, pending); if (rc) return rc;
         // infer.rs:20-33: Wq | Wk | Wv, RoPE, cache append
         p.w[0] = w->wq + li * dd; p.w[1] = w->wk + li * dd; p.w[2] = w->wv + li * dd;
         p.x = b.XN; p.o = b.Q; p.K = dim; p.rows = dim;
@@ -907,21 +917,27 @@ static int run_layers_batched(rama_ctx* c, const rama_config* cfg, const rama_we
             a.dim = dim; a.head_size = hs; a.seq_len = cfg->seq_len; a.tiled = 1;
             a.seqs = seqs ? b.seqs : nullptr; a.layer_off = layer_off;
             const int G = hs <= 64 ? 16 : (hs <= 128 ? 32 : 64);
-            size_t shm = (size_t)(attn_scratch_floats(G) + cfg->seq_len) * sizeof(float);
-            REQUIRE(shm <= 64 * 1024, RAMA_EUNSUP, "token batch: seq_len too long for the single-workgroup attention kernel");
             dim3 grid(cfg->n_heads, 1, nt);
-            if (G == 16) hipLaunchKernelGGL((attention_kernel<16, false>), grid, dim3(kAttnThreads), shm, c->stream, a);
-            else if (G == 32) hipLaunchKernelGGL((attention_kernel<32, false>), grid, dim3(kAttnThreads), shm, c->stream, a);
-            else hipLaunchKernelGGL((attention_kernel<64, false>), grid, dim3(kAttnThreads), shm, c->stream, a);
+            // scores scratch: tmax = the longest context of the pass (timesteps)
+            if (tmax <= 256) {      // short contexts: 4-wave workgroups, 8 of them per CU
+                size_t shm = (size_t)(attn_scratch_floats(G, 4) + tmax) * sizeof(float);
+                if (G == 16) hipLaunchKernelGGL((attention_kernel<16, false, 4>), grid, dim3(256), shm, c->stream, a);
+                else if (G == 32) hipLaunchKernelGGL((attention_kernel<32, false, 4>), grid, dim3(256), shm, c->stream, a);
+                else hipLaunchKernelGGL((attention_kernel<64, false, 4>), grid, dim3(256), shm, c->stream, a);
+            } else {
+                size_t shm = (size_t)(attn_scratch_floats(G) + tmax) * sizeof(float);
+                REQUIRE(shm <= 64 * 1024, RAMA_EUNSUP, "token batch: context too long for the single-workgroup attention kernel");
+                if (G == 16) hipLaunchKernelGGL((attention_kernel<16, false>), grid, dim3(kAttnThreads), shm, c->stream, a);
+                else if (G == 32) hipLaunchKernelGGL((attention_kernel<32, false>), grid, dim3(kAttnThreads), shm, c->stream, a);
+                else hipLaunchKernelGGL((attention_kernel<64, false>), grid, dim3(kAttnThreads), shm, c->stream, a);
+            }
             LAUNCHCHK();
         }
         // infer.rs:35: Wo . xb as K-slices; the residual add (:37) rides in the next rmsnorm
         p.w[0] = w->wo + li * dd; p.x = b.XB; p.o = b.SL; p.K = dim; p.rows = dim; p.ksplit = ks_wo;
         rc = launch_mf<2, EPI_STORE>(c, p, pt); if (rc) return rc;
         // infer.rs:37,39
-        hipLaunchKernelGGL(rmsnorm_tile_kernel, dim3(ntile), dim3(1024), 0, c->stream, b.XN, b.X, w->rms_ffn_weight + li * dim, dim,
-                           (const float*)b.SL, ks_wo, b.slab);
-        LAUNCHCHK();
+        rc = launch_rmsnorm_tile(c, b, w->rms_ffn_weight + li * dim, dim, ntile, ks_wo); if (rc) return rc;
         // infer.rs:41-45: W1 | W3, SiLU * gate
         p.w[0] = w->w1 + li * hd; p.w[1] = w->w3 + li * hd; p.x = b.XN; p.o = b.HB; p.K = dim; p.rows = hidden; p.ksplit = 1;
         rc = launch_mf<2, EPI_SWIGLU>(c, p, pt); if (rc) return rc;
@@ -944,7 +960,7 @@ int rama_prefill(rama_ctx* c, const rama_config* cfg, const rama_weights* w, ram
     for (int i = 0; i < n_tokens; i++) REQUIRE(tokens_host[i] >= 0 && tokens_host[i] < cfg->vocab_size, RAMA_EINVAL, "prefill: token outside the vocabulary");
     if (set_device(c)) return 1;
     const int dim = cfg->dim;
-    const size_t att_floats = (size_t)attn_scratch_floats((dim / cfg->n_heads) <= 64 ? 16 : ((dim / cfg->n_heads) <= 128 ? 32 : 64)) + cfg->seq_len;
+    const size_t att_floats = (size_t)attn_scratch_floats((dim / cfg->n_heads) <= 64 ? 16 : ((dim / cfg->n_heads) <= 128 ? 32 : 64)) + pos0 + n_tokens;
     if (c->tune_ref_order || !mf_shape_ok(cfg) || att_floats * sizeof(float) > 64 * 1024) {
         // reference-order mode; widths that are not whole 16-float blocks, or contexts the one-workgroup attention cannot
         // hold: the reference's own schedule, one forward() per forced token (mod.rs:187-194)
@@ -965,7 +981,7 @@ int rama_prefill(rama_ctx* c, const rama_config* cfg, const rama_weights* w, ram
         HIPCHK(hipMemcpyAsync(b.toks, c->pinned_tok, sizeof(int) * nt, hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(embed_tile_kernel, dim3((dim / 4 + 255) / 256, nt), dim3(256), 0, c->stream, b.X, w->token_embedding_table, (const int*)b.toks, nt, dim);
         LAUNCHCHK();
-        rc = run_layers_batched(c, cfg, w, b, nt, p0, s->key_cache, s->value_cache, false, &nslab);
+        rc = run_layers_batched(c, cfg, w, b, nt, p0, s->key_cache, s->value_cache, false, p0 + nt, &nslab);
         if (rc) return rc;
     }
     // the last position's residual stream (+ the last W2 product), then infer.rs:49-51 for it only
@@ -993,7 +1009,9 @@ int rama_decode_batch(rama_ctx* c, const rama_config* cfg, const rama_weights* w
         for (int j = 0; j < i; j++) REQUIRE(states[j].key_cache != states[i].key_cache && states[j].logits != states[i].logits, RAMA_EINVAL, "decode_batch: two sequences share a run state");
     }
     const int dim = cfg->dim, V = cfg->vocab_size;
-    const size_t att_floats = (size_t)attn_scratch_floats((dim / cfg->n_heads) <= 64 ? 16 : ((dim / cfg->n_heads) <= 128 ? 32 : 64)) + cfg->seq_len;
+    int tmax = 1;
+    for (int i = 0; i < n_seq; i++) tmax = std::max(tmax, pos_host[i] + 1);
+    const size_t att_floats = (size_t)attn_scratch_floats((dim / cfg->n_heads) <= 64 ? 16 : ((dim / cfg->n_heads) <= 128 ? 32 : 64)) + tmax;
     if (c->tune_ref_order || !mf_shape_ok(cfg) || V % 4 != 0 || att_floats * sizeof(float) > 64 * 1024) {   // see rama_prefill: one forward() per sequence
         for (int i = 0; i < n_seq; i++) {
             rama_run_state si = states[i];
@@ -1016,12 +1034,11 @@ int rama_decode_batch(rama_ctx* c, const rama_config* cfg, const rama_weights* w
     hipLaunchKernelGGL(embed_tile_kernel, dim3((dim / 4 + 255) / 256, n_seq), dim3(256), 0, c->stream, b.X, w->token_embedding_table, (const int*)b.toks, n_seq, dim);
     LAUNCHCHK();
     int nslab = 0;
-    rc = run_layers_batched(c, cfg, w, b, n_seq, 0, nullptr, nullptr, true, &nslab);
+    rc = run_layers_batched(c, cfg, w, b, n_seq, 0, nullptr, nullptr, true, tmax, &nslab);
     if (rc) return rc;
     // infer.rs:49-51 for every sequence: fold the last product, final rmsnorm, classifier as one more GEMM
     const int ntile = (n_seq + 15) / 16, pt = ntile <= 1 ? 1 : (ntile == 2 ? 2 : 4);
-    hipLaunchKernelGGL(rmsnorm_tile_kernel, dim3(ntile), dim3(1024), 0, c->stream, b.XN, b.X, w->rms_final_weight, dim, (const float*)b.SL, nslab, b.slab);
-    LAUNCHCHK();
+    rc = launch_rmsnorm_tile(c, b, w->rms_final_weight, dim, ntile, nslab); if (rc) return rc;
     MfParams p{};
     p.n_tok = n_seq; p.ksplit = 1; p.w[0] = w->wcls; p.x = b.XN; p.o = b.LG; p.o_stride = V; p.K = dim; p.rows = V;
     rc = launch_mf<2, EPI_STORE_ROWS>(c, p, pt); if (rc) return rc;
