@@ -141,15 +141,18 @@ __device__ __forceinline__ float dot4(f4 a, f4 b, float acc) {
 // (wave-reduced, wave-uniform) partial sums.
 //   NM   : streams alternate over NM matrices (s % NM): 1, or 2 for W1|W3
 //   NORM : activations are nw[k]*x[k]; ss accumulates sum x[k]^2 (rmsnorm folded in)
-template <int S, int NM, int CH, int NW, bool NORM>
+//   SOLO : the calling wave owns its rows alone and sweeps every chunk itself (small-K kernels:
+//          a row is a few KiB, several waves per row would mostly idle and need an LDS turn)
+template <int S, int NM, int CH, int NW, bool NORM, bool SOLO = false>
 __device__ __forceinline__ void stream_dots(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb,
                                             const unsigned (&rowoff)[S],
                                             __amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t rn,
                                             int K, float (&acc)[S], float& ss) {
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = SOLO ? 0 : threadIdx.x >> 6;
     const int nch = (K + 255) >> 8;          // 256-float chunks in a row
     const unsigned kbytes = (unsigned)K * 4u;
+    static_assert(!SOLO || NW == 1, "a solo wave deals the chunks to itself");
 #pragma unroll
     for (int s = 0; s < S; s++) acc[s] = 0.0f;
     ss = 0.0f;
@@ -350,6 +353,118 @@ __device__ __forceinline__ void gemv_swiglu_body(const SwigluParams& p) {
 }
 template <int R2, int CH, int NW>
 __global__ __launch_bounds__(NW * 64) void gemv_swiglu(SwigluParams p) { gemv_swiglu_body<R2, CH, NW>(p); }
+
+// ---------------------------------------------------------------- small-K matvecs (dim <= ~2048)
+// At the stories15M / 110M widths a weight row is 1-3 KiB: with K split over 8 waves most of the
+// workgroup idles, yet every launch still pays the cross-wave LDS turn and two barriers -- and these
+// launches are latency-bound (a dependent launch costs 1.6 us empty, ~2.4 us streaming 1 MB;
+// tools/launch_floor.hip).  Here ONE wave owns R rows (2 (w1,w3) pairs) outright: it sweeps the whole
+// row, reduces with DPP and runs the epilogue from registers; no LDS, no barrier, waves of a workgroup
+// are independent.  Same arithmetic per wave as the big kernels (chunk order front to back).
+template <int S>
+__device__ __forceinline__ float pick(const float (&a)[S], int i) {
+    // the asm keeps each element an opaque register value: otherwise hipcc folds the select chain
+    // into ONE indexed load of the array, parks the array in LDS (promoted alloca) and reads the
+    // workgroup size from the dispatch packet in host memory to find its slot -- ~25 us per kernel
+    float v = a[0];
+    asm volatile("" : "+v"(v));
+#pragma unroll
+    for (int s = 1; s < S; s++) {
+        float e = a[s];
+        asm volatile("" : "+v"(e));
+        v = (i == s) ? e : v;
+    }
+    return v;
+}
+
+constexpr int kSoloWaves = 1;
+
+template <int R, int CH, bool NORM, int EPI>
+__global__ __launch_bounds__(kSoloWaves * 64) void gemv_rows_solo(GemvParams p) {
+    const int lane = threadIdx.x & 63;
+    const int groups_per_mat = (p.rows + R - 1) / R;
+    // readfirstlane: the wave index is wave-uniform, but only an SGPR tells hipcc so -- otherwise every
+    // buffer descriptor below sits in VGPRs and each load becomes a waterfall loop
+    const int g = blockIdx.x * kSoloWaves + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (g >= p.nmat * groups_per_mat) return;
+    const int m = g / groups_per_mat;
+    const int r0 = (g - m * groups_per_mat) * R;
+    const int t = lane;
+    const float* W = (m == 0) ? p.w[0] : (m == 1 ? p.w[1] : p.w[2]);
+    float* o = (m == 0) ? p.o[0] : (m == 1 ? p.o[1] : p.o[2]);
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(W, (unsigned)p.rows * (unsigned)p.K * 4u);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (unsigned)p.K * 4u);
+    const __amdgpu_buffer_rsrc_t rn = make_rsrc(NORM ? p.nw : p.x, (unsigned)p.K * 4u);
+    unsigned rowoff[R];
+#pragma unroll
+    for (int s = 0; s < R; s++)
+        rowoff[s] = (r0 + s < p.rows) ? (unsigned)(r0 + s) * (unsigned)p.K * 4u : kOOB;
+    float resid = 0.0f, rc = 1.0f, rs = 0.0f;
+    int pos = 0;
+    if (EPI == EPI_RESID) {
+        if (t < R && r0 + t < p.rows) resid = o[r0 + t];
+    } else if (EPI == EPI_QKV) {
+        if (p.zero_me && g == 0 && t == 0) *p.zero_me = 0u;
+        pos = p.ctl ? p.ctl->pos : p.pos_val;
+        if (t < R / 2 && m < 2) {
+            const int i = ((r0 + 2 * t) % p.head_size) >> 1;
+            rc = p.fr[(size_t)pos * (p.head_size >> 1) + i];
+            rs = p.fi[(size_t)pos * (p.head_size >> 1) + i];
+        }
+    }
+    float acc[R], ss;
+    stream_dots<R, 1, CH, 1, NORM, true>(ra, ra, rowoff, rx, rn, p.K, acc, ss);
+    const float v = NORM ? rms_scale(ss, p.K) : 1.0f;
+    if (EPI == EPI_STORE || EPI == EPI_RESID) {
+        if (t < R && r0 + t < p.rows) {
+            float d = pick<R>(acc, t);
+            if (NORM) d *= v;
+            if (EPI == EPI_RESID) d = resid + d;
+            o[r0 + t] = d;
+        }
+    } else {
+        if (t < R / 2) {
+            const int r = r0 + 2 * t;
+            float a = pick<R>(acc, 2 * t), b = pick<R>(acc, 2 * t + 1);
+            if (NORM) { a *= v; b *= v; }
+            if (m < 2) {
+                const float ra_ = a * rc - b * rs;
+                const float rb_ = a * rs + b * rc;
+                a = ra_; b = rb_;
+            }
+            o[r] = a; o[r + 1] = b;
+            if (m == 1) { p.kc[(size_t)pos * p.rows + r] = a; p.kc[(size_t)pos * p.rows + r + 1] = b; }
+            else if (m == 2) { p.vc[(size_t)pos * p.rows + r] = a; p.vc[(size_t)pos * p.rows + r + 1] = b; }
+        }
+    }
+}
+
+template <int R2, int CH>
+__global__ __launch_bounds__(kSoloWaves * 64) void gemv_swiglu_solo(SwigluParams p) {
+    constexpr int S = 2 * R2;
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * kSoloWaves + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r0 = g * R2;
+    if (r0 >= p.rows) return;
+    const unsigned mbytes = (unsigned)p.rows * (unsigned)p.K * 4u;
+    const __amdgpu_buffer_rsrc_t r1 = make_rsrc(p.w1, mbytes);
+    const __amdgpu_buffer_rsrc_t r3 = make_rsrc(p.w3, mbytes);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (unsigned)p.K * 4u);
+    const __amdgpu_buffer_rsrc_t rn = make_rsrc(p.nw, (unsigned)p.K * 4u);
+    unsigned rowoff[S];
+#pragma unroll
+    for (int s = 0; s < S; s++)
+        rowoff[s] = (r0 + (s >> 1) < p.rows) ? (unsigned)(r0 + (s >> 1)) * (unsigned)p.K * 4u : kOOB;
+    float acc[S], ss;
+    stream_dots<S, 2, CH, 1, true, true>(r1, r3, rowoff, rx, rn, p.K, acc, ss);
+    if (lane < R2 && r0 + lane < p.rows) {
+        const float v = rms_scale(ss, p.K);
+        float a = pick<S>(acc, 2 * lane) * v;
+        const float b = pick<S>(acc, 2 * lane + 1) * v;
+        a = a * (1.0f / (1.0f + expf(-a)));   // cpu.rs:56
+        p.hb[r0 + lane] = a * b;              // cpu.rs:59-64
+    }
+}
 
 // generic o_cols > 1 product of the trait signature (never used by forward): one thread per output
 __global__ void matmul_generic(float* o, const float* a, const float* b, int width, int o_rows, int o_cols) {
@@ -729,12 +844,22 @@ __global__ __launch_bounds__(1024) void argmax_kernel(ArgmaxParams p) {
     // order, so "replace unless strictly smaller" keeps the LAST maximum (cpu.rs:165-167)
     const int n4 = (((uintptr_t)p.logits & 15) == 0) ? (p.n >> 2) : 0;
     const f4* l4 = reinterpret_cast<const f4*>(p.logits);
-    for (int i = tid; i < n4; i += 1024) {
-        const f4 v = l4[i];
-        if (!(bv > v.x)) { bv = v.x; bi = 4 * i; }
-        if (!(bv > v.y)) { bv = v.y; bi = 4 * i + 1; }
-        if (!(bv > v.z)) { bv = v.z; bi = 4 * i + 2; }
-        if (!(bv > v.w)) { bv = v.w; bi = 4 * i + 3; }
+    // 8 loads in flight per thread: one workgroup sweeps 128 KB, and a dependent load per iteration
+    // would cost a cache round trip each (this launch is pure latency)
+    for (int i0 = tid; i0 < n4; i0 += 8 * 1024) {
+        f4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = i0 + u * 1024; v[u] = i < n4 ? l4[i] : f4{-INFINITY, -INFINITY, -INFINITY, -INFINITY}; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + u * 1024;
+            if (i < n4) {
+                if (!(bv > v[u].x)) { bv = v[u].x; bi = 4 * i; }
+                if (!(bv > v[u].y)) { bv = v[u].y; bi = 4 * i + 1; }
+                if (!(bv > v[u].z)) { bv = v[u].z; bi = 4 * i + 2; }
+                if (!(bv > v[u].w)) { bv = v[u].w; bi = 4 * i + 3; }
+            }
+        }
     }
     for (int i = 4 * n4 + tid; i < p.n; i += 1024) {
         const float v = p.logits[i];

@@ -76,6 +76,7 @@ struct rama_ctx {
     hipEvent_t cur_start = nullptr, cur_stop = nullptr;   // events the next profiled launch carries
     int tune_geom = 3;
     int tune_persist = 0;                  // 1: decode steps run as one persistent launch (persist.hpp)
+    int tune_solo = -1;                    // small-K matvecs, one wave per row group: 1 on, 0 off, -1 = rows of <= 2048 floats
     int tune_ref_order = 0;                // 1: every op in the reference's own rounding order (ref_order.hpp): bit-comparable, slow
     // device top-p sampler (Device::sample for temperature != 0); temperature 0 = argmax
     float samp_T = 0.0f, samp_topp = 0.9f, samp_u = 0.0f;
@@ -283,6 +284,8 @@ static int check_matvec_shape(size_t width, size_t rows) {
     return 0;
 }
 
+static bool use_solo(const rama_ctx* c, int K) { return c->tune_solo < 0 ? K <= 2048 : c->tune_solo != 0; }
+
 // plain W.x (EPI_STORE) or x += W.y (EPI_RESID)
 template <bool NORM, int EPI>
 static int launch_rows(rama_ctx* c, float* o, const float* W, const float* x, const float* nw, int K, int rows) {
@@ -290,6 +293,13 @@ static int launch_rows(rama_ctx* c, float* o, const float* W, const float* x, co
     if (rc) return rc;
     GemvParams p{};
     p.w[0] = W; p.x = x; p.nw = nw; p.o[0] = o; p.K = K; p.rows = rows; p.nmat = 1;
+    if (use_solo(c, K)) {      // small-K: one wave per 4 rows (kernels.hpp gemv_rows_solo)
+        const dim3 grid(((rows + 3) / 4 + kSoloWaves - 1) / kSoloWaves), block(kSoloWaves * 64);
+        if (K <= 512) RAMA_LAUNCH(c, (gemv_rows_solo<4, 2, NORM, EPI>), grid, block, 0, p);
+        else RAMA_LAUNCH(c, (gemv_rows_solo<4, 4, NORM, EPI>), grid, block, 0, p);
+        LAUNCHCHK();
+        return 0;
+    }
     if (!NORM && EPI == EPI_RESID && c->tune_geom == 3 && c->tune_resid_r2) {
         // the residual matvecs (Wo, W2) read no rmsnorm gain, so a 2-row workgroup's re-read of
         // x is cheap and the finer grain balances better; rows wider than
@@ -646,7 +656,13 @@ static int enqueue_stage(rama_ctx* c, const rama_config* cfg, const rama_weights
             p.ctl = c->ctl; p.fr = w->freq_cis_real; p.fi = w->freq_cis_imag; p.head_size = hs;
             p.kc = kc; p.vc = vc;
             p.zero_me = c->attn_counter;
-            DISPATCH_GEOM(c, RAMA_LAUNCH(c, (gemv_rows<R_, CH_, NW_, true, EPI_QKV>), dim3(3 * (dim / R_)), dim3(NW_ * 64), 0, p));
+            if (use_solo(c, dim)) {
+                const dim3 grid((3 * ((dim + 3) / 4) + kSoloWaves - 1) / kSoloWaves), block(kSoloWaves * 64);
+                if (dim <= 512) RAMA_LAUNCH(c, (gemv_rows_solo<4, 2, true, EPI_QKV>), grid, block, 0, p);
+                else RAMA_LAUNCH(c, (gemv_rows_solo<4, 4, true, EPI_QKV>), grid, block, 0, p);
+            } else {
+                DISPATCH_GEOM(c, RAMA_LAUNCH(c, (gemv_rows<R_, CH_, NW_, true, EPI_QKV>), dim3(3 * (dim / R_)), dim3(NW_ * 64), 0, p));
+            }
             LAUNCHCHK();
         }
         bool merged = false;
@@ -672,7 +688,13 @@ static int enqueue_stage(rama_ctx* c, const rama_config* cfg, const rama_weights
             SwigluParams p{};
             p.w1 = w->w1 + li * hd; p.w3 = w->w3 + li * hd; p.x = s->x; p.nw = w->rms_ffn_weight + li * dim;
             p.hb = s->hb; p.K = dim; p.rows = hidden;
-            DISPATCH_GEOM(c, RAMA_LAUNCH(c, (gemv_swiglu<R2_, CH_, NW_>), dim3((hidden + R2_ - 1) / R2_), dim3(NW_ * 64), 0, p));
+            if (use_solo(c, dim)) {
+                const dim3 grid(((hidden + 1) / 2 + kSoloWaves - 1) / kSoloWaves), block(kSoloWaves * 64);
+                if (dim <= 512) RAMA_LAUNCH(c, (gemv_swiglu_solo<2, 2>), grid, block, 0, p);
+                else RAMA_LAUNCH(c, (gemv_swiglu_solo<2, 4>), grid, block, 0, p);
+            } else {
+                DISPATCH_GEOM(c, RAMA_LAUNCH(c, (gemv_swiglu<R2_, CH_, NW_>), dim3((hidden + R2_ - 1) / R2_), dim3(NW_ * 64), 0, p));
+            }
             LAUNCHCHK();
         }
         {   // infer.rs:46-47: x += W2 . hb
@@ -1262,6 +1284,13 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
     if (!strcmp(key, "merge")) {
         REQUIRE(value >= -1 && value <= 1, RAMA_EINVAL, "set_tuning: merge must be -1, 0 or 1");
         c->tune_merge = value;
+        hipStreamSynchronize(c->stream);
+        drop_graph(c);
+        return 0;
+    }
+    if (!strcmp(key, "solo")) {
+        REQUIRE(value >= -1 && value <= 1, RAMA_EINVAL, "set_tuning: solo must be -1, 0 or 1");
+        c->tune_solo = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
         return 0;
