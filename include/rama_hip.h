@@ -253,21 +253,12 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *                   sequential matvec sums with separate multiply and add, sequential rmsnorm / softmax
  *                   sums, glibc's expf restated) so results can be compared with the reference CPU path
  *                   bit for bit; ~8 ms per llama2-7B token.  Default 0: the fast path, which differs from
- *                   the CPU path by the CPU path's own rounding error (1.5e-4 in llama2-7B logits)
- *   "persist" = 0|1 : 1 runs each chained decode step as ONE persistent launch (persist.hpp:
- *                   one resident workgroup per CU, phases separated by a counter barrier hidden
- *                   behind weight prefetch).  Same results; measured slower than the launch
- *                   path in round 1 (170 vs 235 tok/s at llama2-7B), so it is off by default. */
+ *                   the CPU path by the CPU path's own rounding error (1.5e-4 in llama2-7B logits) */
 int  rama_set_tuning(rama_ctx *ctx, const char *key, int value);
 
 /* glibc 2.35 expf (the exp the reference's f32::exp calls on Linux) as the reference-order kernels
  * evaluate it, elementwise: the bit-exactness test's handle on it */
 int  rama_ref_expf(rama_ctx *ctx, float *o, const float *x, size_t n);
-
-/* diagnostic (not a product path): one persistent decode step with 100 MHz timestamps of workgroup
- * `wg`, 8 slots per phase (0 start, 1 activations staged, 2 steps done, 3 arrived, 4 barrier passed) */
-int  rama_persist_stamps(rama_ctx *ctx, const rama_config *cfg, const rama_weights *w, rama_run_state *s,
-                         int wg, unsigned long long *out_host, int max_phases, int *n_phases);
 
 /* ---------------------------------------------------------------- measurement
  * HIP events on the context's stream (the stream the kernels are launched on). */

@@ -97,7 +97,6 @@ SIGNATURES = {
     "rama_set_graph_mode": (_int, [_vp, _int]),
     "rama_set_tuning": (_int, [_vp, C.c_char_p, _int]),
     "rama_ref_expf": (_int, [_vp, _vp, _vp, _sz]),
-    "rama_persist_stamps": (_int, [_vp, _cfgp, _wp, _sp, _int, C.POINTER(C.c_ulonglong), _int, C.POINTER(_int)]),
     "rama_timer_start": (_int, [_vp]),
     "rama_timer_stop": (_int, [_vp, C.POINTER(C.c_float)]),
     "rama_kprof_enable": (_int, [_vp, _int, _int]),

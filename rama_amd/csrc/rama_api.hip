@@ -2,7 +2,7 @@
 // ops, the fused decode path, measurement.  Kernels are in kernels.hpp.
 #include "../../include/rama_hip.h"
 #include "kernels.hpp"
-#include "persist.hpp"
+#include "attn_wo.hpp"
 #include "prefill_mfma.hpp"
 #include "ref_order.hpp"
 #include <hipcub/hipcub.hpp>
@@ -70,12 +70,11 @@ struct rama_ctx {
     int* pinned_int = nullptr;      // host pinned
     int* pinned_tok = nullptr;      // host pinned staging: token ids + a SeqSlot table of a token-batch pass
     bool graph_mode = false;
-    GraphCache gc[2];                  // [0]: single-workgroup attention, [1]: split-T attention (long contexts)
+    GraphCache gc[3];                  // by attention variant: [0] one 16-wave workgroup per head, [1] split-T (long contexts), [2] one 4-wave workgroup per head (short contexts)
     KProf kp;
     int cu_count = 0;
     hipEvent_t cur_start = nullptr, cur_stop = nullptr;   // events the next profiled launch carries
     int tune_geom = 3;
-    int tune_persist = 0;                  // 1: decode steps run as one persistent launch (persist.hpp)
     int tune_solo = -1;                    // small-K matvecs, one wave per row group: 1 on, 0 off, -1 = rows of <= 2048 floats
     int tune_ref_order = 0;                // 1: every op in the reference's own rounding order (ref_order.hpp): bit-comparable, slow
     // device top-p sampler (Device::sample for temperature != 0); temperature 0 = argmax
@@ -98,12 +97,11 @@ struct rama_ctx {
     size_t pf_floats = 0;
     int host_pos = -1;                     // position of the next chained decode step (mirrors the device cursor)
     bool split_attn = false;               // variant the steps being enqueued / captured use
-    unsigned long long* pbar = nullptr;    // device: [0] barrier counter, [1] error word, [2] epoch
-    size_t persist_lds = 0;
-    unsigned long long* pstamps = nullptr; // diagnostic timestamps of the persistent step (rama_persist_stamps)
-    int pstamp_wg = 0;
-    bool pstamp_armed = false;
-    const void* persist_fn = nullptr;
+    bool small_attn = false;               // 4-wave attention workgroups (contexts of <= kSmallAttnPos timesteps)
+    int tune_small_attn = 0;               // 4-wave attention in the decode step: 0 never (default: measured equal to the merged
+                                           // attention+Wo launch at the stories shapes and to the 16-wave kernel at llama2-7B), 1 whenever
+                                           // it fits, -1 below kSmallAttnPos
+    unsigned long long* pbar = nullptr;    // device: [1] = error word of the merged attention+Wo launch's bounded spin
     const float* embedded_x = nullptr;   // run-state x that already holds emb[ctl.token] (chained decode)
 };
 
@@ -443,6 +441,14 @@ static int split_threshold(const rama_ctx* c, const rama_config* cfg) {
     return kv_bytes_per_pos * cfg->seq_len <= (1L << 20) ? (1 << 30) : kSplitTPos;   // whole head cache <= 1 MiB: never split
 }
 
+// positions up to which the 4-wave attention workgroup is used (it covers 64 timesteps per round;
+// measured faster than the 16-wave one up to ~250 timesteps at head sizes 48 / 64)
+constexpr int kSmallAttnPos = 224;
+static bool small_attn_at(const rama_ctx* c, int pos, bool split) {
+    if (split || c->tune_small_attn == 0) return false;
+    return c->tune_small_attn == 1 ? true : pos < kSmallAttnPos;
+}
+
 static int launch_attention(rama_ctx* c, float* xb, float* att, const float* q, const float* kc_layer,
                             const float* vc_layer, const Ctl* ctl, int pos, int dim, int head_size,
                             int seq_len, int n_heads, bool split = false) {
@@ -468,6 +474,15 @@ static int launch_attention(rama_ctx* c, float* xb, float* att, const float* q, 
         LAUNCHCHK();
         return 0;
     }
+    if (c->small_attn) {     // short contexts: a round of 4 waves covers 64 timesteps (3.5 vs 5.3 us per launch, tools/launch_floor.hip)
+        size_t shm4 = (size_t)(attn_scratch_floats(G, 4) + seq_len) * sizeof(float);
+        REQUIRE(shm4 <= 64 * 1024, RAMA_EUNSUP, "attention: seq_len too long for the single-workgroup kernel");
+        if (G == 16) RAMA_LAUNCH(c, (attention_kernel<16, false, 4>), dim3(n_heads), dim3(256), shm4, p);
+        else if (G == 32) RAMA_LAUNCH(c, (attention_kernel<32, false, 4>), dim3(n_heads), dim3(256), shm4, p);
+        else RAMA_LAUNCH(c, (attention_kernel<64, false, 4>), dim3(n_heads), dim3(256), shm4, p);
+        LAUNCHCHK();
+        return 0;
+    }
     size_t shm = (size_t)(attn_scratch_floats(G) + seq_len) * sizeof(float);
     REQUIRE(shm <= 64 * 1024, RAMA_EUNSUP, "attention: seq_len too long for the single-workgroup kernel");
     if (G == 16) RAMA_LAUNCH(c, (attention_kernel<16, false>), dim3(n_heads), dim3(kAttnThreads), shm, p);
@@ -484,6 +499,7 @@ int rama_multi_head_attention(rama_ctx* c, float* xb, float* att, const float* q
     REQUIRE(pos >= 0 && pos < seq_len && layer >= 0 && n_heads > 0 && n_heads * head_size == dim, RAMA_EINVAL, "multi_head_attention: bad shape");
     const size_t lo = (size_t)layer * seq_len * dim;   // cpu.rs:28
     if (c->tune_ref_order) return launch_attention_ref(c, xb, att, q, key_cache + lo, value_cache + lo, nullptr, pos, dim, head_size, seq_len, n_heads);
+    c->small_attn = small_attn_at(c, pos, false);
     return launch_attention(c, xb, att, q, key_cache + lo, value_cache + lo, nullptr, pos, dim, head_size, seq_len, n_heads);
 }
 
@@ -546,7 +562,7 @@ static int check_cfg(const rama_config* cfg) {
     return 0;
 }
 
-// attention + Wo as one launch (persist.hpp attn_wo_kernel) -- only if the WHOLE grid is resident at
+// attention + Wo as one launch (attn_wo.hpp) -- only if the WHOLE grid is resident at
 // once according to the occupancy API, which is what makes its in-kernel wait deadlock-free.
 // Returns 1 if launched, 0 if the caller must use the two separate launches, < 0 / > 0 on error.
 static int try_launch_attn_wo(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s,
@@ -667,7 +683,7 @@ static int enqueue_stage(rama_ctx* c, const rama_config* cfg, const rama_weights
         }
         bool merged = false;
         const bool want_merge = c->tune_merge < 0 ? dim <= 1024 : c->tune_merge != 0;
-        if (want_merge && !c->split_attn && c->kp.kernel_id < 0) {   // infer.rs:34-37 as one launch (per-kernel timing keeps them apart)
+        if (want_merge && !c->split_attn && !c->small_attn && c->kp.kernel_id < 0) {   // infer.rs:34-37 as one launch (per-kernel timing keeps them apart)
             int rc = try_launch_attn_wo(c, cfg, w, s, li, kc, vc, &merged);
             if (rc) return rc;
         }
@@ -736,6 +752,7 @@ int rama_forward_stage(rama_ctx* c, const rama_config* cfg, const rama_weights* 
     c->embedded_x = nullptr;
     c->host_pos = -1;
     c->split_attn = pos >= split_threshold(c, cfg);
+    c->small_attn = small_attn_at(c, pos, c->split_attn);
     return enqueue_stage(c, cfg, w, s, st);
 }
 
@@ -753,6 +770,7 @@ int rama_forward_stage_devtok(rama_ctx* c, const rama_config* cfg, const rama_we
     c->embedded_x = nullptr;
     c->host_pos = -1;
     c->split_attn = pos >= split_threshold(c, cfg);
+    c->small_attn = small_attn_at(c, pos, c->split_attn);
     return enqueue_stage(c, cfg, w, s, st);
 }
 
@@ -1088,43 +1106,7 @@ int rama_decode_begin(rama_ctx* c, int token, int pos, const int32_t* forced_hos
 
 // One chained step: layers + classifier + (argmax, cursor advance, next token's embedding
 // gather).  x already holds emb[token] on entry (rama_decode_steps primes it once).
-// the same step as ONE persistent launch (persist.hpp): one resident workgroup per CU
-static int enqueue_decode_step_persistent(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s) {
-    PersistParams p{};
-    p.dim = cfg->dim; p.hidden = cfg->hidden_dim; p.n_heads = cfg->n_heads; p.vocab = cfg->vocab_size; p.seq_len = cfg->seq_len;
-    p.n_layers = cfg->n_layers; p.do_cls = 1; p.do_argmax = 1;
-    p.emb = w->token_embedding_table; p.rms_att = w->rms_att_weight; p.rms_ffn = w->rms_ffn_weight;
-    p.wq = w->wq; p.wk = w->wk; p.wv = w->wv; p.wo = w->wo; p.w1 = w->w1; p.w2 = w->w2; p.w3 = w->w3;
-    p.rms_final = w->rms_final_weight; p.fr = w->freq_cis_real; p.fi = w->freq_cis_imag; p.wcls = w->wcls;
-    p.x = s->x; p.xb = s->xb; p.hb = s->hb; p.q = s->q; p.k = s->k; p.v = s->v; p.logits = s->logits;
-    p.kc = s->key_cache; p.vc = s->value_cache;
-    p.ctl = c->ctl; p.forced = c->forced; p.out = c->out; p.out_cap = c->out_cap;
-    p.bar = c->pbar; p.epoch = c->pbar + 2;
-    p.stamps = c->pstamp_armed ? c->pstamps : nullptr; p.stamp_wg = c->pstamp_wg;
-    p.nwg = c->cu_count;
-    REQUIRE(cfg->n_heads <= p.nwg, RAMA_EUNSUP, "persistent step: more heads than compute units");
-    const int hs = cfg->dim / cfg->n_heads;
-    const int G = hs <= 64 ? 16 : (hs <= 128 ? 32 : 64);
-    size_t xfloats = (size_t)std::max(std::max(cfg->dim, cfg->hidden_dim), p_attn_lds_floats(G, cfg->seq_len));
-    // > 80 KiB so that at most ONE workgroup fits a CU's 160 KiB: with grid = #CUs every
-    // workgroup is resident, which the in-kernel barrier relies on
-    size_t lds = std::max<size_t>((2 * kPWaves * kPS + 16 + 256 + ((cfg->dim + 3) & ~3) + xfloats) * sizeof(float), 82 * 1024);
-    REQUIRE(lds <= 160 * 1024, RAMA_EUNSUP, "persistent step: activation vector does not fit LDS");
-    const void* fn = G == 16 ? (const void*)decode_step_kernel<16> : (G == 32 ? (const void*)decode_step_kernel<32> : (const void*)decode_step_kernel<64>);
-    if (lds != c->persist_lds || fn != c->persist_fn) {
-        HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        c->persist_lds = lds; c->persist_fn = fn;
-    }
-    if (G == 16) hipLaunchKernelGGL(decode_step_kernel<16>, dim3(p.nwg), dim3(kPThreads), lds, c->stream, p);
-    else if (G == 32) hipLaunchKernelGGL(decode_step_kernel<32>, dim3(p.nwg), dim3(kPThreads), lds, c->stream, p);
-    else hipLaunchKernelGGL(decode_step_kernel<64>, dim3(p.nwg), dim3(kPThreads), lds, c->stream, p);
-    LAUNCHCHK();
-    return 0;
-}
-
 static int enqueue_decode_step(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s) {
-    // the single-launch step has the argmax built in: any other sampler takes the launch path
-    if (c->tune_persist && !c->tune_ref_order && c->kp.kernel_id < 0 && c->samp_T == 0.0f) return enqueue_decode_step_persistent(c, cfg, w, s);
     rama_stage st{0, cfg->n_layers, 0, 1};
     int rc = enqueue_stage(c, cfg, w, s, &st);
     if (rc) return rc;
@@ -1159,8 +1141,9 @@ int rama_decode_steps(rama_ctx* c, const rama_config* cfg, const rama_weights* w
     for (int i = 0; i < n_steps; i++) {
         // the attention variant depends on the position, which the host mirrors step by step
         c->split_attn = c->host_pos >= split_threshold(c, cfg);
+        c->small_attn = small_attn_at(c, c->host_pos, c->split_attn);
         if (graphs) {
-            GraphCache& g = c->gc[c->split_attn ? 1 : 0];
+            GraphCache& g = c->gc[c->split_attn ? 1 : (c->small_attn ? 2 : 0)];
             if (!same_capture(g, cfg, w, s)) {
                 if (g.exec) hipGraphExecDestroy(g.exec);
                 if (g.graph) hipGraphDestroy(g.graph);
@@ -1190,9 +1173,9 @@ int rama_decode_tokens(rama_ctx* c, int32_t* out_host, int max_tokens, int* n_ou
     unsigned long long perr = 0;
     HIPCHK(hipMemcpyAsync(&perr, c->pbar + 1, sizeof perr, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (perr != 0) {   // a bounded spin of the persistent step gave up: its results are invalid
+    if (perr != 0) {   // the bounded spin of a merged attention+Wo launch gave up: its results are invalid
         hipMemsetAsync(c->pbar, 0, 4 * sizeof(unsigned long long), c->stream);   // counter, error word, base: start over
-        return fail(RAMA_EINVAL, "persistent decode step: barrier timed out", __FILE__, __LINE__);
+        return fail(RAMA_EINVAL, "attention+Wo launch: hand-off timed out", __FILE__, __LINE__);
     }
     if (c->topp_err) {
         unsigned terr = 0;
@@ -1226,7 +1209,7 @@ int rama_generate(rama_ctx* c, const rama_config* cfg, const rama_weights* w, ra
     REQUIRE(n_prompt >= 0 && (n_prompt == 0 || prompt_host), RAMA_EINVAL, "generate_greedy: bad prompt");
     n_prompt = std::min(n_prompt, c->forced_cap);
     int rc;
-    if (c->tune_prefill && n_prompt >= 3 && steps > n_prompt && !c->tune_persist) {
+    if (c->tune_prefill && n_prompt >= 3 && steps > n_prompt) {
         // Positions 0..n_prompt carry known tokens (BOS, then the prompt; mod.rs:182-191) and their
         // `next` is forced, so they go through the layers together (rama_prefill); the logits of
         // position n_prompt give the first sampled token and the chained loop takes over.
@@ -1288,6 +1271,13 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
         drop_graph(c);
         return 0;
     }
+    if (!strcmp(key, "small_attn")) {
+        REQUIRE(value >= -1 && value <= 1, RAMA_EINVAL, "set_tuning: small_attn must be -1, 0 or 1");
+        c->tune_small_attn = value;
+        hipStreamSynchronize(c->stream);
+        drop_graph(c);
+        return 0;
+    }
     if (!strcmp(key, "solo")) {
         REQUIRE(value >= -1 && value <= 1, RAMA_EINVAL, "set_tuning: solo must be -1, 0 or 1");
         c->tune_solo = value;
@@ -1302,13 +1292,6 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
         drop_graph(c);
         return 0;
     }
-    if (!strcmp(key, "persist")) {
-        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: persist must be 0 or 1");
-        c->tune_persist = value;
-        hipStreamSynchronize(c->stream);
-        drop_graph(c);
-        return 0;
-    }
     if (!strcmp(key, "geom")) {
         REQUIRE(value >= 0 && value <= 4, RAMA_EINVAL, "set_tuning: geom must be 0..4");
         c->tune_geom = value;
@@ -1317,30 +1300,6 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
         return 0;
     }
     return fail(RAMA_EINVAL, "set_tuning: unknown key", __FILE__, __LINE__);
-}
-
-// diagnostic: run ONE persistent decode step with timestamps of workgroup `wg` recorded, and
-// return them (8 slots per phase: 0 phase start, 1 activations staged, 2 steps done, 3 arrived,
-// 4 barrier passed; 100 MHz ticks).  Not part of the product path.
-int rama_persist_stamps(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s, int wg,
-                        unsigned long long* out_host, int max_phases, int* n_phases) {
-    REQUIRE(c && cfg && w && s && out_host && n_phases, RAMA_EINVAL, "persist_stamps: NULL argument");
-    const int nph = 5 * cfg->n_layers + 1;
-    REQUIRE(max_phases >= nph, RAMA_EINVAL, "persist_stamps: buffer too small");
-    if (!c->pstamps) HIPCHK(hipMalloc(&c->pstamps, (size_t)8 * 4096 * sizeof(unsigned long long)));
-    REQUIRE(nph <= 4096, RAMA_EINVAL, "persist_stamps: too many phases");
-    HIPCHK(hipMemsetAsync(c->pstamps, 0, (size_t)8 * nph * sizeof(unsigned long long), c->stream));
-    c->pstamp_wg = wg;
-    unsigned long long* keep = c->pstamps;
-    c->pstamp_armed = true;
-    int rc = enqueue_decode_step_persistent(c, cfg, w, s);
-    c->pstamp_armed = false;
-    if (rc) return rc;
-    c->host_pos += 1;
-    HIPCHK(hipMemcpyAsync(out_host, keep, (size_t)8 * nph * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    *n_phases = nph;
-    return 0;
 }
 
 int rama_set_graph_mode(rama_ctx* c, int enabled) {

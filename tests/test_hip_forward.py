@@ -337,16 +337,16 @@ def rnd_vec(n, seed):
     return np.random.default_rng(seed).standard_normal(n).astype(np.float32)
 
 
-# ------------------------------------------------------------------ persistent decode step
+# ------------------------------------------------------------------ opt-in launch structures
 
-@pytest.mark.parametrize("key", [b"persist", b"merge"])
+@pytest.mark.parametrize("key", [b"merge", b"small_attn", b"solo"])
 @pytest.mark.parametrize("name,graph", [("synth_d64_h4", False), ("synth_d288_h6", False), ("synth_d288_h6", True),
                                         ("synth_d768_h12", False), ("ckpt_untied", False), ("synth_d128_h1", False),
                                         ("synth_7bshape_l1", False)])
-def test_persistent_step_equals_launch_path(dev, name, graph, key):
-    """the opt-in launch structures -- rama_set_tuning("persist", 1): the whole step as one
-    resident launch; ("merge", 1): attention + Wo as one launch (persist.hpp) -- must give the
-    oracle's greedy tokens, logits within the bar, and the same KV cache."""
+def test_launch_structures_equal_default_path(dev, name, graph, key):
+    """the opt-in launch structures -- rama_set_tuning("merge", 1): attention + Wo as one launch
+    (attn_wo.hpp); ("small_attn", 1): 4-wave attention workgroups; ("solo", 1): one wave per row group
+    in every matvec -- must give the oracle's greedy tokens, logits within the bar, the same KV cache."""
     import rama_amd
     cfg, w, g = load_case(name)
     prompt = g["tokens"].tolist()[1:4]
@@ -360,7 +360,7 @@ def test_persistent_step_equals_launch_path(dev, name, graph, key):
         got = rama_amd.generate_greedy_device(rcfg, prompt, steps, wv, rsv, dev)
     finally:
         dev.lib.rama_set_graph_mode(dev.ctx, 0)
-        rama_amd._lib.check(dev.lib.rama_set_tuning(dev.ctx, key, 0))
+        rama_amd._lib.check(dev.lib.rama_set_tuning(dev.ctx, key, {b"merge": -1, b"small_attn": 0, b"solo": -1}[key]))
     assert got == want
     assert np.abs(dev.download(rsv.logits) - orc.s["logits"]).max() <= LOGIT_ATOL
     for buf in ("key_cache", "value_cache"):

@@ -23,7 +23,6 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--geom", default="0,1,2,3")
     ap.add_argument("--kprof", type=int, default=1)
-    ap.add_argument("--persist", default="0", help="comma list of 0/1: also time the persistent single-launch step")
     args = ap.parse_args()
     d, h, L, H, V, seq, shared = SHAPES[args.config]
     cfg = rama_amd.Config(d, h, L, H, H, V, seq, shared)
@@ -61,29 +60,6 @@ def main():
                 b = bytes_.get(k)
                 ks[k] = [round(avg_ms * 1e3, 2), round(b / (avg_ms * 1e-3) / 1e9) if b else None]
             out[f"geom{v}"]["kernels_us_GBps"] = ks
-    for pv in [int(v) for v in args.persist.split(",") if v != "0"]:
-        eng.set_tuning("geom", 3)
-        rates = []
-        for rnd in range(args.rounds):
-            for mode in (0, pv):
-                eng.set_tuning("persist", mode)
-                eng.set_graph_mode(True)
-                eng.decode_begin(1, 0, PROMPT)
-                eng.decode_steps(4)
-                dev.sync()
-                t0 = time.perf_counter()
-                eng.decode_steps(args.steps)
-                dev.sync()
-                rates.append((mode, args.steps / (time.perf_counter() - t0)))
-        toks = {}
-        for mode in (0, pv):
-            eng.set_tuning("persist", mode)
-            eng.decode_begin(1, 0, PROMPT)
-            eng.decode_steps(24)
-            toks[mode] = eng.decode_tokens()
-        eng.set_tuning("persist", 0)
-        out[f"persist{pv}"] = {"tok_s": {m: sorted(round(r, 2) for mm, r in rates if mm == m) for m in (0, pv)},
-                               "same_tokens_as_launch_path": toks[0] == toks[pv]}
     print(json.dumps(out, indent=1))
 
 
