@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no-kprof", action="store_true")
     ap.add_argument("--no-placement-tuning", action="store_true",
                     help="skip rama_model_tune_placement (profiling runs: its candidate steps would mix into the kernel statistics)")
+    ap.add_argument("--pos0", type=int, default=0,
+                    help="start the timed generation at this position over a pre-filled (zero) cache: long-context timing, "
+                         "N = 1 only; the default 0 is generate()'s own start (BOS + prompt)")
     ap.add_argument("--cpu-tokens", type=int, default=6)
     ap.add_argument("--cpu-layers", type=int, default=2)
     return ap.parse_args()
@@ -193,8 +196,9 @@ def main():
         return pos
 
     eng.set_graph_mode(bool(args.graph))
-    eng.decode_begin(1, 0, PROMPT)
-    pos = run_steps(args.warmup, 0)
+    pos0 = max(0, min(args.pos0, seq - 1))
+    eng.decode_begin(1, pos0, PROMPT if pos0 == 0 else [])
+    pos = run_steps(args.warmup, pos0)
     dev.sync()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -206,7 +210,7 @@ def main():
     wall_ms = (time.perf_counter() - t0) * 1e3
     ms_per_step = wall_ms / args.steps
     tokens = eng.decode_tokens()
-    assert len(tokens) == (need if need <= seq else pos), (len(tokens), need, pos)
+    assert len(tokens) == (need if pos0 + need <= seq else pos), (len(tokens), need, pos)
 
     roofline, kernels = None, {}
     if not args.no_kprof:
@@ -238,7 +242,7 @@ def main():
         "value": round(tok_s, 3), "unit": "tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.config} fp32 decode, weights resident in HBM, greedy, pos {args.warmup}..{need - 1}" + (" (wrapping at seq_len)" if need > seq else ""),
+        "config": {"workload": f"{args.config} fp32 decode, weights resident in HBM, greedy, pos {pos0 + args.warmup}..{pos0 + need - 1}" + (" (wrapping at seq_len)" if pos0 + need > seq else ""),
                    "dim": d, "hidden_dim": h, "n_layers": L, "n_heads": H, "vocab_size": V, "seq_len": seq,
                    "sequences_in_flight": 1, "parallelism": "single GPU", "hipgraph": bool(args.graph),
                    "w3_placement_tuning": placement},

@@ -229,7 +229,7 @@ __device__ __forceinline__ float rms_scale(float ss, int n) {
 
 // ---------------------------------------------------------------- matvec kernels
 
-enum { EPI_STORE = 0, EPI_RESID = 1, EPI_QKV = 2 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_SWIGLU_PAIR = 5 };   // 3, 4: prefill_mfma.hpp
 
 struct GemvParams {
     const float* w[3];     // nmat matrices, each [rows, K] row-major
@@ -291,6 +291,15 @@ __global__ __launch_bounds__(NW * 64) void gemv_rows(GemvParams p) {
             if (NORM) d *= rms_scale(combined<R, NW>(part, R), p.K);
             if (EPI == EPI_RESID) d = resid + d;     // infer.rs:37,47  x[i] += y[i]
             o[r0 + t] = d;
+        }
+    } else if (EPI == EPI_SWIGLU_PAIR) {
+        // rows (2i, 2i + 1) = row i of W1 and of W3, stored interleaved (model.hip): infer.rs:41-45
+        if (t < R / 2 && r0 + 2 * t < p.rows) {
+            const float v = rms_scale(combined<R, NW>(part, R), p.K);
+            float a = combined<R, NW>(part, 2 * t) * v;
+            const float b = combined<R, NW>(part, 2 * t + 1) * v;
+            a = a * (1.0f / (1.0f + expf(-a)));          // cpu.rs:56
+            o[(r0 >> 1) + t] = a * b;                    // cpu.rs:59-64
         }
     } else {   // EPI_QKV: rows are (even, odd) pairs of one head (R even, head_size even)
         if (t < R / 2) {
@@ -422,6 +431,13 @@ __global__ __launch_bounds__(kSoloWaves * 64) void gemv_rows_solo(GemvParams p) 
             if (EPI == EPI_RESID) d = resid + d;
             o[r0 + t] = d;
         }
+    } else if (EPI == EPI_SWIGLU_PAIR) {
+        if (t < R / 2 && r0 + 2 * t < p.rows) {
+            float a = pick<R>(acc, 2 * t) * v;
+            const float b = pick<R>(acc, 2 * t + 1) * v;
+            a = a * (1.0f / (1.0f + expf(-a)));
+            o[(r0 >> 1) + t] = a * b;
+        }
     } else {
         if (t < R / 2) {
             const int r = r0 + 2 * t;
@@ -533,7 +549,9 @@ __host__ __device__ constexpr int attn_scratch_floats(int G, int W = kAttnWaves)
 
 // W = 4: the token-batch passes' short contexts (a few dozen timesteps per query, thousands of
 // (head, query) workgroups): a round of 4 waves already covers 64 timesteps, and 8 such workgroups fit a CU
-template <int G, bool SPLIT, int W = kAttnWaves>
+// NT: cache rows are fetched non-temporally (long contexts: every row is read once per step and the
+// 2 GB/token K/V stream of llama2-7B at 2K context should not evict anything)
+template <int G, bool SPLIT, int W = kAttnWaves, bool NT = false>
 __global__ __launch_bounds__(W * 64) void attention_kernel(AttnParams p) {
     constexpr int kAttnWaves = W, kAttnThreads = W * 64;       // shadow the 16-wave defaults
     extern __shared__ float sm[];
@@ -575,16 +593,16 @@ __global__ __launch_bounds__(W * 64) void attention_kernel(AttnParams p) {
 
     f4 kt[U], vt[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) kt[u] = ld_c(rk, off_of(t_of(t0, u)));
+    for (int u = 0; u < U; u++) kt[u] = NT ? ld_nt(rk, off_of(t_of(t0, u))) : ld_c(rk, off_of(t_of(t0, u)));
 #pragma unroll
-    for (int u = 0; u < U; u++) vt[u] = ld_c(rv, off_of(t_of(t0, u)));     // needed only after the softmax
+    for (int u = 0; u < U; u++) vt[u] = NT ? ld_nt(rv, off_of(t_of(t0, u))) : ld_c(rv, off_of(t_of(t0, u)));     // needed only after the softmax
     __builtin_amdgcn_sched_barrier(0);
 
     // scores: att[t] = (q . k_t) / sqrt(hs)     (cpu.rs:34-41); s_att is indexed from t0
     for (int base = t0; base < t1; base += TILE) {
         if (base > t0) {
 #pragma unroll
-            for (int u = 0; u < U; u++) kt[u] = ld_c(rk, off_of(t_of(base, u)));
+            for (int u = 0; u < U; u++) kt[u] = NT ? ld_nt(rk, off_of(t_of(base, u))) : ld_c(rk, off_of(t_of(base, u)));
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -642,7 +660,7 @@ __global__ __launch_bounds__(W * 64) void attention_kernel(AttnParams p) {
     for (int base = t0; base < t1; base += TILE) {
         if (base > t0) {
 #pragma unroll
-            for (int u = 0; u < U; u++) vt[u] = ld_c(rv, off_of(t_of(base, u)));
+            for (int u = 0; u < U; u++) vt[u] = NT ? ld_nt(rv, off_of(t_of(base, u))) : ld_c(rv, off_of(t_of(base, u)));
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll

@@ -18,6 +18,8 @@
 
 using namespace rama;
 
+extern "C" const float* rama_internal_w13_lookup(const float* w1, const float* w3);   // model.hip
+
 // ---------------------------------------------------------------- error plumbing
 
 static thread_local std::string g_err;
@@ -75,6 +77,7 @@ struct rama_ctx {
     int cu_count = 0;
     hipEvent_t cur_start = nullptr, cur_stop = nullptr;   // events the next profiled launch carries
     int tune_geom = 3;
+    int tune_w13i = 1;                     // 1: the fused W1|W3 launch streams the model's row-interleaved copy when there is one
     int tune_solo = -1;                    // small-K matvecs, one wave per row group: 1 on, 0 off, -1 = rows of <= 2048 floats
     int tune_ref_order = 0;                // 1: every op in the reference's own rounding order (ref_order.hpp): bit-comparable, slow
     // device top-p sampler (Device::sample for temperature != 0); temperature 0 = argmax
@@ -98,6 +101,9 @@ struct rama_ctx {
     int host_pos = -1;                     // position of the next chained decode step (mirrors the device cursor)
     bool split_attn = false;               // variant the steps being enqueued / captured use
     bool small_attn = false;               // 4-wave attention workgroups (contexts of <= kSmallAttnPos timesteps)
+    int tune_attn_nsplit = 0;              // split-T slices per head: 0 = #CUs / n_heads (<= 16), else 1..32
+    int tune_attn_waves = 8;               // waves per split-T workgroup (16, 8 or 4); 8 measured best at llama2-7B, 1000-1900 tokens
+    int tune_attn_nt = 1;                  // 1: split-T attention reads the cache rows non-temporally (+2.7 % tokens/s at 1900 tokens)
     int tune_small_attn = 0;               // 4-wave attention in the decode step: 0 never (default: measured equal to the merged
                                            // attention+Wo launch at the stories shapes and to the 16-wave kernel at llama2-7B), 1 whenever
                                            // it fits, -1 below kSmallAttnPos
@@ -414,7 +420,10 @@ int rama_softmax(rama_ctx* c, float* x, size_t n) {
     LAUNCHCHK(); return 0;
 }
 
-static int attn_nsplit(const rama_ctx* c, int n_heads) { return std::max(1, std::min(16, c->cu_count / std::max(n_heads, 1))); }
+static int attn_nsplit(const rama_ctx* c, int n_heads) {
+    if (c->tune_attn_nsplit > 0) return c->tune_attn_nsplit;
+    return std::max(1, std::min(16, c->cu_count / std::max(n_heads, 1)));
+}
 
 // scratch for the split-T partials; called outside any stream capture (no allocation inside one)
 static int ensure_attn_part(rama_ctx* c, const rama_config* cfg) {
@@ -463,11 +472,15 @@ static int launch_attention(rama_ctx* c, float* xb, float* att, const float* q, 
         REQUIRE((size_t)n_heads * nsplit * (head_size + 4) <= c->attn_part_floats, RAMA_EINVAL, "attention: split-T scratch not prepared");
         p.part = c->attn_part; p.nsplit = nsplit; p.att = nullptr;
         const int chunk_max = (seq_len + nsplit - 1) / nsplit;
-        size_t shm = (size_t)(attn_scratch_floats(G) + chunk_max) * sizeof(float);
         dim3 grid(n_heads, nsplit);
-        if (G == 16) RAMA_LAUNCH(c, (attention_kernel<16, true>), grid, dim3(kAttnThreads), shm, p);
-        else if (G == 32) RAMA_LAUNCH(c, (attention_kernel<32, true>), grid, dim3(kAttnThreads), shm, p);
-        else RAMA_LAUNCH(c, (attention_kernel<64, true>), grid, dim3(kAttnThreads), shm, p);
+        // template dispatch: G lanes per row x W waves per workgroup x cache-load policy
+#define RAMA_SPLIT_LAUNCH(G_, W_, NT_) RAMA_LAUNCH(c, (attention_kernel<G_, true, W_, NT_>), grid, dim3(W_ * 64), (size_t)(attn_scratch_floats(G_, W_) + chunk_max) * sizeof(float), p)
+#define RAMA_SPLIT_G(W_, NT_) do { if (G == 16) RAMA_SPLIT_LAUNCH(16, W_, NT_); else if (G == 32) RAMA_SPLIT_LAUNCH(32, W_, NT_); else RAMA_SPLIT_LAUNCH(64, W_, NT_); } while (0)
+        const int W = c->tune_attn_waves;
+        if (c->tune_attn_nt) { if (W == 4) RAMA_SPLIT_G(4, true); else if (W == 8) RAMA_SPLIT_G(8, true); else RAMA_SPLIT_G(16, true); }
+        else { if (W == 4) RAMA_SPLIT_G(4, false); else if (W == 8) RAMA_SPLIT_G(8, false); else RAMA_SPLIT_G(16, false); }
+#undef RAMA_SPLIT_G
+#undef RAMA_SPLIT_LAUNCH
         LAUNCHCHK();
         hipLaunchKernelGGL(attention_combine_kernel, dim3(n_heads), dim3(((head_size + 63) / 64) * 64), 0, c->stream,
                            (const float*)c->attn_part, xb, head_size, nsplit);
@@ -654,6 +667,7 @@ static int enqueue_stage(rama_ctx* c, const rama_config* cfg, const rama_weights
     if (c->tune_ref_order) return enqueue_stage_ref(c, cfg, w, s, st);
     const int dim = cfg->dim, hidden = cfg->hidden_dim, hs = dim / cfg->n_heads;
     const size_t dd = (size_t)dim * dim, hd = (size_t)hidden * dim;
+    const float* w13i = (st->layer_end > st->layer_begin && (double)hidden * dim * 8.0 < 2147483648.0) ? rama_internal_w13_lookup(w->w1, w->w3) : nullptr;
     if (st->do_embed) {
         hipLaunchKernelGGL(embed_kernel, dim3((dim + 255) / 256), dim3(256), 0, c->stream, s->x, w->token_embedding_table, (const Ctl*)c->ctl, 0, dim);
         LAUNCHCHK();
@@ -701,15 +715,29 @@ static int enqueue_stage(rama_ctx* c, const rama_config* cfg, const rama_weights
         }
         {   // infer.rs:39-45: rmsnorm, W1|W3, SiLU * gate
             KTimer kt(c, RAMA_K_W13);
-            SwigluParams p{};
-            p.w1 = w->w1 + li * hd; p.w3 = w->w3 + li * hd; p.x = s->x; p.nw = w->rms_ffn_weight + li * dim;
-            p.hb = s->hb; p.K = dim; p.rows = hidden;
-            if (use_solo(c, dim)) {
-                const dim3 grid(((hidden + 1) / 2 + kSoloWaves - 1) / kSoloWaves), block(kSoloWaves * 64);
-                if (dim <= 512) RAMA_LAUNCH(c, (gemv_swiglu_solo<2, 2>), grid, block, 0, p);
-                else RAMA_LAUNCH(c, (gemv_swiglu_solo<2, 4>), grid, block, 0, p);
+            if (w13i && c->tune_w13i) {
+                // the model's row-interleaved copy: one [2 hidden, dim] matrix, rows (2i, 2i + 1) = (W1 row i, W3 row i)
+                GemvParams p{};
+                p.w[0] = w13i + li * 2 * hd; p.x = s->x; p.nw = w->rms_ffn_weight + li * dim; p.o[0] = s->hb;
+                p.K = dim; p.rows = 2 * hidden; p.nmat = 1;
+                if (use_solo(c, dim)) {
+                    const dim3 grid(((2 * hidden + 3) / 4 + kSoloWaves - 1) / kSoloWaves), block(kSoloWaves * 64);
+                    if (dim <= 512) RAMA_LAUNCH(c, (gemv_rows_solo<4, 2, true, EPI_SWIGLU_PAIR>), grid, block, 0, p);
+                    else RAMA_LAUNCH(c, (gemv_rows_solo<4, 4, true, EPI_SWIGLU_PAIR>), grid, block, 0, p);
+                } else {
+                    RAMA_LAUNCH(c, (gemv_rows<4, 2, 8, true, EPI_SWIGLU_PAIR>), dim3((2 * hidden + 3) / 4), dim3(8 * 64), 0, p);
+                }
             } else {
-                DISPATCH_GEOM(c, RAMA_LAUNCH(c, (gemv_swiglu<R2_, CH_, NW_>), dim3((hidden + R2_ - 1) / R2_), dim3(NW_ * 64), 0, p));
+                SwigluParams p{};
+                p.w1 = w->w1 + li * hd; p.w3 = w->w3 + li * hd; p.x = s->x; p.nw = w->rms_ffn_weight + li * dim;
+                p.hb = s->hb; p.K = dim; p.rows = hidden;
+                if (use_solo(c, dim)) {
+                    const dim3 grid(((hidden + 1) / 2 + kSoloWaves - 1) / kSoloWaves), block(kSoloWaves * 64);
+                    if (dim <= 512) RAMA_LAUNCH(c, (gemv_swiglu_solo<2, 2>), grid, block, 0, p);
+                    else RAMA_LAUNCH(c, (gemv_swiglu_solo<2, 4>), grid, block, 0, p);
+                } else {
+                    DISPATCH_GEOM(c, RAMA_LAUNCH(c, (gemv_swiglu<R2_, CH_, NW_>), dim3((hidden + R2_ - 1) / R2_), dim3(NW_ * 64), 0, p));
+                }
             }
             LAUNCHCHK();
         }
@@ -1271,9 +1299,32 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
         drop_graph(c);
         return 0;
     }
+    if (!strcmp(key, "attn_nsplit") || !strcmp(key, "attn_nt")) {
+        const bool ns = !strcmp(key, "attn_nsplit");
+        REQUIRE(value >= 0 && value <= (ns ? 32 : 1), RAMA_EINVAL, "set_tuning: attn_nsplit must be 0..32, attn_nt 0 or 1");
+        HIPCHK(hipStreamSynchronize(c->stream));
+        drop_graph(c);
+        if (ns) { c->tune_attn_nsplit = value; if (c->attn_part) { hipFree(c->attn_part); c->attn_part = nullptr; c->attn_part_floats = 0; } }
+        else c->tune_attn_nt = value;
+        return 0;
+    }
+    if (!strcmp(key, "attn_waves")) {
+        REQUIRE(value == 16 || value == 8 || value == 4, RAMA_EINVAL, "set_tuning: attn_waves must be 16, 8 or 4");
+        HIPCHK(hipStreamSynchronize(c->stream));
+        drop_graph(c);
+        c->tune_attn_waves = value;
+        return 0;
+    }
     if (!strcmp(key, "small_attn")) {
         REQUIRE(value >= -1 && value <= 1, RAMA_EINVAL, "set_tuning: small_attn must be -1, 0 or 1");
         c->tune_small_attn = value;
+        hipStreamSynchronize(c->stream);
+        drop_graph(c);
+        return 0;
+    }
+    if (!strcmp(key, "w13i")) {
+        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: w13i must be 0 or 1");
+        c->tune_w13i = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
         return 0;
