@@ -236,7 +236,7 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *                   3 is the shipping choice, see rama_api.hip DISPATCH_GEOM
  *   "split_pos" = -1 | N : attention switches from one workgroup per head to the split-T variant
  *                   (n_heads x nsplit workgroups + a combine launch) at position N; -1 (default)
- *                   chooses by model size: 384 when one head's whole K+V cache exceeds 1 MiB
+ *                   chooses by model size: 256 when one head's whole K+V cache exceeds 1 MiB
  *                   (llama2-7B), never below that (stories15M / 110M), as measured
  *   "resid_r2" = 0..3 : geometry of the two residual matvecs (Wo, W2) under geometry 3: 0 = 4-row
  *                   workgroups like the rest; 1 = 2 rows x 8 waves (+0.45 % tokens/s at llama2-7B);

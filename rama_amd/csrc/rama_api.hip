@@ -439,9 +439,10 @@ static int ensure_attn_part(rama_ctx* c, const rama_config* cfg) {
 
 // Split-T attention is worth its extra (combine) launch once a head's cache no longer fits a
 // couple of single-workgroup rounds; below the threshold one workgroup per head is faster.
-constexpr int kSplitTPos = 384;
-// Measured (tools/split_sweep.py): at llama2-7B (32 heads x 128) splitting wins from ~position 400 on
-// (209 -> 212 tok/s at 600, 177 -> 205 at 1900); at the stories110M shape (12 heads x 64, 1024
+constexpr int kSplitTPos = 256;
+// Measured (tools/split_sweep.py, round 2: 8-wave slices, nt cache loads): at llama2-7B (32 heads x 128)
+// splitting wins from ~position 256 on (227 -> 231 tok/s at 300, 217 -> 229 at 600, 183 -> 219 at 1900) and
+// loses below it (237 vs 231 at 200); at the stories110M shape (12 heads x 64, 1024
 // positions) the single-workgroup kernel wins everywhere (2 837 vs 2 082 tok/s at 900), because
 // its whole per-head cache is a few rounds of one workgroup and the combine launch costs more.
 static int split_threshold(const rama_ctx* c, const rama_config* cfg) {

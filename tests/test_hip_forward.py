@@ -381,11 +381,11 @@ def _long_ctx_case(n_heads, hs, seq_len=2048, seed=11):
     return cfg, w, kc, vc
 
 
-@pytest.mark.parametrize("split_pos", [384, -1, 1 << 30])
+@pytest.mark.parametrize("split_pos", [256, -1, 1 << 30])
 @pytest.mark.parametrize("n_heads,hs", [(2, 128), (4, 64), (6, 48)])
 def test_split_t_attention_long_context(dev, n_heads, hs, split_pos):
     """long contexts through both attention variants: split-T (n_heads x nsplit workgroups +
-    combine) forced from position 384, the default choice by model size (-1), and the
+    combine) forced from position 256, the default choice by model size (-1), and the
     single-workgroup kernel only; all must give the oracle's logits (one softmax over ALL timesteps)."""
     import rama_amd
     from rama_amd._lib import check
@@ -394,7 +394,7 @@ def test_split_t_attention_long_context(dev, n_heads, hs, split_pos):
     rcfg, ws, wv, rs, rsv = gpu_views(dev, cfg, w)
     check(dev.lib.rama_set_tuning(dev.ctx, b"split_pos", split_pos))
     try:
-        for pos in (383, 384, 385, 1000, 2047):
+        for pos in (255, 256, 257, 1000, 2047):
             orc.s["key_cache"][:] = kc; orc.s["value_cache"][:] = vc
             dev.upload_into(rsv.key_cache, kc); dev.upload_into(rsv.value_cache, vc)
             lo = orc.forward(5, pos).copy()
@@ -411,12 +411,12 @@ def test_split_t_attention_long_context(dev, n_heads, hs, split_pos):
 
 @pytest.mark.parametrize("graph", [False, True])
 def test_decode_across_split_threshold(dev, graph):
-    """a chained greedy run from pos 370 to 400 switches attention variant (and hipGraph) at 384"""
+    """a chained greedy run from pos 242 to 272 switches attention variant (and hipGraph) at 256"""
     import ctypes as C
     import rama_amd
     from rama_amd._lib import S_FIELDS, check, rama_run_state
     cfg, w, kc, vc = _long_ctx_case(2, 128)
-    start, steps = 370, 30
+    start, steps = 242, 30
     orc = O.Oracle(cfg, w)
     orc.s["key_cache"][:] = kc; orc.s["value_cache"][:] = vc
     token, want = 7, []
