@@ -127,6 +127,9 @@ typedef struct {
  * one hipMalloc for the tensor blob, one staged H2D copy (replaces 6.7 G four-byte reads,
  * utils/read.rs:25-33, + 14 htod_sync_copy, hbm.rs:55-90). */
 int  rama_model_load(rama_ctx *ctx, const char *path, rama_model **out);
+/* the same for one pipeline stage: only the stage's layers (and the embedding / classifier tensors it
+ * needs) are copied to this device */
+int  rama_model_load_stage(rama_ctx *ctx, const char *path, const rama_stage *stage, rama_model **out);
 /* Synthetic weights of a given shape, generated in HBM by an integer-hash fill kernel
  * (bit-identical to oracle_fill_synth); only layers of `stage` are materialised.
  * rope_real/rope_imag: host tables [seq_len, head_size/2] or NULL (computed here). */
@@ -198,6 +201,44 @@ int  rama_forward_stage_devtok(rama_ctx *ctx, const rama_config *cfg, const rama
                                rama_run_state *s, const int32_t *token_dev, int pos,
                                const rama_stage *stage);
 int  rama_argmax_dev(rama_ctx *ctx, const float *logits, size_t n, int32_t *result_dev);
+
+/* ---------------------------------------------------------------- layer pipeline over RCCL (csrc/pipe.hip)
+ * One process per GPU; rank r owns layers [r*L/N, (r+1)*L/N) (rama_model_load_stage / rama_model_synth
+ * with a stage), n_seq >= N sequences in flight.  Rank 0 obtains a unique id and ships its
+ * RAMA_PIPE_ID_BYTES bytes to the other ranks by any side channel (a file, an environment variable,
+ * a torch.distributed / MPI broadcast); every rank then creates its end.  RCCL is loaded with dlopen on
+ * first use.  All exchanges are enqueued on the context's stream. */
+#define RAMA_PIPE_ID_BYTES 128
+typedef struct rama_pipe rama_pipe;
+int  rama_pipe_unique_id(void *id_out /* RAMA_PIPE_ID_BYTES */);
+int  rama_pipe_create(rama_ctx *ctx, const void *id_bytes, int rank, int world, rama_pipe **out);
+int  rama_pipe_destroy(rama_pipe *pipe);
+/* One grouped exchange (ncclGroupStart .. ncclGroupEnd): each of the four legs is skipped when its
+ * buffer is NULL.  x legs carry float[n], token legs one int32; peers are ranks of the pipe. */
+int  rama_pipe_exchange(rama_pipe *pipe, const float *send_x, size_t n_send_x, int send_x_peer,
+                        float *recv_x, size_t n_recv_x, int recv_x_peer,
+                        const int32_t *send_tok, int send_tok_peer, int32_t *recv_tok, int recv_tok_peer);
+/* The schedule: item j = (slot j % S, position j / S), S = max(n_seq, world) slots per round (slots
+ * beyond n_seq idle); rank r computes item tick - r at each tick (BOS at position 0, the forced
+ * prompt tokens next, mod.rs:182-191, then the token the last rank sampled: argmax at temperature 0,
+ * else the device top-p sampler), then exchanges: x[dim] to rank r + 1, the sampled id from the last
+ * rank to rank 0.  wrap > 0: a sequence that reaches position `wrap` starts a new generation at 0 in
+ * the same slot. */
+typedef struct {
+    int32_t n_seq, n_pos, wrap;
+    const int32_t *prompt;        /* host: forced prompt tokens, the same for every sequence */
+    int32_t n_prompt;
+    float temperature, topp, u;   /* Device::sample on the last rank (u = the reference's constant draw) */
+    int32_t *out_tokens_dev;      /* rank 0, optional: device [n_seq, n_pos], the id sampled AFTER each position */
+} rama_pipe_plan;
+int  rama_pipe_total_ticks(const rama_pipe *pipe, const rama_pipe_plan *plan);   /* S * n_pos + world - 1 */
+/* Runs ticks [tick_from, tick_to) of this rank: states[s] is sequence s's run state for this stage
+ * (its x is the hand-off buffer), tok_dev[s] its device token word.  Asynchronous on the context's
+ * stream; after the last tick of the last rank tok_dev[s] holds sequence s's newest token. */
+int  rama_pipe_run_ticks(rama_pipe *pipe, const rama_config *cfg, const rama_weights *w, rama_run_state *states,
+                         int32_t *const *tok_dev, const rama_stage *stage, const rama_pipe_plan *plan,
+                         int tick_from, int tick_to);
+const char *rama_pipe_last_error(void);
 
 /* generate() loop of mod.rs:169-206 at temperature 0, chained on the device: token = 1 (BOS)
  * at pos 0; while pos < steps: forward; next = pos < n_prompt ? prompt[pos] : argmax(logits);

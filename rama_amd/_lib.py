@@ -45,6 +45,11 @@ class rama_stage(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("layer_begin", "layer_end", "do_embed", "do_cls")]
 
 
+class rama_pipe_plan(C.Structure):
+    _fields_ = [("n_seq", C.c_int32), ("n_pos", C.c_int32), ("wrap", C.c_int32), ("prompt", C.POINTER(C.c_int32)), ("n_prompt", C.c_int32),
+                ("temperature", C.c_float), ("topp", C.c_float), ("u", C.c_float), ("out_tokens_dev", C.c_void_p)]
+
+
 # name -> (restype, argtypes); every symbol include/rama_hip.h declares
 _vp, _sz, _int = C.c_void_p, C.c_size_t, C.c_int
 _cfgp, _wp, _sp, _stp = C.POINTER(rama_config), C.POINTER(rama_weights), C.POINTER(rama_run_state), C.POINTER(rama_stage)
@@ -71,6 +76,7 @@ SIGNATURES = {
     "rama_sample_argmax": (_int, [_vp, _vp, _sz, i32p]),
     "rama_sample_topp": (_int, [_vp, _vp, _sz, C.c_float, C.c_float, C.c_float, i32p]),
     "rama_model_load": (_int, [_vp, C.c_char_p, C.POINTER(_vp)]),
+    "rama_model_load_stage": (_int, [_vp, C.c_char_p, _stp, C.POINTER(_vp)]),
     "rama_model_synth": (_int, [_vp, _cfgp, C.c_uint64, _stp, _vp, _vp, C.POINTER(_vp)]),
     "rama_model_save": (_int, [_vp, _vp, C.c_char_p]),
     "rama_model_tune_placement": (_int, [_vp, _vp, _int, _vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
@@ -97,6 +103,13 @@ SIGNATURES = {
     "rama_set_graph_mode": (_int, [_vp, _int]),
     "rama_set_tuning": (_int, [_vp, C.c_char_p, _int]),
     "rama_ref_expf": (_int, [_vp, _vp, _vp, _sz]),
+    "rama_pipe_unique_id": (_int, [_vp]),
+    "rama_pipe_create": (_int, [_vp, _vp, _int, _int, C.POINTER(_vp)]),
+    "rama_pipe_destroy": (_int, [_vp]),
+    "rama_pipe_exchange": (_int, [_vp, _vp, _sz, _int, _vp, _sz, _int, _vp, _int, _vp, _int]),
+    "rama_pipe_total_ticks": (_int, [_vp, _vp]),
+    "rama_pipe_run_ticks": (_int, [_vp, _cfgp, _wp, _sp, C.POINTER(_vp), _stp, _vp, _int, _int]),
+    "rama_pipe_last_error": (C.c_char_p, []),
     "rama_timer_start": (_int, [_vp]),
     "rama_timer_stop": (_int, [_vp, C.POINTER(C.c_float)]),
     "rama_kprof_enable": (_int, [_vp, _int, _int]),

@@ -704,15 +704,27 @@ __global__ void attention_combine_kernel(const float* part, float* xb, int head_
     const int h = blockIdx.x, i = threadIdx.x;
     const size_t ps = (size_t)(head_size + 4);
     const float* ph = part + (size_t)h * nsplit * ps;
+    // every slice's (max, sum, acc[i]) is requested before the first use: the launch is one cache
+    // round trip, not one per slice (it sits on the critical path of every long-context layer)
+    constexpr int MAXS = 32;
+    float m[MAXS], l[MAXS], a[MAXS];
+#pragma unroll
+    for (int s = 0; s < MAXS; s++) {
+        const bool on = s < nsplit;
+        m[s] = on ? ph[s * ps] : -INFINITY;
+        l[s] = on ? ph[s * ps + 1] : 0.0f;
+        a[s] = (on && i < head_size) ? ph[s * ps + 4 + i] : 0.0f;
+    }
     float M = -INFINITY;
-    for (int s = 0; s < nsplit; s++) if (ph[s * ps + 1] > 0.0f) M = fmaxf(M, ph[s * ps]);
+#pragma unroll
+    for (int s = 0; s < MAXS; s++) if (l[s] > 0.0f) M = fmaxf(M, m[s]);
     float L = 0.0f, o = 0.0f;
-    for (int s = 0; s < nsplit; s++) {
-        const float l = ph[s * ps + 1];
-        if (l > 0.0f) {
-            const float sc = expf(ph[s * ps] - M);
-            L += sc * l;
-            if (i < head_size) o += sc * ph[s * ps + 4 + i];
+#pragma unroll
+    for (int s = 0; s < MAXS; s++) {
+        if (l[s] > 0.0f) {
+            const float sc = expf(m[s] - M);
+            L += sc * l[s];
+            o += sc * a[s];
         }
     }
     if (i < head_size) xb[(size_t)h * head_size + i] = o / L;

@@ -118,7 +118,7 @@ extern "C" const float* rama_internal_w13_lookup(const float* w1, const float* w
     return nullptr;
 }
 
-extern "C" int rama_model_load(rama_ctx* ctx, const char* path, rama_model** out) {
+extern "C" int rama_model_load_stage(rama_ctx* ctx, const char* path, const rama_stage* stage, rama_model** out) {
     if (!ctx || !path || !out) return bad(RAMA_EINVAL, "rama_model_load: NULL argument");
     int fd = open(path, O_RDONLY);
     if (fd < 0) return bad(RAMA_EIO, "cannot open checkpoint");
@@ -151,24 +151,56 @@ extern "C" int rama_model_load(rama_ctx* ctx, const char* path, rama_model** out
         munmap(map, sb.st_size);
         return bad(RAMA_EIO, "checkpoint size does not match its header (ram.rs:28-51 layout)");
     }
+    const rama_stage st = stage ? *stage : rama_stage{0, c.n_layers, 1, 1};
+    if (st.layer_begin < 0 || st.layer_begin > st.layer_end || st.layer_end > c.n_layers) {
+        munmap(map, sb.st_size);
+        return bad(RAMA_EINVAL, "rama_model_load_stage: bad layer range");
+    }
+    const bool whole = st.layer_begin == 0 && st.layer_end == c.n_layers && st.do_embed && st.do_cls;
+    const size_t nl = (size_t)(st.layer_end - st.layer_begin);
+    const bool need_emb = st.do_embed || (st.do_cls && c.shared_weight);
+    // which floats of each tensor this stage owns (a whole model: the file's blob as it is, one copy)
+    struct Piece { const char* name; size_t n, file_off; };
+    std::vector<Piece> pieces;
+    size_t need = 0, foff = 0;
+    for (auto& t : layout) {
+        size_t n = t.n, src = 0;
+        if (!whole) {
+            if (t.per_layer) { n = nl * t.per_layer; src = (size_t)st.layer_begin * t.per_layer; }
+            else if (!strcmp(t.name, "token_embedding_table")) n = need_emb ? t.n : 0;
+            else if (!strcmp(t.name, "rms_final_weight") || !strcmp(t.name, "wcls")) n = st.do_cls ? t.n : 0;
+        }
+        if (n) { pieces.push_back({t.name, n, foff + src}); need += whole ? n : align64(n); }
+        foff += t.n;
+    }
     rama_model* m = new rama_model();
     m->cfg = c;
-    m->stage = rama_stage{0, c.n_layers, 1, 1};
-    m->blob_floats = total;
-    int rc = rama_alloc_f32(ctx, total, &m->blob);
+    m->stage = st;
+    m->blob_floats = need;
+    int rc = rama_alloc_f32(ctx, need, &m->blob);
     if (rc) { munmap(map, sb.st_size); delete m; return rc; }
     // 28-byte header => the tensor blob starts 12 bytes off a 16-byte boundary in the file,
     // but lands 256-byte aligned in HBM; every tensor size is a multiple of 4 floats.
-    rc = rama_copy_h2d_f32(ctx, m->blob, (const float*)((const char*)map + 28), total);
+    const float* file = (const float*)((const char*)map + 28);
+    size_t off = 0;
+    if (whole) rc = rama_copy_h2d_f32(ctx, m->blob, file, total);
+    for (auto& pc : pieces) {
+        *field(m->w, pc.name) = m->blob + off;
+        if (!whole && !rc) rc = rama_copy_h2d_f32(ctx, m->blob + off, file + pc.file_off, pc.n);
+        off += whole ? pc.n : align64(pc.n);
+    }
     munmap(map, sb.st_size);
     if (rc) { rama_free(ctx, m->blob); delete m; return rc; }
-    size_t off = 0;
-    for (auto& t : layout) { *field(m->w, t.name) = m->blob + off; off += t.n; }
-    if (c.shared_weight) m->w.wcls = m->w.token_embedding_table;   // state.rs:111-117
+    if (c.shared_weight && st.do_cls) m->w.wcls = m->w.token_embedding_table;   // state.rs:111-117
+    if (!st.do_embed && !(st.do_cls && c.shared_weight)) m->w.token_embedding_table = nullptr;
     rc = make_w13i(ctx, m);
     if (rc) { rama_free(ctx, m->blob); delete m; return rc; }
     *out = m;
     return 0;
+}
+
+extern "C" int rama_model_load(rama_ctx* ctx, const char* path, rama_model** out) {
+    return rama_model_load_stage(ctx, path, nullptr, out);
 }
 
 extern "C" int rama_model_synth(rama_ctx* ctx, const rama_config* cfg, uint64_t seed, const rama_stage* stage,

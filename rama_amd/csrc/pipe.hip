@@ -1,0 +1,208 @@
+// pipe.hip -- the layer pipeline under the C ABI: RCCL point-to-point directly, no torch.
+// New functionality (the reference is single-device, gpu.rs:215).
+//
+// Partition: rank r owns layers [r*L/N, (r+1)*L/N) with their weights and KV slabs, rank 0 the
+// embedding table, the last rank the final norm + classifier.  A stage boundary is one ncclSend /
+// ncclRecv of the residual x[dim] (16 KiB at llama2-7B) to the next rank, and of the sampled token
+// id (4 bytes) from the last rank back to rank 0 -- point-to-point over xGMI, no collective.
+// Batch-1 decode is sequential in the layers, so n_seq >= N sequences are kept in flight to keep every
+// stage busy: item j = (slot j % S, position j / S) with S = max(n_seq, N) slots per round (slots
+// beyond n_seq idle: a single sequence works too, N - 1 of N ticks idle per stage); rank r computes
+// item tick - r at each tick, then
+// posts ONE grouped exchange (its output to the next rank + the receive of its next input), which
+// is deadlock-free for any N including N = 2, where both directions share one peer.  Everything is
+// enqueued on the context's stream: no host synchronisation inside the loop.
+//
+// RCCL is loaded with dlopen on first use, so the single-GPU product has no RCCL dependency.
+#include "../../include/rama_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+extern "C" void* rama_internal_stream(rama_ctx* c);      // rama_api.hip
+extern "C" int rama_internal_device(rama_ctx* c);
+
+namespace {
+
+struct Rccl {
+    void* h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+thread_local std::string g_pipe_err;
+
+int bad(int code, const std::string& msg) {
+    g_pipe_err = msg;
+    fprintf(stderr, "rama_pipe: %s\n", msg.c_str());
+    return code;
+}
+
+int load_rccl() {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.h) return 0;
+    void* h = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return bad(RAMA_EIO, std::string("cannot load librccl: ") + dlerror());
+    Rccl r;
+    r.h = h;
+#define SYM(field, name) *(void**)(&r.field) = dlsym(h, name); if (!r.field) { dlclose(h); return bad(RAMA_EIO, "librccl lacks " name); }
+    SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
+    SYM(Send, "ncclSend") SYM(Recv, "ncclRecv") SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd")
+    SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    g_rccl = r;
+    return 0;
+}
+
+#define NCHK(expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) return bad(RAMA_EIO, std::string(#expr) + ": " + g_rccl.GetErrorString(r_)); } while (0)
+
+}  // namespace
+
+struct rama_pipe {
+    rama_ctx* ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+};
+
+static_assert(RAMA_PIPE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "rama_hip.h must carry RCCL's unique-id size");
+
+extern "C" int rama_pipe_unique_id(void* id_out) {
+    if (!id_out) return bad(RAMA_EINVAL, "rama_pipe_unique_id: NULL argument");
+    int rc = load_rccl(); if (rc) return rc;
+    ncclUniqueId id;
+    NCHK(g_rccl.GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof id);
+    return 0;
+}
+
+extern "C" int rama_pipe_create(rama_ctx* ctx, const void* id_bytes, int rank, int world, rama_pipe** out) {
+    if (!ctx || !id_bytes || !out || world < 1 || rank < 0 || rank >= world) return bad(RAMA_EINVAL, "rama_pipe_create: bad argument");
+    int rc = load_rccl(); if (rc) return rc;
+    if (hipSetDevice(rama_internal_device(ctx)) != hipSuccess) return bad(RAMA_EIO, "rama_pipe_create: hipSetDevice failed");
+    ncclUniqueId id;
+    memcpy(&id, id_bytes, sizeof id);
+    rama_pipe* p = new rama_pipe();
+    p->ctx = ctx; p->rank = rank; p->world = world;
+    ncclResult_t r = g_rccl.CommInitRank(&p->comm, world, id, rank);
+    if (r != ncclSuccess) { delete p; return bad(RAMA_EIO, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r)); }
+    *out = p;
+    return 0;
+}
+
+extern "C" int rama_pipe_destroy(rama_pipe* p) {
+    if (!p) return 0;
+    rama_sync(p->ctx);
+    if (p->comm) g_rccl.CommDestroy(p->comm);
+    delete p;
+    return 0;
+}
+
+extern "C" int rama_pipe_exchange(rama_pipe* p, const float* send_x, size_t n_send_x, int send_x_peer,
+                                  float* recv_x, size_t n_recv_x, int recv_x_peer,
+                                  const int32_t* send_tok, int send_tok_peer, int32_t* recv_tok, int recv_tok_peer) {
+    if (!p) return bad(RAMA_EINVAL, "rama_pipe_exchange: NULL pipe");
+    if (!send_x && !recv_x && !send_tok && !recv_tok) return 0;
+    hipStream_t st = (hipStream_t)rama_internal_stream(p->ctx);
+    auto peer_ok = [&](int peer) { return peer >= 0 && peer < p->world; };
+    if ((send_x && !peer_ok(send_x_peer)) || (recv_x && !peer_ok(recv_x_peer)) || (send_tok && !peer_ok(send_tok_peer)) ||
+        (recv_tok && !peer_ok(recv_tok_peer)))
+        return bad(RAMA_EINVAL, "rama_pipe_exchange: peer outside the communicator");
+    NCHK(g_rccl.GroupStart());
+    ncclResult_t r = ncclSuccess;
+    if (send_x) r = g_rccl.Send(send_x, n_send_x, ncclFloat32, send_x_peer, p->comm, st);
+    if (r == ncclSuccess && send_tok) r = g_rccl.Send(send_tok, 1, ncclInt32, send_tok_peer, p->comm, st);
+    if (r == ncclSuccess && recv_x) r = g_rccl.Recv(recv_x, n_recv_x, ncclFloat32, recv_x_peer, p->comm, st);
+    if (r == ncclSuccess && recv_tok) r = g_rccl.Recv(recv_tok, 1, ncclInt32, recv_tok_peer, p->comm, st);
+    ncclResult_t e = g_rccl.GroupEnd();
+    if (r != ncclSuccess) return bad(RAMA_EIO, std::string("ncclSend/ncclRecv: ") + g_rccl.GetErrorString(r));
+    if (e != ncclSuccess) return bad(RAMA_EIO, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(e));
+    return 0;
+}
+
+// ---- the schedule (pure bookkeeping, mirrored by rama_amd/pipeline.py Schedule and its gloo tests)
+namespace {
+struct Item { bool on; int seq, pos; };
+int slots_of(const rama_pipe_plan& pl, int world) { return pl.n_seq > world ? pl.n_seq : world; }
+Item item_of(const rama_pipe_plan& pl, int world, int rank, int tick) {
+    const long S = slots_of(pl, world), j = (long)tick - rank, total = S * pl.n_pos;
+    if (j < 0 || j >= total) return {false, 0, 0};
+    const int seq = (int)(j % S);
+    return {seq < pl.n_seq, seq, (int)(j / S)};
+}
+}  // namespace
+
+extern "C" int rama_pipe_total_ticks(const rama_pipe* p, const rama_pipe_plan* plan) {
+    if (!p || !plan) return -1;
+    return slots_of(*plan, p->world) * plan->n_pos + p->world - 1;
+}
+
+extern "C" int rama_pipe_run_ticks(rama_pipe* p, const rama_config* cfg, const rama_weights* w, rama_run_state* states,
+                                   int32_t* const* tok_dev, const rama_stage* stage, const rama_pipe_plan* plan,
+                                   int tick_from, int tick_to) {
+    if (!p || !cfg || !w || !states || !tok_dev || !stage || !plan) return bad(RAMA_EINVAL, "rama_pipe_run_ticks: NULL argument");
+    if (plan->n_seq < 1 || plan->n_pos < 1) return bad(RAMA_EINVAL, "rama_pipe_run_ticks: n_seq and n_pos must be positive");
+    if (plan->n_prompt < 0 || (plan->n_prompt && !plan->prompt)) return bad(RAMA_EINVAL, "rama_pipe_run_ticks: bad prompt");
+    const int rank = p->rank, world = p->world, last = world - 1;
+    for (int tick = tick_from; tick < tick_to; tick++) {
+        const Item it = item_of(*plan, world, rank, tick);
+        if (it.on) {
+            const int pos = plan->wrap > 0 ? it.pos % plan->wrap : it.pos;
+            rama_run_state* st = &states[it.seq];
+            int rc;
+            if (rank == 0 && pos == 0) rc = rama_forward_stage(p->ctx, cfg, w, st, /*BOS, mod.rs:182*/ 1, pos, stage);
+            else if (rank == 0 && pos <= plan->n_prompt) rc = rama_forward_stage(p->ctx, cfg, w, st, plan->prompt[pos - 1], pos, stage);   // mod.rs:190-191
+            else rc = rama_forward_stage_devtok(p->ctx, cfg, w, st, rank == 0 ? tok_dev[it.seq] : nullptr, pos, stage);
+            if (rc) return rc;
+            if (rank == last) {      // Device::sample (cpu.rs:155-179), result stays on the device
+                rc = plan->temperature == 0.0f ? rama_argmax_dev(p->ctx, st->logits, (size_t)cfg->vocab_size, tok_dev[it.seq])
+                                               : rama_sample_topp_dev(p->ctx, st->logits, (size_t)cfg->vocab_size, plan->temperature, plan->topp, plan->u, tok_dev[it.seq]);
+                if (rc) return rc;
+                if (world == 1 && plan->out_tokens_dev &&
+                    hipMemcpyAsync(plan->out_tokens_dev + (size_t)it.seq * plan->n_pos + it.pos, tok_dev[it.seq], sizeof(int32_t),
+                                   hipMemcpyDeviceToDevice, (hipStream_t)rama_internal_stream(p->ctx)) != hipSuccess)
+                    return bad(RAMA_EIO, "rama_pipe_run_ticks: token copy failed");
+            }
+        }
+        if (world == 1) continue;
+        // what I send after computing, and what my upstream neighbour sends me this tick
+        const float* sx = nullptr; const int32_t* stok = nullptr; float* rx = nullptr; int32_t* rtok = nullptr;
+        int sx_peer = 0, stok_peer = 0, rx_peer = 0, rtok_peer = 0;
+        if (it.on) {
+            if (rank < last) { sx = states[it.seq].x; sx_peer = rank + 1; }
+            else { stok = tok_dev[it.seq]; stok_peer = 0; }
+        }
+        const int src = rank > 0 ? rank - 1 : last;
+        const Item up = item_of(*plan, world, src, tick);
+        if (up.on) {
+            if (rank > 0) { rx = states[up.seq].x; rx_peer = src; }
+            else { rtok = tok_dev[up.seq]; rtok_peer = src; }
+        }
+        int rc = rama_pipe_exchange(p, sx, (size_t)cfg->dim, sx_peer, rx, (size_t)cfg->dim, rx_peer, stok, stok_peer, rtok, rtok_peer);
+        if (rc) return rc;
+        // rank 0 keeps the history of sampled ids (generate() prints every `next`, mod.rs:196-200)
+        if (rtok && plan->out_tokens_dev &&
+            hipMemcpyAsync(plan->out_tokens_dev + (size_t)up.seq * plan->n_pos + up.pos, rtok, sizeof(int32_t), hipMemcpyDeviceToDevice,
+                           (hipStream_t)rama_internal_stream(p->ctx)) != hipSuccess)
+            return bad(RAMA_EIO, "rama_pipe_run_ticks: token copy failed");
+    }
+    return 0;
+}
+
+extern "C" const char* rama_pipe_last_error(void) { return g_pipe_err.c_str(); }

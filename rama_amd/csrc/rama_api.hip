@@ -113,6 +113,10 @@ struct rama_ctx {
 
 static int set_device(rama_ctx* c) { HIPCHK(hipSetDevice(c->device)); return 0; }
 
+// internal accessors for the library's other translation units (pipe.hip); not in the C ABI header
+extern "C" void* rama_internal_stream(rama_ctx* c) { return c ? (void*)c->stream : nullptr; }
+extern "C" int rama_internal_device(rama_ctx* c) { return c ? c->device : 0; }
+
 int rama_ctx_create(int device, void* hip_stream, rama_ctx** out) {
     REQUIRE(out, RAMA_EINVAL, "rama_ctx_create: out is NULL");
     int n = 0;

@@ -1,0 +1,124 @@
+"""-m gpu: the layer pipeline under the C ABI (csrc/pipe.hip: RCCL by dlopen, the native tick loop,
+stage-wise checkpoint loading).  One GPU is all this box has, so the communicator has ONE rank: RCCL's
+grouped send-to-self / receive-from-self still runs every line of rama_pipe_exchange (symbol
+resolution, signatures, stream order), and the tick loop is checked against the oracle's generate().
+The multi-rank schedule itself is covered on CPU (tests/test_pipeline_gloo.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from oracle import synth as S
+
+from .helpers import GOLDEN, load_case, to_rama_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import rama_amd
+    d = rama_amd.Hip(0)
+    yield d
+    d.close()
+
+
+@pytest.fixture(scope="module")
+def pipe(dev):
+    from rama_amd._lib import check
+    ident = (C.c_char * 128)()
+    check(dev.lib.rama_pipe_unique_id(ident), "rama_pipe_unique_id")
+    h = C.c_void_p()
+    check(dev.lib.rama_pipe_create(dev.ctx, ident, 0, 1, C.byref(h)), "rama_pipe_create")
+    yield h
+    dev.lib.rama_pipe_destroy(h)
+
+
+def test_exchange_with_self(dev, pipe):
+    """x[dim] and a token id sent to rank 0 and received from rank 0 in one group"""
+    import rama_amd
+    from rama_amd._lib import check
+    x = np.random.default_rng(0).standard_normal(4096).astype(np.float32)
+    sx = dev.allocate(x); rx = dev.alloc(4096)
+    tok = dev.allocate(np.array([12345], np.int32).view(np.float32)); rtok = dev.alloc(1)
+    check(dev.lib.rama_pipe_exchange(pipe, sx.ptr, 4096, 0, rx.ptr, 4096, 0, tok.ptr, 0, rtok.ptr, 0), "rama_pipe_exchange")
+    assert np.array_equal(dev.download(rx), x)
+    assert dev.download(rtok).view(np.int32)[0] == 12345
+    with pytest.raises(rama_amd.RamaError):
+        check(dev.lib.rama_pipe_exchange(pipe, sx.ptr, 4096, 1, None, 0, 0, None, 0, None, 0))      # peer outside the communicator
+
+
+@pytest.mark.parametrize("n_seq,temperature", [(1, 0.0), (3, 0.0), (2, 1.0)])
+def test_native_tick_loop_equals_generate(dev, pipe, n_seq, temperature):
+    """rama_pipe_run_ticks on a one-rank pipe = generate() (mod.rs:169-206) for every sequence in flight:
+    BOS, the forced prompt tokens, then the sampled ones; the history lands in out_tokens_dev"""
+    import rama_amd
+    from rama_amd._lib import check, rama_pipe_plan, rama_run_state, rama_stage
+    cfg, w, g = load_case("synth_d288_h6")
+    prompt = g["tokens"].tolist()[1:4]
+    n_pos = 24
+    u = 0.2721174359321594
+    orc = O.Oracle(cfg, w)
+    want = []
+    token = 1
+    for pos in range(n_pos):
+        lo = orc.forward(token, pos)
+        nxt = int(O.sample(lo.copy(), temperature, 0.9, u))
+        want.append(nxt)
+        token = prompt[pos] if pos < len(prompt) else nxt
+    model = rama_amd.Model.synth(dev, to_rama_cfg(cfg), int(g["seed"]), rope=(g["freq_cis_real"], g["freq_cis_imag"]))
+    engines = [rama_amd.Engine(dev, model) for _ in range(n_seq)]
+    states = (rama_run_state * n_seq)(*[e.state for e in engines])
+    toks = [dev.alloc(1) for _ in range(n_seq)]
+    tok_ptrs = (C.c_void_p * n_seq)(*[t.ptr for t in toks])
+    out = dev.alloc(n_seq * n_pos)
+    pr = (C.c_int32 * len(prompt))(*prompt)
+    plan = rama_pipe_plan(n_seq, n_pos, 0, pr, len(prompt), temperature, 0.9, u, out.ptr)
+    stage = rama_stage(0, cfg.n_layers, 1, 1)
+    total = dev.lib.rama_pipe_total_ticks(pipe, C.byref(plan))
+    assert total == n_seq * n_pos
+    if temperature != 0.0:      # the device sampler's scratch is sized outside the loop
+        check(dev.lib.rama_sample_topp_dev(dev.ctx, engines[0].state.logits, cfg.vocab_size, temperature, 0.9, u, toks[0].ptr))
+    check(dev.lib.rama_pipe_run_ticks(pipe, C.byref(model.ccfg), C.byref(model.weights), states, tok_ptrs, C.byref(stage),
+                                      C.byref(plan), 0, total // 2), "rama_pipe_run_ticks")
+    check(dev.lib.rama_pipe_run_ticks(pipe, C.byref(model.ccfg), C.byref(model.weights), states, tok_ptrs, C.byref(stage),
+                                      C.byref(plan), total // 2, total), "rama_pipe_run_ticks")
+    hist = dev.download(out).view(np.int32).reshape(n_seq, n_pos)
+    for s in range(n_seq):
+        assert hist[s].tolist() == want, (s, hist[s].tolist(), want)
+    for e in engines:
+        e.free()
+    model.free()
+
+
+@pytest.mark.parametrize("name", ["ckpt_tied", "ckpt_untied"])
+def test_load_stage_two_stages_on_one_gpu(dev, name):
+    """rama_model_load_stage: the checkpoint split into two stages (each holds only its tensors) gives
+    the whole model's logits when x is handed from stage 0 to stage 1"""
+    import rama_amd
+    from rama_amd._lib import check, rama_config, rama_stage
+    cfg, w, g = load_case(name)
+    path = str(GOLDEN / f"{name}.bin").encode()
+    mid = cfg.n_layers // 2
+    models, engines = [], []
+    for st in (rama_stage(0, mid, 1, 0), rama_stage(mid, cfg.n_layers, 0, 1)):
+        h = C.c_void_p()
+        check(dev.lib.rama_model_load_stage(dev.ctx, path, C.byref(st), C.byref(h)), "rama_model_load_stage")
+        m = rama_amd.Model(dev, h, st)
+        models.append(m); engines.append(rama_amd.Engine(dev, m))
+    whole = rama_amd.Model.load(dev, GOLDEN / f"{name}.bin")
+    assert models[0].bytes < whole.bytes and models[1].bytes < whole.bytes
+    assert not models[1].weights.token_embedding_table or cfg.shared_weight
+    orc = O.Oracle(cfg, w)
+    toks = g["tokens"].tolist()[:6]
+    for pos, t in enumerate(toks):
+        lo = orc.forward(t, pos)
+        engines[0].forward(t, pos)
+        engines[1].set_buffer("x", engines[0].buffer("x", cfg.dim))
+        engines[1].forward(t, pos)
+        assert np.abs(engines[1].logits() - lo).max() <= 1e-4
+    for e in engines:
+        e.free()
+    for m in models + [whole]:
+        m.free()
