@@ -225,8 +225,8 @@ def main():
                 kernels[k] = {"avg_us": round(avg_ms * 1e3, 2), "launches": n,
                               "GBps": round(b / (avg_ms * 1e-3) / 1e9, 1) if b else None}
             a = kernels["w13"]["GBps"]
-            traffic, traffic_src = pmc_traffic("gemv_swiglu<") if args.config == "llama2-7B" else (None, None)
-            roofline = {"bound": "hbm", "kernel": "gemv_swiglu<2,2,8> (rmsnorm + W1|W3 matvec + SiLU*gate)",
+            traffic, traffic_src = pmc_traffic("gemv_rows<4, 2, 8, true, 5>") if args.config == "llama2-7B" else (None, None)
+            roofline = {"bound": "hbm", "kernel": "gemv_rows<4,2,8,NORM,EPI_SWIGLU_PAIR> (rmsnorm + row-interleaved W1|W3 matvec + SiLU*gate)",
                         "achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBPS, 4),
                         "traffic": traffic, "traffic_source": traffic_src,
                         "algorithmic_bytes_per_launch": bytes_["w13"],

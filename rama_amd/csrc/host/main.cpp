@@ -5,13 +5,18 @@
 // closing line `elapsed: S.mmm s, avg tok/s: X` with X = (step - 1) / elapsed (main.rs:96-103).
 // RAMA_PATH=ops     forward() composed from the 1:1 Device ops (the drop-in path)
 // RAMA_PATH=fused   (default) rama_forward: five fused launches per layer
-// RAMA_PATH=chained temperature 0 only: the whole loop chained on the device, text printed at the end
+// RAMA_PATH=chained the whole loop chained on the device, text printed at the end
+// RAMA_WORLD=N RAMA_RANK=r RAMA_PIPE_ID_FILE=path [RAMA_DEVICE=d]
+//                   layer pipeline over N processes, one GPU each (csrc/pipe.hip: RCCL send/recv of
+//                   x[dim] and the sampled token id).  Rank r loads layers [r*L/N, (r+1)*L/N) only;
+//                   rank 0 writes the RCCL unique id to the file, the others wait for it; rank 0 prints.
 #include "engine.hpp"
 #include "tokenizer.hpp"
 
 #include <chrono>
 #include <cstring>
 #include <iostream>
+#include <thread>
 
 using namespace rama_host;
 
@@ -54,8 +59,96 @@ static Args parse(int argc, char** argv) {
     return a;
 }
 
+// ---- RAMA_WORLD > 1: this process is one stage of the layer pipeline
+static int run_pipeline_stage(const Args& args, int world, int rank) {
+    const char* id_file = std::getenv("RAMA_PIPE_ID_FILE");
+    if (!id_file) { std::fprintf(stderr, "RAMA_WORLD > 1 needs RAMA_PIPE_ID_FILE (a path every rank can read)\n"); return 2; }
+    const char* dev_env = std::getenv("RAMA_DEVICE");
+    Hip device(dev_env ? std::atoi(dev_env) : rank);
+    std::ifstream rd(args.model, std::ios::binary);
+    if (!rd) { std::fprintf(stderr, "couldn't open %s\n", args.model.c_str()); return 1; }
+    const Config config = Config::from_file(rd);
+    rd.close();
+    const int L = (int)config.n_layers, base = L / world, rem = L % world;
+    const int lo = rank * base + std::min(rank, rem), hi = lo + base + (rank < rem ? 1 : 0);
+    const rama_stage stage{lo, hi, rank == 0, rank == world - 1};
+    rama_model* model = nullptr;
+    ck(rama_model_load_stage(device.ctx, args.model.c_str(), &stage, &model), "rama_model_load_stage");
+    rama_config c = config.c();
+    rama_weights w{};
+    ck(rama_model_weights(model, &w), "rama_model_weights");
+    rama_run_state st{};
+    ck(rama_state_create(device.ctx, &c, hi - lo, &st), "rama_state_create");
+    // the communicator: rank 0 publishes the id (write to a temporary name, then rename: readers never see a partial file)
+    unsigned char id[RAMA_PIPE_ID_BYTES];
+    if (rank == 0) {
+        ck(rama_pipe_unique_id(id), "rama_pipe_unique_id");
+        const std::string tmp = std::string(id_file) + ".tmp";
+        std::ofstream f(tmp, std::ios::binary);
+        f.write(reinterpret_cast<const char*>(id), sizeof id);
+        f.close();
+        if (std::rename(tmp.c_str(), id_file) != 0) { std::fprintf(stderr, "cannot write %s\n", id_file); return 1; }
+    } else {
+        for (int tries = 0;; tries++) {
+            std::ifstream f(id_file, std::ios::binary);
+            if (f && f.read(reinterpret_cast<char*>(id), sizeof id)) break;
+            if (tries > 600) { std::fprintf(stderr, "rank %d: no unique id in %s after 60 s\n", rank, id_file); return 1; }
+            std::this_thread::sleep_for(std::chrono::milliseconds(100));
+        }
+    }
+    rama_pipe* pipe = nullptr;
+    ck(rama_pipe_create(device.ctx, id, rank, world, &pipe), "rama_pipe_create");
+
+    Tokenizer tokenizer;
+    std::vector<size_t> prompt_tokens;
+    try {
+        tokenizer = Tokenizer::from_file(args.tokenizer, config.vocab_size);
+        if (!args.prompt.empty()) prompt_tokens = tokenizer.encode(args.prompt);
+    } catch (const std::exception& e) { std::fprintf(stderr, "panic: %s\n", e.what()); return 101; }
+    const size_t steps = args.step;
+    if (steps > config.seq_len) { std::fprintf(stderr, "step %zu exceeds the checkpoint's seq_len %zu\n", steps, config.seq_len); return 1; }
+    const auto start = std::chrono::steady_clock::now();
+    std::vector<int32_t> pt(prompt_tokens.begin(), prompt_tokens.end());
+    float* tok_word = nullptr; float* hist = nullptr;
+    ck(rama_alloc_f32(device.ctx, 1, &tok_word), "rama_alloc_f32");
+    ck(rama_alloc_f32(device.ctx, steps ? steps : 1, &hist), "rama_alloc_f32");
+    int32_t* tok_dev[1] = {reinterpret_cast<int32_t*>(tok_word)};
+    rama_pipe_plan plan{};
+    plan.n_seq = 1; plan.n_pos = (int32_t)steps; plan.wrap = 0; plan.prompt = pt.data(); plan.n_prompt = (int32_t)pt.size();
+    plan.temperature = args.temperature; plan.topp = args.topp; plan.u = device.topp_draw;
+    plan.out_tokens_dev = rank == 0 ? reinterpret_cast<int32_t*>(hist) : nullptr;
+    if (steps) ck(rama_pipe_run_ticks(pipe, &c, &w, &st, tok_dev, &stage, &plan, 0, rama_pipe_total_ticks(pipe, &plan)), "rama_pipe_run_ticks");
+    ck(rama_sync(device.ctx), "rama_sync");
+    if (rank == 0) {
+        std::vector<float> raw(steps ? steps : 1);
+        ck(rama_download_f32(device.ctx, hist, steps ? steps : 1, raw.data()), "rama_download_f32");
+        const int32_t* sampled = reinterpret_cast<const int32_t*>(raw.data());
+        for (size_t pos = 0; pos < steps; pos++) {          // mod.rs:190-200: the forced prompt token, else the sample
+            const size_t next = pos < prompt_tokens.size() ? prompt_tokens[pos] : (size_t)sampled[pos];
+            std::cout << decode(tokenizer.vocab[next]);
+        }
+        std::cout.flush();
+        const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
+        std::printf("\n--------------------------------\n");
+        std::printf("elapsed: %lld.%03lld s, avg tok/s: %g\n", (long long)elapsed, (long long)(elapsed * 1000) % 1000,
+                    (double)((float)(args.step - 1) / (float)elapsed));
+    }
+    rama_pipe_destroy(pipe);
+    rama_free(device.ctx, tok_word); rama_free(device.ctx, hist);
+    rama_state_free(device.ctx, &st);
+    rama_model_free(device.ctx, model);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     const Args args = parse(argc, argv);
+    if (const char* we = std::getenv("RAMA_WORLD")) {
+        const int world = std::atoi(we), rank = std::getenv("RAMA_RANK") ? std::atoi(std::getenv("RAMA_RANK")) : 0;
+        if (world > 1 || std::getenv("RAMA_PIPE_ID_FILE")) {
+            if (world < 1 || rank < 0 || rank >= world) { std::fprintf(stderr, "bad RAMA_WORLD / RAMA_RANK\n"); return 2; }
+            return run_pipeline_stage(args, world, rank);
+        }
+    }
     const char* path_env = std::getenv("RAMA_PATH");
     const std::string path = path_env ? path_env : "fused";
 

@@ -21,6 +21,7 @@
 
 #include <dlfcn.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -54,6 +55,10 @@ int bad(int code, const std::string& msg) {
 int load_rccl() {
     std::lock_guard<std::mutex> lk(g_rccl_mu);
     if (g_rccl.h) return 0;
+    // RCCL prints a version banner on STDOUT at NCCL_DEBUG=VERSION and =WARN (some images export one of
+    // them): it would land in the middle of the generated text.  RAMA_NCCL_DEBUG passes a level through.
+    const char* dbg = getenv("RAMA_NCCL_DEBUG");
+    setenv("NCCL_DEBUG", dbg ? dbg : "NONE", 1);
     void* h = nullptr;
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
         h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);

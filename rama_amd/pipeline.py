@@ -16,6 +16,13 @@ deadlock-free for any N including N = 2, where both directions share one peer.
 
 `Schedule` is pure bookkeeping and `run_pipeline` only needs a backend object with
 x_buffers / tok_buffers / compute(); tests drive it with gloo and the CPU oracle as the backend.
+
+Two data paths run the same schedule on GPUs:
+  * native (default): csrc/pipe.hip under the C ABI -- RCCL ncclSend/ncclRecv issued by the library on the
+    context's stream, the tick loop in C++ (rama_pipe_run_ticks), no host synchronisation per tick.
+    torch.distributed (gloo) only carries the 128-byte RCCL unique id and the barriers of the bench.
+  * torch (RAMA_TORCH_PIPE=1, or when the native end cannot be created): the exchanges as
+    torch.distributed P2P ops (backend "nccl" = RCCL), the tick loop in Python.
 """
 from __future__ import annotations
 
@@ -171,8 +178,154 @@ class HipStage:
         self.dev.close()
 
 
-def run_pipeline_bench(args, cfg, rank: int, world: int, local_rank: int) -> dict:
-    """bench.py --gpus N > 1: N sequences in flight, a step = N ticks (every sequence advances
+class NativeStage:
+    """This rank's end of the native pipe: its stage of the model, one run state and one device token
+    word per in-flight sequence, the RCCL communicator (csrc/pipe.hip)."""
+
+    def __init__(self, cfg, rank: int, world: int, local_rank: int, n_seq: int, ident: bytes, seed: int = 0, rope=None):
+        import rama_amd
+        from rama_amd._lib import check, rama_run_state, rama_stage
+        self.check = check
+        self.cfg, self.rank, self.world, self.n_seq = cfg, rank, world, n_seq
+        self.dev = rama_amd.Hip(local_rank)
+        lo, hi = split_layers(cfg.n_layers, world, rank)
+        self.stage = rama_stage(lo, hi, int(rank == 0), int(rank == world - 1))
+        self.model = rama_amd.Model.synth(self.dev, cfg, seed, self.stage, rope)
+        self.states = (rama_run_state * n_seq)()
+        for s in range(n_seq):
+            check(self.dev.lib.rama_state_create(self.dev.ctx, C.byref(self.model.ccfg), hi - lo, C.byref(self.states[s])))
+        self.toks = [self.dev.alloc(1) for _ in range(n_seq)]
+        self.tok_ptrs = (C.c_void_p * n_seq)(*[t.ptr for t in self.toks])
+        self.pipe = C.c_void_p()
+        buf = (C.c_char * 128).from_buffer_copy(ident)
+        check(self.dev.lib.rama_pipe_create(self.dev.ctx, buf, rank, world, C.byref(self.pipe)), "rama_pipe_create")
+        self.dev.sync()
+
+    @staticmethod
+    def unique_id(lib) -> bytes:
+        from rama_amd._lib import check
+        buf = (C.c_char * 128)()
+        check(lib.rama_pipe_unique_id(buf), "rama_pipe_unique_id")
+        return bytes(buf.raw)
+
+    def plan(self, n_pos: int, prompt, wrap: int = 0, temperature: float = 0.0, topp: float = 0.9, u: float = 0.0, out=None):
+        from rama_amd._lib import rama_pipe_plan
+        self._prompt = (C.c_int32 * max(len(prompt), 1))(*prompt)
+        return rama_pipe_plan(self.n_seq, n_pos, wrap, self._prompt, len(prompt), temperature, topp, u, out)
+
+    def total_ticks(self, plan) -> int:
+        return self.dev.lib.rama_pipe_total_ticks(self.pipe, C.byref(plan))
+
+    def run_ticks(self, plan, tick_from: int, tick_to: int):
+        self.check(self.dev.lib.rama_pipe_run_ticks(self.pipe, C.byref(self.model.ccfg), C.byref(self.model.weights), self.states,
+                                                    self.tok_ptrs, C.byref(self.stage), C.byref(plan), tick_from, tick_to),
+                   "rama_pipe_run_ticks")
+
+    def free(self):
+        self.dev.lib.rama_pipe_destroy(self.pipe)
+        for s in range(self.n_seq):
+            self.dev.lib.rama_state_free(self.dev.ctx, C.byref(self.states[s]))
+        self.model.free()
+        self.dev.close()
+
+
+def _bench_line(args, cfg, world, n_seq, tok_s, dt, roofline, path):
+    import rama_amd
+    from bench import HBM_PEAK_GBPS
+    bytes_ = rama_amd.algorithmic_bytes(cfg)
+    return {
+        "metric": "tokens/sec decode + matvec achieved-HBM-GB/s vs roofline, llama2-7B fp32 1xMI355X",
+        "value": round(tok_s, 3), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.config} fp32 decode, layer pipeline over {world} GPUs, {n_seq} sequences in flight, greedy",
+                   "dim": cfg.dim, "hidden_dim": cfg.hidden_dim, "n_layers": cfg.n_layers, "n_heads": cfg.n_heads,
+                   "vocab_size": cfg.vocab_size, "seq_len": cfg.seq_len, "sequences_in_flight": n_seq,
+                   "parallelism": f"pp{world} (RCCL send/recv of x[dim] and the token id; {path})", "hipgraph": False},
+        "token_level": {"algorithmic_bytes_per_token": bytes_["token"],
+                        "achieved_GBps_aggregate": round(bytes_["token"] * tok_s / 1e9, 1),
+                        "frac_of_aggregate_8TBps": round(bytes_["token"] * tok_s / 1e9 / (HBM_PEAK_GBPS * world), 4)},
+        "roofline": roofline, "cpu_baseline": None,   # cpu_baseline: rank 0 at N = 1 only (bench.py)
+    }
+
+
+def _stage_roofline(check, lib, ctx, compute, n_local, cfg):
+    """dominant kernel (W1|W3 SwiGLU matvec) of this rank's stage, event-bracketed per launch; traffic from
+    the committed PMC pass of the same kernel (bench.pmc_traffic)"""
+    import rama_amd
+    from bench import HBM_PEAK_GBPS, pmc_traffic
+    bytes_ = rama_amd.algorithmic_bytes(cfg)
+    reps = 8
+    check(lib.rama_kprof_enable(ctx, 3, reps * n_local))
+    for _ in range(reps):
+        compute()
+    n, tot = C.c_int(), C.c_double()
+    check(lib.rama_kprof_read(ctx, C.byref(n), C.byref(tot)))
+    if not n.value:
+        return None
+    avg_ms = tot.value / n.value
+    a = bytes_["w13"] / (avg_ms * 1e-3) / 1e9
+    traffic, src = pmc_traffic("gemv_rows<4, 2, 8, true, 5>") if cfg.dim == 4096 else (None, None)
+    return {"bound": "hbm", "kernel": "rmsnorm + W1|W3 matvec + SiLU*gate, rank 0's stage",
+            "achieved": round(a, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBPS, 4),
+            "traffic": traffic, "traffic_source": src,
+            "algorithmic_bytes_per_launch": bytes_["w13"], "avg_launch_us": round(avg_ms * 1e3, 2)}
+
+
+def run_pipeline_bench_native(args, cfg, rank: int, world: int, local_rank: int) -> dict:
+    """bench.py --gpus N > 1 on the native path: N sequences in flight, a step = N ticks."""
+    import torch
+    import torch.distributed as dist
+    import rama_amd
+    from bench import PROMPT
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    os.environ["NCCL_DEBUG"] = os.environ.get("RAMA_NCCL_DEBUG", "NONE")    # RCCL prints its version banner on stdout at VERSION / WARN: one JSON line
+    if not dist.is_initialized():      # control plane only: the id, barriers, the max over ranks
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    box = [NativeStage.unique_id(rama_amd.load()) if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    n_seq = world
+    n_pos = args.warmup + args.steps
+    st = NativeStage(cfg, rank, world, local_rank, n_seq, box[0], seed=0)
+    plan = st.plan(n_pos, PROMPT, wrap=cfg.seq_len)
+    total = st.total_ticks(plan)
+    t_warm, t_end = args.warmup * n_seq, (args.warmup + args.steps) * n_seq
+    st.run_ticks(plan, 0, t_warm)
+    st.dev.sync(); torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    st.run_ticks(plan, t_warm, t_end)
+    st.dev.sync(); torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    st.run_ticks(plan, t_end, total)      # drain, untimed
+    st.dev.sync()
+    tmax = torch.tensor([dt], dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    roofline = None
+    n_local = st.stage.layer_end - st.stage.layer_begin
+    if n_local > 0 and not args.no_kprof:
+        from rama_amd._lib import rama_run_state
+        L = st.dev.lib
+
+        def one():
+            if rank == 0:
+                st.check(L.rama_forward_stage(st.dev.ctx, C.byref(st.model.ccfg), C.byref(st.model.weights), C.byref(st.states[0]), BOS, 5, C.byref(st.stage)))
+            else:
+                st.check(L.rama_forward_stage_devtok(st.dev.ctx, C.byref(st.model.ccfg), C.byref(st.model.weights), C.byref(st.states[0]), None, 5, C.byref(st.stage)))
+        roofline = _stage_roofline(st.check, L, st.dev.ctx, one, n_local, cfg)
+    line = _bench_line(args, cfg, world, n_seq, args.steps * n_seq / dt, dt, roofline, "native: csrc/pipe.hip, tick loop in C++")
+    st.free()
+    dist.barrier()
+    dist.destroy_process_group()
+    return line
+
+
+def run_pipeline_bench_torch(args, cfg, rank: int, world: int, local_rank: int) -> dict:
+    """bench.py --gpus N > 1 on the torch.distributed path: N sequences in flight, a step = N ticks (every sequence advances
     one token, every rank does one full-stage pass per sequence: per-GPU work is fixed -> weak)."""
     import torch
     import torch.distributed as dist
@@ -181,6 +334,7 @@ def run_pipeline_bench(args, cfg, rank: int, world: int, local_rank: int) -> dic
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29531")
+    os.environ["NCCL_DEBUG"] = os.environ.get("RAMA_NCCL_DEBUG", "NONE")    # RCCL prints its version banner on stdout at VERSION / WARN: one JSON line
     if not dist.is_initialized():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
@@ -207,42 +361,20 @@ def run_pipeline_bench(args, cfg, rank: int, world: int, local_rank: int) -> dic
     tmax = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", local_rank))
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    tokens = args.steps * n_seq
-    tok_s = tokens / dt
-    bytes_ = rama_amd.algorithmic_bytes(cfg)
-    # dominant kernel (W1|W3 SwiGLU matvec) on this rank's stage, event-bracketed per launch
     roofline = None
     n_local = backend.stage.layer_end - backend.stage.layer_begin
     if n_local > 0 and not args.no_kprof:
-        L = backend.dev.lib
-        reps = 8
-        backend.check(L.rama_kprof_enable(backend.dev.ctx, 3, reps * n_local))
-        for _ in range(reps):
-            backend.compute(0, (n_pos - 1) % cfg.seq_len, BOS if rank == 0 else None)
-        n, tot = C.c_int(), C.c_double()
-        backend.check(L.rama_kprof_read(backend.dev.ctx, C.byref(n), C.byref(tot)))
-        if n.value:
-            avg_ms = tot.value / n.value
-            a = bytes_["w13"] / (avg_ms * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": "gemv_swiglu (rmsnorm + W1|W3 matvec + SiLU*gate), rank 0's stage",
-                        "achieved": round(a, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": round(a / HBM_PEAK_GBPS, 4), "traffic": None,
-                        "algorithmic_bytes_per_launch": bytes_["w13"], "avg_launch_us": round(avg_ms * 1e3, 2)}
-    line = {
-        "metric": "tokens/sec decode + matvec achieved-HBM-GB/s vs roofline, llama2-7B fp32 1xMI355X",
-        "value": round(tok_s, 3), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.config} fp32 decode, layer pipeline over {world} GPUs, {n_seq} sequences in flight, greedy",
-                   "dim": cfg.dim, "hidden_dim": cfg.hidden_dim, "n_layers": cfg.n_layers, "n_heads": cfg.n_heads,
-                   "vocab_size": cfg.vocab_size, "seq_len": cfg.seq_len, "sequences_in_flight": n_seq,
-                   "parallelism": f"pp{world} (RCCL send/recv of x[dim] and the token id)", "hipgraph": False},
-        "token_level": {"algorithmic_bytes_per_token": bytes_["token"],
-                        "achieved_GBps_aggregate": round(bytes_["token"] * tok_s / 1e9, 1),
-                        "frac_of_aggregate_8TBps": round(bytes_["token"] * tok_s / 1e9 / (HBM_PEAK_GBPS * world), 4)},
-        "roofline": roofline, "cpu_baseline": None,   # cpu_baseline: rank 0 at N = 1 only (bench.py)
-    }
+        roofline = _stage_roofline(backend.check, backend.dev.lib, backend.dev.ctx,
+                                   lambda: backend.compute(0, (n_pos - 1) % cfg.seq_len, BOS if rank == 0 else None), n_local, cfg)
+    line = _bench_line(args, cfg, world, n_seq, args.steps * n_seq / dt, dt, roofline, "torch.distributed P2P, tick loop in Python")
     backend.free()
     dist.barrier()
     dist.destroy_process_group()
     return line
+
+
+def run_pipeline_bench(args, cfg, rank: int, world: int, local_rank: int) -> dict:
+    """bench.py --gpus N > 1: the native path unless RAMA_TORCH_PIPE=1."""
+    if os.environ.get("RAMA_TORCH_PIPE"):
+        return run_pipeline_bench_torch(args, cfg, rank, world, local_rank)
+    return run_pipeline_bench_native(args, cfg, rank, world, local_rank)

@@ -160,6 +160,37 @@ def test_engine_cli_temperature_one_text_parity(tmp_path, path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("temperature", ["0", "1"])
+def test_engine_cli_pipeline_stage_mode_one_rank(tmp_path, temperature):
+    """RAMA_WORLD / RAMA_RANK / RAMA_PIPE_ID_FILE: the CLI as a pipeline stage (csrc/pipe.hip: unique id
+    through a file, rama_model_load_stage, the native tick loop, device sampler).  One GPU here, so one
+    rank: the text must equal generate()'s."""
+    import os
+    name = "ckpt_untied"
+    cfg, w, g = load_case(name)
+    tokp = tmp_path / "tok.bin"
+    write_tokenizer(tokp, cli_vocab(cfg.vocab_size))
+    tok = Tokenizer(tokp, cfg.vocab_size)
+    prompt, steps, u = "hi b", 12, 0.2721174359321594
+    pt = tok.encode(prompt)
+    orc = O.Oracle(cfg, w)
+    token, want_ids = 1, []
+    for pos in range(steps):
+        lo = orc.forward(token, pos)
+        nxt = pt[pos] if pos < len(pt) else O.sample(lo.copy(), float(temperature), 0.9, u)
+        want_ids.append(int(nxt)); token = nxt
+    env = dict(os.environ, RAMA_WORLD="1", RAMA_RANK="0", RAMA_PIPE_ID_FILE=str(tmp_path / "pipe.id"), RAMA_DEVICE="0")
+    r = subprocess.run([str(ENGINE), "-m", str(GOLDEN / f"{name}.bin"), "-t", str(tokp), "-p", prompt, "-s", str(steps), "-r", temperature, "-l", "0.9"],
+                       capture_output=True, text=True, env=env, timeout=120)
+    if 0 in want_ids:
+        assert r.returncode in (101, 0)
+        return
+    assert r.returncode == 0, r.stderr
+    body = r.stdout.partition("\n--------------------------------\n")[0]
+    assert body == "".join(decode(tok.vocab[i]) for i in want_ids)
+
+
+@pytest.mark.gpu
 def test_engine_cli_rejects_too_many_steps(tmp_path):
     tokp = tmp_path / "tok.bin"
     write_tokenizer(tokp, cli_vocab(64))
