@@ -45,13 +45,12 @@ def parse():
     ap.add_argument("--graph", type=int, default=1, help="replay each decode step from a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kprof", action="store_true")
-    ap.add_argument("--no-placement-tuning", action="store_true",
-                    help="skip rama_model_tune_placement (profiling runs: its candidate steps would mix into the kernel statistics)")
+    ap.add_argument("--no-placement-tuning", action="store_true", help="accepted and ignored (round-1 flag: the tuner is gone)")
     ap.add_argument("--pos0", type=int, default=0,
                     help="start the timed generation at this position over a pre-filled (zero) cache: long-context timing, "
                          "N = 1 only; the default 0 is generate()'s own start (BOS + prompt)")
-    ap.add_argument("--cpu-tokens", type=int, default=6)
-    ap.add_argument("--cpu-layers", type=int, default=2)
+    ap.add_argument("--cpu-tokens", type=int, default=8)
+    ap.add_argument("--cpu-layers", type=int, default=8, help="layers of the CPU baseline's sample (all of them when the model has fewer)")
     return ap.parse_args()
 
 
@@ -130,12 +129,10 @@ def main():
             raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
-    import torch
     import rama_amd
 
     d, h, L, H, V, seq, shared = SHAPES[args.config]
     cfg = rama_amd.Config(d, h, L, H, H, V, seq, shared)
-    torch.cuda.set_device(local_rank)
 
     # RAMA_FORCE_PIPELINE=1 rehearses the N > 1 code path (process group, HipStage, the
     # grouped exchanges' bookkeeping) with a single rank on a 1-GPU box
@@ -152,35 +149,6 @@ def main():
     eng = rama_amd.Engine(dev, model)
     dev.sync()
     bytes_ = rama_amd.algorithmic_bytes(cfg)
-
-    # One-off, outside the timed region: physical placement of W3 moves the W1|W3 kernel between 53.5
-    # and 57 us from allocation to allocation.  Try 8 fresh allocations and keep the one
-    # under which THIS decode loop (this state, hipGraph replay) is fastest.
-    def step_ms():
-        eng.set_graph_mode(bool(args.graph))
-        eng.decode_begin(1, 0, PROMPT)
-        eng.decode_steps(6)
-        dev.sync()
-        t = time.perf_counter()
-        eng.decode_steps(24)
-        dev.sync()
-        return (time.perf_counter() - t) * 1e3 / 24
-    # under rocprofv3 the tuning is skipped: every candidate re-captures the step's hipGraph, and the
-    # profiler (ROCm 7.2) segfaults in hipGraphLaunch once a process has instantiated a second
-    # ~160-node graph (profiles/README.md); its candidate steps would also mix into the statistics
-    profiled = "ROCP_TOOL_LIBRARIES" in os.environ or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
-    placement = None
-    if args.config == "llama2-7B" and not args.no_placement_tuning and not profiled:
-        try:
-            placement = model.tune_placement(8, timer=step_ms)
-        except rama_amd.RamaError as e:          # tuning is optional: never let it take the bench down
-            placement = {"error": str(e)}
-    if placement:
-        # releasing the rejected candidates (tens of GB) is followed by ~0.5 s of slower steps (page-table
-        # work, measured 4.38 -> 4.22 -> 4.20 ms over consecutive 64-step runs): let it pass, untimed
-        eng.decode_begin(1, 0, PROMPT)
-        eng.decode_steps(min(256, seq - 1))
-        dev.sync()
 
     def run_steps(n, pos):
         """n decode steps from position pos; a generation that reaches seq_len is followed by a new
@@ -199,14 +167,12 @@ def main():
     pos0 = max(0, min(args.pos0, seq - 1))
     eng.decode_begin(1, pos0, PROMPT if pos0 == 0 else [])
     pos = run_steps(args.warmup, pos0)
-    dev.sync()
-    torch.cuda.synchronize()
+    dev.sync()      # N = 1: no other rank to meet; everything runs on the context's stream, which this drains
     t0 = time.perf_counter()
     eng.timer_start()
     pos = run_steps(args.steps, pos)
     ev_ms = eng.timer_stop()
     dev.sync()
-    torch.cuda.synchronize()
     wall_ms = (time.perf_counter() - t0) * 1e3
     ms_per_step = wall_ms / args.steps
     tokens = eng.decode_tokens()
@@ -245,7 +211,7 @@ def main():
         "config": {"workload": f"{args.config} fp32 decode, weights resident in HBM, greedy, pos {pos0 + args.warmup}..{pos0 + need - 1}" + (" (wrapping at seq_len)" if pos0 + need > seq else ""),
                    "dim": d, "hidden_dim": h, "n_layers": L, "n_heads": H, "vocab_size": V, "seq_len": seq,
                    "sequences_in_flight": 1, "parallelism": "single GPU", "hipgraph": bool(args.graph),
-                   "w3_placement_tuning": placement},
+                   "w13_layout": "row-interleaved copy per model (no placement tuning)"},
         "token_level": {"algorithmic_bytes_per_token": bytes_["token"],
                         "achieved_GBps": round(bytes_["token"] * tok_s / 1e9, 1),
                         "frac_of_8TBps": round(bytes_["token"] * tok_s / 1e9 / HBM_PEAK_GBPS, 4),

@@ -139,18 +139,10 @@ int  rama_model_synth(rama_ctx *ctx, const rama_config *cfg, uint64_t seed, cons
  * (legacy_export) produces and transformer/ram.rs:28-51 reads, so upstream Rama loads it too
  * (SURVEY section 8 row f2).  RAMA_EINVAL for a model that holds only a pipeline stage. */
 int  rama_model_save(rama_ctx *ctx, const rama_model *model, const char *path);
-/* Placement tuning (optional, once per model): the W1|W3 kernel streams two tensors that sit
- * gigabytes apart, and how their pages fall onto HBM channels differs from allocation to
- * allocation (53.5 vs 57 us for the same launch on two boxes).  Copies W3 into up to `tries`
- * (<= 12) fresh allocations and keeps the one under which a decode step is fastest, or the
- * original.  `timer` (optional) is the caller's measurement of ITS decode loop with the candidate
- * weight table -- milliseconds per step, > 0; isolated-kernel or scratch-state timings do not
- * predict the real loop, measured -- NULL times eager steps over a scratch state instead.
- * before_ms / after_ms (optional) = that time before and after.  Costs one extra copy of W3 in
- * HBM when it moves; values are untouched. */
-typedef float (*rama_step_timer)(void *user, const rama_weights *candidate);
-int  rama_model_tune_placement(rama_ctx *ctx, rama_model *model, int tries, rama_step_timer timer, void *user,
-                               float *before_ms, float *after_ms);
+/* A model also keeps W1 and W3 row-interleaved per layer (row i of W1, then row i of W3: +11.5 GB at
+ * llama2-7B): the fused decode path finds that copy by the addresses of w1 / w3 in rama_weights and
+ * streams ONE contiguous block per workgroup; weights uploaded tensor by tensor (rama_upload_f32) take
+ * the two-tensor kernel.  rama_set_tuning "w13i" = 0 turns the lookup off. */
 int  rama_model_config(const rama_model *m, rama_config *cfg);
 int  rama_model_weights(const rama_model *m, rama_weights *w);
 size_t rama_model_bytes(const rama_model *m);

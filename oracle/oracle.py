@@ -188,6 +188,8 @@ def read_checkpoint(path):
     the shared-classifier flag) then fp32 LE tensors (ram.rs:28-51)."""
     raw = np.memmap(path, dtype=np.uint8, mode="r")
     hdr = np.frombuffer(raw[:28].tobytes(), dtype="<i4")
+    if int(hdr[0]) == 0x616b3432:      # "ak42": a v1 / v2 file (export.py:132-260), which the engine does not read
+        raise ValueError("llama2.c v1/v2 checkpoint (ak42 header): the reference engine reads the v0 legacy format only")
     vocab = int(hdr[5])
     cfg = Config(int(hdr[0]), int(hdr[1]), int(hdr[2]), int(hdr[3]), int(hdr[4]),
                  abs(vocab), int(hdr[6]), vocab > 0)

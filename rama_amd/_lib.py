@@ -79,7 +79,6 @@ SIGNATURES = {
     "rama_model_load_stage": (_int, [_vp, C.c_char_p, _stp, C.POINTER(_vp)]),
     "rama_model_synth": (_int, [_vp, _cfgp, C.c_uint64, _stp, _vp, _vp, C.POINTER(_vp)]),
     "rama_model_save": (_int, [_vp, _vp, C.c_char_p]),
-    "rama_model_tune_placement": (_int, [_vp, _vp, _int, _vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "rama_model_config": (_int, [_vp, _cfgp]),
     "rama_model_weights": (_int, [_vp, _wp]),
     "rama_model_bytes": (_sz, [_vp]),
@@ -115,8 +114,6 @@ SIGNATURES = {
     "rama_kprof_enable": (_int, [_vp, _int, _int]),
     "rama_kprof_read": (_int, [_vp, C.POINTER(_int), C.POINTER(C.c_double)]),
 }
-
-STEP_TIMER = C.CFUNCTYPE(C.c_float, C.c_void_p, C.POINTER(rama_weights))
 
 _lib = None
 

@@ -150,10 +150,13 @@ struct Device {
 // ---- the MI355X backend (replaces gpu.rs's GPU)
 struct Hip final : Device {
     rama_ctx* ctx = nullptr;
-    // The reference re-seeds ChaCha20 with 100 on every sample() call (cpu.rs:161-162), so its
-    // "random" draw is one constant.  Value derived from the published rand_core/ChaCha20
-    // algorithms; provisional until checked against a Rust build.
-    float topp_draw = 0.2721174359321594f;
+    // The reference re-seeds ChaCha20 on every sample() call, so its "random" draw is one constant:
+    // seed 100 on the CPU backend (cpu.rs:161-162) -> 0.2721174359321594, seed 10 on the CUDA backend
+    // (gpu.rs:151-152) -> 0.03743588924407959 (derived from the published rand_core / ChaCha20
+    // algorithms; two independent derivations agree, no Rust build has confirmed them).
+    // The parity target of this backend is the CPU path, so its constant is the default; RAMA_TOPP_U
+    // overrides it (e.g. with the CUDA backend's value).
+    float topp_draw = std::getenv("RAMA_TOPP_U") ? std::strtof(std::getenv("RAMA_TOPP_U"), nullptr) : 0.2721174359321594f;
 
     explicit Hip(int device = 0) { ck(rama_ctx_create(device, nullptr, &ctx), "rama_ctx_create"); }   // GPU::new, gpu.rs:213-234
     ~Hip() override { rama_ctx_destroy(ctx); }

@@ -26,8 +26,6 @@ struct rama_model {
     float* w13i = nullptr;      // W1 | W3 row-interleaved per layer: [n_local_layers, hidden, 2, dim] (see below)
     float* blob = nullptr;      // one allocation holding every tensor
     size_t blob_floats = 0;
-    std::vector<float*> arenas; // extra allocations owning W3 / W1 once rama_model_tune_placement has moved them
-    bool tuned = false;
     rama_stage stage{};
 };
 
@@ -308,98 +306,8 @@ extern "C" int rama_model_weights(const rama_model* m, rama_weights* w) {
     return 0;
 }
 extern "C" size_t rama_model_bytes(const rama_model* m) { return m ? m->blob_floats * sizeof(float) : 0; }
-// Placement tuning.  The W1|W3 kernel streams two tensors that sit gigabytes apart, and how their
-// pages fall onto HBM channels/banks differs from allocation to allocation: the same binary runs
-// that kernel in 53.5 us on one box and 57 us on another.  This copies W3
-// into up to `tries` fresh allocations and keeps the one under which the model's REAL decode step is
-// fastest (or the original).  What is timed is the whole step (rama_forward_stage over this model's
-// layers, eager launches): the kernel in isolation, back to back with itself, does not predict its
-// time between Wo and W2 (measured: an "isolated-faster" placement made the step 3 % slower).
-// Earlier candidates stay allocated while the next one is made, so each try lands on different
-// physical pages; offsets inside one allocation only make it worse (+3..6 us for any non-zero one).
-namespace {
-int time_steps(rama_ctx* ctx, const rama_model* m, const rama_weights& w, rama_run_state* st, float* ms_per_step) {
-    hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return bad(RAMA_EIO, "tune_placement: event");
-    const int reps = 3;
-    int rc = 0;
-    for (int r = -1; r < reps && !rc; r++) {
-        if (r == 0) { rama_sync(ctx); hipEventRecord(e0, 0); }            // host-side wall of the stream: sync + legacy-stream events
-        rc = rama_forward_stage(ctx, &m->cfg, &w, st, 1, r + 1, &m->stage);
-    }
-    if (!rc) rc = rama_sync(ctx);
-    hipEventRecord(e1, 0);
-    hipEventSynchronize(e1);
-    float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
-    hipEventDestroy(e0); hipEventDestroy(e1);
-    *ms_per_step = ms / reps;
-    return rc;
-}
-}  // namespace
-
-extern "C" int rama_model_tune_placement(rama_ctx* ctx, rama_model* m, int tries, rama_step_timer timer, void* user,
-                                         float* before_ms, float* after_ms) {
-    if (!ctx || !m) return bad(RAMA_EINVAL, "rama_model_tune_placement: NULL argument");
-    const rama_config& c = m->cfg;
-    const int nl = m->stage.layer_end - m->stage.layer_begin;
-    if (before_ms) *before_ms = 0.f;
-    if (after_ms) *after_ms = 0.f;
-    if (nl <= 0 || tries <= 0 || !m->w.w1 || !m->w.w3) return 0;
-    rama_run_state st{};
-    int rc = timer ? 0 : rama_state_create(ctx, &c, nl, &st);
-    if (rc) return rc;
-    // the caller's timer measures ITS decode loop (its run state, its hipGraph) with the candidate
-    // weights; without one, eager steps over a scratch state stand in
-    auto measure = [&](const rama_weights& w, float* ms) -> int {
-        if (!timer) return time_steps(ctx, m, w, &st, ms);
-        *ms = timer(user, &w);
-        return *ms > 0.f ? 0 : bad(RAMA_EINVAL, "rama_model_tune_placement: the timer returned a non-positive time");
-    };
-    float base = 0.f;
-    rc = measure(m->w, &base);
-    if (rc) { rama_state_free(ctx, &st); return rc; }
-    if (before_ms) *before_ms = base;
-    if (after_ms) *after_ms = base;
-    if (m->tuned) { rama_state_free(ctx, &st); return 0; }   // already tuned once: measure only
-    m->tuned = true;
-    const size_t n = (size_t)nl * c.hidden_dim * c.dim;
-    const int nt = std::min(tries, 12);
-    float best = base;
-    // W3 first, then W1 with W3 where it ended up: either stream of the pair can be the unlucky one
-    const float** fields[2] = {&m->w.w3, &m->w.w1};
-    const char* names[2] = {"W3", "W1"};
-    for (int f = 0; f < 2 && !rc; f++) {
-        std::vector<float*> cand;
-        int best_k = -1;
-        for (int k = 0; k < nt; k++) {
-            float* a = nullptr;
-            if (rama_alloc_f32(ctx, n, &a) != 0) break;       // out of memory: stop trying, keep what we have
-            cand.push_back(a);
-            if (hipMemcpy(a, *fields[f], n * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess) { rc = bad(RAMA_EIO, "rama_model_tune_placement: copy failed"); break; }
-            rama_weights w = m->w;
-            if (f == 0) w.w3 = a; else w.w1 = a;
-            float ms = 0.f;
-            rc = measure(w, &ms);
-            if (rc) break;
-            if (getenv("RAMA_TUNE_VERBOSE")) fprintf(stderr, "[tune] %s in fresh allocation %d: step %.1f us (best so far %.1f)\n", names[f], k, ms * 1e3f, best * 1e3f);
-            if (ms < best * 0.995f) { best = ms; best_k = k; }
-        }
-        for (int k = 0; k < (int)cand.size(); k++) if (k != best_k || rc) rama_free(ctx, cand[k]);
-        if (!rc && best_k >= 0) {                            // the old copy stays allocated inside the blob, unused
-            *fields[f] = cand[best_k];
-            m->arenas.push_back(cand[best_k]);
-        }
-    }
-    rama_state_free(ctx, &st);
-    if (rc) return rc;
-    if (after_ms) *after_ms = best;
-    return 0;
-}
-
 extern "C" int rama_model_free(rama_ctx* ctx, rama_model* m) {
     if (!m) return 0;
-    for (float* a : m->arenas) rama_free(ctx, a);
     if (m->w13i) {
         {
             std::lock_guard<std::mutex> lk(g_w13_mu);

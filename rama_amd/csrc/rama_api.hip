@@ -431,6 +431,7 @@ static int attn_nsplit(const rama_ctx* c, int n_heads) {
 
 // scratch for the split-T partials; called outside any stream capture (no allocation inside one)
 static int ensure_attn_part(rama_ctx* c, const rama_config* cfg) {
+    if (set_device(c)) return 1;
     const int hs = cfg->dim / cfg->n_heads;
     const size_t need = (size_t)cfg->n_heads * attn_nsplit(c, cfg->n_heads) * (hs + 4);
     if (need > c->attn_part_floats) {
@@ -451,7 +452,11 @@ constexpr int kSplitTPos = 256;
 // its whole per-head cache is a few rounds of one workgroup and the combine launch costs more.
 static int split_threshold(const rama_ctx* c, const rama_config* cfg) {
     if (c->tune_split_pos >= 0) return c->tune_split_pos;
-    const long kv_bytes_per_pos = 2L * (cfg->dim / cfg->n_heads) * 4;          // one head's K + V row
+    const int hs = cfg->dim / cfg->n_heads;
+    const int G = hs <= 64 ? 16 : (hs <= 128 ? 32 : 64);
+    // a context the one-workgroup kernel's LDS score buffer cannot hold (seq_len > ~15 000) must split
+    if ((size_t)(attn_scratch_floats(G) + cfg->seq_len) * sizeof(float) > 64 * 1024) return kSplitTPos;
+    const long kv_bytes_per_pos = 2L * hs * 4;          // one head's K + V row
     return kv_bytes_per_pos * cfg->seq_len <= (1L << 20) ? (1 << 30) : kSplitTPos;   // whole head cache <= 1 MiB: never split
 }
 
@@ -501,8 +506,11 @@ static int launch_attention(rama_ctx* c, float* xb, float* att, const float* q, 
         LAUNCHCHK();
         return 0;
     }
-    size_t shm = (size_t)(attn_scratch_floats(G) + seq_len) * sizeof(float);
-    REQUIRE(shm <= 64 * 1024, RAMA_EUNSUP, "attention: seq_len too long for the single-workgroup kernel");
+    // score buffer: seq_len timesteps, or what 64 KiB hold when the context is longer (such models run
+    // split-T from position 256 on, split_threshold; a known position beyond the buffer is an error)
+    const int cap = std::min(seq_len, (int)(64 * 1024 / sizeof(float)) - attn_scratch_floats(G));
+    REQUIRE((ctl ? c->host_pos : pos) < cap, RAMA_EUNSUP, "attention: position beyond the single-workgroup kernel's score buffer");
+    size_t shm = (size_t)(attn_scratch_floats(G) + cap) * sizeof(float);
     if (G == 16) RAMA_LAUNCH(c, (attention_kernel<16, false>), dim3(n_heads), dim3(kAttnThreads), shm, p);
     else if (G == 32) RAMA_LAUNCH(c, (attention_kernel<32, false>), dim3(n_heads), dim3(kAttnThreads), shm, p);
     else RAMA_LAUNCH(c, (attention_kernel<64, false>), dim3(n_heads), dim3(kAttnThreads), shm, p);
@@ -775,6 +783,7 @@ static int check_stage(const rama_config* cfg, const rama_weights* w, const rama
 int rama_forward_stage(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s,
                        int token, int pos, const rama_stage* st) {
     REQUIRE(c, RAMA_EINVAL, "ctx is NULL");
+    if (set_device(c)) return 1;
     int rc = check_cfg(cfg); if (rc) return rc;
     rc = check_stage(cfg, w, s, st); if (rc) return rc;
     REQUIRE(pos >= 0 && pos < cfg->seq_len, RAMA_EINVAL, "forward: pos outside [0, seq_len)");
@@ -793,6 +802,7 @@ int rama_forward_stage(rama_ctx* c, const rama_config* cfg, const rama_weights* 
 int rama_forward_stage_devtok(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s,
                               const int32_t* token_dev, int pos, const rama_stage* st) {
     REQUIRE(c, RAMA_EINVAL, "ctx is NULL");
+    if (set_device(c)) return 1;
     int rc = check_cfg(cfg); if (rc) return rc;
     rc = check_stage(cfg, w, s, st); if (rc) return rc;
     REQUIRE(pos >= 0 && pos < cfg->seq_len, RAMA_EINVAL, "forward: pos outside [0, seq_len)");
@@ -812,6 +822,7 @@ int rama_forward_stage_devtok(rama_ctx* c, const rama_config* cfg, const rama_we
 // scratch for n logits; called outside any stream capture
 static int ensure_topp_scratch(rama_ctx* c, int n) {
     if (n <= c->topp_cap) return 0;
+    if (set_device(c)) return 1;
     HIPCHK(hipStreamSynchronize(c->stream));
     for (int i = 0; i < 2; i++) {
         hipFree(c->topp_keys[i]); hipFree(c->topp_vals[i]);
@@ -1156,6 +1167,7 @@ static bool same_capture(const GraphCache& g, const rama_config* cfg, const rama
 
 int rama_decode_steps(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s, int n_steps) {
     REQUIRE(c, RAMA_EINVAL, "ctx is NULL");
+    if (set_device(c)) return 1;
     int rc = check_cfg(cfg); if (rc) return rc;
     rama_stage st{0, cfg->n_layers, 1, 1};
     rc = check_stage(cfg, w, s, &st); if (rc) return rc;

@@ -63,27 +63,6 @@ class Model:
         """write the model as a llama2.c v0 .bin (export.py legacy layout; upstream Rama loads it)"""
         check(self.device.lib.rama_model_save(self.device.ctx, self.handle, str(path).encode()), "rama_model_save")
 
-    def tune_placement(self, tries: int = 8, timer=None) -> dict:
-        """copy W3 into up to `tries` fresh allocations and keep the one under which a decode step is
-        fastest (rama_model_tune_placement).  timer() -> ms per step of the CALLER's decode loop, called
-        after self.weights has been switched to the candidate; None = eager steps over a scratch state."""
-        from ._lib import STEP_TIMER
-        b, a = C.c_float(), C.c_float()
-        cb = None
-        if timer is not None:
-            def _cb(_user, wptr):
-                C.memmove(C.byref(self.weights), wptr, C.sizeof(rama_weights))
-                return float(timer())
-            cb = STEP_TIMER(_cb)
-        try:
-            check(self.device.lib.rama_model_tune_placement(self.device.ctx, self.handle, tries,
-                                                            C.cast(cb, C.c_void_p) if cb else None, None, C.byref(b), C.byref(a)),
-                  "rama_model_tune_placement")
-        finally:    # whatever happened, self.weights must be the model's own table again (W3 / W1 may have moved)
-            check(self.device.lib.rama_model_weights(self.handle, C.byref(self.weights)))
-        return {"step_us_before": round(b.value * 1e3, 1), "step_us_after": round(a.value * 1e3, 1),
-                "moved": a.value < b.value, "tries": tries}
-
     @property
     def bytes(self) -> int:
         return self.device.lib.rama_model_bytes(self.handle)

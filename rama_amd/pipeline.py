@@ -178,6 +178,21 @@ class HipStage:
         self.dev.close()
 
 
+class _stdout_to_stderr:
+    """route file descriptor 1 to stderr for a while (native libraries that print banners on stdout)"""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 class NativeStage:
     """This rank's end of the native pipe: its stage of the model, one run state and one device token
     word per in-flight sequence, the RCCL communicator (csrc/pipe.hip)."""
@@ -283,7 +298,8 @@ def run_pipeline_bench_native(args, cfg, rank: int, world: int, local_rank: int)
     os.environ.setdefault("MASTER_PORT", "29531")
     os.environ["NCCL_DEBUG"] = os.environ.get("RAMA_NCCL_DEBUG", "NONE")    # RCCL prints its version banner on stdout at VERSION / WARN: one JSON line
     if not dist.is_initialized():      # control plane only: the id, barriers, the max over ranks
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        with _stdout_to_stderr():      # gloo announces its connections on stdout; the bench prints ONE JSON line there
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     box = [NativeStage.unique_id(rama_amd.load()) if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
     n_seq = world

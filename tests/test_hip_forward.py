@@ -742,27 +742,49 @@ def test_decode_batch_argument_errors(dev):
     a.free(); b.free(); m.free()
 
 
-def test_model_tune_placement_keeps_the_weights(dev, tmp_path):
-    """placement tuning may move W3 to another allocation; values, logits and the saved file stay the same"""
+def test_interleaved_w13_copy_equals_two_tensor_path(dev, tmp_path):
+    """a rama_model keeps W1 | W3 row-interleaved for the fused SwiGLU launch (model.hip); logits with
+    the copy in use ("w13i" = 1, default) and with the checkpoint's two tensors ("w13i" = 0) are the
+    same to the last bit -- the same four rows per workgroup, the same order of operations -- and the
+    saved file still holds the checkpoint layout"""
     import rama_amd
-    cfg, w, g = load_case("synth_d288_h6")
+    name = "synth_d288_h6"
+    cfg, w, g = load_case(name)
     m = rama_amd.Model.synth(dev, to_rama_cfg(cfg), int(g["seed"]), rope=(g["freq_cis_real"], g["freq_cis_imag"]))
     eng = rama_amd.Engine(dev, m)
-    toks = g["tokens"].tolist()[:5]
-    before = []
-    for p_, t in enumerate(toks):
-        eng.forward(t, p_); before.append(eng.logits().copy())
-    rep = m.tune_placement(12)
-    assert rep["step_us_after"] <= rep["step_us_before"] and rep["tries"] == 12
-    assert np.array_equal(m.tensor("w3", w["w3"].size), np.asarray(w["w3"]).reshape(-1))
-    assert np.array_equal(m.tensor("w1", w["w1"].size), np.asarray(w["w1"]).reshape(-1))
-    eng2 = rama_amd.Engine(dev, m)
-    for p_, t in enumerate(toks):
-        eng2.forward(t, p_)
-        assert np.array_equal(eng2.logits(), before[p_])
-    m.tune_placement(4)                                   # a second call measures, never moves again
-    out = tmp_path / "tuned.bin"
-    m.save(out)
-    cfg2, w2 = O.read_checkpoint(out)
-    assert np.array_equal(np.asarray(w2["w3"]).reshape(-1), np.asarray(w["w3"]).reshape(-1))
-    eng.free(); eng2.free(); m.free()
+    toks = g["tokens"].tolist()[:6]
+    runs = {}
+    for v in (1, 0):
+        eng.set_tuning("w13i", v)
+        e2 = rama_amd.Engine(dev, m)
+        out = []
+        for pos, t in enumerate(toks):
+            e2.forward(t, pos)
+            out.append(e2.logits())
+        runs[v] = out
+        e2.free()
+    eng.set_tuning("w13i", 1)
+    for a, b in zip(runs[0], runs[1]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    orc = O.Oracle(cfg, w)
+    for pos, t in enumerate(toks):
+        assert np.abs(runs[1][pos] - orc.forward(t, pos)).max() <= LOGIT_ATOL
+    p = tmp_path / "saved.bin"
+    m.save(p)
+    cfg2, w2 = O.read_checkpoint(p)
+    assert cfg2 == cfg
+    for k in ("w1", "w3", "w2"):
+        assert np.array_equal(w2[k].reshape(-1), w[k].reshape(-1)), k
+    eng.free(); m.free()
+
+
+def test_v1_ak42_checkpoint_is_rejected(dev):
+    """a llama2.c v1 file written by the reference's own version1_export (export.py:132-180, magic
+    "ak42" + 256-byte header): the engine reads v0 only (mod.rs:141-166), the loader must say so
+    instead of taking the magic for `dim`"""
+    import rama_amd
+    with pytest.raises(rama_amd.RamaError) as e:
+        rama_amd.Model.load(dev, GOLDEN / "ckpt_v1_ak42.bin")
+    assert "(-2)" in str(e.value)           # RAMA_EUNSUP
+    with pytest.raises(Exception):
+        O.read_checkpoint(GOLDEN / "ckpt_v1_ak42.bin")

@@ -138,3 +138,13 @@ def test_checkpoint_reader_layout(golden_dir):
     hs = cfg.head_size
     assert w["freq_cis_real"].shape == (cfg.seq_len, hs // 2)
     assert np.allclose(w["freq_cis_real"][0], 1.0) and np.allclose(w["freq_cis_imag"][0], 0.0)
+
+
+def test_v1_ak42_fixture_is_not_a_v0_file(golden_dir):
+    """the reference's version1_export wrote this one: magic "ak42", 256-byte header (export.py:132-180)"""
+    raw = (golden_dir / "ckpt_v1_ak42.bin").read_bytes()
+    assert raw[:4] == b"24ka" and int.from_bytes(raw[:4], "little") == 0x616b3432
+    assert int.from_bytes(raw[4:8], "little") == 1                      # version
+    assert int.from_bytes(raw[8:12], "little") == 32                    # dim of the tiny model
+    with pytest.raises(ValueError, match="ak42"):
+        O.read_checkpoint(golden_dir / "ckpt_v1_ak42.bin")

@@ -142,6 +142,19 @@ def make_ckpt_case(name, seed, shared):
     print(name, "bin bytes", path.stat().st_size, "logits", logits.shape)
 
 
+def make_v1_case(name, seed):
+    """the same tiny model written by the reference's version1_export (export.py:132-180): a 256-byte
+    header that starts with the magic "ak42".  The engine cannot read it (mod.rs:141-166 reads seven
+    ints); the loader must reject it with an explanation instead of mis-parsing the magic as `dim`."""
+    torch.manual_seed(seed)
+    cfg = O.Config(dim=32, hidden_dim=96, n_layers=2, n_heads=2, n_kv_heads=2,
+                   vocab_size=64, seq_len=16, shared_weight=True)
+    m = build_ref_model(cfg, multiple_of=32)
+    path = OUT / f"{name}.bin"
+    ref_export.version1_export(m, str(path))
+    print(name, "bin bytes", path.stat().st_size, "magic", path.read_bytes()[:4])
+
+
 def make_synth_case(name, cfg: O.Config, seed, n_tokens, multiple_of=32):
     w = synth_weights(cfg, seed)
     m = build_ref_model(cfg, multiple_of=multiple_of)
@@ -166,6 +179,10 @@ def make_synth_case(name, cfg: O.Config, seed, n_tokens, multiple_of=32):
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "v1":      # only the v1 fixture (added in round 2)
+        make_v1_case("ckpt_v1_ak42", seed=0)
+        return
+    make_v1_case("ckpt_v1_ak42", seed=0)
     make_ckpt_case("ckpt_tied", seed=0, shared=True)
     make_ckpt_case("ckpt_untied", seed=1, shared=False)
     # head_size 16, generic small
