@@ -192,7 +192,8 @@ def main():
                               "GBps": round(b / (avg_ms * 1e-3) / 1e9, 1) if b else None}
             a = kernels["w13"]["GBps"]
             traffic, traffic_src = pmc_traffic("gemv_rows<4, 2, 8, true, 5>") if args.config == "llama2-7B" else (None, None)
-            roofline = {"bound": "hbm", "kernel": "gemv_rows<4,2,8,NORM,EPI_SWIGLU_PAIR> (rmsnorm + row-interleaved W1|W3 matvec + SiLU*gate)",
+            kname = "gemv_rows_solo<4,CH,NORM,EPI_SWIGLU_PAIR>" if d <= 2048 else "gemv_rows<4,2,8,NORM,EPI_SWIGLU_PAIR>"
+            roofline = {"bound": "hbm", "kernel": kname + " (rmsnorm + row-interleaved W1|W3 matvec + SiLU*gate)",
                         "achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBPS, 4),
                         "traffic": traffic, "traffic_source": traffic_src,
                         "algorithmic_bytes_per_launch": bytes_["w13"],

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Aggregate decode throughput with B independent sequences sharing each weight pass
-(rama_decode_batch, B = 1..8) at the llama2-7B shape; greedy tokens are fed back through the host
+(rama_decode_batch, B = 1..64) at the llama2-7B shape; greedy tokens are fed back through the host
 (argmax of each sequence's logits on the device, 4 bytes each).  Prints one JSON line."""
 import ctypes as C
 import json, sys, time
@@ -16,7 +16,7 @@ cfg = rama_amd.Config(d, h, L, H, H, V, seq, shared)
 dev = rama_amd.Hip(0)
 model = rama_amd.Model.synth(dev, cfg, seed=0)
 out = {}
-for B in (1, 2, 4, 8):
+for B in (1, 8, 16, 32, 64):
     engs = [rama_amd.Engine(dev, model) for _ in range(B)]
     cur = [1 + i for i in range(B)]
     nxt = C.c_int32()
