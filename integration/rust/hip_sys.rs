@@ -64,7 +64,7 @@ extern "C" {
                         s: *mut rama_run_state, token: c_int, pos: c_int) -> c_int;
     pub fn rama_prefill(ctx: *mut rama_ctx, cfg: *const rama_config, w: *const rama_weights,
                         s: *mut rama_run_state, tokens_host: *const i32, n_tokens: c_int, pos0: c_int) -> c_int;
-    /// one decode step for up to 8 independent sequences (states: array of n_seq run states)
+    /// one decode step for up to 64 independent sequences (states: array of n_seq run states)
     pub fn rama_decode_batch(ctx: *mut rama_ctx, cfg: *const rama_config, w: *const rama_weights,
                              states: *const rama_run_state, tokens_host: *const i32, positions_host: *const i32,
                              n_seq: c_int) -> c_int;
@@ -78,4 +78,31 @@ extern "C" {
     pub fn rama_model_config(m: *const rama_model, cfg: *mut rama_config) -> c_int;
     pub fn rama_model_weights(m: *const rama_model, w: *mut rama_weights) -> c_int;
     pub fn rama_model_free(ctx: *mut rama_ctx, m: *mut rama_model) -> c_int;
+    /// one pipeline stage's tensors only (layers [layer_begin, layer_end), embedding / classifier as flagged)
+    pub fn rama_model_load_stage(ctx: *mut rama_ctx, path: *const c_char, stage: *const rama_stage,
+                                 out: *mut *mut rama_model) -> c_int;
+
+    // performance / parity knobs: "ref_order" = 1 switches every op to the CPU backend's rounding order
+    // (bit-identical logits, for diffing against `cargo run --release`)
+    pub fn rama_set_tuning(ctx: *mut rama_ctx, key: *const c_char, value: c_int) -> c_int;
+
+    // layer pipeline over RCCL, one process per GPU (csrc/pipe.hip)
+    pub fn rama_pipe_unique_id(id_out: *mut u8) -> c_int;                       // RAMA_PIPE_ID_BYTES = 128
+    pub fn rama_pipe_create(ctx: *mut rama_ctx, id: *const u8, rank: c_int, world: c_int, out: *mut *mut rama_pipe) -> c_int;
+    pub fn rama_pipe_destroy(pipe: *mut rama_pipe) -> c_int;
+    pub fn rama_pipe_total_ticks(pipe: *const rama_pipe, plan: *const rama_pipe_plan) -> c_int;
+    pub fn rama_pipe_run_ticks(pipe: *mut rama_pipe, cfg: *const rama_config, w: *const rama_weights,
+                               states: *mut rama_run_state, tok_dev: *const *mut i32, stage: *const rama_stage,
+                               plan: *const rama_pipe_plan, tick_from: c_int, tick_to: c_int) -> c_int;
+}
+
+#[repr(C)] pub struct rama_pipe { _p: [u8; 0] }
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct rama_stage { pub layer_begin: i32, pub layer_end: i32, pub do_embed: i32, pub do_cls: i32 }
+#[repr(C)]
+pub struct rama_pipe_plan {
+    pub n_seq: i32, pub n_pos: i32, pub wrap: i32,
+    pub prompt: *const i32, pub n_prompt: i32,
+    pub temperature: f32, pub topp: f32, pub u: f32,
+    pub out_tokens_dev: *mut i32,
 }
