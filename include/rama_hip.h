@@ -285,8 +285,9 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *   "attn_nsplit" = 0..32, "attn_waves" = 16|8|4, "attn_nt" = 0|1 : geometry of the split-T attention of long
  *                   contexts: slices per head (0 = #CUs / n_heads, at most 16), waves per workgroup (default 8)
  *                   and non-temporal cache-row loads (default 1); tools/attn_sweep.py
- *   "small_attn" = -1|0|1 : 4-wave attention workgroups in the decode step (default 0: never; the token-batch
- *                   passes use them on their own for contexts <= 256)
+ *   "small_attn" = -1|0|1, "small_attn_waves" = 4|8, "small_attn_pos" = N : fewer-wave attention workgroups in the
+ *                   decode step; -1 (default): 8 waves per head below position 256 where attention is not
+ *                   merged with Wo (+0.7 % tokens/s at llama2-7B, positions 8..135)
  *   "solo" = -1|0|1 : matvecs with one wave per row group and no LDS turn; -1 (default) = for rows of <= 2048
  *                   floats (the stories15M / 110M widths), where launches are latency-bound
  *   "ref_order" = 0|1 : 1 computes every op in the REFERENCE'S OWN rounding order (csrc/ref_order.hpp: 4-lane

@@ -700,13 +700,32 @@ __global__ __launch_bounds__(W * 64) void attention_kernel(AttnParams p) {
 
 // split-T combine: xb[h] = sum_s e^(m_s - M) acc_s / sum_s e^(m_s - M) l_s,  M = max_s m_s
 // (algebraically the softmax over all timesteps; an empty slice has l = 0 and drops out)
+// the plain loop (round 1), kept for A/B (rama_set_tuning "combine_v" = 0)
+__global__ void attention_combine_loop_kernel(const float* part, float* xb, int head_size, int nsplit) {
+    const int h = blockIdx.x, i = threadIdx.x;
+    const size_t ps = (size_t)(head_size + 4);
+    const float* ph = part + (size_t)h * nsplit * ps;
+    float M = -INFINITY;
+    for (int s = 0; s < nsplit; s++) if (ph[s * ps + 1] > 0.0f) M = fmaxf(M, ph[s * ps]);
+    float L = 0.0f, o = 0.0f;
+    for (int s = 0; s < nsplit; s++) {
+        const float l = ph[s * ps + 1];
+        if (l > 0.0f) {
+            const float sc = expf(ph[s * ps] - M);
+            L += sc * l;
+            if (i < head_size) o += sc * ph[s * ps + 4 + i];
+        }
+    }
+    if (i < head_size) xb[(size_t)h * head_size + i] = o / L;
+}
+
+template <int MAXS>
 __global__ void attention_combine_kernel(const float* part, float* xb, int head_size, int nsplit) {
     const int h = blockIdx.x, i = threadIdx.x;
     const size_t ps = (size_t)(head_size + 4);
     const float* ph = part + (size_t)h * nsplit * ps;
     // every slice's (max, sum, acc[i]) is requested before the first use: the launch is one cache
     // round trip, not one per slice (it sits on the critical path of every long-context layer)
-    constexpr int MAXS = 32;
     float m[MAXS], l[MAXS], a[MAXS];
 #pragma unroll
     for (int s = 0; s < MAXS; s++) {

@@ -41,6 +41,8 @@ static int fail(int code, const char* what, const char* file, int line) {
 
 // ---------------------------------------------------------------- context
 
+constexpr int kSmallAttnPosDefault = 256;
+
 struct KProf {
     int kernel_id = -1;
     int max_records = 0;
@@ -101,12 +103,13 @@ struct rama_ctx {
     int host_pos = -1;                     // position of the next chained decode step (mirrors the device cursor)
     bool split_attn = false;               // variant the steps being enqueued / captured use
     bool small_attn = false;               // 4-wave attention workgroups (contexts of <= kSmallAttnPos timesteps)
+    int tune_small_waves = 8, tune_small_pos = kSmallAttnPosDefault;   // waves per head and position limit of the small-attention variant
+    int tune_combine_v = 1;                // split-T combine: 1 = all slice loads up front, 0 = round 1's loop
     int tune_attn_nsplit = 0;              // split-T slices per head: 0 = #CUs / n_heads (<= 16), else 1..32
     int tune_attn_waves = 8;               // waves per split-T workgroup (16, 8 or 4); 8 measured best at llama2-7B, 1000-1900 tokens
     int tune_attn_nt = 1;                  // 1: split-T attention reads the cache rows non-temporally (+2.7 % tokens/s at 1900 tokens)
-    int tune_small_attn = 0;               // 4-wave attention in the decode step: 0 never (default: measured equal to the merged
-                                           // attention+Wo launch at the stories shapes and to the 16-wave kernel at llama2-7B), 1 whenever
-                                           // it fits, -1 below kSmallAttnPos
+    int tune_small_attn = -1;              // fewer-wave attention in the decode step: -1 (default) below tune_small_pos where attention
+                                           // is not merged with Wo, 0 never, 1 always (below the split threshold)
     unsigned long long* pbar = nullptr;    // device: [1] = error word of the merged attention+Wo launch's bounded spin
     const float* embedded_x = nullptr;   // run-state x that already holds emb[ctl.token] (chained decode)
 };
@@ -462,10 +465,14 @@ static int split_threshold(const rama_ctx* c, const rama_config* cfg) {
 
 // positions up to which the 4-wave attention workgroup is used (it covers 64 timesteps per round;
 // measured faster than the 16-wave one up to ~250 timesteps at head sizes 48 / 64)
-constexpr int kSmallAttnPos = 224;
-static bool small_attn_at(const rama_ctx* c, int pos, bool split) {
+// Below the split-T threshold an 8-wave workgroup per head covers 128 timesteps per round instead of
+// the 16-wave kernel's 256: fewer waves to synchronise, measured +0.7 % tokens/s at llama2-7B for
+// positions 8..135 (tools/small_attn_sweep.py).  Not where attention is merged with Wo (dim <= 1024).
+static bool merge_wanted(const rama_ctx* c, int dim) { return c->tune_merge < 0 ? dim <= 1024 : c->tune_merge != 0; }
+static bool small_attn_at(const rama_ctx* c, int pos, bool split, int dim) {
     if (split || c->tune_small_attn == 0) return false;
-    return c->tune_small_attn == 1 ? true : pos < kSmallAttnPos;
+    if (c->tune_small_attn == 1) return true;
+    return !merge_wanted(c, dim) && pos < c->tune_small_pos;
 }
 
 static int launch_attention(rama_ctx* c, float* xb, float* att, const float* q, const float* kc_layer,
@@ -492,17 +499,26 @@ static int launch_attention(rama_ctx* c, float* xb, float* att, const float* q, 
 #undef RAMA_SPLIT_G
 #undef RAMA_SPLIT_LAUNCH
         LAUNCHCHK();
-        hipLaunchKernelGGL(attention_combine_kernel, dim3(n_heads), dim3(((head_size + 63) / 64) * 64), 0, c->stream,
-                           (const float*)c->attn_part, xb, head_size, nsplit);
+        {
+            const dim3 cg(n_heads), cb(((head_size + 63) / 64) * 64);
+            const float* part = c->attn_part;
+            if (c->tune_combine_v == 0) hipLaunchKernelGGL(attention_combine_loop_kernel, cg, cb, 0, c->stream, part, xb, head_size, nsplit);
+            else if (nsplit <= 8) hipLaunchKernelGGL(attention_combine_kernel<8>, cg, cb, 0, c->stream, part, xb, head_size, nsplit);
+            else if (nsplit <= 16) hipLaunchKernelGGL(attention_combine_kernel<16>, cg, cb, 0, c->stream, part, xb, head_size, nsplit);
+            else hipLaunchKernelGGL(attention_combine_kernel<32>, cg, cb, 0, c->stream, part, xb, head_size, nsplit);
+        }
         LAUNCHCHK();
         return 0;
     }
-    if (c->small_attn) {     // short contexts: a round of 4 waves covers 64 timesteps (3.5 vs 5.3 us per launch, tools/launch_floor.hip)
-        size_t shm4 = (size_t)(attn_scratch_floats(G, 4) + seq_len) * sizeof(float);
+    if (c->small_attn) {     // short contexts: fewer waves per head, one round covers the whole context
+        const int W = c->tune_small_waves;
+        size_t shm4 = (size_t)(attn_scratch_floats(G, W) + seq_len) * sizeof(float);
         REQUIRE(shm4 <= 64 * 1024, RAMA_EUNSUP, "attention: seq_len too long for the single-workgroup kernel");
-        if (G == 16) RAMA_LAUNCH(c, (attention_kernel<16, false, 4>), dim3(n_heads), dim3(256), shm4, p);
-        else if (G == 32) RAMA_LAUNCH(c, (attention_kernel<32, false, 4>), dim3(n_heads), dim3(256), shm4, p);
-        else RAMA_LAUNCH(c, (attention_kernel<64, false, 4>), dim3(n_heads), dim3(256), shm4, p);
+#define RAMA_SMALL_G(W_) do { if (G == 16) RAMA_LAUNCH(c, (attention_kernel<16, false, W_>), dim3(n_heads), dim3(W_ * 64), shm4, p); \
+                              else if (G == 32) RAMA_LAUNCH(c, (attention_kernel<32, false, W_>), dim3(n_heads), dim3(W_ * 64), shm4, p); \
+                              else RAMA_LAUNCH(c, (attention_kernel<64, false, W_>), dim3(n_heads), dim3(W_ * 64), shm4, p); } while (0)
+        if (W == 4) RAMA_SMALL_G(4); else RAMA_SMALL_G(8);
+#undef RAMA_SMALL_G
         LAUNCHCHK();
         return 0;
     }
@@ -525,7 +541,7 @@ int rama_multi_head_attention(rama_ctx* c, float* xb, float* att, const float* q
     REQUIRE(pos >= 0 && pos < seq_len && layer >= 0 && n_heads > 0 && n_heads * head_size == dim, RAMA_EINVAL, "multi_head_attention: bad shape");
     const size_t lo = (size_t)layer * seq_len * dim;   // cpu.rs:28
     if (c->tune_ref_order) return launch_attention_ref(c, xb, att, q, key_cache + lo, value_cache + lo, nullptr, pos, dim, head_size, seq_len, n_heads);
-    c->small_attn = small_attn_at(c, pos, false);
+    c->small_attn = small_attn_at(c, pos, false, dim);
     return launch_attention(c, xb, att, q, key_cache + lo, value_cache + lo, nullptr, pos, dim, head_size, seq_len, n_heads);
 }
 
@@ -709,7 +725,7 @@ static int enqueue_stage(rama_ctx* c, const rama_config* cfg, const rama_weights
             LAUNCHCHK();
         }
         bool merged = false;
-        const bool want_merge = c->tune_merge < 0 ? dim <= 1024 : c->tune_merge != 0;
+        const bool want_merge = merge_wanted(c, dim);
         if (want_merge && !c->split_attn && !c->small_attn && c->kp.kernel_id < 0) {   // infer.rs:34-37 as one launch (per-kernel timing keeps them apart)
             int rc = try_launch_attn_wo(c, cfg, w, s, li, kc, vc, &merged);
             if (rc) return rc;
@@ -794,7 +810,7 @@ int rama_forward_stage(rama_ctx* c, const rama_config* cfg, const rama_weights* 
     c->embedded_x = nullptr;
     c->host_pos = -1;
     c->split_attn = pos >= split_threshold(c, cfg);
-    c->small_attn = small_attn_at(c, pos, c->split_attn);
+    c->small_attn = small_attn_at(c, pos, c->split_attn, cfg->dim);
     return enqueue_stage(c, cfg, w, s, st);
 }
 
@@ -813,7 +829,7 @@ int rama_forward_stage_devtok(rama_ctx* c, const rama_config* cfg, const rama_we
     c->embedded_x = nullptr;
     c->host_pos = -1;
     c->split_attn = pos >= split_threshold(c, cfg);
-    c->small_attn = small_attn_at(c, pos, c->split_attn);
+    c->small_attn = small_attn_at(c, pos, c->split_attn, cfg->dim);
     return enqueue_stage(c, cfg, w, s, st);
 }
 
@@ -1186,7 +1202,7 @@ int rama_decode_steps(rama_ctx* c, const rama_config* cfg, const rama_weights* w
     for (int i = 0; i < n_steps; i++) {
         // the attention variant depends on the position, which the host mirrors step by step
         c->split_attn = c->host_pos >= split_threshold(c, cfg);
-        c->small_attn = small_attn_at(c, c->host_pos, c->split_attn);
+        c->small_attn = small_attn_at(c, c->host_pos, c->split_attn, cfg->dim);
         if (graphs) {
             GraphCache& g = c->gc[c->split_attn ? 1 : (c->small_attn ? 2 : 0)];
             if (!same_capture(g, cfg, w, s)) {
@@ -1323,6 +1339,21 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
         drop_graph(c);
         if (ns) { c->tune_attn_nsplit = value; if (c->attn_part) { hipFree(c->attn_part); c->attn_part = nullptr; c->attn_part_floats = 0; } }
         else c->tune_attn_nt = value;
+        return 0;
+    }
+    if (!strcmp(key, "small_attn_waves") || !strcmp(key, "small_attn_pos")) {
+        const bool wv = !strcmp(key, "small_attn_waves");
+        REQUIRE(wv ? (value == 4 || value == 8) : value >= 0, RAMA_EINVAL, "set_tuning: small_attn_waves must be 4 or 8, small_attn_pos >= 0");
+        HIPCHK(hipStreamSynchronize(c->stream));
+        drop_graph(c);
+        if (wv) c->tune_small_waves = value; else c->tune_small_pos = value;
+        return 0;
+    }
+    if (!strcmp(key, "combine_v")) {
+        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: combine_v must be 0 or 1");
+        HIPCHK(hipStreamSynchronize(c->stream));
+        drop_graph(c);
+        c->tune_combine_v = value;
         return 0;
     }
     if (!strcmp(key, "attn_waves")) {

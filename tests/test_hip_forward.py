@@ -360,7 +360,7 @@ def test_launch_structures_equal_default_path(dev, name, graph, key):
         got = rama_amd.generate_greedy_device(rcfg, prompt, steps, wv, rsv, dev)
     finally:
         dev.lib.rama_set_graph_mode(dev.ctx, 0)
-        rama_amd._lib.check(dev.lib.rama_set_tuning(dev.ctx, key, {b"merge": -1, b"small_attn": 0, b"solo": -1}[key]))
+        rama_amd._lib.check(dev.lib.rama_set_tuning(dev.ctx, key, {b"merge": -1, b"small_attn": -1, b"solo": -1}[key]))
     assert got == want
     assert np.abs(dev.download(rsv.logits) - orc.s["logits"]).max() <= LOGIT_ATOL
     for buf in ("key_cache", "value_cache"):
