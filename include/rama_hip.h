@@ -223,6 +223,8 @@ typedef struct {
     float temperature, topp, u;   /* Device::sample on the last rank (u = the reference's constant draw) */
     int32_t *out_tokens_dev;      /* rank 0, optional: device [n_seq, n_pos], the id sampled AFTER each position */
 } rama_pipe_plan;
+/* the schedule alone (no GPU): 1 + (*seq, *pos) if `rank` of `world` computes an item at `tick`, 0 if idle */
+int  rama_pipe_item(const rama_pipe_plan *plan, int world, int rank, int tick, int *seq, int *pos);
 int  rama_pipe_total_ticks(const rama_pipe *pipe, const rama_pipe_plan *plan);   /* S * n_pos + world - 1 */
 /* Runs ticks [tick_from, tick_to) of this rank: states[s] is sequence s's run state for this stage
  * (its x is the hand-off buffer), tok_dev[s] its device token word.  Asynchronous on the context's

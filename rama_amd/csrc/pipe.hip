@@ -153,6 +153,16 @@ Item item_of(const rama_pipe_plan& pl, int world, int rank, int tick) {
 }
 }  // namespace
 
+// the schedule as pure arithmetic (no GPU, no communicator): what `rank` of `world` computes at `tick`.
+// Returns 1 and fills seq / pos when there is an item, 0 for an idle tick.
+extern "C" int rama_pipe_item(const rama_pipe_plan* plan, int world, int rank, int tick, int* seq, int* pos) {
+    if (!plan || world < 1 || rank < 0 || rank >= world || plan->n_seq < 1 || plan->n_pos < 1) return -1;
+    const Item it = item_of(*plan, world, rank, tick);
+    if (seq) *seq = it.seq;
+    if (pos) *pos = it.pos;
+    return it.on ? 1 : 0;
+}
+
 extern "C" int rama_pipe_total_ticks(const rama_pipe* p, const rama_pipe_plan* plan) {
     if (!p || !plan) return -1;
     return slots_of(*plan, p->world) * plan->n_pos + p->world - 1;

@@ -79,7 +79,7 @@ typedef __attribute__((ext_vector_type(4))) float acc4;
 // LD  1 (product): weights as described above.  2 / 3 are TIMING PROBES of the microbenchmark with
 //     wrong results: 2 = the same reads without the lane permute, 3 = fully contiguous 1-KiB reads
 //     (what a pre-swizzled second copy of the weights would give).
-template <int PT, int RT, int EPI, int JN = 2, int LD = 1>
+template <int PT, int RT, int EPI, int JN = 2, int LD = 1, int STAGGER = 0>
 __global__ __launch_bounds__(kMfThreads) void gemm_mfma_rows(MfParams p) {
     constexpr int NT = RT * PT;                          // accumulator tiles per wave
     constexpr bool ACROSS = EPI == EPI_QKV || EPI == EPI_SWIGLU;
@@ -258,6 +258,9 @@ __global__ __launch_bounds__(kMfThreads) void gemm_mfma_rows(MfParams p) {
 #pragma unroll 1
     for (int ul = 0; ul < nunit; ul++) {
         zero_acc();
+        // the two waves of a SIMD run the same program: half a step of delay for waves 4-7 lets one
+        // wave's loads / permutes fall under the other's MFMAs instead of both stalling together
+        if (STAGGER > 0 && wave >= kMfWaves / 2) __builtin_amdgcn_s_sleep(STAGGER);
 #pragma unroll 1
         for (int i = 0; i < S2; i++) {
             __builtin_amdgcn_sched_barrier(0);

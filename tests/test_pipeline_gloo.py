@@ -155,3 +155,33 @@ def test_run_ticks_wraps_at_seq_len():
     seq1 = [(p, t) for s, p, t in be.calls if s == 1]
     assert seq0 == [(0, BOS), (1, 11), (2, 12), (0, BOS), (1, 11), (2, 12), (0, BOS)]
     assert seq1 == [(0, BOS), (1, None), (2, None), (0, BOS), (1, None), (2, None), (0, BOS)]
+
+
+def test_native_schedule_matches_python_schedule():
+    """csrc/pipe.hip's tick -> item arithmetic (rama_pipe_item, no GPU involved) against Schedule, for
+    every rank and tick; with fewer sequences than stages the native plan idles the extra slots"""
+    import ctypes as C
+    import rama_amd
+    from rama_amd._lib import rama_pipe_plan
+    from rama_amd.pipeline import Schedule
+    lib = rama_amd.load()
+    for world, n_seq, n_pos in [(1, 1, 5), (2, 2, 4), (3, 5, 3), (4, 4, 6), (8, 8, 3)]:
+        sched = Schedule(world, n_seq, n_pos)
+        plan = rama_pipe_plan(n_seq, n_pos, 0, None, 0, 0.0, 0.9, 0.0, None)
+        for rank in range(world):
+            for tick in range(sched.ticks + 2):
+                seq, pos = C.c_int(), C.c_int()
+                on = lib.rama_pipe_item(C.byref(plan), world, rank, tick, C.byref(seq), C.byref(pos))
+                it = sched.item(rank, tick)
+                assert on == (1 if it is not None else 0), (world, n_seq, rank, tick)
+                if it is not None:
+                    assert (seq.value, pos.value) == (it.seq, it.pos)
+    # one sequence through four stages: a slot round is 4 ticks, position p enters rank r at tick 4 p + r
+    plan = rama_pipe_plan(1, 3, 0, None, 0, 0.0, 0.9, 0.0, None)
+    for rank in range(4):
+        busy = []
+        for tick in range(4 * 3 + 3):
+            seq, pos = C.c_int(), C.c_int()
+            if lib.rama_pipe_item(C.byref(plan), 4, rank, tick, C.byref(seq), C.byref(pos)) == 1:
+                busy.append((tick, seq.value, pos.value))
+        assert busy == [(4 * p + rank, 0, p) for p in range(3)]

@@ -32,7 +32,7 @@ __global__ void fill_kernel(float* d, size_t n, unsigned seed, float scale) {
 struct Shape { const char* name; int rows, K; };
 
 enum { MODE_ROWS = 0, MODE_QKV = 1, MODE_SWIGLU = 2 };
-template <int PT, int RT, int JN, int LD, int MODE>
+template <int PT, int RT, int JN, int LD, int MODE, int STAGGER = 0>
 static void launch(hipStream_t st, const float* W, const float* XT, float* O, size_t slab, int K, int rows, int P, int cus, int ks) {
     MfParams p{};
     p.x = XT; p.o = O; p.slab_floats = slab; p.o_stride = rows; p.K = K; p.n_tok = P; p.ksplit = ks;
@@ -48,7 +48,7 @@ static void launch(hipStream_t st, const float* W, const float* XT, float* O, si
     p.nunit = std::max(1, (total + cus - 1) / cus);
     const int grid = (total + p.nunit - 1) / p.nunit;
     constexpr int EPI = MODE == MODE_QKV ? EPI_QKV : (MODE == MODE_SWIGLU ? EPI_SWIGLU : EPI_STORE);
-    hipLaunchKernelGGL((gemm_mfma_rows<PT, RT, EPI, JN, LD>), dim3(grid), dim3(kMfThreads), 0, st, p);
+    hipLaunchKernelGGL((gemm_mfma_rows<PT, RT, EPI, JN, LD, STAGGER>), dim3(grid), dim3(kMfThreads), 0, st, p);
 }
 typedef void (*LaunchFn)(hipStream_t, const float*, const float*, float*, size_t, int, int, int, int, int);
 struct Variant { const char* name; LaunchFn fn; int P; int ks; bool check; };
@@ -74,23 +74,17 @@ int main(int argc, char** argv) {
     CK(hipStreamSynchronize(st));
 
     std::vector<Variant> vs = {
-        {"PT4 RT1 J2 ks1        ", launch<4, 1, 2, 1, MODE_ROWS>, 64, 1, true},
-        {"PT4 RT1 J2 ks1 mfmaX  ", launch<4, 1, 2, 5, MODE_ROWS>, 64, 1, false},
-        {"PT4 RT2 J2 ks2        ", launch<4, 2, 2, 1, MODE_ROWS>, 64, 2, true},
-        {"PT4 RT2 J2 ks2 mfmaX  ", launch<4, 2, 2, 5, MODE_ROWS>, 64, 2, false},
-        {"PT4 RT2 J4 ks2        ", launch<4, 2, 4, 1, MODE_ROWS>, 64, 2, true},
-        {"PT2 RT2 J4 ks2        ", launch<2, 2, 4, 1, MODE_ROWS>, 32, 2, true},
-        {"PT2 RT2 J2 ks2        ", launch<2, 2, 2, 1, MODE_ROWS>, 32, 2, true},
-        {"PT1 RT2 J4 ks2        ", launch<1, 2, 4, 1, MODE_ROWS>, 16, 2, true},
-        {"PT1 RT1 J4 ks1        ", launch<1, 1, 4, 1, MODE_ROWS>, 16, 1, true},
-        {"PT4 qkv3 J2 (time only)", launch<4, 3, 2, 1, MODE_QKV>, 64, 1, false},
-        {"PT2 qkv3 J2 (time only)", launch<2, 3, 2, 1, MODE_QKV>, 32, 1, false},
-        {"PT2 qkv3 J4 (time only)", launch<2, 3, 4, 1, MODE_QKV>, 32, 1, false},
-        {"PT1 qkv3 J4 (time only)", launch<1, 3, 4, 1, MODE_QKV>, 16, 1, false},
-        {"PT4 swiglu J2 (time only)", launch<4, 2, 2, 1, MODE_SWIGLU>, 64, 1, false},
-        {"PT2 swiglu J2 (time only)", launch<2, 2, 2, 1, MODE_SWIGLU>, 32, 1, false},
-        {"PT2 swiglu J4 (time only)", launch<2, 2, 4, 1, MODE_SWIGLU>, 32, 1, false},
-        {"PT1 swiglu J4 (time only)", launch<1, 2, 4, 1, MODE_SWIGLU>, 16, 1, false},
+        {"PT4 RT2 J2 ks2          ", launch<4, 2, 2, 1, MODE_ROWS>, 64, 2, true},
+        {"PT4 RT2 J2 ks2 stagger8 ", launch<4, 2, 2, 1, MODE_ROWS, 8>, 64, 2, true},
+        {"PT4 RT2 J2 ks2 stagger16", launch<4, 2, 2, 1, MODE_ROWS, 16>, 64, 2, true},
+        {"PT4 RT2 J2 ks2 stagger32", launch<4, 2, 2, 1, MODE_ROWS, 32>, 64, 2, true},
+        {"PT4 qkv3 J2             ", launch<4, 3, 2, 1, MODE_QKV>, 64, 1, false},
+        {"PT4 qkv3 J2 stagger16   ", launch<4, 3, 2, 1, MODE_QKV, 16>, 64, 1, false},
+        {"PT4 qkv3 J2 stagger32   ", launch<4, 3, 2, 1, MODE_QKV, 32>, 64, 1, false},
+        {"PT4 qkv3 J2 stagger64   ", launch<4, 3, 2, 1, MODE_QKV, 64>, 64, 1, false},
+        {"PT4 swiglu J2           ", launch<4, 2, 2, 1, MODE_SWIGLU>, 64, 1, false},
+        {"PT4 swiglu J2 stagger16 ", launch<4, 2, 2, 1, MODE_SWIGLU, 16>, 64, 1, false},
+        {"PT4 swiglu J2 stagger32 ", launch<4, 2, 2, 1, MODE_SWIGLU, 32>, 64, 1, false},
     };
     for (const Shape& sh : shapes) {
         printf("== %s\n", sh.name);
