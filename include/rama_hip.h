@@ -292,6 +292,10 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *                   merged with Wo (+0.7 % tokens/s at llama2-7B, positions 8..135)
  *   "solo" = -1|0|1 : matvecs with one wave per row group and no LDS turn; -1 (default) = for rows of <= 2048
  *                   floats (the stories15M / 110M widths), where launches are latency-bound
+ *   "topp_sort" = 0|1 : ordering step of the top-p sampler for vocabularies <= 32768: 1 (default) = block sorts in
+ *                   LDS + ranks by binary search (2 launches, csrc/topp_sort.hpp); 0 = the library radix sort of all
+ *                   n pairs (what larger vocabularies always take).  Same token either way.
+ *   "topp_keep_sums" = 0|1 : 1 makes the top-p sampler also store its running sums in device scratch (tests)
  *   "ref_order" = 0|1 : 1 computes every op in the REFERENCE'S OWN rounding order (csrc/ref_order.hpp: 4-lane
  *                   sequential matvec sums with separate multiply and add, sequential rmsnorm / softmax
  *                   sums, glibc's expf restated) so results can be compared with the reference CPU path

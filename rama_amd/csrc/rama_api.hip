@@ -3,6 +3,7 @@
 #include "../../include/rama_hip.h"
 #include "kernels.hpp"
 #include "attn_wo.hpp"
+#include "topp_sort.hpp"
 #include "prefill_mfma.hpp"
 #include "ref_order.hpp"
 #include <hipcub/hipcub.hpp>
@@ -87,6 +88,9 @@ struct rama_ctx {
     float* topp_keys[2] = {nullptr, nullptr}; int* topp_vals[2] = {nullptr, nullptr};
     float* topp_prefix = nullptr; int* topp_m = nullptr; unsigned* topp_err = nullptr;
     void* topp_tmp = nullptr; size_t topp_tmp_bytes = 0; int topp_cap = 0;
+    float* topp_bp = nullptr; int* topp_bi = nullptr; int* topp_bcount = nullptr;       // topp_sort.hpp
+    int tune_topp_sort = 1;                 // 0: library radix sort for every vocabulary size
+    int tune_topp_keep_sums = 0;            // 1: the scan sampler also writes its running sums to global memory (tests)
     int tune_split_pos = -1;               // attention runs split-T (+ combine launch) from this position on; -1 = by model size
     int tune_resid_r2 = 2;                 // Wo / W2 under geometry 3: 0 = 4-row workgroups, 1 = 2 rows x 8 waves (+0.45 %),
                                            // 2 = additionally 16 waves for rows wider than 8192 floats (W2: +1.15 % more), 3 = 16 waves x 4 chunks
@@ -119,6 +123,14 @@ static int set_device(rama_ctx* c) { HIPCHK(hipSetDevice(c->device)); return 0; 
 // internal accessors for the library's other translation units (pipe.hip); not in the C ABI header
 extern "C" void* rama_internal_stream(rama_ctx* c) { return c ? (void*)c->stream : nullptr; }
 extern "C" int rama_internal_device(rama_ctx* c) { return c ? c->device : 0; }
+// the sampler's device scratch after a rama_sample_topp* call (tests compare the running sums with a
+// sequential fp32 cumsum): sorted probabilities, sorted indices, running sums, candidate count
+extern "C" void rama_internal_topp_scratch(rama_ctx* c, float** keys, int** vals, float** prefix, int** m) {
+    if (keys) *keys = c->topp_keys[1];
+    if (vals) *vals = c->topp_vals[1];
+    if (prefix) *prefix = c->topp_prefix;
+    if (m) *m = c->topp_m;
+}
 
 int rama_ctx_create(int device, void* hip_stream, rama_ctx** out) {
     REQUIRE(out, RAMA_EINVAL, "rama_ctx_create: out is NULL");
@@ -173,6 +185,7 @@ int rama_ctx_destroy(rama_ctx* c) {
     hipFree(c->ctl); hipFree(c->out); hipFree(c->forced); hipFree(c->argmax_result); hipFree(c->pbar); hipFree(c->attn_counter); hipFree(c->attn_part);
     for (int i = 0; i < 2; i++) { hipFree(c->topp_keys[i]); hipFree(c->topp_vals[i]); }
     hipFree(c->topp_prefix); hipFree(c->topp_m); hipFree(c->topp_err); hipFree(c->topp_tmp); hipFree(c->pf_blob);
+    hipFree(c->topp_bp); hipFree(c->topp_bi); hipFree(c->topp_bcount);
     hipHostFree(c->pinned_int); hipHostFree(c->pinned_tok);
     hipEventDestroy(c->t0); hipEventDestroy(c->t1);
     if (c->own_stream) hipStreamDestroy(c->stream);
@@ -833,7 +846,8 @@ int rama_forward_stage_devtok(rama_ctx* c, const rama_config* cfg, const rama_we
     return enqueue_stage(c, cfg, w, s, st);
 }
 
-// ---- device top-p sampler (kernels.hpp: topp_prepare_kernel, hipCUB stable radix sort, topp_pick_kernel)
+// ---- device top-p sampler (topp_sort.hpp: block sorts + ranks for n <= 32768, else kernels.hpp's
+//      topp_prepare_kernel + hipCUB stable radix sort; then topp_pick_kernel)
 
 // scratch for n logits; called outside any stream capture
 static int ensure_topp_scratch(rama_ctx* c, int n) {
@@ -846,7 +860,12 @@ static int ensure_topp_scratch(rama_ctx* c, int n) {
         HIPCHK(hipMalloc(&c->topp_vals[i], sizeof(int) * n));
     }
     hipFree(c->topp_prefix); HIPCHK(hipMalloc(&c->topp_prefix, sizeof(float) * n));
-    if (!c->topp_m) { HIPCHK(hipMalloc(&c->topp_m, sizeof(int))); HIPCHK(hipMalloc(&c->topp_err, sizeof(unsigned))); HIPCHK(hipMemset(c->topp_err, 0, sizeof(unsigned))); }
+    if (!c->topp_m) {
+        HIPCHK(hipMalloc(&c->topp_m, sizeof(int))); HIPCHK(hipMalloc(&c->topp_err, sizeof(unsigned))); HIPCHK(hipMemset(c->topp_err, 0, sizeof(unsigned)));
+        HIPCHK(hipMalloc(&c->topp_bp, sizeof(float) * kToppBlock * kToppMaxBlocks));
+        HIPCHK(hipMalloc(&c->topp_bi, sizeof(int) * kToppBlock * kToppMaxBlocks));
+        HIPCHK(hipMalloc(&c->topp_bcount, sizeof(int) * kToppMaxBlocks));
+    }
     size_t bytes = 0;
     HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes, c->topp_keys[0], c->topp_keys[1], c->topp_vals[0], c->topp_vals[1], n, 0, 32, c->stream));
     hipFree(c->topp_tmp); c->topp_tmp = nullptr;
@@ -868,13 +887,28 @@ static int enqueue_sample(rama_ctx* c, ArgmaxParams fin, float temperature, floa
     ToppParams tp{};
     tp.logits = fin.logits; tp.n = fin.n; tp.temperature = temperature; tp.topp = topp; tp.u = u;
     tp.keys = c->topp_keys[0]; tp.vals = c->topp_vals[0]; tp.prefix = c->topp_prefix; tp.m = c->topp_m; tp.err = c->topp_err;
-    hipLaunchKernelGGL(topp_prepare_kernel, dim3(1), dim3(1024), 0, c->stream, tp);
-    LAUNCHCHK();
-    size_t bytes = c->topp_tmp_bytes;
-    HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(c->topp_tmp, bytes, c->topp_keys[0], c->topp_keys[1], c->topp_vals[0], c->topp_vals[1],
-                                                        fin.n, 0, 32, c->stream));
+    const bool lds_path = c->tune_topp_sort && fin.n <= kToppBlock * kToppMaxBlocks;     // the list fits one workgroup's LDS
+    if (lds_path) {
+        // block sorts in LDS + rank by binary search (topp_sort.hpp): 2 launches
+        ToppSortParams sp{};
+        sp.logits = fin.logits; sp.n = fin.n; sp.temperature = temperature; sp.topp = topp;
+        sp.bp = c->topp_bp; sp.bi = c->topp_bi; sp.bcount = c->topp_bcount; sp.keys = c->topp_keys[1]; sp.vals = c->topp_vals[1];
+        sp.m = c->topp_m; sp.err = c->topp_err; sp.nblk = (fin.n + kToppBlock - 1) / kToppBlock;
+        hipLaunchKernelGGL(topp_blocksort_kernel, dim3(sp.nblk), dim3(1024), 0, c->stream, sp);
+        LAUNCHCHK();
+        hipLaunchKernelGGL(topp_rank_kernel<kToppMaxBlocks>, dim3(sp.nblk * (kToppBlock / kRankThreads)), dim3(kRankThreads), 0, c->stream, sp);
+        LAUNCHCHK();
+    } else {
+        hipLaunchKernelGGL(topp_prepare_kernel, dim3(1), dim3(1024), 0, c->stream, tp);
+        LAUNCHCHK();
+        size_t bytes = c->topp_tmp_bytes;
+        HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(c->topp_tmp, bytes, c->topp_keys[0], c->topp_keys[1], c->topp_vals[0], c->topp_vals[1],
+                                                            fin.n, 0, 32, c->stream));
+    }
     tp.keys = c->topp_keys[1]; tp.vals = c->topp_vals[1];
-    hipLaunchKernelGGL(topp_pick_kernel, dim3(1), dim3(1024), 0, c->stream, tp, fin);
+    if (lds_path && !c->tune_topp_keep_sums) tp.prefix = nullptr;
+    if (lds_path) hipLaunchKernelGGL(topp_pick_scan_kernel, dim3(1), dim3(1024), 0, c->stream, tp, fin);
+    else hipLaunchKernelGGL(topp_pick_kernel, dim3(1), dim3(1024), 0, c->stream, tp, fin);
     LAUNCHCHK();
     return 0;
 }
@@ -1366,6 +1400,13 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
     if (!strcmp(key, "small_attn")) {
         REQUIRE(value >= -1 && value <= 1, RAMA_EINVAL, "set_tuning: small_attn must be -1, 0 or 1");
         c->tune_small_attn = value;
+        hipStreamSynchronize(c->stream);
+        drop_graph(c);
+        return 0;
+    }
+    if (!strcmp(key, "topp_sort") || !strcmp(key, "topp_keep_sums")) {
+        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: topp_sort / topp_keep_sums must be 0 or 1");
+        if (!strcmp(key, "topp_sort")) c->tune_topp_sort = value; else c->tune_topp_keep_sums = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
         return 0;

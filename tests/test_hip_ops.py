@@ -307,6 +307,102 @@ def test_sample_topp_dev_ties_keep_index_order(dev):
         assert _topp_dev(dev, x, 1.0, 0.9, u) == O.sample(x.copy(), 1.0, 0.9, u)
 
 
+@pytest.mark.parametrize("n", [2047, 2048, 2049, 4096, 31999, 32768, 32769])
+@pytest.mark.parametrize("scale", [0.05, 3.0, 12.0])
+def test_sample_topp_dev_both_orderings_agree(dev, n, scale):
+    """the block-sort + rank ordering (csrc/topp_sort.hpp, n <= 32768) and the library radix sort give
+    the same token as the oracle at the block-size boundaries; 32769 takes the radix sort either way"""
+    from rama_amd._lib import check
+    x = rnd(n, 100 + n % 97, scale)
+    x[[0, n // 2, n - 1]] = x.max()                      # equal maxima in the first, a middle and the last block
+    for temperature, topp, u in [(1.0, 0.9, 0.2721174359321594), (0.8, 0.95, 0.6), (1.0, 1.0, 0.97)]:
+        want = O.sample(x.copy(), temperature, topp, u)
+        got = {}
+        try:
+            for mode in (1, 0):
+                check(dev.lib.rama_set_tuning(dev.ctx, b"topp_sort", mode))
+                got[mode] = _topp_dev(dev, x, temperature, topp, u)
+        finally:
+            check(dev.lib.rama_set_tuning(dev.ctx, b"topp_sort", 1))
+        assert got[1] == got[0], (n, scale, temperature, topp, u, got, want)
+        if u * topp <= 0.9:                               # away from the far tail (see the test above)
+            assert got[1] == want, (n, scale, temperature, topp, u, got, want)
+
+
+def test_sample_topp_dev_many_ties_across_blocks(dev):
+    """every logit equal: 32000 equal probabilities, all kept -- the order is the index order, in and
+    across the 2048-entry sorting blocks (infer.rs:64 stable sort)"""
+    x = np.full(32000, 0.25, dtype=np.float32)
+    for u in (0.0, 0.1, 0.5, 0.9, 0.999):
+        assert _topp_dev(dev, x, 1.0, 0.9, u) == O.sample(x.copy(), 1.0, 0.9, u)
+    x[::3] = 0.5                                           # two probability levels interleaved over all blocks
+    for u in (0.0, 0.3, 0.6, 0.99):
+        assert _topp_dev(dev, x, 1.0, 0.9, u) == O.sample(x.copy(), 1.0, 0.9, u)
+
+
+def _topp_scratch(dev, nmax):
+    """(m, sorted probabilities, sorted indices, running sums) the sampler left on the device"""
+    import ctypes as C
+    from rama_amd._lib import check
+    f = dev.lib.rama_internal_topp_scratch
+    f.restype = None
+    f.argtypes = [C.c_void_p] + [C.POINTER(C.c_void_p)] * 4
+    keys, vals, prefix, m = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+    f(dev.ctx, C.byref(keys), C.byref(vals), C.byref(prefix), C.byref(m))
+    def down(ptr, n):
+        out = np.empty(n, dtype=np.float32)
+        check(dev.lib.rama_download_f32(dev.ctx, ptr, n, out.ctypes.data), "rama_download_f32")
+        return out
+    mm = int(down(m, 1).view(np.int32)[0])
+    return mm, down(keys, nmax)[:mm], down(vals, nmax).view(np.int32)[:mm], down(prefix, nmax)
+
+
+def _seq_cumsum_until(p, topp):
+    """infer.rs:70-73 on the host: sequential fp32 sums; (sums up to and including the crossing, last)"""
+    cum = np.cumsum(p, dtype=np.float32)                  # add.accumulate: one rounding per element, in order
+    over = np.nonzero(cum > np.float32(topp))[0]
+    last = int(over[0]) if over.size else len(p) - 1
+    return cum[:last + 1], last
+
+
+TOPP_SUM_CASES = [("flat", 32000, 0.05, 0.9), ("flat", 32000, 0.05, 1.0), ("ordinary", 32000, 3.0, 0.9), ("peaked", 32000, 12.0, 0.95),
+                  ("equal", 32000, 0.0, 0.9), ("equal", 30011, 0.0, 0.99), ("two_levels", 32000, 0.0, 0.9), ("pow2", 32768, 0.0, 0.9),
+                  ("flat", 2049, 0.1, 0.9), ("ordinary", 4097, 2.0, 0.999), ("flat", 100, 0.1, 0.5), ("steps", 32000, 0.0, 0.97)]
+
+
+@pytest.mark.parametrize("kind,n,scale,topp", TOPP_SUM_CASES)
+def test_sample_topp_dev_running_sums_are_the_sequential_ones(dev, kind, n, scale, topp):
+    """the sampler's sorted order and every running sum up to the crossing, bit for bit against a
+    sequential fp32 accumulation of the device's own sorted probabilities (csrc/topp_sort.hpp forms
+    them with a parallel scan over integer increments): flat lists where cum walks through ~15
+    binades, all-equal probabilities (every add in a binade rounds the same way; ties to even when
+    the probability's low bits are 10..0), power-of-two probabilities, staircase lists"""
+    if kind == "equal":
+        x = np.full(n, 0.125, dtype=np.float32)
+    elif kind == "two_levels":
+        x = np.full(n, 0.0, dtype=np.float32); x[::3] = np.float32(np.log(2.0))
+    elif kind == "pow2":
+        x = np.zeros(n, dtype=np.float32)                  # p = 2^-15 exactly: every add is exact until the ties begin
+    elif kind == "steps":
+        x = (np.arange(n) // 1000).astype(np.float32) * np.float32(0.6931472)       # 32 plateaus, each twice the last
+    else:
+        x = rnd(n, 7 + n % 13, scale)
+    from rama_amd._lib import check
+    check(dev.lib.rama_set_tuning(dev.ctx, b"topp_keep_sums", 1))
+    try:
+        _topp_dev(dev, x, 1.0, topp, 0.5)
+    finally:
+        check(dev.lib.rama_set_tuning(dev.ctx, b"topp_keep_sums", 0))
+    m, ps, idx, prefix = _topp_scratch(dev, n)
+    assert m > 0
+    # order: descending probability, equal ones by ascending index (stable sort of the index-ordered list)
+    assert np.all((ps[:-1] > ps[1:]) | ((ps[:-1] == ps[1:]) & (idx[:-1] < idx[1:])))
+    assert len(set(idx.tolist())) == m
+    want, last = _seq_cumsum_until(ps, topp)
+    got = prefix[:last + 1]
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (kind, int(np.nonzero(got != want)[0][0]), last, m)
+
+
 def test_sample_topp_dev_temperature_zero_is_argmax(dev):
     x = rnd(5000, 9, 2.0)
     x[[10, 4000]] = 50.0
