@@ -287,6 +287,9 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *   "attn_nsplit" = 0..32, "attn_waves" = 16|8|4, "attn_nt" = 0|1 : geometry of the split-T attention of long
  *                   contexts: slices per head (0 = #CUs / n_heads, at most 16), waves per workgroup (default 8)
  *                   and non-temporal cache-row loads (default 1); tools/attn_sweep.py
+ *   "attn_u" = 8|16 : cache rows of K and of V a lane requests per round there; 16 (at <= 8 waves) makes a round 256
+ *                   timesteps at head size 128 -- a whole slice of a 2048-token context in one round trip; measured
+ *                   no faster (14.9 vs 14.1 us per launch at 1900 tokens), default 8
  *   "small_attn" = -1|0|1, "small_attn_waves" = 4|8, "small_attn_pos" = N : fewer-wave attention workgroups in the
  *                   decode step; -1 (default): 8 waves per head below position 256 where attention is not
  *                   merged with Wo (+0.7 % tokens/s at llama2-7B, positions 8..135)

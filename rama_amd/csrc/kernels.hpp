@@ -551,7 +551,10 @@ __host__ __device__ constexpr int attn_scratch_floats(int G, int W = kAttnWaves)
 // (head, query) workgroups): a round of 4 waves already covers 64 timesteps, and 8 such workgroups fit a CU
 // NT: cache rows are fetched non-temporally (long contexts: every row is read once per step and the
 // 2 GB/token K/V stream of llama2-7B at 2K context should not evict anything)
-template <int G, bool SPLIT, int W = kAttnWaves, bool NT = false>
+// UU: cache rows a lane keeps in flight per round (K and V each).  16 at 8 waves makes a round 256
+// timesteps (head_size 128): a whole split-T slice of a 2048-token context, so K AND V are requested
+// up front and the slice costs one memory round trip instead of three.
+template <int G, bool SPLIT, int W = kAttnWaves, bool NT = false, int UU = 8>
 __global__ __launch_bounds__(W * 64) void attention_kernel(AttnParams p) {
     constexpr int kAttnWaves = W, kAttnThreads = W * 64;       // shadow the 16-wave defaults
     extern __shared__ float sm[];
@@ -559,7 +562,7 @@ __global__ __launch_bounds__(W * 64) void attention_kernel(AttnParams p) {
     float* s_sum = sm + kAttnWaves;
     float* s_acc = sm + 2 * kAttnWaves;
     float* s_att = sm + attn_scratch_floats(G, W);
-    constexpr int U = 8;
+    constexpr int U = UU;
     constexpr int TPW = 64 / G;                       // timesteps per wave-instruction
     constexpr int TILE = kAttnWaves * TPW * U;        // timesteps per workgroup round
     const int h = blockIdx.x;

@@ -89,6 +89,7 @@ struct rama_ctx {
     float* topp_prefix = nullptr; int* topp_m = nullptr; unsigned* topp_err = nullptr;
     void* topp_tmp = nullptr; size_t topp_tmp_bytes = 0; int topp_cap = 0;
     float* topp_bp = nullptr; int* topp_bi = nullptr; int* topp_bcount = nullptr;       // topp_sort.hpp
+    int tune_attn_u = 8;                    // cache rows per lane and round in the split-T attention (8 | 16; 16 measured no faster)
     int tune_topp_sort = 1;                 // 0: library radix sort for every vocabulary size
     int tune_topp_keep_sums = 0;            // 1: the scan sampler also writes its running sums to global memory (tests)
     int tune_split_pos = -1;               // attention runs split-T (+ combine launch) from this position on; -1 = by model size
@@ -504,11 +505,19 @@ static int launch_attention(rama_ctx* c, float* xb, float* att, const float* q, 
         const int chunk_max = (seq_len + nsplit - 1) / nsplit;
         dim3 grid(n_heads, nsplit);
         // template dispatch: G lanes per row x W waves per workgroup x cache-load policy
-#define RAMA_SPLIT_LAUNCH(G_, W_, NT_) RAMA_LAUNCH(c, (attention_kernel<G_, true, W_, NT_>), grid, dim3(W_ * 64), (size_t)(attn_scratch_floats(G_, W_) + chunk_max) * sizeof(float), p)
-#define RAMA_SPLIT_G(W_, NT_) do { if (G == 16) RAMA_SPLIT_LAUNCH(16, W_, NT_); else if (G == 32) RAMA_SPLIT_LAUNCH(32, W_, NT_); else RAMA_SPLIT_LAUNCH(64, W_, NT_); } while (0)
+#define RAMA_SPLIT_LAUNCH(G_, W_, NT_, U_) RAMA_LAUNCH(c, (attention_kernel<G_, true, W_, NT_, U_>), grid, dim3(W_ * 64), (size_t)(attn_scratch_floats(G_, W_) + chunk_max) * sizeof(float), p)
+#define RAMA_SPLIT_G(W_, NT_, U_) do { if (G == 16) RAMA_SPLIT_LAUNCH(16, W_, NT_, U_); else if (G == 32) RAMA_SPLIT_LAUNCH(32, W_, NT_, U_); else RAMA_SPLIT_LAUNCH(64, W_, NT_, U_); } while (0)
         const int W = c->tune_attn_waves;
-        if (c->tune_attn_nt) { if (W == 4) RAMA_SPLIT_G(4, true); else if (W == 8) RAMA_SPLIT_G(8, true); else RAMA_SPLIT_G(16, true); }
-        else { if (W == 4) RAMA_SPLIT_G(4, false); else if (W == 8) RAMA_SPLIT_G(8, false); else RAMA_SPLIT_G(16, false); }
+        const bool deep = c->tune_attn_u == 16 && W <= 8;          // 16 rows of K and of V per lane in flight: 128 VGPRs, fine at <= 2 waves per SIMD
+        if (c->tune_attn_nt) {
+            if (W == 4) { if (deep) RAMA_SPLIT_G(4, true, 16); else RAMA_SPLIT_G(4, true, 8); }
+            else if (W == 8) { if (deep) RAMA_SPLIT_G(8, true, 16); else RAMA_SPLIT_G(8, true, 8); }
+            else RAMA_SPLIT_G(16, true, 8);
+        } else {
+            if (W == 4) { if (deep) RAMA_SPLIT_G(4, false, 16); else RAMA_SPLIT_G(4, false, 8); }
+            else if (W == 8) { if (deep) RAMA_SPLIT_G(8, false, 16); else RAMA_SPLIT_G(8, false, 8); }
+            else RAMA_SPLIT_G(16, false, 8);
+        }
 #undef RAMA_SPLIT_G
 #undef RAMA_SPLIT_LAUNCH
         LAUNCHCHK();
@@ -1388,6 +1397,13 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
         HIPCHK(hipStreamSynchronize(c->stream));
         drop_graph(c);
         c->tune_combine_v = value;
+        return 0;
+    }
+    if (!strcmp(key, "attn_u")) {
+        REQUIRE(value == 8 || value == 16, RAMA_EINVAL, "set_tuning: attn_u must be 8 or 16");
+        HIPCHK(hipStreamSynchronize(c->stream));
+        drop_graph(c);
+        c->tune_attn_u = value;
         return 0;
     }
     if (!strcmp(key, "attn_waves")) {

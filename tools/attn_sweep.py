@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Long-context decode at the llama2-7B shape: tokens/s and the attention launches' time vs the number
-of split-T slices per head and the cache-load policy (rama_set_tuning "attn_nsplit", "attn_nt").
+of split-T slices per head, the cache-load policy and the rows in flight per lane (rama_set_tuning
+"attn_nsplit", "attn_nt", "attn_waves", "attn_u").
 The cache rows before the start position are zeros (uniform attention): timing only."""
 import json
 import sys
@@ -15,11 +16,11 @@ d, h, L, H, V, seq, shared = SHAPES["llama2-7B"]
 cfg = rama_amd.Config(d, h, L, H, H, V, seq, shared)
 dev = rama_amd.Hip(0)
 eng = rama_amd.Engine(dev, rama_amd.Model.synth(dev, cfg, seed=0))
-combos = [(1, 8, 16), (1, 8, 8), (1, 16, 8), (1, 24, 8), (1, 16, 4), (1, 32, 4), (1, 32, 8), (0, 16, 8)]
-for nt, ns, wv in combos:
+combos = [(1, 8, 8, 16), (1, 8, 8, 8), (1, 16, 8, 16), (1, 16, 8, 8), (1, 8, 4, 16), (1, 16, 4, 16), (1, 8, 16, 8), (0, 8, 8, 16)]
+for nt, ns, wv, au in combos:
     if True:
-        eng.set_tuning("attn_nt", nt); eng.set_tuning("attn_nsplit", ns); eng.set_tuning("attn_waves", wv)
-        row = {"attn_nt": nt, "attn_nsplit": ns, "attn_waves": wv}
+        eng.set_tuning("attn_nt", nt); eng.set_tuning("attn_nsplit", ns); eng.set_tuning("attn_waves", wv); eng.set_tuning("attn_u", au)
+        row = {"attn_nt": nt, "attn_nsplit": ns, "attn_waves": wv, "attn_u": au}
         for s in starts:
             eng.set_graph_mode(True)
             best = 0.0
