@@ -295,6 +295,10 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *                   merged with Wo (+0.7 % tokens/s at llama2-7B, positions 8..135)
  *   "solo" = -1|0|1 : matvecs with one wave per row group and no LDS turn; -1 (default) = for rows of <= 2048
  *                   floats (the stories15M / 110M widths), where launches are latency-bound
+ *   "graph_steps" = -1|1..32 : decode steps captured per hipGraph in rama_decode_steps / rama_generate (the cursor
+ *                   lives on the device, so consecutive steps are the same launches).  A graph launch costs ~7 us on
+ *                   top of its kernels; 4 steps per graph: +5.3 % tokens/s at stories15M, +1.4 % at 110M, +0.1 % at
+ *                   llama2-7B; 8 and more are slower again.  -1 (default): 4 for dim <= 1024, else 1
  *   "topp_sort" = 0|1 : ordering step of the top-p sampler for vocabularies <= 32768: 1 (default) = block sorts in
  *                   LDS + ranks by binary search (2 launches, csrc/topp_sort.hpp); 0 = the library radix sort of all
  *                   n pairs (what larger vocabularies always take).  Same token either way.

@@ -59,6 +59,7 @@ struct GraphCache {
     rama_weights w{};
     rama_run_state s{};
     bool valid = false;
+    int steps = 1;                     // decode steps in the captured graph
 };
 
 struct rama_ctx {
@@ -75,7 +76,7 @@ struct rama_ctx {
     int* pinned_int = nullptr;      // host pinned
     int* pinned_tok = nullptr;      // host pinned staging: token ids + a SeqSlot table of a token-batch pass
     bool graph_mode = false;
-    GraphCache gc[3];                  // by attention variant: [0] one 16-wave workgroup per head, [1] split-T (long contexts), [2] one 4-wave workgroup per head (short contexts)
+    GraphCache gc[6];                  // [0..2] one step per graph, [3..5] tune_graph_steps steps per graph; by attention variant: [0] one 16-wave workgroup per head, [1] split-T (long contexts), [2] one 4-wave workgroup per head (short contexts)
     KProf kp;
     int cu_count = 0;
     hipEvent_t cur_start = nullptr, cur_stop = nullptr;   // events the next profiled launch carries
@@ -89,6 +90,7 @@ struct rama_ctx {
     float* topp_prefix = nullptr; int* topp_m = nullptr; unsigned* topp_err = nullptr;
     void* topp_tmp = nullptr; size_t topp_tmp_bytes = 0; int topp_cap = 0;
     float* topp_bp = nullptr; int* topp_bi = nullptr; int* topp_bcount = nullptr;       // topp_sort.hpp
+    int tune_graph_steps = -1;              // decode steps captured per hipGraph (the cursor lives on the device, so steps are identical); -1: 4 for dim <= 1024, else 1
     int tune_attn_u = 8;                    // cache rows per lane and round in the split-T attention (8 | 16; 16 measured no faster)
     int tune_topp_sort = 1;                 // 0: library radix sort for every vocabulary size
     int tune_topp_keep_sums = 0;            // 1: the scan sampler also writes its running sums to global memory (tests)
@@ -1242,30 +1244,39 @@ int rama_decode_steps(rama_ctx* c, const rama_config* cfg, const rama_weights* w
     if (c->samp_T != 0.0f) { rc = ensure_topp_scratch(c, cfg->vocab_size); if (rc) return rc; }
     REQUIRE(c->host_pos + n_steps <= cfg->seq_len, RAMA_EINVAL, "decode_steps: would run past seq_len");
     const bool graphs = c->graph_mode && c->kp.kernel_id < 0;
-    for (int i = 0; i < n_steps; i++) {
+    auto variant_at = [&](int pos) {
+        const bool split = pos >= split_threshold(c, cfg);
+        return split ? 1 : (small_attn_at(c, pos, split, cfg->dim) ? 2 : 0);
+    };
+    for (int i = 0; i < n_steps;) {
         // the attention variant depends on the position, which the host mirrors step by step
         c->split_attn = c->host_pos >= split_threshold(c, cfg);
         c->small_attn = small_attn_at(c, c->host_pos, c->split_attn, cfg->dim);
+        int take = 1;
         if (graphs) {
-            GraphCache& g = c->gc[c->split_attn ? 1 : (c->small_attn ? 2 : 0)];
-            if (!same_capture(g, cfg, w, s)) {
+            const int v = variant_at(c->host_pos);
+            const int M = c->tune_graph_steps > 0 ? c->tune_graph_steps : (cfg->dim <= 1024 ? 4 : 1);
+            if (M > 1 && n_steps - i >= M && variant_at(c->host_pos + M - 1) == v) take = M;   // the variant changes at most once, monotonically
+            GraphCache& g = c->gc[v + (take > 1 ? 3 : 0)];
+            if (!same_capture(g, cfg, w, s) || g.steps != take) {
                 if (g.exec) hipGraphExecDestroy(g.exec);
                 if (g.graph) hipGraphDestroy(g.graph);
                 g = GraphCache();
                 HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-                rc = enqueue_decode_step(c, cfg, w, s);
+                for (int k = 0; k < take && !rc; k++) rc = enqueue_decode_step(c, cfg, w, s);
                 hipError_t e = hipStreamEndCapture(c->stream, &g.graph);
                 if (rc) return rc;
                 HIPCHK(e);
                 HIPCHK(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
-                g.cfg = *cfg; g.w = *w; g.s = *s; g.valid = true;
+                g.cfg = *cfg; g.w = *w; g.s = *s; g.valid = true; g.steps = take;
             }
             HIPCHK(hipGraphLaunch(g.exec, c->stream));
         } else {
             rc = enqueue_decode_step(c, cfg, w, s);
             if (rc) return rc;
         }
-        c->host_pos += 1;
+        c->host_pos += take;
+        i += take;
     }
     return 0;
 }
@@ -1397,6 +1408,13 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
         HIPCHK(hipStreamSynchronize(c->stream));
         drop_graph(c);
         c->tune_combine_v = value;
+        return 0;
+    }
+    if (!strcmp(key, "graph_steps")) {
+        REQUIRE(value == -1 || (value >= 1 && value <= 32), RAMA_EINVAL, "set_tuning: graph_steps must be -1 or 1..32");
+        HIPCHK(hipStreamSynchronize(c->stream));
+        drop_graph(c);
+        c->tune_graph_steps = value;
         return 0;
     }
     if (!strcmp(key, "attn_u")) {
