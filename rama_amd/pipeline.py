@@ -297,6 +297,7 @@ def run_pipeline_bench_native(args, cfg, rank: int, world: int, local_rank: int)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29531")
     os.environ["NCCL_DEBUG"] = os.environ.get("RAMA_NCCL_DEBUG", "NONE")    # RCCL prints its version banner on stdout at VERSION / WARN: one JSON line
+    torch.cuda.set_device(local_rank)  # torch.cuda.synchronize() below must mean THIS rank's GPU, not device 0 for everybody
     if not dist.is_initialized():      # control plane only: the id, barriers, the max over ranks
         with _stdout_to_stderr():      # gloo announces its connections on stdout; the bench prints ONE JSON line there
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
