@@ -295,6 +295,9 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *                   merged with Wo (+0.7 % tokens/s at llama2-7B, positions 8..135)
  *   "solo" = -1|0|1 : matvecs with one wave per row group and no LDS turn; -1 (default) = for rows of <= 2048
  *                   floats (the stories15M / 110M widths), where launches are latency-bound
+ *   "prefill_attn" = 0|1 : 1 (default) runs the attention of a prefill pass as fp32 MFMA tiles, 16 queries of a head
+ *                   per workgroup sharing every cache row (csrc/prefill_attn.hpp; head sizes 16, 32, 48, 64, 128); 0 = one
+ *                   decode-attention workgroup per (head, query)
  *   "graph_steps" = -1|1..32 : decode steps captured per hipGraph in rama_decode_steps / rama_generate (the cursor
  *                   lives on the device, so consecutive steps are the same launches).  A graph launch costs ~7 us on
  *                   top of its kernels; 4 steps per graph: +5.3 % tokens/s at stories15M, +1.4 % at 110M, +0.1 % at

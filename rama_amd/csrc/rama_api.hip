@@ -4,6 +4,7 @@
 #include "kernels.hpp"
 #include "attn_wo.hpp"
 #include "topp_sort.hpp"
+#include "prefill_attn.hpp"
 #include "prefill_mfma.hpp"
 #include "ref_order.hpp"
 #include <hipcub/hipcub.hpp>
@@ -90,6 +91,7 @@ struct rama_ctx {
     float* topp_prefix = nullptr; int* topp_m = nullptr; unsigned* topp_err = nullptr;
     void* topp_tmp = nullptr; size_t topp_tmp_bytes = 0; int topp_cap = 0;
     float* topp_bp = nullptr; int* topp_bi = nullptr; int* topp_bcount = nullptr;       // topp_sort.hpp
+    int tune_prefill_attn = 1;              // 1: prefill passes run attention as MFMA tiles, 16 queries per workgroup (prefill_attn.hpp)
     int tune_graph_steps = -1;              // decode steps captured per hipGraph (the cursor lives on the device, so steps are identical); -1: 4 for dim <= 1024, else 1
     int tune_attn_u = 8;                    // cache rows per lane and round in the split-T attention (8 | 16; 16 measured no faster)
     int tune_topp_sort = 1;                 // 0: library radix sort for every vocabulary size
@@ -1063,6 +1065,19 @@ static int run_layers_batched(rama_ctx* c, const rama_config* cfg, const rama_we
             a.seqs = seqs ? b.seqs : nullptr; a.layer_off = layer_off;
             const int G = hs <= 64 ? 16 : (hs <= 128 ? 32 : 64);
             dim3 grid(cfg->n_heads, 1, nt);
+            const bool tiles = !seqs && c->tune_prefill_attn && (hs == 16 || hs == 32 || hs == 48 || hs == 64 || hs == 128);
+            if (tiles) {            // one sequence: 16 queries per workgroup share every cache row (prefill_attn.hpp)
+                const dim3 tg(cfg->n_heads, ntile);
+#define RAMA_TILE_ATTN(W_) do { \
+                    if (hs == 16) hipLaunchKernelGGL((attention_tile_mfma_kernel<1, W_>), tg, dim3(W_ * 64), 0, c->stream, a, nt); \
+                    else if (hs == 32) hipLaunchKernelGGL((attention_tile_mfma_kernel<2, W_>), tg, dim3(W_ * 64), 0, c->stream, a, nt); \
+                    else if (hs == 48) hipLaunchKernelGGL((attention_tile_mfma_kernel<3, W_>), tg, dim3(W_ * 64), 0, c->stream, a, nt); \
+                    else if (hs == 64) hipLaunchKernelGGL((attention_tile_mfma_kernel<4, W_>), tg, dim3(W_ * 64), 0, c->stream, a, nt); \
+                    else hipLaunchKernelGGL((attention_tile_mfma_kernel<8, W_>), tg, dim3(W_ * 64), 0, c->stream, a, nt); } while (0)
+                if (tmax >= 512) RAMA_TILE_ATTN(8);     // long contexts: 8 waves share the key tiles
+                else RAMA_TILE_ATTN(4);
+#undef RAMA_TILE_ATTN
+            } else
             // scores scratch: tmax = the longest context of the pass (timesteps)
             if (tmax <= 256) {      // short contexts: 4-wave workgroups, 8 of them per CU
                 size_t shm = (size_t)(attn_scratch_floats(G, 4) + tmax) * sizeof(float);
@@ -1408,6 +1423,11 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
         HIPCHK(hipStreamSynchronize(c->stream));
         drop_graph(c);
         c->tune_combine_v = value;
+        return 0;
+    }
+    if (!strcmp(key, "prefill_attn")) {
+        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: prefill_attn must be 0 or 1");
+        c->tune_prefill_attn = value;
         return 0;
     }
     if (!strcmp(key, "graph_steps")) {

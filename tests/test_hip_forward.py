@@ -559,6 +559,39 @@ def test_prefill_long_prompts_cross_tile_and_pass_boundaries(dev, n_tokens, pos0
     rs.free(); ws.free()
 
 
+@pytest.mark.parametrize("n_heads,n_tokens,pos0", [(2, 150, 0), (2, 65, 3), (1, 100, 21), (2, 610, 7), (1, 530, 0)])
+def test_prefill_attention_tiles_long_contexts(dev, n_heads, n_tokens, pos0):
+    """the MFMA tile attention of a prefill pass (csrc/prefill_attn.hpp) at head sizes 64 and 128: several
+    key tiles per wave, start positions that are no multiple of 16 (a query tile then ends inside a
+    key tile), the 8-wave variant of contexts >= 512, and the per-query kernels as the other arm"""
+    import rama_amd
+    from rama_amd._lib import check
+    cfg = O.Config(128, 352, 2, n_heads, n_heads, 256, 640, False)
+    w = S.synth_weights(cfg, seed=13)
+    rng = np.random.default_rng(n_tokens)
+    toks = [1] + [int(t) for t in rng.integers(0, cfg.vocab_size, pos0 + n_tokens - 1)]
+    orc = O.Oracle(cfg, w)
+    for pos in range(pos0 + n_tokens):
+        lo = orc.forward(toks[pos], pos)
+    outs = {}
+    for mode in (1, 0):
+        rcfg, ws, wv, rs, rsv = gpu_views(dev, cfg, w)
+        for pos in range(pos0):
+            rama_amd.forward_fused(rcfg, wv, rsv, toks[pos], pos, dev)
+        check(dev.lib.rama_set_tuning(dev.ctx, b"prefill_attn", mode))
+        try:
+            _prefill(dev, rcfg, wv, rsv, toks[pos0:pos0 + n_tokens], pos0)
+        finally:
+            check(dev.lib.rama_set_tuning(dev.ctx, b"prefill_attn", 1))
+        outs[mode] = dev.download(rsv.logits)
+        assert np.abs(outs[mode] - lo).max() <= LOGIT_ATOL, mode
+        assert np.abs(dev.download(rsv.x) - orc.s["xb"]).max() <= STATE_ATOL
+        for buf in ("key_cache", "value_cache"):
+            assert np.abs(dev.download(getattr(rsv, buf)) - orc.s[buf]).max() <= STATE_ATOL
+        rs.free(); ws.free()
+    assert np.abs(outs[1] - outs[0]).max() <= 2e-5
+
+
 def test_prefill_argument_errors(dev):
     import rama_amd
     cfg, w, g = load_case("synth_d64_h4")
