@@ -368,6 +368,32 @@ def test_launch_structures_equal_default_path(dev, name, graph, key):
     rs.free(); ws.free()
 
 
+@pytest.mark.parametrize("graph_steps,merge,steps", [(4, 0, 290), (4, -1, 150), (3, 0, 271), (8, 0, 262), (1, 0, 262)])
+def test_multi_step_graphs_across_the_attention_variant_boundary(dev, graph_steps, merge, steps):
+    """rama_set_tuning("graph_steps", M): M decode steps captured per hipGraph (the cursor lives on the
+    device).  With attention as its own launch (merge 0) the launch structure changes at position 256
+    (8-wave attention below it): a group of M steps must never straddle that boundary, the tail
+    shorter than M runs step by step, and the tokens are the oracle's throughout."""
+    import rama_amd
+    from rama_amd._lib import check
+    cfg = O.Config(64, 176, 2, 4, 4, 96, 300, True)
+    w = S.synth_weights(cfg, seed=21)
+    prompt = [5, 9, 33]
+    want = O.Oracle(cfg, w).generate_greedy(prompt, steps)
+    rcfg, ws, wv, rs, rsv = gpu_views(dev, cfg, w)
+    check(dev.lib.rama_set_tuning(dev.ctx, b"graph_steps", graph_steps))
+    check(dev.lib.rama_set_tuning(dev.ctx, b"merge", merge))
+    dev.lib.rama_set_graph_mode(dev.ctx, 1)
+    try:
+        got = rama_amd.generate_greedy_device(rcfg, prompt, steps, wv, rsv, dev)
+    finally:
+        dev.lib.rama_set_graph_mode(dev.ctx, 0)
+        check(dev.lib.rama_set_tuning(dev.ctx, b"graph_steps", -1))
+        check(dev.lib.rama_set_tuning(dev.ctx, b"merge", -1))
+    assert got == want
+    rs.free(); ws.free()
+
+
 # ------------------------------------------------------------------ long contexts: split-T attention
 
 def _long_ctx_case(n_heads, hs, seq_len=2048, seed=11):
