@@ -1,4 +1,5 @@
-//! Raw bindings of include/rama_hip.h (the subset the Device trait and the optional fast path need).
+//! Raw bindings of include/rama_hip.h: every entry point (first the ones the Device trait and the optional
+//! fast path need, then the rest).
 //! `*mut f32` / `*const f32` are DEVICE pointers; every function returns 0 or an error code and
 //! leaves a message in `rama_last_error()` (thread-local).
 #![allow(non_camel_case_types, dead_code)]
@@ -94,6 +95,42 @@ extern "C" {
     pub fn rama_pipe_run_ticks(pipe: *mut rama_pipe, cfg: *const rama_config, w: *const rama_weights,
                                states: *mut rama_run_state, tok_dev: *const *mut i32, stage: *const rama_stage,
                                plan: *const rama_pipe_plan, tick_from: c_int, tick_to: c_int) -> c_int;
+    pub fn rama_pipe_exchange(pipe: *mut rama_pipe, send_x: *const f32, n_send_x: usize, send_x_peer: c_int,
+                              recv_x: *mut f32, n_recv_x: usize, recv_x_peer: c_int,
+                              send_tok: *const i32, send_tok_peer: c_int, recv_tok: *mut i32, recv_tok_peer: c_int) -> c_int;
+    pub fn rama_pipe_item(plan: *const rama_pipe_plan, world: c_int, rank: c_int, tick: c_int, seq: *mut c_int, pos: *mut c_int) -> c_int;
+    pub fn rama_pipe_last_error() -> *const c_char;
+
+    // the rest of include/rama_hip.h, for hosts that want more than the trait: stage-wise forwards
+    // (pipeline), the chained decode loop piece by piece, device-resident sampling, model helpers,
+    // measurement.  tests/test_abi_and_host.py keeps this block and the header in step.
+    pub fn rama_device_info(ctx: *mut rama_ctx, name: *mut c_char /* [64] */, compute_units: *mut c_int, hbm_bytes: *mut usize) -> c_int;
+    pub fn rama_copy_h2d_f32(ctx: *mut rama_ctx, dst: *mut f32, host: *const f32, n: usize) -> c_int;
+    pub fn rama_fill_synth(ctx: *mut rama_ctx, dst: *mut f32, n: usize, seed: u64, tag: u64, offset: u64, scale: f32, bias: f32) -> c_int;
+    pub fn rama_forward_stage(ctx: *mut rama_ctx, cfg: *const rama_config, w: *const rama_weights, s: *mut rama_run_state,
+                              token: c_int, pos: c_int, stage: *const rama_stage) -> c_int;
+    pub fn rama_forward_stage_devtok(ctx: *mut rama_ctx, cfg: *const rama_config, w: *const rama_weights, s: *mut rama_run_state,
+                                     token_dev: *const i32, pos: c_int, stage: *const rama_stage) -> c_int;
+    pub fn rama_argmax_dev(ctx: *mut rama_ctx, logits: *const f32, n: usize, result_dev: *mut i32) -> c_int;
+    pub fn rama_sample_topp_dev(ctx: *mut rama_ctx, logits: *const f32, n: usize, temperature: f32, topp: f32, u: f32,
+                                result_dev: *mut i32) -> c_int;
+    pub fn rama_generate_greedy(ctx: *mut rama_ctx, cfg: *const rama_config, w: *const rama_weights, s: *mut rama_run_state,
+                                prompt_tokens_host: *const i32, n_prompt: c_int, steps: c_int, out_tokens_host: *mut i32) -> c_int;
+    pub fn rama_decode_begin(ctx: *mut rama_ctx, token: c_int, pos: c_int, forced_tokens_host: *const i32, n_forced: c_int) -> c_int;
+    pub fn rama_decode_sampler(ctx: *mut rama_ctx, temperature: f32, topp: f32, u: f32) -> c_int;
+    pub fn rama_decode_steps(ctx: *mut rama_ctx, cfg: *const rama_config, w: *const rama_weights, s: *mut rama_run_state, n_steps: c_int) -> c_int;
+    pub fn rama_decode_tokens(ctx: *mut rama_ctx, out_tokens_host: *mut i32, max_tokens: c_int, n_out: *mut c_int) -> c_int;
+    pub fn rama_state_create(ctx: *mut rama_ctx, cfg: *const rama_config, n_local_layers: c_int, out: *mut rama_run_state) -> c_int;
+    pub fn rama_state_free(ctx: *mut rama_ctx, s: *mut rama_run_state) -> c_int;
+    pub fn rama_model_synth(ctx: *mut rama_ctx, cfg: *const rama_config, seed: u64, stage: *const rama_stage,
+                            rope_real_host: *const f32, rope_imag_host: *const f32, out: *mut *mut rama_model) -> c_int;
+    pub fn rama_model_save(ctx: *mut rama_ctx, model: *const rama_model, path: *const c_char) -> c_int;
+    pub fn rama_model_bytes(m: *const rama_model) -> usize;
+    pub fn rama_ref_expf(ctx: *mut rama_ctx, o: *mut f32, x: *const f32, n: usize) -> c_int;
+    pub fn rama_timer_start(ctx: *mut rama_ctx) -> c_int;
+    pub fn rama_timer_stop(ctx: *mut rama_ctx, elapsed_ms: *mut f32) -> c_int;
+    pub fn rama_kprof_enable(ctx: *mut rama_ctx, kernel_id: c_int, max_records: c_int) -> c_int;
+    pub fn rama_kprof_read(ctx: *mut rama_ctx, n_launches: *mut c_int, total_ms: *mut f64) -> c_int;
 }
 
 #[repr(C)] pub struct rama_pipe { _p: [u8; 0] }

@@ -28,6 +28,15 @@ def test_library_exports_every_declared_symbol():
     assert set(syms) == set(_lib.SIGNATURES), set(syms) ^ set(_lib.SIGNATURES)
 
 
+def test_rust_bindings_declare_every_header_symbol():
+    """integration/rust/hip_sys.rs cannot be compiled here (no Rust toolchain); at least it must name every
+    entry point of the header exactly once, and nothing the header does not have"""
+    text = (REPO / "integration" / "rust" / "hip_sys.rs").read_text()
+    declared = re.findall(r"pub fn (rama_[a-z0-9_]+)\s*\(", text)
+    assert sorted(declared) == header_symbols(), set(declared) ^ set(header_symbols())
+    assert len(declared) == len(set(declared))
+
+
 def test_no_gpu_means_loud_failure():
     import torch
     if torch.cuda.is_available():
