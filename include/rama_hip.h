@@ -264,7 +264,11 @@ int  rama_decode_steps(rama_ctx *ctx, const rama_config *cfg, const rama_weights
                        rama_run_state *s, int n_steps);
 /* tokens produced since rama_decode_begin (synchronises) */
 int  rama_decode_tokens(rama_ctx *ctx, int32_t *out_tokens_host, int max_tokens, int *n_out);
-/* 1: capture each decode step into a hipGraph and replay it (default 0 = eager launches) */
+/* 1: replay launches from hipGraphs (default 0 = eager launches): rama_decode_steps / rama_generate capture a
+ * decode step (or a few, "graph_steps") once per attention variant; rama_forward and rama_forward_stage* keep one
+ * graph per (run state, stage, attention variant) -- token and position travel through the device cursor, so a
+ * trait-level host or a pipeline stage issues one cursor write and one graph launch per token.  Setting 0
+ * synchronises and drops every captured graph; free a run state only after that (or after rama_ctx_destroy). */
 int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
 /* Performance knobs (results are unaffected up to fp32 summation order).  Keys:
  *   "geom" = 0..3 : matvec workgroup geometry (rows per workgroup, waves, chunks per step);

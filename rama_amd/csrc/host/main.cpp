@@ -98,6 +98,7 @@ static int run_pipeline_stage(const Args& args, int world, int rank) {
     }
     rama_pipe* pipe = nullptr;
     ck(rama_pipe_create(device.ctx, id, rank, world, &pipe), "rama_pipe_create");
+    if (!std::getenv("RAMA_PIPE_EAGER")) ck(rama_set_graph_mode(device.ctx, 1), "rama_set_graph_mode");   // a stage pass = one hipGraph replay
 
     Tokenizer tokenizer;
     std::vector<size_t> prompt_tokens;

@@ -14,6 +14,9 @@
 // enqueued on the context's stream: no host synchronisation inside the loop.
 //
 // RCCL is loaded with dlopen on first use, so the single-GPU product has no RCCL dependency.
+// (A process that also imports PyTorch should import it first: torch ships its own librccl.so.1, the
+// loader serves every later request for that soname from the copy already in the process, and torch
+// on the other build crashes at exit.  dlopen("librccl.so.1") here then simply reuses torch's copy.)
 #include "../../include/rama_hip.h"
 
 #include <hip/hip_runtime.h>

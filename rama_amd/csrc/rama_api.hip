@@ -77,6 +77,9 @@ struct rama_ctx {
     int* pinned_int = nullptr;      // host pinned
     int* pinned_tok = nullptr;      // host pinned staging: token ids + a SeqSlot table of a token-batch pass
     bool graph_mode = false;
+    struct StageGraph { GraphCache g; rama_stage st{}; int variant = 0; unsigned long long used = 0; };
+    std::vector<StageGraph> sg;        // rama_forward / rama_forward_stage* in graph mode: one graph per (state, stage, attention variant)
+    unsigned long long sg_clock = 0;
     GraphCache gc[6];                  // [0..2] one step per graph, [3..5] tune_graph_steps steps per graph; by attention variant: [0] one 16-wave workgroup per head, [1] split-T (long contexts), [2] one 4-wave workgroup per head (short contexts)
     KProf kp;
     int cu_count = 0;
@@ -179,6 +182,11 @@ static void drop_graph(rama_ctx* c) {
         if (g.graph) hipGraphDestroy(g.graph);
         g = GraphCache();
     }
+    for (auto& e : c->sg) {
+        if (e.g.exec) hipGraphExecDestroy(e.g.exec);
+        if (e.g.graph) hipGraphDestroy(e.g.graph);
+    }
+    c->sg.clear();
 }
 
 int rama_ctx_destroy(rama_ctx* c) {
@@ -810,6 +818,44 @@ static int enqueue_stage(rama_ctx* c, const rama_config* cfg, const rama_weights
     return 0;
 }
 
+static bool same_capture(const GraphCache& g, const rama_config* cfg, const rama_weights* w, const rama_run_state* s);
+
+// enqueue_stage, replayed from a hipGraph when graph mode is on: token and position live in the device
+// cursor (written by the caller just before), so the launches of a (state, stage, attention variant)
+// are the same every time.  Used by rama_forward / rama_forward_stage* -- the per-token entry points
+// of a trait-level host and of the pipeline stages (csrc/pipe.hip).
+constexpr size_t kMaxStageGraphs = 48;
+static int run_stage(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s, const rama_stage* st) {
+    if (!c->graph_mode || c->kp.kernel_id >= 0) return enqueue_stage(c, cfg, w, s, st);
+    const int variant = c->split_attn ? 1 : (c->small_attn ? 2 : 0);
+    rama_ctx::StageGraph* hit = nullptr;
+    for (auto& e : c->sg)
+        if (e.variant == variant && !memcmp(&e.st, st, sizeof *st) && same_capture(e.g, cfg, w, s)) { hit = &e; break; }
+    if (!hit) {
+        if (c->sg.size() >= kMaxStageGraphs) {       // evict the entry used longest ago
+            size_t old = 0;
+            for (size_t i = 1; i < c->sg.size(); i++) if (c->sg[i].used < c->sg[old].used) old = i;
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (c->sg[old].g.exec) hipGraphExecDestroy(c->sg[old].g.exec);
+            if (c->sg[old].g.graph) hipGraphDestroy(c->sg[old].g.graph);
+            c->sg.erase(c->sg.begin() + (long)old);
+        }
+        rama_ctx::StageGraph e;
+        HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        const int rc = enqueue_stage(c, cfg, w, s, st);
+        const hipError_t err = hipStreamEndCapture(c->stream, &e.g.graph);
+        if (rc) { if (e.g.graph) hipGraphDestroy(e.g.graph); return rc; }
+        HIPCHK(err);
+        HIPCHK(hipGraphInstantiate(&e.g.exec, e.g.graph, nullptr, nullptr, 0));
+        e.g.cfg = *cfg; e.g.w = *w; e.g.s = *s; e.g.valid = true; e.st = *st; e.variant = variant;
+        c->sg.push_back(e);
+        hit = &c->sg.back();
+    }
+    hit->used = ++c->sg_clock;
+    HIPCHK(hipGraphLaunch(hit->g.exec, c->stream));
+    return 0;
+}
+
 static int check_stage(const rama_config* cfg, const rama_weights* w, const rama_run_state* s, const rama_stage* st) {
     REQUIRE(w && s && st, RAMA_EINVAL, "forward: NULL argument");
     REQUIRE(st->layer_begin >= 0 && st->layer_begin <= st->layer_end && st->layer_end <= cfg->n_layers, RAMA_EINVAL, "forward: bad layer range");
@@ -837,7 +883,7 @@ int rama_forward_stage(rama_ctx* c, const rama_config* cfg, const rama_weights* 
     c->host_pos = -1;
     c->split_attn = pos >= split_threshold(c, cfg);
     c->small_attn = small_attn_at(c, pos, c->split_attn, cfg->dim);
-    return enqueue_stage(c, cfg, w, s, st);
+    return run_stage(c, cfg, w, s, st);
 }
 
 // pipeline-stage variants: the token id stays in device memory end to end
@@ -856,7 +902,7 @@ int rama_forward_stage_devtok(rama_ctx* c, const rama_config* cfg, const rama_we
     c->host_pos = -1;
     c->split_attn = pos >= split_threshold(c, cfg);
     c->small_attn = small_attn_at(c, pos, c->split_attn, cfg->dim);
-    return enqueue_stage(c, cfg, w, s, st);
+    return run_stage(c, cfg, w, s, st);
 }
 
 // ---- device top-p sampler (topp_sort.hpp: block sorts + ranks for n <= 32768, else kernels.hpp's

@@ -214,6 +214,8 @@ class NativeStage:
         self.pipe = C.c_void_p()
         buf = (C.c_char * 128).from_buffer_copy(ident)
         check(self.dev.lib.rama_pipe_create(self.dev.ctx, buf, rank, world, C.byref(self.pipe)), "rama_pipe_create")
+        if not os.environ.get("RAMA_PIPE_EAGER"):      # every stage pass of a sequence is one hipGraph replay (rama_forward_stage* in graph mode)
+            check(self.dev.lib.rama_set_graph_mode(self.dev.ctx, 1), "rama_set_graph_mode")
         self.dev.sync()
 
     @staticmethod
@@ -334,7 +336,7 @@ def run_pipeline_bench_native(args, cfg, rank: int, world: int, local_rank: int)
             else:
                 st.check(L.rama_forward_stage_devtok(st.dev.ctx, C.byref(st.model.ccfg), C.byref(st.model.weights), C.byref(st.states[0]), None, 5, C.byref(st.stage)))
         roofline = _stage_roofline(st.check, L, st.dev.ctx, one, n_local, cfg)
-    line = _bench_line(args, cfg, world, n_seq, args.steps * n_seq / dt, dt, roofline, "native: csrc/pipe.hip, tick loop in C++")
+    line = _bench_line(args, cfg, world, n_seq, args.steps * n_seq / dt, dt, roofline, "native: csrc/pipe.hip, tick loop in C++, one hipGraph per (sequence, stage)" if not os.environ.get("RAMA_PIPE_EAGER") else "native: csrc/pipe.hip, tick loop in C++, eager launches")
     st.free()
     dist.barrier()
     dist.destroy_process_group()

@@ -394,6 +394,42 @@ def test_multi_step_graphs_across_the_attention_variant_boundary(dev, graph_step
     rs.free(); ws.free()
 
 
+def test_forward_in_graph_mode_replays_the_same_launches(dev):
+    """rama_forward with rama_set_graph_mode(1): the step is captured once per (state, stage, attention
+    variant) and replayed -- token and position travel through the device cursor -- and must leave
+    bit-identical logits and caches, across the position where the launch structure changes (256
+    with attention as its own launch) and for two states in turn"""
+    import rama_amd
+    from rama_amd._lib import check
+    cfg = O.Config(64, 176, 2, 4, 4, 96, 300, True)
+    w = S.synth_weights(cfg, seed=23)
+    rng = np.random.default_rng(5)
+    toks = [1] + [int(t) for t in rng.integers(0, cfg.vocab_size, 269)]
+    check(dev.lib.rama_set_tuning(dev.ctx, b"merge", 0))
+    try:
+        rcfg, ws, wv, rs_a, rsv_a = gpu_views(dev, cfg, w)
+        _, ws_b, wv_b, rs_b, rsv_b = gpu_views(dev, cfg, w)
+        _, ws_c, wv_c, rs_c, rsv_c = gpu_views(dev, cfg, w)
+        check_at = {pos for pos in range(len(toks)) if pos % 37 == 0} | {255, 256, 257, len(toks) - 1}
+        eager = {}
+        for pos, t in enumerate(toks):                    # eager first: leaving graph mode drops the captured graphs
+            rama_amd.forward_fused(rcfg, wv, rsv_a, t, pos, dev)
+            if pos in check_at: eager[pos] = dev.download(rsv_a.logits)
+        dev.lib.rama_set_graph_mode(dev.ctx, 1)
+        for pos, t in enumerate(toks):                    # two states in turn: two graphs per variant, replayed ~135 times each
+            rama_amd.forward_fused(rcfg, wv_b, rsv_b, t, pos, dev)
+            rama_amd.forward_fused(rcfg, wv_c, rsv_c, t, pos, dev)
+            if pos in check_at:
+                assert np.array_equal(eager[pos], dev.download(rsv_b.logits)) and np.array_equal(eager[pos], dev.download(rsv_c.logits)), pos
+        for buf in ("key_cache", "value_cache"):
+            assert np.array_equal(dev.download(getattr(rsv_a, buf)), dev.download(getattr(rsv_b, buf)))
+    finally:
+        dev.lib.rama_set_graph_mode(dev.ctx, 0)
+        check(dev.lib.rama_set_tuning(dev.ctx, b"merge", -1))
+    for r in (rs_a, rs_b, rs_c, ws, ws_b, ws_c):
+        r.free()
+
+
 # ------------------------------------------------------------------ long contexts: split-T attention
 
 def _long_ctx_case(n_heads, hs, seq_len=2048, seed=11):

@@ -18,6 +18,10 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def dev():
+    # PyTorch bundles its own librccl.so.1; /opt/rocm has another build with the same soname.  Whichever is
+    # loaded first serves both users of the process, so torch goes first (as in the driver's whole-suite
+    # order and in bench.py): torch running on the other build crashes at interpreter exit.
+    import torch  # noqa: F401
     import rama_amd
     d = rama_amd.Hip(0)
     yield d
@@ -49,10 +53,11 @@ def test_exchange_with_self(dev, pipe):
         check(dev.lib.rama_pipe_exchange(pipe, sx.ptr, 4096, 1, None, 0, 0, None, 0, None, 0))      # peer outside the communicator
 
 
-@pytest.mark.parametrize("n_seq,temperature", [(1, 0.0), (3, 0.0), (2, 1.0)])
-def test_native_tick_loop_equals_generate(dev, pipe, n_seq, temperature):
+@pytest.mark.parametrize("n_seq,temperature,graph", [(1, 0.0, 0), (3, 0.0, 0), (2, 1.0, 0), (3, 0.0, 1), (2, 1.0, 1)])
+def test_native_tick_loop_equals_generate(dev, pipe, n_seq, temperature, graph):
     """rama_pipe_run_ticks on a one-rank pipe = generate() (mod.rs:169-206) for every sequence in flight:
-    BOS, the forced prompt tokens, then the sampled ones; the history lands in out_tokens_dev"""
+    BOS, the forced prompt tokens, then the sampled ones; the history lands in out_tokens_dev.
+    graph = 1: the stage passes are replayed from hipGraphs (one per sequence state)"""
     import rama_amd
     from rama_amd._lib import check, rama_pipe_plan, rama_run_state, rama_stage
     cfg, w, g = load_case("synth_d288_h6")
@@ -78,12 +83,14 @@ def test_native_tick_loop_equals_generate(dev, pipe, n_seq, temperature):
     stage = rama_stage(0, cfg.n_layers, 1, 1)
     total = dev.lib.rama_pipe_total_ticks(pipe, C.byref(plan))
     assert total == n_seq * n_pos
+    dev.lib.rama_set_graph_mode(dev.ctx, graph)      # 1: every stage pass of a sequence is a hipGraph replay (rama_forward_stage* in graph mode)
     if temperature != 0.0:      # the device sampler's scratch is sized outside the loop
         check(dev.lib.rama_sample_topp_dev(dev.ctx, engines[0].state.logits, cfg.vocab_size, temperature, 0.9, u, toks[0].ptr))
     check(dev.lib.rama_pipe_run_ticks(pipe, C.byref(model.ccfg), C.byref(model.weights), states, tok_ptrs, C.byref(stage),
                                       C.byref(plan), 0, total // 2), "rama_pipe_run_ticks")
     check(dev.lib.rama_pipe_run_ticks(pipe, C.byref(model.ccfg), C.byref(model.weights), states, tok_ptrs, C.byref(stage),
                                       C.byref(plan), total // 2, total), "rama_pipe_run_ticks")
+    dev.lib.rama_set_graph_mode(dev.ctx, 0)
     hist = dev.download(out).view(np.int32).reshape(n_seq, n_pos)
     for s in range(n_seq):
         assert hist[s].tolist() == want, (s, hist[s].tolist(), want)
