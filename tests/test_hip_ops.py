@@ -403,6 +403,46 @@ def test_sample_topp_dev_running_sums_are_the_sequential_ones(dev, kind, n, scal
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (kind, int(np.nonzero(got != want)[0][0]), last, m)
 
 
+@pytest.mark.parametrize("seed", range(40))
+def test_sample_topp_dev_running_sums_random_structures(dev, seed):
+    """the exact parallel running sum on randomly structured lists: mixtures of plateaus (equal
+    probabilities: ties in every binade or in none), exact powers of two (adds that are exact until
+    they tie), geometric tails and noise, random sizes up to the LDS path's 32768 and random topp"""
+    from rama_amd._lib import check
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([3, 64, 65, 1000, 2048, 4097, 20000, 32000, 32768]))
+    kind = seed % 4
+    if kind == 0:      # plateaus of equal logits, heights on a log-2 grid
+        levels = rng.integers(0, 12, size=int(rng.integers(1, 9)))
+        x = (rng.choice(levels, size=n) * np.log(2.0)).astype(np.float32)
+    elif kind == 1:    # gaussian noise of a random scale, a few exact duplicates
+        x = (rng.standard_normal(n) * rng.choice([0.02, 0.3, 1.0, 2.5, 6.0])).astype(np.float32)
+        x[rng.integers(0, n, size=max(1, n // 50))] = x[0]
+    elif kind == 2:    # geometric tail
+        x = (-np.arange(n) * rng.choice([1e-4, 1e-3, 0.01, 0.3])).astype(np.float32)
+        rng.shuffle(x)
+    else:              # two plateaus plus noise below the float resolution of the sums
+        x = np.where(rng.random(n) < 0.1, 3.0, 0.0).astype(np.float32) + (rng.standard_normal(n) * 1e-6).astype(np.float32)
+    topp = float(rng.choice([0.5, 0.9, 0.95, 0.999, 1.0]))
+    check(dev.lib.rama_set_tuning(dev.ctx, b"topp_keep_sums", 1))
+    try:
+        got_tok = _topp_dev(dev, x, 1.0, topp, 0.37)
+    finally:
+        check(dev.lib.rama_set_tuning(dev.ctx, b"topp_keep_sums", 0))
+    m, ps, idx, prefix = _topp_scratch(dev, n)
+    if m == 0:
+        assert got_tok == -1
+        return
+    assert np.all((ps[:-1] > ps[1:]) | ((ps[:-1] == ps[1:]) & (idx[:-1] < idx[1:])))
+    want, last = _seq_cumsum_until(ps, topp)
+    got = prefix[:last + 1]
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (seed, kind, n, topp, int(np.nonzero(got != want)[0][0]), last, m)
+    # and the draw inside the prefix (infer.rs:75-84) from those sums
+    r = np.float32(0.37) * want[last]
+    below = int(np.count_nonzero(~(r < want[:last])))
+    assert got_tok == int(idx[min(below, last)])
+
+
 def test_sample_topp_dev_temperature_zero_is_argmax(dev):
     x = rnd(5000, 9, 2.0)
     x[[10, 4000]] = 50.0
