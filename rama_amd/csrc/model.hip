@@ -24,6 +24,7 @@ struct rama_model {
     rama_config cfg{};
     rama_weights w{};
     float* w13i = nullptr;      // W1 | W3 row-interleaved per layer: [n_local_layers, hidden, 2, dim] (see below)
+    float* tiled = nullptr;     // every matrix once more in MFMA tile order, for the token-batch GEMMs (see below)
     float* blob = nullptr;      // one allocation holding every tensor
     size_t blob_floats = 0;
     rama_stage stage{};
@@ -107,7 +108,73 @@ int make_w13i(rama_ctx* ctx, rama_model* m) {
     return 0;
 }
 
+// ---- the matrices in MFMA tile order.  The token-batch GEMMs (prefill_mfma.hpp) want the weight tile of
+// a v_mfma_f32_16x16x4_f32 chain -- 16 rows x 16 floats, lane = row + 16 (k / 4 % 4), register = k % 4 --
+// and a wave that collects it from row-major memory reads 16 rows x 64 bytes per instruction: at 16
+// tokens per pass that access pattern alone holds the launch at 4.8 TB/s where the decode matvecs
+// stream 6.4-6.8.  A model therefore keeps a second copy of wq, wk, wv, wo, w1, w3, w2 (and wcls) in
+// exactly the activations' tile layout (tile_idx): the A operand is then one fully coalesced 1-KiB read
+// per wave with no lane permute (+27 GB at llama2-7B of 288; skipped when memory is short or
+// RAMA_NO_TILED is set -- the row-major kernels remain).  Found through a registry keyed by the
+// row-major tensor's base address.
+struct TiledEntry { const float* src; const float* tiled; };
+std::vector<TiledEntry> g_tiled;
+std::mutex g_tiled_mu;
+
+__global__ void tile_weights_kernel(float* dst, const float* src, size_t nmat, int rows, int K) {
+    const size_t per = (size_t)rows * K, n4 = nmat * per / 4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i * 4, l = e / per, in = e - l * per;
+        const int r = (int)(in / K), k = (int)(in - (size_t)r * K);
+        // tile_idx(r, k, K) of prefill_mfma.hpp
+        const size_t t = ((size_t)((r >> 4) * (K >> 4) + (k >> 4)) * 64 + (size_t)(((k >> 2) & 3) * 16 + (r & 15))) * 4;
+        *reinterpret_cast<float4*>(dst + l * per + t) = *reinterpret_cast<const float4*>(src + e);
+    }
+}
+
+int make_tiled(rama_ctx* ctx, rama_model* m) {
+    if (getenv("RAMA_NO_TILED")) return 0;
+    const size_t nl = (size_t)(m->stage.layer_end - m->stage.layer_begin);
+    const int dim = m->cfg.dim, hidden = m->cfg.hidden_dim, V = m->cfg.vocab_size;
+    if (dim % 16 || hidden % 16) return 0;
+    const size_t dd = (size_t)dim * dim, hd = (size_t)hidden * dim;
+    const bool cls = m->stage.do_cls && m->w.wcls && V % 16 == 0;
+    const size_t total = nl * (4 * dd + 3 * hd) + (cls ? (size_t)V * dim : 0);
+    if (!total) return 0;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < total * 4 + ((size_t)16 << 30)) return 0;   // keep 16 GiB for states and scratch
+    if (rama_alloc_f32(ctx, total, &m->tiled)) { m->tiled = nullptr; return 0; }
+    rama_sync(ctx);
+    struct T { const float* src; size_t nmat; int rows, K; };
+    std::vector<T> ts;
+    if (nl) {
+        ts.push_back({m->w.wq, nl, dim, dim}); ts.push_back({m->w.wk, nl, dim, dim}); ts.push_back({m->w.wv, nl, dim, dim});
+        ts.push_back({m->w.wo, nl, dim, dim}); ts.push_back({m->w.w1, nl, hidden, dim}); ts.push_back({m->w.w3, nl, hidden, dim});
+        ts.push_back({m->w.w2, nl, dim, hidden});
+    }
+    if (cls) ts.push_back({m->w.wcls, 1, V, dim});
+    float* dst = m->tiled;
+    std::vector<TiledEntry> mine;
+    for (const T& t : ts) {
+        if (!t.src) { rama_free(ctx, m->tiled); m->tiled = nullptr; return 0; }
+        hipLaunchKernelGGL(tile_weights_kernel, dim3(4096), dim3(256), 0, 0, dst, t.src, t.nmat, t.rows, t.K);
+        mine.push_back({t.src, dst});
+        dst += t.nmat * (size_t)t.rows * t.K;
+    }
+    if (hipDeviceSynchronize() != hipSuccess) { rama_free(ctx, m->tiled); m->tiled = nullptr; return bad(RAMA_EIO, "tiling the weights failed"); }
+    std::lock_guard<std::mutex> lk(g_tiled_mu);
+    for (auto& e : mine) g_tiled.push_back(e);
+    return 0;
+}
+
 }  // namespace
+
+// internal: the tile-order copy of a row-major weight tensor (by its base address) a model registered, or NULL
+extern "C" const float* rama_internal_tiled_lookup(const float* src) {
+    std::lock_guard<std::mutex> lk(g_tiled_mu);
+    for (auto& e : g_tiled) if (e.src == src) return e.tiled;
+    return nullptr;
+}
 
 // internal (not in the C ABI header): the interleaved copy of the (w1, w3) pair a model registered, or NULL
 extern "C" const float* rama_internal_w13_lookup(const float* w1, const float* w3) {
@@ -192,6 +259,7 @@ extern "C" int rama_model_load_stage(rama_ctx* ctx, const char* path, const rama
     if (c.shared_weight && st.do_cls) m->w.wcls = m->w.token_embedding_table;   // state.rs:111-117
     if (!st.do_embed && !(st.do_cls && c.shared_weight)) m->w.token_embedding_table = nullptr;
     rc = make_w13i(ctx, m);
+    if (!rc) rc = make_tiled(ctx, m);
     if (rc) { rama_free(ctx, m->blob); delete m; return rc; }
     *out = m;
     return 0;
@@ -258,6 +326,7 @@ extern "C" int rama_model_synth(rama_ctx* ctx, const rama_config* cfg, uint64_t 
     if (cfg->shared_weight && st.do_cls) m->w.wcls = m->w.token_embedding_table;
     if (!st.do_embed && !(st.do_cls && cfg->shared_weight)) m->w.token_embedding_table = nullptr;
     rc = make_w13i(ctx, m);
+    if (!rc) rc = make_tiled(ctx, m);
     if (rc) { rama_free(ctx, m->blob); delete m; return rc; }
     *out = m;
     return 0;
@@ -314,6 +383,17 @@ extern "C" int rama_model_free(rama_ctx* ctx, rama_model* m) {
             for (size_t i = 0; i < g_w13.size(); i++) if (g_w13[i].w13i == m->w13i) { g_w13.erase(g_w13.begin() + i); break; }
         }
         rama_free(ctx, m->w13i);
+    }
+    if (m->tiled) {
+        {
+            std::lock_guard<std::mutex> lk(g_tiled_mu);
+            const float* lo = m->tiled;
+            for (size_t i = g_tiled.size(); i-- > 0;)      // every entry of this model points into its one allocation
+                if (g_tiled[i].src == m->w.wq || g_tiled[i].src == m->w.wk || g_tiled[i].src == m->w.wv || g_tiled[i].src == m->w.wo ||
+                    g_tiled[i].src == m->w.w1 || g_tiled[i].src == m->w.w3 || g_tiled[i].src == m->w.w2 || g_tiled[i].src == m->w.wcls)
+                    if (g_tiled[i].tiled >= lo) g_tiled.erase(g_tiled.begin() + (long)i);
+        }
+        rama_free(ctx, m->tiled);
     }
     int rc = rama_free(ctx, m->blob);
     delete m;

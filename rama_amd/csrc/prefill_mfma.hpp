@@ -55,7 +55,8 @@ __host__ __device__ __forceinline__ size_t tile_idx(int tk, int k, int K) {
 __host__ __device__ __forceinline__ size_t tile_floats(int n_tok, int K) { return (size_t)((n_tok + 15) >> 4) * 16 * (size_t)K; }
 
 struct MfParams {
-    const float* w[3];     // matrices [rows, K] row-major (EPI_QKV: wq, wk, wv; EPI_SWIGLU: w1, w3)
+    const float* w[3];     // matrices [rows, K] row-major (EPI_QKV: wq, wk, wv; EPI_SWIGLU: w1, w3), or their tile-order copies
+    int tiled;             // 1: w[] are tile-order copies (host picks the LD = 3 instantiation)
     const float* x;        // activations, tile layout [ceil(n_tok / 16) * 16, K]
     float* o;              // output, tile layout [.., rows] (EPI_QKV: q; EPI_STORE_ROWS: row-major [n_tok, o_stride])
     size_t slab_floats;    // split-K: partial sums of K-slice ks go to o + ks * slab_floats
@@ -76,9 +77,9 @@ typedef __attribute__((ext_vector_type(4))) float acc4;
 //     rt, all at the same rows; the others take RT consecutive tiles of w[0]
 // JN  16-float blocks of K per wave per step (2 or 4): the prefetch unit.  Registers per lane =
 //     2 * 4 JN (RT + PT) double-buffered operands + 4 RT PT accumulators.
-// LD  1 (product): weights as described above.  2 / 3 are TIMING PROBES of the microbenchmark with
-//     wrong results: 2 = the same reads without the lane permute, 3 = fully contiguous 1-KiB reads
-//     (what a pre-swizzled second copy of the weights would give).
+// LD  1: row-major weights as described above.  3: weights in tile order (the model's second copy,
+//     model.hip make_tiled): the A operand is one contiguous 1-KiB read per wave, no lane permute.
+//     2, 4, 5 are TIMING PROBES of the microbenchmark with wrong results.
 template <int PT, int RT, int EPI, int JN = 2, int LD = 1, int STAGGER = 0>
 __global__ __launch_bounds__(kMfThreads) void gemm_mfma_rows(MfParams p) {
     constexpr int NT = RT * PT;                          // accumulator tiles per wave
@@ -129,7 +130,10 @@ __global__ __launch_bounds__(kMfThreads) void gemm_mfma_rows(MfParams p) {
 #pragma unroll
             for (int j = 0; j < JN; j++) {
                 const unsigned kb = kb0 + (unsigned)j * 64u;
-                if (LD == 3) A[rt][j] = ld_nt(ra, (c < nch && r < p.rows) ? (unsigned)(r0 + (ACROSS ? 0 : rt * 16)) * kbytes + (unsigned)(c * JN + j) * 1024u + lane * 16u : kOOB);
+                if (LD == 3) {      // tile (r0 / 16 [+ rt]), block c JN + j of K / 16: 1 KiB, lane l at 16 l
+                    const int rtile0 = r0 + (ACROSS ? 0 : rt * 16), jb = c * JN + j;
+                    A[rt][j] = ld_nt(ra, (c < nch && jb < nblk && rtile0 < p.rows) ? (unsigned)rtile0 * kbytes + (unsigned)jb * 1024u + lane * 16u : kOOB);
+                }
                 else A[rt][j] = ld_nt(ra, (c < nch && kb < kbytes && r < p.rows) ? (unsigned)r * kbytes + kb : kOOB);
             }
         }

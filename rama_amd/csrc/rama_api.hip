@@ -21,6 +21,7 @@
 using namespace rama;
 
 extern "C" const float* rama_internal_w13_lookup(const float* w1, const float* w3);   // model.hip
+extern "C" const float* rama_internal_tiled_lookup(const float* src);                    // model.hip
 
 // ---------------------------------------------------------------- error plumbing
 
@@ -94,6 +95,7 @@ struct rama_ctx {
     float* topp_prefix = nullptr; int* topp_m = nullptr; unsigned* topp_err = nullptr;
     void* topp_tmp = nullptr; size_t topp_tmp_bytes = 0; int topp_cap = 0;
     float* topp_bp = nullptr; int* topp_bi = nullptr; int* topp_bcount = nullptr;       // topp_sort.hpp
+    int tune_tiled = 1;                     // token-batch GEMMs read the model's tile-order weight copy when it exists
     int tune_prefill_attn = 1;              // 1: prefill passes run attention as MFMA tiles, 16 queries per workgroup (prefill_attn.hpp)
     int tune_graph_steps = -1;              // decode steps captured per hipGraph (the cursor lives on the device, so steps are identical); -1: 4 for dim <= 1024, else 1
     int tune_attn_u = 8;                    // cache rows per lane and round in the split-T attention (8 | 16; 16 measured no faster)
@@ -1021,11 +1023,26 @@ static int launch_mf(rama_ctx* c, MfParams& p, int pt) {
     const int total = groups * p.ksplit;
     p.nunit = std::max(1, (total + std::max(1, c->cu_count) - 1) / std::max(1, c->cu_count));
     const dim3 grid((total + p.nunit - 1) / p.nunit), block(kMfThreads);
-    if (pt == 1) hipLaunchKernelGGL((gemm_mfma_rows<1, RT, EPI>), grid, block, 0, c->stream, p);
-    else if (pt == 2) hipLaunchKernelGGL((gemm_mfma_rows<2, RT, EPI>), grid, block, 0, c->stream, p);
-    else hipLaunchKernelGGL((gemm_mfma_rows<4, RT, EPI>), grid, block, 0, c->stream, p);
+    if (p.tiled) {      // p.w[] point at the model's tile-order copies: contiguous 1-KiB weight reads, no lane permute
+        if (pt == 1) hipLaunchKernelGGL((gemm_mfma_rows<1, RT, EPI, 2, 3>), grid, block, 0, c->stream, p);
+        else if (pt == 2) hipLaunchKernelGGL((gemm_mfma_rows<2, RT, EPI, 2, 3>), grid, block, 0, c->stream, p);
+        else hipLaunchKernelGGL((gemm_mfma_rows<4, RT, EPI, 2, 3>), grid, block, 0, c->stream, p);
+    } else {
+        if (pt == 1) hipLaunchKernelGGL((gemm_mfma_rows<1, RT, EPI>), grid, block, 0, c->stream, p);
+        else if (pt == 2) hipLaunchKernelGGL((gemm_mfma_rows<2, RT, EPI>), grid, block, 0, c->stream, p);
+        else hipLaunchKernelGGL((gemm_mfma_rows<4, RT, EPI>), grid, block, 0, c->stream, p);
+    }
     LAUNCHCHK();
     return 0;
+}
+
+// p.w[0..n) = layer li of the given row-major tensors, or of their tile-order copies when the model has them all
+static void mf_weights(const rama_ctx* c, MfParams& p, int n, const float* const* base, size_t per_layer, size_t li) {
+    const float* t[3] = {nullptr, nullptr, nullptr};
+    bool all = c->tune_tiled != 0;
+    for (int i = 0; i < n && all; i++) { t[i] = rama_internal_tiled_lookup(base[i]); all = t[i] != nullptr; }
+    for (int i = 0; i < n; i++) p.w[i] = (all ? t[i] : base[i]) + li * per_layer;
+    p.tiled = all ? 1 : 0;
 }
 
 // K-slices of the Wo / W2 products: enough (row group, slice) units to give every CU one, while a
@@ -1098,7 +1115,7 @@ static int run_layers_batched(rama_ctx* c, const rama_config* cfg, const rama_we
         // infer.rs:19 (+ the residual add of the previous layer's W2 product, :47)
         rc = launch_rmsnorm_tile(c, b, w->rms_att_weight + li * dim, dim, ntile, pending); if (rc) return rc;
         // infer.rs:20-33: Wq | Wk | Wv, RoPE, cache append
-        p.w[0] = w->wq + li * dd; p.w[1] = w->wk + li * dd; p.w[2] = w->wv + li * dd;
+        { const float* bs[3] = {w->wq, w->wk, w->wv}; mf_weights(c, p, 3, bs, dd, li); }
         p.x = b.XN; p.o = b.Q; p.K = dim; p.rows = dim;
         p.pos0 = p0; p.fr = w->freq_cis_real; p.fi = w->freq_cis_imag; p.head_size = hs;
         p.kc = key_cache ? key_cache + layer_off : nullptr; p.vc = value_cache ? value_cache + layer_off : nullptr;
@@ -1140,15 +1157,18 @@ static int run_layers_batched(rama_ctx* c, const rama_config* cfg, const rama_we
             LAUNCHCHK();
         }
         // infer.rs:35: Wo . xb as K-slices; the residual add (:37) rides in the next rmsnorm
-        p.w[0] = w->wo + li * dd; p.x = b.XB; p.o = b.SL; p.K = dim; p.rows = dim; p.ksplit = ks_wo;
+        { const float* bs[1] = {w->wo}; mf_weights(c, p, 1, bs, dd, li); }
+        p.x = b.XB; p.o = b.SL; p.K = dim; p.rows = dim; p.ksplit = ks_wo;
         rc = launch_mf<2, EPI_STORE>(c, p, pt); if (rc) return rc;
         // infer.rs:37,39
         rc = launch_rmsnorm_tile(c, b, w->rms_ffn_weight + li * dim, dim, ntile, ks_wo); if (rc) return rc;
         // infer.rs:41-45: W1 | W3, SiLU * gate
-        p.w[0] = w->w1 + li * hd; p.w[1] = w->w3 + li * hd; p.x = b.XN; p.o = b.HB; p.K = dim; p.rows = hidden; p.ksplit = 1;
+        { const float* bs[2] = {w->w1, w->w3}; mf_weights(c, p, 2, bs, hd, li); }
+        p.x = b.XN; p.o = b.HB; p.K = dim; p.rows = hidden; p.ksplit = 1;
         rc = launch_mf<2, EPI_SWIGLU>(c, p, pt); if (rc) return rc;
         // infer.rs:46: W2 . hb as K-slices (:47 rides in the next rmsnorm / the caller's fold)
-        p.w[0] = w->w2 + li * hd; p.x = b.HB; p.o = b.SL; p.K = hidden; p.rows = dim; p.ksplit = ks_w2;
+        { const float* bs[1] = {w->w2}; mf_weights(c, p, 1, bs, hd, li); }
+        p.x = b.HB; p.o = b.SL; p.K = hidden; p.rows = dim; p.ksplit = ks_w2;
         rc = launch_mf<2, EPI_STORE>(c, p, pt); if (rc) return rc;
         pending = ks_w2;
     }
@@ -1246,7 +1266,8 @@ int rama_decode_batch(rama_ctx* c, const rama_config* cfg, const rama_weights* w
     const int ntile = (n_seq + 15) / 16, pt = ntile <= 1 ? 1 : (ntile == 2 ? 2 : 4);
     rc = launch_rmsnorm_tile(c, b, w->rms_final_weight, dim, ntile, nslab); if (rc) return rc;
     MfParams p{};
-    p.n_tok = n_seq; p.ksplit = 1; p.w[0] = w->wcls; p.x = b.XN; p.o = b.LG; p.o_stride = V; p.K = dim; p.rows = V;
+    p.n_tok = n_seq; p.ksplit = 1; { const float* bs[1] = {w->wcls}; mf_weights(c, p, 1, bs, 0, 0); }
+    p.x = b.XN; p.o = b.LG; p.o_stride = V; p.K = dim; p.rows = V;
     rc = launch_mf<2, EPI_STORE_ROWS>(c, p, pt); if (rc) return rc;
     for (int i = 0; i < n_seq; i++)
         HIPCHK(hipMemcpyAsync(states[i].logits, b.LG + (size_t)i * V, sizeof(float) * V, hipMemcpyDeviceToDevice, c->stream));
@@ -1469,6 +1490,11 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
         HIPCHK(hipStreamSynchronize(c->stream));
         drop_graph(c);
         c->tune_combine_v = value;
+        return 0;
+    }
+    if (!strcmp(key, "tiled")) {
+        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: tiled must be 0 or 1");
+        c->tune_tiled = value;
         return 0;
     }
     if (!strcmp(key, "prefill_attn")) {

@@ -654,6 +654,56 @@ def test_prefill_attention_tiles_long_contexts(dev, n_heads, n_tokens, pos0):
     assert np.abs(outs[1] - outs[0]).max() <= 2e-5
 
 
+@pytest.mark.parametrize("shape,n_tokens", [((288, 768, 2, 6, 512, 96), 5), ((288, 768, 2, 6, 512, 96), 40), ((128, 352, 3, 2, 256, 160), 17),
+                                            ((128, 352, 3, 2, 256, 160), 70), ((768, 2048, 1, 12, 1024, 80), 33)])
+def test_tile_order_weight_copy_gives_identical_results(dev, shape, n_tokens):
+    """a rama_model keeps its matrices once more in MFMA tile order (csrc/model.hip make_tiled) and
+    rama_prefill / rama_decode_batch read that copy (one contiguous 1-KiB weight read per wave, no lane
+    permute): same MFMA sequence, so logits and caches are bit-identical to the row-major path
+    (rama_set_tuning "tiled" = 0), and within the bar of the oracle"""
+    import ctypes as C
+    import rama_amd
+    from rama_amd._lib import check, rama_run_state
+    dim, hidden, L, H, V, seq = shape
+    ocfg = O.Config(dim, hidden, L, H, H, V, seq, True)
+    cfg = rama_amd.Config(dim, hidden, L, H, H, V, seq, True)
+    rope = S.rope_tables(seq, dim // H)
+    w = S.synth_weights(ocfg, seed=31, rope=rope)
+    model = rama_amd.Model.synth(dev, cfg, 31, rope=rope)
+    rng = np.random.default_rng(n_tokens)
+    toks = [1] + [int(t) for t in rng.integers(0, V, n_tokens - 1)]
+    orc = O.Oracle(ocfg, w)
+    for pos, t in enumerate(toks):
+        lo = orc.forward(t, pos)
+    arr = (C.c_int32 * n_tokens)(*toks)
+    outs = {}
+    for mode in (1, 0):
+        eng = rama_amd.Engine(dev, model)
+        check(dev.lib.rama_set_tuning(dev.ctx, b"tiled", mode))
+        try:
+            check(dev.lib.rama_prefill(dev.ctx, C.byref(model.ccfg), C.byref(model.weights), C.byref(eng.state), arr, n_tokens, 0), "rama_prefill")
+            lg = eng.logits()
+            kc = eng.buffer("key_cache", L * seq * dim)
+            # one more token for 3 sequences at once: the classifier GEMM reads wcls's tile-order copy too
+            engs = [eng] + [rama_amd.Engine(dev, model) for _ in range(2)]
+            for e in engs[1:]:
+                check(dev.lib.rama_prefill(dev.ctx, C.byref(model.ccfg), C.byref(model.weights), C.byref(e.state), arr, n_tokens, 0), "rama_prefill")
+            states = (rama_run_state * 3)(*[e.state for e in engs])
+            nxt = (C.c_int32 * 3)(7, 11, 13)
+            poss = (C.c_int32 * 3)(n_tokens, n_tokens, n_tokens)
+            check(dev.lib.rama_decode_batch(dev.ctx, C.byref(model.ccfg), C.byref(model.weights), states, nxt, poss, 3), "rama_decode_batch")
+            outs[mode] = (lg, kc, [e.logits() for e in engs])
+            for e in engs:
+                e.free()
+        finally:
+            check(dev.lib.rama_set_tuning(dev.ctx, b"tiled", 1))
+    assert np.abs(outs[1][0] - lo).max() <= LOGIT_ATOL
+    assert np.array_equal(outs[1][0], outs[0][0]) and np.array_equal(outs[1][1], outs[0][1])
+    for a, b in zip(outs[1][2], outs[0][2]):
+        assert np.array_equal(a, b)
+    model.free()
+
+
 def test_prefill_argument_errors(dev):
     import rama_amd
     cfg, w, g = load_case("synth_d64_h4")
