@@ -299,6 +299,9 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *                   merged with Wo (+0.7 % tokens/s at llama2-7B, positions 8..135)
  *   "solo" = -1|0|1 : matvecs with one wave per row group and no LDS turn; -1 (default) = for rows of <= 2048
  *                   floats (the stories15M / 110M widths), where launches are latency-bound
+ *   "norm_in_gemm" = 0|1 : token-batch passes: 1 (default) = an rmsnorm is one launch (fold the pending K-slices,
+ *                   X * gain, partial sums of squares) and the GEMM that consumes it scales its outputs per token,
+ *                   as the decode matvecs do; 0 = a second launch writes the normalised activations
  *   "tiled" = 0|1 : 1 (default) lets rama_prefill / rama_decode_batch read the tile-order copy of the weights a
  *                   rama_model keeps (csrc/model.hip make_tiled; +27 GB at llama2-7B, RAMA_NO_TILED=1 skips it):
  *                   contiguous 1-KiB weight reads -- 16-token passes 6.4 -> 4.7 ms at llama2-7B; 0 = row-major weights

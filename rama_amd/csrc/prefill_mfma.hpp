@@ -57,6 +57,8 @@ __host__ __device__ __forceinline__ size_t tile_floats(int n_tok, int K) { retur
 struct MfParams {
     const float* w[3];     // matrices [rows, K] row-major (EPI_QKV: wq, wk, wv; EPI_SWIGLU: w1, w3), or their tile-order copies
     int tiled;             // 1: w[] are tile-order copies (host picks the LD = 3 instantiation)
+    const float* ssp;      // rmsnorm folded in: x holds X * gain and every output is scaled per token by
+                           // 1 / sqrt(mean(X^2) + eps) from these partial sums (rms_fold_kernel); NULL: x is used as is
     const float* x;        // activations, tile layout [ceil(n_tok / 16) * 16, K]
     float* o;              // output, tile layout [.., rows] (EPI_QKV: q; EPI_STORE_ROWS: row-major [n_tok, o_stride])
     size_t slab_floats;    // split-K: partial sums of K-slice ks go to o + ks * slab_floats
@@ -89,6 +91,7 @@ __global__ __launch_bounds__(kMfThreads) void gemm_mfma_rows(MfParams p) {
     static_assert(EPI != EPI_QKV || RT == 3, "QKV groups are one tile of each of wq, wk, wv");
     constexpr int CHUNK = 16 * JN;                       // floats of K per wave per step
     __shared__ float part[kMfWaves][NT][4][64];
+    __shared__ float s_scale[64];                        // per token of the pass: the rmsnorm scale (p.ssp)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rows_per_grp = ACROSS ? 16 : 16 * RT;
     const int ngroups = (p.rows + rows_per_grp - 1) / rows_per_grp;
@@ -200,6 +203,16 @@ __global__ __launch_bounds__(kMfThreads) void gemm_mfma_rows(MfParams p) {
             for (int pt = 0; pt < PT; pt++)
 #pragma unroll
                 for (int e = 0; e < 4; e++) part[wave][rt * PT + pt][e][lane] = acc[rt][pt][e];
+        if (p.ssp && tid < PT * 16) {      // cpu.rs:66-79's scale per token, from the kRmsParts partial sums of squares
+            float t[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) t[q] = p.ssp[((size_t)(tid >> 4) * 16 + q) * 16 + (tid & 15)];
+#pragma unroll
+            for (int n = 16; n > 1; n >>= 1)
+#pragma unroll
+                for (int q = 0; q < n / 2; q++) t[q] = t[2 * q] + t[2 * q + 1];
+            s_scale[tid] = rms_scale(t[0], p.K);
+        }
         __syncthreads();
         auto total4 = [&](int tile, int ln) {
             acc4 r;
@@ -223,8 +236,11 @@ __global__ __launch_bounds__(kMfThreads) void gemm_mfma_rows(MfParams p) {
             const int tk = pt * 16 + (ln & 15), r = r0 + (ACROSS ? 0 : rt * 16) + (ln >> 4) * 4;     // rows r .. r + 3
             if (tk >= p.n_tok || r >= p.rows) continue;     // rows % 4 == 0: a unit is all in or all out
             acc4 a = total4(PAIR ? pt : tile, ln);
+            const float nv = p.ssp ? s_scale[pt * 16 + (ln & 15)] : 1.0f;
+            if (p.ssp) { a[0] *= nv; a[1] *= nv; a[2] *= nv; a[3] *= nv; }
             if (PAIR) {
-                const acc4 b = total4(PT + pt, ln);
+                acc4 b = total4(PT + pt, ln);
+                if (p.ssp) { b[0] *= nv; b[1] *= nv; b[2] *= nv; b[3] *= nv; }
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const float sg = a[e] * (1.0f / (1.0f + expf(-a[e])));      // cpu.rs:56
@@ -321,7 +337,11 @@ __device__ __forceinline__ f4 fold_slabs(f4 x, const float* slabs, int nslab, si
 //   rms_scale_kernel  v = 1 / sqrt(sum of the parts (fixed order) / n + 1e-5); o = w * (v * x)
 constexpr int kRmsParts = 16;
 
-__global__ __launch_bounds__(256) void rms_fold_kernel(float* X, float* ssp, int dim, const float* slabs, int nslab, size_t slab_floats) {
+// X += pending K-slices; partial sums of squares per (token tile, part, token) -> ssp; and, with a gain
+// vector, XN = X * gain (infer.rs:19/39/50's rmsnorm without its per-token scale, which the consuming
+// GEMM applies to its outputs: W (v g x) = v W (g x), as the decode matvecs do)
+__global__ __launch_bounds__(256) void rms_fold_kernel(float* X, float* ssp, int dim, const float* slabs, int nslab, size_t slab_floats,
+                                                       float* XN = nullptr, const float* gain = nullptr) {
     __shared__ float red[4][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nblk = dim >> 4, per = (nblk + kRmsParts - 1) / kRmsParts;
@@ -334,6 +354,12 @@ __global__ __launch_bounds__(256) void rms_fold_kernel(float* X, float* ssp, int
         if (nslab > 0) {
             x = fold_slabs(x, slabs, nslab, slab_floats, o);
             *reinterpret_cast<f4*>(X + o) = x;
+        }
+        if (XN) {
+            const f4 g = *reinterpret_cast<const f4*>(gain + jb * 16 + (lane >> 4) * 4);
+            f4 r;
+            r.x = g.x * x.x; r.y = g.y * x.y; r.z = g.z * x.z; r.w = g.w * x.w;
+            *reinterpret_cast<f4*>(XN + o) = r;
         }
         ss = dot4(x, x, ss);
     }

@@ -95,6 +95,7 @@ struct rama_ctx {
     float* topp_prefix = nullptr; int* topp_m = nullptr; unsigned* topp_err = nullptr;
     void* topp_tmp = nullptr; size_t topp_tmp_bytes = 0; int topp_cap = 0;
     float* topp_bp = nullptr; int* topp_bi = nullptr; int* topp_bcount = nullptr;       // topp_sort.hpp
+    int tune_norm_in_gemm = 1;              // token-batch passes: the rmsnorm's per-token scale is applied by the consuming GEMM (one launch per norm instead of two)
     int tune_tiled = 1;                     // token-batch GEMMs read the model's tile-order weight copy when it exists
     int tune_prefill_attn = 1;              // 1: prefill passes run attention as MFMA tiles, 16 queries per workgroup (prefill_attn.hpp)
     int tune_graph_steps = -1;              // decode steps captured per hipGraph (the cursor lives on the device, so steps are identical); -1: 4 for dim <= 1024, else 1
@@ -1084,13 +1085,21 @@ static int ensure_batch_scratch(rama_ctx* c, const rama_config* cfg, bool with_l
 }
 
 // b.XN = rmsnorm(b.X += the nslab pending K-slices in b.SL) * gain, per token (prefill_mfma.hpp)
+// With tune_norm_in_gemm (default) this is ONE launch: b.XN = b.X * gain, and the GEMM that consumes
+// b.XN scales its outputs per token from the partial sums in b.SSP (MfParams::ssp = norm_ssp(c, b)).
 static int launch_rmsnorm_tile(rama_ctx* c, const BatchScratch& b, const float* gain, int dim, int ntile, int nslab) {
-    hipLaunchKernelGGL(rms_fold_kernel, dim3(ntile, kRmsParts), dim3(256), 0, c->stream, b.X, b.SSP, dim, (const float*)b.SL, nslab, b.slab);
+    if (c->tune_norm_in_gemm) {
+        hipLaunchKernelGGL(rms_fold_kernel, dim3(ntile, kRmsParts), dim3(256), 0, c->stream, b.X, b.SSP, dim, (const float*)b.SL, nslab, b.slab, b.XN, gain);
+        LAUNCHCHK();
+        return 0;
+    }
+    hipLaunchKernelGGL(rms_fold_kernel, dim3(ntile, kRmsParts), dim3(256), 0, c->stream, b.X, b.SSP, dim, (const float*)b.SL, nslab, b.slab, (float*)nullptr, (const float*)nullptr);
     LAUNCHCHK();
     hipLaunchKernelGGL(rms_scale_kernel, dim3(ntile, kRmsParts), dim3(256), 0, c->stream, b.XN, (const float*)b.X, gain, (const float*)b.SSP, dim);
     LAUNCHCHK();
     return 0;
 }
+static const float* norm_ssp(const rama_ctx* c, const BatchScratch& b) { return c->tune_norm_in_gemm ? b.SSP : nullptr; }
 
 static bool mf_shape_ok(const rama_config* cfg) { return cfg->dim % 16 == 0 && cfg->hidden_dim % 16 == 0; }
 
@@ -1116,7 +1125,7 @@ static int run_layers_batched(rama_ctx* c, const rama_config* cfg, const rama_we
         rc = launch_rmsnorm_tile(c, b, w->rms_att_weight + li * dim, dim, ntile, pending); if (rc) return rc;
         // infer.rs:20-33: Wq | Wk | Wv, RoPE, cache append
         { const float* bs[3] = {w->wq, w->wk, w->wv}; mf_weights(c, p, 3, bs, dd, li); }
-        p.x = b.XN; p.o = b.Q; p.K = dim; p.rows = dim;
+        p.x = b.XN; p.o = b.Q; p.K = dim; p.rows = dim; p.ssp = norm_ssp(c, b);
         p.pos0 = p0; p.fr = w->freq_cis_real; p.fi = w->freq_cis_imag; p.head_size = hs;
         p.kc = key_cache ? key_cache + layer_off : nullptr; p.vc = value_cache ? value_cache + layer_off : nullptr;
         p.seqs = seqs ? b.seqs : nullptr; p.layer_off = layer_off;
@@ -1158,17 +1167,17 @@ static int run_layers_batched(rama_ctx* c, const rama_config* cfg, const rama_we
         }
         // infer.rs:35: Wo . xb as K-slices; the residual add (:37) rides in the next rmsnorm
         { const float* bs[1] = {w->wo}; mf_weights(c, p, 1, bs, dd, li); }
-        p.x = b.XB; p.o = b.SL; p.K = dim; p.rows = dim; p.ksplit = ks_wo;
+        p.x = b.XB; p.o = b.SL; p.K = dim; p.rows = dim; p.ksplit = ks_wo; p.ssp = nullptr;
         rc = launch_mf<2, EPI_STORE>(c, p, pt); if (rc) return rc;
         // infer.rs:37,39
         rc = launch_rmsnorm_tile(c, b, w->rms_ffn_weight + li * dim, dim, ntile, ks_wo); if (rc) return rc;
         // infer.rs:41-45: W1 | W3, SiLU * gate
         { const float* bs[2] = {w->w1, w->w3}; mf_weights(c, p, 2, bs, hd, li); }
-        p.x = b.XN; p.o = b.HB; p.K = dim; p.rows = hidden; p.ksplit = 1;
+        p.x = b.XN; p.o = b.HB; p.K = dim; p.rows = hidden; p.ksplit = 1; p.ssp = norm_ssp(c, b);
         rc = launch_mf<2, EPI_SWIGLU>(c, p, pt); if (rc) return rc;
         // infer.rs:46: W2 . hb as K-slices (:47 rides in the next rmsnorm / the caller's fold)
         { const float* bs[1] = {w->w2}; mf_weights(c, p, 1, bs, hd, li); }
-        p.x = b.HB; p.o = b.SL; p.K = hidden; p.rows = dim; p.ksplit = ks_w2;
+        p.x = b.HB; p.o = b.SL; p.K = hidden; p.rows = dim; p.ksplit = ks_w2; p.ssp = nullptr;
         rc = launch_mf<2, EPI_STORE>(c, p, pt); if (rc) return rc;
         pending = ks_w2;
     }
@@ -1267,7 +1276,7 @@ int rama_decode_batch(rama_ctx* c, const rama_config* cfg, const rama_weights* w
     rc = launch_rmsnorm_tile(c, b, w->rms_final_weight, dim, ntile, nslab); if (rc) return rc;
     MfParams p{};
     p.n_tok = n_seq; p.ksplit = 1; { const float* bs[1] = {w->wcls}; mf_weights(c, p, 1, bs, 0, 0); }
-    p.x = b.XN; p.o = b.LG; p.o_stride = V; p.K = dim; p.rows = V;
+    p.x = b.XN; p.o = b.LG; p.o_stride = V; p.K = dim; p.rows = V; p.ssp = norm_ssp(c, b);
     rc = launch_mf<2, EPI_STORE_ROWS>(c, p, pt); if (rc) return rc;
     for (int i = 0; i < n_seq; i++)
         HIPCHK(hipMemcpyAsync(states[i].logits, b.LG + (size_t)i * V, sizeof(float) * V, hipMemcpyDeviceToDevice, c->stream));
@@ -1490,6 +1499,11 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
         HIPCHK(hipStreamSynchronize(c->stream));
         drop_graph(c);
         c->tune_combine_v = value;
+        return 0;
+    }
+    if (!strcmp(key, "norm_in_gemm")) {
+        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: norm_in_gemm must be 0 or 1");
+        c->tune_norm_in_gemm = value;
         return 0;
     }
     if (!strcmp(key, "tiled")) {
