@@ -74,17 +74,16 @@ int main(int argc, char** argv) {
     CK(hipStreamSynchronize(st));
 
     std::vector<Variant> vs = {
-        {"PT1 qkv3 J2 LD1 (product)", launch<1, 3, 2, 1, MODE_QKV>, 16, 1, false},
-        {"PT1 qkv3 J2 LD2 no permute", launch<1, 3, 2, 2, MODE_QKV>, 16, 1, false},
-        {"PT1 qkv3 J2 LD3 contiguous", launch<1, 3, 2, 3, MODE_QKV>, 16, 1, false},
-        {"PT1 qkv3 J2 LD4 loads only", launch<1, 3, 2, 4, MODE_QKV>, 16, 1, false},
-        {"PT1 swiglu J2 LD1         ", launch<1, 2, 2, 1, MODE_SWIGLU>, 16, 1, false},
-        {"PT1 swiglu J2 LD3         ", launch<1, 2, 2, 3, MODE_SWIGLU>, 16, 1, false},
-        {"PT1 swiglu J4 LD3         ", launch<1, 2, 4, 3, MODE_SWIGLU>, 16, 1, false},
-        {"PT4 qkv3 J2 LD1 (product)", launch<4, 3, 2, 1, MODE_QKV>, 64, 1, false},
-        {"PT4 qkv3 J2 LD3 contiguous", launch<4, 3, 2, 3, MODE_QKV>, 64, 1, false},
-        {"PT4 swiglu J2 LD1         ", launch<4, 2, 2, 1, MODE_SWIGLU>, 64, 1, false},
-        {"PT4 swiglu J2 LD3         ", launch<4, 2, 2, 3, MODE_SWIGLU>, 64, 1, false},
+        {"PT4 qkv3 J2 LD3            ", launch<4, 3, 2, 3, MODE_QKV>, 64, 1, false},
+        {"PT4 swiglu J2 LD3          ", launch<4, 2, 2, 3, MODE_SWIGLU>, 64, 1, false},
+        {"PT4 swiglu J4 LD3          ", launch<4, 2, 4, 3, MODE_SWIGLU>, 64, 1, false},
+        {"PT4 RT2 J2 ks2 LD3         ", launch<4, 2, 2, 3, MODE_ROWS>, 64, 2, false},
+        {"PT4 RT2 J4 ks2 LD3         ", launch<4, 2, 4, 3, MODE_ROWS>, 64, 2, false},
+        {"PT4 RT2 J2 ks1 LD3         ", launch<4, 2, 2, 3, MODE_ROWS>, 64, 1, false},
+        {"PT4 RT3 J2 ks1 LD3         ", launch<4, 3, 2, 3, MODE_ROWS>, 64, 1, false},
+        {"PT4 RT4 J2 ks1 LD3         ", launch<4, 4, 2, 3, MODE_ROWS>, 64, 1, false},
+        {"PT2 qkv3 J2 LD3            ", launch<2, 3, 2, 3, MODE_QKV>, 32, 1, false},
+        {"PT2 swiglu J4 LD3          ", launch<2, 2, 4, 3, MODE_SWIGLU>, 32, 1, false},
     };
     for (const Shape& sh : shapes) {
         printf("== %s\n", sh.name);
