@@ -27,7 +27,7 @@ __global__ __launch_bounds__(kTileAttnWaves * 64) void attention_tile_mfma_kerne
     __shared__ float s_m[kTileAttnWaves][16], s_l[kTileAttnWaves][16];
     __shared__ acc4 s_o[kTileAttnWaves][NB][64];
     const int h = blockIdx.x, qt = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: scalar loop control and tile addresses
     const int i = lane & 15, g = lane >> 4;
     const int hs = NB * 16, dim = p.dim;
     const int q_tok = qt * 16 + i;                         // my query (column of every tile)
