@@ -142,7 +142,11 @@ int  rama_model_save(rama_ctx *ctx, const rama_model *model, const char *path);
 /* A model also keeps W1 and W3 row-interleaved per layer (row i of W1, then row i of W3: +11.5 GB at
  * llama2-7B): the fused decode path finds that copy by the addresses of w1 / w3 in rama_weights and
  * streams ONE contiguous block per workgroup; weights uploaded tensor by tensor (rama_upload_f32) take
- * the two-tensor kernel.  rama_set_tuning "w13i" = 0 turns the lookup off. */
+ * the two-tensor kernel.  rama_set_tuning "w13i" = 0 turns the lookup off.
+ * And every matrix once more in MFMA tile order (+27 GB at llama2-7B; skipped when fewer than 16 GiB of
+ * HBM would remain, or with RAMA_NO_TILED=1 in the environment): rama_prefill / rama_decode_batch read
+ * that copy -- one contiguous 1-KiB weight read per wave -- found the same way ("tiled" = 0: off).
+ * rama_model_bytes counts the checkpoint tensors only. */
 int  rama_model_config(const rama_model *m, rama_config *cfg);
 int  rama_model_weights(const rama_model *m, rama_weights *w);
 size_t rama_model_bytes(const rama_model *m);
