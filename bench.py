@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--pos0", type=int, default=0,
                     help="start the timed generation at this position over a pre-filled (zero) cache: long-context timing, "
                          "N = 1 only; the default 0 is generate()'s own start (BOS + prompt)")
+    ap.add_argument("--mode", default="fast", choices=["fast", "parity"],
+                    help="parity: every op in the reference's own rounding order (bit-identical logits), on the model's chain-order weight copy")
     ap.add_argument("--cpu-tokens", type=int, default=8)
     ap.add_argument("--cpu-layers", type=int, default=8, help="layers of the CPU baseline's sample (all of them when the model has fewer)")
     return ap.parse_args()
@@ -164,6 +166,8 @@ def main():
         return pos
 
     eng.set_graph_mode(bool(args.graph))
+    if args.mode == "parity":
+        eng.set_tuning("ref_order", 1)
     pos0 = max(0, min(args.pos0, seq - 1))
     eng.decode_begin(1, pos0, PROMPT if pos0 == 0 else [])
     pos = run_steps(args.warmup, pos0)

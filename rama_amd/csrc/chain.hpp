@@ -1,0 +1,792 @@
+// chain.hpp -- the reference's arithmetic order AT STREAMING SPEED ("parity mode",
+// rama_set_tuning(ctx, "ref_order", 1) on a resident model).
+//
+// ref_order.hpp reproduces engine/src/device/cpu.rs operation by operation but parallel only across
+// whole outputs (one thread per row): bit-identical to the oracle, ~2x slower than the fast path.  This
+// file keeps the same rounding sequence and restores the parallelism the sequence allows:
+//
+//  * matmul (cpu.rs:127-153): o[r] = (v0 + v1) + (v2 + v3), v_j += W[r][4i + j] * x[4i + j] for i
+//    ascending, product and sum rounded separately.  The four lane sums of a row are independent
+//    chains, so ONE LANE OWNS ONE (row, j) CHAIN: a wave is 16 rows x 4 chains, a quad finishes a row
+//    with two DPP adds.  A model keeps a CHAIN-ORDER copy of every matrix (model.hip):
+//        [rows / 16][K / 16][lane = (r % 16) * 4 + j][t = 0..3] = W[r][16 s + 4 t + j]
+//    so one `buffer_load_dwordx4 nt` gives a lane four consecutive steps of its own chain and the
+//    wave reads 1 KiB contiguous; a wave streams its 16 rows front to back as ONE contiguous region
+//    (16 K floats) through a ring of D loads in flight.  The activations are staged once per wave in
+//    LDS in the same order, so a step's four x values are one broadcast ds_read_b128.
+//    A chain is K / 4 dependent adds (~5 cycles each): 1-3 us against 10-80 us of HBM time per launch,
+//    so the kernels stay bandwidth-bound as long as the ring keeps the loads coming.
+//  * rmsnorm (cpu.rs:99-117) and softmax (cpu.rs:187-192; the oracle's sequential order) sum
+//    non-negative terms one by one.  That chain is reproduced bit for bit by the parallel scan of
+//    topp_sort.hpp: between two changes of the sum's exponent the fp32 adds are integer increments that
+//    depend only on the parity of the running integer, such maps compose associatively, a workgroup
+//    scans them, and the one add that leaves the binade is done in fp32 (seq_sum_exact below).
+//  * attention (cpu.rs:23-52): one thread per timestep for the sequential q.k dots, cooperative tile
+//    loads + one thread per head column for the t-ascending value accumulation.
+//  * RoPE, SiLU * gate and the residual adds ride in the matvec epilogues with the reference's
+//    roundings (contraction off, glibc's expf restated in ref_order.hpp).
+// Results are bit-identical to ref_order.hpp's and to the oracle's (tests/test_hip_ref_order.py,
+// tests/test_hip_parity_7b.py).
+#pragma once
+#include "kernels.hpp"
+#include "ref_order.hpp"
+#include "topp_sort.hpp"
+
+namespace rama {
+
+// (the copy itself is made by chain_weights_kernel in model.hip)
+
+// ---------------------------------------------------------------- the sequential sum, exact and parallel
+// s = ((a_0 + a_1) + a_2) + ... of n non-negative floats a[scan_slot(i)] in LDS, every add rounded to
+// fp32 in that order (Iterator::sum of cpu.rs:112 / the oracle's softmax sum), computed by all NW
+// waves of the workgroup.  Same construction as topp_sort.hpp's running sum (elem_of / Inc maps), without
+// the stored partial sums: the first 64 elements by a lane ripple (the sum passes through several short
+// binades there), then rounds of NW * 64 * R elements -- scan of the increment maps, the first element
+// that would leave the binade is added in fp32 by its owner and the next round starts behind it.
+// Sums outside the scan's exponent range (zero, subnormal-ish, inf, nan) finish on one thread.
+template <int NW>
+struct SeqSumShared {
+    Inc w[2][NW];
+    int ev[2][NW];
+    int pos[2];
+    float cum[2];
+};
+
+template <int R, int NW>
+__device__ __forceinline__ void seqsum_round(const float* a, int n, SeqSumShared<NW>& sh, int par) {
+    RAMA_NO_CONTRACT
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pos = sh.pos[par];
+    const unsigned cb = __float_as_uint(sh.cum[par]);
+    const int E = (int)(cb >> 23);
+    const int c0 = (int)((cb & 0x7FFFFFu) | 0x800000u);
+    const float U = __uint_as_float((unsigned)(E - 23) << 23);
+    const float invU = __uint_as_float((unsigned)(277 - E) << 23);
+    constexpr int climit = (1 << 24) - 1;
+    const int i0 = pos + tid * R;
+    int e[R];
+    int x0 = 0, x1 = 1;
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        const int i = i0 + k;
+        const float pk = a[scan_slot(min(i, n - 1))];
+        e[k] = elem_of(i < n ? pk : 0.0f, invU);
+        x0 = elem_apply(x0, e[k]);
+        x1 = elem_apply(x1, e[k]);
+    }
+    Inc inc{min(x0, kScanClamp), min(x1 - 1, kScanClamp)};
+    inc = inc_then(inc_dpp<0x111, 0xF>(inc), inc);             // row_shr:1
+    inc = inc_then(inc_dpp<0x112, 0xF>(inc), inc);             // row_shr:2
+    inc = inc_then(inc_dpp<0x114, 0xF>(inc), inc);             // row_shr:4
+    inc = inc_then(inc_dpp<0x118, 0xF>(inc), inc);             // row_shr:8
+    inc = inc_then(inc_dpp<0x142, 0xA>(inc), inc);             // row_bcast:15 into rows 1 and 3
+    inc = inc_then(inc_dpp<0x143, 0xC>(inc), inc);             // row_bcast:31 into rows 2 and 3
+    if (lane == 63) sh.w[par][wave] = inc;
+    const Inc before = inc_dpp<0x138, 0xF>(inc);               // wave_shr:1: all earlier lanes of this wave
+    __syncthreads();
+    Inc pre{0, 0};
+#pragma unroll
+    for (int w = 0; w < NW - 1; w++) if (w < wave) pre = inc_then(pre, sh.w[par][w]);
+    pre = inc_then(pre, before);
+    int c = min(c0 + ((c0 & 1) ? pre.d1 : pre.d0), kScanClamp);
+    int quiet = 0, c_before_ev = c;
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        c = elem_apply(c, e[k]);
+        const bool ok = c <= climit;
+        quiet += ok;
+        c_before_ev = ok ? c : c_before_ev;
+    }
+    const int ev = (quiet < R && i0 + quiet < n) ? i0 + quiet : kNoEvent;
+    const int wev = ~wave_max_i(~ev);
+    if (lane == 0) sh.ev[par][wave] = wev;
+    __syncthreads();
+    int first = sh.ev[par][0];
+#pragma unroll
+    for (int w = 1; w < NW; w++) first = min(first, sh.ev[par][w]);
+    if (first == kNoEvent) {
+        if (tid == 64 * NW - 1) { sh.pos[par ^ 1] = pos + 64 * NW * R; sh.cum[par ^ 1] = (float)c * U; }
+    } else if (ev == first) {
+        sh.pos[par ^ 1] = first + 1;
+        sh.cum[par ^ 1] = (float)c_before_ev * U + a[scan_slot(first)];
+    }
+    __syncthreads();
+}
+
+template <int NW>
+__device__ __forceinline__ float seq_sum_exact(const float* a, int n, SeqSumShared<NW>& sh) {
+    RAMA_NO_CONTRACT
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        // the first elements by a lane ripple: lane i holds a_i, 63 steps of s_i = s_{i-1} + a_i leave S_i in lane i
+        // (zeros behind the list leave the sum as it is).  Up to kRipple blocks of 64: the sum passes through many
+        // short binades here, where a scan round would cost more than the ~0.15 us of a ripple.
+        constexpr int kRipple = 4;
+        float carry = 0.0f;
+        int done = 0;
+#pragma unroll 1
+        for (int b = 0; b < kRipple && done < n; b++, done += 64) {
+            const int i = done + tid;
+            const float pv = i < n ? a[scan_slot(i)] : 0.0f;
+            float sv = (b > 0 && tid == 0) ? carry + pv : pv;
+#pragma unroll
+            for (int k = 0; k < 63; k++)
+                asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(sv) : "v"(pv));
+            carry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sv), 63));
+        }
+        if (tid == 0) { sh.pos[0] = min(done, n); sh.cum[0] = carry; }
+    }
+    __syncthreads();
+    int par = 0;
+    while (true) {
+        const int pos = sh.pos[par];
+        if (pos >= n) break;                                      // uniform
+        const int E = (int)(__float_as_uint(sh.cum[par]) >> 23);
+        if (E < 24 || E > 253) {                                  // uniform: outside the scan's range
+            if (tid == 0) {
+                float s = sh.cum[par];
+                for (int i = pos; i < n; i++) s = s + a[scan_slot(i)];
+                sh.pos[par ^ 1] = n; sh.cum[par ^ 1] = s;
+            }
+            __syncthreads();
+            par ^= 1;
+            continue;
+        }
+        const int want = min(max(pos, 64), n - pos);              // binades double in length
+        if (want <= 64 * NW) seqsum_round<1, NW>(a, n, sh, par);
+        else if (want <= 128 * NW) seqsum_round<2, NW>(a, n, sh, par);
+        else if (want <= 256 * NW) seqsum_round<4, NW>(a, n, sh, par);
+        else if (want <= 512 * NW) seqsum_round<8, NW>(a, n, sh, par);
+        else seqsum_round<16, NW>(a, n, sh, par);
+        par ^= 1;
+    }
+    return sh.cum[par];
+}
+
+// ---------------------------------------------------------------- the same sum in ONE pass: predict, then verify
+// seq_sum_exact pays three barriers and a scan per binade the sum passes through (6-10 rounds for 4096 terms).
+// But the increment map of a run of elements depends only on the BINADE the sum is in while it crosses the
+// run, not on the sum's value -- and the binade can be predicted from an ordinary (tree-ordered, approximate)
+// parallel prefix sum, which differs from the sequential fp32 sum by ~1e-6 relative (1.2e-4 is allowed for; a
+// wrong prediction is caught in step 4 and costs only time).  So:
+//   1. thread t owns the contiguous run [t R, (t + 1) R); approximate prefix sums lo_t (before the run) and hi_t
+//      (behind it) come from one block scan;
+//   2. if lo_t (1 - 2^-13) and hi_t (1 + 2^-13) lie in one binade e, the run is a MAP item: its elements' increments
+//      for U = ulp(2^e) are composed into one map; otherwise (the sum may change binade inside the run, or is
+//      still tiny: the first few runs) it is a SEQ item;
+//   3. inside a wave, neighbouring MAP items of one binade are composed by a segmented DPP scan;
+//   4. ONE lane then walks the items in order with the true sum: a SEQ item's elements are added in fp32, a
+//      segment's map is applied as c -> c + D[c & 1] AFTER checking that the true sum really is in the predicted
+//      binade, and that it still is behind the segment (c < 2^24: the sum only grows, so every add in between was
+//      in that binade too).  Either check failing means the prediction was wrong: the caller falls back to
+//      seq_sum_exact.  The result is the sequential sum bit for bit whenever it is returned.
+// phase time stamps for tools/seqsum_bench.hip only (100 MHz counter, thread 0)
+#ifdef RAMA_SEQ_STAMPS
+__device__ unsigned long long g_seq_stamps[16];
+#define SEQ_STAMP(id) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_seq_stamps[id] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SEQ_STAMP(id) do { } while (0)
+#endif
+__device__ unsigned g_pred_stats[2];      // diagnostics: [0] sums the one-pass path returned, [1] sums that fell back
+constexpr int kMaxSeq = 12;                // SEQ items the one-pass walk handles (binade crossings behind the first 64 elements)
+template <int NW>
+struct PredShared {
+    float wsum[NW];
+    int wf[NW], wd0[NW], wd1[NW], wefirst[NW], welast[NW];
+    unsigned long long smask[NW];
+    int d0[NW * 64], d1[NW * 64], ebin[NW * 64];
+    int seqlist[kMaxSeq];
+    float head;
+    float result;
+    int fail;
+};
+struct SegInc { int f; Inc m; };
+__device__ __forceinline__ SegInc seg_then(SegInc a, SegInc b) {      // a (earlier items) first, then b; a segment start in b hides a
+    SegInc r;
+    const Inc ab = inc_then(a.m, b.m);
+    r.m.d0 = b.f ? b.m.d0 : ab.d0;
+    r.m.d1 = b.f ? b.m.d1 : ab.d1;
+    r.f = a.f | b.f;
+    return r;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ SegInc seg_dpp(SegInc v) {                 // lanes without a source get (no start, identity)
+    return SegInc{__builtin_amdgcn_update_dpp(0, v.f, CTRL, ROW_MASK, 0xF, true), inc_dpp<CTRL, ROW_MASK>(v.m)};
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float fadd_dpp(float v) {                  // v + (value of the source lane, 0 without one)
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, true));
+}
+
+// Elements 0..63 are summed by the lane ripple of seq_sum_exact (the sum passes through a binade every few
+// elements there); the items cover elements 64.. : thread t owns [64 + t R, 64 + (t + 1) R).
+// RMAX: the run is fetched from LDS once, all reads in flight together, and kept in registers (R <= RMAX)
+template <int NW, int RMAX>
+__device__ __forceinline__ bool seq_sum_predict_r(const float* a, int n, PredShared<NW>& ps, float* out) {
+    RAMA_NO_CONTRACT
+    constexpr int T = NW * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int R = max((n - 64 + T - 1) / T, 1);
+    const int i0 = 64 + tid * R;
+    float run[RMAX];
+#pragma unroll
+    for (int k = 0; k < RMAX; k++) { const int i = i0 + k; const float v_ = a[scan_slot(min(i, n - 1))]; run[k] = (k < R && i < n) ? v_ : 0.0f; }
+    SEQ_STAMP(1);
+    // 1. approximate prefix sums (wave 0 first ripples the head: exact, and the prefix's base)
+    if (wave == 0) {
+        const float pv = lane < n ? a[scan_slot(lane)] : 0.0f;
+        float sv = pv;
+#pragma unroll
+        for (int k = 0; k < 63; k++)
+            asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(sv) : "v"(pv));
+        if (lane == 63) { ps.head = sv; ps.fail = 0; }
+    }
+    float loc = 0.0f;
+    {   // any order will do for the estimate: four partial sums
+        float l4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < RMAX; k++) l4[k & 3] += run[k];
+        loc = (l4[0] + l4[1]) + (l4[2] + l4[3]);
+    }
+    float inc = loc;
+    inc = fadd_dpp<0x111, 0xF>(inc); inc = fadd_dpp<0x112, 0xF>(inc); inc = fadd_dpp<0x114, 0xF>(inc); inc = fadd_dpp<0x118, 0xF>(inc);
+    inc = fadd_dpp<0x142, 0xA>(inc); inc = fadd_dpp<0x143, 0xC>(inc);
+    if (lane == 63) ps.wsum[wave] = inc;
+    __syncthreads();
+    float base = ps.head;
+#pragma unroll
+    for (int w = 0; w < NW - 1; w++) base += w < wave ? ps.wsum[w] : 0.0f;
+    const float lo = base + (inc - loc), hi = base + inc;
+    SEQ_STAMP(2);
+    // 2. one binade for the whole run?
+    const int el = (int)(__float_as_uint(lo * (1.0f - 0x1p-13f)) >> 23), eh = (int)(__float_as_uint(hi * (1.0f + 0x1p-13f)) >> 23);
+    const bool conf = lo > 0.0f && el == eh && el >= 24 && el <= 253;     // (a sign bit or nan makes the exponents differ or leave the range)
+    const int e = conf ? el : -1;
+    const int eprev = __builtin_amdgcn_update_dpp(-2, e, 0x138, 0xF, 0xF, false);      // wave_shr:1; lane 0 keeps -2
+    // a segment start inside the wave; whether lane 0 continues the previous wave's segment is settled in step 3b
+    const bool F = !conf || (lane != 0 && eprev != e);
+    SegInc sv{F ? 1 : 0, Inc{0, 0}};
+    if (conf) {
+        const float invU = __uint_as_float((unsigned)(277 - e) << 23);
+        int x0 = 0, x1 = 1;
+#pragma unroll
+        for (int k = 0; k < RMAX; k++) {           // (elements behind the run are zeros: identity increments)
+            const int el_ = elem_of(run[k], invU);
+            x0 = elem_apply(x0, el_);
+            x1 = elem_apply(x1, el_);
+            if ((k & 7) == 7) { x0 = min(x0, kScanClamp); x1 = min(x1, kScanClamp); }      // 8 increments of <= 2^25 cannot overflow
+        }
+        sv.m = Inc{min(x0, kScanClamp), min(x1, kScanClamp) - 1};
+    }
+    SEQ_STAMP(3);
+    // 3a. segmented inclusive scan over the wave
+    sv = seg_then(seg_dpp<0x111, 0xF>(sv), sv);
+    sv = seg_then(seg_dpp<0x112, 0xF>(sv), sv);
+    sv = seg_then(seg_dpp<0x114, 0xF>(sv), sv);
+    sv = seg_then(seg_dpp<0x118, 0xF>(sv), sv);
+    sv = seg_then(seg_dpp<0x142, 0xA>(sv), sv);
+    sv = seg_then(seg_dpp<0x143, 0xC>(sv), sv);
+    const unsigned long long sm = __ballot(!conf);
+    if (lane == 0) { ps.wefirst[wave] = e; ps.smask[wave] = sm; }
+    if (lane == 63) { ps.wf[wave] = sv.f; ps.wd0[wave] = sv.m.d0; ps.wd1[wave] = sv.m.d1; ps.welast[wave] = e; }
+    __syncthreads();
+    // 3b. across the waves: wave w' continues the segment that ends wave w' - 1 iff both border items are MAP items of one binade
+    {
+        SegInc carry{1, Inc{0, 0}};
+        int prev_last = -3, rank = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            if (w < wave) {
+                SegInc tot{ps.wf[w], Inc{ps.wd0[w], ps.wd1[w]}};
+                const int ef = ps.wefirst[w];
+                if (!(ef >= 0 && ef == prev_last)) tot.f = 1;
+                carry = seg_then(carry, tot);
+                prev_last = ps.welast[w];
+                rank += __popcll(ps.smask[w]);
+            }
+        }
+        const int ef = ps.wefirst[wave];
+        const bool cont = ef >= 0 && ef == prev_last;            // uniform over the wave
+        if (!sv.f && cont) sv.m = inc_then(carry.m, sv.m);
+        ps.d0[tid] = sv.m.d0; ps.d1[tid] = sv.m.d1; ps.ebin[tid] = e;
+        if (!conf) {
+            rank += __popcll(sm & ((1ull << lane) - 1ull));
+            if (rank < kMaxSeq) ps.seqlist[rank] = tid;
+        }
+    }
+    __syncthreads();
+    SEQ_STAMP(4);
+    // 4. the walk, by wave 0, every operand fetched up front: per SEQ item (in order) the map of the segment in front
+    // of it, then its R elements (lane k: element k; zeros behind the run and the list leave the sum as it is); at the
+    // end the segment behind the last SEQ item.
+    if (wave == 0) {
+        int nseq = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) nseq += __popcll(ps.smask[w]);
+        int it[kMaxSeq + 1], cd0[kMaxSeq + 1], cd1[kMaxSeq + 1], ceb[kMaxSeq + 1];
+        float ev[kMaxSeq];
+#pragma unroll
+        for (int g = 0; g <= kMaxSeq; g++) {
+            it[g] = (g < kMaxSeq && g < nseq) ? ps.seqlist[g] : T;             // behind the last SEQ item: the item "T"
+        }
+#pragma unroll
+        for (int g = 0; g <= kMaxSeq; g++) {
+            const int t = max(it[g] - 1, 0);
+            cd0[g] = ps.d0[t]; cd1[g] = ps.d1[t]; ceb[g] = ps.ebin[t];
+            if (g < kMaxSeq) {
+                const int j = 64 + it[g] * R + lane;
+                ev[g] = (it[g] < T && lane < R && j < n) ? a[scan_slot(min(j, n - 1))] : 0.0f;
+            }
+        }
+        float s = ps.head;
+        int bad = nseq > kMaxSeq ? 1 : 0;
+        const int nsteps = __builtin_amdgcn_readfirstlane(min(nseq, kMaxSeq));
+#pragma unroll
+        for (int g = 0; g <= kMaxSeq; g++) {
+            if (g <= nsteps) {                                    // uniform
+            // a segment lies in front of SEQ item g iff the item before it is a MAP item (and there is one)
+            const int prev = g == 0 ? -1 : it[g - 1];
+            const bool seg = it[g] - 1 > prev;
+            {
+                const unsigned sb = __float_as_uint(s);
+                const int c0 = (int)((sb & 0x7FFFFFu) | 0x800000u);
+                const int c = c0 + ((c0 & 1) ? cd1[g] : cd0[g]);
+                const bool wrong = (int)(sb >> 23) != ceb[g] || c > (1 << 24) - 1;
+                const float sn = (float)c * __uint_as_float((unsigned)(max(ceb[g], 23) - 23) << 23);
+                bad |= (seg && wrong) ? 1 : 0;
+                s = seg ? sn : s;
+            }
+            if (g < kMaxSeq && g < nsteps) {
+                // the run's elements sit in lanes 0..R-1: lane 0 is seeded with s + e_0 and a ripple of >= R - 1 steps
+                // t_i = t_(i-1) + e_i leaves the sum in lane R - 1 (further steps recompute the same values)
+                float t_ = lane == 0 ? s + ev[g] : ev[g];
+                for (int k = 1; k < R; k += 8) {
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(t_) : "v"(ev[g]));
+                }
+                s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t_), min(R, 64) - 1));
+            }
+            }
+        }
+        if (lane == 0) { ps.result = s; ps.fail = bad; atomicAdd(&g_pred_stats[bad ? 1 : 0], 1u); }
+    }
+    __syncthreads();
+    SEQ_STAMP(5);
+    *out = ps.result;
+    return ps.fail == 0;
+}
+
+template <int NW>
+__device__ __forceinline__ bool seq_sum_predict(const float* a, int n, PredShared<NW>& ps, float* out) {
+    const int R = (n - 64 + NW * 64 - 1) / (NW * 64);             // uniform
+    if (R <= 4) return seq_sum_predict_r<NW, 4>(a, n, ps, out);
+    if (R <= 16) return seq_sum_predict_r<NW, 16>(a, n, ps, out);
+    if (R <= 32) return seq_sum_predict_r<NW, 32>(a, n, ps, out);
+    return seq_sum_predict_r<NW, 64>(a, n, ps, out);
+}
+
+// ---------------------------------------------------------------- cpu.rs:99-117 rmsnorm, one workgroup
+// o[i] = w[i] * (v * x[i]), v = 1 / sqrt(sum(x^2) / n + 1e-5) with the sum in index order.  copy_to, when
+// given, receives x unchanged first (infer.rs:49: xb = x before the final norm writes x in place).
+constexpr int kNormMax = 16384;
+constexpr int kNormWaves = 4, kNormThreads = kNormWaves * 64;     // one wave per SIMD: the scan rounds are bound by instruction issue
+__global__ __launch_bounds__(kNormThreads) void rmsnorm_chain_kernel(float* o, const float* x, const float* w, int n, float* copy_to) {
+    RAMA_NO_CONTRACT
+    extern __shared__ __attribute__((aligned(16))) float s_sq[];
+    __shared__ SeqSumShared<kNormWaves> sh;
+    __shared__ PredShared<kNormWaves> ps;
+    const int tid = threadIdx.x;
+    SEQ_STAMP(0);
+    const bool vec = n % 4 == 0 && ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)o | (uintptr_t)copy_to) & 15) == 0) && n <= 16 * kNormThreads;
+    if (vec) {     // up to 4 x 16 bytes per thread, everything requested up front
+        const int n4 = n >> 2;
+        f4 xv[4], wv[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = tid + kNormThreads * k;
+            xv[k] = i < n4 ? reinterpret_cast<const f4*>(x)[i] : f4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = tid + kNormThreads * k;
+            wv[k] = i < n4 ? reinterpret_cast<const f4*>(w)[i] : f4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = tid + kNormThreads * k;
+            if (i < n4) {
+                float* d = s_sq + scan_slot(4 * i);               // 4 i .. 4 i + 3 share a 32-element stretch of slots
+                d[0] = xv[k].x * xv[k].x; d[1] = xv[k].y * xv[k].y; d[2] = xv[k].z * xv[k].z; d[3] = xv[k].w * xv[k].w;
+            }
+        }
+        __syncthreads();
+        float ss;
+        if (!seq_sum_predict<kNormWaves>(s_sq, n, ps, &ss)) ss = seq_sum_exact<kNormWaves>(s_sq, n, sh);
+        const float v = 1.0f / sqrtf(ss / (float)n + 1e-5f);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = tid + kNormThreads * k;
+            if (i < n4) {
+                if (copy_to) reinterpret_cast<f4*>(copy_to)[i] = xv[k];
+                f4 r;
+                r.x = wv[k].x * (v * xv[k].x); r.y = wv[k].y * (v * xv[k].y); r.z = wv[k].z * (v * xv[k].z); r.w = wv[k].w * (v * xv[k].w);
+                reinterpret_cast<f4*>(o)[i] = r;
+            }
+        }
+        SEQ_STAMP(6);
+        return;
+    }
+    for (int i = tid; i < n; i += kNormThreads) { const float a = x[i]; s_sq[scan_slot(i)] = a * a; }
+    __syncthreads();
+    float ss;
+    if (!seq_sum_predict<kNormWaves>(s_sq, n, ps, &ss)) ss = seq_sum_exact<kNormWaves>(s_sq, n, sh);
+    const float v = 1.0f / sqrtf(ss / (float)n + 1e-5f);
+    // every thread rewrites only the indices it reads (o may alias x: infer.rs:49-50)
+    for (int i = tid; i < n; i += kNormThreads) {
+        const float a = x[i];
+        if (copy_to) copy_to[i] = a;
+        o[i] = w[i] * (v * a);
+    }
+}
+
+// cpu.rs:119-125 Device::softmax over a whole view (n <= kNormMax), the oracle's order: max, exp, sequential sum, divide
+__global__ __launch_bounds__(kNormThreads) void softmax_chain_kernel(float* x, int n) {
+    RAMA_NO_CONTRACT
+    extern __shared__ __attribute__((aligned(16))) float s_e[];
+    __shared__ SeqSumShared<kNormWaves> sh;
+    __shared__ PredShared<kNormWaves> ps;
+    __shared__ float red[16];
+    const int tid = threadIdx.x;
+    float mx = -INFINITY;
+    for (int i = tid; i < n; i += kNormThreads) mx = fmaxf(mx, x[i]);
+    mx = block_max(mx, red);
+    for (int i = tid; i < n; i += kNormThreads) s_e[scan_slot(i)] = expf_glibc(x[i] - mx);
+    __syncthreads();
+    float sum;
+    if (!seq_sum_predict<kNormWaves>(s_e, n, ps, &sum)) sum = seq_sum_exact<kNormWaves>(s_e, n, sh);
+    for (int i = tid; i < n; i += kNormThreads) x[i] = s_e[scan_slot(i)] / sum;
+}
+
+// ---------------------------------------------------------------- cpu.rs:127-153 matmul on chain-order weights
+enum { CEPI_STORE = 0, CEPI_RESID = 1, CEPI_QKV = 2, CEPI_SWIGLU = 3 };
+
+struct ChainParams {
+    const float* w[3];     // chain-order matrices (nmat <= 3), each [ceil(rows/16)*16, K]
+    float* o[3];           // STORE: o[0]; RESID: o[0] = the product (xb2 / xb); QKV: q, k, v; SWIGLU: o[0] = hb, o[1] = hb2
+    const float* x;        // [K] activations, row-major
+    float* resid;          // RESID: resid[r] += product (infer.rs:37,47)
+    int K, rows, nmat;     // SWIGLU: rows = 2 * hidden (interleaved W1 | W3)
+    const Ctl* ctl; int pos_val;
+    const float* fr; const float* fi; int head_size;
+    float* kc; float* vc;  // this layer's cache slabs [seq, dim]
+};
+
+// a descriptor whose inputs the compiler must take as wave-uniform (they are: kernel arguments and blockIdx)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_uniform(const void* p, unsigned bytes) {
+    const unsigned long long b = (unsigned long long)(uintptr_t)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return make_rsrc(reinterpret_cast<const void*>((uintptr_t)(((unsigned long long)hi << 32) | lo)), (unsigned)__builtin_amdgcn_readfirstlane((int)bytes));
+}
+__device__ __forceinline__ f4 ld_nt_s(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 2));
+}
+
+// A workgroup of W waves owns 16 rows; grid = nmat * ceil(rows / 16).  The chain of a row group is cut
+// into chunks of D blocks (1 KiB of weights each); chunk c is summed by wave c mod W, which receives the 64
+// running sums through LDS from the wave before it and meanwhile keeps its next chunk's D loads in flight:
+// W x D KiB per group on the way at any time, one wave adding.  (W = 1: a rolling ring of D loads.)
+// Measured (tools/chain_bench.hip, tools/chain_sweep.py): a CU takes ~64 KiB of loads in flight -- issuing
+// 4 x 48 loads per CU lasts 4.8 us, 2 x 32 lasts 0.8 -- so deeper rings only delay the first turn; in steady state
+// every geometry streams at 6.2-6.9 TB/s and what separates a launch from bytes / 6.9 TB/s is ~2.3 us of start
+// (the first HBM round trip under the burst of every CU's ring) and ~2 us of tail and launch gap.
+// XD = activation blocks read ahead from LDS.  Dynamic LDS: K + chain_pad_floats(W, D, XD) floats.
+__host__ __device__ constexpr int chain_pad_floats(int W, int D, int XD) { return 16 * ((W + 1) * D + XD); }   // everything the x ring can touch
+// time stamps of one wave for tools/chain_bench.hip only (100 MHz counter; lane 0 of wave 0 of block RAMA_CHAIN_STAMP_BLOCK)
+#ifdef RAMA_CHAIN_STAMPS
+__device__ unsigned long long g_chain_stamps[64];
+#define CHAIN_STAMP(id) do { if (threadIdx.x == 0 && blockIdx.x == RAMA_CHAIN_STAMP_BLOCK) g_chain_stamps[id] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CHAIN_STAMP(id) do { } while (0)
+#endif
+template <int W, int D, int XD, int EPI>
+__global__ __launch_bounds__(W * 64) void gemv_chain_kernel(ChainParams p) {
+    RAMA_NO_CONTRACT
+    CHAIN_STAMP(0);
+    static_assert(D % XD == 0, "the x ring must divide the weight ring");
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    __shared__ float relay[64];
+    const int lane = threadIdx.x & 63;
+    const int wave = W == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 3, rr = lane >> 2;
+    const int groups = (p.rows + 15) >> 4;
+    // (the quotient comes out of the vector ALU: without readfirstlane everything derived from it -- the buffer
+    // descriptors above all -- counts as divergent and every load turns into a waterfall loop)
+    const int m = __builtin_amdgcn_readfirstlane(blockIdx.x / groups), g = blockIdx.x - m * groups;
+    const float* Wm = m == 0 ? p.w[0] : (m == 1 ? p.w[1] : p.w[2]);
+    const int nblk = p.K >> 4;
+    const int nchunk = (nblk + D - 1) / D;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    static_assert(D % 16 == 0, "a chunk is made of whole 16-block stretches");
+    const int n16 = (nblk + 15) >> 4;
+    // the descriptor of stretch q (16 blocks = 16 KiB of the group's stream): as many bytes as the row still has there,
+    // so that blocks behind the end of the row are dropped by the range check with no select in the loop
+    auto stretch = [&](int q) {
+        const int left = min(max(nblk - q * 16, 0), 16);
+        return make_rsrc_uniform(Wm + ((size_t)g * (size_t)nblk + (size_t)min(q, n16) * 16) * 256, (unsigned)left * 1024u);
+    };
+    unsigned vo[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) vo[k] = lane16 + (unsigned)k * 4096u;
+    // The activations are requested FIRST (they come from L2), then this wave's first chunk of weights (from HBM):
+    // a wave's loads complete in order, so x asked for behind the weights would wait for the whole first HBM round
+    // trip before the staging below could even begin.
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc_uniform(p.x, (unsigned)p.K * 4u);
+    const int n4 = p.K >> 2;
+    constexpr int T = W * 64, XU = 16;
+    f4 xa[XU];
+#pragma unroll
+    for (int u = 0; u < XU; u++) xa[u] = ld_c(rx, ((int)threadIdx.x + T * u) < n4 ? (unsigned)((int)threadIdx.x + T * u) * 16u : kOOB);
+    f4 wr[D];
+#pragma unroll
+    for (int h = 0; h < D / 16; h++) {
+        const __amdgpu_buffer_rsrc_t r0 = stretch(wave * (D / 16) + h);
+#pragma unroll
+        for (int u = 0; u < 16; u++) wr[h * 16 + u] = ld_nt(r0, vo[u >> 2] + (unsigned)(u & 3) * 1024u);
+    }
+    const int row = 16 * g + rr;
+    // epilogue operands
+    float xold = 0.0f, rc = 1.0f, rs = 0.0f;
+    int pos = 0;
+    if (EPI == CEPI_RESID) {
+        if (j == 0 && row < p.rows) xold = p.resid[row];
+    } else if (EPI == CEPI_QKV) {
+        pos = p.ctl ? p.ctl->pos : p.pos_val;
+        if (m < 2) {
+            const int i = ((row & ~1) % p.head_size) >> 1;       // infer.rs:15-16: table row pos, pair i of the head
+            rc = p.fr[(size_t)pos * (p.head_size >> 1) + i];
+            rs = p.fi[(size_t)pos * (p.head_size >> 1) + i];
+        }
+    }
+    CHAIN_STAMP(1);
+    // activations -> LDS in chain order: xs[16 s + 4 j + t] = x[16 s + 4 t + j]
+    {
+#pragma unroll
+        for (int u = 0; u < XU; u++) {
+            // no branch around the stores (it would serialise the loads): a lane past the end holds zeros and
+            // drops them onto the zero padding behind x
+            const int i = (int)threadIdx.x + T * u;
+            float* d = xs + (i < n4 ? 16 * (i >> 2) + (i & 3) : p.K);
+            d[0] = xa[u].x; d[4] = xa[u].y; d[8] = xa[u].z; d[12] = xa[u].w;
+        }
+        for (int i0 = (int)threadIdx.x + T * XU; i0 < n4; i0 += T * 8) {      // rows longer than 64 T floats: the rest, behind the weights
+            f4 a[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) a[u] = ld_c(rx, (i0 + T * u) < n4 ? (unsigned)(i0 + T * u) * 16u : kOOB);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = i0 + T * u;
+                float* d = xs + (i < n4 ? 16 * (i >> 2) + (i & 3) : p.K);
+                d[0] = a[u].x; d[4] = a[u].y; d[8] = a[u].z; d[12] = a[u].w;
+            }
+        }
+    }
+    // zeros behind x: D blocks that may be multiplied (by weights the range check zeroed) + the x ring's read-ahead
+    for (int i = p.K + (int)threadIdx.x; i < p.K + chain_pad_floats(W, D, XD); i += W * 64) xs[i] = 0.0f;
+    __syncthreads();
+    // A lone wave issues one instruction per several cycles whatever its kind, and only ONE wave of the group can
+    // be adding at any time, so the adding wave's instruction count per block is what bounds a launch with one
+    // group per CU.  Hence: no guards and no selects in the loop (blocks behind the end of the row are dropped by
+    // the descriptor's range check and read as 0; LDS holds zeros behind x, so such a block adds 0 * 0 = +0 to a
+    // sum that can never be -0: the bits stay), chunk-relative immediate offsets, and -- with W > 1 -- the
+    // PRODUCTS are formed outside the turn: a wave multiplies its next chunk in place (wr *= x, rounded: the
+    // reference's separate multiply) while the wave before it is adding, so a turn is 4 dependent adds and one
+    // reload per block.
+    CHAIN_STAMP(2);
+    const f4* xq = reinterpret_cast<const f4*>(xs) + j;          // block s: xq[4 s]
+    float v = 0.0f;
+    if (W == 1) {
+        f4 xr[XD];
+#pragma unroll
+        for (int u = 0; u < XD; u++) xr[u] = xq[4 * u];
+        for (int c = 0; c < nchunk; c++) {
+            __amdgpu_buffer_rsrc_t rn[D / 16];                    // the chunk reloaded behind this one, stretch by stretch
+#pragma unroll
+            for (int h = 0; h < D / 16; h++) rn[h] = stretch((c + 1) * (D / 16) + h);
+            const f4* xc = xq + 4 * c * D;
+#pragma unroll
+            for (int u = 0; u < D; u++) {
+                const f4 xv = xr[u % XD];
+                xr[u % XD] = xc[4 * (u + XD)];
+                const f4 wv = wr[u];
+                v = v + wv.x * xv.x;
+                v = v + wv.y * xv.y;
+                v = v + wv.z * xv.z;
+                v = v + wv.w * xv.w;
+                wr[u] = ld_nt(rn[u >> 4], vo[(u & 15) >> 2] + (unsigned)(u & 3) * 1024u);
+                __builtin_amdgcn_sched_barrier(0);                // keep the ring rolling: one reload per consumed block
+            }
+        }
+    } else {
+        auto premultiply = [&](int c) {                           // wr <- wr * x for chunk c (this wave's next turn)
+            const f4* xc = xq + 4 * c * D;
+#pragma unroll
+            for (int u = 0; u < D; u++) {
+                const f4 xv = xc[4 * u];
+                wr[u].x = wr[u].x * xv.x; wr[u].y = wr[u].y * xv.y; wr[u].z = wr[u].z * xv.z; wr[u].w = wr[u].w * xv.w;
+            }
+        };
+        if (wave == 0) premultiply(0);
+        CHAIN_STAMP(3);
+        for (int c = 0; c < nchunk; c++) {
+            if ((c % W) == wave) {                                // uniform: my turn
+                if (c < 24) CHAIN_STAMP(8 + 2 * c);
+                if (c > 0) v = relay[lane];
+                __amdgpu_buffer_rsrc_t rn[D / 16];
+#pragma unroll
+                for (int h = 0; h < D / 16; h++) rn[h] = stretch((c + W) * (D / 16) + h);
+#pragma unroll
+                for (int u = 0; u < D; u++) {
+                    const f4 pv = wr[u];
+                    v = v + pv.x;
+                    v = v + pv.y;
+                    v = v + pv.z;
+                    v = v + pv.w;
+                    wr[u] = ld_nt(rn[u >> 4], vo[(u & 15) >> 2] + (unsigned)(u & 3) * 1024u);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (c + 1 < nchunk) relay[lane] = v;
+                if (c < 24) CHAIN_STAMP(9 + 2 * c);
+            } else if (((c + 1) % W) == wave && c + 1 < nchunk) { // my turn is next: the products, while the wave before me adds
+                premultiply(c + 1);
+            }
+            __syncthreads();
+        }
+    }
+    CHAIN_STAMP(4);
+    if (W > 1 && ((nchunk - 1) % W) != wave) return;             // the wave that summed the last chunk finishes the rows
+    // (v0 + v1) + (v2 + v3): both adds are commutative, so every lane of the quad ends with the row's bits
+    const float t2 = v + dpp_mov<0xB1>(v);                       // quad_perm [1,0,3,2]
+    const float d = t2 + dpp_mov<0x4E>(t2);                      // quad_perm [2,3,0,1]
+    if (EPI == CEPI_STORE) {
+        if (j == 0 && row < p.rows) p.o[0][row] = d;
+    } else if (EPI == CEPI_RESID) {
+        if (j == 0 && row < p.rows) { p.o[0][row] = d; p.resid[row] = xold + d; }
+    } else if (EPI == CEPI_QKV) {
+        const float other = __shfl_xor(d, 4);                    // the pair's other row (neighbouring quad)
+        const float a = (rr & 1) ? other : d, b = (rr & 1) ? d : other;
+        float out = d;
+        if (m < 2) out = (rr & 1) ? a * rs + b * rc : a * rc - b * rs;      // cpu.rs:87-96
+        if (j == 0 && row < p.rows) {
+            float* o = m == 0 ? p.o[0] : (m == 1 ? p.o[1] : p.o[2]);
+            o[row] = out;
+            if (m == 1) p.kc[(size_t)pos * p.rows + row] = out;              // infer.rs:32
+            else if (m == 2) p.vc[(size_t)pos * p.rows + row] = out;         // infer.rs:33
+        }
+    } else {   // CEPI_SWIGLU: even row = W1 row i, odd row = W3 row i
+        const float h3 = __shfl_xor(d, 4);
+        if (j == 0 && !(rr & 1) && row < p.rows) {
+            const float sl = d * (1.0f / (1.0f + expf_glibc(-d)));           // cpu.rs:56
+            p.o[0][row >> 1] = sl * h3;                                        // cpu.rs:59-64
+            p.o[1][row >> 1] = h3;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- cpu.rs:23-52 multi_head_attention
+// One workgroup of NW waves per head.  Scores: thread t owns timestep t (t, t + 64 NW, ...), its
+// q.k dot runs over the head in index order.  Softmax: max, glibc expf, the sequential sum (exact
+// scan), divide.  Values: tiles of kAttTile cache rows are loaded by all threads (16-byte loads, the
+// next tile in flight while this one is consumed), thread i < head_size adds att[t] * v[t][i], t ascending.
+constexpr int kAttTile = 64;
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attention_chain_kernel(RefAttnParams p) {
+    RAMA_NO_CONTRACT
+    constexpr int T = NW * 64;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ SeqSumShared<NW> sh;
+    __shared__ PredShared<NW> ps;
+    __shared__ float red[16];
+    const int h = blockIdx.x, tid = threadIdx.x;
+    const int pos = p.ctl ? p.ctl->pos : p.pos_val;
+    const int hs = p.head_size, hs4 = hs >> 2;
+    float* s_q = sm;                                              // [hs]
+    float* s_v = sm + ((hs + 3) & ~3);                            // [kAttTile][hs]
+    float* s_att = s_v + kAttTile * hs;                           // [scan_slot(seq_len)]
+    const size_t col = (size_t)h * hs;
+    for (int i = tid; i < hs; i += T) s_q[i] = p.q[col + i];
+    __syncthreads();
+    const float scale_div = sqrtf((float)hs);
+    const f4* q4 = reinterpret_cast<const f4*>(s_q);
+    for (int t = tid; t <= pos; t += T) {
+        const f4* k4 = reinterpret_cast<const f4*>(p.kc + (size_t)t * p.dim + col);
+        float acc = 0.0f;
+        int i = 0;
+        for (; i + 8 <= hs4; i += 8) {
+            f4 kk[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) kk[u] = k4[i + u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const f4 qq = q4[i + u];
+                acc = acc + qq.x * kk[u].x; acc = acc + qq.y * kk[u].y; acc = acc + qq.z * kk[u].z; acc = acc + qq.w * kk[u].w;
+            }
+        }
+        for (; i < hs4; i++) {
+            const f4 kk = k4[i], qq = q4[i];
+            acc = acc + qq.x * kk.x; acc = acc + qq.y * kk.y; acc = acc + qq.z * kk.z; acc = acc + qq.w * kk.w;
+        }
+        s_att[scan_slot(t)] = acc / scale_div;
+    }
+    __syncthreads();
+    // softmax_num (cpu.rs:187-192)
+    float mx = -INFINITY;
+    for (int t = tid; t <= pos; t += T) mx = fmaxf(mx, s_att[scan_slot(t)]);
+    mx = block_max(mx, red);
+    for (int t = tid; t <= pos; t += T) s_att[scan_slot(t)] = expf_glibc(s_att[scan_slot(t)] - mx);
+    __syncthreads();
+    float sum;
+    if (!seq_sum_predict<NW>(s_att, pos + 1, ps, &sum)) sum = seq_sum_exact<NW>(s_att, pos + 1, sh);
+    for (int t = tid; t <= pos; t += T) {
+        const float a = s_att[scan_slot(t)] / sum;
+        s_att[scan_slot(t)] = a;
+        if (p.att) p.att[(size_t)h * p.seq_len + t] = a;
+    }
+    // xb[i] = sum_t att[t] * v[t][i], t ascending (cpu.rs:43-49)
+    constexpr int U = 8;
+    const int tile4 = kAttTile * hs4;                             // f4 elements of a tile
+    f4 vr[U];
+    auto issue = [&](int t0) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int e = tid + u * T;
+            const int r = e / hs4, c4 = e - r * hs4;
+            const bool on = e < tile4 && t0 + r <= pos;
+            vr[u] = on ? *reinterpret_cast<const f4*>(p.vc + (size_t)(t0 + r) * p.dim + col + 4 * c4) : f4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    float acc = 0.0f;
+    issue(0);
+    for (int t0 = 0; t0 <= pos; t0 += kAttTile) {
+        __syncthreads();                                          // the previous tile has been consumed (and att is final)
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int e = tid + u * T;
+            if (e < tile4) *reinterpret_cast<f4*>(s_v + 4 * e) = vr[u];
+        }
+        __syncthreads();
+        if (t0 + kAttTile <= pos) issue(t0 + kAttTile);           // uniform
+        if (tid < hs) {
+            const int nt = min(kAttTile, pos + 1 - t0);
+            for (int r = 0; r < nt; r++) acc = acc + s_att[scan_slot(t0 + r)] * s_v[r * hs + tid];
+        }
+    }
+    if (tid < hs) p.xb[col + tid] = acc;
+}
+// the loader covers a tile with U * T 16-byte loads: kAttTile * head_size / 4 <= 8 * 64 NW
+__host__ __device__ constexpr bool attn_chain_fits(int head_size, int nw) { return kAttTile * (head_size / 4) <= 8 * 64 * nw; }
+__host__ __device__ constexpr size_t attn_chain_lds_floats(int head_size, int seq_len) {
+    return (size_t)((head_size + 3) & ~3) + (size_t)kAttTile * head_size + (size_t)seq_len + (size_t)(seq_len >> 5) + 2;
+}
+
+}  // namespace rama

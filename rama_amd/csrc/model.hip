@@ -24,7 +24,9 @@ struct rama_model {
     rama_config cfg{};
     rama_weights w{};
     float* w13i = nullptr;      // W1 | W3 row-interleaved per layer: [n_local_layers, hidden, 2, dim] (see below)
-    float* tiled = nullptr;     // every matrix once more in MFMA tile order, for the token-batch GEMMs (see below)
+    float* tiled = nullptr;     // every matrix once more in MFMA tile order, for the token-batch GEMMs (see below); made on first use
+    float* chain = nullptr;     // every matrix once more in chain order, for parity mode (chain.hpp); made on first use
+    bool tiled_tried = false, chain_tried = false;
     float* blob = nullptr;      // one allocation holding every tensor
     size_t blob_floats = 0;
     rama_stage stage{};
@@ -167,6 +169,98 @@ int make_tiled(rama_ctx* ctx, rama_model* m) {
     return 0;
 }
 
+// ---------------------------------------------------------------- chain-order weight copy
+// dst[(g * (K/16) + s) * 256 + lane * 4 + t] = src_row(16 g + lane / 4)[16 s + 4 t + lane % 4]; rows beyond
+// `rows` read as zero.  INTER: source row r is row r / 2 of w1 (r even) or of w3 (r odd) -- the
+// (W1 row i, W3 row i) pairs infer.rs:41-45 consumes together land in neighbouring quads.
+template <bool INTER>
+__global__ void chain_weights_kernel(float* dst, const float* src, const float* src2, size_t nmat, int rows, int K) {
+    const int nblk = K >> 4, groups = (rows + 15) >> 4;
+    const size_t per_dst = (size_t)groups * 16 * K, per_src = (size_t)(INTER ? rows / 2 : rows) * K;
+    const size_t n4 = nmat * per_dst / 4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t l = i / (per_dst / 4), in = i - l * (per_dst / 4);
+        const int lane = (int)(in & 63);
+        const size_t blk = in >> 6;
+        const int g = (int)(blk / nblk), s = (int)(blk - (size_t)g * nblk);
+        const int r = 16 * g + (lane >> 2), j = lane & 3;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < rows) {
+            const float* row = INTER ? ((r & 1) ? src2 : src) + l * per_src + (size_t)(r >> 1) * K
+                                     : src + l * per_src + (size_t)r * K;
+            v.x = row[16 * s + j]; v.y = row[16 * s + 4 + j]; v.z = row[16 * s + 8 + j]; v.w = row[16 * s + 12 + j];
+        }
+        *reinterpret_cast<float4*>(dst + i * 4) = v;
+    }
+}
+
+
+// registry of the chain-order copies: a row-major tensor [nmat][rows][K] (or the (w1, w3) pair, rows = 2 hidden) -> its copy
+struct ChainEntry { const float* src; const float* src2; size_t per_src; size_t nmat; int rows, K; const float* chain; };
+std::vector<ChainEntry> g_chain;
+std::mutex g_chain_mu;
+
+std::vector<rama_model*> g_models;     // every live model: lets the lazily made copies be found from a rama_weights
+std::mutex g_models_mu;
+
+int make_chain(rama_ctx* ctx, rama_model* m) {
+    if (getenv("RAMA_NO_CHAIN")) return 0;
+    const size_t nl = (size_t)(m->stage.layer_end - m->stage.layer_begin);
+    const int dim = m->cfg.dim, hidden = m->cfg.hidden_dim, V = m->cfg.vocab_size;
+    if (dim % 16 || hidden % 16) return 0;          // the reference-order fallback kernels take it
+    auto r16 = [](int r) { return (size_t)((r + 15) / 16) * 16; };
+    const bool cls = m->stage.do_cls && m->w.wcls;
+    struct T { const float* src; const float* src2; size_t nmat; int rows, K; };
+    std::vector<T> ts;
+    if (nl) {
+        if (!m->w.wq || !m->w.wk || !m->w.wv || !m->w.wo || !m->w.w1 || !m->w.w2 || !m->w.w3) return 0;
+        ts.push_back({m->w.wq, nullptr, nl, dim, dim}); ts.push_back({m->w.wk, nullptr, nl, dim, dim}); ts.push_back({m->w.wv, nullptr, nl, dim, dim});
+        ts.push_back({m->w.wo, nullptr, nl, dim, dim}); ts.push_back({m->w.w1, m->w.w3, nl, 2 * hidden, dim});
+        ts.push_back({m->w.w2, nullptr, nl, dim, hidden});
+    }
+    if (cls) ts.push_back({m->w.wcls, nullptr, 1, V, dim});
+    size_t total = 0;
+    for (const T& t : ts) total += t.nmat * r16(t.rows) * (size_t)t.K;
+    if (!total) return 0;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < total * 4 + ((size_t)16 << 30)) return 0;   // keep 16 GiB for states and scratch
+    if (rama_alloc_f32(ctx, total, &m->chain)) { m->chain = nullptr; return 0; }
+    rama_sync(ctx);
+    float* dst = m->chain;
+    std::vector<ChainEntry> mine;
+    for (const T& t : ts) {
+        if (t.src2) hipLaunchKernelGGL(chain_weights_kernel<true>, dim3(4096), dim3(256), 0, 0, dst, t.src, t.src2, t.nmat, t.rows, t.K);
+        else hipLaunchKernelGGL(chain_weights_kernel<false>, dim3(4096), dim3(256), 0, 0, dst, t.src, t.src2, t.nmat, t.rows, t.K);
+        mine.push_back({t.src, t.src2, (size_t)(t.src2 ? t.rows / 2 : t.rows) * t.K, t.nmat, t.rows, t.K, dst});
+        dst += t.nmat * r16(t.rows) * (size_t)t.K;
+    }
+    if (hipDeviceSynchronize() != hipSuccess) { rama_free(ctx, m->chain); m->chain = nullptr; return bad(RAMA_EIO, "chain-ordering the weights failed"); }
+    std::lock_guard<std::mutex> lk(g_chain_mu);
+    for (auto& e : mine) g_chain.push_back(e);
+    return 0;
+}
+
+void drop_chain(rama_ctx* ctx, rama_model* m) {
+    if (!m->chain) return;
+    {
+        std::lock_guard<std::mutex> lk(g_chain_mu);
+        const float* lo = m->chain;
+        for (size_t i = g_chain.size(); i-- > 0;)
+            if (g_chain[i].chain >= lo && (g_chain[i].src == m->w.wq || g_chain[i].src == m->w.wk || g_chain[i].src == m->w.wv || g_chain[i].src == m->w.wo ||
+                                           g_chain[i].src == m->w.w1 || g_chain[i].src == m->w.w2 || g_chain[i].src == m->w.wcls))
+                g_chain.erase(g_chain.begin() + (long)i);
+    }
+    rama_free(ctx, m->chain);
+    m->chain = nullptr;
+}
+
+// the live model that owns these weights (matched on its first layer tensor, or the classifier of a layerless stage)
+rama_model* model_of(const rama_weights* w) {
+    for (rama_model* m : g_models)
+        if ((w->wq && m->w.wq == w->wq) || (!w->wq && w->wcls && m->w.wcls == w->wcls && !m->w.wq)) return m;
+    return nullptr;
+}
+
 }  // namespace
 
 // internal: the tile-order copy of a row-major weight tensor (by its base address) a model registered, or NULL
@@ -181,6 +275,48 @@ extern "C" const float* rama_internal_w13_lookup(const float* w1, const float* w
     std::lock_guard<std::mutex> lk(g_w13_mu);
     for (auto& e : g_w13) if (e.w1 == w1 && e.w3 == w3) return e.w13i;
     return nullptr;
+}
+
+// internal: the chain-order copy of layer-aligned `a` = (a row-major [rows, K] matrix inside a registered tensor), or NULL.
+// The (w1, w3) pair is looked up by w1 with rows = 2 * hidden.
+extern "C" const float* rama_internal_chain_lookup(const float* a, int rows, int K) {
+    std::lock_guard<std::mutex> lk(g_chain_mu);
+    for (auto& e : g_chain) {
+        if (e.rows != rows || e.K != K || a < e.src) continue;
+        const size_t off = (size_t)(a - e.src);
+        if (off >= e.nmat * e.per_src || off % e.per_src) continue;
+        return e.chain + (off / e.per_src) * ((size_t)((rows + 15) / 16) * 16) * (size_t)K;
+    }
+    return nullptr;
+}
+
+// internal: make the lazily built copies of the model these weights belong to (what: 1 = chain order, 2 = tile order).
+// Never called inside a stream capture (it allocates and synchronises).  No model, or no room: nothing happens and
+// the callers' row-major kernels run.
+extern "C" int rama_internal_model_ensure(rama_ctx* ctx, const rama_weights* w, int what) {
+    if (!ctx || !w) return 0;
+    rama_model* m;
+    {
+        std::lock_guard<std::mutex> lk(g_models_mu);
+        m = model_of(w);
+        if (!m) return 0;
+        if (what == 1) { if (m->chain_tried) return 0; m->chain_tried = true; }
+        else { if (m->tiled_tried) return 0; m->tiled_tried = true; }
+    }
+    return what == 1 ? make_chain(ctx, m) : make_tiled(ctx, m);
+}
+// the same for the model whose weight blob contains `p` (the 1:1 trait ops see views, not a rama_weights)
+extern "C" int rama_internal_model_ensure_ptr(rama_ctx* ctx, const float* p, int what) {
+    if (!ctx || !p) return 0;
+    rama_weights w{};
+    {
+        std::lock_guard<std::mutex> lk(g_models_mu);
+        const rama_model* hit = nullptr;
+        for (rama_model* m : g_models) if (p >= m->blob && p < m->blob + m->blob_floats) { hit = m; break; }
+        if (!hit) return 0;
+        w = hit->w;
+    }
+    return rama_internal_model_ensure(ctx, &w, what);
 }
 
 extern "C" int rama_model_load_stage(rama_ctx* ctx, const char* path, const rama_stage* stage, rama_model** out) {
@@ -259,8 +395,14 @@ extern "C" int rama_model_load_stage(rama_ctx* ctx, const char* path, const rama
     if (c.shared_weight && st.do_cls) m->w.wcls = m->w.token_embedding_table;   // state.rs:111-117
     if (!st.do_embed && !(st.do_cls && c.shared_weight)) m->w.token_embedding_table = nullptr;
     rc = make_w13i(ctx, m);
-    if (!rc) rc = make_tiled(ctx, m);
     if (rc) { rama_free(ctx, m->blob); delete m; return rc; }
+    if (getenv("RAMA_EAGER_COPIES")) {      // the derived copies are otherwise made on first use (rama_internal_model_ensure)
+        m->tiled_tried = m->chain_tried = true;
+        rc = make_tiled(ctx, m);
+        if (!rc) rc = make_chain(ctx, m);
+        if (rc) { rama_model_free(ctx, m); return rc; }
+    }
+    { std::lock_guard<std::mutex> lk(g_models_mu); g_models.push_back(m); }
     *out = m;
     return 0;
 }
@@ -326,8 +468,14 @@ extern "C" int rama_model_synth(rama_ctx* ctx, const rama_config* cfg, uint64_t 
     if (cfg->shared_weight && st.do_cls) m->w.wcls = m->w.token_embedding_table;
     if (!st.do_embed && !(st.do_cls && cfg->shared_weight)) m->w.token_embedding_table = nullptr;
     rc = make_w13i(ctx, m);
-    if (!rc) rc = make_tiled(ctx, m);
     if (rc) { rama_free(ctx, m->blob); delete m; return rc; }
+    if (getenv("RAMA_EAGER_COPIES")) {      // the derived copies are otherwise made on first use (rama_internal_model_ensure)
+        m->tiled_tried = m->chain_tried = true;
+        rc = make_tiled(ctx, m);
+        if (!rc) rc = make_chain(ctx, m);
+        if (rc) { rama_model_free(ctx, m); return rc; }
+    }
+    { std::lock_guard<std::mutex> lk(g_models_mu); g_models.push_back(m); }
     *out = m;
     return 0;
 }
@@ -377,6 +525,8 @@ extern "C" int rama_model_weights(const rama_model* m, rama_weights* w) {
 extern "C" size_t rama_model_bytes(const rama_model* m) { return m ? m->blob_floats * sizeof(float) : 0; }
 extern "C" int rama_model_free(rama_ctx* ctx, rama_model* m) {
     if (!m) return 0;
+    { std::lock_guard<std::mutex> lk(g_models_mu); g_models.erase(std::remove(g_models.begin(), g_models.end(), m), g_models.end()); }
+    drop_chain(ctx, m);
     if (m->w13i) {
         {
             std::lock_guard<std::mutex> lk(g_w13_mu);

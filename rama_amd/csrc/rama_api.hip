@@ -7,6 +7,7 @@
 #include "prefill_attn.hpp"
 #include "prefill_mfma.hpp"
 #include "ref_order.hpp"
+#include "chain.hpp"
 #include <hipcub/hipcub.hpp>
 
 #include <hip/hip_ext.h>   // hipExtLaunchKernelGGL: start/stop events carried by the dispatch itself
@@ -22,6 +23,9 @@ using namespace rama;
 
 extern "C" const float* rama_internal_w13_lookup(const float* w1, const float* w3);   // model.hip
 extern "C" const float* rama_internal_tiled_lookup(const float* src);                    // model.hip
+extern "C" const float* rama_internal_chain_lookup(const float* a, int rows, int K);     // model.hip
+extern "C" int rama_internal_model_ensure(rama_ctx* ctx, const rama_weights* w, int what);       // model.hip: 1 = chain order, 2 = tile order
+extern "C" int rama_internal_model_ensure_ptr(rama_ctx* ctx, const float* p, int what);
 
 // ---------------------------------------------------------------- error plumbing
 
@@ -88,7 +92,9 @@ struct rama_ctx {
     int tune_geom = 3;
     int tune_w13i = 1;                     // 1: the fused W1|W3 launch streams the model's row-interleaved copy when there is one
     int tune_solo = -1;                    // small-K matvecs, one wave per row group: 1 on, 0 off, -1 = rows of <= 2048 floats
-    int tune_ref_order = 0;                // 1: every op in the reference's own rounding order (ref_order.hpp): bit-comparable, slow
+    int tune_ref_order = 0;                // 1: every op in the reference's own rounding order: bit-comparable with the CPU path ("parity mode")
+    int tune_chain = 1;                    // parity mode streams the model's chain-order weight copy (chain.hpp); 0: ref_order.hpp's one-thread-per-row kernels
+    int tune_chain_d = 0;                  // chain-order matvec geometry: 0 = by row groups per CU, else 100 W + D (waves per group, blocks per wave in flight)
     // device top-p sampler (Device::sample for temperature != 0); temperature 0 = argmax
     float samp_T = 0.0f, samp_topp = 0.9f, samp_u = 0.0f;
     float* topp_keys[2] = {nullptr, nullptr}; int* topp_vals[2] = {nullptr, nullptr};
@@ -141,6 +147,17 @@ extern "C" void rama_internal_topp_scratch(rama_ctx* c, float** keys, int** vals
     if (vals) *vals = c->topp_vals[1];
     if (prefix) *prefix = c->topp_prefix;
     if (m) *m = c->topp_m;
+}
+
+// diagnostics (not in the C ABI header): how often the one-pass exact sum (chain.hpp seq_sum_predict) held / fell back
+extern "C" int rama_internal_pred_stats(rama_ctx* c, unsigned* held, unsigned* fell_back, int reset) {
+    unsigned h[2] = {0, 0};
+    hipStreamSynchronize(c->stream);
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(rama::g_pred_stats), sizeof h) != hipSuccess) return 1;
+    if (held) *held = h[0];
+    if (fell_back) *fell_back = h[1];
+    if (reset) { const unsigned z[2] = {0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rama::g_pred_stats), z, sizeof z) != hipSuccess) return 1; }
+    return 0;
 }
 
 int rama_ctx_create(int device, void* hip_stream, rama_ctx** out) {
@@ -388,6 +405,65 @@ static int launch_attention_ref(rama_ctx* c, float* xb, float* att, const float*
     return 0;
 }
 
+// ---------------------------------------------------------------- parity mode at streaming speed (chain.hpp)
+
+// W waves per 16 rows, D blocks per wave in flight: by how many row groups share a CU (few groups -> more waves
+// and deeper rings per group, so that >= ~128 KiB per CU are on the way); tune_chain_d = 100 W + D overrides
+template <int EPI>
+static int launch_chain(rama_ctx* c, ChainParams& p) {
+    REQUIRE(p.K % 16 == 0 && p.K > 0 && p.rows > 0, RAMA_EINVAL, "chain-order matvec: width must be a multiple of 16");
+    const int groups = p.nmat * ((p.rows + 15) / 16);
+    int W, D;
+    if (c->tune_chain_d > 0) { W = c->tune_chain_d / 100; D = c->tune_chain_d % 100; }
+    else {
+        const int cus = std::max(c->cu_count, 1);
+        if (groups >= 5 * cus) { W = 1; D = 16; }   // W1 | W3, classifier: several groups per SIMD, each with its own ring
+        else { W = 2; D = 16; }                     // one to three groups per CU (tools/chain_sweep.py: 216 best or equal everywhere)
+        if (p.K / 16 <= 2 * D) { W = 1; D = 16; }   // a row of a few blocks: nothing to relay
+    }
+    if ((size_t)(p.K + chain_pad_floats(W, D, 4)) * sizeof(float) > 64 * 1024) { W = 1; D = 16; }
+    const size_t lds = (size_t)(p.K + chain_pad_floats(W, D, 4)) * sizeof(float);      // x + the zeros behind it
+    REQUIRE(lds <= 64 * 1024, RAMA_EUNSUP, "chain-order matvec: row longer than ~15800 floats");
+    const dim3 grid(groups);
+#define RAMA_CHAIN(W_, D_) RAMA_LAUNCH(c, (gemv_chain_kernel<W_, D_, 4, EPI>), grid, dim3(W_ * 64), lds, p)
+    if (W == 1 && D == 16) RAMA_CHAIN(1, 16);
+    else if (W == 1 && D == 32) RAMA_CHAIN(1, 32);
+    else if (W == 2 && D == 16) RAMA_CHAIN(2, 16);
+    else if (W == 2 && D == 32) RAMA_CHAIN(2, 32);
+
+    else if (W == 4 && D == 16) RAMA_CHAIN(4, 16);
+    else if (W == 4 && D == 32) RAMA_CHAIN(4, 32);
+    else return fail(RAMA_EINVAL, "chain-order matvec: no such geometry", __FILE__, __LINE__);
+#undef RAMA_CHAIN
+    LAUNCHCHK();
+    return 0;
+}
+static bool rmsnorm_chain_ok(size_t n) { return n <= (size_t)kNormMax && (n + (n >> 5) + 2) * sizeof(float) <= 64 * 1024; }
+static int launch_rmsnorm_chain(rama_ctx* c, float* o, const float* x, const float* w, int n, float* copy_to) {
+    const size_t lds = ((size_t)n + ((size_t)n >> 5) + 2) * sizeof(float);
+    hipLaunchKernelGGL(rmsnorm_chain_kernel, dim3(1), dim3(kNormThreads), lds, c->stream, o, x, w, n, copy_to);
+    LAUNCHCHK();
+    return 0;
+}
+static int attn_chain_waves(int head_size) { return attn_chain_fits(head_size, 4) ? 4 : (attn_chain_fits(head_size, 8) ? 8 : 16); }
+static bool attn_chain_ok(int head_size, int seq_len) {
+    return head_size % 4 == 0 && attn_chain_fits(head_size, 16) && attn_chain_lds_floats(head_size, seq_len) * sizeof(float) <= 64 * 1024;
+}
+static int launch_attention_chain(rama_ctx* c, float* xb, float* att, const float* q, const float* kc_layer, const float* vc_layer,
+                                  const Ctl* ctl, int pos, int dim, int head_size, int seq_len, int n_heads) {
+    REQUIRE(aligned16(q) && aligned16(kc_layer) && aligned16(vc_layer) && dim % 4 == 0, RAMA_EINVAL, "attention: buffers must be 16-byte aligned");
+    RefAttnParams p{};
+    p.q = q; p.kc = kc_layer; p.vc = vc_layer; p.att = att; p.xb = xb; p.ctl = ctl; p.pos_val = pos;
+    p.dim = dim; p.head_size = head_size; p.seq_len = seq_len;
+    const size_t lds = attn_chain_lds_floats(head_size, seq_len) * sizeof(float);
+    const int nw = attn_chain_waves(head_size);
+    if (nw == 4) RAMA_LAUNCH(c, (attention_chain_kernel<4>), dim3(n_heads), dim3(256), lds, p);
+    else if (nw == 8) RAMA_LAUNCH(c, (attention_chain_kernel<8>), dim3(n_heads), dim3(512), lds, p);
+    else RAMA_LAUNCH(c, (attention_chain_kernel<16>), dim3(n_heads), dim3(1024), lds, p);
+    LAUNCHCHK();
+    return 0;
+}
+
 // ---------------------------------------------------------------- Device<T> ops, 1:1
 
 int rama_array_add(rama_ctx* c, float* t, const float* s, size_t n) {
@@ -417,7 +493,7 @@ int rama_copy_from_slice(rama_ctx* c, float* t, const float* s, size_t n) {
 }
 int rama_rmsnorm(rama_ctx* c, float* o, const float* x, const float* w, size_t n) {
     REQUIRE(c && o && x && w && n > 0, RAMA_EINVAL, "rmsnorm: bad argument");
-    if (c->tune_ref_order) return launch_rmsnorm_ref(c, o, x, w, (int)n);
+    if (c->tune_ref_order) return c->tune_chain && rmsnorm_chain_ok(n) ? launch_rmsnorm_chain(c, o, x, w, (int)n, nullptr) : launch_rmsnorm_ref(c, o, x, w, (int)n);
     hipLaunchKernelGGL(rmsnorm_kernel, dim3(1), dim3(1024), 0, c->stream, o, x, w, (int)n);
     LAUNCHCHK(); return 0;
 }
@@ -437,7 +513,18 @@ int rama_matmul(rama_ctx* c, float* o, const float* a, const float* b, size_t wi
     REQUIRE(o_cols >= 1, RAMA_EINVAL, "matmul: o_cols == 0");
     int rc = check_matvec_shape(width, o_rows);
     if (rc) return rc;
-    if (c->tune_ref_order && o_cols == 1) return launch_matvec_ref1(c, o, a, b, (int)width, (int)o_rows);
+    if (c->tune_ref_order && o_cols == 1) {
+        // a layer-aligned view of a resident model's matrix streams the model's chain-order copy
+        if (c->tune_chain && width % 16 == 0 && width <= 16000 && aligned16(b)) {
+            rc = rama_internal_model_ensure_ptr(c, a, 1); if (rc) return rc;
+            if (const float* ch = rama_internal_chain_lookup(a, (int)o_rows, (int)width)) {
+                ChainParams p{};
+                p.w[0] = ch; p.o[0] = o; p.x = b; p.K = (int)width; p.rows = (int)o_rows; p.nmat = 1;
+                return launch_chain<CEPI_STORE>(c, p);
+            }
+        }
+        return launch_matvec_ref1(c, o, a, b, (int)width, (int)o_rows);
+    }
     if (o_cols != 1) {   // forward() never takes this path (o_cols is always 1, infer.rs:20-51)
         size_t n = o_rows * o_cols;
         hipLaunchKernelGGL(matmul_generic, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, o, a, b, (int)width, (int)o_rows, (int)o_cols);
@@ -451,6 +538,10 @@ int rama_matmul(rama_ctx* c, float* o, const float* a, const float* b, size_t wi
 }
 int rama_softmax(rama_ctx* c, float* x, size_t n) {
     REQUIRE(c && x && n > 0, RAMA_EINVAL, "softmax: bad argument");
+    if (c->tune_ref_order && c->tune_chain && rmsnorm_chain_ok(n)) {
+        hipLaunchKernelGGL(softmax_chain_kernel, dim3(1), dim3(kNormThreads), (n + (n >> 5) + 2) * sizeof(float), c->stream, x, (int)n);
+        LAUNCHCHK(); return 0;
+    }
     if (c->tune_ref_order) { hipLaunchKernelGGL(softmax_ref_kernel, dim3(1), dim3(1024), 0, c->stream, x, (int)n); LAUNCHCHK(); return 0; }
     hipLaunchKernelGGL(softmax_kernel, dim3(1), dim3(1024), 0, c->stream, x, (int)n);
     LAUNCHCHK(); return 0;
@@ -577,6 +668,8 @@ int rama_multi_head_attention(rama_ctx* c, float* xb, float* att, const float* q
     REQUIRE(c && xb && att && q && key_cache && value_cache, RAMA_EINVAL, "multi_head_attention: NULL argument");
     REQUIRE(pos >= 0 && pos < seq_len && layer >= 0 && n_heads > 0 && n_heads * head_size == dim, RAMA_EINVAL, "multi_head_attention: bad shape");
     const size_t lo = (size_t)layer * seq_len * dim;   // cpu.rs:28
+    if (c->tune_ref_order && c->tune_chain && attn_chain_ok(head_size, seq_len) && aligned16(q) && aligned16(key_cache + lo) && aligned16(value_cache + lo) && dim % 4 == 0)
+        return launch_attention_chain(c, xb, att, q, key_cache + lo, value_cache + lo, nullptr, pos, dim, head_size, seq_len, n_heads);
     if (c->tune_ref_order) return launch_attention_ref(c, xb, att, q, key_cache + lo, value_cache + lo, nullptr, pos, dim, head_size, seq_len, n_heads);
     c->small_attn = small_attn_at(c, pos, false, dim);
     return launch_attention(c, xb, att, q, key_cache + lo, value_cache + lo, nullptr, pos, dim, head_size, seq_len, n_heads);
@@ -727,10 +820,85 @@ static int enqueue_stage_ref(rama_ctx* c, const rama_config* cfg, const rama_wei
     return 0;
 }
 
+// the same (every RunState buffer as the CPU path leaves it, bit for bit) on the model's chain-order weight
+// copies: 7 launches per layer.  Returns false when a copy is missing (weights uploaded tensor by tensor,
+// widths that are not whole 16-float blocks, no memory for the copy): the caller takes enqueue_stage_ref.
+static int enqueue_stage_chain(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s, const rama_stage* st, bool* done) {
+    *done = false;
+    const int dim = cfg->dim, hidden = cfg->hidden_dim, hs = dim / cfg->n_heads, V = cfg->vocab_size;
+    if (!c->tune_chain || dim % 16 || hidden % 16 || dim > 16000 || hidden > 16000 || !attn_chain_ok(hs, cfg->seq_len)) return 0;
+    const bool layers = st->layer_end > st->layer_begin;
+    const float *cq = nullptr, *ck = nullptr, *cv = nullptr, *co = nullptr, *c13 = nullptr, *c2 = nullptr, *ccls = nullptr;
+    if (layers) {
+        cq = rama_internal_chain_lookup(w->wq, dim, dim); ck = rama_internal_chain_lookup(w->wk, dim, dim);
+        cv = rama_internal_chain_lookup(w->wv, dim, dim); co = rama_internal_chain_lookup(w->wo, dim, dim);
+        c13 = rama_internal_chain_lookup(w->w1, 2 * hidden, dim); c2 = rama_internal_chain_lookup(w->w2, dim, hidden);
+        if (!cq || !ck || !cv || !co || !c13 || !c2) return 0;
+    }
+    if (st->do_cls) { ccls = rama_internal_chain_lookup(w->wcls, V, dim); if (!ccls) return 0; }
+    REQUIRE(s->xb2 && s->hb2 && s->k && s->v, RAMA_EINVAL, "forward (reference order): xb2 / hb2 / k / v buffers are required");
+    *done = true;
+    const size_t dd = (size_t)dim * dim, hd = (size_t)hidden * dim;                 // chain-order copies keep the row-major sizes (rows are multiples of 16)
+    int rc;
+    if (st->do_embed) {
+        hipLaunchKernelGGL(embed_kernel, dim3((dim + 255) / 256), dim3(256), 0, c->stream, s->x, w->token_embedding_table, (const Ctl*)c->ctl, 0, dim);
+        LAUNCHCHK();
+    }
+    for (int layer = st->layer_begin; layer < st->layer_end; layer++) {
+        const size_t li = (size_t)(layer - st->layer_begin);
+        float* kc = s->key_cache + li * cfg->seq_len * dim;
+        float* vc = s->value_cache + li * cfg->seq_len * dim;
+        rc = launch_rmsnorm_chain(c, s->xb, s->x, w->rms_att_weight + li * dim, dim, nullptr); if (rc) return rc;       // infer.rs:19
+        {   // :20-33: Wq | Wk | Wv, RoPE, cache append
+            KTimer kt(c, RAMA_K_QKV);
+            ChainParams p{};
+            p.w[0] = cq + li * dd; p.w[1] = ck + li * dd; p.w[2] = cv + li * dd;
+            p.o[0] = s->q; p.o[1] = s->k; p.o[2] = s->v; p.x = s->xb; p.K = dim; p.rows = dim; p.nmat = 3;
+            p.ctl = c->ctl; p.fr = w->freq_cis_real; p.fi = w->freq_cis_imag; p.head_size = hs; p.kc = kc; p.vc = vc;
+            rc = launch_chain<CEPI_QKV>(c, p); if (rc) return rc;
+        }
+        {   // :34
+            KTimer kt(c, RAMA_K_ATTN);
+            rc = launch_attention_chain(c, s->xb, s->att, s->q, kc, vc, c->ctl, 0, dim, hs, cfg->seq_len, cfg->n_heads); if (rc) return rc;
+        }
+        {   // :35-37: xb2 = Wo . xb; x += xb2
+            KTimer kt(c, RAMA_K_WO);
+            ChainParams p{};
+            p.w[0] = co + li * dd; p.o[0] = s->xb2; p.resid = s->x; p.x = s->xb; p.K = dim; p.rows = dim; p.nmat = 1;
+            rc = launch_chain<CEPI_RESID>(c, p); if (rc) return rc;
+        }
+        rc = launch_rmsnorm_chain(c, s->xb, s->x, w->rms_ffn_weight + li * dim, dim, nullptr); if (rc) return rc;        // :39
+        {   // :41-45: hb = silu(W1 . xb) * (hb2 = W3 . xb)
+            KTimer kt(c, RAMA_K_W13);
+            ChainParams p{};
+            p.w[0] = c13 + li * 2 * hd; p.o[0] = s->hb; p.o[1] = s->hb2; p.x = s->xb; p.K = dim; p.rows = 2 * hidden; p.nmat = 1;
+            rc = launch_chain<CEPI_SWIGLU>(c, p); if (rc) return rc;
+        }
+        {   // :46-47: xb = W2 . hb; x += xb
+            KTimer kt(c, RAMA_K_W2);
+            ChainParams p{};
+            p.w[0] = c2 + li * hd; p.o[0] = s->xb; p.resid = s->x; p.x = s->hb; p.K = hidden; p.rows = dim; p.nmat = 1;
+            rc = launch_chain<CEPI_RESID>(c, p); if (rc) return rc;
+        }
+    }
+    if (st->do_cls) {   // :49-51: xb = x; x = rmsnorm(xb); logits = Wcls . x
+        rc = launch_rmsnorm_chain(c, s->x, s->x, w->rms_final_weight, dim, s->xb); if (rc) return rc;
+        KTimer kt(c, RAMA_K_CLS);
+        ChainParams p{};
+        p.w[0] = ccls; p.o[0] = s->logits; p.x = s->x; p.K = dim; p.rows = V; p.nmat = 1;
+        rc = launch_chain<CEPI_STORE>(c, p); if (rc) return rc;
+    }
+    return 0;
+}
+
 // one (token, pos) step over a layer range; ctl on the device holds token/pos
 static int enqueue_stage(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s,
                          const rama_stage* st) {
-    if (c->tune_ref_order) return enqueue_stage_ref(c, cfg, w, s, st);
+    if (c->tune_ref_order) {
+        bool done = false;
+        const int rc = enqueue_stage_chain(c, cfg, w, s, st, &done);
+        return done ? rc : (rc ? rc : enqueue_stage_ref(c, cfg, w, s, st));
+    }
     const int dim = cfg->dim, hidden = cfg->hidden_dim, hs = dim / cfg->n_heads;
     const size_t dd = (size_t)dim * dim, hd = (size_t)hidden * dim;
     const float* w13i = (st->layer_end > st->layer_begin && (double)hidden * dim * 8.0 < 2147483648.0) ? rama_internal_w13_lookup(w->w1, w->w3) : nullptr;
@@ -880,6 +1048,7 @@ int rama_forward_stage(rama_ctx* c, const rama_config* cfg, const rama_weights* 
     REQUIRE(pos >= 0 && pos < cfg->seq_len, RAMA_EINVAL, "forward: pos outside [0, seq_len)");
     REQUIRE(token >= 0 && token < cfg->vocab_size, RAMA_EINVAL, "forward: token outside the vocabulary");
     rc = ensure_attn_part(c, cfg); if (rc) return rc;
+    if (c->tune_ref_order && c->tune_chain) { rc = rama_internal_model_ensure(c, w, 1); if (rc) return rc; }
     hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(1), 0, c->stream, c->ctl, token, pos, 0, 0);
     LAUNCHCHK();
     c->embedded_x = nullptr;
@@ -899,6 +1068,7 @@ int rama_forward_stage_devtok(rama_ctx* c, const rama_config* cfg, const rama_we
     REQUIRE(pos >= 0 && pos < cfg->seq_len, RAMA_EINVAL, "forward: pos outside [0, seq_len)");
     REQUIRE(token_dev || !st->do_embed, RAMA_EINVAL, "forward: an embedding stage needs a token");
     rc = ensure_attn_part(c, cfg); if (rc) return rc;
+    if (c->tune_ref_order && c->tune_chain) { rc = rama_internal_model_ensure(c, w, 1); if (rc) return rc; }
     hipLaunchKernelGGL(set_ctl_dev_kernel, dim3(1), dim3(1), 0, c->stream, c->ctl, (const int*)token_dev, pos, cfg->vocab_size);
     LAUNCHCHK();
     c->embedded_x = nullptr;
@@ -1203,6 +1373,7 @@ int rama_prefill(rama_ctx* c, const rama_config* cfg, const rama_weights* w, ram
         return 0;
     }
     BatchScratch b{};
+    if (c->tune_tiled) { rc = rama_internal_model_ensure(c, w, 2); if (rc) return rc; }
     rc = ensure_batch_scratch(c, cfg, false, &b); if (rc) return rc;
     c->embedded_x = nullptr; c->host_pos = -1;
     int last_nt = 0, nslab = 0;
@@ -1255,6 +1426,7 @@ int rama_decode_batch(rama_ctx* c, const rama_config* cfg, const rama_weights* w
         return 0;
     }
     BatchScratch b{};
+    if (c->tune_tiled) { rc = rama_internal_model_ensure(c, w, 2); if (rc) return rc; }
     rc = ensure_batch_scratch(c, cfg, true, &b); if (rc) return rc;
     c->embedded_x = nullptr; c->host_pos = -1;
     // ids and the sequence table go through pinned staging (the source arrays are the caller's / locals)
@@ -1332,6 +1504,7 @@ int rama_decode_steps(rama_ctx* c, const rama_config* cfg, const rama_weights* w
     }
     REQUIRE(c->host_pos >= 0, RAMA_EINVAL, "decode_steps: call rama_decode_begin first");
     rc = ensure_attn_part(c, cfg); if (rc) return rc;
+    if (c->tune_ref_order && c->tune_chain) { rc = rama_internal_model_ensure(c, w, 1); if (rc) return rc; }
     if (c->samp_T != 0.0f) { rc = ensure_topp_scratch(c, cfg->vocab_size); if (rc) return rc; }
     REQUIRE(c->host_pos + n_steps <= cfg->seq_len, RAMA_EINVAL, "decode_steps: would run past seq_len");
     const bool graphs = c->graph_mode && c->kp.kernel_id < 0;
@@ -1568,6 +1741,14 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
     if (!strcmp(key, "ref_order")) {
         REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: ref_order must be 0 or 1");
         c->tune_ref_order = value;
+        hipStreamSynchronize(c->stream);
+        drop_graph(c);
+        return 0;
+    }
+    if (!strcmp(key, "chain") || !strcmp(key, "chain_d")) {
+        const bool cd = !strcmp(key, "chain_d");
+        REQUIRE(cd ? (value == 0 || (value >= 116 && value <= 432)) : (value == 0 || value == 1), RAMA_EINVAL, "set_tuning: chain must be 0 or 1, chain_d 0 or 100 W + D");
+        if (cd) c->tune_chain_d = value; else c->tune_chain = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
         return 0;

@@ -206,3 +206,122 @@ def test_full_shape_logits_bit_exact(dev, shape):
     eng2 = rama_amd.Engine(dev, model)
     assert eng2.generate_greedy(prompt, steps) == O.Oracle(cfg, w).generate_greedy(prompt, steps)
     eng.free(); eng2.free(); model.free()
+
+
+# ------------------------------------------------------------------ parity mode on a RESIDENT MODEL: chain-order weights (csrc/chain.hpp)
+
+def _engine_buf(eng, name, n):
+    return eng.buffer(name, n)
+
+
+@pytest.mark.parametrize("name", CKPT_CASES + SYNTH_CASES)
+def test_model_forward_every_buffer_bit_exact(dev, name, tmp_path):
+    """a resident model (rama_model_load / rama_model_synth) runs parity mode on its chain-order weight
+    copy -- one lane per (row, k mod 4) chain, the exact scan for the sequential sums: every RunState
+    buffer must still be the oracle's, bit for bit, and identical to the one-thread-per-row kernels'"""
+    import rama_amd
+    from .helpers import GOLDEN, to_rama_cfg
+    cfg, w, g = load_case(name)
+    toks = g["tokens"].tolist()[:10]
+    orc = O.Oracle(cfg, w)
+    if name.startswith("ckpt_"):
+        model = rama_amd.Model.load(dev, GOLDEN / f"{name}.bin")
+    else:
+        model = rama_amd.Model.synth(dev, to_rama_cfg(cfg), int(g["seed"]), rope=(g["freq_cis_real"], g["freq_cis_imag"]))
+    eng = rama_amd.Engine(dev, model)
+    sizes = dict(x=cfg.dim, xb=cfg.dim, xb2=cfg.dim, hb=cfg.hidden_dim, hb2=cfg.hidden_dim, q=cfg.dim, k=cfg.dim, v=cfg.dim,
+                 logits=cfg.vocab_size, key_cache=cfg.n_layers * cfg.seq_len * cfg.dim, value_cache=cfg.n_layers * cfg.seq_len * cfg.dim)
+    for pos, t in enumerate(toks):
+        orc.forward(t, pos)
+        eng.forward(t, pos)
+        for buf, n in sizes.items():
+            assert_bits_equal(eng.buffer(buf, n), orc.s[buf], f"{name} model pos {pos} {buf}")
+        att = eng.buffer("att", cfg.n_heads * cfg.seq_len).reshape(cfg.n_heads, cfg.seq_len)[:, :pos + 1]
+        assert_bits_equal(att, orc.s["att"].reshape(cfg.n_heads, cfg.seq_len)[:, :pos + 1], f"{name} model pos {pos} att")
+    # the same positions without the chain-order copy (ref_order.hpp's kernels) give the same bits
+    eng.set_tuning("chain", 0)
+    try:
+        eng2 = rama_amd.Engine(dev, model)
+        for pos, t in enumerate(toks):
+            eng2.forward(t, pos)
+        for buf, n in sizes.items():
+            assert_bits_equal(eng2.buffer(buf, n), orc.s[buf], f"{name} model (chain off) {buf}")
+        eng2.free()
+    finally:
+        eng.set_tuning("chain", 1)
+    eng.free(); model.free()
+
+
+@pytest.mark.parametrize("dim,hidden,heads,vocab,seq", [(48, 80, 3, 50, 40), (144, 400, 3, 100, 70), (16, 16, 1, 17, 8), (272, 720, 17, 333, 64)])
+def test_model_ragged_shapes_bit_exact(dev, dim, hidden, heads, vocab, seq):
+    """row counts that are not multiples of 16 (padded chain groups), widths of a few 16-float blocks
+    (shorter than the load ring), odd head counts: logits and caches bit for bit over a short generation"""
+    import rama_amd
+    from .helpers import to_rama_cfg
+    cfg = O.Config(dim, hidden, 2, heads, heads, vocab, seq, False)
+    rope = S.rope_tables(seq, dim // heads)
+    w = S.synth_weights(cfg, 3, rope=rope)
+    orc = O.Oracle(cfg, w)
+    model = rama_amd.Model.synth(dev, to_rama_cfg(cfg), 3, rope=rope)
+    eng = rama_amd.Engine(dev, model)
+    token = 1
+    for pos in range(min(seq, 12)):
+        lo = orc.forward(token, pos)
+        eng.forward(token, pos)
+        assert_bits_equal(eng.logits(), lo, f"ragged pos {pos} logits")
+        assert_bits_equal(eng.buffer("key_cache", 2 * seq * dim), orc.s["key_cache"], f"ragged pos {pos} key_cache")
+        assert_bits_equal(eng.buffer("hb", hidden), orc.s["hb"], f"ragged pos {pos} hb")
+        token = O.argmax(lo)
+    eng.free(); model.free()
+
+
+def test_model_matmul_views_take_the_chain_copy(dev):
+    """Device::matmul on a layer-aligned view of a resident model's tensor streams the chain-order copy;
+    any other view (row offset, fewer rows) takes the row-major kernel: same bits either way"""
+    import rama_amd
+    from rama_amd._lib import check
+    from .helpers import to_rama_cfg
+    cfg = O.Config(64, 176, 3, 4, 4, 96, 16, False)
+    rope = S.rope_tables(cfg.seq_len, cfg.head_size)
+    w = S.synth_weights(cfg, 5, rope=rope)
+    model = rama_amd.Model.synth(dev, to_rama_cfg(cfg), 5, rope=rope)
+    x = rnd(cfg.dim, 9, 1.5); xh = rnd(cfg.hidden_dim, 10, 1.5)
+    tx = up(dev, x); txh = up(dev, xh)
+    cases = [("wq", 1, cfg.dim, cfg.dim, 0, x, tx), ("wo", 2, cfg.dim, cfg.dim, 0, x, tx), ("w1", 1, cfg.hidden_dim, cfg.dim, 0, x, tx),
+             ("w2", 2, cfg.dim, cfg.hidden_dim, 0, xh, txh), ("wcls", 0, cfg.vocab_size, cfg.dim, 0, x, tx),
+             ("wk", 1, cfg.dim - 8, cfg.dim, 8, x, tx)]      # the last one starts 8 rows into the layer: not chain-aligned
+    for name, layer, rows, K, row0, xv, txv in cases:
+        full = w[name].reshape(-1)
+        per = (cfg.vocab_size if name == "wcls" else (cfg.hidden_dim if name in ("w1", "w3") else cfg.dim)) * K
+        off = layer * per + row0 * K
+        want = np.empty(rows, np.float32)
+        O.matmul(want, np.ascontiguousarray(full[off:off + rows * K]), xv, K, rows)
+        to = up(dev, np.zeros(rows, np.float32))
+        a_ptr = getattr(model.weights, name) + 4 * off
+        check(dev.lib.rama_matmul(dev.ctx, to.ptr, a_ptr, txv.ptr, K, rows, 1))
+        assert_bits_equal(dev.download(to), want, f"matmul view {name} layer {layer} row0 {row0}")
+    model.free()
+
+
+@pytest.mark.parametrize("n,scale", [(1, 1.0), (63, 1.0), (64, 1.0), (65, 3.0), (1000, 0.01), (4096, 1.0), (4097, 50.0), (11008, 1.0), (16384, 1e-3)])
+def test_exact_sequential_sums(dev, n, scale):
+    """rmsnorm's sum of squares and softmax's sum of exponentials are sequential fp32 sums in the
+    reference (Iterator::sum, cpu.rs:112; the oracle's softmax order): the parallel scan must give the
+    sequential bits for every length, magnitude and structure (ties, powers of two, zeros, spikes)"""
+    rng = np.random.default_rng(n)
+    variants = [rnd(n, n, scale), np.full(n, scale, np.float32), (2.0 ** rng.integers(-6, 6, n)).astype(np.float32) * np.float32(scale),
+                np.where(rng.random(n) < 0.5, 0.0, scale).astype(np.float32)]
+    spike = rnd(n, n + 1, scale); spike[n // 2] = np.float32(1000.0 * scale); variants.append(spike)
+    grow = (np.arange(1, n + 1, dtype=np.float32) * np.float32(scale / n)); variants.append(grow)
+    for vi, x in enumerate(variants):
+        w = rnd(n, 7)
+        want = np.empty(n, np.float32)
+        O.rmsnorm(want, x, w, n)
+        tx = up(dev, x); tw = up(dev, w); to = up(dev, np.zeros(n, np.float32))
+        dev.rmsnorm(to, tx.as_view(), tw.as_view(), n)
+        assert_bits_equal(dev.download(to), want, f"rmsnorm n={n} variant {vi}")
+        s = (x * np.float32(4.0 / max(scale, 1e-6))).astype(np.float32)
+        ts = up(dev, s)
+        dev.softmax(ts, n)
+        O.softmax(s, n)
+        assert_bits_equal(dev.download(ts), s, f"softmax n={n} variant {vi}")

@@ -1,0 +1,34 @@
+// seqsum_bench.hip -- times rmsnorm_chain_kernel (csrc/chain.hpp: the exact sequential sum of squares) and prints where
+// its time goes.  Not part of the product.  Build: hipcc --offload-arch=gfx950 -O3 -DRAMA_SEQ_STAMPS -o seqsum_bench seqsum_bench.hip
+#include "../rama_amd/csrc/chain.hpp"
+#include <cstdio>
+#include <vector>
+#include <random>
+using namespace rama;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+int main(int argc, char** argv) {
+    const int n = argc > 1 ? atoi(argv[1]) : 4096;
+    std::mt19937 rng(1); std::normal_distribution<float> nd(0.f, 1.f);
+    std::vector<float> x(n), w(n, 1.0f);
+    for (auto& v : x) v = nd(rng);
+    float *dx, *dw, *dout;
+    CK(hipMalloc(&dx, n * 4)); CK(hipMalloc(&dw, n * 4)); CK(hipMalloc(&dout, n * 4));
+    CK(hipMemcpy(dx, x.data(), n * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dw, w.data(), n * 4, hipMemcpyHostToDevice));
+    const size_t lds = ((size_t)n + (n >> 5) + 2) * 4;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 3; rep++) {
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < 200; i++) hipLaunchKernelGGL(rmsnorm_chain_kernel, dim3(1), dim3(kNormThreads), lds, 0, dout, dx, dw, n, (float*)nullptr);
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("n=%d rmsnorm_chain_kernel: %.2f us per launch (back to back)\n", n, ms * 1e3 / 200);
+    }
+    unsigned long long st[16];
+    CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(rama::g_seq_stamps), sizeof st));
+    const char* names[] = {"load+squares+barrier", "approx prefix", "classify", "maps", "seg scan + barrier", "walk + barrier", "scale + store"};
+    for (int i = 0; i < 6; i++) printf("  %-22s %6.2f us\n", names[i], (double)(st[i + 1] - st[i]) * 0.01);
+    printf("  debug: nseq %llu smask %016llx %016llx %016llx %016llx head %g\n", st[8], st[9], st[10], st[11], st[12], *(float*)&st[15]);
+    unsigned ps[2]; CK(hipMemcpyFromSymbol(ps, HIP_SYMBOL(rama::g_pred_stats), sizeof ps));
+    printf("  held %u fell back %u\n", ps[0], ps[1]);
+    return 0;
+}
