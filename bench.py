@@ -2,24 +2,31 @@
 """bench.py -- decode throughput of the HIP path on llama2-7B-shaped synthetic fp32 weights.
 
   python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N ...          (N > 1 without a launcher: this script starts the N ranks itself)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 N = 1: one decode step = one forward() (infer.rs:8-53) + greedy sample, chained on the device,
-starting at pos 0 like generate() (BOS, then the Rama-BPE ids of 'once upon a time').
-N > 1: the layer stack is pipeline-sharded over the N ranks (rank r owns layers
-[r*L/N, (r+1)*L/N)) with N sequences in flight; a step advances every sequence by one
-token; the residual x[dim] travels rank r -> r+1 and the sampled token id last -> first over
-RCCL point-to-point (rama_amd/pipeline.py).
+starting at pos 0 like generate() (BOS, then the Rama-BPE ids of 'once upon a time').  Two modes of
+the SAME entry points are timed in one run:
+  * parity mode (`value`): every op in the reference CPU path's own rounding order, on the model's
+    chain-order weight copy (csrc/chain.hpp) -- logits bit-identical to engine/src/device/cpu.rs;
+  * fast mode (`fast_mode`): fused multiply-adds and tree-shaped sums (csrc/kernels.hpp) -- closer to
+    the exact logits than the reference itself, but up to 1.5e-4 from it at full depth.
+Then stories15M / stories110M (BASELINE.json configs 2-3) in both modes (`other_configs`).
+N > 1: the layer stack is pipeline-sharded over the N ranks with N sequences in flight; a step advances
+every sequence by one token (rama_amd/pipeline.py, csrc/pipe.hip).
 
-Prints ONE JSON line (see the driver contract): whole-job tokens/s, plus `roofline` for the
-dominant kernel (W1|W3 SwiGLU matvec, 43 % of the bytes) and `cpu_baseline` (the oracle --
-the C restatement of the reference CPU path -- timed on the host cores, rank 0, N = 1 only).
+Prints ONE JSON line (see the driver contract): whole-job tokens/s, `roofline` for the dominant kernel
+(W1|W3 SwiGLU matvec, 43 % of the bytes) and `cpu_baseline` (the oracle -- the C restatement of the
+reference CPU path -- timed at full depth on the host cores, rank 0, N = 1 only).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -34,26 +41,28 @@ SHAPES = {   # dim, hidden, layers, heads, vocab, seq_len, 
 }
 PROMPT = [10646, 2501, 263, 931]   # Rama-BPE of 'once upon a time' 
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+METRIC_1GPU = "tokens/sec decode + matvec achieved-HBM-GB/s vs roofline, llama2-7B fp32 1xMI355X"
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--config", default="llama2-7B", choices=list(SHAPES))
     ap.add_argument("--graph", type=int, default=1, help="replay each decode step from a hipGraph")
+    ap.add_argument("--mode", default="both", choices=["both", "parity", "fast"],
+                    help="parity: the reference's rounding order (bit-identical logits; the headline); fast: fused/tree sums")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kprof", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the stories15M / stories110M lines")
     ap.add_argument("--no-placement-tuning", action="store_true", help="accepted and ignored (round-1 flag: the tuner is gone)")
     ap.add_argument("--pos0", type=int, default=0,
                     help="start the timed generation at this position over a pre-filled (zero) cache: long-context timing, "
                          "N = 1 only; the default 0 is generate()'s own start (BOS + prompt)")
-    ap.add_argument("--mode", default="fast", choices=["fast", "parity"],
-                    help="parity: every op in the reference's own rounding order (bit-identical logits), on the model's chain-order weight copy")
-    ap.add_argument("--cpu-tokens", type=int, default=8)
-    ap.add_argument("--cpu-layers", type=int, default=8, help="layers of the CPU baseline's sample (all of them when the model has fewer)")
-    return ap.parse_args()
+    ap.add_argument("--cpu-tokens", type=int, default=4, help="tokens of the CPU baseline's sample (the first one warms up)")
+    ap.add_argument("--rank-timeout", type=float, default=900.0, help="seconds the self-started ranks of --gpus N may take")
+    return ap.parse_args(argv)
 
 
 def pmc_traffic(kernel_substr):
@@ -61,29 +70,43 @@ def pmc_traffic(kernel_substr):
     its own: rocprofv3 --pmc FETCH_SIZE cannot ride along with a timed run), already carrying
     the guide's gfx950 correction (FETCH_SIZE counts 128-B requests at 64 B: x2)."""
     import glob
-    files = sorted(glob.glob(str(REPO / "profiles" / "r*_bench_7b_pmc_fetch_size.json")))
-    if not files:
-        return None, None
-    with open(files[-1]) as f:
-        rows = json.load(f)["rows"]
-    for r in rows:
-        if kernel_substr in r["kernel"] and r["counter"] == "FETCH_SIZE":
-            return r["hbm_read_bytes_corrected"], f"profiles/{Path(files[-1]).name}"
+    files = sorted(glob.glob(str(REPO / "profiles" / "r*_bench_7b*_pmc_fetch_size.json")))
+    for f in reversed(files):
+        with open(f) as fh:
+            rows = json.load(fh)["rows"]
+        for r in rows:
+            if kernel_substr in r["kernel"] and r["counter"] == "FETCH_SIZE":
+                return r["hbm_read_bytes_corrected"], f"profiles/{Path(f).name}"
     return None, None
 
 
-def cpu_baseline(shape_name, n_tokens, n_layers_sample):
-    """Time the oracle (reference-algorithm CPU restatement, OpenMP over rows/heads like the
-    reference's rayon) on a bounded sample of the same workload: `n_layers_sample` of the L
-    layers + the classifier, same synthetic weights, same token positions; the layer part is
-    scaled by L / n_layers_sample."""
+def _mem_available_gb() -> float:
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    return int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
+
+
+def cpu_baseline(shape_name, n_tokens, parity_engine=None):
+    """Time the oracle (reference-algorithm CPU restatement, OpenMP over rows/heads like the reference's
+    rayon) at FULL depth on the same synthetic weights and token positions (BOS + prompt from position 0).
+    With `parity_engine` (a rama_amd.Engine in parity mode) the same positions run on the GPU and the
+    logits are compared with the oracle's -- the oracle as the checker, never as the thing measured.
+    llama2-7B needs ~30 GB of host memory for the weights; a box without it gets an 8-layer sample
+    scaled by 4 (said so in `sample`)."""
     import numpy as np
     from oracle import oracle as O
     from oracle import synth as S
     d, h, L, H, V, seq, shared = SHAPES[shape_name]
-    ls = min(n_layers_sample, L)
-    cfg = O.Config(d, h, ls, H, H, V, min(seq, 64), shared)
     full = O.Config(d, h, L, H, H, V, seq, shared)
+    cseq = min(seq, 64)        # the sample's positions are < 64; the caches are sized for them
+    need_gb = 4e-9 * (L * (4 * d * d + 3 * d * h) + (1 if shared else 2) * V * d + 2 * L * cseq * d) + 2.0
+    ls = L if _mem_available_gb() > need_gb + 4.0 else min(8, L)
+    cfg = O.Config(d, h, ls, H, H, V, cseq, shared)
     spec = S.synth_spec(full)
     w = {}
     for name, shp in O.weight_shapes(cfg):
@@ -91,34 +114,269 @@ def cpu_baseline(shape_name, n_tokens, n_layers_sample):
             continue
         tag, scale, bias = spec[name]
         w[name] = O.fill_synth(int(np.prod(shp)), 0, tag, scale, bias).reshape(shp)
-    w["freq_cis_real"], w["freq_cis_imag"] = S.rope_tables(cfg.seq_len, cfg.head_size)
-    # the GPU box shows 256 CPUs but a 1-GPU job owns a 16-CPU share
-    try:
+    if parity_engine is not None:      # the checkpoint's own RoPE tables (the first rows of the resident model's), so both sides read the same weights
+        nrope = cfg.seq_len * (cfg.head_size // 2)
+        w["freq_cis_real"] = parity_engine.model.tensor("freq_cis_real", nrope).reshape(cfg.seq_len, -1)
+        w["freq_cis_imag"] = parity_engine.model.tensor("freq_cis_imag", nrope).reshape(cfg.seq_len, -1)
+    else:
+        w["freq_cis_real"], w["freq_cis_imag"] = S.rope_tables(cfg.seq_len, cfg.head_size)
+    try:   # the GPU box shows 256 CPUs but a 1-GPU job owns a 16-CPU share
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(16, avail))
-    orc = O.Oracle(cfg, w, threads=cores)
+    orc = O.Oracle(cfg, w, threads=max(1, min(16, avail)))
     toks = [1] + PROMPT
     t_layers = t_cls = 0.0
-    token = 1
-    for pos in range(n_tokens):
+    token, worst, identical, checked = 1, 0.0, True, 0
+    for pos in range(min(n_tokens, cseq)):
         t0 = time.perf_counter()
         orc.forward_range(token, pos, 0, ls, True, False)
         t1 = time.perf_counter()
         orc.forward_range(token, pos, ls, ls, False, True)
         t2 = time.perf_counter()
-        if pos > 0:   # first token pages the weights in
+        if pos > 0:   # the first token pages the weights in
             t_layers += t1 - t0
             t_cls += t2 - t1
+        if parity_engine is not None and ls == L:
+            parity_engine.forward(token, pos)
+            lg = parity_engine.logits()
+            lo = orc.s["logits"]
+            worst = max(worst, float(np.abs(lg - lo).max()))
+            identical = identical and bool(np.array_equal(lg.view(np.uint32), lo.view(np.uint32)))
+            checked += 1
         token = toks[pos + 1] if pos + 1 < len(toks) else O.argmax(orc.s["logits"])
-    n = max(n_tokens - 1, 1)
+    n = max(min(n_tokens, cseq) - 1, 1)
     per_token = (t_layers / n) * (L / ls) + t_cls / n
-    return {"value": round(1.0 / per_token, 4), "unit": "tokens/s", "cores": O.lib().oracle_get_threads(),
-            "kind": "port",
-            "sample": f"{shape_name} shape, {ls} of {L} layers + classifier, {n} tokens after 1 warm-up, "
-                      f"layer time scaled x{L / ls:g}; oracle/rama_oracle.c (C restatement of engine/src/device/cpu.rs), "
-                      f"OpenMP threads={O.lib().oracle_get_threads()}"}
+    threads = O.lib().oracle_get_threads()
+    out = {"value": round(1.0 / per_token, 4), "unit": "tokens/s", "cores": threads, "kind": "port",
+           "sample": f"{shape_name} shape, " + (f"all {L} layers" if ls == L else f"{ls} of {L} layers (layer time scaled x{L / ls:g})")
+                     + f" + classifier, {n} tokens after 1 warm-up (BOS + prompt from position 0); oracle/rama_oracle.c "
+                     f"(C restatement of engine/src/device/cpu.rs), OpenMP threads={threads}"}
+    check = None
+    if checked:
+        check = {"checked_positions": checked, "worst_vs_oracle": worst, "bit_identical_to_oracle": identical}
+    return out, check
+
+
+def time_decode(eng, dev, seq, steps, warmup, pos0, prompt):
+    """`warmup` untimed + `steps` timed chained decode steps; a generation that reaches seq_len is followed
+    by a new one (BOS + prompt at position 0), so a run may be longer than the model's context"""
+    def run_steps(n, pos):
+        while n > 0:
+            if pos == seq:
+                eng.decode_begin(1, 0, prompt)
+                pos = 0
+            m = min(n, seq - pos)
+            eng.decode_steps(m)
+            n -= m
+            pos += m
+        return pos
+    eng.decode_begin(1, pos0, prompt if pos0 == 0 else [])
+    pos = run_steps(warmup, pos0)
+    dev.sync()      # N = 1: no other rank to meet; everything runs on the context's stream, which this drains
+    t0 = time.perf_counter()
+    eng.timer_start()
+    pos = run_steps(steps, pos)
+    ev_ms = eng.timer_stop()
+    dev.sync()
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    tokens = eng.decode_tokens()
+    need = warmup + steps
+    assert len(tokens) == (need if pos0 + need <= seq else pos), (len(tokens), need, pos)
+    return wall_ms, ev_ms, pos, tokens
+
+
+def kernel_times(eng, cfg_seq, pos, tokens, bytes_, ksteps=16):
+    """per-launch device time of every kernel class over `ksteps` eager decode steps (events carried by the dispatch)"""
+    kernels = {}
+    kpos = min(pos, cfg_seq - ksteps)
+    if kpos < 0:
+        return kernels
+    for k in ("qkv", "attn", "wo", "w13", "w2", "cls"):
+        eng.decode_begin(tokens[-1] if tokens else 1, kpos, [])
+        avg_ms, n = eng.kprof(k, ksteps)
+        b = bytes_.get(k)
+        if n:
+            kernels[k] = {"avg_us": round(avg_ms * 1e3, 2), "launches": n,
+                          "GBps": round(b / (avg_ms * 1e-3) / 1e9, 1) if b else None}
+    return kernels
+
+
+def run_shape(dev, name, steps, warmup, pos0, graph, modes, kprof):
+    """the requested modes of one shape on one resident model -> (cfg, model, bytes, {mode: {...}})"""
+    import rama_amd
+    d, h, L, H, V, seq, shared = SHAPES[name]
+    cfg = rama_amd.Config(d, h, L, H, H, V, seq, shared)
+    model = rama_amd.Model.synth(dev, cfg, seed=0)
+    bytes_ = rama_amd.algorithmic_bytes(cfg)
+    out = {}
+    pos0 = max(0, min(pos0, seq - 1))
+    for mode in modes:
+        eng = rama_amd.Engine(dev, model)
+        eng.set_tuning("ref_order", 1 if mode == "parity" else 0)
+        eng.set_graph_mode(bool(graph))
+        wall_ms, ev_ms, pos, tokens = time_decode(eng, dev, seq, steps, warmup, pos0, PROMPT)
+        tok_s = steps / (wall_ms * 1e-3)
+        r = {"tok_s": round(tok_s, 3), "ms_per_step": round(wall_ms / steps, 4), "event_ms_per_step": round(ev_ms / steps, 4),
+             "achieved_GBps": round(bytes_["token"] * tok_s / 1e9, 1),
+             "frac_of_8TBps": round(bytes_["token"] * tok_s / 1e9 / HBM_PEAK_GBPS, 4),
+             "positions": f"{pos0 + warmup}..{pos0 + warmup + steps - 1}" + (" (wrapping at seq_len)" if pos0 + warmup + steps > seq else ""),
+             "tokens": tokens}
+        if kprof:
+            eng.set_graph_mode(False)   # per-launch event brackets need eager launches
+            r["kernels"] = kernel_times(eng, seq, pos, tokens, bytes_)
+        eng.set_tuning("ref_order", 0)
+        eng.free()
+        out[mode] = r
+    return cfg, model, bytes_, out
+
+
+def roofline_of(kernels, bytes_, mode, d):
+    if not kernels or "w13" not in kernels:
+        return None
+    a = kernels["w13"]["GBps"]
+    if mode == "parity":
+        kname = "gemv_chain_kernel<W,D,XD,CEPI_SWIGLU> (chain-order W1|W3 matvec in the reference's rounding order + SiLU*gate)"
+        traffic, traffic_src = pmc_traffic("gemv_chain_kernel<1, 16, 4, 3>") if d == 4096 else (None, None)
+    else:
+        kname = ("gemv_rows_solo<4,CH,NORM,EPI_SWIGLU_PAIR>" if d <= 2048 else "gemv_rows<4,2,8,NORM,EPI_SWIGLU_PAIR>") + " (rmsnorm + row-interleaved W1|W3 matvec + SiLU*gate)"
+        traffic, traffic_src = pmc_traffic("gemv_rows<4, 2, 8, true, 5>") if d == 4096 else (None, None)
+    return {"bound": "hbm", "kernel": kname, "achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBPS, 4),
+            "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": bytes_["w13"], "avg_launch_us": kernels["w13"]["avg_us"]}
+
+
+def single_gpu(args, local_rank):
+    import rama_amd
+    dev = rama_amd.Hip(local_rank)
+    modes = ["fast", "parity"] if args.mode == "both" else [args.mode]
+    head = "parity" if "parity" in modes else "fast"
+    cfg, model, bytes_, res = run_shape(dev, args.config, args.steps, args.warmup, args.pos0, args.graph, modes, not args.no_kprof)
+    d, h, L, H, V, seq, shared = SHAPES[args.config]
+    if "fast" in res and "parity" in res:
+        res["parity"]["greedy_tokens_equal_fast_mode"] = res["parity"]["tokens"] == res["fast"]["tokens"]
+
+    def baseline_for(name, mdl, n_tokens):
+        peng = None
+        if "parity" in modes:
+            peng = rama_amd.Engine(dev, mdl)
+            peng.set_tuning("ref_order", 1)
+        try:
+            return cpu_baseline(name, n_tokens, peng)
+        finally:
+            if peng is not None:
+                peng.set_tuning("ref_order", 0)
+                peng.free()
+
+    cpu, check = (None, None) if args.no_cpu_baseline else baseline_for(args.config, model, args.cpu_tokens)
+    model.free()
+
+    others = {}
+    if not args.no_other_configs:
+        for name in SHAPES:
+            if name == args.config:
+                continue
+            oseq = SHAPES[name][5]
+            osteps, owarm = min(200, oseq - 28), 28            # the README's 200-token generation (positions 28..227)
+            _, om, ob, orr = run_shape(dev, name, osteps, owarm, 0, args.graph, modes, False)
+            ocpu, ocheck = (None, None) if args.no_cpu_baseline else baseline_for(name, om, 16)
+            om.free()
+            entry = {"steps": osteps, "warmup": owarm, "algorithmic_bytes_per_token": ob["token"],
+                     "tok_s": orr[head]["tok_s"], "frac_of_8TBps": orr[head]["frac_of_8TBps"]}
+            for m_, r in orr.items():
+                entry[m_ + "_mode"] = {k: v for k, v in r.items() if k not in ("tokens", "kernels")}
+            if ocheck and "parity" in orr:
+                entry["parity_mode"].update(ocheck)
+            entry["cpu_baseline"] = ocpu
+            others[name] = entry
+
+    r = res[head]
+    line = {
+        "metric": METRIC_1GPU,
+        "value": r["tok_s"], "unit": "tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.config} fp32 decode, weights resident in HBM, greedy, pos {r['positions']}",
+                   "mode": ("parity: every op in the reference CPU path's rounding order (chain-order weight copy), logits bit-identical to cpu.rs"
+                            if head == "parity" else "fast: fused multiply-adds, tree-shaped sums"),
+                   "dim": d, "hidden_dim": h, "n_layers": L, "n_heads": H, "vocab_size": V, "seq_len": seq,
+                   "sequences_in_flight": 1, "parallelism": "single GPU", "hipgraph": bool(args.graph)},
+        "token_level": {"algorithmic_bytes_per_token": bytes_["token"], "achieved_GBps": r["achieved_GBps"],
+                        "frac_of_8TBps": r["frac_of_8TBps"], "event_ms_per_step": r["event_ms_per_step"]},
+        "roofline": roofline_of(r.get("kernels"), bytes_, head, d), "kernels": r.get("kernels", {}),
+        "cpu_baseline": cpu,
+    }
+    for m_ in modes:
+        block = {k: v for k, v in res[m_].items() if k != "tokens"}
+        if m_ == "parity" and check:
+            block.update(check)
+        if m_ != head:
+            block["roofline"] = roofline_of(block.get("kernels"), bytes_, m_, d)
+        line[m_ + "_mode"] = block
+    if others:
+        line["other_configs"] = others
+    print(json.dumps(line), flush=True)
+    dev.close()
+
+
+# ------------------------------------------------------------------ N > 1 without a launcher: start the ranks here
+
+def _free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(argv, n, timeout, python=sys.executable, script=None, extra_env=None):
+    """Start `n` ranks of this script as child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
+    environment, a free rendezvous port), BEFORE anything in this process has touched a GPU.  Rank 0's stdout is
+    passed through (the one JSON line); any rank failing or the timeout expiring ends the others and gives a
+    non-zero exit code.  Returns the exit code."""
+    script = script or str(Path(__file__).resolve())
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RAMA_SELF_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if extra_env:
+            env.update(extra_env)
+        procs.append(subprocess.Popen([python, script] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None))
+    deadline = time.time() + timeout
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in list(pending):
+                code = procs[r].poll()
+                if code is not None:
+                    pending.discard(r)
+                    if code != 0:
+                        print(f"bench.py: rank {r} exited with code {code}", file=sys.stderr)
+                        rc = rc or code or 1
+            if rc or time.time() > deadline:
+                if not rc:
+                    print(f"bench.py: ranks still running after {timeout:.0f} s", file=sys.stderr)
+                    rc = 124
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:       # the exact children started above, nothing else
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    out = procs[0].stdout.read().decode() if procs[0].stdout else ""
+    if rc == 0:
+        sys.stdout.write(out)
+        sys.stdout.flush()
+    else:
+        sys.stderr.write(out)
+    return rc
 
 
 def main():
@@ -126,105 +384,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        # no launcher around us: become one.  Nothing has touched a GPU yet (rama_amd is imported further down).
+        raise SystemExit(spawn_ranks(sys.argv[1:], args.gpus, args.rank_timeout))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
     import rama_amd
 
-    d, h, L, H, V, seq, shared = SHAPES[args.config]
-    cfg = rama_amd.Config(d, h, L, H, H, V, seq, shared)
-
-    # RAMA_FORCE_PIPELINE=1 rehearses the N > 1 code path (process group, HipStage, the
+    # RAMA_FORCE_PIPELINE=1 rehearses the N > 1 code path (process group, the stage objects, the
     # grouped exchanges' bookkeeping) with a single rank on a 1-GPU box
     if args.gpus > 1 or os.environ.get("RAMA_FORCE_PIPELINE"):
         from rama_amd.pipeline import run_pipeline_bench
+        d, h, L, H, V, seq, shared = SHAPES[args.config]
+        cfg = rama_amd.Config(d, h, L, H, H, V, seq, shared)
         line = run_pipeline_bench(args, cfg, rank, world, local_rank)
         if rank == 0:
             print(json.dumps(line), flush=True)
         return
-
-    need = args.warmup + args.steps
-    dev = rama_amd.Hip(local_rank)
-    model = rama_amd.Model.synth(dev, cfg, seed=0)
-    eng = rama_amd.Engine(dev, model)
-    dev.sync()
-    bytes_ = rama_amd.algorithmic_bytes(cfg)
-
-    def run_steps(n, pos):
-        """n decode steps from position pos; a generation that reaches seq_len is followed by a new
-        one (BOS + prompt at position 0), so a run may be longer than the model's context"""
-        while n > 0:
-            if pos == seq:
-                eng.decode_begin(1, 0, PROMPT)
-                pos = 0
-            m = min(n, seq - pos)
-            eng.decode_steps(m)
-            n -= m
-            pos += m
-        return pos
-
-    eng.set_graph_mode(bool(args.graph))
-    if args.mode == "parity":
-        eng.set_tuning("ref_order", 1)
-    pos0 = max(0, min(args.pos0, seq - 1))
-    eng.decode_begin(1, pos0, PROMPT if pos0 == 0 else [])
-    pos = run_steps(args.warmup, pos0)
-    dev.sync()      # N = 1: no other rank to meet; everything runs on the context's stream, which this drains
-    t0 = time.perf_counter()
-    eng.timer_start()
-    pos = run_steps(args.steps, pos)
-    ev_ms = eng.timer_stop()
-    dev.sync()
-    wall_ms = (time.perf_counter() - t0) * 1e3
-    ms_per_step = wall_ms / args.steps
-    tokens = eng.decode_tokens()
-    assert len(tokens) == (need if pos0 + need <= seq else pos), (len(tokens), need, pos)
-
-    roofline, kernels = None, {}
-    if not args.no_kprof:
-        eng.set_graph_mode(False)   # per-launch event brackets need eager launches
-        ksteps = 16
-        kpos = min(pos, seq - ksteps)
-        if kpos >= 0:
-            for k in ("qkv", "attn", "wo", "w13", "w2", "cls"):
-                eng.decode_begin(tokens[-1] if tokens else 1, kpos, [])
-                avg_ms, n = eng.kprof(k, ksteps)
-                b = bytes_.get(k)
-                kernels[k] = {"avg_us": round(avg_ms * 1e3, 2), "launches": n,
-                              "GBps": round(b / (avg_ms * 1e-3) / 1e9, 1) if b else None}
-            a = kernels["w13"]["GBps"]
-            traffic, traffic_src = pmc_traffic("gemv_rows<4, 2, 8, true, 5>") if args.config == "llama2-7B" else (None, None)
-            kname = "gemv_rows_solo<4,CH,NORM,EPI_SWIGLU_PAIR>" if d <= 2048 else "gemv_rows<4,2,8,NORM,EPI_SWIGLU_PAIR>"
-            roofline = {"bound": "hbm", "kernel": kname + " (rmsnorm + row-interleaved W1|W3 matvec + SiLU*gate)",
-                        "achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBPS, 4),
-                        "traffic": traffic, "traffic_source": traffic_src,
-                        "algorithmic_bytes_per_launch": bytes_["w13"],
-                        "avg_launch_us": kernels["w13"]["avg_us"]}
-
-    cpu = None
-    if not args.no_cpu_baseline and rank == 0:
-        cpu = cpu_baseline(args.config, args.cpu_tokens, args.cpu_layers)
-
-    tok_s = args.steps / (wall_ms * 1e-3)
-    line = {
-        "metric": "tokens/sec decode + matvec achieved-HBM-GB/s vs roofline, llama2-7B fp32 1xMI355X",
-        "value": round(tok_s, 3), "unit": "tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.config} fp32 decode, weights resident in HBM, greedy, pos {pos0 + args.warmup}..{pos0 + need - 1}" + (" (wrapping at seq_len)" if pos0 + need > seq else ""),
-                   "dim": d, "hidden_dim": h, "n_layers": L, "n_heads": H, "vocab_size": V, "seq_len": seq,
-                   "sequences_in_flight": 1, "parallelism": "single GPU", "hipgraph": bool(args.graph),
-                   "w13_layout": "row-interleaved copy per model (no placement tuning)"},
-        "token_level": {"algorithmic_bytes_per_token": bytes_["token"],
-                        "achieved_GBps": round(bytes_["token"] * tok_s / 1e9, 1),
-                        "frac_of_8TBps": round(bytes_["token"] * tok_s / 1e9 / HBM_PEAK_GBPS, 4),
-                        "event_ms_per_step": round(ev_ms / args.steps, 4)},
-        "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
-    }
-    print(json.dumps(line), flush=True)
-    eng.free(); model.free(); dev.close()
+    single_gpu(args, local_rank)
 
 
 if __name__ == "__main__":

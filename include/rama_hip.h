@@ -199,8 +199,8 @@ int  rama_forward_stage_devtok(rama_ctx *ctx, const rama_config *cfg, const rama
 int  rama_argmax_dev(rama_ctx *ctx, const float *logits, size_t n, int32_t *result_dev);
 
 /* ---------------------------------------------------------------- layer pipeline over RCCL (csrc/pipe.hip)
- * One process per GPU; rank r owns layers [r*L/N, (r+1)*L/N) (rama_model_load_stage / rama_model_synth
- * with a stage), n_seq >= N sequences in flight.  Rank 0 obtains a unique id and ships its
+ * One process per GPU; rank r owns a contiguous layer range -- as even as possible, the first L mod N ranks
+ * one layer more -- (rama_model_load_stage / rama_model_synth with a stage), n_seq >= N sequences in flight.  Rank 0 obtains a unique id and ships its
  * RAMA_PIPE_ID_BYTES bytes to the other ranks by any side channel (a file, an environment variable,
  * a torch.distributed / MPI broadcast); every rank then creates its end.  RCCL is loaded with dlopen on
  * first use.  All exchanges are enqueued on the context's stream. */
@@ -209,6 +209,8 @@ typedef struct rama_pipe rama_pipe;
 int  rama_pipe_unique_id(void *id_out /* RAMA_PIPE_ID_BYTES */);
 int  rama_pipe_create(rama_ctx *ctx, const void *id_bytes, int rank, int world, rama_pipe **out);
 int  rama_pipe_destroy(rama_pipe *pipe);
+/* the communicator's own count of ranks and this end's rank in it (ncclCommCount / ncclCommUserRank) */
+int  rama_pipe_comm_info(const rama_pipe *pipe, int *n_ranks, int *rank);
 /* One grouped exchange (ncclGroupStart .. ncclGroupEnd): each of the four legs is skipped when its
  * buffer is NULL.  x legs carry float[n], token legs one int32; peers are ranks of the pipe. */
 int  rama_pipe_exchange(rama_pipe *pipe, const float *send_x, size_t n_send_x, int send_x_peer,

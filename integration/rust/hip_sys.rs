@@ -91,6 +91,7 @@ extern "C" {
     pub fn rama_pipe_unique_id(id_out: *mut u8) -> c_int;                       // RAMA_PIPE_ID_BYTES = 128
     pub fn rama_pipe_create(ctx: *mut rama_ctx, id: *const u8, rank: c_int, world: c_int, out: *mut *mut rama_pipe) -> c_int;
     pub fn rama_pipe_destroy(pipe: *mut rama_pipe) -> c_int;
+    pub fn rama_pipe_comm_info(pipe: *const rama_pipe, n_ranks: *mut c_int, rank: *mut c_int) -> c_int;
     pub fn rama_pipe_total_ticks(pipe: *const rama_pipe, plan: *const rama_pipe_plan) -> c_int;
     pub fn rama_pipe_run_ticks(pipe: *mut rama_pipe, cfg: *const rama_config, w: *const rama_weights,
                                states: *mut rama_run_state, tok_dev: *const *mut i32, stage: *const rama_stage,

@@ -108,6 +108,7 @@ SIGNATURES = {
     "rama_pipe_exchange": (_int, [_vp, _vp, _sz, _int, _vp, _sz, _int, _vp, _int, _vp, _int]),
     "rama_pipe_item": (_int, [_vp, _int, _int, _int, C.POINTER(_int), C.POINTER(_int)]),
     "rama_pipe_total_ticks": (_int, [_vp, _vp]),
+    "rama_pipe_comm_info": (_int, [_vp, C.POINTER(_int), C.POINTER(_int)]),
     "rama_pipe_run_ticks": (_int, [_vp, _cfgp, _wp, _sp, C.POINTER(_vp), _stp, _vp, _int, _int]),
     "rama_pipe_last_error": (C.c_char_p, []),
     "rama_timer_start": (_int, [_vp]),

@@ -12,6 +12,7 @@
 //                   rank 0 writes the RCCL unique id to the file, the others wait for it; rank 0 prints.
 #include "engine.hpp"
 #include "tokenizer.hpp"
+#include "pipe_id.hpp"
 
 #include <chrono>
 #include <cstring>
@@ -79,25 +80,20 @@ static int run_pipeline_stage(const Args& args, int world, int rank) {
     ck(rama_model_weights(model, &w), "rama_model_weights");
     rama_run_state st{};
     ck(rama_state_create(device.ctx, &c, hi - lo, &st), "rama_state_create");
-    // the communicator: rank 0 publishes the id (write to a temporary name, then rename: readers never see a partial file)
+    // the communicator: rank 0 publishes the id through RAMA_PIPE_ID_FILE, tagged with RAMA_PIPE_RUN_ID (host/pipe_id.hpp)
     unsigned char id[RAMA_PIPE_ID_BYTES];
+    const char* run_id = std::getenv("RAMA_PIPE_RUN_ID");
     if (rank == 0) {
+        rama_host::pipe_id_prepare(id_file);                 // a file left by an earlier run must not meet this run's readers
         ck(rama_pipe_unique_id(id), "rama_pipe_unique_id");
-        const std::string tmp = std::string(id_file) + ".tmp";
-        std::ofstream f(tmp, std::ios::binary);
-        f.write(reinterpret_cast<const char*>(id), sizeof id);
-        f.close();
-        if (std::rename(tmp.c_str(), id_file) != 0) { std::fprintf(stderr, "cannot write %s\n", id_file); return 1; }
-    } else {
-        for (int tries = 0;; tries++) {
-            std::ifstream f(id_file, std::ios::binary);
-            if (f && f.read(reinterpret_cast<char*>(id), sizeof id)) break;
-            if (tries > 600) { std::fprintf(stderr, "rank %d: no unique id in %s after 60 s\n", rank, id_file); return 1; }
-            std::this_thread::sleep_for(std::chrono::milliseconds(100));
-        }
+        if (!rama_host::pipe_id_publish(id_file, run_id, id, sizeof id)) { std::fprintf(stderr, "cannot write %s\n", id_file); return 1; }
+    } else if (!rama_host::pipe_id_wait(id_file, run_id, id, sizeof id, 60000)) {
+        std::fprintf(stderr, "rank %d: no unique id of this run in %s after 60 s\n", rank, id_file);
+        return 1;
     }
     rama_pipe* pipe = nullptr;
     ck(rama_pipe_create(device.ctx, id, rank, world, &pipe), "rama_pipe_create");
+    if (rank == 0) rama_host::pipe_id_remove(id_file);       // every rank has joined, so every rank has read it
     if (!std::getenv("RAMA_PIPE_EAGER")) ck(rama_set_graph_mode(device.ctx, 1), "rama_set_graph_mode");   // a stage pass = one hipGraph replay
 
     Tokenizer tokenizer;

@@ -1,7 +1,8 @@
 // pipe.hip -- the layer pipeline under the C ABI: RCCL point-to-point directly, no torch.
 // New functionality (the reference is single-device, gpu.rs:215).
 //
-// Partition: rank r owns layers [r*L/N, (r+1)*L/N) with their weights and KV slabs, rank 0 the
+// Partition: contiguous layer ranges, as even as possible, the first L mod N ranks one layer more (pipeline.py split_layers,
+// host/main.cpp): rank r owns its range with the weights and KV slabs, rank 0 the
 // embedding table, the last rank the final norm + classifier.  A stage boundary is one ncclSend /
 // ncclRecv of the residual x[dim] (16 KiB at llama2-7B) to the next rank, and of the sampled token
 // id (4 bytes) from the last rank back to rank 0 -- point-to-point over xGMI, no collective.
@@ -28,6 +29,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <strings.h>
 
 extern "C" void* rama_internal_stream(rama_ctx* c);      // rama_api.hip
 extern "C" int rama_internal_device(rama_ctx* c);
@@ -44,6 +46,8 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;         // optional
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;      // optional
 };
 Rccl g_rccl;
 std::mutex g_rccl_mu;
@@ -60,8 +64,12 @@ int load_rccl() {
     if (g_rccl.h) return 0;
     // RCCL prints a version banner on STDOUT at NCCL_DEBUG=VERSION and =WARN (some images export one of
     // them): it would land in the middle of the generated text.  RAMA_NCCL_DEBUG passes a level through.
+    // The user's own NCCL_DEBUG is respected (INFO / TRACE go to stderr and are what one needs when a rendezvous hangs);
+    // only the two banner levels, or no setting at all, are replaced.
     const char* dbg = getenv("RAMA_NCCL_DEBUG");
-    setenv("NCCL_DEBUG", dbg ? dbg : "NONE", 1);
+    const char* cur = getenv("NCCL_DEBUG");
+    if (dbg) setenv("NCCL_DEBUG", dbg, 1);
+    else if (!cur || !strcasecmp(cur, "VERSION") || !strcasecmp(cur, "WARN")) setenv("NCCL_DEBUG", "NONE", 1);
     void* h = nullptr;
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
         h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
@@ -75,6 +83,8 @@ int load_rccl() {
     SYM(Send, "ncclSend") SYM(Recv, "ncclRecv") SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd")
     SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
+    *(void**)(&r.CommCount) = dlsym(h, "ncclCommCount");
+    *(void**)(&r.CommUserRank) = dlsym(h, "ncclCommUserRank");
     g_rccl = r;
     return 0;
 }
@@ -111,6 +121,17 @@ extern "C" int rama_pipe_create(rama_ctx* ctx, const void* id_bytes, int rank, i
     ncclResult_t r = g_rccl.CommInitRank(&p->comm, world, id, rank);
     if (r != ncclSuccess) { delete p; return bad(RAMA_EIO, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r)); }
     *out = p;
+    return 0;
+}
+
+// what the communicator itself says about its size and this end's rank (the bench line's `rccl_ranks`)
+extern "C" int rama_pipe_comm_info(const rama_pipe* p, int* n_ranks, int* rank) {
+    if (!p || !p->comm) return bad(RAMA_EINVAL, "rama_pipe_comm_info: no communicator");
+    int n = p->world, r = p->rank;
+    if (g_rccl.CommCount) NCHK(g_rccl.CommCount(p->comm, &n));
+    if (g_rccl.CommUserRank) NCHK(g_rccl.CommUserRank(p->comm, &r));
+    if (n_ranks) *n_ranks = n;
+    if (rank) *rank = r;
     return 0;
 }
 

@@ -640,8 +640,11 @@ static int launch_attention(rama_ctx* c, float* xb, float* att, const float* q, 
     }
     if (c->small_attn) {     // short contexts: fewer waves per head, one round covers the whole context
         const int W = c->tune_small_waves;
-        size_t shm4 = (size_t)(attn_scratch_floats(G, W) + seq_len) * sizeof(float);
-        REQUIRE(shm4 <= 64 * 1024, RAMA_EUNSUP, "attention: seq_len too long for the single-workgroup kernel");
+        // score buffer: seq_len timesteps, or what 64 KiB hold when the context is longer (this variant only runs below
+        // tune_small_pos, and such models split from position 256 on: split_threshold)
+        const int cap4 = std::min(seq_len, (int)(64 * 1024 / sizeof(float)) - attn_scratch_floats(G, W));
+        REQUIRE((ctl ? c->host_pos : pos) < cap4, RAMA_EUNSUP, "attention: position beyond the single-workgroup kernel's score buffer");
+        size_t shm4 = (size_t)(attn_scratch_floats(G, W) + cap4) * sizeof(float);
 #define RAMA_SMALL_G(W_) do { if (G == 16) RAMA_LAUNCH(c, (attention_kernel<16, false, W_>), dim3(n_heads), dim3(W_ * 64), shm4, p); \
                               else if (G == 32) RAMA_LAUNCH(c, (attention_kernel<32, false, W_>), dim3(n_heads), dim3(W_ * 64), shm4, p); \
                               else RAMA_LAUNCH(c, (attention_kernel<64, false, W_>), dim3(n_heads), dim3(W_ * 64), shm4, p); } while (0)

@@ -2,7 +2,8 @@
 over xGMI on ROCm, "gloo" on CPU for tests).  New functionality: the reference is single-device
 (SURVEY.md section 8e).
 
-Partition: rank r owns layers [r*L/N, (r+1)*L/N) with their weights and KV slabs; rank 0 also owns
+Partition: contiguous layer ranges, as even as possible (the first L mod N ranks hold one layer more:
+split_layers), each with its weights and KV slabs; rank 0 also owns
 the embedding table, the last rank the final norm + classifier.  The only exchanges are
 point-to-point: the residual x[dim] (16 KiB at llama2-7B) from rank r to r+1 and the sampled token
 id (4 bytes) from the last rank back to rank 0 -- no collective.
@@ -246,19 +247,22 @@ class NativeStage:
         self.dev.close()
 
 
-def _bench_line(args, cfg, world, n_seq, tok_s, dt, roofline, path):
+def _bench_line(args, cfg, world, n_seq, tok_s, dt, roofline, path, hipgraph, rccl_ranks=None):
     import rama_amd
     from bench import HBM_PEAK_GBPS
     bytes_ = rama_amd.algorithmic_bytes(cfg)
     return {
-        "metric": "tokens/sec decode + matvec achieved-HBM-GB/s vs roofline, llama2-7B fp32 1xMI355X",
+        "metric": f"tokens/sec decode + matvec achieved-HBM-GB/s vs roofline, {args.config} fp32 layer pipeline over {world}xMI355X"
+                  if world > 1 else "tokens/sec decode + matvec achieved-HBM-GB/s vs roofline, llama2-7B fp32 1xMI355X",
         "value": round(tok_s, 3), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.config} fp32 decode, layer pipeline over {world} GPUs, {n_seq} sequences in flight, greedy",
+                   "mode": "fast: fused multiply-adds, tree-shaped sums (the pipeline stages run the default kernels)",
                    "dim": cfg.dim, "hidden_dim": cfg.hidden_dim, "n_layers": cfg.n_layers, "n_heads": cfg.n_heads,
                    "vocab_size": cfg.vocab_size, "seq_len": cfg.seq_len, "sequences_in_flight": n_seq,
-                   "parallelism": f"pp{world} (RCCL send/recv of x[dim] and the token id; {path})", "hipgraph": False},
+                   "parallelism": f"pp{world} (RCCL send/recv of x[dim] and the token id; {path})", "hipgraph": bool(hipgraph)},
+        "rccl_ranks": rccl_ranks,
         "token_level": {"algorithmic_bytes_per_token": bytes_["token"],
                         "achieved_GBps_aggregate": round(bytes_["token"] * tok_s / 1e9, 1),
                         "frac_of_aggregate_8TBps": round(bytes_["token"] * tok_s / 1e9 / (HBM_PEAK_GBPS * world), 4)},
@@ -289,6 +293,23 @@ def _stage_roofline(check, lib, ctx, compute, n_local, cfg):
             "algorithmic_bytes_per_launch": bytes_["w13"], "avg_launch_us": round(avg_ms * 1e3, 2)}
 
 
+def _rendezvous_env():
+    """MASTER_ADDR / MASTER_PORT come from the launcher (torch.distributed.run, or bench.py's own spawn_ranks, which
+    picks a free port); only a single rank rehearsing the path (RAMA_FORCE_PIPELINE) has to pick them itself.
+    NCCL_DEBUG: the user's value stands unless it is one of the two levels that print a banner on stdout."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in os.environ:
+        import socket
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s_:
+            s_.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+    cur = os.environ.get("NCCL_DEBUG", "")
+    if "RAMA_NCCL_DEBUG" in os.environ:
+        os.environ["NCCL_DEBUG"] = os.environ["RAMA_NCCL_DEBUG"]
+    elif cur.upper() in ("", "VERSION", "WARN"):
+        os.environ["NCCL_DEBUG"] = "NONE"
+
+
 def run_pipeline_bench_native(args, cfg, rank: int, world: int, local_rank: int) -> dict:
     """bench.py --gpus N > 1 on the native path: N sequences in flight, a step = N ticks."""
     import torch
@@ -296,9 +317,7 @@ def run_pipeline_bench_native(args, cfg, rank: int, world: int, local_rank: int)
     import rama_amd
     from bench import PROMPT
 
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29531")
-    os.environ["NCCL_DEBUG"] = os.environ.get("RAMA_NCCL_DEBUG", "NONE")    # RCCL prints its version banner on stdout at VERSION / WARN: one JSON line
+    _rendezvous_env()
     torch.cuda.set_device(local_rank)  # torch.cuda.synchronize() below must mean THIS rank's GPU, not device 0 for everybody
     if not dist.is_initialized():      # control plane only: the id, barriers, the max over ranks
         with _stdout_to_stderr():      # gloo announces its connections on stdout; the bench prints ONE JSON line there
@@ -336,7 +355,13 @@ def run_pipeline_bench_native(args, cfg, rank: int, world: int, local_rank: int)
             else:
                 st.check(L.rama_forward_stage_devtok(st.dev.ctx, C.byref(st.model.ccfg), C.byref(st.model.weights), C.byref(st.states[0]), None, 5, C.byref(st.stage)))
         roofline = _stage_roofline(st.check, L, st.dev.ctx, one, n_local, cfg)
-    line = _bench_line(args, cfg, world, n_seq, args.steps * n_seq / dt, dt, roofline, "native: csrc/pipe.hip, tick loop in C++, one hipGraph per (sequence, stage)" if not os.environ.get("RAMA_PIPE_EAGER") else "native: csrc/pipe.hip, tick loop in C++, eager launches")
+    nr, rk = C.c_int(), C.c_int()
+    st.check(st.dev.lib.rama_pipe_comm_info(st.pipe, C.byref(nr), C.byref(rk)), "rama_pipe_comm_info")
+    assert nr.value == world and rk.value == rank, (nr.value, rk.value, world, rank)
+    graphs = not os.environ.get("RAMA_PIPE_EAGER")
+    line = _bench_line(args, cfg, world, n_seq, args.steps * n_seq / dt, dt, roofline,
+                       "native: csrc/pipe.hip, tick loop in C++, one hipGraph per (sequence, stage)" if graphs else "native: csrc/pipe.hip, tick loop in C++, eager launches",
+                       graphs, rccl_ranks=nr.value)
     st.free()
     dist.barrier()
     dist.destroy_process_group()
@@ -351,9 +376,7 @@ def run_pipeline_bench_torch(args, cfg, rank: int, world: int, local_rank: int) 
     import rama_amd
     from bench import HBM_PEAK_GBPS, PROMPT
 
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29531")
-    os.environ["NCCL_DEBUG"] = os.environ.get("RAMA_NCCL_DEBUG", "NONE")    # RCCL prints its version banner on stdout at VERSION / WARN: one JSON line
+    _rendezvous_env()
     if not dist.is_initialized():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
@@ -385,7 +408,8 @@ def run_pipeline_bench_torch(args, cfg, rank: int, world: int, local_rank: int) 
     if n_local > 0 and not args.no_kprof:
         roofline = _stage_roofline(backend.check, backend.dev.lib, backend.dev.ctx,
                                    lambda: backend.compute(0, (n_pos - 1) % cfg.seq_len, BOS if rank == 0 else None), n_local, cfg)
-    line = _bench_line(args, cfg, world, n_seq, args.steps * n_seq / dt, dt, roofline, "torch.distributed P2P, tick loop in Python")
+    line = _bench_line(args, cfg, world, n_seq, args.steps * n_seq / dt, dt, roofline, "torch.distributed P2P, tick loop in Python",
+                       False, rccl_ranks=dist.get_world_size())
     backend.free()
     dist.barrier()
     dist.destroy_process_group()

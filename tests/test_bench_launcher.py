@@ -1,0 +1,78 @@
+"""CPU: bench.py --gpus N without a launcher starts its N ranks itself (spawn_ranks): one process per rank with
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set and a free port, rank 0's line passed through, any failure or a
+timeout ends every child and gives a non-zero exit code.  Driven here with stub stages (no GPU)."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO))
+import bench  # noqa: E402
+
+
+def _stub(tmp_path, body):
+    p = tmp_path / "stub_rank.py"
+    p.write_text(textwrap.dedent(body))
+    return str(p)
+
+
+def test_spawn_ranks_passes_rank0_line_and_env(tmp_path, capfd):
+    stub = _stub(tmp_path, """
+        import json, os, socket, sys, time
+        r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        assert os.environ["LOCAL_RANK"] == str(r) and os.environ["MASTER_ADDR"] == "127.0.0.1"
+        port = int(os.environ["MASTER_PORT"])
+        # a gloo-less rendezvous: rank 0 listens on the port the launcher picked, the others connect
+        if r == 0:
+            s = socket.socket(); s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1); s.bind(("127.0.0.1", port)); s.listen(w)
+            peers = sorted(int(s.accept()[0].recv(16).decode()) for _ in range(w - 1))
+            print(json.dumps({"value": 1.0, "n_gpus": w, "peers": peers, "argv": sys.argv[1:]}), flush=True)
+        else:
+            for _ in range(100):
+                try:
+                    c = socket.create_connection(("127.0.0.1", port), timeout=1); break
+                except OSError:
+                    time.sleep(0.05)
+            c.send(str(r).encode()); c.close()
+    """)
+    rc = bench.spawn_ranks(["--gpus", "3", "--steps", "2"], 3, timeout=60, script=stub)
+    out = capfd.readouterr().out.strip().splitlines()
+    assert rc == 0 and len(out) == 1
+    line = json.loads(out[0])
+    assert line["n_gpus"] == 3 and line["peers"] == [1, 2] and line["argv"] == ["--gpus", "3", "--steps", "2"]
+
+
+def test_spawn_ranks_one_failure_ends_the_others(tmp_path, capfd):
+    stub = _stub(tmp_path, """
+        import os, sys, time
+        if os.environ["RANK"] == "1":
+            sys.exit(7)
+        time.sleep(120)          # the survivors would hang in a collective
+    """)
+    t0 = time.time()
+    rc = bench.spawn_ranks([], 3, timeout=60, script=stub)
+    assert rc == 7 and time.time() - t0 < 30
+    assert capfd.readouterr().out == ""          # no line on stdout from a failed job
+
+
+def test_spawn_ranks_timeout(tmp_path):
+    stub = _stub(tmp_path, "import time; time.sleep(120)")
+    t0 = time.time()
+    rc = bench.spawn_ranks([], 2, timeout=1.0, script=stub)
+    assert rc == 124 and time.time() - t0 < 30
+
+
+def test_bench_gpus_n_without_launcher_spawns_before_touching_a_gpu(tmp_path):
+    """`python bench.py --gpus 2` with no RANK in the environment must go through spawn_ranks (here: the children fail
+    loudly because this container has no GPU, and the parent reports it with a non-zero code instead of hanging)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--rank-timeout", "120"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "rank" in r.stderr
+        assert r.stdout.strip() == ""

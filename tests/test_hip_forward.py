@@ -471,6 +471,24 @@ def test_split_t_attention_long_context(dev, n_heads, hs, split_pos):
     rs.free(); ws.free()
 
 
+@pytest.mark.parametrize("n_heads,hs", [(2, 128), (3, 64)])
+def test_context_longer_than_the_score_buffer(dev, n_heads, hs):
+    """seq_len 16384: more timesteps than any single-workgroup attention variant's 64 KiB score buffer holds.  Positions
+    below 256 take the fewer-wave variant (its buffer is sized for what fits, not for seq_len), the rest split-T"""
+    import rama_amd
+    cfg, w, kc, vc = _long_ctx_case(n_heads, hs, seq_len=16384, seed=3)
+    orc = O.Oracle(cfg, w)
+    rcfg, ws, wv, rs, rsv = gpu_views(dev, cfg, w)
+    for pos in (0, 100, 300, 9000, 16383):
+        orc.s["key_cache"][:] = kc; orc.s["value_cache"][:] = vc
+        dev.upload_into(rsv.key_cache, kc); dev.upload_into(rsv.value_cache, vc)
+        lo = orc.forward(5, pos).copy()
+        rama_amd.forward_fused(rcfg, wv, rsv, 5, pos, dev)
+        lg = dev.download(rsv.logits)
+        assert np.abs(lg - lo).max() <= LOGIT_ATOL, (pos, float(np.abs(lg - lo).max()))
+    rs.free(); ws.free()
+
+
 @pytest.mark.parametrize("graph", [False, True])
 def test_decode_across_split_threshold(dev, graph):
     """a chained greedy run from pos 242 to 272 switches attention variant (and hipGraph) at 256"""
