@@ -377,8 +377,32 @@ __device__ __forceinline__ bool seq_sum_predict_r(const float* a, int n, PredSha
     return ps.fail == 0;
 }
 
+// short lists: wave 0 ripples through them 64 elements at a time (~0.3 us per block), nothing else to set up
+constexpr int kRippleMax = 512;
+template <int NW>
+__device__ __forceinline__ float seq_sum_ripples(const float* a, int n, PredShared<NW>& ps) {
+    RAMA_NO_CONTRACT
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        float carry = 0.0f;
+        for (int done = 0; done < n; done += 64) {
+            const int i = done + tid;
+            const float pv = i < n ? a[scan_slot(i)] : 0.0f;
+            float sv = (done > 0 && tid == 0) ? carry + pv : pv;
+#pragma unroll
+            for (int k = 0; k < 63; k++)
+                asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(sv) : "v"(pv));
+            carry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sv), 63));
+        }
+        if (tid == 0) ps.result = carry;
+    }
+    __syncthreads();
+    return ps.result;
+}
+
 template <int NW>
 __device__ __forceinline__ bool seq_sum_predict(const float* a, int n, PredShared<NW>& ps, float* out) {
+    if (n <= kRippleMax) { *out = seq_sum_ripples<NW>(a, n, ps); return true; }     // uniform
     const int R = (n - 64 + NW * 64 - 1) / (NW * 64);             // uniform
     if (R <= 4) return seq_sum_predict_r<NW, 4>(a, n, ps, out);
     if (R <= 16) return seq_sum_predict_r<NW, 16>(a, n, ps, out);
@@ -694,11 +718,30 @@ __global__ __launch_bounds__(W * 64) void gemv_chain_kernel(ChainParams p) {
 }
 
 // ---------------------------------------------------------------- cpu.rs:23-52 multi_head_attention
-// One workgroup of NW waves per head.  Scores: thread t owns timestep t (t, t + 64 NW, ...), its
-// q.k dot runs over the head in index order.  Softmax: max, glibc expf, the sequential sum (exact
-// scan), divide.  Values: tiles of kAttTile cache rows are loaded by all threads (16-byte loads, the
-// next tile in flight while this one is consumed), thread i < head_size adds att[t] * v[t][i], t ascending.
+// One workgroup of NW waves per head.
+//  * Scores: thread t owns timestep t; its q.k dot runs over the head in index order.  A lane reading its own
+//    512-byte cache row 16 bytes at a time is 64 different lines per wave instruction (70 us per layer at 1900
+//    timesteps), so a wave stages 64 rows x 32 floats at a time through a PRIVATE piece of LDS: coalesced 16-byte
+//    loads (8 lanes per row), stored with rows 36 floats apart, then every lane reads its own row back
+//    (conflict-free) and continues its chain.  No workgroup barrier inside; the next piece's loads are in flight
+//    while this one is summed.
+//  * Softmax: max, glibc expf, the sequential sum (seq_sum_predict / seq_sum_exact), divide.
+//  * Values: xb[i] = sum_t att[t] * v[t][i], t ascending, is one chain per head column: pos + 1 dependent adds that
+//    nothing can shorten.  So everything else leaves the chain: all threads load tiles of kAttTile cache rows and
+//    store the PRODUCTS att[t] * v[t][i] (rounded, as the reference's `a * vi`) in LDS, two tiles in turn (one
+//    barrier per tile), and thread i < head_size only adds them up in row order.
 constexpr int kAttTile = 64;
+constexpr int kAttPiece = 32;                 // floats of a row per staged piece
+constexpr int kAttStride = kAttPiece + 4;     // row pitch of a staged piece (16-byte aligned, conflict-free row reads)
+__host__ __device__ constexpr size_t attn_chain_region_floats(int head_size, int nw) {
+    return (size_t)(nw * 64 * kAttStride) > (size_t)(2 * kAttTile * head_size) ? (size_t)(nw * 64 * kAttStride) : (size_t)(2 * kAttTile * head_size);
+}
+__host__ __device__ constexpr size_t attn_chain_lds_floats(int head_size, int seq_len, int nw) {
+    return (size_t)((head_size + 3) & ~3) + (size_t)seq_len + (size_t)(seq_len >> 5) + 4 + (size_t)((seq_len + 3) & ~3) + attn_chain_region_floats(head_size, nw);
+}
+// the value tiles are loaded with 8 x 16 bytes per thread
+__host__ __device__ constexpr bool attn_chain_fits(int head_size, int nw) { return kAttTile * (head_size / 4) <= 8 * 64 * nw; }
+
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void attention_chain_kernel(RefAttnParams p) {
     RAMA_NO_CONTRACT
@@ -707,86 +750,171 @@ __global__ __launch_bounds__(NW * 64) void attention_chain_kernel(RefAttnParams 
     __shared__ SeqSumShared<NW> sh;
     __shared__ PredShared<NW> ps;
     __shared__ float red[16];
-    const int h = blockIdx.x, tid = threadIdx.x;
+    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pos = p.ctl ? p.ctl->pos : p.pos_val;
     const int hs = p.head_size, hs4 = hs >> 2;
     float* s_q = sm;                                              // [hs]
-    float* s_v = sm + ((hs + 3) & ~3);                            // [kAttTile][hs]
-    float* s_att = s_v + kAttTile * hs;                           // [scan_slot(seq_len)]
+    float* s_p = sm + ((hs + 3) & ~3);                            // [seq_len] the probabilities, unskewed (read 4 at a time)
+    float* s_att = s_p + ((p.seq_len + 3) & ~3);                  // [scan_slot(seq_len)] scores -> exponentials
+    float* region = s_att + p.seq_len + (p.seq_len >> 5) + 4;     // score staging, then the product tiles
+    region = reinterpret_cast<float*>(((uintptr_t)region + 15) & ~(uintptr_t)15);
     const size_t col = (size_t)h * hs;
+    SEQ_STAMP(8);
     for (int i = tid; i < hs; i += T) s_q[i] = p.q[col + i];
     __syncthreads();
     const float scale_div = sqrtf((float)hs);
     const f4* q4 = reinterpret_cast<const f4*>(s_q);
-    for (int t = tid; t <= pos; t += T) {
-        const f4* k4 = reinterpret_cast<const f4*>(p.kc + (size_t)t * p.dim + col);
-        float acc = 0.0f;
-        int i = 0;
-        for (; i + 8 <= hs4; i += 8) {
-            f4 kk[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) kk[u] = k4[i + u];
+    if (hs % kAttPiece == 0 && pos >= 4 * T) {                    // long contexts: staged pieces, two of them in flight per wave
+        float* stage = region + wave * (64 * kAttStride);
+        const int npiece = hs / kAttPiece;
+        const int lrow = lane >> 3, lc4 = lane & 7;               // loader role: row (+ 8 u) and 16-byte column of the piece
+        const int ngroup = (pos + 64) >> 6;                       // groups of 64 timesteps
+        const int nstep = ((ngroup - wave + NW - 1) / NW) * npiece;          // this wave's (group, piece) steps, in order
+        auto load_step = [&](int st, f4 (&d)[8]) {                // step st = piece st % npiece of group wave + (st / npiece) NW
+            const int g = wave + (st / npiece) * NW, pc = st % npiece;
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-                const f4 qq = q4[i + u];
-                acc = acc + qq.x * kk[u].x; acc = acc + qq.y * kk[u].y; acc = acc + qq.z * kk[u].z; acc = acc + qq.w * kk[u].w;
+                const int t = g * 64 + u * 8 + lrow;
+                d[u] = (st < nstep && t <= pos) ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.kc + (size_t)t * p.dim + col + pc * kAttPiece) + lc4)
+                                                : f4{0.f, 0.f, 0.f, 0.f};
             }
+        };
+        f4 na[8], nb[8];
+        load_step(0, na);
+        load_step(1, nb);
+        float acc = 0.0f;
+        auto consume = [&](int st, f4 (&d)[8]) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) *reinterpret_cast<f4*>(stage + (u * 8 + lrow) * kAttStride + 4 * lc4) = d[u];
+            load_step(st + 2, d);                                 // this buffer's next use
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the piece is in LDS (a wave's LDS operations finish in order)
+            const int pc = st % npiece;
+            const f4* row = reinterpret_cast<const f4*>(stage + lane * kAttStride);
+            f4 kk[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) kk[i] = row[i];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const f4 qq = q4[pc * 8 + i];
+                acc = acc + qq.x * kk[i].x; acc = acc + qq.y * kk[i].y; acc = acc + qq.z * kk[i].z; acc = acc + qq.w * kk[i].w;
+            }
+            if (pc + 1 == npiece) {
+                const int t = (wave + (st / npiece) * NW) * 64 + lane;
+                if (t <= pos) s_att[scan_slot(t)] = acc / scale_div;
+                acc = 0.0f;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // rows read before the next piece overwrites them
+            __builtin_amdgcn_wave_barrier();
+        };
+        for (int st = 0; st < nstep; st += 2) {                   // uniform per wave
+            consume(st, na);
+            if (st + 1 < nstep) consume(st + 1, nb);
         }
-        for (; i < hs4; i++) {
-            const f4 kk = k4[i], qq = q4[i];
-            acc = acc + qq.x * kk.x; acc = acc + qq.y * kk.y; acc = acc + qq.z * kk.z; acc = acc + qq.w * kk.w;
+    } else {
+        for (int t = tid; t <= pos; t += T) {                     // a few rounds of timesteps: straight from the cache, a row's loads together
+            const f4* k4 = reinterpret_cast<const f4*>(p.kc + (size_t)t * p.dim + col);
+            float acc = 0.0f;
+            int i = 0;
+            for (; i + 32 <= hs4; i += 32) {
+                f4 kk[32];
+#pragma unroll
+                for (int u = 0; u < 32; u++) kk[u] = k4[i + u];
+#pragma unroll
+                for (int u = 0; u < 32; u++) {
+                    const f4 qq = q4[i + u];
+                    acc = acc + qq.x * kk[u].x; acc = acc + qq.y * kk[u].y; acc = acc + qq.z * kk[u].z; acc = acc + qq.w * kk[u].w;
+                }
+            }
+            for (; i + 4 <= hs4; i += 4) {
+                f4 kk[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) kk[u] = k4[i + u];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const f4 qq = q4[i + u];
+                    acc = acc + qq.x * kk[u].x; acc = acc + qq.y * kk[u].y; acc = acc + qq.z * kk[u].z; acc = acc + qq.w * kk[u].w;
+                }
+            }
+            for (; i < hs4; i++) {
+                const f4 kk = k4[i], qq = q4[i];
+                acc = acc + qq.x * kk.x; acc = acc + qq.y * kk.y; acc = acc + qq.z * kk.z; acc = acc + qq.w * kk.w;
+            }
+            s_att[scan_slot(t)] = acc / scale_div;
         }
-        s_att[scan_slot(t)] = acc / scale_div;
     }
     __syncthreads();
+    SEQ_STAMP(9);
     // softmax_num (cpu.rs:187-192)
     float mx = -INFINITY;
     for (int t = tid; t <= pos; t += T) mx = fmaxf(mx, s_att[scan_slot(t)]);
     mx = block_max(mx, red);
     for (int t = tid; t <= pos; t += T) s_att[scan_slot(t)] = expf_glibc(s_att[scan_slot(t)] - mx);
     __syncthreads();
+    SEQ_STAMP(10);
     float sum;
     if (!seq_sum_predict<NW>(s_att, pos + 1, ps, &sum)) sum = seq_sum_exact<NW>(s_att, pos + 1, sh);
+    SEQ_STAMP(11);
     for (int t = tid; t <= pos; t += T) {
         const float a = s_att[scan_slot(t)] / sum;
-        s_att[scan_slot(t)] = a;
+        s_p[t] = a;
         if (p.att) p.att[(size_t)h * p.seq_len + t] = a;
     }
     // xb[i] = sum_t att[t] * v[t][i], t ascending (cpu.rs:43-49)
     constexpr int U = 8;
     const int tile4 = kAttTile * hs4;                             // f4 elements of a tile
-    f4 vr[U];
-    auto issue = [&](int t0) {
+    int er[U], ec[U];                                             // tile element e = tid + u T: its row and 16-byte column (one division each, here)
+#pragma unroll
+    for (int u = 0; u < U; u++) { const int e = tid + u * T; er[u] = e / hs4; ec[u] = e - er[u] * hs4; }
+    auto vissue = [&](int t0, f4 (&vr)[U]) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int e = tid + u * T;
-            const int r = e / hs4, c4 = e - r * hs4;
+            const int r = er[u], c4 = ec[u];
             const bool on = e < tile4 && t0 + r <= pos;
-            vr[u] = on ? *reinterpret_cast<const f4*>(p.vc + (size_t)(t0 + r) * p.dim + col + 4 * c4) : f4{0.f, 0.f, 0.f, 0.f};
+            vr[u] = on ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.vc + (size_t)(t0 + r) * p.dim + col) + c4) : f4{0.f, 0.f, 0.f, 0.f};
         }
     };
     float acc = 0.0f;
-    issue(0);
-    for (int t0 = 0; t0 <= pos; t0 += kAttTile) {
-        __syncthreads();                                          // the previous tile has been consumed (and att is final)
+    SEQ_STAMP(12);
+    f4 va[U], vb[U];                                              // two tiles on their way while a third is added up
+    vissue(0, va);
+    vissue(kAttTile, vb);
+    __syncthreads();                                              // the probabilities are final; the staging region is free
+    auto vtile = [&](int t0, int buf, f4 (&vr)[U]) {
+        float* tile = region + buf * (kAttTile * hs);
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int e = tid + u * T;
-            if (e < tile4) *reinterpret_cast<f4*>(s_v + 4 * e) = vr[u];
+            if (e < tile4) {
+                const float a = s_p[min(t0 + er[u], pos)];
+                f4 pr;
+                pr.x = a * vr[u].x; pr.y = a * vr[u].y; pr.z = a * vr[u].z; pr.w = a * vr[u].w;     // cpu.rs:48 `a * vi`, rounded
+                *reinterpret_cast<f4*>(tile + 4 * e) = pr;
+            }
         }
-        __syncthreads();
-        if (t0 + kAttTile <= pos) issue(t0 + kAttTile);           // uniform
+        vissue(t0 + 2 * kAttTile, vr);
+        __syncthreads();                                          // this tile is written; the other one (read last round) is free again
         if (tid < hs) {
             const int nt = min(kAttTile, pos + 1 - t0);
-            for (int r = 0; r < nt; r++) acc = acc + s_att[scan_slot(t0 + r)] * s_v[r * hs + tid];
+            int r = 0;
+            for (; r + 16 <= nt; r += 16) {                       // 16 reads in flight, then the adds in row order
+                float v16[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) v16[u] = tile[(r + u) * hs + tid];
+#pragma unroll
+                for (int u = 0; u < 16; u++) acc = acc + v16[u];
+            }
+            for (; r < nt; r++) acc = acc + tile[r * hs + tid];
         }
+    };
+    for (int t0 = 0; t0 <= pos; t0 += 2 * kAttTile) {
+        vtile(t0, 0, va);
+        if (t0 + kAttTile <= pos) vtile(t0 + kAttTile, 1, vb);    // uniform
     }
     if (tid < hs) p.xb[col + tid] = acc;
-}
-// the loader covers a tile with U * T 16-byte loads: kAttTile * head_size / 4 <= 8 * 64 NW
-__host__ __device__ constexpr bool attn_chain_fits(int head_size, int nw) { return kAttTile * (head_size / 4) <= 8 * 64 * nw; }
-__host__ __device__ constexpr size_t attn_chain_lds_floats(int head_size, int seq_len) {
-    return (size_t)((head_size + 3) & ~3) + (size_t)kAttTile * head_size + (size_t)seq_len + (size_t)(seq_len >> 5) + 2;
+    SEQ_STAMP(13);
 }
 
 }  // namespace rama

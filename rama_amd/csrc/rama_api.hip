@@ -49,6 +49,8 @@ static int fail(int code, const char* what, const char* file, int line) {
 // ---------------------------------------------------------------- context
 
 constexpr int kSmallAttnPosDefault = 256;
+constexpr size_t kAttnChainMaxLds = 136 * 1024;      // dynamic LDS attention_chain_kernel may ask for (allowed once per device in rama_ctx_create)
+constexpr int kLongAttnPos = 256;          // parity mode: attention_chain_kernel runs 16 waves per head from this position on
 
 struct KProf {
     int kernel_id = -1;
@@ -123,6 +125,8 @@ struct rama_ctx {
     size_t pf_floats = 0;
     int host_pos = -1;                     // position of the next chained decode step (mirrors the device cursor)
     bool split_attn = false;               // variant the steps being enqueued / captured use
+    bool long_attn = false;                // parity mode: the position is >= 256 (16 waves per head in attention_chain_kernel)
+    int variant = 0;                       // attn_variant() of the steps being enqueued / captured
     bool small_attn = false;               // 4-wave attention workgroups (contexts of <= kSmallAttnPos timesteps)
     int tune_small_waves = 8, tune_small_pos = kSmallAttnPosDefault;   // waves per head and position limit of the small-attention variant
     int tune_combine_v = 1;                // split-T combine: 1 = all slice loads up front, 0 = round 1's loop
@@ -192,6 +196,10 @@ int rama_ctx_create(int device, void* hip_stream, rama_ctx** out) {
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     c->cu_count = prop.multiProcessorCount;
+    // parity mode's attention keeps two product tiles + the scores of a whole context in LDS: more than the 64 KiB a kernel gets by default
+    HIPCHK(hipFuncSetAttribute((const void*)attention_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnChainMaxLds));
+    HIPCHK(hipFuncSetAttribute((const void*)attention_chain_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnChainMaxLds));
+    HIPCHK(hipFuncSetAttribute((const void*)attention_chain_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnChainMaxLds));
     *out = c;
     return 0;
 }
@@ -445,21 +453,29 @@ static int launch_rmsnorm_chain(rama_ctx* c, float* o, const float* x, const flo
     LAUNCHCHK();
     return 0;
 }
-static int attn_chain_waves(int head_size) { return attn_chain_fits(head_size, 4) ? 4 : (attn_chain_fits(head_size, 8) ? 8 : 16); }
-static bool attn_chain_ok(int head_size, int seq_len) {
-    return head_size % 4 == 0 && attn_chain_fits(head_size, 16) && attn_chain_lds_floats(head_size, seq_len) * sizeof(float) <= 64 * 1024;
+static int attn_chain_waves(int head_size, bool long_ctx) {
+    const int want = long_ctx ? 8 : 4;
+    return attn_chain_fits(head_size, want) ? want : (attn_chain_fits(head_size, 8) ? 8 : 16);
 }
+static bool attn_chain_ok(int head_size, int seq_len) {      // the largest variant a launch may pick must fit
+    if (head_size % 4 || !attn_chain_fits(head_size, 16)) return false;
+    return attn_chain_lds_floats(head_size, seq_len, attn_chain_waves(head_size, true)) * sizeof(float) + 16 <= kAttnChainMaxLds;
+}
+// long_ctx: 8 waves per head (twice the timesteps per score round, twice the loaders of the value tiles) -- from position 256 on
 static int launch_attention_chain(rama_ctx* c, float* xb, float* att, const float* q, const float* kc_layer, const float* vc_layer,
-                                  const Ctl* ctl, int pos, int dim, int head_size, int seq_len, int n_heads) {
+                                  const Ctl* ctl, int pos, int dim, int head_size, int seq_len, int n_heads, bool long_ctx = false) {
     REQUIRE(aligned16(q) && aligned16(kc_layer) && aligned16(vc_layer) && dim % 4 == 0, RAMA_EINVAL, "attention: buffers must be 16-byte aligned");
     RefAttnParams p{};
     p.q = q; p.kc = kc_layer; p.vc = vc_layer; p.att = att; p.xb = xb; p.ctl = ctl; p.pos_val = pos;
     p.dim = dim; p.head_size = head_size; p.seq_len = seq_len;
-    const size_t lds = attn_chain_lds_floats(head_size, seq_len) * sizeof(float);
-    const int nw = attn_chain_waves(head_size);
-    if (nw == 4) RAMA_LAUNCH(c, (attention_chain_kernel<4>), dim3(n_heads), dim3(256), lds, p);
-    else if (nw == 8) RAMA_LAUNCH(c, (attention_chain_kernel<8>), dim3(n_heads), dim3(512), lds, p);
-    else RAMA_LAUNCH(c, (attention_chain_kernel<16>), dim3(n_heads), dim3(1024), lds, p);
+    const int nw = attn_chain_waves(head_size, long_ctx);
+    const size_t lds = attn_chain_lds_floats(head_size, seq_len, nw) * sizeof(float) + 16;
+    REQUIRE(lds <= kAttnChainMaxLds, RAMA_EUNSUP, "attention (parity mode): context too long for the score buffer");
+#define RAMA_ATTN_CHAIN(NW_) RAMA_LAUNCH(c, (attention_chain_kernel<NW_>), dim3(n_heads), dim3(NW_ * 64), lds, p)
+    if (nw == 4) RAMA_ATTN_CHAIN(4);
+    else if (nw == 8) RAMA_ATTN_CHAIN(8);
+    else RAMA_ATTN_CHAIN(16);
+#undef RAMA_ATTN_CHAIN
     LAUNCHCHK();
     return 0;
 }
@@ -595,6 +611,20 @@ static bool small_attn_at(const rama_ctx* c, int pos, bool split, int dim) {
     return !merge_wanted(c, dim) && pos < c->tune_small_pos;
 }
 
+// Which launches a step at `pos` consists of (one hipGraph per variant): fast mode 0 = one 16-wave workgroup per head,
+// 1 = split-T (long contexts), 2 = fewer waves per head (short contexts); parity mode 0 = 4 waves per head, 1 = 16 (pos >= 256)
+static int attn_variant(const rama_ctx* c, const rama_config* cfg, int pos) {
+    if (c->tune_ref_order) return pos >= kLongAttnPos ? 1 : 0;
+    const bool split = pos >= split_threshold(c, cfg);
+    return split ? 1 : (small_attn_at(c, pos, split, cfg->dim) ? 2 : 0);
+}
+static int apply_attn_variant(rama_ctx* c, const rama_config* cfg, int pos) {
+    c->split_attn = pos >= split_threshold(c, cfg);
+    c->small_attn = small_attn_at(c, pos, c->split_attn, cfg->dim);
+    c->long_attn = pos >= kLongAttnPos;
+    return c->variant = attn_variant(c, cfg, pos);
+}
+
 static int launch_attention(rama_ctx* c, float* xb, float* att, const float* q, const float* kc_layer,
                             const float* vc_layer, const Ctl* ctl, int pos, int dim, int head_size,
                             int seq_len, int n_heads, bool split = false) {
@@ -672,7 +702,7 @@ int rama_multi_head_attention(rama_ctx* c, float* xb, float* att, const float* q
     REQUIRE(pos >= 0 && pos < seq_len && layer >= 0 && n_heads > 0 && n_heads * head_size == dim, RAMA_EINVAL, "multi_head_attention: bad shape");
     const size_t lo = (size_t)layer * seq_len * dim;   // cpu.rs:28
     if (c->tune_ref_order && c->tune_chain && attn_chain_ok(head_size, seq_len) && aligned16(q) && aligned16(key_cache + lo) && aligned16(value_cache + lo) && dim % 4 == 0)
-        return launch_attention_chain(c, xb, att, q, key_cache + lo, value_cache + lo, nullptr, pos, dim, head_size, seq_len, n_heads);
+        return launch_attention_chain(c, xb, att, q, key_cache + lo, value_cache + lo, nullptr, pos, dim, head_size, seq_len, n_heads, pos >= 256);
     if (c->tune_ref_order) return launch_attention_ref(c, xb, att, q, key_cache + lo, value_cache + lo, nullptr, pos, dim, head_size, seq_len, n_heads);
     c->small_attn = small_attn_at(c, pos, false, dim);
     return launch_attention(c, xb, att, q, key_cache + lo, value_cache + lo, nullptr, pos, dim, head_size, seq_len, n_heads);
@@ -862,7 +892,7 @@ static int enqueue_stage_chain(rama_ctx* c, const rama_config* cfg, const rama_w
         }
         {   // :34
             KTimer kt(c, RAMA_K_ATTN);
-            rc = launch_attention_chain(c, s->xb, s->att, s->q, kc, vc, c->ctl, 0, dim, hs, cfg->seq_len, cfg->n_heads); if (rc) return rc;
+            rc = launch_attention_chain(c, s->xb, s->att, s->q, kc, vc, c->ctl, 0, dim, hs, cfg->seq_len, cfg->n_heads, c->long_attn); if (rc) return rc;
         }
         {   // :35-37: xb2 = Wo . xb; x += xb2
             KTimer kt(c, RAMA_K_WO);
@@ -1001,7 +1031,7 @@ static bool same_capture(const GraphCache& g, const rama_config* cfg, const rama
 constexpr size_t kMaxStageGraphs = 48;
 static int run_stage(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s, const rama_stage* st) {
     if (!c->graph_mode || c->kp.kernel_id >= 0) return enqueue_stage(c, cfg, w, s, st);
-    const int variant = c->split_attn ? 1 : (c->small_attn ? 2 : 0);
+    const int variant = c->variant;
     rama_ctx::StageGraph* hit = nullptr;
     for (auto& e : c->sg)
         if (e.variant == variant && !memcmp(&e.st, st, sizeof *st) && same_capture(e.g, cfg, w, s)) { hit = &e; break; }
@@ -1056,8 +1086,7 @@ int rama_forward_stage(rama_ctx* c, const rama_config* cfg, const rama_weights* 
     LAUNCHCHK();
     c->embedded_x = nullptr;
     c->host_pos = -1;
-    c->split_attn = pos >= split_threshold(c, cfg);
-    c->small_attn = small_attn_at(c, pos, c->split_attn, cfg->dim);
+    apply_attn_variant(c, cfg, pos);
     return run_stage(c, cfg, w, s, st);
 }
 
@@ -1076,8 +1105,7 @@ int rama_forward_stage_devtok(rama_ctx* c, const rama_config* cfg, const rama_we
     LAUNCHCHK();
     c->embedded_x = nullptr;
     c->host_pos = -1;
-    c->split_attn = pos >= split_threshold(c, cfg);
-    c->small_attn = small_attn_at(c, pos, c->split_attn, cfg->dim);
+    apply_attn_variant(c, cfg, pos);
     return run_stage(c, cfg, w, s, st);
 }
 
@@ -1511,17 +1539,12 @@ int rama_decode_steps(rama_ctx* c, const rama_config* cfg, const rama_weights* w
     if (c->samp_T != 0.0f) { rc = ensure_topp_scratch(c, cfg->vocab_size); if (rc) return rc; }
     REQUIRE(c->host_pos + n_steps <= cfg->seq_len, RAMA_EINVAL, "decode_steps: would run past seq_len");
     const bool graphs = c->graph_mode && c->kp.kernel_id < 0;
-    auto variant_at = [&](int pos) {
-        const bool split = pos >= split_threshold(c, cfg);
-        return split ? 1 : (small_attn_at(c, pos, split, cfg->dim) ? 2 : 0);
-    };
+    auto variant_at = [&](int pos) { return attn_variant(c, cfg, pos); };
     for (int i = 0; i < n_steps;) {
         // the attention variant depends on the position, which the host mirrors step by step
-        c->split_attn = c->host_pos >= split_threshold(c, cfg);
-        c->small_attn = small_attn_at(c, c->host_pos, c->split_attn, cfg->dim);
+        const int v = apply_attn_variant(c, cfg, c->host_pos);
         int take = 1;
         if (graphs) {
-            const int v = variant_at(c->host_pos);
             const int M = c->tune_graph_steps > 0 ? c->tune_graph_steps : (cfg->dim <= 1024 ? 4 : 1);
             if (M > 1 && n_steps - i >= M && variant_at(c->host_pos + M - 1) == v) take = M;   // the variant changes at most once, monotonically
             GraphCache& g = c->gc[v + (take > 1 ? 3 : 0)];

@@ -325,3 +325,32 @@ def test_exact_sequential_sums(dev, n, scale):
         dev.softmax(ts, n)
         O.softmax(s, n)
         assert_bits_equal(dev.download(ts), s, f"softmax n={n} variant {vi}")
+
+
+@pytest.mark.parametrize("n_heads,hs", [(2, 128), (3, 64)])
+def test_model_long_context_bit_exact(dev, n_heads, hs):
+    """parity mode over a pre-filled cache at positions around the 4-wave / 16-wave switch (256) and deep into the
+    context (the exact sequential softmax sum over ~2000 terms, ~30 value tiles): every logit bit as the oracle's"""
+    import rama_amd
+    from .helpers import to_rama_cfg
+    dim, seq = n_heads * hs, 2048
+    cfg = O.Config(dim, 2 * dim, 1, n_heads, n_heads, 64, seq, False)
+    rope = S.rope_tables(seq, hs)
+    w = S.synth_weights(cfg, 11, rope=rope)
+    rng = np.random.default_rng(11)
+    kc = rng.standard_normal(seq * dim).astype(np.float32)
+    vc = rng.standard_normal(seq * dim).astype(np.float32)
+    orc = O.Oracle(cfg, w)
+    model = rama_amd.Model.synth(dev, to_rama_cfg(cfg), 11, rope=rope)
+    eng = rama_amd.Engine(dev, model)
+    for graph in (False, True):
+        eng.set_graph_mode(graph)
+        for pos in (255, 256, 257, 1000, 2047):
+            orc.s["key_cache"][:] = kc; orc.s["value_cache"][:] = vc
+            eng.set_buffer("key_cache", kc); eng.set_buffer("value_cache", vc)
+            lo = orc.forward(5, pos).copy()
+            eng.forward(5, pos)
+            assert_bits_equal(eng.logits(), lo, f"long context pos {pos} graph {graph}")
+            assert_bits_equal(eng.buffer("xb2", dim), orc.s["xb2"], f"long context pos {pos} xb2")
+    eng.set_graph_mode(False)
+    eng.free(); model.free()

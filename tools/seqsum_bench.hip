@@ -28,6 +28,34 @@ int main(int argc, char** argv) {
     const char* names[] = {"load+squares+barrier", "approx prefix", "classify", "maps", "seg scan + barrier", "walk + barrier", "scale + store"};
     for (int i = 0; i < 6; i++) printf("  %-22s %6.2f us\n", names[i], (double)(st[i + 1] - st[i]) * 0.01);
     printf("  debug: nseq %llu smask %016llx %016llx %016llx %016llx head %g\n", st[8], st[9], st[10], st[11], st[12], *(float*)&st[15]);
+    {   // the parity-mode attention at a long context: 32 heads x 128, position argv[2] (default 1900)
+        const int pos = argc > 2 ? atoi(argv[2]) : 1900, H = 32, hs = 128, dim = H * hs, seq = 2048;
+        float *q, *kc, *vc, *xb;
+        CK(hipMalloc(&q, dim * 4)); CK(hipMalloc(&xb, dim * 4)); CK(hipMalloc(&kc, (size_t)seq * dim * 4)); CK(hipMalloc(&vc, (size_t)seq * dim * 4));
+        std::vector<float> h((size_t)seq * dim);
+        for (auto& v : h) v = nd(rng);
+        CK(hipMemcpy(kc, h.data(), h.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(vc, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(q, h.data(), dim * 4, hipMemcpyHostToDevice));
+        RefAttnParams ap{}; ap.q = q; ap.kc = kc; ap.vc = vc; ap.xb = xb; ap.pos_val = pos; ap.dim = dim; ap.head_size = hs; ap.seq_len = seq;
+        CK(hipFuncSetAttribute((const void*)attention_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+        CK(hipFuncSetAttribute((const void*)attention_chain_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+        for (int nw : {4, 8}) {
+            const size_t alds = attn_chain_lds_floats(hs, seq, nw) * 4 + 16;
+            for (int rep = 0; rep < 2; rep++) {
+                CK(hipEventRecord(e0, 0));
+                for (int i = 0; i < 20; i++) {
+                    if (nw == 4) hipLaunchKernelGGL((attention_chain_kernel<4>), dim3(H), dim3(256), alds, 0, ap);
+                    else hipLaunchKernelGGL((attention_chain_kernel<8>), dim3(H), dim3(512), alds, 0, ap);
+                }
+                CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                if (rep) printf("attention_chain_kernel<%d> pos %d: %.2f us per launch\n", nw, pos, ms * 1e3 / 20);
+            }
+            CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(rama::g_seq_stamps), sizeof st));
+            printf("   q %.2f | scores %.2f | max+exp %.2f | sum %.2f | divide %.2f | values %.2f us\n", (st[9] - st[8]) * 0.01 * 0 + 0.0, (st[9] - st[8]) * 0.01, (st[10] - st[9]) * 0.01,
+                   (st[11] - st[10]) * 0.01, (st[12] - st[11]) * 0.01, (st[13] - st[12]) * 0.01);
+        }
+    }
     unsigned ps[2]; CK(hipMemcpyFromSymbol(ps, HIP_SYMBOL(rama::g_pred_stats), sizeof ps));
     printf("  held %u fell back %u\n", ps[0], ps[1]);
     return 0;
