@@ -21,10 +21,13 @@ class Tokenizer:
                 self.vocab_scores.append(score)
                 self.word_token_map[s] = idx     # HashMap::insert: a later duplicate wins
 
+    # str::trim (bpe.rs:53) strips the Unicode White_Space code points
+    WHITE_SPACE = "".join(map(chr, [0x09, 0x0A, 0x0B, 0x0C, 0x0D, 0x20, 0x85, 0xA0, 0x1680, *range(0x2000, 0x200B), 0x2028, 0x2029, 0x202F, 0x205F, 0x3000]))
+
     def encode(self, s: str):
         """bpe.rs:50-96"""
         tokens = []
-        for c in s.strip(" \t\n\r\v\f"):
+        for c in s.strip(self.WHITE_SPACE):
             if c == "\n":
                 continue
             tokens.append(self.word_token_map[c])       # KeyError = the reference's unwrap() panic

@@ -41,14 +41,38 @@ struct Tokenizer {
         return t;
     }
 
-    static bool is_space(unsigned char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; }
+    // str::trim (bpe.rs:53) strips the code points with the Unicode White_Space property, not just ASCII blanks
+    static bool is_white_space(uint32_t c) {
+        return (c >= 0x09 && c <= 0x0D) || c == 0x20 || c == 0x85 || c == 0xA0 || c == 0x1680 || (c >= 0x2000 && c <= 0x200A) ||
+               c == 0x2028 || c == 0x2029 || c == 0x202F || c == 0x205F || c == 0x3000;
+    }
+    // the UTF-8 scalar that starts at text[i] (n = its length); malformed bytes count as one-byte characters that are no white space
+    static uint32_t scalar_at(const std::string& text, size_t i, size_t end, size_t& n) {
+        const unsigned char c = (unsigned char)text[i];
+        n = c < 0x80 ? 1 : (c >> 5) == 6 ? 2 : (c >> 4) == 14 ? 3 : (c >> 3) == 30 ? 4 : 1;
+        if (i + n > end) { n = 1; return 0xFFFFFFFFu; }
+        if (n == 1) return c < 0x80 ? c : 0xFFFFFFFFu;
+        uint32_t v = c & (0xFF >> (n + 1));
+        for (size_t k = 1; k < n; k++) {
+            const unsigned char d = (unsigned char)text[i + k];
+            if ((d >> 6) != 2) { n = 1; return 0xFFFFFFFFu; }
+            v = (v << 6) | (d & 0x3F);
+        }
+        return v;
+    }
 
     // bpe.rs:50-96.  Throws where the reference panics (a character missing from the
     // vocabulary, bpe.rs:55; a prompt that trims to nothing, bpe.rs:66 `len() - 1`).
     std::vector<size_t> encode(const std::string& text) const {
         size_t a = 0, b = text.size();
-        while (a < b && is_space((unsigned char)text[a])) a++;     // str::trim (ASCII white space)
-        while (b > a && is_space((unsigned char)text[b - 1])) b--;
+        for (size_t n; a < b && is_white_space(scalar_at(text, a, b, n)); a += n) {}       // str::trim, front
+        while (b > a) {                                            // and back: step to the start of the last scalar
+            size_t st = b - 1;
+            while (st > a && ((unsigned char)text[st] >> 6) == 2) st--;
+            size_t n;
+            if (!is_white_space(scalar_at(text, st, b, n)) || st + n != b) break;
+            b = st;
+        }
         std::vector<size_t> tokens;
         for (size_t i = a; i < b;) {                               // .chars(): one UTF-8 scalar at a time
             unsigned char c = (unsigned char)text[i];

@@ -934,73 +934,19 @@ __global__ __launch_bounds__(1024) void argmax_kernel(ArgmaxParams p) {
 
 // ---------------------------------------------------------------- top-p sampling on the device
 // Device::sample for temperature != 0 (cpu.rs:168-178 + sample_top_q, infer.rs:55-85), without the
-// reference GPU path's 128 KB logits download per token (gpu.rs:153):
-//   topp_prepare_kernel   logits (/ T if T < 1) -> softmax (max, exp, sum, divide) -> keys[i] = p_i
-//                         if p_i > (1 - topp) / (n - 1) else -1, vals[i] = i, *m = #candidates
-//   (stable descending radix sort of the n pairs, hipCUB)      = the reference's stable sort of
-//                         the filtered list: equal probabilities keep ascending index order
+// reference GPU path's 128 KB logits download per token (gpu.rs:153).  The ordering (softmax, cutoff,
+// stable descending order) is topp_sort.hpp; below: the parameters and the generic pick --
 //   topp_pick_kernel      cum += p in sorted order until cum > topp (sequential fp32, one thread,
 //                         staged through LDS); r = u * cum; first i < last with r < cum_i, else last
-// The only arithmetic that differs from the CPU path is the order of the softmax's sum (the
-// reference's own rayon sum has no fixed order either) and the device expf.
+// for candidate lists longer than one workgroup's LDS (topp_sort.hpp's topp_pick_scan_kernel otherwise).
 struct ToppParams {
     const float* logits; int n;
     float temperature, topp, u;
-    float* keys; int* vals;          // [n] unsorted pairs (prepare) -- sorted pairs (pick)
+    float* keys; int* vals;          // [n] the kept probabilities / their indices in the reference's order
     float* prefix;                   // [n] scratch: running sums of the sorted probabilities
     int* m;                          // number of candidates
     unsigned* err;                   // set to 1 when no probability exceeds the cutoff
 };
-
-__global__ __launch_bounds__(1024) void topp_prepare_kernel(ToppParams p) {
-    __shared__ float s_r[16];
-    __shared__ int s_c[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool scale = p.temperature < 1.0f;                       // cpu.rs:170-172: T > 1 has no effect
-    auto x_of = [&](int i) { const float v = p.logits[i]; return scale ? v / p.temperature : v; };
-    float mx = -INFINITY;
-    for (int i = tid; i < p.n; i += 1024) mx = fmaxf(mx, x_of(i));
-    mx = wave_max(mx);
-    if (lane == 0) s_r[wave] = mx;
-    __syncthreads();
-    mx = s_r[0];
-#pragma unroll
-    for (int w = 1; w < 16; w++) mx = fmaxf(mx, s_r[w]);
-    __syncthreads();
-    float sum = 0.0f;
-    for (int i = tid; i < p.n; i += 1024) { const float e = expf(x_of(i) - mx); p.keys[i] = e; sum += e; }
-    sum = wave_sum(sum);
-    if (lane == 0) s_r[wave] = sum;
-    __syncthreads();
-    {
-        float t[16];
-#pragma unroll
-        for (int w = 0; w < 16; w++) t[w] = s_r[w];
-#pragma unroll
-        for (int n = 16; n > 1; n >>= 1)
-#pragma unroll
-            for (int w = 0; w < n / 2; w++) t[w] = t[2 * w] + t[2 * w + 1];
-        sum = t[0];
-    }
-    const float cutoff = (1.0f - p.topp) / (float)(p.n - 1);      // infer.rs:56
-    int cnt = 0;
-    for (int i = tid; i < p.n; i += 1024) {
-        const float pr = p.keys[i] / sum;
-        const bool keep = pr > cutoff;
-        p.keys[i] = keep ? pr : -1.0f;
-        p.vals[i] = i;
-        cnt += keep;
-    }
-    cnt = wave_sum_i(cnt);
-    if (lane == 0) s_c[wave] = cnt;
-    __syncthreads();
-    if (tid == 0) {
-        int m = 0;
-        for (int w = 0; w < 16; w++) m += s_c[w];
-        *p.m = m;
-        if (m == 0 && p.err) *p.err = 1u;
-    }
-}
 
 constexpr int kToppChunk = 4096;
 __global__ __launch_bounds__(1024) void topp_pick_kernel(ToppParams p, ArgmaxParams fin) {

@@ -8,7 +8,6 @@
 #include "prefill_mfma.hpp"
 #include "ref_order.hpp"
 #include "chain.hpp"
-#include <hipcub/hipcub.hpp>
 
 #include <hip/hip_ext.h>   // hipExtLaunchKernelGGL: start/stop events carried by the dispatch itself
 
@@ -101,14 +100,14 @@ struct rama_ctx {
     float samp_T = 0.0f, samp_topp = 0.9f, samp_u = 0.0f;
     float* topp_keys[2] = {nullptr, nullptr}; int* topp_vals[2] = {nullptr, nullptr};
     float* topp_prefix = nullptr; int* topp_m = nullptr; unsigned* topp_err = nullptr;
-    void* topp_tmp = nullptr; size_t topp_tmp_bytes = 0; int topp_cap = 0;
+    int topp_cap = 0;
     float* topp_bp = nullptr; int* topp_bi = nullptr; int* topp_bcount = nullptr;       // topp_sort.hpp
     int tune_norm_in_gemm = 1;              // token-batch passes: the rmsnorm's per-token scale is applied by the consuming GEMM (one launch per norm instead of two)
     int tune_tiled = 1;                     // token-batch GEMMs read the model's tile-order weight copy when it exists
     int tune_prefill_attn = 1;              // 1: prefill passes run attention as MFMA tiles, 16 queries per workgroup (prefill_attn.hpp)
     int tune_graph_steps = -1;              // decode steps captured per hipGraph (the cursor lives on the device, so steps are identical); -1: 4 for dim <= 1024, else 1
     int tune_attn_u = 8;                    // cache rows per lane and round in the split-T attention (8 | 16; 16 measured no faster)
-    int tune_topp_sort = 1;                 // 0: library radix sort for every vocabulary size
+    int tune_topp_sort = 1;                 // 0: ranks through global memory (topp_rank_global_kernel) for every vocabulary size
     int tune_topp_keep_sums = 0;            // 1: the scan sampler also writes its running sums to global memory (tests)
     int tune_split_pos = -1;               // attention runs split-T (+ combine launch) from this position on; -1 = by model size
     int tune_resid_r2 = 2;                 // Wo / W2 under geometry 3: 0 = 4-row workgroups, 1 = 2 rows x 8 waves (+0.45 %),
@@ -225,7 +224,7 @@ int rama_ctx_destroy(rama_ctx* c) {
     for (auto e : c->kp.ev) hipEventDestroy(e);
     hipFree(c->ctl); hipFree(c->out); hipFree(c->forced); hipFree(c->argmax_result); hipFree(c->pbar); hipFree(c->attn_counter); hipFree(c->attn_part);
     for (int i = 0; i < 2; i++) { hipFree(c->topp_keys[i]); hipFree(c->topp_vals[i]); }
-    hipFree(c->topp_prefix); hipFree(c->topp_m); hipFree(c->topp_err); hipFree(c->topp_tmp); hipFree(c->pf_blob);
+    hipFree(c->topp_prefix); hipFree(c->topp_m); hipFree(c->topp_err); hipFree(c->pf_blob);
     hipFree(c->topp_bp); hipFree(c->topp_bi); hipFree(c->topp_bcount);
     hipHostFree(c->pinned_int); hipHostFree(c->pinned_tok);
     hipEventDestroy(c->t0); hipEventDestroy(c->t1);
@@ -1109,31 +1108,23 @@ int rama_forward_stage_devtok(rama_ctx* c, const rama_config* cfg, const rama_we
     return run_stage(c, cfg, w, s, st);
 }
 
-// ---- device top-p sampler (topp_sort.hpp: block sorts + ranks for n <= 32768, else kernels.hpp's
-//      topp_prepare_kernel + hipCUB stable radix sort; then topp_pick_kernel)
+// ---- device top-p sampler (topp_sort.hpp: block sorts + ranks + the exact running sum; every kernel hand-written)
 
 // scratch for n logits; called outside any stream capture
 static int ensure_topp_scratch(rama_ctx* c, int n) {
     if (n <= c->topp_cap) return 0;
     if (set_device(c)) return 1;
     HIPCHK(hipStreamSynchronize(c->stream));
-    for (int i = 0; i < 2; i++) {
-        hipFree(c->topp_keys[i]); hipFree(c->topp_vals[i]);
-        HIPCHK(hipMalloc(&c->topp_keys[i], sizeof(float) * n));
-        HIPCHK(hipMalloc(&c->topp_vals[i], sizeof(int) * n));
-    }
+    const size_t nblk = ((size_t)n + kToppBlock - 1) / kToppBlock;
+    hipFree(c->topp_keys[1]); hipFree(c->topp_vals[1]);
+    HIPCHK(hipMalloc(&c->topp_keys[1], sizeof(float) * n));
+    HIPCHK(hipMalloc(&c->topp_vals[1], sizeof(int) * n));
     hipFree(c->topp_prefix); HIPCHK(hipMalloc(&c->topp_prefix, sizeof(float) * n));
-    if (!c->topp_m) {
-        HIPCHK(hipMalloc(&c->topp_m, sizeof(int))); HIPCHK(hipMalloc(&c->topp_err, sizeof(unsigned))); HIPCHK(hipMemset(c->topp_err, 0, sizeof(unsigned)));
-        HIPCHK(hipMalloc(&c->topp_bp, sizeof(float) * kToppBlock * kToppMaxBlocks));
-        HIPCHK(hipMalloc(&c->topp_bi, sizeof(int) * kToppBlock * kToppMaxBlocks));
-        HIPCHK(hipMalloc(&c->topp_bcount, sizeof(int) * kToppMaxBlocks));
-    }
-    size_t bytes = 0;
-    HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes, c->topp_keys[0], c->topp_keys[1], c->topp_vals[0], c->topp_vals[1], n, 0, 32, c->stream));
-    hipFree(c->topp_tmp); c->topp_tmp = nullptr;
-    HIPCHK(hipMalloc(&c->topp_tmp, bytes ? bytes : 16));
-    c->topp_tmp_bytes = bytes;
+    if (!c->topp_m) { HIPCHK(hipMalloc(&c->topp_m, sizeof(int))); HIPCHK(hipMalloc(&c->topp_err, sizeof(unsigned))); HIPCHK(hipMemset(c->topp_err, 0, sizeof(unsigned))); }
+    hipFree(c->topp_bp); hipFree(c->topp_bi); hipFree(c->topp_bcount);
+    HIPCHK(hipMalloc(&c->topp_bp, sizeof(float) * kToppBlock * std::max<size_t>(nblk, kToppMaxBlocks)));
+    HIPCHK(hipMalloc(&c->topp_bi, sizeof(int) * kToppBlock * std::max<size_t>(nblk, kToppMaxBlocks)));
+    HIPCHK(hipMalloc(&c->topp_bcount, sizeof(int) * std::max<size_t>(nblk, kToppMaxBlocks)));
     c->topp_cap = n;
     return 0;
 }
@@ -1149,27 +1140,22 @@ static int enqueue_sample(rama_ctx* c, ArgmaxParams fin, float temperature, floa
     REQUIRE(fin.n > 1 && fin.n <= c->topp_cap, RAMA_EINVAL, "top-p sampler: scratch not prepared");
     ToppParams tp{};
     tp.logits = fin.logits; tp.n = fin.n; tp.temperature = temperature; tp.topp = topp; tp.u = u;
-    tp.keys = c->topp_keys[0]; tp.vals = c->topp_vals[0]; tp.prefix = c->topp_prefix; tp.m = c->topp_m; tp.err = c->topp_err;
-    const bool lds_path = c->tune_topp_sort && fin.n <= kToppBlock * kToppMaxBlocks;     // the list fits one workgroup's LDS
-    if (lds_path) {
-        // block sorts in LDS + rank by binary search (topp_sort.hpp): 2 launches
-        ToppSortParams sp{};
-        sp.logits = fin.logits; sp.n = fin.n; sp.temperature = temperature; sp.topp = topp;
-        sp.bp = c->topp_bp; sp.bi = c->topp_bi; sp.bcount = c->topp_bcount; sp.keys = c->topp_keys[1]; sp.vals = c->topp_vals[1];
-        sp.m = c->topp_m; sp.err = c->topp_err; sp.nblk = (fin.n + kToppBlock - 1) / kToppBlock;
-        hipLaunchKernelGGL(topp_blocksort_kernel, dim3(sp.nblk), dim3(1024), 0, c->stream, sp);
-        LAUNCHCHK();
-        hipLaunchKernelGGL(topp_rank_kernel<kToppMaxBlocks>, dim3(sp.nblk * (kToppBlock / kRankThreads)), dim3(kRankThreads), 0, c->stream, sp);
-        LAUNCHCHK();
-    } else {
-        hipLaunchKernelGGL(topp_prepare_kernel, dim3(1), dim3(1024), 0, c->stream, tp);
-        LAUNCHCHK();
-        size_t bytes = c->topp_tmp_bytes;
-        HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(c->topp_tmp, bytes, c->topp_keys[0], c->topp_keys[1], c->topp_vals[0], c->topp_vals[1],
-                                                            fin.n, 0, 32, c->stream));
-    }
-    tp.keys = c->topp_keys[1]; tp.vals = c->topp_vals[1];
+    tp.keys = c->topp_keys[1]; tp.vals = c->topp_vals[1]; tp.prefix = c->topp_prefix; tp.m = c->topp_m; tp.err = c->topp_err;
+    // block sorts in LDS, then every kept entry's rank by binary searches in the other blocks (topp_sort.hpp): through LDS
+    // when the whole list fits one workgroup's LDS (n <= 32768), through global memory otherwise (or with "topp_sort" = 0)
+    const bool lds_path = c->tune_topp_sort && fin.n <= kToppBlock * kToppMaxBlocks;
+    ToppSortParams sp{};
+    sp.logits = fin.logits; sp.n = fin.n; sp.temperature = temperature; sp.topp = topp;
+    sp.bp = c->topp_bp; sp.bi = c->topp_bi; sp.bcount = c->topp_bcount; sp.keys = c->topp_keys[1]; sp.vals = c->topp_vals[1];
+    sp.m = c->topp_m; sp.err = c->topp_err; sp.nblk = (fin.n + kToppBlock - 1) / kToppBlock;
+    if (fin.n <= kToppBlock * kToppMaxBlocks) hipLaunchKernelGGL(topp_blocksort_kernel<false>, dim3(sp.nblk), dim3(1024), 0, c->stream, sp);
+    else hipLaunchKernelGGL(topp_blocksort_kernel<true>, dim3(sp.nblk), dim3(1024), 0, c->stream, sp);
+    LAUNCHCHK();
+    if (lds_path) hipLaunchKernelGGL(topp_rank_kernel<kToppMaxBlocks>, dim3(sp.nblk * (kToppBlock / kRankThreads)), dim3(kRankThreads), 0, c->stream, sp);
+    else hipLaunchKernelGGL(topp_rank_global_kernel, dim3(sp.nblk * (kToppBlock / 256)), dim3(256), 0, c->stream, sp);
+    LAUNCHCHK();
     if (lds_path && !c->tune_topp_keep_sums) tp.prefix = nullptr;
+    // the running sums: the exact parallel scan with the list in LDS, or (longer lists) the staged lane ripple
     if (lds_path) hipLaunchKernelGGL(topp_pick_scan_kernel, dim3(1), dim3(1024), 0, c->stream, tp, fin);
     else hipLaunchKernelGGL(topp_pick_kernel, dim3(1), dim3(1024), 0, c->stream, tp, fin);
     LAUNCHCHK();

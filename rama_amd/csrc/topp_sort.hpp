@@ -1,10 +1,9 @@
 // Ordering step of the device top-p sampler (Device::sample, cpu.rs:168-178 + sample_top_q,
-// infer.rs:55-85) for vocabularies up to 32768 entries: two launches instead of a library radix sort
-// of all n pairs.
+// infer.rs:55-85): two launches, any vocabulary size, no library sort.
 //
 //   topp_blocksort_kernel   one workgroup per 2048 logits.  Every workgroup repeats the softmax
 //                           statistics over the whole vector (max, then sum of exp in the same
-//                           per-thread order as topp_prepare_kernel, so all of them hold the same
+//                           per-thread order everywhere, so all of them hold the same
 //                           bits), keeps the entries of its slice with p > (1 - topp)/(n - 1)
 //                           (infer.rs:56-63) and sorts them in LDS.
 //   topp_rank_kernel        a kept entry's place in the whole order = its place in its block + the
@@ -30,7 +29,7 @@ __device__ unsigned long long g_topp_stamps[64];
 #endif
 
 constexpr int kToppBlock = 2048;        // logits per sorting workgroup
-constexpr int kToppMaxBlocks = 16;      // => n <= 32768 on this path; larger vocabularies take the radix sort
+constexpr int kToppMaxBlocks = 16;      // => n <= 32768 on the LDS-rank path; larger vocabularies rank through global memory (topp_rank_global_kernel)
 
 struct ToppSortParams {
     const float* logits; int n;
@@ -48,6 +47,9 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// BIG: n > 32768 -- the softmax statistics loop over the logits instead of holding them in registers (same
+// per-thread order: ascending i = tid + 1024 k, then the wave tree, then the 16-wave tree)
+template <bool BIG>
 __global__ __launch_bounds__(1024) void topp_blocksort_kernel(ToppSortParams p) {
     __shared__ float s_r[16];
     __shared__ unsigned long long s_k[2][kToppBlock];
@@ -56,17 +58,21 @@ __global__ __launch_bounds__(1024) void topp_blocksort_kernel(ToppSortParams p) 
     const bool scale = p.temperature < 1.0f;                       // cpu.rs:170-172: T > 1 has no effect
     TOPP_STAMP(0);
     // thread t owns logits t, t + 1024, ... (n <= 32768: at most 32 of them, all requested at once)
-    float x[32];
+    float x[BIG ? 1 : 32];
+    float mx = -INFINITY;
+    if (!BIG) {
 #pragma unroll
-    for (int k = 0; k < 32; k++) {
-        const int i = tid + 1024 * k;
-        const float v = i < p.n ? p.logits[i] : -INFINITY;
-        x[k] = scale ? v / p.temperature : v;
+        for (int k = 0; k < 32; k++) {
+            const int i = tid + 1024 * k;
+            const float v = i < p.n ? p.logits[i] : -INFINITY;
+            x[BIG ? 0 : k] = scale ? v / p.temperature : v;
+        }
+#pragma unroll
+        for (int k = 0; k < 32; k++) mx = fmaxf(mx, x[BIG ? 0 : k]);
+    } else {
+        for (int i = tid; i < p.n; i += 1024) { const float v = p.logits[i]; mx = fmaxf(mx, scale ? v / p.temperature : v); }
     }
     if (tid == 0) s_n = 0;
-    float mx = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < 32; k++) mx = fmaxf(mx, x[k]);
     mx = wave_max(mx);
     if (lane == 0) s_r[wave] = mx;
     __syncthreads();
@@ -75,12 +81,15 @@ __global__ __launch_bounds__(1024) void topp_blocksort_kernel(ToppSortParams p) 
     for (int w = 1; w < 16; w++) mx = fmaxf(mx, s_r[w]);
     __syncthreads();
     TOPP_STAMP(1);
-    // sum of exp: per thread in ascending index order, wave tree, then the 16-wave tree -- the order
-    // topp_prepare_kernel uses, so both sorting paths divide by the same sum
+    // sum of exp: per thread in ascending index order, wave tree, then the 16-wave tree
     float sum = 0.0f;
+    if (!BIG) {
 #pragma unroll
-    for (int k = 0; k < 32; k++)
-        if (tid + 1024 * k < p.n) sum += expf(x[k] - mx);
+        for (int k = 0; k < 32; k++)
+            if (tid + 1024 * k < p.n) sum += expf(x[BIG ? 0 : k] - mx);
+    } else {
+        for (int i = tid; i < p.n; i += 1024) { const float v = p.logits[i]; sum += expf((scale ? v / p.temperature : v) - mx); }
+    }
     sum = wave_sum(sum);
     if (lane == 0) s_r[wave] = sum;
     __syncthreads();
@@ -229,6 +238,49 @@ __global__ __launch_bounds__(kRankThreads) void topp_rank_kernel(ToppSortParams 
 #pragma unroll
     for (int o = 0; o < NB; o++) rank += pos[o];
     TOPP_STAMP(10);
+    p.keys[rank] = __uint_as_float(key);
+    p.vals[rank] = p.bi[(size_t)b * kToppBlock + s];
+}
+
+// The same ranking for ANY number of blocks (vocabularies above 32768 entries; rama_set_tuning "topp_sort" = 0 anywhere):
+// the other blocks' sorted probabilities are probed in global memory (L2) instead of LDS, eight blocks' probes of a
+// step in flight together.  Replaces the library radix sort of rounds 1-2: no library kernel is left in the product.
+__global__ __launch_bounds__(256) void topp_rank_global_kernel(ToppSortParams p) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const int b = g / kToppBlock, s = g % kToppBlock;              // b is uniform over the workgroup (2048 % 256 == 0)
+    if (g == 0) {
+        int total = 0;
+        for (int o = 0; o < p.nblk; o++) total += p.bcount[o];
+        *p.m = total;
+        if (total == 0 && p.err) *p.err = 1u;
+    }
+    if (b >= p.nblk) return;
+    const int mine = p.bcount[b];
+    if (s >= mine) return;
+    const unsigned key = __float_as_uint(p.bp[(size_t)b * kToppBlock + s]);
+    int rank = s;
+    for (int o0 = 0; o0 < p.nblk; o0 += 8) {
+        int cnt[8], pos[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const int o = o0 + q; cnt[q] = (o < p.nblk && o != b) ? p.bcount[o] : 0; pos[q] = 0; }
+        for (int step = kToppBlock; step >= 1; step >>= 1) {         // pos grows by every power of two whose last covered entry still precedes
+            unsigned probe[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int o = o0 + q;
+                const int j = min(pos[q] + step - 1, kToppBlock - 1);
+                probe[q] = cnt[q] > 0 ? __float_as_uint(p.bp[(size_t)min(o, p.nblk - 1) * kToppBlock + j]) : 0u;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int o = o0 + q;
+                const bool precedes = o < b ? probe[q] >= key : probe[q] > key;
+                pos[q] += (pos[q] + step <= cnt[q] && precedes) ? step : 0;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) rank += pos[q];
+    }
     p.keys[rank] = __uint_as_float(key);
     p.vals[rank] = p.bi[(size_t)b * kToppBlock + s];
 }

@@ -307,11 +307,11 @@ def test_sample_topp_dev_ties_keep_index_order(dev):
         assert _topp_dev(dev, x, 1.0, 0.9, u) == O.sample(x.copy(), 1.0, 0.9, u)
 
 
-@pytest.mark.parametrize("n", [2047, 2048, 2049, 4096, 31999, 32768, 32769])
+@pytest.mark.parametrize("n", [2047, 2048, 2049, 4096, 31999, 32768, 32769, 50257, 131072])
 @pytest.mark.parametrize("scale", [0.05, 3.0, 12.0])
 def test_sample_topp_dev_both_orderings_agree(dev, n, scale):
-    """the block-sort + rank ordering (csrc/topp_sort.hpp, n <= 32768) and the library radix sort give
-    the same token as the oracle at the block-size boundaries; 32769 takes the radix sort either way"""
+    """ranking through LDS (n <= 32768) and through global memory (csrc/topp_sort.hpp topp_rank_global_kernel: any n,
+    "topp_sort" = 0) give the same token as the oracle at the block-size boundaries and beyond one workgroup's LDS"""
     from rama_amd._lib import check
     x = rnd(n, 100 + n % 97, scale)
     x[[0, n // 2, n - 1]] = x.max()                      # equal maxima in the first, a middle and the last block
@@ -325,7 +325,10 @@ def test_sample_topp_dev_both_orderings_agree(dev, n, scale):
         finally:
             check(dev.lib.rama_set_tuning(dev.ctx, b"topp_sort", 1))
         assert got[1] == got[0], (n, scale, temperature, topp, u, got, want)
-        if u * topp <= 0.9:                               # away from the far tail (see the test above)
+        # away from the far tail (see the test above); a flat distribution over 131072 entries is skipped: its 1e5 running
+        # sums of 7.6e-6 each round by 0.4 % of an element per add, so one ulp in the softmax sum (whose order the
+        # reference does not fix) moves the drawn index by thousands
+        if u * topp <= 0.9 and not (n > 100000 and scale < 1.0):
             assert got[1] == want, (n, scale, temperature, topp, u, got, want)
 
 

@@ -88,6 +88,25 @@ def test_tokenizer_edge_cases(tmp_path):
     assert run_tool(tmp_path / "missing.bin", 4, "encode", "a").returncode == 101
 
 
+def test_trim_is_unicode_white_space(tmp_path):
+    """str::trim (bpe.rs:53) strips every White_Space code point at both ends -- U+00A0, U+2003, U+3000, U+0085 ... --
+    and nothing else (U+200B ZERO WIDTH SPACE and U+001F are no white space for Rust: they reach the vocabulary lookup)"""
+    entries = synthetic_vocab(40, 5)
+    p = tmp_path / "tok.bin"
+    write_tokenizer(p, entries)
+    tok = Tokenizer(p, len(entries))
+    want = [str(v) for v in tok.encode("abc")]
+    for pad in ("\u00a0", "\u2003", "\u3000", "\u0085", "\u1680 \t", "\u2028\u2029", "\u202f\u205f"):
+        r = run_tool(p, len(entries), "encode", pad + "abc" + pad)
+        assert r.returncode == 0 and r.stdout.split() == want, (pad.encode("unicode_escape"), r.stderr)
+        assert tok.encode(pad + "abc" + pad) == tok.encode("abc")
+    for nonspace in ("\u200b", "\u001f"):
+        assert run_tool(p, len(entries), "encode", nonspace + "abc").returncode == 101      # not trimmed, not in the vocabulary
+        with pytest.raises(KeyError):
+            tok.encode(nonspace + "abc")
+    assert run_tool(p, len(entries), "encode", "\u3000\u00a0").returncode == 101          # trims to nothing
+
+
 @pytest.mark.skipif(not REF_TOK.exists(), reason="reference tokenizer.bin only exists in the build container")
 def test_reference_tokenizer_prompt_ids():
     """'once upon a time' -> [10646, 2501, 263, 931] (no sentencepiece dummy prefix)"""
