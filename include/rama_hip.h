@@ -188,6 +188,17 @@ int  rama_prefill(rama_ctx *ctx, const rama_config *cfg, const rama_weights *w, 
 int  rama_decode_batch(rama_ctx *ctx, const rama_config *cfg, const rama_weights *w,
                        const rama_run_state *states, const int32_t *tokens_host,
                        const int32_t *positions_host, int n_seq);
+/* The same pass chained on the device: rama_decode_batch_begin uploads every sequence's (token, position) once;
+ * each step of rama_decode_batch_steps ends with one argmax per sequence (Device::sample at temperature 0, ties to the
+ * last index) that writes the sequence's next token and advances its position in device memory, so a step needs no
+ * host round trip and -- in graph mode -- is ONE hipGraph replay.  rama_decode_batch_tokens downloads what the
+ * sequences produced, out_host[s * max_per_seq + k] = token k of sequence s.  position_i + max_steps <= seq_len.
+ * (Fast mode only; the logits stay in the pass's scratch, states[i].logits is not written.) */
+int  rama_decode_batch_begin(rama_ctx *ctx, const rama_config *cfg, const rama_weights *w,
+                             const rama_run_state *states, const int32_t *tokens_host,
+                             const int32_t *positions_host, int n_seq, int max_steps);
+int  rama_decode_batch_steps(rama_ctx *ctx, int n_steps);
+int  rama_decode_batch_tokens(rama_ctx *ctx, int32_t *out_host, int max_per_seq, int *n_per_seq);
 
 /* Layer-pipeline stage variants (no reference counterpart: the reference is single-device).
  * The token id is read from / written to DEVICE memory, so a stage boundary is one RCCL

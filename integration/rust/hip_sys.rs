@@ -69,6 +69,10 @@ extern "C" {
     pub fn rama_decode_batch(ctx: *mut rama_ctx, cfg: *const rama_config, w: *const rama_weights,
                              states: *const rama_run_state, tokens_host: *const i32, positions_host: *const i32,
                              n_seq: c_int) -> c_int;
+    pub fn rama_decode_batch_begin(ctx: *mut rama_ctx, cfg: *const rama_config, w: *const rama_weights, states: *const rama_run_state,
+                                   tokens_host: *const i32, positions_host: *const i32, n_seq: c_int, max_steps: c_int) -> c_int;
+    pub fn rama_decode_batch_steps(ctx: *mut rama_ctx, n_steps: c_int) -> c_int;
+    pub fn rama_decode_batch_tokens(ctx: *mut rama_ctx, out_host: *mut i32, max_per_seq: c_int, n_per_seq: *mut c_int) -> c_int;
     pub fn rama_generate(ctx: *mut rama_ctx, cfg: *const rama_config, w: *const rama_weights,
                          s: *mut rama_run_state, prompt_tokens_host: *const i32, n_prompt: c_int, steps: c_int,
                          temperature: f32, topp: f32, u: f32, out_tokens_host: *mut i32) -> c_int;

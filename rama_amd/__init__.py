@@ -9,4 +9,4 @@ from ._lib import RamaError, load  # noqa: F401
 from .transformer import (Config, Hip, HipSlice, MutView, RunState, RunStateView,  # noqa: F401
                           TransformerWeights, TransformerWeightsView, View, forward,
                           forward_fused, generate, generate_device, generate_greedy_device)
-from .engine import Engine, Model, algorithmic_bytes, decode_batch  # noqa: F401
+from .engine import Engine, Model, algorithmic_bytes, decode_batch, decode_batch_chained  # noqa: F401

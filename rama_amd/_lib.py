@@ -90,6 +90,9 @@ SIGNATURES = {
     "rama_forward_stage": (_int, [_vp, _cfgp, _wp, _sp, _int, _int, _stp]),
     "rama_prefill": (_int, [_vp, _cfgp, _wp, _sp, i32p, _int, _int]),
     "rama_decode_batch": (_int, [_vp, _cfgp, _wp, _sp, i32p, i32p, _int]),
+    "rama_decode_batch_begin": (_int, [_vp, _cfgp, _wp, _sp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _int, _int]),
+    "rama_decode_batch_steps": (_int, [_vp, _int]),
+    "rama_decode_batch_tokens": (_int, [_vp, C.POINTER(C.c_int32), _int, C.POINTER(_int)]),
     "rama_forward_stage_devtok": (_int, [_vp, _cfgp, _wp, _sp, _vp, _int, _stp]),
     "rama_argmax_dev": (_int, [_vp, _vp, _sz, _vp]),
     "rama_generate_greedy": (_int, [_vp, _cfgp, _wp, _sp, i32p, _int, _int, i32p]),

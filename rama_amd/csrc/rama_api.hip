@@ -136,6 +136,15 @@ struct rama_ctx {
                                            // is not merged with Wo, 0 never, 1 always (below the split threshold)
     unsigned long long* pbar = nullptr;    // device: [1] = error word of the merged attention+Wo launch's bounded spin
     const float* embedded_x = nullptr;   // run-state x that already holds emb[ctl.token] (chained decode)
+    // rama_decode_batch_begin / _steps: the sequences' cursors live on the device
+    struct BatchChain {
+        int n_seq = 0, pos_max = 0, out_cap = 0, steps_done = 0;
+        int* toks = nullptr;               // [kMfMaxTok] the token each sequence feeds next
+        SeqSlot* seqs = nullptr;           // [kMfMaxTok] cache bases + position of every sequence
+        int* out = nullptr;                // [kMfMaxTok, out_cap] the tokens produced
+        rama_config cfg{}; rama_weights w{};
+        hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; int graph_bucket = -1;
+    } bc;
 };
 
 static int set_device(rama_ctx* c) { HIPCHK(hipSetDevice(c->device)); return 0; }
@@ -204,6 +213,9 @@ int rama_ctx_create(int device, void* hip_stream, rama_ctx** out) {
 }
 
 static void drop_graph(rama_ctx* c) {
+    if (c->bc.exec) { hipGraphExecDestroy(c->bc.exec); c->bc.exec = nullptr; }
+    if (c->bc.graph) { hipGraphDestroy(c->bc.graph); c->bc.graph = nullptr; }
+    c->bc.graph_bucket = -1;
     for (auto& g : c->gc) {
         if (g.exec) hipGraphExecDestroy(g.exec);
         if (g.graph) hipGraphDestroy(g.graph);
@@ -226,6 +238,7 @@ int rama_ctx_destroy(rama_ctx* c) {
     for (int i = 0; i < 2; i++) { hipFree(c->topp_keys[i]); hipFree(c->topp_vals[i]); }
     hipFree(c->topp_prefix); hipFree(c->topp_m); hipFree(c->topp_err); hipFree(c->pf_blob);
     hipFree(c->topp_bp); hipFree(c->topp_bi); hipFree(c->topp_bcount);
+    hipFree(c->bc.toks); hipFree(c->bc.seqs); hipFree(c->bc.out);
     hipHostFree(c->pinned_int); hipHostFree(c->pinned_tok);
     hipEventDestroy(c->t0); hipEventDestroy(c->t1);
     if (c->own_stream) hipStreamDestroy(c->stream);
@@ -1415,6 +1428,24 @@ int rama_prefill(rama_ctx* c, const rama_config* cfg, const rama_weights* w, ram
     return launch_rows<true, EPI_STORE>(c, s->logits, w->wcls, s->x, w->rms_final_weight, dim, cfg->vocab_size);
 }
 
+// One pass for the n_seq sequences of the device tables b.toks / b.seqs: embedding rows, every layer, final norm and
+// the classifier as one more GEMM into b.LG [n_seq, vocab] (row-major).  tmax bounds the longest context (score buffers).
+static int enqueue_batch_pass(rama_ctx* c, const rama_config* cfg, const rama_weights* w, const BatchScratch& b, int n_seq, int tmax) {
+    const int dim = cfg->dim, V = cfg->vocab_size;
+    hipLaunchKernelGGL(embed_tile_kernel, dim3((dim / 4 + 255) / 256, n_seq), dim3(256), 0, c->stream, b.X, w->token_embedding_table, (const int*)b.toks, n_seq, dim);
+    LAUNCHCHK();
+    int nslab = 0;
+    int rc = run_layers_batched(c, cfg, w, b, n_seq, 0, nullptr, nullptr, true, tmax, &nslab);
+    if (rc) return rc;
+    // infer.rs:49-51 for every sequence: fold the last product, final rmsnorm, classifier
+    const int ntile = (n_seq + 15) / 16, pt = ntile <= 1 ? 1 : (ntile == 2 ? 2 : 4);
+    rc = launch_rmsnorm_tile(c, b, w->rms_final_weight, dim, ntile, nslab); if (rc) return rc;
+    MfParams p{};
+    p.n_tok = n_seq; p.ksplit = 1; { const float* bs[1] = {w->wcls}; mf_weights(c, p, 1, bs, 0, 0); }
+    p.x = b.XN; p.o = b.LG; p.o_stride = V; p.K = dim; p.rows = V; p.ssp = norm_ssp(c, b);
+    return launch_mf<2, EPI_STORE_ROWS>(c, p, pt);
+}
+
 // ---- one decode step for up to kMfMaxTok INDEPENDENT sequences (the server's concurrent requests,
 // SURVEY 8e): every weight row is streamed once for all of them.  No reference counterpart; the
 // contract is "what forward(token_i, pos_i) leaves in state_i, for every i": cache rows + logits.
@@ -1455,20 +1486,149 @@ int rama_decode_batch(rama_ctx* c, const rama_config* cfg, const rama_weights* w
     }
     HIPCHK(hipMemcpyAsync(b.toks, c->pinned_tok, sizeof(int) * n_seq, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(b.seqs, slots, sizeof(SeqSlot) * n_seq, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(embed_tile_kernel, dim3((dim / 4 + 255) / 256, n_seq), dim3(256), 0, c->stream, b.X, w->token_embedding_table, (const int*)b.toks, n_seq, dim);
-    LAUNCHCHK();
-    int nslab = 0;
-    rc = run_layers_batched(c, cfg, w, b, n_seq, 0, nullptr, nullptr, true, tmax, &nslab);
+    rc = enqueue_batch_pass(c, cfg, w, b, n_seq, tmax);
     if (rc) return rc;
-    // infer.rs:49-51 for every sequence: fold the last product, final rmsnorm, classifier as one more GEMM
-    const int ntile = (n_seq + 15) / 16, pt = ntile <= 1 ? 1 : (ntile == 2 ? 2 : 4);
-    rc = launch_rmsnorm_tile(c, b, w->rms_final_weight, dim, ntile, nslab); if (rc) return rc;
-    MfParams p{};
-    p.n_tok = n_seq; p.ksplit = 1; { const float* bs[1] = {w->wcls}; mf_weights(c, p, 1, bs, 0, 0); }
-    p.x = b.XN; p.o = b.LG; p.o_stride = V; p.K = dim; p.rows = V; p.ssp = norm_ssp(c, b);
-    rc = launch_mf<2, EPI_STORE_ROWS>(c, p, pt); if (rc) return rc;
     for (int i = 0; i < n_seq; i++)
         HIPCHK(hipMemcpyAsync(states[i].logits, b.LG + (size_t)i * V, sizeof(float) * V, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+// ---- the same pass CHAINED ON THE DEVICE: every sequence's (token, position) lives in device memory, a step ends with
+// one argmax per sequence that writes the next token and advances the position, and a step is one hipGraph replay --
+// no per-sequence download, no host round trip per step (rama_decode_batch costs one call and n_seq 4-byte downloads
+// per step when the tokens are fed back through the host).
+struct BatchArgmaxParams { const float* logits; int n; int* toks; SeqSlot* seqs; int* out; int out_cap; };
+__global__ __launch_bounds__(1024) void argmax_batch_kernel(BatchArgmaxParams p) {
+    // Device::sample at temperature 0 per sequence (cpu.rs:163-167: the LAST maximal index), then mod.rs:196-203:
+    // token = next, pos += 1
+    __shared__ float s_v[16];
+    __shared__ int s_i[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* lg = p.logits + (size_t)b * p.n;
+    float bv = -INFINITY; int bi = -1;
+    const int n4 = p.n >> 2;                                      // rows of the logits slab are 16-byte aligned (n % 4 == 0)
+    const f4* l4 = reinterpret_cast<const f4*>(lg);
+    for (int i0 = tid; i0 < n4; i0 += 8 * 1024) {
+        f4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = i0 + u * 1024; v[u] = i < n4 ? l4[i] : f4{-INFINITY, -INFINITY, -INFINITY, -INFINITY}; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + u * 1024;
+            if (i < n4) {
+                if (!(bv > v[u].x)) { bv = v[u].x; bi = 4 * i; }
+                if (!(bv > v[u].y)) { bv = v[u].y; bi = 4 * i + 1; }
+                if (!(bv > v[u].z)) { bv = v[u].z; bi = 4 * i + 2; }
+                if (!(bv > v[u].w)) { bv = v[u].w; bi = 4 * i + 3; }
+            }
+        }
+    }
+    const float wm = wave_max(bv);
+    const int wi = wave_max_i(bv == wm ? bi : -1);
+    if (lane == 0) { s_v[wave] = wm; s_i[wave] = wi; }
+    __syncthreads();
+    if (tid == 0) {
+        float v = s_v[0]; int idx = s_i[0];
+        for (int w = 1; w < 16; w++) {
+            const float ov = s_v[w]; const int oi = s_i[w];
+            if (oi >= 0 && (idx < 0 || ov > v || (ov == v && oi > idx))) { v = ov; idx = oi; }
+        }
+        idx = idx < 0 ? 0 : idx;
+        p.toks[b] = idx;
+        p.seqs[b].pos += 1;
+        const int k = p.seqs[b].pad;                              // tokens this sequence has produced so far
+        if (k < p.out_cap) p.out[(size_t)b * p.out_cap + k] = idx;
+        p.seqs[b].pad = k + 1;
+    }
+}
+
+int rama_decode_batch_begin(rama_ctx* c, const rama_config* cfg, const rama_weights* w, const rama_run_state* states,
+                            const int32_t* tokens_host, const int32_t* pos_host, int n_seq, int max_steps) {
+    REQUIRE(c && states && tokens_host && pos_host, RAMA_EINVAL, "decode_batch_begin: NULL argument");
+    REQUIRE(n_seq >= 1 && n_seq <= kMfMaxTok, RAMA_EINVAL, "decode_batch_begin: 1..64 sequences");
+    REQUIRE(max_steps >= 1 && max_steps <= (1 << 20), RAMA_EINVAL, "decode_batch_begin: bad max_steps");
+    int rc = check_cfg(cfg); if (rc) return rc;
+    REQUIRE(mf_shape_ok(cfg) && cfg->vocab_size % 4 == 0 && !c->tune_ref_order, RAMA_EUNSUP,
+            "decode_batch_begin: needs dim, hidden_dim multiples of 16, vocab_size a multiple of 4, fast mode");
+    rama_stage st{0, cfg->n_layers, 1, 1};
+    if (set_device(c)) return 1;
+    int pmax = 0;
+    for (int i = 0; i < n_seq; i++) {
+        rc = check_stage(cfg, w, &states[i], &st); if (rc) return rc;
+        REQUIRE(tokens_host[i] >= 0 && tokens_host[i] < cfg->vocab_size, RAMA_EINVAL, "decode_batch_begin: token outside the vocabulary");
+        REQUIRE(pos_host[i] >= 0 && pos_host[i] + max_steps <= cfg->seq_len, RAMA_EINVAL, "decode_batch_begin: position + max_steps beyond seq_len");
+        for (int j = 0; j < i; j++) REQUIRE(states[j].key_cache != states[i].key_cache, RAMA_EINVAL, "decode_batch_begin: two sequences share a run state");
+        pmax = std::max(pmax, pos_host[i]);
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    auto& bc = c->bc;
+    drop_graph(c);
+    if (!bc.toks) { HIPCHK(hipMalloc(&bc.toks, sizeof(int) * kMfMaxTok)); HIPCHK(hipMalloc(&bc.seqs, sizeof(SeqSlot) * kMfMaxTok)); }
+    if (bc.out_cap < max_steps) {
+        hipFree(bc.out); bc.out = nullptr;
+        HIPCHK(hipMalloc(&bc.out, sizeof(int) * (size_t)kMfMaxTok * max_steps));
+        bc.out_cap = max_steps;
+    }
+    SeqSlot* slots = reinterpret_cast<SeqSlot*>(c->pinned_tok + kMfMaxTok);
+    for (int i = 0; i < n_seq; i++) {
+        c->pinned_tok[i] = tokens_host[i];
+        slots[i].kc = states[i].key_cache; slots[i].vc = states[i].value_cache; slots[i].pos = pos_host[i]; slots[i].pad = 0;
+    }
+    HIPCHK(hipMemcpyAsync(bc.toks, c->pinned_tok, sizeof(int) * n_seq, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(bc.seqs, slots, sizeof(SeqSlot) * n_seq, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    bc.n_seq = n_seq; bc.pos_max = pmax; bc.steps_done = 0; bc.cfg = *cfg; bc.w = *w;
+    if (c->tune_tiled) { rc = rama_internal_model_ensure(c, w, 2); if (rc) return rc; }
+    BatchScratch b{};
+    return ensure_batch_scratch(c, cfg, true, &b);
+}
+
+int rama_decode_batch_steps(rama_ctx* c, int n_steps) {
+    REQUIRE(c && c->bc.n_seq > 0, RAMA_EINVAL, "decode_batch_steps: call rama_decode_batch_begin first");
+    REQUIRE(n_steps >= 0 && c->bc.steps_done + n_steps <= c->bc.out_cap, RAMA_EINVAL, "decode_batch_steps: more steps than rama_decode_batch_begin allowed for");
+    if (set_device(c)) return 1;
+    auto& bc = c->bc;
+    const rama_config* cfg = &bc.cfg;
+    BatchScratch b{};
+    int rc = ensure_batch_scratch(c, cfg, true, &b); if (rc) return rc;
+    b.toks = bc.toks; b.seqs = bc.seqs;                           // the chain's own cursors, not the scratch of a single pass
+    c->embedded_x = nullptr; c->host_pos = -1;
+    for (int i = 0; i < n_steps; i++) {
+        // the score buffers are sized by the longest context: one graph per bucket of 256 timesteps
+        const int tmax = bc.pos_max + 1, bucket = (tmax + 255) / 256;
+        BatchArgmaxParams ap{b.LG, cfg->vocab_size, bc.toks, bc.seqs, bc.out, bc.out_cap};
+        if (!c->graph_mode) {
+            rc = enqueue_batch_pass(c, cfg, &bc.w, b, bc.n_seq, bucket * 256); if (rc) return rc;
+            hipLaunchKernelGGL(argmax_batch_kernel, dim3(bc.n_seq), dim3(1024), 0, c->stream, ap);
+            LAUNCHCHK();
+        } else {
+            if (bc.graph_bucket != bucket) {
+                if (bc.exec) { hipGraphExecDestroy(bc.exec); bc.exec = nullptr; }
+                if (bc.graph) { hipGraphDestroy(bc.graph); bc.graph = nullptr; }
+                HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+                rc = enqueue_batch_pass(c, cfg, &bc.w, b, bc.n_seq, bucket * 256);
+                if (!rc) { hipLaunchKernelGGL(argmax_batch_kernel, dim3(bc.n_seq), dim3(1024), 0, c->stream, ap); }
+                const hipError_t e = hipStreamEndCapture(c->stream, &bc.graph);
+                if (rc) return rc;
+                HIPCHK(e);
+                HIPCHK(hipGraphInstantiate(&bc.exec, bc.graph, nullptr, nullptr, 0));
+                bc.graph_bucket = bucket;
+            }
+            HIPCHK(hipGraphLaunch(bc.exec, c->stream));
+        }
+        bc.pos_max++; bc.steps_done++;
+    }
+    return 0;
+}
+
+int rama_decode_batch_tokens(rama_ctx* c, int32_t* out_host, int max_per_seq, int* n_per_seq) {
+    REQUIRE(c && out_host && n_per_seq && c->bc.n_seq > 0, RAMA_EINVAL, "decode_batch_tokens: bad argument");
+    auto& bc = c->bc;
+    const int n = std::min(bc.steps_done, max_per_seq);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int s_ = 0; s_ < bc.n_seq && n > 0; s_++)
+        HIPCHK(hipMemcpy(out_host + (size_t)s_ * max_per_seq, bc.out + (size_t)s_ * bc.out_cap, sizeof(int) * n, hipMemcpyDeviceToHost));
+    *n_per_seq = n;
     return 0;
 }
 

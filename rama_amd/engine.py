@@ -181,3 +181,21 @@ def decode_batch(engines: Sequence["Engine"], tokens: Sequence[int], positions: 
     poss = (C.c_int32 * len(engines))(*positions)
     check(e0.device.lib.rama_decode_batch(e0.device.ctx, C.byref(e0.model.ccfg), C.byref(e0.model.weights),
                                           states, toks, poss, len(engines)), "rama_decode_batch")
+
+
+def decode_batch_chained(engines: Sequence["Engine"], tokens: Sequence[int], positions: Sequence[int], n_steps: int):
+    """n_steps greedy decode steps of up to 64 independent sequences chained on the device (rama_decode_batch_begin /
+    _steps / _tokens): -> per sequence the n_steps tokens it produced.  engines[i]'s caches are advanced."""
+    assert 1 <= len(engines) == len(tokens) == len(positions) <= 64
+    e0 = engines[0]
+    L = e0.device.lib
+    states = (rama_run_state * len(engines))(*[e.state for e in engines])
+    toks = (C.c_int32 * len(engines))(*tokens)
+    poss = (C.c_int32 * len(engines))(*positions)
+    check(L.rama_decode_batch_begin(e0.device.ctx, C.byref(e0.model.ccfg), C.byref(e0.model.weights), states, toks, poss,
+                                    len(engines), max(n_steps, 1)), "rama_decode_batch_begin")
+    check(L.rama_decode_batch_steps(e0.device.ctx, n_steps), "rama_decode_batch_steps")
+    out = (C.c_int32 * (len(engines) * max(n_steps, 1)))()
+    n = C.c_int()
+    check(L.rama_decode_batch_tokens(e0.device.ctx, out, max(n_steps, 1), C.byref(n)), "rama_decode_batch_tokens")
+    return [[int(out[s * max(n_steps, 1) + k]) for k in range(n.value)] for s in range(len(engines))]

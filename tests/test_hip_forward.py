@@ -891,6 +891,71 @@ def test_decode_batch_many_sequences(dev, n_seq):
     m.free()
 
 
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("n_seq", [1, 5, 19, 64])
+def test_decode_batch_chained_equals_independent_generations(dev, n_seq, graph):
+    """rama_decode_batch_begin / _steps / _tokens: the cursors of every sequence live on the device, a step ends with
+    one argmax per sequence and (graph mode) is one hipGraph replay.  Every sequence must produce the greedy tokens
+    its own oracle generation produces, from its own start position, and end with that generation's caches."""
+    import rama_amd
+    cfg = O.Config(128, 352, 2, 4, 4, 256, 40, True)
+    rope = S.rope_tables(cfg.seq_len, cfg.head_size)
+    w = S.synth_weights(cfg, seed=4, rope=rope)
+    m = rama_amd.Model.synth(dev, to_rama_cfg(cfg), 4, rope=rope)
+    batch = [rama_amd.Engine(dev, m) for _ in range(n_seq)]
+    orcs = [O.Oracle(cfg, w) for _ in range(n_seq)]
+    rng = np.random.default_rng(100 + n_seq)
+    cur = [int(t) for t in rng.integers(0, cfg.vocab_size, n_seq)]
+    pos = [0] * n_seq
+    for i in range(n_seq):                        # stagger: sequence i is advanced alone i % 4 times first
+        for _ in range(i % 4):
+            lo = orcs[i].forward(cur[i], pos[i]); batch[i].forward(cur[i], pos[i])
+            cur[i] = O.argmax(lo); pos[i] += 1
+    steps = 9
+    batch[0].set_graph_mode(graph)
+    try:
+        got = rama_amd.decode_batch_chained(batch, cur, pos, steps)
+    finally:
+        batch[0].set_graph_mode(False)
+    for i in range(n_seq):
+        want, t, p_ = [], cur[i], pos[i]
+        for _ in range(steps):
+            t = O.argmax(orcs[i].forward(t, p_)); p_ += 1
+            want.append(t)
+        assert got[i] == want, (i, got[i], want)
+    for i in (0, n_seq // 2, n_seq - 1):
+        for buf in ("key_cache", "value_cache"):
+            assert np.abs(batch[i].buffer(buf, orcs[i].s[buf].size) - orcs[i].s[buf]).max() <= STATE_ATOL, (i, buf)
+    for e in batch: e.free()
+    m.free()
+
+
+def test_decode_batch_chained_across_score_buffer_buckets(dev):
+    """the attention score buffers are sized per bucket of 256 timesteps: a chained run that crosses a bucket boundary
+    re-captures its graph and keeps producing the single-sequence tokens"""
+    import rama_amd
+    cfg = O.Config(64, 176, 1, 4, 4, 96, 300, False)
+    rope = S.rope_tables(cfg.seq_len, cfg.head_size)
+    w = S.synth_weights(cfg, seed=8, rope=rope)
+    m = rama_amd.Model.synth(dev, to_rama_cfg(cfg), 8, rope=rope)
+    a, b = rama_amd.Engine(dev, m), rama_amd.Engine(dev, m)
+    a.set_graph_mode(True)
+    try:
+        got = rama_amd.decode_batch_chained([a, b], [3, 7], [0, 0], 270)
+    finally:
+        a.set_graph_mode(False)
+    for i, t0 in enumerate((3, 7)):
+        e = rama_amd.Engine(dev, m)
+        assert got[i] == e.generate_greedy([], 271)[1:] if False else True     # (generate() starts from BOS; compared below instead)
+        orc = O.Oracle(cfg, w)
+        t, want = t0, []
+        for p_ in range(270):
+            t = O.argmax(orc.forward(t, p_)); want.append(t)
+        assert got[i] == want, (i, next(k for k in range(270) if got[i][k] != want[k]))
+        e.free()
+    a.free(); b.free(); m.free()
+
+
 def test_decode_batch_argument_errors(dev):
     import rama_amd
     cfg, w, g = load_case("synth_d64_h4")

@@ -32,5 +32,20 @@ for B in (1, 8, 16, 32, 64):
     dev.sync()
     dt = time.perf_counter() - t0
     out[B] = {"ms_per_step": round(dt * 1e3 / steps, 3), "aggregate_tok_s": round(B * steps / dt, 1)}
+    # the same chained on the device: cursors and argmax per sequence in device memory, one hipGraph per step
+    for graph in (0, 1):
+        engs[0].set_graph_mode(bool(graph))
+        states = (rama_amd._lib.rama_run_state * B)(*[e.state for e in engs])
+        toks = (C.c_int32 * B)(*[1 + i for i in range(B)])
+        poss = (C.c_int32 * B)(*([0] * B))
+        check(dev.lib.rama_decode_batch_begin(dev.ctx, C.byref(model.ccfg), C.byref(model.weights), states, toks, poss, B, steps + 4))
+        check(dev.lib.rama_decode_batch_steps(dev.ctx, 4))
+        dev.sync()
+        t0 = time.perf_counter()
+        check(dev.lib.rama_decode_batch_steps(dev.ctx, steps))
+        dev.sync()
+        dt = time.perf_counter() - t0
+        out[B]["chained_graph" if graph else "chained_eager"] = {"ms_per_step": round(dt * 1e3 / steps, 3), "aggregate_tok_s": round(B * steps / dt, 1)}
+    engs[0].set_graph_mode(False)
     for e in engs: e.free()
 print(json.dumps({"config": name, "steps": steps, "by_batch": out}))
