@@ -26,10 +26,13 @@ REPO = Path(__file__).resolve().parent.parent
 ap = argparse.ArgumentParser()
 ap.add_argument("--round", type=int, default=1)
 ap.add_argument("--out", default=str(REPO / "gpurun_out" / "profiles"))
+ap.add_argument("--mode", default="fast", choices=["fast", "parity"], help="which decode mode of bench.py to profile")
 a = ap.parse_args()
 out = Path(a.out).resolve()
 out.mkdir(parents=True, exist_ok=True)
 tag = f"r{a.round:02d}"
+suffix = "_parity" if a.mode == "parity" else ""
+mode_args = ["--mode", a.mode, "--no-other-configs"]
 env = dict(os.environ, TMPDIR="/tmp")
 bench = str(REPO / "bench.py")
 
@@ -44,17 +47,17 @@ def run(cmd, workdir):
 d1 = out / "_trace"
 shutil.rmtree(d1, ignore_errors=True)
 cmd1 = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", str(d1), "-o", "bench", "--",
-        "python3", bench, "--steps", "64", "--warmup", "8", "--no-cpu-baseline", "--no-kprof"]     # 128 + 8 graph replays crash rocprofv3 (ROCm 7.2), 64 + 8 do not
+        "python3", bench, "--steps", "32", "--warmup", "4", "--graph", "0", "--no-cpu-baseline", "--no-kprof"] + mode_args     # long graph replays crash rocprofv3 (ROCm 7.2): eager launches, same kernels
 run(cmd1, d1)
 stats = glob.glob(str(d1 / "**" / "*kernel_stats.csv"), recursive=True)
 assert stats, "rocprofv3 wrote no kernel_stats.csv"
-shutil.copy(stats[0], out / f"{tag}_bench_7b_kernel_stats.csv")
+shutil.copy(stats[0], out / f"{tag}_bench_7b{suffix}_kernel_stats.csv")
 
 # 2. counters, in a pass of their own
 d2 = out / "_pmc"
 shutil.rmtree(d2, ignore_errors=True)
 cmd2 = ["rocprofv3", "--kernel-trace", "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", str(d2), "-o", "pmc", "--",
-        "python3", bench, "--steps", "16", "--warmup", "2", "--no-cpu-baseline", "--no-kprof", "--graph", "0"]
+        "python3", bench, "--steps", "16", "--warmup", "2", "--no-cpu-baseline", "--no-kprof", "--graph", "0"] + mode_args
 run(cmd2, d2)
 cc = glob.glob(str(d2 / "**" / "*counter_collection.csv"), recursive=True)
 assert cc, "rocprofv3 wrote no counter_collection.csv"
@@ -68,7 +71,7 @@ with open(cc[0]) as f:
         k[1] += float(r["Counter_Value"])
 rows = [{"kernel": name, "counter": "FETCH_SIZE", "launches": n, "avg_value_KB": round(tot / n, 3),
          "hbm_read_bytes_corrected": int(round(tot / n * 1024 * 2))} for name, (n, tot) in sorted(acc.items())]
-with open(out / f"{tag}_bench_7b_pmc_fetch_size.json", "w") as f:
+with open(out / f"{tag}_bench_7b{suffix}_pmc_fetch_size.json", "w") as f:
     json.dump({"command": " ".join(cmd2[:5]) + " -- python bench.py --steps 16 --warmup 2 --no-cpu-baseline --no-kprof --graph 0",
                "note": "FETCH_SIZE is reported in KB; on gfx950 it counts 128-B requests at 64 B, i.e. exactly half of a wide "
                        "coalesced read (MI355X_MICROARCH.md, HBM section): hbm_read_bytes_corrected = value * 1024 * 2",
@@ -76,6 +79,6 @@ with open(out / f"{tag}_bench_7b_pmc_fetch_size.json", "w") as f:
 shutil.rmtree(d1, ignore_errors=True)
 shutil.rmtree(d2, ignore_errors=True)
 for r in rows:
-    if "true, 5>" in r["kernel"] or "swiglu" in r["kernel"]:
+    if "true, 5>" in r["kernel"] or "swiglu" in r["kernel"] or "4, 3>" in r["kernel"]:
         print(r)
 print("wrote", sorted(p.name for p in out.iterdir()))
