@@ -765,7 +765,7 @@ __global__ __launch_bounds__(NW * 64) void attention_chain_kernel(RefAttnParams 
     __syncthreads();
     const float scale_div = sqrtf((float)hs);
     const f4* q4 = reinterpret_cast<const f4*>(s_q);
-    if (hs % kAttPiece == 0 && pos >= 4 * T) {                    // long contexts: staged pieces, two of them in flight per wave
+    if (hs % kAttPiece == 0 && pos >= 1024) {                     // long contexts: staged pieces, two of them in flight per wave
         float* stage = region + wave * (64 * kAttStride);
         const int npiece = hs / kAttPiece;
         const int lrow = lane >> 3, lc4 = lane & 7;               // loader role: row (+ 8 u) and 16-byte column of the piece
