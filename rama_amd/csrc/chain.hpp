@@ -917,4 +917,140 @@ __global__ __launch_bounds__(NW * 64) void attention_chain_kernel(RefAttnParams 
     SEQ_STAMP(13);
 }
 
+// ---------------------------------------------------------------- the same attention spread over the chip (long contexts)
+// One workgroup per head leaves 224 CUs idle, and a CU takes ~64 KiB of loads in flight: at 1 900 timesteps K and V
+// arrive at ~1 TB/s and the launch lasts 81 us.  From position 1 024 on the three phases are three launches:
+//   attn_scores_chain_kernel   grid (heads x groups of 64 timesteps), one wave each: the staged q.k chains -> att (scores)
+//   attn_softmax_chain_kernel  grid heads: max, glibc expf, the exact sequential sum, divide -> att (probabilities)
+//   attn_values_chain_kernel   grid (heads x slices of 32 head columns): product tiles of 256 rows x 32 columns, the 32
+//                              chains of the slice add them in row order
+// Same operations in the same order per output as attention_chain_kernel: the same bits.
+__global__ __launch_bounds__(64) void attn_scores_chain_kernel(RefAttnParams p) {
+    RAMA_NO_CONTRACT
+    __shared__ __attribute__((aligned(16))) float stage[64 * kAttStride];
+    __shared__ __attribute__((aligned(16))) float s_q[256];
+    const int h = blockIdx.x, g = blockIdx.y, lane = threadIdx.x;
+    const int pos = p.ctl ? p.ctl->pos : p.pos_val;
+    if (g * 64 > pos) return;                                     // uniform
+    const int hs = p.head_size, npiece = hs / kAttPiece;
+    const size_t col = (size_t)h * hs;
+    const int lrow = lane >> 3, lc4 = lane & 7;
+    auto load_piece = [&](int pc, f4 (&d)[8]) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int t = g * 64 + u * 8 + lrow;
+            d[u] = (pc < npiece && t <= pos) ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.kc + (size_t)t * p.dim + col + pc * kAttPiece) + lc4)
+                                             : f4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    f4 na[8], nb[8];
+    load_piece(0, na);
+    load_piece(1, nb);
+    for (int i = lane; i < hs; i += 64) s_q[i] = p.q[col + i];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const f4* q4 = reinterpret_cast<const f4*>(s_q);
+    const float scale_div = sqrtf((float)hs);
+    float acc = 0.0f;
+    auto consume = [&](int pc, f4 (&d)[8]) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) *reinterpret_cast<f4*>(stage + (u * 8 + lrow) * kAttStride + 4 * lc4) = d[u];
+        load_piece(pc + 2, d);
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const f4* row = reinterpret_cast<const f4*>(stage + lane * kAttStride);
+        f4 kk[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) kk[i] = row[i];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const f4 qq = q4[pc * 8 + i];
+            acc = acc + qq.x * kk[i].x; acc = acc + qq.y * kk[i].y; acc = acc + qq.z * kk[i].z; acc = acc + qq.w * kk[i].w;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    };
+    for (int pc = 0; pc < npiece; pc += 2) {
+        consume(pc, na);
+        if (pc + 1 < npiece) consume(pc + 1, nb);
+    }
+    const int t = g * 64 + lane;
+    if (t <= pos) p.att[(size_t)h * p.seq_len + t] = acc / scale_div;
+}
+
+constexpr int kSoftWaves = 4;
+__global__ __launch_bounds__(kSoftWaves * 64) void attn_softmax_chain_kernel(RefAttnParams p) {
+    RAMA_NO_CONTRACT
+    constexpr int T = kSoftWaves * 64;
+    extern __shared__ __attribute__((aligned(16))) float s_att[];      // [scan_slot(seq_len)]
+    __shared__ SeqSumShared<kSoftWaves> sh;
+    __shared__ PredShared<kSoftWaves> ps;
+    __shared__ float red[16];
+    const int h = blockIdx.x, tid = threadIdx.x;
+    const int pos = p.ctl ? p.ctl->pos : p.pos_val;
+    float* att = p.att + (size_t)h * p.seq_len;
+    float mx = -INFINITY;
+    for (int t = tid; t <= pos; t += T) { const float a = att[t]; s_att[scan_slot(t)] = a; mx = fmaxf(mx, a); }
+    mx = block_max(mx, red);
+    for (int t = tid; t <= pos; t += T) s_att[scan_slot(t)] = expf_glibc(s_att[scan_slot(t)] - mx);
+    __syncthreads();
+    float sum;
+    if (!seq_sum_predict<kSoftWaves>(s_att, pos + 1, ps, &sum)) sum = seq_sum_exact<kSoftWaves>(s_att, pos + 1, sh);
+    for (int t = tid; t <= pos; t += T) att[t] = s_att[scan_slot(t)] / sum;
+}
+
+constexpr int kValCols = 32, kValRows = 256, kValWaves = 4;            // a slice's tile: 256 rows x 32 columns = 32 KiB of products
+__global__ __launch_bounds__(kValWaves * 64) void attn_values_chain_kernel(RefAttnParams p) {
+    RAMA_NO_CONTRACT
+    constexpr int T = kValWaves * 64, U = kValRows * (kValCols / 4) / T;      // 8 x 16 bytes per thread and tile
+    __shared__ __attribute__((aligned(16))) float tile[2][kValRows * kValCols];
+    const int h = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x;
+    const int pos = p.ctl ? p.ctl->pos : p.pos_val;
+    const size_t col = (size_t)h * p.head_size + (size_t)sl * kValCols;
+    const float* att = p.att + (size_t)h * p.seq_len;
+    // tile element e = tid + u T: row e / 8, 16-byte column e % 8
+    f4 va[U], vb[U];
+    float aa[U], ab[U];
+    auto vissue = [&](int t0, f4 (&vr)[U], float (&ar)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int e = tid + u * T, r = e >> 3, c4 = e & 7;
+            const bool on = t0 + r <= pos;
+            vr[u] = on ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.vc + (size_t)(t0 + r) * p.dim + col) + c4) : f4{0.f, 0.f, 0.f, 0.f};
+            ar[u] = on ? att[t0 + r] : 0.0f;
+        }
+    };
+    vissue(0, va, aa);
+    vissue(kValRows, vb, ab);
+    float acc = 0.0f;
+    auto vtile = [&](int t0, int buf, f4 (&vr)[U], float (&ar)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int e = tid + u * T;
+            f4 pr;
+            pr.x = ar[u] * vr[u].x; pr.y = ar[u] * vr[u].y; pr.z = ar[u] * vr[u].z; pr.w = ar[u] * vr[u].w;     // cpu.rs:48 `a * vi`, rounded
+            *reinterpret_cast<f4*>(&tile[buf][4 * e]) = pr;
+        }
+        vissue(t0 + 2 * kValRows, vr, ar);
+        __syncthreads();                                          // this tile is written; the other one (read last round) is free again
+        if (tid < kValCols) {
+            const int nt = min(kValRows, pos + 1 - t0);
+            int r = 0;
+            for (; r + 16 <= nt; r += 16) {
+                float v16[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) v16[u] = tile[buf][(r + u) * kValCols + tid];
+#pragma unroll
+                for (int u = 0; u < 16; u++) acc = acc + v16[u];
+            }
+            for (; r < nt; r++) acc = acc + tile[buf][r * kValCols + tid];
+        }
+    };
+    for (int t0 = 0; t0 <= pos; t0 += 2 * kValRows) {
+        vtile(t0, 0, va, aa);
+        if (t0 + kValRows <= pos) vtile(t0 + kValRows, 1, vb, ab);      // uniform
+    }
+    if (tid < kValCols) p.xb[col + tid] = acc;
+}
+
 }  // namespace rama

@@ -49,6 +49,7 @@ static int fail(int code, const char* what, const char* file, int line) {
 
 constexpr int kSmallAttnPosDefault = 256;
 constexpr size_t kAttnChainMaxLds = 136 * 1024;      // dynamic LDS attention_chain_kernel may ask for (allowed once per device in rama_ctx_create)
+constexpr int kSpreadAttnPos = 1024;       // parity mode: from this position on attention is three launches spread over the chip (chain.hpp)
 constexpr int kLongAttnPos = 256;          // parity mode: attention_chain_kernel runs 16 waves per head from this position on
 
 struct KProf {
@@ -125,6 +126,7 @@ struct rama_ctx {
     int host_pos = -1;                     // position of the next chained decode step (mirrors the device cursor)
     bool split_attn = false;               // variant the steps being enqueued / captured use
     bool long_attn = false;                // parity mode: the position is >= 256 (16 waves per head in attention_chain_kernel)
+    bool spread_attn = false;              // parity mode: the position is >= 1024 (attention as three launches over the whole chip)
     int variant = 0;                       // attn_variant() of the steps being enqueued / captured
     bool small_attn = false;               // 4-wave attention workgroups (contexts of <= kSmallAttnPos timesteps)
     int tune_small_waves = 8, tune_small_pos = kSmallAttnPosDefault;   // waves per head and position limit of the small-attention variant
@@ -475,11 +477,26 @@ static bool attn_chain_ok(int head_size, int seq_len) {      // the largest vari
 }
 // long_ctx: 8 waves per head (twice the timesteps per score round, twice the loaders of the value tiles) -- from position 256 on
 static int launch_attention_chain(rama_ctx* c, float* xb, float* att, const float* q, const float* kc_layer, const float* vc_layer,
-                                  const Ctl* ctl, int pos, int dim, int head_size, int seq_len, int n_heads, bool long_ctx = false) {
+                                  const Ctl* ctl, int pos, int dim, int head_size, int seq_len, int n_heads, bool long_ctx = false, bool spread_wanted = false) {
+    // spread: the three-launch form for long contexts; it needs whole staged pieces and 32-column slices, a score
+    // buffer that fits the softmax kernel's LDS, and the att buffer
+    const bool spread = spread_wanted && att && head_size % kAttPiece == 0 && head_size % kValCols == 0 && head_size <= 256 &&
+                        ((size_t)seq_len + ((size_t)seq_len >> 5) + 4) * sizeof(float) <= 60 * 1024;
     REQUIRE(aligned16(q) && aligned16(kc_layer) && aligned16(vc_layer) && dim % 4 == 0, RAMA_EINVAL, "attention: buffers must be 16-byte aligned");
     RefAttnParams p{};
     p.q = q; p.kc = kc_layer; p.vc = vc_layer; p.att = att; p.xb = xb; p.ctl = ctl; p.pos_val = pos;
     p.dim = dim; p.head_size = head_size; p.seq_len = seq_len;
+    if (spread) {
+        // three launches over the whole chip (chain.hpp): needs att (the scores / probabilities travel through it)
+        const int ngroups = (seq_len + 63) / 64;
+        RAMA_LAUNCH(c, attn_scores_chain_kernel, dim3(n_heads, ngroups), dim3(64), 0, p);
+        LAUNCHCHK();
+        hipLaunchKernelGGL(attn_softmax_chain_kernel, dim3(n_heads), dim3(kSoftWaves * 64), ((size_t)seq_len + ((size_t)seq_len >> 5) + 4) * sizeof(float), c->stream, p);
+        LAUNCHCHK();
+        hipLaunchKernelGGL(attn_values_chain_kernel, dim3(n_heads, head_size / kValCols), dim3(kValWaves * 64), 0, c->stream, p);
+        LAUNCHCHK();
+        return 0;
+    }
     const int nw = attn_chain_waves(head_size, long_ctx);
     const size_t lds = attn_chain_lds_floats(head_size, seq_len, nw) * sizeof(float) + 16;
     REQUIRE(lds <= kAttnChainMaxLds, RAMA_EUNSUP, "attention (parity mode): context too long for the score buffer");
@@ -624,9 +641,10 @@ static bool small_attn_at(const rama_ctx* c, int pos, bool split, int dim) {
 }
 
 // Which launches a step at `pos` consists of (one hipGraph per variant): fast mode 0 = one 16-wave workgroup per head,
-// 1 = split-T (long contexts), 2 = fewer waves per head (short contexts); parity mode 0 = 4 waves per head, 1 = 16 (pos >= 256)
+// 1 = split-T (long contexts), 2 = fewer waves per head (short contexts); parity mode 0 = 4 waves per head, 1 = 8 (pos >= 256),
+// 2 = three launches spread over the chip (pos >= 1024)
 static int attn_variant(const rama_ctx* c, const rama_config* cfg, int pos) {
-    if (c->tune_ref_order) return pos >= kLongAttnPos ? 1 : 0;
+    if (c->tune_ref_order) return pos >= kSpreadAttnPos ? 2 : (pos >= kLongAttnPos ? 1 : 0);
     const bool split = pos >= split_threshold(c, cfg);
     return split ? 1 : (small_attn_at(c, pos, split, cfg->dim) ? 2 : 0);
 }
@@ -634,6 +652,7 @@ static int apply_attn_variant(rama_ctx* c, const rama_config* cfg, int pos) {
     c->split_attn = pos >= split_threshold(c, cfg);
     c->small_attn = small_attn_at(c, pos, c->split_attn, cfg->dim);
     c->long_attn = pos >= kLongAttnPos;
+    c->spread_attn = pos >= kSpreadAttnPos;
     return c->variant = attn_variant(c, cfg, pos);
 }
 
@@ -714,7 +733,7 @@ int rama_multi_head_attention(rama_ctx* c, float* xb, float* att, const float* q
     REQUIRE(pos >= 0 && pos < seq_len && layer >= 0 && n_heads > 0 && n_heads * head_size == dim, RAMA_EINVAL, "multi_head_attention: bad shape");
     const size_t lo = (size_t)layer * seq_len * dim;   // cpu.rs:28
     if (c->tune_ref_order && c->tune_chain && attn_chain_ok(head_size, seq_len) && aligned16(q) && aligned16(key_cache + lo) && aligned16(value_cache + lo) && dim % 4 == 0)
-        return launch_attention_chain(c, xb, att, q, key_cache + lo, value_cache + lo, nullptr, pos, dim, head_size, seq_len, n_heads, pos >= 256);
+        return launch_attention_chain(c, xb, att, q, key_cache + lo, value_cache + lo, nullptr, pos, dim, head_size, seq_len, n_heads, pos >= kLongAttnPos, pos >= kSpreadAttnPos);
     if (c->tune_ref_order) return launch_attention_ref(c, xb, att, q, key_cache + lo, value_cache + lo, nullptr, pos, dim, head_size, seq_len, n_heads);
     c->small_attn = small_attn_at(c, pos, false, dim);
     return launch_attention(c, xb, att, q, key_cache + lo, value_cache + lo, nullptr, pos, dim, head_size, seq_len, n_heads);
@@ -904,7 +923,7 @@ static int enqueue_stage_chain(rama_ctx* c, const rama_config* cfg, const rama_w
         }
         {   // :34
             KTimer kt(c, RAMA_K_ATTN);
-            rc = launch_attention_chain(c, s->xb, s->att, s->q, kc, vc, c->ctl, 0, dim, hs, cfg->seq_len, cfg->n_heads, c->long_attn); if (rc) return rc;
+            rc = launch_attention_chain(c, s->xb, s->att, s->q, kc, vc, c->ctl, 0, dim, hs, cfg->seq_len, cfg->n_heads, c->long_attn, c->spread_attn); if (rc) return rc;
         }
         {   // :35-37: xb2 = Wo . xb; x += xb2
             KTimer kt(c, RAMA_K_WO);

@@ -345,12 +345,14 @@ def test_model_long_context_bit_exact(dev, n_heads, hs):
     eng = rama_amd.Engine(dev, model)
     for graph in (False, True):
         eng.set_graph_mode(graph)
-        for pos in (255, 256, 257, 1000, 2047):
+        for pos in (255, 256, 257, 1000, 1023, 1024, 1025, 2047):     # 4 waves per head | 8 waves | three launches over the chip
             orc.s["key_cache"][:] = kc; orc.s["value_cache"][:] = vc
             eng.set_buffer("key_cache", kc); eng.set_buffer("value_cache", vc)
             lo = orc.forward(5, pos).copy()
             eng.forward(5, pos)
             assert_bits_equal(eng.logits(), lo, f"long context pos {pos} graph {graph}")
             assert_bits_equal(eng.buffer("xb2", dim), orc.s["xb2"], f"long context pos {pos} xb2")
+            att = eng.buffer("att", n_heads * seq).reshape(n_heads, seq)[:, :pos + 1]
+            assert_bits_equal(att, orc.s["att"].reshape(n_heads, seq)[:, :pos + 1], f"long context pos {pos} att")
     eng.set_graph_mode(False)
     eng.free(); model.free()
