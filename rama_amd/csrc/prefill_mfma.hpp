@@ -42,7 +42,8 @@ namespace rama {
 
 constexpr int kMfWaves = 8;
 constexpr int kMfThreads = kMfWaves * 64;
-constexpr int kMfMaxTok = 64;                // tokens per pass (PT <= 4)
+constexpr int kMfMaxTok = 128;               // tokens per pass (PT <= 8; PT = 8 needs the tile-order weight copy)
+constexpr int kMfMaxTokRows = 64;            // ... with row-major weights (PT <= 4)
 
 enum { EPI_SWIGLU = 3, EPI_STORE_ROWS = 4 };
 
@@ -74,6 +75,21 @@ struct MfParams {
 
 typedef __attribute__((ext_vector_type(4))) float acc4;
 
+// in-kernel time stamps of workgroup RAMA_MF_STAMP_BLOCK (tools/pf_mfma_bench.hip -DRAMA_MF_STAMPS): 100 MHz ticks per wave
+#ifdef RAMA_MF_STAMPS
+#ifndef RAMA_MF_STAMP_BLOCK
+#define RAMA_MF_STAMP_BLOCK 0
+#endif
+__device__ unsigned long long g_mf_stamps[kMfWaves][8];
+__device__ unsigned long long g_mf_blocks[1024][4];      // per workgroup: start, end, HW_ID, XCC_ID
+#define MF_BLOCK_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 1024) { g_mf_blocks[blockIdx.x][k] = __builtin_amdgcn_s_memrealtime(); \
+    if (k == 0) { g_mf_blocks[blockIdx.x][2] = __builtin_amdgcn_s_getreg(63492); g_mf_blocks[blockIdx.x][3] = __builtin_amdgcn_s_getreg(63508); } } } while (0)
+#define MF_STAMP(id) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == RAMA_MF_STAMP_BLOCK) g_mf_stamps[threadIdx.x >> 6][id] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MF_STAMP(id) do { } while (0)
+#define MF_BLOCK_STAMP(k) do { } while (0)
+#endif
+
 // PT  token tiles of 16 (P = 16 PT tokens per pass)
 // RT  row tiles of 16 per group.  EPI_QKV (RT = 3) and EPI_SWIGLU (RT = 2) take tile rt from matrix
 //     rt, all at the same rows; the others take RT consecutive tiles of w[0]
@@ -81,17 +97,23 @@ typedef __attribute__((ext_vector_type(4))) float acc4;
 //     2 * 4 JN (RT + PT) double-buffered operands + 4 RT PT accumulators.
 // LD  1: row-major weights as described above.  3: weights in tile order (the model's second copy,
 //     model.hip make_tiled): the A operand is one contiguous 1-KiB read per wave, no lane permute.
-//     2, 4, 5 are TIMING PROBES of the microbenchmark with wrong results.
-template <int PT, int RT, int EPI, int JN = 2, int LD = 1, int STAGGER = 0>
+//     4, 5 (row-major) and 6, 7 (tile order) are TIMING PROBES of the microbenchmark with wrong results:
+//     5, 6 load in the first two steps only, 4, 7 replace the MFMAs by one vector add per operand.
+// MIX 1: the loads of the next step and their scalar bookkeeping are scheduled INTO the current step's
+//     MFMA stream (one MFMA, then a few scalar / vector / memory instructions, ...) instead of in front of it: a wave
+//     issues them in the shadow of its own MFMAs, whatever the SIMD's other wave is doing
+template <int PT, int RT, int EPI, int JN = 2, int LD = 1, int STAGGER = 0, int MIX = 0>
 __global__ __launch_bounds__(kMfThreads) void gemm_mfma_rows(MfParams p) {
-    constexpr int NT = RT * PT;                          // accumulator tiles per wave
     constexpr bool ACROSS = EPI == EPI_QKV || EPI == EPI_SWIGLU;
     constexpr bool PAIR = EPI == EPI_SWIGLU;
     static_assert(!PAIR || RT == 2, "SwiGLU groups are one w1 tile + one w3 tile");
     static_assert(EPI != EPI_QKV || RT == 3, "QKV groups are one tile of each of wq, wk, wv");
     constexpr int CHUNK = 16 * JN;                       // floats of K per wave per step
-    __shared__ float part[kMfWaves][NT][4][64];
-    __shared__ float s_scale[64];                        // per token of the pass: the rmsnorm scale (p.ssp)
+    constexpr bool TILED = LD == 3 || (LD >= 6 && LD <= 10);
+    constexpr int PTC = PT > 4 ? 4 : PT;                 // token tiles per round of the cross-wave fold (LDS: 8 KiB per tile)
+    constexpr int NTC = RT * PTC;
+    __shared__ float part[kMfWaves][NTC][4][64];
+    __shared__ float s_scale[PT * 16 > 64 ? PT * 16 : 64];      // per token of the pass: the rmsnorm scale (p.ssp)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rows_per_grp = ACROSS ? 16 : 16 * RT;
     const int ngroups = (p.rows + rows_per_grp - 1) / rows_per_grp;
@@ -127,10 +149,10 @@ __global__ __launch_bounds__(kMfThreads) void gemm_mfma_rows(MfParams p) {
         const int u = u0 + ul;
         const int g = p.ksplit == 1 ? u : u / p.ksplit, ks = u - g * p.ksplit;
         const int r0 = g * rows_per_grp;
-        const int cl = (LD == 3 ? wv : wave) + s * kMfWaves;                   // chunk within the K-slice
+        const int cl = (TILED ? wv : wave) + s * kMfWaves;                   // chunk within the K-slice
         int c = (ul < nunit && s < S && cl < cps) ? ks * cps + cl : nch;
-        if (LD == 5 && !(ul == 0 && s < 2)) c = nch;       // probe: only the first two steps load
-        if (LD == 3) {
+        if ((LD == 5 || LD == 6 || LD == 8) && !(ul == 0 && s < 2)) c = nch;       // probe: only the first two steps load
+        if (TILED) {
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) {
                 const float* Wm = ACROSS ? p.w[rt] : p.w[0];
@@ -138,7 +160,7 @@ __global__ __launch_bounds__(kMfThreads) void gemm_mfma_rows(MfParams p) {
 #pragma unroll
                 for (int j = 0; j < JN; j++) {      // tile (rtile0 / 16), block jb of K / 16: 1 KiB, lane l at 16 l
                     const int jb = c * JN + j;
-                    const bool ok = c < nch && jb < nblk && rtile0 < p.rows;
+                    const bool ok = c < nch && jb < nblk && rtile0 < p.rows && !(LD == 10 && !(ul == 0 && s < 2));      // LD 10: probe without weight reads
                     const __amdgpu_buffer_rsrc_t ra = make_rsrc(Wm, ok ? mbytes : 0u);
                     A[rt][j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ra, (int)lane16, (int)((unsigned)rtile0 * kbytes + (unsigned)jb * 1024u), 2));
                 }
@@ -148,7 +170,7 @@ __global__ __launch_bounds__(kMfThreads) void gemm_mfma_rows(MfParams p) {
 #pragma unroll
                 for (int j = 0; j < JN; j++) {
                     const int jb = c * JN + j;
-                    const bool ok = c < nch && jb < nblk && pt < ntile;
+                    const bool ok = c < nch && jb < nblk && pt < ntile && !(LD == 9 && !(ul == 0 && s < 2));           // LD 9: probe without activation reads
                     const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.x, ok ? (unsigned)ntile * 16u * kbytes : 0u);
                     B[pt][j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rb, (int)lane16, (int)((unsigned)(pt * nblk + jb) * 1024u), 0));
                 }
@@ -184,7 +206,7 @@ __global__ __launch_bounds__(kMfThreads) void gemm_mfma_rows(MfParams p) {
     };
 
     auto compute = [&](f4 (&A)[RT][JN], f4 (&B)[PT][JN]) {
-        if (LD == 4) {      // probe: consume the loads with one VALU op each, no MFMA
+        if (LD == 4 || LD == 7) {      // probe: consume the loads with one VALU op each, no MFMA
 #pragma unroll
             for (int j = 0; j < JN; j++) {
 #pragma unroll
@@ -214,7 +236,7 @@ __global__ __launch_bounds__(kMfThreads) void gemm_mfma_rows(MfParams p) {
                 for (int rt = 0; rt < RT; rt++)
 #pragma unroll
                     for (int pt = 0; pt < PT; pt++)
-                        acc[rt][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[rt][j][e], B[pt][j][e], acc[rt][pt], 0, 0, 0);
+                        acc[rt][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[rt][j][e], B[pt][j][LD == 8 ? (e + 1) & 3 : e], acc[rt][pt], 0, 0, 0);      // LD 8: probe of operand register banks
     };
 
     // cross-wave sum of the unit's tiles + the fused epilogue.  D layout of a 16x16 tile: lane l
@@ -223,12 +245,6 @@ __global__ __launch_bounds__(kMfThreads) void gemm_mfma_rows(MfParams p) {
         const int u = u0 + ul;
         const int g = u / p.ksplit, ks = u - g * p.ksplit;
         const int r0 = g * rows_per_grp;
-#pragma unroll
-        for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-            for (int pt = 0; pt < PT; pt++)
-#pragma unroll
-                for (int e = 0; e < 4; e++) part[wave][rt * PT + pt][e][lane] = acc[rt][pt][e];
         if (p.ssp && tid < PT * 16) {      // cpu.rs:66-79's scale per token, from the kRmsParts partial sums of squares
             float t[16];
 #pragma unroll
@@ -239,7 +255,6 @@ __global__ __launch_bounds__(kMfThreads) void gemm_mfma_rows(MfParams p) {
                 for (int q = 0; q < n / 2; q++) t[q] = t[2 * q] + t[2 * q + 1];
             s_scale[tid] = rms_scale(t[0], p.K);
         }
-        __syncthreads();
         auto total4 = [&](int tile, int ln) {
             acc4 r;
 #pragma unroll
@@ -255,51 +270,99 @@ __global__ __launch_bounds__(kMfThreads) void gemm_mfma_rows(MfParams p) {
             }
             return r;
         };
-        constexpr int UNITS = (PAIR ? PT : NT) * 64;      // one unit = 4 consecutive rows of one token
-        for (int v = tid; v < UNITS; v += kMfThreads) {
-            const int ln = v & 63, tile = v >> 6;
-            const int rt = PAIR ? 0 : tile / PT, pt = PAIR ? tile : tile - rt * PT;
-            const int tk = pt * 16 + (ln & 15), r = r0 + (ACROSS ? 0 : rt * 16) + (ln >> 4) * 4;     // rows r .. r + 3
-            if (tk >= p.n_tok || r >= p.rows) continue;     // rows % 4 == 0: a unit is all in or all out
-            acc4 a = total4(PAIR ? pt : tile, ln);
-            const float nv = p.ssp ? s_scale[pt * 16 + (ln & 15)] : 1.0f;
-            if (p.ssp) { a[0] *= nv; a[1] *= nv; a[2] *= nv; a[3] *= nv; }
-            if (PAIR) {
-                acc4 b = total4(PT + pt, ln);
-                if (p.ssp) { b[0] *= nv; b[1] *= nv; b[2] *= nv; b[3] *= nv; }
+        // the tiles meet in LDS PTC token tiles at a time (one round for PT <= 4)
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const float sg = a[e] * (1.0f / (1.0f + expf(-a[e])));      // cpu.rs:56
-                    a[e] = sg * b[e];                                              // cpu.rs:59-64
+        for (int c0 = 0; c0 < PT; c0 += PTC) {
+            if (c0 > 0) __syncthreads();       // the previous round's reads are done
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                for (int pl = 0; pl < PTC; pl++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) part[wave][rt * PTC + pl][e][lane] = acc[rt][c0 + pl][e];
+            constexpr int UNITS = (PAIR ? PTC : NTC) * 64;      // one unit = 4 consecutive rows of one token
+            constexpr int ITER = (UNITS + kMfThreads - 1) / kMfThreads;
+            // EPI_QKV: the rotation coefficients and positions of my units are on their way before the barrier
+            float rot[ITER][4];
+            int posv[ITER];
+            if (EPI == EPI_QKV) {
+#pragma unroll
+                for (int it = 0; it < ITER; it++) {
+                    const int v = tid + it * kMfThreads, ln = v & 63, tile = v >> 6;
+                    const int rt = tile / PTC, tk = (c0 + tile - rt * PTC) * 16 + (ln & 15), r = r0 + (ln >> 4) * 4;
+                    rot[it][0] = rot[it][1] = rot[it][2] = rot[it][3] = 0.0f; posv[it] = 0;
+                    if (v < UNITS && tk < p.n_tok && r < p.rows) {
+                        posv[it] = p.seqs ? p.seqs[tk].pos : p.pos0 + tk;
+                        if (rt < 2) {
+                            const size_t fo = (size_t)posv[it] * (p.head_size >> 1) + ((r % p.head_size) >> 1);
+                            rot[it][0] = p.fr[fo]; rot[it][1] = p.fi[fo]; rot[it][2] = p.fr[fo + 1]; rot[it][3] = p.fi[fo + 1];
+                        }
+                    }
                 }
-                *reinterpret_cast<acc4*>(p.o + tile_idx(tk, r, p.rows)) = a;
-            } else if (EPI == EPI_QKV) {
-                const int pos = p.seqs ? p.seqs[tk].pos : p.pos0 + tk;
-                if (rt < 2) {                                                      // cpu.rs:87-96 rotate (q, k)
-                    const int i = (r % p.head_size) >> 1;
-                    const size_t fo = (size_t)pos * (p.head_size >> 1) + i;
-                    const float c0 = p.fr[fo], s0 = p.fi[fo], c1 = p.fr[fo + 1], s1 = p.fi[fo + 1];
-                    const acc4 t = a;
-                    a[0] = t[0] * c0 - t[1] * s0; a[1] = t[0] * s0 + t[1] * c0;
-                    a[2] = t[2] * c1 - t[3] * s1; a[3] = t[2] * s1 + t[3] * c1;
+            }
+            if (c0 == 0) MF_STAMP(2);
+            __syncthreads();
+            if (c0 == 0) MF_STAMP(3);
+#pragma unroll
+            for (int it = 0; it < ITER; it++) {
+                const int v = tid + it * kMfThreads;
+                if (v >= UNITS) break;
+                const int ln = v & 63, tile = v >> 6;
+                const int rt = PAIR ? 0 : tile / PTC, pl = PAIR ? tile : tile - rt * PTC, pt = c0 + pl;
+                const int tk = pt * 16 + (ln & 15), r = r0 + (ACROSS ? 0 : rt * 16) + (ln >> 4) * 4;     // rows r .. r + 3
+                if (tk >= p.n_tok || r >= p.rows) continue;     // rows % 4 == 0: a unit is all in or all out
+                acc4 a = total4(PAIR ? pl : tile, ln);
+                const float nv = p.ssp ? s_scale[pt * 16 + (ln & 15)] : 1.0f;
+                if (p.ssp) { a[0] *= nv; a[1] *= nv; a[2] *= nv; a[3] *= nv; }
+                if (PAIR) {
+                    acc4 b = total4(PTC + pl, ln);
+                    if (p.ssp) { b[0] *= nv; b[1] *= nv; b[2] *= nv; b[3] *= nv; }
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float sg = a[e] * (1.0f / (1.0f + expf(-a[e])));      // cpu.rs:56
+                        a[e] = sg * b[e];                                              // cpu.rs:59-64
+                    }
+                    *reinterpret_cast<acc4*>(p.o + tile_idx(tk, r, p.rows)) = a;
+                } else if (EPI == EPI_QKV) {
+                    const int pos = posv[it];
+                    if (rt < 2) {                                                      // cpu.rs:87-96 rotate (q, k)
+                        const float c0_ = rot[it][0], s0 = rot[it][1], c1 = rot[it][2], s1 = rot[it][3];
+                        const acc4 t = a;
+                        a[0] = t[0] * c0_ - t[1] * s0; a[1] = t[0] * s0 + t[1] * c0_;
+                        a[2] = t[2] * c1 - t[3] * s1; a[3] = t[2] * s1 + t[3] * c1;
+                    }
+                    if (rt == 0) *reinterpret_cast<acc4*>(p.o + tile_idx(tk, r, p.rows)) = a;
+                    else {                                                             // infer.rs:32-33
+                        float* cache = (rt == 1 ? (p.seqs ? p.seqs[tk].kc + p.layer_off : p.kc) : (p.seqs ? p.seqs[tk].vc + p.layer_off : p.vc));
+                        *reinterpret_cast<acc4*>(cache + (size_t)pos * p.rows + r) = a;
+                    }
+                } else if (EPI == EPI_STORE_ROWS) {
+                    *reinterpret_cast<acc4*>(p.o + (size_t)tk * p.o_stride + r) = a;
+                } else {                                                               // K-slice ks of the product, tile layout
+                    *reinterpret_cast<acc4*>(p.o + (size_t)ks * p.slab_floats + tile_idx(tk, r, p.rows)) = a;
                 }
-                if (rt == 0) *reinterpret_cast<acc4*>(p.o + tile_idx(tk, r, p.rows)) = a;
-                else {                                                             // infer.rs:32-33
-                    float* cache = (rt == 1 ? (p.seqs ? p.seqs[tk].kc + p.layer_off : p.kc) : (p.seqs ? p.seqs[tk].vc + p.layer_off : p.vc));
-                    *reinterpret_cast<acc4*>(cache + (size_t)pos * p.rows + r) = a;
-                }
-            } else if (EPI == EPI_STORE_ROWS) {
-                *reinterpret_cast<acc4*>(p.o + (size_t)tk * p.o_stride + r) = a;
-            } else {                                                               // K-slice ks of the product, tile layout
-                *reinterpret_cast<acc4*>(p.o + (size_t)ks * p.slab_floats + tile_idx(tk, r, p.rows)) = a;
             }
         }
         __syncthreads();       // part[] is rewritten by the next unit
     };
 
+    // MIX: the order of one step's region -- every load within the first MFMAs, the scalar work spread under all of them
+    auto mix = [&]() {
+        constexpr int NMF = 4 * JN * RT * PT, NLD = JN * (RT + PT);
+#pragma unroll
+        for (int i = 0; i < NMF; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x004, MIX, 0);                  // scalar ALU
+            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                    // vector ALU
+            if (i < NLD) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // one load
+        }
+    };
+
     // steps of a unit in pairs (buffer 0, buffer 1); the loads of the step after next are issued
     // before the current step's MFMAs, the first loads of the next unit before this unit's epilogue
     const int S2 = (S + 1) >> 1;
+    MF_STAMP(0);
+    MF_BLOCK_STAMP(0);
     issue(A0, B0, 0, 0);
 #pragma unroll 1
     for (int ul = 0; ul < nunit; ul++) {
@@ -307,19 +370,26 @@ __global__ __launch_bounds__(kMfThreads) void gemm_mfma_rows(MfParams p) {
         // the two waves of a SIMD run the same program: half a step of delay for waves 4-7 lets one
         // wave's loads / permutes fall under the other's MFMAs instead of both stalling together
         if (STAGGER > 0 && wave >= kMfWaves / 2) __builtin_amdgcn_s_sleep(STAGGER);
+        if (STAGGER == -1 && wave >= kMfWaves / 2) __builtin_amdgcn_s_setprio(1);      // probe: the SIMD's younger wave first
 #pragma unroll 1
         for (int i = 0; i < S2; i++) {
             __builtin_amdgcn_sched_barrier(0);
+            if (STAGGER == -2) { if (((i >> 1) & 1) == (wave >= kMfWaves / 2 ? 1 : 0)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }      // probe: turns
             issue(A1, B1, ul, 2 * i + 1);
-            __builtin_amdgcn_sched_barrier(0);
+            if (MIX == 0) __builtin_amdgcn_sched_barrier(0);
             compute(A0, B0);
+            if (MIX != 0) mix();
             __builtin_amdgcn_sched_barrier(0);
             if (i + 1 < S2) issue(A0, B0, ul, 2 * i + 2); else issue(A0, B0, ul + 1, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            if (MIX == 0) __builtin_amdgcn_sched_barrier(0);
             compute(A1, B1);
+            if (MIX != 0) mix();
         }
+        MF_STAMP(1);
         finish_unit(ul);
+        MF_STAMP(4);
     }
+    MF_BLOCK_STAMP(1);
 }
 
 // ---- small kernels on the tile layout

@@ -105,6 +105,7 @@ struct rama_ctx {
     float* topp_bp = nullptr; int* topp_bi = nullptr; int* topp_bcount = nullptr;       // topp_sort.hpp
     int tune_norm_in_gemm = 1;              // token-batch passes: the rmsnorm's per-token scale is applied by the consuming GEMM (one launch per norm instead of two)
     int tune_tiled = 1;                     // token-batch GEMMs read the model's tile-order weight copy when it exists
+    int tune_prefill_tok = kMfMaxTok;       // prompt positions per weight pass of rama_prefill: 128 (needs the tile-order copies) or 64
     int tune_prefill_attn = 1;              // 1: prefill passes run attention as MFMA tiles, 16 queries per workgroup (prefill_attn.hpp)
     int tune_graph_steps = -1;              // decode steps captured per hipGraph (the cursor lives on the device, so steps are identical); -1: 4 for dim <= 1024, else 1
     int tune_attn_u = 8;                    // cache rows per lane and round in the split-T attention (8 | 16; 16 measured no faster)
@@ -1246,8 +1247,11 @@ static int launch_mf(rama_ctx* c, MfParams& p, int pt) {
     if (p.tiled) {      // p.w[] point at the model's tile-order copies: contiguous 1-KiB weight reads, no lane permute
         if (pt == 1) hipLaunchKernelGGL((gemm_mfma_rows<1, RT, EPI, 2, 3>), grid, block, 0, c->stream, p);
         else if (pt == 2) hipLaunchKernelGGL((gemm_mfma_rows<2, RT, EPI, 2, 3>), grid, block, 0, c->stream, p);
-        else hipLaunchKernelGGL((gemm_mfma_rows<4, RT, EPI, 2, 3>), grid, block, 0, c->stream, p);
+        // MIX (loads scheduled into the MFMA stream) where tools/pf_mfma_bench.hip measures it faster: same arithmetic, same bits
+        else if (pt <= 4) hipLaunchKernelGGL((gemm_mfma_rows<4, RT, EPI, 2, 3, 0, (EPI == EPI_QKV || EPI == EPI_STORE) ? 2 : 0>), grid, block, 0, c->stream, p);
+        else hipLaunchKernelGGL((gemm_mfma_rows<8, RT, EPI, 1, 3, 0, EPI == EPI_QKV ? 2 : 0>), grid, block, 0, c->stream, p);      // 128 tokens: one K-block per step
     } else {
+        REQUIRE(pt <= 4, RAMA_EUNSUP, "token batch: more than 64 tokens per pass need the tile-order weight copy");
         if (pt == 1) hipLaunchKernelGGL((gemm_mfma_rows<1, RT, EPI>), grid, block, 0, c->stream, p);
         else if (pt == 2) hipLaunchKernelGGL((gemm_mfma_rows<2, RT, EPI>), grid, block, 0, c->stream, p);
         else hipLaunchKernelGGL((gemm_mfma_rows<4, RT, EPI>), grid, block, 0, c->stream, p);
@@ -1331,7 +1335,7 @@ static int run_layers_batched(rama_ctx* c, const rama_config* cfg, const rama_we
                               int nt, int p0, float* key_cache, float* value_cache, bool seqs, int tmax, int* nslab_out) {
     const int dim = cfg->dim, hidden = cfg->hidden_dim, hs = dim / cfg->n_heads;
     const size_t dd = (size_t)dim * dim, hd = (size_t)hidden * dim;
-    const int ntile = (nt + 15) / 16, pt = ntile <= 1 ? 1 : (ntile == 2 ? 2 : 4);
+    const int ntile = (nt + 15) / 16, pt = ntile <= 1 ? 1 : (ntile == 2 ? 2 : (ntile <= 4 ? 4 : 8));
     const int ks_wo = mf_ksplit(c, dim, dim), ks_w2 = mf_ksplit(c, dim, hidden);
     int pending = 0;      // K-slices of the previous product waiting in b.SL
     int rc;
@@ -1426,8 +1430,16 @@ int rama_prefill(rama_ctx* c, const rama_config* cfg, const rama_weights* w, ram
     rc = ensure_batch_scratch(c, cfg, false, &b); if (rc) return rc;
     c->embedded_x = nullptr; c->host_pos = -1;
     int last_nt = 0, nslab = 0;
-    for (int c0 = 0; c0 < n_tokens; c0 += kMfMaxTok) {
-        const int nt = std::min(kMfMaxTok, n_tokens - c0), p0 = pos0 + c0;
+    // positions per weight pass: 128 when every layer matrix has its tile-order copy, else 64
+    int per_pass = std::min(c->tune_prefill_tok, kMfMaxTok);
+    {
+        const float* ms[7] = {w->wq, w->wk, w->wv, w->wo, w->w1, w->w2, w->w3};
+        bool all = c->tune_tiled != 0;
+        for (int i = 0; i < 7 && all; i++) all = rama_internal_tiled_lookup(ms[i]) != nullptr;
+        if (!all) per_pass = std::min(per_pass, kMfMaxTokRows);
+    }
+    for (int c0 = 0; c0 < n_tokens; c0 += per_pass) {
+        const int nt = std::min(per_pass, n_tokens - c0), p0 = pos0 + c0;
         last_nt = nt;
         // the ids go through the context's pinned staging buffer: the caller's array may be gone
         // before the copy runs
@@ -1457,7 +1469,7 @@ static int enqueue_batch_pass(rama_ctx* c, const rama_config* cfg, const rama_we
     int rc = run_layers_batched(c, cfg, w, b, n_seq, 0, nullptr, nullptr, true, tmax, &nslab);
     if (rc) return rc;
     // infer.rs:49-51 for every sequence: fold the last product, final rmsnorm, classifier
-    const int ntile = (n_seq + 15) / 16, pt = ntile <= 1 ? 1 : (ntile == 2 ? 2 : 4);
+    const int ntile = (n_seq + 15) / 16, pt = ntile <= 1 ? 1 : (ntile == 2 ? 2 : (ntile <= 4 ? 4 : 8));
     rc = launch_rmsnorm_tile(c, b, w->rms_final_weight, dim, ntile, nslab); if (rc) return rc;
     MfParams p{};
     p.n_tok = n_seq; p.ksplit = 1; { const float* bs[1] = {w->wcls}; mf_weights(c, p, 1, bs, 0, 0); }
@@ -1471,7 +1483,7 @@ static int enqueue_batch_pass(rama_ctx* c, const rama_config* cfg, const rama_we
 int rama_decode_batch(rama_ctx* c, const rama_config* cfg, const rama_weights* w, const rama_run_state* states,
                       const int32_t* tokens_host, const int32_t* pos_host, int n_seq) {
     REQUIRE(c && states && tokens_host && pos_host, RAMA_EINVAL, "decode_batch: NULL argument");
-    REQUIRE(n_seq >= 1 && n_seq <= kMfMaxTok, RAMA_EINVAL, "decode_batch: 1..64 sequences per call");
+    REQUIRE(n_seq >= 1 && n_seq <= kMfMaxTokRows, RAMA_EINVAL, "decode_batch: 1..64 sequences per call");
     int rc = check_cfg(cfg); if (rc) return rc;
     rama_stage st{0, cfg->n_layers, 1, 1};
     if (set_device(c)) return 1;
@@ -1564,7 +1576,7 @@ __global__ __launch_bounds__(1024) void argmax_batch_kernel(BatchArgmaxParams p)
 int rama_decode_batch_begin(rama_ctx* c, const rama_config* cfg, const rama_weights* w, const rama_run_state* states,
                             const int32_t* tokens_host, const int32_t* pos_host, int n_seq, int max_steps) {
     REQUIRE(c && states && tokens_host && pos_host, RAMA_EINVAL, "decode_batch_begin: NULL argument");
-    REQUIRE(n_seq >= 1 && n_seq <= kMfMaxTok, RAMA_EINVAL, "decode_batch_begin: 1..64 sequences");
+    REQUIRE(n_seq >= 1 && n_seq <= kMfMaxTokRows, RAMA_EINVAL, "decode_batch_begin: 1..64 sequences");
     REQUIRE(max_steps >= 1 && max_steps <= (1 << 20), RAMA_EINVAL, "decode_batch_begin: bad max_steps");
     int rc = check_cfg(cfg); if (rc) return rc;
     REQUIRE(mf_shape_ok(cfg) && cfg->vocab_size % 4 == 0 && !c->tune_ref_order, RAMA_EUNSUP,
@@ -1873,6 +1885,11 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
     if (!strcmp(key, "tiled")) {
         REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: tiled must be 0 or 1");
         c->tune_tiled = value;
+        return 0;
+    }
+    if (!strcmp(key, "prefill_tok")) {
+        REQUIRE(value == 64 || value == 128, RAMA_EINVAL, "set_tuning: prefill_tok must be 64 or 128");
+        c->tune_prefill_tok = value;
         return 0;
     }
     if (!strcmp(key, "prefill_attn")) {

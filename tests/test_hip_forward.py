@@ -695,6 +695,7 @@ def test_tile_order_weight_copy_gives_identical_results(dev, shape, n_tokens):
         lo = orc.forward(t, pos)
     arr = (C.c_int32 * n_tokens)(*toks)
     outs = {}
+    check(dev.lib.rama_set_tuning(dev.ctx, b"prefill_tok", 64))      # 128-token passes split K differently: their own test below
     for mode in (1, 0):
         eng = rama_amd.Engine(dev, model)
         check(dev.lib.rama_set_tuning(dev.ctx, b"tiled", mode))
@@ -715,10 +716,61 @@ def test_tile_order_weight_copy_gives_identical_results(dev, shape, n_tokens):
                 e.free()
         finally:
             check(dev.lib.rama_set_tuning(dev.ctx, b"tiled", 1))
+    check(dev.lib.rama_set_tuning(dev.ctx, b"prefill_tok", 128))
     assert np.abs(outs[1][0] - lo).max() <= LOGIT_ATOL
     assert np.array_equal(outs[1][0], outs[0][0]) and np.array_equal(outs[1][1], outs[0][1])
     for a, b in zip(outs[1][2], outs[0][2]):
         assert np.array_equal(a, b)
+    model.free()
+
+
+@pytest.mark.parametrize("shape,n_tokens,pos0", [((128, 352, 2, 2, 256, 320), 65, 0), ((128, 352, 2, 2, 256, 320), 100, 3), ((128, 352, 2, 2, 256, 320), 128, 0),
+                                                 ((128, 352, 2, 2, 256, 320), 129, 0), ((128, 352, 2, 1, 256, 320), 300, 5), ((288, 768, 2, 6, 512, 256), 113, 0),
+                                                 ((768, 2048, 1, 12, 1024, 256), 128, 17)])
+def test_prefill_128_positions_per_weight_pass(dev, shape, n_tokens, pos0):
+    """with the tile-order weight copies a prefill pass takes up to 128 positions (8 token tiles per wave, one
+    K-block per step, the cross-wave fold in two rounds): every tile count 5..8, a partly filled last tile, several
+    passes and a non-zero start give the state sequential forward() calls leave (oracle as referee), and
+    the 64-position passes (rama_set_tuning "prefill_tok" = 64) agree to rounding"""
+    import ctypes as C
+    import rama_amd
+    from rama_amd._lib import check
+    dim, hidden, L, H, V, seq = shape
+    ocfg = O.Config(dim, hidden, L, H, H, V, seq, True)
+    cfg = rama_amd.Config(dim, hidden, L, H, H, V, seq, True)
+    rope = S.rope_tables(seq, dim // H)
+    w = S.synth_weights(ocfg, seed=37, rope=rope)
+    model = rama_amd.Model.synth(dev, cfg, 37, rope=rope)
+    rng = np.random.default_rng(n_tokens)
+    toks = [1] + [int(t) for t in rng.integers(0, V, pos0 + n_tokens - 1)]
+    orc = O.Oracle(ocfg, w)
+    for pos, t in enumerate(toks):
+        lo = orc.forward(t, pos)
+    lo = lo.copy()
+    want = {k: orc.s[k].copy() for k in ("key_cache", "value_cache", "xb")}
+    nxt = O.argmax(lo)
+    lo2 = orc.forward(nxt, pos0 + n_tokens).copy()
+    arr = (C.c_int32 * n_tokens)(*toks[pos0:])
+    outs = {}
+    for per_pass in (128, 64):
+        eng = rama_amd.Engine(dev, model)
+        for pos in range(pos0):
+            eng.forward(toks[pos], pos)
+        check(dev.lib.rama_set_tuning(dev.ctx, b"prefill_tok", per_pass))
+        try:
+            check(dev.lib.rama_prefill(dev.ctx, C.byref(model.ccfg), C.byref(model.weights), C.byref(eng.state), arr, n_tokens, pos0), "rama_prefill")
+        finally:
+            check(dev.lib.rama_set_tuning(dev.ctx, b"prefill_tok", 128))
+        outs[per_pass] = (eng.logits(), eng.buffer("key_cache", L * seq * dim), eng.buffer("value_cache", L * seq * dim), eng.buffer("x", dim))
+        assert np.abs(outs[per_pass][0] - lo).max() <= LOGIT_ATOL, per_pass
+        assert np.abs(outs[per_pass][1] - want["key_cache"]).max() <= STATE_ATOL, per_pass
+        assert np.abs(outs[per_pass][2] - want["value_cache"]).max() <= STATE_ATOL, per_pass
+        assert np.abs(outs[per_pass][3] - want["xb"]).max() <= STATE_ATOL, per_pass
+        # and decoding simply continues from there
+        eng.forward(nxt, pos0 + n_tokens)
+        assert np.abs(eng.logits() - lo2).max() <= LOGIT_ATOL, per_pass
+        eng.free()
+    assert np.abs(outs[128][0] - outs[64][0]).max() <= 2e-5
     model.free()
 
 

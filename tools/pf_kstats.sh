@@ -1,0 +1,19 @@
+#!/bin/bash
+# kernel-trace statistics of one prefill (on the GPU box): tools/pf_kstats.sh <name> <n_positions> [shape]
+# -> gpurun_out/<name>_kernel_stats.csv   (rocprofv3 gets `python3 tools/prefill_once.py ...` directly after `--`)
+set -e
+name=$1; shift
+repo=${GRAFT_REPO_ROOT:-/root/repo}
+out=$repo/gpurun_out
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/_ks_$name
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/_ks_$name -o t -- python3 $repo/tools/prefill_once.py "$@" > $out/${name}.log 2>&1
+cp $(find /tmp/_ks_$name -name '*kernel_stats.csv' | head -1) $out/${name}_kernel_stats.csv
+python3 - $out/${name}_kernel_stats.csv <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
+for r in rows[:14]:
+    print(f'{float(r["AverageNs"])/1e3:9.2f} us x{int(r["Calls"]):6d}  {float(r["Percentage"]):5.1f}%  {r["Name"][:120]}')
+PY
