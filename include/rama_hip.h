@@ -173,13 +173,15 @@ int  rama_forward_stage(rama_ctx *ctx, const rama_config *cfg, const rama_weight
 
 /* Batched-prompt prefill (no reference counterpart): the same state as
  * n_tokens calls rama_forward(tokens[i], pos0 + i) -- KV-cache rows pos0..pos0+n-1 of every layer,
- * residual x and logits of the LAST position -- with the weights streamed once per 64 positions, as
+ * residual x and logits of the LAST position -- with the weights streamed once per 128 positions (64 when the
+ * weights are not a resident rama_model's: the 128-position kernels read the model's tile-order copies), as
  * dense fp32 GEMMs on the matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, csrc/prefill_mfma.hpp).
  * dim or hidden_dim not a multiple of 16: falls back to one rama_forward per token. */
 int  rama_prefill(rama_ctx *ctx, const rama_config *cfg, const rama_weights *w, rama_run_state *s,
                   const int32_t *tokens_host, int n_tokens, int pos0);
 
-/* One decode step for up to 64 INDEPENDENT sequences (the server's concurrent requests), every
+/* One decode step for up to 128 INDEPENDENT sequences (64 without a resident rama_model's tile-order copies; the
+ * server's concurrent requests), every
  * weight row streamed once for all of them (no reference counterpart; same MFMA kernels as the
  * prefill).  states[i] is sequence i's run state; afterwards it holds what
  * rama_forward(token_i, pos_i) would have left in it: the appended cache rows and the logits
@@ -299,7 +301,8 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *                   2 (default) = as 1, and rows wider than 8192 floats (W2) spread over 16 waves,
  *                   one chunk each per step (+1.15 % more); 3 = 16 waves x 4 chunks
  *   "prefill" = 0|1 : 1 (default) lets rama_generate_greedy push the forced prompt positions through
- *                   rama_prefill (up to 64 positions per weight pass) instead of one forward per token
+ *                   rama_prefill (up to 128 positions per weight pass) instead of one forward per token
+ *   "prefill_tok" = 64|128 : positions per weight pass of rama_prefill (default 128; 64 = round 2's kernels)
  *   "merge" = -1|0|1 : 1 runs attention and the Wo matvec as one launch when the occupancy API says
  *                   its whole grid is resident (Wo's weights stream while attention runs); -1
  *                   (default) turns it on for dim <= 1024 only: measured +4.2 % / +7.7 % tokens/s at

@@ -1285,7 +1285,7 @@ struct BatchScratch { float *X, *XN, *Q, *XB, *HB, *SL, *LG, *SSP; size_t slab; 
 
 static int ensure_batch_scratch(rama_ctx* c, const rama_config* cfg, bool with_logits, BatchScratch* b) {
     const size_t T = kMfMaxTok, dim = cfg->dim, hidden = cfg->hidden_dim;
-    const size_t ints = 64 + (sizeof(SeqSlot) / sizeof(int)) * T;
+    const size_t ints = T + (sizeof(SeqSlot) / sizeof(int)) * T;      // token ids [T], then the sequence table [T]
     const size_t ssp = (T / 16) * kRmsParts * 16;        // partial sums of squares per (tile, part, token)
     const size_t need = T * (8 * dim + hidden) + ssp + ints + 64 + (with_logits ? T * (size_t)cfg->vocab_size : 0);
     if (need > c->pf_floats) {
@@ -1302,7 +1302,7 @@ static int ensure_batch_scratch(rama_ctx* c, const rama_config* cfg, bool with_l
     b->SL = b->XB + T * dim; b->HB = b->SL + 4 * T * dim;
     b->SSP = b->HB + T * hidden;
     b->toks = reinterpret_cast<int*>(b->SSP + ssp);
-    b->seqs = reinterpret_cast<SeqSlot*>(b->toks + 64);
+    b->seqs = reinterpret_cast<SeqSlot*>(b->toks + T);
     b->LG = reinterpret_cast<float*>(b->toks + ints + 64);      // ints is a multiple of 4: 16-byte aligned
     return 0;
 }
@@ -1323,6 +1323,15 @@ static int launch_rmsnorm_tile(rama_ctx* c, const BatchScratch& b, const float* 
     return 0;
 }
 static const float* norm_ssp(const rama_ctx* c, const BatchScratch& b) { return c->tune_norm_in_gemm ? b.SSP : nullptr; }
+
+// tokens (prefill) / sequences (decode_batch) one weight pass can take: 128 when every matrix it streams has its
+// tile-order copy (8 token tiles per wave need the contiguous 1-KiB weight reads), else 64
+static int mf_pass_cap(const rama_ctx* c, const rama_weights* w, bool with_cls) {
+    const float* ms[8] = {w->wq, w->wk, w->wv, w->wo, w->w1, w->w2, w->w3, w->wcls};
+    bool all = c->tune_tiled != 0;
+    for (int i = 0; i < (with_cls ? 8 : 7) && all; i++) all = rama_internal_tiled_lookup(ms[i]) != nullptr;
+    return all ? kMfMaxTok : kMfMaxTokRows;
+}
 
 static bool mf_shape_ok(const rama_config* cfg) { return cfg->dim % 16 == 0 && cfg->hidden_dim % 16 == 0; }
 
@@ -1431,13 +1440,7 @@ int rama_prefill(rama_ctx* c, const rama_config* cfg, const rama_weights* w, ram
     c->embedded_x = nullptr; c->host_pos = -1;
     int last_nt = 0, nslab = 0;
     // positions per weight pass: 128 when every layer matrix has its tile-order copy, else 64
-    int per_pass = std::min(c->tune_prefill_tok, kMfMaxTok);
-    {
-        const float* ms[7] = {w->wq, w->wk, w->wv, w->wo, w->w1, w->w2, w->w3};
-        bool all = c->tune_tiled != 0;
-        for (int i = 0; i < 7 && all; i++) all = rama_internal_tiled_lookup(ms[i]) != nullptr;
-        if (!all) per_pass = std::min(per_pass, kMfMaxTokRows);
-    }
+    const int per_pass = std::min(c->tune_prefill_tok, mf_pass_cap(c, w, false));
     for (int c0 = 0; c0 < n_tokens; c0 += per_pass) {
         const int nt = std::min(per_pass, n_tokens - c0), p0 = pos0 + c0;
         last_nt = nt;
@@ -1483,10 +1486,13 @@ static int enqueue_batch_pass(rama_ctx* c, const rama_config* cfg, const rama_we
 int rama_decode_batch(rama_ctx* c, const rama_config* cfg, const rama_weights* w, const rama_run_state* states,
                       const int32_t* tokens_host, const int32_t* pos_host, int n_seq) {
     REQUIRE(c && states && tokens_host && pos_host, RAMA_EINVAL, "decode_batch: NULL argument");
-    REQUIRE(n_seq >= 1 && n_seq <= kMfMaxTokRows, RAMA_EINVAL, "decode_batch: 1..64 sequences per call");
+    REQUIRE(n_seq >= 1 && n_seq <= kMfMaxTok, RAMA_EINVAL, "decode_batch: 1..128 sequences per call");
     int rc = check_cfg(cfg); if (rc) return rc;
     rama_stage st{0, cfg->n_layers, 1, 1};
     if (set_device(c)) return 1;
+    if (c->tune_tiled && !c->tune_ref_order && n_seq > kMfMaxTokRows) { rc = rama_internal_model_ensure(c, w, 2); if (rc) return rc; }
+    REQUIRE(n_seq <= kMfMaxTokRows || c->tune_ref_order || mf_pass_cap(c, w, true) >= n_seq, RAMA_EINVAL,
+            "decode_batch: more than 64 sequences per call need a resident model's tile-order weight copies");
     for (int i = 0; i < n_seq; i++) {
         rc = check_stage(cfg, w, &states[i], &st); if (rc) return rc;
         REQUIRE(tokens_host[i] >= 0 && tokens_host[i] < cfg->vocab_size, RAMA_EINVAL, "decode_batch: token outside the vocabulary");
@@ -1576,13 +1582,16 @@ __global__ __launch_bounds__(1024) void argmax_batch_kernel(BatchArgmaxParams p)
 int rama_decode_batch_begin(rama_ctx* c, const rama_config* cfg, const rama_weights* w, const rama_run_state* states,
                             const int32_t* tokens_host, const int32_t* pos_host, int n_seq, int max_steps) {
     REQUIRE(c && states && tokens_host && pos_host, RAMA_EINVAL, "decode_batch_begin: NULL argument");
-    REQUIRE(n_seq >= 1 && n_seq <= kMfMaxTokRows, RAMA_EINVAL, "decode_batch_begin: 1..64 sequences");
+    REQUIRE(n_seq >= 1 && n_seq <= kMfMaxTok, RAMA_EINVAL, "decode_batch_begin: 1..128 sequences");
     REQUIRE(max_steps >= 1 && max_steps <= (1 << 20), RAMA_EINVAL, "decode_batch_begin: bad max_steps");
     int rc = check_cfg(cfg); if (rc) return rc;
     REQUIRE(mf_shape_ok(cfg) && cfg->vocab_size % 4 == 0 && !c->tune_ref_order, RAMA_EUNSUP,
             "decode_batch_begin: needs dim, hidden_dim multiples of 16, vocab_size a multiple of 4, fast mode");
     rama_stage st{0, cfg->n_layers, 1, 1};
     if (set_device(c)) return 1;
+    if (c->tune_tiled && n_seq > kMfMaxTokRows) { rc = rama_internal_model_ensure(c, w, 2); if (rc) return rc; }
+    REQUIRE(n_seq <= kMfMaxTokRows || mf_pass_cap(c, w, true) >= n_seq, RAMA_EINVAL,
+            "decode_batch_begin: more than 64 sequences need a resident model's tile-order weight copies");
     int pmax = 0;
     for (int i = 0; i < n_seq; i++) {
         rc = check_stage(cfg, w, &states[i], &st); if (rc) return rc;

@@ -174,7 +174,7 @@ class Engine:
 def decode_batch(engines: Sequence["Engine"], tokens: Sequence[int], positions: Sequence[int]):
     """One decode step for up to 64 independent sequences over the same model (rama_decode_batch):
     engines[i] advances by forward(tokens[i], positions[i]); its logits()/caches are updated."""
-    assert 1 <= len(engines) == len(tokens) == len(positions) <= 64
+    assert 1 <= len(engines) == len(tokens) == len(positions) <= 128
     e0 = engines[0]
     states = (rama_run_state * len(engines))(*[e.state for e in engines])
     toks = (C.c_int32 * len(engines))(*tokens)
@@ -186,7 +186,7 @@ def decode_batch(engines: Sequence["Engine"], tokens: Sequence[int], positions: 
 def decode_batch_chained(engines: Sequence["Engine"], tokens: Sequence[int], positions: Sequence[int], n_steps: int):
     """n_steps greedy decode steps of up to 64 independent sequences chained on the device (rama_decode_batch_begin /
     _steps / _tokens): -> per sequence the n_steps tokens it produced.  engines[i]'s caches are advanced."""
-    assert 1 <= len(engines) == len(tokens) == len(positions) <= 64
+    assert 1 <= len(engines) == len(tokens) == len(positions) <= 128
     e0 = engines[0]
     L = e0.device.lib
     states = (rama_run_state * len(engines))(*[e.state for e in engines])

@@ -912,9 +912,10 @@ def test_decode_batch_equals_independent_forwards(dev, name, n_seq):
     m.free()
 
 
-@pytest.mark.parametrize("n_seq", [17, 40, 64])
+@pytest.mark.parametrize("n_seq", [17, 40, 64, 65, 100, 128])
 def test_decode_batch_many_sequences(dev, n_seq):
-    """more sequences than one 16-token MFMA tile: up to 64 independent sequences per weight pass"""
+    """more sequences than one 16-token MFMA tile: up to 128 independent sequences per weight pass (beyond 64: the
+    8-token-tile kernels on the model's tile-order copies)"""
     import rama_amd
     cfg = O.Config(128, 352, 2, 4, 4, 256, 24, True)
     rope = S.rope_tables(cfg.seq_len, cfg.head_size)
@@ -944,7 +945,7 @@ def test_decode_batch_many_sequences(dev, n_seq):
 
 
 @pytest.mark.parametrize("graph", [False, True])
-@pytest.mark.parametrize("n_seq", [1, 5, 19, 64])
+@pytest.mark.parametrize("n_seq", [1, 5, 19, 64, 97])
 def test_decode_batch_chained_equals_independent_generations(dev, n_seq, graph):
     """rama_decode_batch_begin / _steps / _tokens: the cursors of every sequence live on the device, a step ends with
     one argmax per sequence and (graph mode) is one hipGraph replay.  Every sequence must produce the greedy tokens
@@ -1020,6 +1021,27 @@ def test_decode_batch_argument_errors(dev):
     with pytest.raises(rama_amd.RamaError):
         rama_amd.decode_batch([a, b], [1, 1], [0, cfg.seq_len])       # position outside the context
     a.free(); b.free(); m.free()
+
+
+def test_decode_batch_beyond_64_needs_the_tile_order_copies(dev):
+    """65+ sequences per pass run the 8-token-tile kernels, which read the model's tile-order weight copies: with the
+    copies switched off ("tiled" = 0) the call is refused, not silently split"""
+    import rama_amd
+    from rama_amd._lib import check
+    cfg = O.Config(64, 176, 1, 4, 4, 96, 8, True)
+    rope = S.rope_tables(cfg.seq_len, cfg.head_size)
+    m = rama_amd.Model.synth(dev, to_rama_cfg(cfg), 2, rope=rope)
+    batch = [rama_amd.Engine(dev, m) for _ in range(65)]
+    check(dev.lib.rama_set_tuning(dev.ctx, b"tiled", 0))
+    try:
+        with pytest.raises(rama_amd.RamaError):
+            rama_amd.decode_batch(batch, [1] * 65, [0] * 65)
+        rama_amd.decode_batch(batch[:64], [1] * 64, [0] * 64)
+    finally:
+        check(dev.lib.rama_set_tuning(dev.ctx, b"tiled", 1))
+    rama_amd.decode_batch(batch, [1] * 65, [0] * 65)
+    for e in batch: e.free()
+    m.free()
 
 
 def test_interleaved_w13_copy_equals_two_tensor_path(dev, tmp_path):

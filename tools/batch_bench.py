@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Aggregate decode throughput with B independent sequences sharing each weight pass
-(rama_decode_batch, B = 1..64) at the llama2-7B shape; greedy tokens are fed back through the host
-(argmax of each sequence's logits on the device, 4 bytes each).  Prints one JSON line."""
+(rama_decode_batch, B = 1..128) at the llama2-7B shape; greedy tokens are fed back through the host
+(argmax of each sequence's logits on the device, 4 bytes each).  Prints one JSON line.
+Usage: python tools/batch_bench.py [shape] [steps] [seq_len override]"""
 import ctypes as C
 import json, sys, time
 from pathlib import Path
@@ -12,11 +13,13 @@ from bench import SHAPES
 name = sys.argv[1] if len(sys.argv) > 1 else "llama2-7B"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 48
 d, h, L, H, V, seq, shared = SHAPES[name]
+if len(sys.argv) > 3: seq = int(sys.argv[3])      # a shorter context: 128 sequences x 2 048 positions of KV cache would not fit beside the model
 cfg = rama_amd.Config(d, h, L, H, H, V, seq, shared)
 dev = rama_amd.Hip(0)
 model = rama_amd.Model.synth(dev, cfg, seed=0)
 out = {}
-for B in (1, 8, 16, 32, 64):
+for B in (1, 8, 16, 32, 64, 128):
+    if B * 2 * L * seq * d * 4 > 150e9: continue
     engs = [rama_amd.Engine(dev, model) for _ in range(B)]
     cur = [1 + i for i in range(B)]
     nxt = C.c_int32()
@@ -48,4 +51,4 @@ for B in (1, 8, 16, 32, 64):
         out[B]["chained_graph" if graph else "chained_eager"] = {"ms_per_step": round(dt * 1e3 / steps, 3), "aggregate_tok_s": round(B * steps / dt, 1)}
     engs[0].set_graph_mode(False)
     for e in engs: e.free()
-print(json.dumps({"config": name, "steps": steps, "by_batch": out}))
+print(json.dumps({"config": name, "seq_len": seq, "steps": steps, "by_batch": out}))
