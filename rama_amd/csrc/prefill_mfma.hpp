@@ -84,7 +84,8 @@ __device__ unsigned long long g_mf_stamps[kMfWaves][8];
 __device__ unsigned long long g_mf_blocks[1024][4];      // per workgroup: start, end, HW_ID, XCC_ID
 #define MF_BLOCK_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 1024) { g_mf_blocks[blockIdx.x][k] = __builtin_amdgcn_s_memrealtime(); \
     if (k == 0) { g_mf_blocks[blockIdx.x][2] = __builtin_amdgcn_s_getreg(63492); g_mf_blocks[blockIdx.x][3] = __builtin_amdgcn_s_getreg(63508); } } } while (0)
-#define MF_STAMP(id) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == RAMA_MF_STAMP_BLOCK) g_mf_stamps[threadIdx.x >> 6][id] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define MF_STAMP(id) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == RAMA_MF_STAMP_BLOCK) { g_mf_stamps[threadIdx.x >> 6][id] = __builtin_amdgcn_s_memrealtime(); \
+    if (id < 2) g_mf_stamps[threadIdx.x >> 6][5 + id] = __builtin_amdgcn_s_memtime(); } } while (0)      /* [5], [6]: core-clock cycles at stamps 0 and 1 */
 #else
 #define MF_STAMP(id) do { } while (0)
 #define MF_BLOCK_STAMP(k) do { } while (0)
@@ -98,7 +99,8 @@ __device__ unsigned long long g_mf_blocks[1024][4];      // per workgroup: start
 // LD  1: row-major weights as described above.  3: weights in tile order (the model's second copy,
 //     model.hip make_tiled): the A operand is one contiguous 1-KiB read per wave, no lane permute.
 //     4, 5 (row-major) and 6, 7 (tile order) are TIMING PROBES of the microbenchmark with wrong results:
-//     5, 6 load in the first two steps only, 4, 7 replace the MFMAs by one vector add per operand.
+//     5, 6 load in the first two steps only (8: + rotated B registers; 9 / 10: only the activation / weight loads go;
+//     11: the whole issue section goes), 4, 7 replace the MFMAs by one vector add per operand.
 // MIX 1: the loads of the next step and their scalar bookkeeping are scheduled INTO the current step's
 //     MFMA stream (one MFMA, then a few scalar / vector / memory instructions, ...) instead of in front of it: a wave
 //     issues them in the shadow of its own MFMAs, whatever the SIMD's other wave is doing
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(kMfThreads) void gemm_mfma_rows(MfParams p) {
     static_assert(!PAIR || RT == 2, "SwiGLU groups are one w1 tile + one w3 tile");
     static_assert(EPI != EPI_QKV || RT == 3, "QKV groups are one tile of each of wq, wk, wv");
     constexpr int CHUNK = 16 * JN;                       // floats of K per wave per step
-    constexpr bool TILED = LD == 3 || (LD >= 6 && LD <= 10);
+    constexpr bool TILED = LD == 3 || (LD >= 6 && LD <= 11);
     constexpr int PTC = PT > 4 ? 4 : PT;                 // token tiles per round of the cross-wave fold (LDS: 8 KiB per tile)
     constexpr int NTC = RT * PTC;
     __shared__ float part[kMfWaves][NTC][4][64];
@@ -146,6 +148,7 @@ __global__ __launch_bounds__(kMfThreads) void gemm_mfma_rows(MfParams p) {
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const unsigned lane16 = (unsigned)lane * 16u;
     auto issue = [&](f4 (&A)[RT][JN], f4 (&B)[PT][JN], int ul, int s) {
+        if (LD == 11 && !(ul == 0 && s < 2)) return;                             // probe: nothing but MFMAs after the first two steps
         const int u = u0 + ul;
         const int g = p.ksplit == 1 ? u : u / p.ksplit, ks = u - g * p.ksplit;
         const int r0 = g * rows_per_grp;
@@ -370,11 +373,12 @@ __global__ __launch_bounds__(kMfThreads) void gemm_mfma_rows(MfParams p) {
         // the two waves of a SIMD run the same program: half a step of delay for waves 4-7 lets one
         // wave's loads / permutes fall under the other's MFMAs instead of both stalling together
         if (STAGGER > 0 && wave >= kMfWaves / 2) __builtin_amdgcn_s_sleep(STAGGER);
-        if (STAGGER == -1 && wave >= kMfWaves / 2) __builtin_amdgcn_s_setprio(1);      // probe: the SIMD's younger wave first
+        if (STAGGER == -1 && wv >= kMfWaves / 2) __builtin_amdgcn_s_setprio(1);      // the SIMD's younger wave first (wv: wave-uniform, or the branch is an exec mask around an unconditional s_setprio)
 #pragma unroll 1
         for (int i = 0; i < S2; i++) {
             __builtin_amdgcn_sched_barrier(0);
-            if (STAGGER == -2) { if (((i >> 1) & 1) == (wave >= kMfWaves / 2 ? 1 : 0)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }      // probe: turns
+            if (STAGGER == -2) { if ((i & 1) == (wv >= kMfWaves / 2 ? 1 : 0)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }      // probe: the two waves of a SIMD take turns per pair of steps
+            if (STAGGER == -3) { if (((i >> 2) & 1) == (wv >= kMfWaves / 2 ? 1 : 0)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }      // ... per 8 steps
             issue(A1, B1, ul, 2 * i + 1);
             if (MIX == 0) __builtin_amdgcn_sched_barrier(0);
             compute(A0, B0);

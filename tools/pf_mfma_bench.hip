@@ -104,10 +104,18 @@ int main(int argc, char** argv) {
         {"PT8 swiglu probe: no X lds ", launch<8, 2, 1, 9, MODE_SWIGLU>, 128, 1, false},
         {"PT8 swiglu probe: no W lds ", launch<8, 2, 1, 10, MODE_SWIGLU>, 128, 1, false},
         {"PT8 swiglu probe: no loads ", launch<8, 2, 1, 6, MODE_SWIGLU>, 128, 1, false},
+        {"PT8 qkv3 MFMAs only        ", launch<8, 3, 1, 11, MODE_QKV>, 128, 1, false},
+        {"PT8 swiglu MFMAs only      ", launch<8, 2, 1, 11, MODE_SWIGLU>, 128, 1, false},
         {"PT8 qkv3 no loads, B bank+1", launch<8, 3, 1, 8, MODE_QKV>, 128, 1, false},
         {"PT8 qkv3 no loads, prio 4-7", launch<8, 3, 1, 6, MODE_QKV, -1>, 128, 1, false},
         {"PT8 qkv3 no loads, prio alt", launch<8, 3, 1, 6, MODE_QKV, -2>, 128, 1, false},
+        {"PT8 qkv3 MFMAs only prio4-7", launch<8, 3, 1, 11, MODE_QKV, -1>, 128, 1, false},
+        {"PT8 qkv3 MFMAs only prioalt", launch<8, 3, 1, 11, MODE_QKV, -2>, 128, 1, false},
+        {"PT8 qkv3 J1 prio 4-7       ", launch<8, 3, 1, 3, MODE_QKV, -1>, 128, 1, false},
         {"PT8 qkv3 J1 prio alt       ", launch<8, 3, 1, 3, MODE_QKV, -2>, 128, 1, false},
+        {"PT8 qkv3 J1 prio alt8      ", launch<8, 3, 1, 3, MODE_QKV, -3>, 128, 1, false},
+        {"PT8 swiglu J1 prio 4-7     ", launch<8, 2, 1, 3, MODE_SWIGLU, -1>, 128, 1, false},
+        {"PT8 swiglu J1 prio alt     ", launch<8, 2, 1, 3, MODE_SWIGLU, -2>, 128, 1, false},
         {"PT8 qkv3 J1 probe: no MFMA ", launch<8, 3, 1, 7, MODE_QKV>, 128, 1, false},
         {"PT8 RT2 ks2 probe: no loads", launch<8, 2, 1, 6, MODE_ROWS>, 128, 2, false},
         {"PT4 qkv3 J2 probe: no loads", launch<4, 3, 2, 6, MODE_QKV>, 64, 1, false},
@@ -177,7 +185,8 @@ int main(int argc, char** argv) {
                 for (int w = 0; w < kMfWaves; w++) {
                     printf("      wave %d:", w);
                     for (int k = 0; k < 5; k++) printf(" %7.2f", (double)(h[w][k] - h[0][0]) / 100.0);
-                    printf("   (start, loop end, fold written, barrier, epilogue end) us\n");
+                    printf("   (start, loop end, fold written, barrier, epilogue end) us; core clock over the loop %.0f MHz\n",
+                           (double)(h[w][6] - h[w][5]) / ((double)(h[w][1] - h[w][0]) / 100.0));
                 }
             }
 #endif
