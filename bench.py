@@ -80,6 +80,20 @@ def pmc_traffic(kernel_substr):
     return None, None
 
 
+def pmc_token_traffic(shape, mode):
+    """HBM read bytes per TOKEN (every launch of the decode loop) from the committed PMC pass of a small shape
+    (tools/collect_profiles.py --config <shape>), gfx950 correction applied; None when there is no such pass."""
+    import glob
+    suffix = "_parity" if mode == "parity" else ""
+    files = sorted(glob.glob(str(REPO / "profiles" / f"r*_bench_{shape}{suffix}_pmc_fetch_size.json")))
+    for f in reversed(files):
+        with open(f) as fh:
+            v = json.load(fh).get("hbm_read_bytes_per_token_corrected")
+        if v:
+            return v, f"profiles/{Path(f).name}"
+    return None, None
+
+
 def _mem_available_gb() -> float:
     try:
         with open("/proc/meminfo") as f:
@@ -285,6 +299,9 @@ def single_gpu(args, local_rank):
                      "tok_s": orr[head]["tok_s"], "frac_of_8TBps": orr[head]["frac_of_8TBps"]}
             for m_, r in orr.items():
                 entry[m_ + "_mode"] = {k: v for k, v in r.items() if k not in ("tokens", "kernels")}
+                tr, src = pmc_token_traffic(name, m_)
+                entry[m_ + "_mode"]["traffic_per_token"] = tr           # whole-token HBM reads (PMC pass of its own), vs algorithmic_bytes_per_token
+                entry[m_ + "_mode"]["traffic_source"] = src
             if ocheck and "parity" in orr:
                 entry["parity_mode"].update(ocheck)
             entry["cpu_baseline"] = ocpu

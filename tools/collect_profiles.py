@@ -27,12 +27,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--round", type=int, default=1)
 ap.add_argument("--out", default=str(REPO / "gpurun_out" / "profiles"))
 ap.add_argument("--mode", default="fast", choices=["fast", "parity"], help="which decode mode of bench.py to profile")
+ap.add_argument("--config", default="llama2-7B", help="shape of bench.py to profile (files are named ..._bench_7b... for llama2-7B, ..._bench_<shape>... otherwise)")
 a = ap.parse_args()
 out = Path(a.out).resolve()
 out.mkdir(parents=True, exist_ok=True)
 tag = f"r{a.round:02d}"
 suffix = "_parity" if a.mode == "parity" else ""
-mode_args = ["--mode", a.mode, "--no-other-configs"]
+mode_args = ["--mode", a.mode, "--no-other-configs", "--config", a.config]
+short = "7b" if a.config == "llama2-7B" else a.config
 env = dict(os.environ, TMPDIR="/tmp")
 bench = str(REPO / "bench.py")
 
@@ -51,7 +53,7 @@ cmd1 = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d"
 run(cmd1, d1)
 stats = glob.glob(str(d1 / "**" / "*kernel_stats.csv"), recursive=True)
 assert stats, "rocprofv3 wrote no kernel_stats.csv"
-shutil.copy(stats[0], out / f"{tag}_bench_7b{suffix}_kernel_stats.csv")
+shutil.copy(stats[0], out / f"{tag}_bench_{short}{suffix}_kernel_stats.csv")
 
 # 2. counters, in a pass of their own
 d2 = out / "_pmc"
@@ -71,8 +73,13 @@ with open(cc[0]) as f:
         k[1] += float(r["Counter_Value"])
 rows = [{"kernel": name, "counter": "FETCH_SIZE", "launches": n, "avg_value_KB": round(tot / n, 3),
          "hbm_read_bytes_corrected": int(round(tot / n * 1024 * 2))} for name, (n, tot) in sorted(acc.items())]
-with open(out / f"{tag}_bench_7b{suffix}_pmc_fetch_size.json", "w") as f:
-    json.dump({"command": " ".join(cmd2[:5]) + " -- python bench.py --steps 16 --warmup 2 --no-cpu-baseline --no-kprof --graph 0",
+# whole-token traffic: every launch of the decode loop (one argmax launch per token; model set-up kernels left out)
+setup = ("fill_synth", "tile_weights", "interleave_rows", "chain_weights", "rocclr", "rope_table")
+tokens = sum(n for name, (n, tot) in acc.items() if "argmax_kernel" in name)
+per_token = int(round(sum(tot for name, (n, tot) in acc.items() if not any(k in name for k in setup)) * 1024 * 2 / tokens)) if tokens else None
+with open(out / f"{tag}_bench_{short}{suffix}_pmc_fetch_size.json", "w") as f:
+    json.dump({"command": " ".join(cmd2[:5]) + f" -- python bench.py --steps 16 --warmup 2 --no-cpu-baseline --no-kprof --graph 0 --mode {a.mode} --config {a.config}",
+               "tokens": tokens, "hbm_read_bytes_per_token_corrected": per_token,
                "note": "FETCH_SIZE is reported in KB; on gfx950 it counts 128-B requests at 64 B, i.e. exactly half of a wide "
                        "coalesced read (MI355X_MICROARCH.md, HBM section): hbm_read_bytes_corrected = value * 1024 * 2",
                "rows": rows}, f, indent=1)
