@@ -53,6 +53,8 @@ def parse(argv=None):
     ap.add_argument("--graph", type=int, default=1, help="replay each decode step from a hipGraph")
     ap.add_argument("--mode", default="both", choices=["both", "parity", "fast"],
                     help="parity: the reference's rounding order (bit-identical logits; the headline); fast: fused/tree sums")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
+                    help="rama_set_tuning(KEY, VALUE) on every engine before timing (A/B runs under the profiler); repeatable")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kprof", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the stories15M / stories110M lines")
@@ -216,6 +218,9 @@ def kernel_times(eng, cfg_seq, pos, tokens, bytes_, ksteps=16):
     return kernels
 
 
+TUNE = []      # (key, value) pairs of --tune
+
+
 def run_shape(dev, name, steps, warmup, pos0, graph, modes, kprof):
     """the requested modes of one shape on one resident model -> (cfg, model, bytes, {mode: {...}})"""
     import rama_amd
@@ -228,6 +233,8 @@ def run_shape(dev, name, steps, warmup, pos0, graph, modes, kprof):
     for mode in modes:
         eng = rama_amd.Engine(dev, model)
         eng.set_tuning("ref_order", 1 if mode == "parity" else 0)
+        for k_, v_ in TUNE:
+            eng.set_tuning(k_, v_)
         eng.set_graph_mode(bool(graph))
         wall_ms, ev_ms, pos, tokens = time_decode(eng, dev, seq, steps, warmup, pos0, PROMPT)
         tok_s = steps / (wall_ms * 1e-3)
@@ -262,6 +269,7 @@ def roofline_of(kernels, bytes_, mode, d):
 
 def single_gpu(args, local_rank):
     import rama_amd
+    TUNE[:] = [(kv.split("=")[0], int(kv.split("=")[1])) for kv in args.tune]
     dev = rama_amd.Hip(local_rank)
     modes = ["fast", "parity"] if args.mode == "both" else [args.mode]
     head = "parity" if "parity" in modes else "fast"
