@@ -415,8 +415,10 @@ __device__ __forceinline__ bool seq_sum_predict(const float* a, int n, PredShare
 // given, receives x unchanged first (infer.rs:49: xb = x before the final norm writes x in place).
 constexpr int kNormMax = 16384;
 constexpr int kNormWaves = 4, kNormThreads = kNormWaves * 64;     // one wave per SIMD: the scan rounds are bound by instruction issue
-__global__ __launch_bounds__(kNormThreads) void rmsnorm_chain_kernel(float* o, const float* x, const float* w, int n, float* copy_to) {
+// (a grid of several workgroups: vector b of a token batch, `stride` floats after the one before it)
+__global__ __launch_bounds__(kNormThreads) void rmsnorm_chain_kernel(float* o, const float* x, const float* w, int n, float* copy_to, int stride = 0) {
     RAMA_NO_CONTRACT
+    o += (size_t)blockIdx.x * stride; x += (size_t)blockIdx.x * stride;
     extern __shared__ __attribute__((aligned(16))) float s_sq[];
     __shared__ SeqSumShared<kNormWaves> sh;
     __shared__ PredShared<kNormWaves> ps;
@@ -717,6 +719,164 @@ __global__ __launch_bounds__(W * 64) void gemv_chain_kernel(ChainParams p) {
     }
 }
 
+// ---------------------------------------------------------------- token batches in the reference's order (parity-mode prefill)
+// O[t][r] = the chain-order product of row r with activation vector t, for T = 4 TPW tokens at once: the same
+// per-output sequence of roundings as gemv_chain_kernel (k ascending in each of the four lane chains k = j mod 4, separate
+// multiply and add, (v0 + v1) + (v2 + v3)), with every weight read ONCE for the T tokens.
+//   A workgroup of 4 waves owns 16 rows; lane = (row, chain j) as in the decode kernel; wave w carries the sums of
+//   tokens w TPW .. w TPW + TPW - 1.  The chain is walked in chunks of 16 blocks (256 floats of K): 16 KiB of weights
+//   (chain order: a straight copy) and 1 KiB of activations per token (transposed into chain order on the way) go
+//   HBM / L2 -> registers -> LDS, three chunks in flight in registers, two LDS slots, ONE barrier per chunk; from LDS a wave
+//   reads a block's weights once (16 bytes per lane) and each of its tokens' 4 x 4 activations as a broadcast.
+//   Per block and wave: TPW x (4 multiplies + 4 adds) -- at TPW = 4 a pass is bound by the vector ALUs and the HBM
+//   stream about equally (13 GFLOP-pairs per token at 2 instructions each vs 26.4 GB per pass at llama2-7B).
+//   Blocks behind the end of a row: weights dropped by the descriptor's range check, activations stored as zeros: + (0 * 0).
+struct GemmChainParams {
+    const float* w[3];      // chain-order matrices (nmat <= 3), each [ceil(rows / 16) * 16, K]
+    int nmat, K, rows;      // SWIGLU: rows = 2 * hidden (interleaved W1 | W3)
+    const float* x; int xstride;          // activations [n_tok][xstride], row-major
+    float* o[3]; int ostride;             // STORE / RESID: o[0][t][row] (RESID: may be NULL); QKV: q = o[0]; SWIGLU: hb = o[0][t][row / 2]
+    float* resid; int rstride;            // RESID: resid[t][row] += product (infer.rs:37,47)
+    int n_tok;
+    int pos0; const float* fr; const float* fi; int head_size; float* kc; float* vc;      // QKV: token t sits at pos0 + t; this layer's cache slabs
+};
+constexpr int kGcWaves = 4, kGcThreads = kGcWaves * 64;
+constexpr int kGcBlocks = 16;            // blocks of 16 floats per chunk
+constexpr int kGcSets = 3;               // chunks in flight in registers
+__host__ __device__ constexpr size_t gemm_chain_lds_bytes(int tpw) { return 2 * ((size_t)kGcBlocks * 1024 + (size_t)(4 * tpw) * kGcBlocks * 64); }
+
+template <int TPW, int EPI>
+__global__ __launch_bounds__(kGcThreads) void gemm_chain_kernel(GemmChainParams p) {
+    RAMA_NO_CONTRACT
+    constexpr int T = kGcWaves * TPW;                            // tokens of a pass
+    constexpr int XF = TPW;                                      // 16-byte pieces of activations per thread and chunk (T x 64 / 256)
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    f4* wl = reinterpret_cast<f4*>(gsm);                         // [2][kGcBlocks * 64] weights, chain order
+    float* xl = gsm + 2 * kGcBlocks * 256;                       // [2][T][kGcBlocks * 16] activations, chain order per token
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 3, rr = lane >> 2;
+    const int groups = (p.rows + 15) >> 4;
+    const int m = __builtin_amdgcn_readfirstlane(blockIdx.x / groups), g = blockIdx.x - m * groups;
+    const float* Wm = m == 0 ? p.w[0] : (m == 1 ? p.w[1] : p.w[2]);
+    const int nblk = p.K >> 4;
+    const int nchunk = (nblk + kGcBlocks - 1) / kGcBlocks;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc_uniform(p.x, (unsigned)((size_t)p.n_tok * (size_t)p.xstride * 4u));
+    f4 wreg[kGcSets][4], xreg[kGcSets][XF];
+
+    // loads of chunk c into register set S (c >= nchunk: nothing but zeros, no memory touched)
+    auto issue = [&](int c, f4 (&wr)[4], f4 (&xr)[XF]) {
+        const int left = min(max(nblk - c * kGcBlocks, 0), kGcBlocks);
+        const __amdgpu_buffer_rsrc_t rw = make_rsrc_uniform(Wm + ((size_t)g * (size_t)nblk + (size_t)min(c, nchunk) * kGcBlocks) * 256, (unsigned)left * 1024u);
+#pragma unroll
+        for (int n = 0; n < 4; n++) wr[n] = ld_nt(rw, (unsigned)(tid + kGcThreads * n) * 16u);
+#pragma unroll
+        for (int n = 0; n < XF; n++) {
+            const int q = tid + kGcThreads * n, t = q >> 6, i = q & 63;      // token, 16-byte piece of its 256 floats
+            const int k = c * (kGcBlocks * 16) + i * 4;
+            xr[n] = ld_c(rx, (t < p.n_tok && k < p.K) ? (unsigned)(((size_t)t * (size_t)p.xstride + (size_t)k) * 4u) : kOOB);
+        }
+    };
+    // registers -> LDS slot: weights as they are, activations xs[16 s + 4 j + i] = x[16 s + 4 i + j] (gemv_chain_kernel's order)
+    auto stage = [&](int slot, const f4 (&wr)[4], const f4 (&xr)[XF]) {
+#pragma unroll
+        for (int n = 0; n < 4; n++) wl[slot * (kGcBlocks * 64) + tid + kGcThreads * n] = wr[n];
+#pragma unroll
+        for (int n = 0; n < XF; n++) {
+            const int q = tid + kGcThreads * n, t = q >> 6, i = q & 63;
+            float* d = xl + ((size_t)slot * T + t) * (kGcBlocks * 16) + 16 * (i >> 2) + (i & 3);
+            d[0] = xr[n].x; d[4] = xr[n].y; d[8] = xr[n].z; d[12] = xr[n].w;
+        }
+    };
+    float acc[TPW];
+#pragma unroll
+    for (int tt = 0; tt < TPW; tt++) acc[tt] = 0.0f;
+    auto compute = [&](int slot) {
+        const f4* wq = wl + slot * (kGcBlocks * 64) + lane;
+        const float* xb = xl + ((size_t)slot * T + (size_t)wave * TPW) * (kGcBlocks * 16) + 4 * j;
+#pragma unroll
+        for (int u = 0; u < kGcBlocks; u++) {
+            const f4 wv = wq[u * 64];
+#pragma unroll
+            for (int tt = 0; tt < TPW; tt++) {
+                const f4 xv = *reinterpret_cast<const f4*>(xb + tt * (kGcBlocks * 16) + 16 * u);
+                float v = acc[tt];
+                v = v + wv.x * xv.x;
+                v = v + wv.y * xv.y;
+                v = v + wv.z * xv.z;
+                v = v + wv.w * xv.w;
+                acc[tt] = v;
+            }
+        }
+    };
+    // chunk c is computed from slot c % 2; before that, chunk c + 1 (in registers since step c - 2) goes to the other
+    // slot and chunk c + 1 + kGcSets is requested into the registers it leaves
+    issue(0, wreg[0], xreg[0]);
+    issue(1, wreg[1], xreg[1]);
+    issue(2, wreg[2], xreg[2]);
+    stage(0, wreg[0], xreg[0]);
+    issue(3, wreg[0], xreg[0]);
+    __syncthreads();
+#define RAMA_GC_STEP(S_)                                                                          \
+    if (c + S_ < nchunk) {                                                                         \
+        stage((c + S_ + 1) & 1, wreg[(S_ + 1) % kGcSets], xreg[(S_ + 1) % kGcSets]);              \
+        issue(c + S_ + 1 + kGcSets, wreg[(S_ + 1) % kGcSets], xreg[(S_ + 1) % kGcSets]);          \
+        compute((c + S_) & 1);                                                                     \
+        __syncthreads();                                                                           \
+    }
+    for (int c = 0; c < nchunk; c += 6) {      // 6 = lcm(register sets, slots): every index below is a constant
+        RAMA_GC_STEP(0) RAMA_GC_STEP(1) RAMA_GC_STEP(2) RAMA_GC_STEP(3) RAMA_GC_STEP(4) RAMA_GC_STEP(5)
+    }
+#undef RAMA_GC_STEP
+    // epilogues of gemv_chain_kernel, per token
+    const int row = 16 * g + rr;
+#pragma unroll
+    for (int tt = 0; tt < TPW; tt++) {
+        const int t = wave * TPW + tt;
+        const float v = acc[tt];
+        const float t2 = v + dpp_mov<0xB1>(v);                   // (v0 + v1) + (v2 + v3)
+        const float d = t2 + dpp_mov<0x4E>(t2);
+        const float other = __shfl_xor(d, 4);                    // the neighbouring row (RoPE pair / W3 row)
+        if (t >= p.n_tok) continue;                              // uniform per wave
+        if (EPI == CEPI_STORE) {
+            if (j == 0 && row < p.rows) p.o[0][(size_t)t * p.ostride + row] = d;
+        } else if (EPI == CEPI_RESID) {
+            if (j == 0 && row < p.rows) {
+                if (p.o[0]) p.o[0][(size_t)t * p.ostride + row] = d;
+                float* xr_ = p.resid + (size_t)t * p.rstride + row;
+                *xr_ = *xr_ + d;
+            }
+        } else if (EPI == CEPI_QKV) {
+            const int pos = p.pos0 + t;
+            float out = d;
+            if (m < 2) {
+                const int i = ((row & ~1) % p.head_size) >> 1;   // infer.rs:15-16
+                const float rc = p.fr[(size_t)pos * (p.head_size >> 1) + i], rs = p.fi[(size_t)pos * (p.head_size >> 1) + i];
+                const float a = (rr & 1) ? other : d, b = (rr & 1) ? d : other;
+                out = (rr & 1) ? a * rs + b * rc : a * rc - b * rs;          // cpu.rs:87-96
+            }
+            if (j == 0 && row < p.rows) {
+                if (m == 0) p.o[0][(size_t)t * p.ostride + row] = out;
+                else if (m == 1) p.kc[(size_t)pos * p.rows + row] = out;     // infer.rs:32
+                else p.vc[(size_t)pos * p.rows + row] = out;                 // infer.rs:33
+            }
+        } else {   // CEPI_SWIGLU: even row = W1 row i, odd row = W3 row i
+            if (j == 0 && !(rr & 1) && row < p.rows) {
+                const float sl = d * (1.0f / (1.0f + expf_glibc(-d)));       // cpu.rs:56
+                p.o[0][(size_t)t * p.ostride + (row >> 1)] = sl * other;      // cpu.rs:59-64
+            }
+        }
+    }
+}
+
+// X[t] = token_embedding_table[tokens[t]] (infer.rs:13), rows of a token batch
+__global__ void embed_rows_kernel(float* X, const float* emb, const int* tokens, int n_tok, int dim) {
+    const int t = blockIdx.y;
+    if (t >= n_tok) return;
+    const size_t base = (size_t)tokens[t] * dim;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < dim; k += gridDim.x * blockDim.x) X[(size_t)t * dim + k] = emb[base + k];
+}
+
 // ---------------------------------------------------------------- cpu.rs:23-52 multi_head_attention
 // One workgroup of NW waves per head.
 //  * Scores: thread t owns timestep t; its q.k dot runs over the head in index order.  A lane reading its own
@@ -752,7 +912,9 @@ __global__ __launch_bounds__(NW * 64) void attention_chain_kernel(RefAttnParams 
     __shared__ float red[16];
     const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pos = p.ctl ? p.ctl->pos : p.pos_val;
+    const int pos = (p.ctl ? p.ctl->pos : p.pos_val) + (int)blockIdx.y;
+    p.q += (size_t)blockIdx.y * p.tok_stride; p.xb += (size_t)blockIdx.y * p.tok_stride;
+    if (p.att) p.att += (size_t)blockIdx.y * p.att_stride;
     const int hs = p.head_size, hs4 = hs >> 2;
     float* s_q = sm;                                              // [hs]
     float* s_p = sm + ((hs + 3) & ~3);                            // [seq_len] the probabilities, unskewed (read 4 at a time)

@@ -123,6 +123,9 @@ struct rama_ctx {
     float* attn_part = nullptr;            // split-T partials [n_heads, nsplit, head_size + 4]
     size_t attn_part_floats = 0;
     float* pf_blob = nullptr;              // token-batch scratch (tile layout): see BatchScratch
+    float* pc_blob = nullptr;              // parity-mode prefill scratch (row-major token batches): see prefill_chain
+    size_t pc_floats = 0;
+    int tune_prefill_chain = 1;            // parity mode: prompt positions go through the chain-order token-batch kernels (16 per weight pass); 0: one forward() each
     size_t pf_floats = 0;
     int host_pos = -1;                     // position of the next chained decode step (mirrors the device cursor)
     bool split_attn = false;               // variant the steps being enqueued / captured use
@@ -211,6 +214,12 @@ int rama_ctx_create(int device, void* hip_stream, rama_ctx** out) {
     HIPCHK(hipFuncSetAttribute((const void*)attention_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnChainMaxLds));
     HIPCHK(hipFuncSetAttribute((const void*)attention_chain_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnChainMaxLds));
     HIPCHK(hipFuncSetAttribute((const void*)attention_chain_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnChainMaxLds));
+#define RAMA_GC_ATTR(TPW_) \
+    HIPCHK(hipFuncSetAttribute((const void*)gemm_chain_kernel<TPW_, CEPI_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_chain_lds_bytes(TPW_))); \
+    HIPCHK(hipFuncSetAttribute((const void*)gemm_chain_kernel<TPW_, CEPI_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_chain_lds_bytes(TPW_))); \
+    HIPCHK(hipFuncSetAttribute((const void*)gemm_chain_kernel<TPW_, CEPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_chain_lds_bytes(TPW_)));
+    RAMA_GC_ATTR(1) RAMA_GC_ATTR(2) RAMA_GC_ATTR(4)
+#undef RAMA_GC_ATTR
     *out = c;
     return 0;
 }
@@ -239,7 +248,7 @@ int rama_ctx_destroy(rama_ctx* c) {
     for (auto e : c->kp.ev) hipEventDestroy(e);
     hipFree(c->ctl); hipFree(c->out); hipFree(c->forced); hipFree(c->argmax_result); hipFree(c->pbar); hipFree(c->attn_counter); hipFree(c->attn_part);
     for (int i = 0; i < 2; i++) { hipFree(c->topp_keys[i]); hipFree(c->topp_vals[i]); }
-    hipFree(c->topp_prefix); hipFree(c->topp_m); hipFree(c->topp_err); hipFree(c->pf_blob);
+    hipFree(c->topp_prefix); hipFree(c->topp_m); hipFree(c->topp_err); hipFree(c->pf_blob); hipFree(c->pc_blob);
     hipFree(c->topp_bp); hipFree(c->topp_bi); hipFree(c->topp_bcount);
     hipFree(c->bc.toks); hipFree(c->bc.seqs); hipFree(c->bc.out);
     hipHostFree(c->pinned_int); hipHostFree(c->pinned_tok);
@@ -462,9 +471,9 @@ static int launch_chain(rama_ctx* c, ChainParams& p) {
     return 0;
 }
 static bool rmsnorm_chain_ok(size_t n) { return n <= (size_t)kNormMax && (n + (n >> 5) + 2) * sizeof(float) <= 64 * 1024; }
-static int launch_rmsnorm_chain(rama_ctx* c, float* o, const float* x, const float* w, int n, float* copy_to) {
+static int launch_rmsnorm_chain(rama_ctx* c, float* o, const float* x, const float* w, int n, float* copy_to, int batch = 1, int stride = 0) {
     const size_t lds = ((size_t)n + ((size_t)n >> 5) + 2) * sizeof(float);
-    hipLaunchKernelGGL(rmsnorm_chain_kernel, dim3(1), dim3(kNormThreads), lds, c->stream, o, x, w, n, copy_to);
+    hipLaunchKernelGGL(rmsnorm_chain_kernel, dim3(batch), dim3(kNormThreads), lds, c->stream, o, x, w, n, copy_to, stride);
     LAUNCHCHK();
     return 0;
 }
@@ -1417,6 +1426,103 @@ static int run_layers_batched(rama_ctx* c, const rama_config* cfg, const rama_we
     return 0;
 }
 
+// ---- parity mode: the forced prompt positions in the reference's rounding order, 16 per weight pass (chain.hpp
+// gemm_chain_kernel).  Every position's cache rows are what its own forward() writes, bit for bit: the same chains per
+// output, the same exact sums in the norms and the softmax, the same attention per (head, position).  The LAST position
+// then goes through forward() itself, which leaves the run state (x, xb, q, .., logits) exactly as the reference's loop
+// does (mod.rs:187-194).  *done = false: shape or copies not available, nothing was enqueued.
+template <int EPI>
+static int launch_gemm_chain(rama_ctx* c, GemmChainParams& p) {
+    const dim3 grid(p.nmat * ((p.rows + 15) / 16)), block(kGcThreads);
+    if (p.n_tok <= 4) hipLaunchKernelGGL((gemm_chain_kernel<1, EPI>), grid, block, gemm_chain_lds_bytes(1), c->stream, p);
+    else if (p.n_tok <= 8) hipLaunchKernelGGL((gemm_chain_kernel<2, EPI>), grid, block, gemm_chain_lds_bytes(2), c->stream, p);
+    else hipLaunchKernelGGL((gemm_chain_kernel<4, EPI>), grid, block, gemm_chain_lds_bytes(4), c->stream, p);
+    LAUNCHCHK();
+    return 0;
+}
+constexpr int kGcMaxTok = 4 * kGcWaves;
+
+static int prefill_chain(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s,
+                         const int32_t* tokens_host, int n_tokens, int pos0, bool* done) {
+    *done = false;
+    const int dim = cfg->dim, hidden = cfg->hidden_dim, hs = dim / cfg->n_heads, H = cfg->n_heads, seq = cfg->seq_len;
+    if (!c->tune_chain || !c->tune_prefill_chain || dim % 16 || hidden % 16 || dim > 16000 || hidden > 16000 || !attn_chain_ok(hs, seq)) return 0;
+    if (!rmsnorm_chain_ok((size_t)dim) || n_tokens < 2) return 0;
+    int rc = rama_internal_model_ensure(c, w, 1); if (rc) return rc;
+    const float* cq = rama_internal_chain_lookup(w->wq, dim, dim), *ck = rama_internal_chain_lookup(w->wk, dim, dim);
+    const float* cv = rama_internal_chain_lookup(w->wv, dim, dim), *co = rama_internal_chain_lookup(w->wo, dim, dim);
+    const float* c13 = rama_internal_chain_lookup(w->w1, 2 * hidden, dim), *c2 = rama_internal_chain_lookup(w->w2, dim, hidden);
+    if (!cq || !ck || !cv || !co || !c13 || !c2) return 0;
+    *done = true;
+    // scratch, row-major per token: X residual stream, XN its norm, Q, XB attention output, HB; att rows; token ids
+    const size_t T = kGcMaxTok;
+    const size_t need = T * (4 * (size_t)dim + hidden) + T * (size_t)H * seq + 64;
+    if (need > c->pc_floats) {
+        if (c->pc_blob) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->pc_blob)); c->pc_blob = nullptr; }
+        HIPCHK(hipMalloc(&c->pc_blob, need * sizeof(float)));
+        c->pc_floats = need;
+    }
+    float* X = c->pc_blob, *XN = X + T * dim, *Q = XN + T * dim, *XB = Q + T * dim, *HB = XB + T * dim, *ATT = HB + T * hidden;
+    int* toks = reinterpret_cast<int*>(ATT + T * (size_t)H * seq);
+    const size_t dd = (size_t)dim * dim, hd = (size_t)hidden * dim;
+    const int nw = attn_chain_waves(hs, false);
+    const size_t att_lds = attn_chain_lds_floats(hs, seq, nw) * sizeof(float) + 16;
+    REQUIRE(att_lds <= kAttnChainMaxLds, RAMA_EUNSUP, "prefill (parity mode): context too long for the score buffer");
+    c->embedded_x = nullptr; c->host_pos = -1;
+    const int n_batch = n_tokens - 1;                             // the last position runs as forward()
+    for (int c0 = 0; c0 < n_batch; c0 += kGcMaxTok) {
+        const int nt = std::min(kGcMaxTok, n_batch - c0), p0 = pos0 + c0;
+        HIPCHK(hipStreamSynchronize(c->stream));                  // the pinned staging buffer is free again
+        memcpy(c->pinned_tok, tokens_host + c0, sizeof(int) * nt);
+        HIPCHK(hipMemcpyAsync(toks, c->pinned_tok, sizeof(int) * nt, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(embed_rows_kernel, dim3((dim + 255) / 256, nt), dim3(256), 0, c->stream, X, w->token_embedding_table, (const int*)toks, nt, dim);
+        LAUNCHCHK();
+        for (int layer = 0; layer < cfg->n_layers; layer++) {
+            const size_t li = (size_t)layer;
+            float* kc = s->key_cache + li * seq * dim;
+            float* vc = s->value_cache + li * seq * dim;
+            rc = launch_rmsnorm_chain(c, XN, X, w->rms_att_weight + li * dim, dim, nullptr, nt, dim); if (rc) return rc;      // infer.rs:19
+            {   // :20-33
+                GemmChainParams p{};
+                p.w[0] = cq + li * dd; p.w[1] = ck + li * dd; p.w[2] = cv + li * dd; p.nmat = 3; p.K = dim; p.rows = dim;
+                p.x = XN; p.xstride = dim; p.o[0] = Q; p.ostride = dim; p.n_tok = nt;
+                p.pos0 = p0; p.fr = w->freq_cis_real; p.fi = w->freq_cis_imag; p.head_size = hs; p.kc = kc; p.vc = vc;
+                rc = launch_gemm_chain<CEPI_QKV>(c, p); if (rc) return rc;
+            }
+            {   // :34, one workgroup per (head, position)
+                RefAttnParams a{};
+                a.q = Q; a.kc = kc; a.vc = vc; a.att = ATT; a.xb = XB; a.ctl = nullptr; a.pos_val = p0;
+                a.dim = dim; a.head_size = hs; a.seq_len = seq; a.tok_stride = dim; a.att_stride = H * seq;
+                const dim3 grid(H, nt);
+                if (nw == 4) hipLaunchKernelGGL((attention_chain_kernel<4>), grid, dim3(4 * 64), att_lds, c->stream, a);
+                else if (nw == 8) hipLaunchKernelGGL((attention_chain_kernel<8>), grid, dim3(8 * 64), att_lds, c->stream, a);
+                else hipLaunchKernelGGL((attention_chain_kernel<16>), grid, dim3(16 * 64), att_lds, c->stream, a);
+                LAUNCHCHK();
+            }
+            {   // :35-37
+                GemmChainParams p{};
+                p.w[0] = co + li * dd; p.nmat = 1; p.K = dim; p.rows = dim; p.x = XB; p.xstride = dim; p.n_tok = nt;
+                p.resid = X; p.rstride = dim;
+                rc = launch_gemm_chain<CEPI_RESID>(c, p); if (rc) return rc;
+            }
+            rc = launch_rmsnorm_chain(c, XN, X, w->rms_ffn_weight + li * dim, dim, nullptr, nt, dim); if (rc) return rc;      // :39
+            {   // :41-45
+                GemmChainParams p{};
+                p.w[0] = c13 + li * 2 * hd; p.nmat = 1; p.K = dim; p.rows = 2 * hidden; p.x = XN; p.xstride = dim; p.n_tok = nt;
+                p.o[0] = HB; p.ostride = hidden;
+                rc = launch_gemm_chain<CEPI_SWIGLU>(c, p); if (rc) return rc;
+            }
+            {   // :46-47
+                GemmChainParams p{};
+                p.w[0] = c2 + li * hd; p.nmat = 1; p.K = hidden; p.rows = dim; p.x = HB; p.xstride = hidden; p.n_tok = nt;
+                p.resid = X; p.rstride = dim;
+                rc = launch_gemm_chain<CEPI_RESID>(c, p); if (rc) return rc;
+            }
+        }
+    }
+    return rama_forward(c, cfg, w, s, tokens_host[n_tokens - 1], pos0 + n_tokens - 1);
+}
+
 int rama_prefill(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s,
                  const int32_t* tokens_host, int n_tokens, int pos0) {
     REQUIRE(c && tokens_host, RAMA_EINVAL, "prefill: NULL argument");
@@ -1428,6 +1534,11 @@ int rama_prefill(rama_ctx* c, const rama_config* cfg, const rama_weights* w, ram
     if (set_device(c)) return 1;
     const int dim = cfg->dim;
     const size_t att_floats = (size_t)attn_scratch_floats((dim / cfg->n_heads) <= 64 ? 16 : ((dim / cfg->n_heads) <= 128 ? 32 : 64)) + pos0 + n_tokens;
+    if (c->tune_ref_order) {      // parity mode: the chain-order token-batch kernels when the shape and the copies allow
+        bool done = false;
+        rc = prefill_chain(c, cfg, w, s, tokens_host, n_tokens, pos0, &done);
+        if (rc || done) return rc;
+    }
     if (c->tune_ref_order || !mf_shape_ok(cfg) || att_floats * sizeof(float) > 64 * 1024) {
         // reference-order mode; widths that are not whole 16-float blocks, or contexts the one-workgroup attention cannot
         // hold: the reference's own schedule, one forward() per forced token (mod.rs:187-194)
@@ -1894,6 +2005,11 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
     if (!strcmp(key, "tiled")) {
         REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: tiled must be 0 or 1");
         c->tune_tiled = value;
+        return 0;
+    }
+    if (!strcmp(key, "prefill_chain")) {
+        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: prefill_chain must be 0 or 1");
+        c->tune_prefill_chain = value;
         return 0;
     }
     if (!strcmp(key, "prefill_tok")) {

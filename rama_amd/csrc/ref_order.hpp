@@ -179,6 +179,9 @@ struct RefAttnParams {
     float* att; float* xb;
     const Ctl* ctl; int pos_val;
     int dim, head_size, seq_len;
+    // a grid of (heads, tokens) -- the parity-mode prefill pass, chain.hpp: token y sits at position pos + y, its q / xb
+    // rows are y * tok_stride floats further on, its att rows y * att_stride.  (0, 0 and gridDim.y = 1: one token.)
+    int tok_stride, att_stride;
 };
 
 __global__ __launch_bounds__(1024) void attention_ref_kernel(RefAttnParams p) {

@@ -356,3 +356,47 @@ def test_model_long_context_bit_exact(dev, n_heads, hs):
             assert_bits_equal(att, orc.s["att"].reshape(n_heads, seq)[:, :pos + 1], f"long context pos {pos} att")
     eng.set_graph_mode(False)
     eng.free(); model.free()
+
+
+@pytest.mark.parametrize("shape,n_tokens,pos0", [((64, 176, 2, 4, 96, 48), 2, 0), ((64, 176, 2, 4, 96, 48), 5, 0), ((64, 176, 2, 4, 96, 48), 6, 3),
+                                                 ((128, 352, 2, 2, 256, 80), 9, 0), ((128, 352, 2, 2, 256, 80), 17, 0), ((128, 352, 2, 2, 256, 80), 18, 5),
+                                                 ((288, 768, 2, 6, 512, 96), 40, 0), ((272, 720, 2, 17, 333, 64), 21, 2),
+                                                 ((768, 2048, 1, 12, 1024, 64), 34, 0), ((48, 80, 2, 3, 50, 40), 12, 1)])
+def test_parity_prefill_bit_exact(dev, shape, n_tokens, pos0):
+    """parity mode's rama_prefill: the forced positions go through the chain-order token-batch kernels 16 at a time
+    (csrc/chain.hpp gemm_chain_kernel; every weight read once per 16 positions) and the last one through forward().
+    Cache rows of every position, the logits and the run state of the last are the ORACLE's, bit for bit -- and
+    therefore those of one forward() per position ("prefill_chain" = 0), which is compared too.  Shapes: widths
+    that are no whole 256-float chunk, rows that are no multiple of 16, one to three passes, partly filled passes of 1-3,
+    5-8 and 9-16 tokens (the three instantiations), a start position > 0."""
+    import rama_amd
+    from rama_amd._lib import check
+    from .helpers import to_rama_cfg
+    dim, hidden, L, H, V, seq = shape
+    cfg = O.Config(dim, hidden, L, H, H, V, seq, False)
+    rope = S.rope_tables(seq, dim // H)
+    w = S.synth_weights(cfg, 7, rope=rope)
+    model = rama_amd.Model.synth(dev, to_rama_cfg(cfg), 7, rope=rope)
+    rng = np.random.default_rng(n_tokens)
+    toks = [1] + [int(t) for t in rng.integers(0, V, pos0 + n_tokens - 1)]
+    orc = O.Oracle(cfg, w)
+    for pos, t in enumerate(toks):
+        lo = orc.forward(t, pos)
+    arr = (C.c_int32 * n_tokens)(*toks[pos0:])
+    outs = {}
+    for batched in (1, 0):
+        eng = rama_amd.Engine(dev, model)
+        for pos in range(pos0):
+            eng.forward(toks[pos], pos)
+        check(dev.lib.rama_set_tuning(dev.ctx, b"prefill_chain", batched))
+        try:
+            check(dev.lib.rama_prefill(dev.ctx, C.byref(model.ccfg), C.byref(model.weights), C.byref(eng.state), arr, n_tokens, pos0), "rama_prefill")
+        finally:
+            check(dev.lib.rama_set_tuning(dev.ctx, b"prefill_chain", 1))
+        outs[batched] = {"logits": eng.logits(), "key_cache": eng.buffer("key_cache", L * seq * dim), "value_cache": eng.buffer("value_cache", L * seq * dim),
+                         "x": eng.buffer("x", dim), "xb": eng.buffer("xb", dim), "hb": eng.buffer("hb", hidden), "q": eng.buffer("q", dim)}
+        assert_bits_equal(outs[batched]["logits"], lo, f"logits, batched={batched}")
+        for buf in ("key_cache", "value_cache", "x", "xb", "hb", "q"):
+            assert_bits_equal(outs[batched][buf], orc.s[buf], f"{buf}, batched={batched}")
+        eng.free()
+    model.free()

@@ -18,7 +18,7 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int rep = 0; rep < 3; rep++) {
         CK(hipEventRecord(e0, 0));
-        for (int i = 0; i < 200; i++) hipLaunchKernelGGL(rmsnorm_chain_kernel, dim3(1), dim3(kNormThreads), lds, 0, dout, dx, dw, n, (float*)nullptr);
+        for (int i = 0; i < 200; i++) hipLaunchKernelGGL(rmsnorm_chain_kernel, dim3(1), dim3(kNormThreads), lds, 0, dout, dx, dw, n, (float*)nullptr, 0);
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("n=%d rmsnorm_chain_kernel: %.2f us per launch (back to back)\n", n, ms * 1e3 / 200);
