@@ -726,7 +726,7 @@ __global__ __launch_bounds__(W * 64) void gemv_chain_kernel(ChainParams p) {
 //   A workgroup of 4 waves owns 16 rows; lane = (row, chain j) as in the decode kernel; wave w carries the sums of
 //   tokens w TPW .. w TPW + TPW - 1.  The chain is walked in chunks of 16 blocks (256 floats of K): 16 KiB of weights
 //   (chain order: a straight copy) and 1 KiB of activations per token (transposed into chain order on the way) go
-//   HBM / L2 -> registers -> LDS, three chunks in flight in registers, two LDS slots, ONE barrier per chunk; from LDS a wave
+//   HBM / L2 -> registers -> LDS, two chunks in flight in registers, two LDS slots, ONE barrier per chunk; from LDS a wave
 //   reads a block's weights once (16 bytes per lane) and each of its tokens' 4 x 4 activations as a broadcast.
 //   Per block and wave: TPW x (4 multiplies + 4 adds) -- at TPW = 4 a pass is bound by the vector ALUs and the HBM
 //   stream about equally (13 GFLOP-pairs per token at 2 instructions each vs 26.4 GB per pass at llama2-7B).
@@ -742,7 +742,7 @@ struct GemmChainParams {
 };
 constexpr int kGcWaves = 4, kGcThreads = kGcWaves * 64;
 constexpr int kGcBlocks = 16;            // blocks of 16 floats per chunk
-constexpr int kGcSets = 3;               // chunks in flight in registers
+constexpr int kGcSets = 2;               // chunks in flight in registers
 __host__ __device__ constexpr size_t gemm_chain_lds_bytes(int tpw) { return 2 * ((size_t)kGcBlocks * 1024 + (size_t)(4 * tpw) * kGcBlocks * 64); }
 
 template <int TPW, int EPI>
@@ -755,7 +755,6 @@ __global__ __launch_bounds__(kGcThreads) void gemm_chain_kernel(GemmChainParams 
     float* xl = gsm + 2 * kGcBlocks * 256;                       // [2][T][kGcBlocks * 16] activations, chain order per token
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 3, rr = lane >> 2;
     const int groups = (p.rows + 15) >> 4;
     const int m = __builtin_amdgcn_readfirstlane(blockIdx.x / groups), g = blockIdx.x - m * groups;
     const float* Wm = m == 0 ? p.w[0] : (m == 1 ? p.w[1] : p.w[2]);
@@ -777,63 +776,76 @@ __global__ __launch_bounds__(kGcThreads) void gemm_chain_kernel(GemmChainParams 
             xr[n] = ld_c(rx, (t < p.n_tok && k < p.K) ? (unsigned)(((size_t)t * (size_t)p.xstride + (size_t)k) * 4u) : kOOB);
         }
     };
-    // registers -> LDS slot: weights as they are, activations xs[16 s + 4 j + i] = x[16 s + 4 i + j] (gemv_chain_kernel's order)
+    // registers -> LDS slot: weights as they are; activations in gemv_chain_kernel's order, element e = 16 s + 4 j + i holds
+    // x[16 s + 4 i + j] -- of PW tokens side by side (PW = 2 from two tokens per wave on: a lane's multiply and add then
+    // take two tokens per instruction, v_pk_mul_f32 / v_pk_add_f32, each half rounded like the scalar operation)
+    constexpr int PW = TPW >= 2 ? 2 : 1;
+    typedef float xvec __attribute__((ext_vector_type(PW)));
     auto stage = [&](int slot, const f4 (&wr)[4], const f4 (&xr)[XF]) {
 #pragma unroll
         for (int n = 0; n < 4; n++) wl[slot * (kGcBlocks * 64) + tid + kGcThreads * n] = wr[n];
 #pragma unroll
         for (int n = 0; n < XF; n++) {
             const int q = tid + kGcThreads * n, t = q >> 6, i = q & 63;
-            float* d = xl + ((size_t)slot * T + t) * (kGcBlocks * 16) + 16 * (i >> 2) + (i & 3);
-            d[0] = xr[n].x; d[4] = xr[n].y; d[8] = xr[n].z; d[12] = xr[n].w;
+            float* d = xl + ((size_t)slot * T + (size_t)(t / PW) * PW) * (kGcBlocks * 16) + (size_t)(16 * (i >> 2) + (i & 3)) * PW + (t % PW);
+            d[0] = xr[n].x; d[4 * PW] = xr[n].y; d[8 * PW] = xr[n].z; d[12 * PW] = xr[n].w;
         }
     };
-    float acc[TPW];
+    const int j = lane & 3, rr = lane >> 2;
+    xvec acc[TPW / PW];
 #pragma unroll
-    for (int tt = 0; tt < TPW; tt++) acc[tt] = 0.0f;
+    for (int tt = 0; tt < TPW / PW; tt++) acc[tt] = (xvec)(0.0f);
+    // no branch in here (a second basic block in the loop body and hipcc sinks the adds of a whole chunk behind it)
     auto compute = [&](int slot) {
         const f4* wq = wl + slot * (kGcBlocks * 64) + lane;
-        const float* xb = xl + ((size_t)slot * T + (size_t)wave * TPW) * (kGcBlocks * 16) + 4 * j;
+        const float* xb = xl + ((size_t)slot * T + (size_t)wave * TPW) * (kGcBlocks * 16) + 4 * j * PW;
 #pragma unroll
         for (int u = 0; u < kGcBlocks; u++) {
             const f4 wv = wq[u * 64];
 #pragma unroll
-            for (int tt = 0; tt < TPW; tt++) {
-                const f4 xv = *reinterpret_cast<const f4*>(xb + tt * (kGcBlocks * 16) + 16 * u);
-                float v = acc[tt];
-                v = v + wv.x * xv.x;
-                v = v + wv.y * xv.y;
-                v = v + wv.z * xv.z;
-                v = v + wv.w * xv.w;
+            for (int tt = 0; tt < TPW / PW; tt++) {
+                const xvec* xp = reinterpret_cast<const xvec*>(xb + (size_t)tt * PW * (kGcBlocks * 16) + 16 * u * PW);
+                const xvec x0 = xp[0], x1 = xp[1], x2 = xp[2], x3 = xp[3];
+                xvec v = acc[tt];
+                v = v + wv.x * x0;
+                v = v + wv.y * x1;
+                v = v + wv.z * x2;
+                v = v + wv.w * x3;
                 acc[tt] = v;
             }
+            if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // reads at most four blocks ahead of their use
         }
     };
-    // chunk c is computed from slot c % 2; before that, chunk c + 1 (in registers since step c - 2) goes to the other
-    // slot and chunk c + 1 + kGcSets is requested into the registers it leaves
+    // chunk c is computed from slot c % 2; before that, chunk c + 1 (in registers since step c - 1) goes to the other
+    // slot and chunk c + 3 is requested into the registers it leaves.  No branch in the loop: the steps behind the last
+    // chunk (the count is rounded up to the unroll) load nothing, stage zeros and add + (0 * 0) -- with a condition
+    // around a step hipcc's waitcnt pass forgets what is in flight at the join and drains the loads just issued
+    // (vmcnt(0): measured 5 us per chunk instead of 1).
     issue(0, wreg[0], xreg[0]);
     issue(1, wreg[1], xreg[1]);
-    issue(2, wreg[2], xreg[2]);
     stage(0, wreg[0], xreg[0]);
-    issue(3, wreg[0], xreg[0]);
+    issue(2, wreg[0], xreg[0]);
     __syncthreads();
-#define RAMA_GC_STEP(S_)                                                                          \
-    if (c + S_ < nchunk) {                                                                         \
-        stage((c + S_ + 1) & 1, wreg[(S_ + 1) % kGcSets], xreg[(S_ + 1) % kGcSets]);              \
-        issue(c + S_ + 1 + kGcSets, wreg[(S_ + 1) % kGcSets], xreg[(S_ + 1) % kGcSets]);          \
-        compute((c + S_) & 1);                                                                     \
-        __syncthreads();                                                                           \
+    for (int c = 0; c < nchunk; c += 2) {
+        stage(1, wreg[1], xreg[1]);                              // chunk c + 1
+        __builtin_amdgcn_sched_barrier(0);
+        issue(c + 3, wreg[1], xreg[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(0);                                              // chunk c
+        __syncthreads();
+        stage(0, wreg[0], xreg[0]);                              // chunk c + 2
+        __builtin_amdgcn_sched_barrier(0);
+        issue(c + 4, wreg[0], xreg[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(1);                                              // chunk c + 1
+        __syncthreads();
     }
-    for (int c = 0; c < nchunk; c += 6) {      // 6 = lcm(register sets, slots): every index below is a constant
-        RAMA_GC_STEP(0) RAMA_GC_STEP(1) RAMA_GC_STEP(2) RAMA_GC_STEP(3) RAMA_GC_STEP(4) RAMA_GC_STEP(5)
-    }
-#undef RAMA_GC_STEP
     // epilogues of gemv_chain_kernel, per token
     const int row = 16 * g + rr;
 #pragma unroll
     for (int tt = 0; tt < TPW; tt++) {
         const int t = wave * TPW + tt;
-        const float v = acc[tt];
+        const float v = acc[tt / PW][tt % PW];
         const float t2 = v + dpp_mov<0xB1>(v);                   // (v0 + v1) + (v2 + v3)
         const float d = t2 + dpp_mov<0x4E>(t2);
         const float other = __shfl_xor(d, 4);                    // the neighbouring row (RoPE pair / W3 row)
