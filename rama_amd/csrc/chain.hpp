@@ -741,15 +741,30 @@ struct GemmChainParams {
     int pos0; const float* fr; const float* fi; int head_size; float* kc; float* vc;      // QKV: token t sits at pos0 + t; this layer's cache slabs
 };
 constexpr int kGcWaves = 4, kGcThreads = kGcWaves * 64;
-constexpr int kGcBlocks = 16;            // blocks of 16 floats per chunk
+constexpr int kGcBlocks = 8;             // blocks of 16 floats per chunk (8 KiB of weights; 32 KiB of LDS per workgroup at 16 tokens: four workgroups per CU)
 constexpr int kGcSets = 2;               // chunks in flight in registers
-__host__ __device__ constexpr size_t gemm_chain_lds_bytes(int tpw) { return 2 * ((size_t)kGcBlocks * 1024 + (size_t)(4 * tpw) * kGcBlocks * 64); }
+__host__ __device__ constexpr size_t gemm_chain_lds_bytes(int tpw) { return 2 * ((size_t)kGcBlocks * 1024 + (size_t)(kGcWaves * tpw) * kGcBlocks * 64); }
+
+// a * w with a taken from lane I of the caller's DPP row (16 lanes): one v_mul_f32 with the row broadcast on its source
+// operand -- the rounded product of the reference's separate multiply.  (As assembly: hipcc would pack the multiplies of two
+// tokens into v_pk_mul_f32, which takes no DPP operand, and pay for it with a broadcast move and shuffles per product.)
+template <int I>
+__device__ __forceinline__ float mul_row(float a, float w) {
+    float r;
+    if (I == 0) asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(a), "v"(w));
+    else if (I == 1) asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:1 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(a), "v"(w));
+    else if (I == 2) asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(a), "v"(w));
+    else asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(a), "v"(w));
+    return r;
+}
 
 template <int TPW, int EPI>
 __global__ __launch_bounds__(kGcThreads) void gemm_chain_kernel(GemmChainParams p) {
     RAMA_NO_CONTRACT
     constexpr int T = kGcWaves * TPW;                            // tokens of a pass
-    constexpr int XF = TPW;                                      // 16-byte pieces of activations per thread and chunk (T x 64 / 256)
+    constexpr int WN = kGcBlocks * 64 / kGcThreads;               // 16-byte pieces of weights per thread and chunk
+    constexpr int PPT = kGcBlocks * 4;                            // 16-byte pieces of one token's activations per chunk
+    constexpr int XF = (T * PPT + kGcThreads - 1) / kGcThreads;   // ... of activations per thread and chunk
     extern __shared__ __attribute__((aligned(16))) float gsm[];
     f4* wl = reinterpret_cast<f4*>(gsm);                         // [2][kGcBlocks * 64] weights, chain order
     float* xl = gsm + 2 * kGcBlocks * 256;                       // [2][T][kGcBlocks * 16] activations, chain order per token
@@ -761,59 +776,87 @@ __global__ __launch_bounds__(kGcThreads) void gemm_chain_kernel(GemmChainParams 
     const int nblk = p.K >> 4;
     const int nchunk = (nblk + kGcBlocks - 1) / kGcBlocks;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc_uniform(p.x, (unsigned)((size_t)p.n_tok * (size_t)p.xstride * 4u));
-    f4 wreg[kGcSets][4], xreg[kGcSets][XF];
+    f4 wreg[kGcSets][WN], xreg[kGcSets][XF];
 
     // loads of chunk c into register set S (c >= nchunk: nothing but zeros, no memory touched)
-    auto issue = [&](int c, f4 (&wr)[4], f4 (&xr)[XF]) {
+    auto issue = [&](int c, f4 (&wr)[WN], f4 (&xr)[XF]) {
         const int left = min(max(nblk - c * kGcBlocks, 0), kGcBlocks);
         const __amdgpu_buffer_rsrc_t rw = make_rsrc_uniform(Wm + ((size_t)g * (size_t)nblk + (size_t)min(c, nchunk) * kGcBlocks) * 256, (unsigned)left * 1024u);
 #pragma unroll
-        for (int n = 0; n < 4; n++) wr[n] = ld_nt(rw, (unsigned)(tid + kGcThreads * n) * 16u);
+        for (int n = 0; n < WN; n++) wr[n] = ld_nt(rw, (unsigned)(tid + kGcThreads * n) * 16u);
 #pragma unroll
         for (int n = 0; n < XF; n++) {
-            const int q = tid + kGcThreads * n, t = q >> 6, i = q & 63;      // token, 16-byte piece of its 256 floats
+            const int q = tid + kGcThreads * n, t = q / PPT, i = q % PPT;    // token, 16-byte piece of its chunk
             const int k = c * (kGcBlocks * 16) + i * 4;
             xr[n] = ld_c(rx, (t < p.n_tok && k < p.K) ? (unsigned)(((size_t)t * (size_t)p.xstride + (size_t)k) * 4u) : kOOB);
         }
     };
-    // registers -> LDS slot: weights as they are; activations in gemv_chain_kernel's order, element e = 16 s + 4 j + i holds
-    // x[16 s + 4 i + j] -- of PW tokens side by side (PW = 2 from two tokens per wave on: a lane's multiply and add then
-    // take two tokens per instruction, v_pk_mul_f32 / v_pk_add_f32, each half rounded like the scalar operation)
-    constexpr int PW = TPW >= 2 ? 2 : 1;
-    typedef float xvec __attribute__((ext_vector_type(PW)));
-    auto stage = [&](int slot, const f4 (&wr)[4], const f4 (&xr)[XF]) {
+    // registers -> LDS slot: weights as they are, activations xs[16 s + 4 j + i] = x[16 s + 4 i + j] (gemv_chain_kernel's order)
+    auto stage = [&](int slot, const f4 (&wr)[WN], const f4 (&xr)[XF]) {
 #pragma unroll
-        for (int n = 0; n < 4; n++) wl[slot * (kGcBlocks * 64) + tid + kGcThreads * n] = wr[n];
+        for (int n = 0; n < WN; n++) wl[slot * (kGcBlocks * 64) + tid + kGcThreads * n] = wr[n];
 #pragma unroll
         for (int n = 0; n < XF; n++) {
-            const int q = tid + kGcThreads * n, t = q >> 6, i = q & 63;
-            float* d = xl + ((size_t)slot * T + (size_t)(t / PW) * PW) * (kGcBlocks * 16) + (size_t)(16 * (i >> 2) + (i & 3)) * PW + (t % PW);
-            d[0] = xr[n].x; d[4 * PW] = xr[n].y; d[8 * PW] = xr[n].z; d[12 * PW] = xr[n].w;
+            const int q = tid + kGcThreads * n, t = q / PPT, i = q % PPT;
+            if (T * PPT % kGcThreads == 0 || q < T * PPT) {
+                float* d = xl + ((size_t)slot * T + t) * (kGcBlocks * 16) + 16 * (i >> 2) + (i & 3);
+                d[0] = xr[n].x; d[4] = xr[n].y; d[8] = xr[n].z; d[12] = xr[n].w;
+            }
         }
     };
-    const int j = lane & 3, rr = lane >> 2;
-    xvec acc[TPW / PW];
+    // In the sums a lane is (chain j = lane / 16, row = lane % 16): the 16 lanes of a DPP row share a chain, hence the
+    // four activations of a block and token.  With every lane reading all four (16 bytes) the LDS array bounded the
+    // kernel (1 KiB per token, block and wave for 64 bytes of data); so a lane reads ONE of them -- step i = row % 4 --
+    // and the multiply of step i takes it from lane i of the row through DPP (row_newbcast:i on the source operand).
+    const int jj = lane >> 4, r16 = lane & 15;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    float acc1 = 0.0f;                                           // TPW == 1
+    f2 acc2[TPW >= 2 ? TPW / 2 : 1];                             // TPW >= 2: tokens (2 tp, 2 tp + 1)
 #pragma unroll
-    for (int tt = 0; tt < TPW / PW; tt++) acc[tt] = (xvec)(0.0f);
-    // no branch in here (a second basic block in the loop body and hipcc sinks the adds of a whole chunk behind it)
+    for (int tp = 0; tp < (TPW >= 2 ? TPW / 2 : 1); tp++) acc2[tp] = f2{0.0f, 0.0f};
+    // (one basic block: with a branch in here hipcc sinks the adds of a whole chunk behind it)
     auto compute = [&](int slot) {
-        const f4* wq = wl + slot * (kGcBlocks * 64) + lane;
-        const float* xb = xl + ((size_t)slot * T + (size_t)wave * TPW) * (kGcBlocks * 16) + 4 * j * PW;
+        const f4* wq = wl + slot * (kGcBlocks * 64) + (r16 * 4 + jj);          // the chain-order copy keeps lane = row * 4 + chain
+        const float* xb = xl + ((size_t)slot * T + (size_t)wave * TPW) * (kGcBlocks * 16) + 4 * jj + (r16 & 3);
+        // the operands of block u + 1 are read while block u is summed; no further ahead (registers), two sets in turn
+        f4 w0, w1;
+        float xa[TPW], xc[TPW];
+        auto fetch = [&](int u, f4& wv, float (&xv)[TPW]) {
+            wv = wq[u * 64];
 #pragma unroll
-        for (int u = 0; u < kGcBlocks; u++) {
-            const f4 wv = wq[u * 64];
+            for (int tt = 0; tt < TPW; tt++) xv[tt] = xb[tt * (kGcBlocks * 16) + 16 * u];
+        };
+        auto sums = [&](const f4& wv, const float (&xs1)[TPW]) {
+            if constexpr (TPW == 1) {
+                float v = acc1;
+                v = v + mul_row<0>(xs1[0], wv.x);
+                v = v + mul_row<1>(xs1[0], wv.y);
+                v = v + mul_row<2>(xs1[0], wv.z);
+                v = v + mul_row<3>(xs1[0], wv.w);
+                acc1 = v;
+            } else {
 #pragma unroll
-            for (int tt = 0; tt < TPW / PW; tt++) {
-                const xvec* xp = reinterpret_cast<const xvec*>(xb + (size_t)tt * PW * (kGcBlocks * 16) + 16 * u * PW);
-                const xvec x0 = xp[0], x1 = xp[1], x2 = xp[2], x3 = xp[3];
-                xvec v = acc[tt];
-                v = v + wv.x * x0;
-                v = v + wv.y * x1;
-                v = v + wv.z * x2;
-                v = v + wv.w * x3;
-                acc[tt] = v;
+                for (int tp = 0; tp < TPW / 2; tp++) {
+                    f2 v = acc2[tp];
+                    v = v + f2{mul_row<0>(xs1[2 * tp], wv.x), mul_row<0>(xs1[2 * tp + 1], wv.x)};
+                    v = v + f2{mul_row<1>(xs1[2 * tp], wv.y), mul_row<1>(xs1[2 * tp + 1], wv.y)};
+                    v = v + f2{mul_row<2>(xs1[2 * tp], wv.z), mul_row<2>(xs1[2 * tp + 1], wv.z)};
+                    v = v + f2{mul_row<3>(xs1[2 * tp], wv.w), mul_row<3>(xs1[2 * tp + 1], wv.w)};
+                    acc2[tp] = v;
+                }
             }
-            if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // reads at most four blocks ahead of their use
+        };
+        fetch(0, w0, xa);
+#pragma unroll
+        for (int u = 0; u < kGcBlocks; u += 2) {
+            fetch(u + 1, w1, xc);
+            __builtin_amdgcn_sched_barrier(0);
+            sums(w0, xa);
+            __builtin_amdgcn_sched_barrier(0);
+            if (u + 2 < kGcBlocks) fetch(u + 2, w0, xa);
+            __builtin_amdgcn_sched_barrier(0);
+            sums(w1, xc);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     // chunk c is computed from slot c % 2; before that, chunk c + 1 (in registers since step c - 1) goes to the other
@@ -826,6 +869,7 @@ __global__ __launch_bounds__(kGcThreads) void gemm_chain_kernel(GemmChainParams 
     stage(0, wreg[0], xreg[0]);
     issue(2, wreg[0], xreg[0]);
     __syncthreads();
+#pragma unroll 1
     for (int c = 0; c < nchunk; c += 2) {
         stage(1, wreg[1], xreg[1]);                              // chunk c + 1
         __builtin_amdgcn_sched_barrier(0);
@@ -840,20 +884,20 @@ __global__ __launch_bounds__(kGcThreads) void gemm_chain_kernel(GemmChainParams 
         compute(1);                                              // chunk c + 1
         __syncthreads();
     }
-    // epilogues of gemv_chain_kernel, per token
-    const int row = 16 * g + rr;
+    // epilogues of gemv_chain_kernel, per token (the four chains of a row sit 16 lanes apart here, its neighbour row one lane)
+    const int row = 16 * g + r16;
 #pragma unroll
     for (int tt = 0; tt < TPW; tt++) {
         const int t = wave * TPW + tt;
-        const float v = acc[tt / PW][tt % PW];
-        const float t2 = v + dpp_mov<0xB1>(v);                   // (v0 + v1) + (v2 + v3)
-        const float d = t2 + dpp_mov<0x4E>(t2);
-        const float other = __shfl_xor(d, 4);                    // the neighbouring row (RoPE pair / W3 row)
+        const float v = TPW == 1 ? acc1 : acc2[tt / 2][tt & 1];
+        const float t2 = v + __shfl_xor(v, 16);                  // (v0 + v1) + (v2 + v3)
+        const float d = t2 + __shfl_xor(t2, 32);
+        const float other = __shfl_xor(d, 1);                    // the neighbouring row (RoPE pair / W3 row)
         if (t >= p.n_tok) continue;                              // uniform per wave
         if (EPI == CEPI_STORE) {
-            if (j == 0 && row < p.rows) p.o[0][(size_t)t * p.ostride + row] = d;
+            if (jj == 0 && row < p.rows) p.o[0][(size_t)t * p.ostride + row] = d;
         } else if (EPI == CEPI_RESID) {
-            if (j == 0 && row < p.rows) {
+            if (jj == 0 && row < p.rows) {
                 if (p.o[0]) p.o[0][(size_t)t * p.ostride + row] = d;
                 float* xr_ = p.resid + (size_t)t * p.rstride + row;
                 *xr_ = *xr_ + d;
@@ -864,16 +908,16 @@ __global__ __launch_bounds__(kGcThreads) void gemm_chain_kernel(GemmChainParams 
             if (m < 2) {
                 const int i = ((row & ~1) % p.head_size) >> 1;   // infer.rs:15-16
                 const float rc = p.fr[(size_t)pos * (p.head_size >> 1) + i], rs = p.fi[(size_t)pos * (p.head_size >> 1) + i];
-                const float a = (rr & 1) ? other : d, b = (rr & 1) ? d : other;
-                out = (rr & 1) ? a * rs + b * rc : a * rc - b * rs;          // cpu.rs:87-96
+                const float a = (r16 & 1) ? other : d, b = (r16 & 1) ? d : other;
+                out = (r16 & 1) ? a * rs + b * rc : a * rc - b * rs;         // cpu.rs:87-96
             }
-            if (j == 0 && row < p.rows) {
+            if (jj == 0 && row < p.rows) {
                 if (m == 0) p.o[0][(size_t)t * p.ostride + row] = out;
                 else if (m == 1) p.kc[(size_t)pos * p.rows + row] = out;     // infer.rs:32
                 else p.vc[(size_t)pos * p.rows + row] = out;                 // infer.rs:33
             }
         } else {   // CEPI_SWIGLU: even row = W1 row i, odd row = W3 row i
-            if (j == 0 && !(rr & 1) && row < p.rows) {
+            if (jj == 0 && !(r16 & 1) && row < p.rows) {
                 const float sl = d * (1.0f / (1.0f + expf_glibc(-d)));       // cpu.rs:56
                 p.o[0][(size_t)t * p.ostride + (row >> 1)] = sl * other;      // cpu.rs:59-64
             }
