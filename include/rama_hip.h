@@ -176,7 +176,10 @@ int  rama_forward_stage(rama_ctx *ctx, const rama_config *cfg, const rama_weight
  * residual x and logits of the LAST position -- with the weights streamed once per 128 positions (64 when the
  * weights are not a resident rama_model's: the 128-position kernels read the model's tile-order copies), as
  * dense fp32 GEMMs on the matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, csrc/prefill_mfma.hpp).
- * dim or hidden_dim not a multiple of 16: falls back to one rama_forward per token. */
+ * dim or hidden_dim not a multiple of 16: falls back to one rama_forward per token.
+ * Parity mode ("ref_order" = 1) on a resident model: the positions go through token-batch kernels in the reference's
+ * rounding order, 16 per weight pass, the last one through rama_forward -- cache rows, logits and run state are
+ * bit for bit those of one rama_forward per position ("prefill_chain" = 0 gives exactly that loop). */
 int  rama_prefill(rama_ctx *ctx, const rama_config *cfg, const rama_weights *w, rama_run_state *s,
                   const int32_t *tokens_host, int n_tokens, int pos0);
 
@@ -302,6 +305,7 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *                   one chunk each per step (+1.15 % more); 3 = 16 waves x 4 chunks
  *   "prefill" = 0|1 : 1 (default) lets rama_generate_greedy push the forced prompt positions through
  *                   rama_prefill (up to 128 positions per weight pass) instead of one forward per token
+ *   "prefill_chain" = 0|1 : parity mode's rama_prefill through the chain-order token-batch kernels (default 1)
  *   "prefill_tok" = 64|128 : positions per weight pass of rama_prefill (default 128; 64 = round 2's kernels)
  *   "merge" = -1|0|1 : 1 runs attention and the Wo matvec as one launch when the occupancy API says
  *                   its whole grid is resident (Wo's weights stream while attention runs); -1
