@@ -57,6 +57,7 @@ def parse(argv=None):
                     help="rama_set_tuning(KEY, VALUE) on every engine before timing (A/B runs under the profiler); repeatable")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kprof", action="store_true")
+    ap.add_argument("--no-prefill", action="store_true", help="skip the prompt-ingestion (rama_prefill) figures")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the stories15M / stories110M lines")
     ap.add_argument("--no-placement-tuning", action="store_true", help="accepted and ignored (round-1 flag: the tuner is gone)")
     ap.add_argument("--pos0", type=int, default=0,
@@ -202,6 +203,30 @@ def time_decode(eng, dev, seq, steps, warmup, pos0, prompt):
     return wall_ms, ev_ms, pos, tokens
 
 
+def time_prefill(dev, model, mode, n_positions, V):
+    """prompt positions per second of rama_prefill (the forced positions of generate(), mod.rs:187-194, as token
+    batches: fp32 MFMA GEMMs, 128 positions per weight pass, in fast mode; chain-order kernels in the reference's
+    rounding order, 16 per pass, in parity mode), best of 3 after one warm-up; reported beside `value`, never as it"""
+    import ctypes as C
+    import numpy as np
+    import rama_amd
+    from rama_amd._lib import check
+    eng = rama_amd.Engine(dev, model)
+    eng.set_tuning("ref_order", 1 if mode == "parity" else 0)
+    toks = [1] + [int(v) for v in np.random.default_rng(0).integers(2, V, n_positions - 1)]
+    arr = (C.c_int32 * n_positions)(*toks)
+    best = 1e9
+    for i in range(4):
+        t0 = time.perf_counter()
+        check(dev.lib.rama_prefill(dev.ctx, C.byref(model.ccfg), C.byref(model.weights), C.byref(eng.state), arr, n_positions, 0))
+        dev.sync()
+        if i:
+            best = min(best, time.perf_counter() - t0)
+    eng.set_tuning("ref_order", 0)
+    eng.free()
+    return {"positions": n_positions, "ms": round(best * 1e3, 2), "prompt_tok_s": round(n_positions / best, 1)}
+
+
 def kernel_times(eng, cfg_seq, pos, tokens, bytes_, ksteps=16):
     """per-launch device time of every kernel class over `ksteps` eager decode steps (events carried by the dispatch)"""
     kernels = {}
@@ -290,6 +315,9 @@ def single_gpu(args, local_rank):
                 peng.set_tuning("ref_order", 0)
                 peng.free()
 
+    prefill = None
+    if not args.no_prefill:
+        prefill = {m_: time_prefill(dev, model, m_, min(256, seq), V) for m_ in modes}
     cpu, check = (None, None) if args.no_cpu_baseline else baseline_for(args.config, model, args.cpu_tokens)
     model.free()
 
@@ -338,6 +366,8 @@ def single_gpu(args, local_rank):
         if m_ != head:
             block["roofline"] = roofline_of(block.get("kernels"), bytes_, m_, d)
         line[m_ + "_mode"] = block
+    if prefill:
+        line["prefill"] = prefill      # prompt ingestion (rama_prefill), the same resident model; not part of `value`
     if others:
         line["other_configs"] = others
     print(json.dumps(line), flush=True)
