@@ -742,6 +742,7 @@ struct GemmChainParams {
     float* resid; int rstride;            // RESID: resid[t][row] += product (infer.rs:37,47)
     int n_tok;
     int pos0; const float* fr; const float* fi; int head_size; float* kc; float* vc;      // QKV: token t sits at pos0 + t; this layer's cache slabs
+    const SeqSlot* seqs; size_t layer_off;   // QKV, independent sequences: token t at seqs[t].pos, its caches at seqs[t].kc / .vc + layer_off
 };
 constexpr int kGcWaves = 4, kGcThreads = kGcWaves * 64;
 constexpr int kGcBlocks = 8;             // blocks of 16 floats per chunk (8 KiB of weights; 32 KiB of LDS per workgroup at 16 tokens: four workgroups per CU)
@@ -906,7 +907,9 @@ __global__ __launch_bounds__(kGcThreads) void gemm_chain_kernel(GemmChainParams 
                 *xr_ = *xr_ + d;
             }
         } else if (EPI == CEPI_QKV) {
-            const int pos = p.pos0 + t;
+            const int pos = p.seqs ? p.seqs[t].pos : p.pos0 + t;
+            float* kcl = p.seqs ? p.seqs[t].kc + p.layer_off : p.kc;
+            float* vcl = p.seqs ? p.seqs[t].vc + p.layer_off : p.vc;
             float out = d;
             if (m < 2) {
                 const int i = ((row & ~1) % p.head_size) >> 1;   // infer.rs:15-16
@@ -916,8 +919,8 @@ __global__ __launch_bounds__(kGcThreads) void gemm_chain_kernel(GemmChainParams 
             }
             if (jj == 0 && row < p.rows) {
                 if (m == 0) p.o[0][(size_t)t * p.ostride + row] = out;
-                else if (m == 1) p.kc[(size_t)pos * p.rows + row] = out;     // infer.rs:32
-                else p.vc[(size_t)pos * p.rows + row] = out;                 // infer.rs:33
+                else if (m == 1) kcl[(size_t)pos * p.rows + row] = out;      // infer.rs:32
+                else vcl[(size_t)pos * p.rows + row] = out;                  // infer.rs:33
             }
         } else {   // CEPI_SWIGLU: even row = W1 row i, odd row = W3 row i
             if (jj == 0 && !(r16 & 1) && row < p.rows) {
@@ -971,7 +974,8 @@ __global__ __launch_bounds__(NW * 64) void attention_chain_kernel(RefAttnParams 
     __shared__ float red[16];
     const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pos = (p.ctl ? p.ctl->pos : p.pos_val) + (int)blockIdx.y;
+    const int pos = p.seqs ? p.seqs[blockIdx.y].pos : (p.ctl ? p.ctl->pos : p.pos_val) + (int)blockIdx.y;
+    if (p.seqs) { p.kc = p.seqs[blockIdx.y].kc + p.layer_off; p.vc = p.seqs[blockIdx.y].vc + p.layer_off; }
     p.q += (size_t)blockIdx.y * p.tok_stride; p.xb += (size_t)blockIdx.y * p.tok_stride;
     if (p.att) p.att += (size_t)blockIdx.y * p.att_stride;
     const int hs = p.head_size, hs4 = hs >> 2;

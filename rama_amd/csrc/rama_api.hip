@@ -215,6 +215,7 @@ int rama_ctx_create(int device, void* hip_stream, rama_ctx** out) {
     HIPCHK(hipFuncSetAttribute((const void*)attention_chain_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnChainMaxLds));
     HIPCHK(hipFuncSetAttribute((const void*)attention_chain_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnChainMaxLds));
 #define RAMA_GC_ATTR(TPW_) \
+    HIPCHK(hipFuncSetAttribute((const void*)gemm_chain_kernel<TPW_, CEPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_chain_lds_bytes(TPW_))); \
     HIPCHK(hipFuncSetAttribute((const void*)gemm_chain_kernel<TPW_, CEPI_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_chain_lds_bytes(TPW_))); \
     HIPCHK(hipFuncSetAttribute((const void*)gemm_chain_kernel<TPW_, CEPI_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_chain_lds_bytes(TPW_))); \
     HIPCHK(hipFuncSetAttribute((const void*)gemm_chain_kernel<TPW_, CEPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_chain_lds_bytes(TPW_)));
@@ -1442,32 +1443,106 @@ static int launch_gemm_chain(rama_ctx* c, GemmChainParams& p) {
 }
 constexpr int kGcMaxTok = 4 * kGcWaves;
 
-static int prefill_chain(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s,
-                         const int32_t* tokens_host, int n_tokens, int pos0, bool* done) {
-    *done = false;
+// the layers of one pass of nt <= 16 tokens whose residual rows sit in b.X: consecutive positions p0.. of one sequence
+// (key_cache / value_cache its cache bases), or -- seqs != NULL -- token t of independent sequence t (device table)
+struct ChainBatch { float *X, *XN, *Q, *XB, *HB, *ATT; const float *cq, *ck, *cv, *co, *c13, *c2; int nw; size_t att_lds; };
+static int chain_batch_layers(rama_ctx* c, const rama_config* cfg, const rama_weights* w, const ChainBatch& b, int nt, int p0,
+                              float* key_cache, float* value_cache, const SeqSlot* seqs) {
     const int dim = cfg->dim, hidden = cfg->hidden_dim, hs = dim / cfg->n_heads, H = cfg->n_heads, seq = cfg->seq_len;
+    const size_t dd = (size_t)dim * dim, hd = (size_t)hidden * dim;
+    int rc;
+    for (int layer = 0; layer < cfg->n_layers; layer++) {
+        const size_t li = (size_t)layer, layer_off = li * seq * dim;
+        float* kc = key_cache ? key_cache + layer_off : nullptr;
+        float* vc = value_cache ? value_cache + layer_off : nullptr;
+        rc = launch_rmsnorm_chain(c, b.XN, b.X, w->rms_att_weight + li * dim, dim, nullptr, nt, dim); if (rc) return rc;      // infer.rs:19
+        {   // :20-33
+            GemmChainParams p{};
+            p.w[0] = b.cq + li * dd; p.w[1] = b.ck + li * dd; p.w[2] = b.cv + li * dd; p.nmat = 3; p.K = dim; p.rows = dim;
+            p.x = b.XN; p.xstride = dim; p.o[0] = b.Q; p.ostride = dim; p.n_tok = nt;
+            p.pos0 = p0; p.fr = w->freq_cis_real; p.fi = w->freq_cis_imag; p.head_size = hs; p.kc = kc; p.vc = vc;
+            p.seqs = seqs; p.layer_off = layer_off;
+            rc = launch_gemm_chain<CEPI_QKV>(c, p); if (rc) return rc;
+        }
+        {   // :34, one workgroup per (head, token)
+            RefAttnParams a{};
+            a.q = b.Q; a.kc = kc; a.vc = vc; a.att = b.ATT; a.xb = b.XB; a.ctl = nullptr; a.pos_val = p0;
+            a.dim = dim; a.head_size = hs; a.seq_len = seq; a.tok_stride = dim; a.att_stride = H * seq;
+            a.seqs = seqs; a.layer_off = layer_off;
+            const dim3 grid(H, nt);
+            if (b.nw == 4) hipLaunchKernelGGL((attention_chain_kernel<4>), grid, dim3(4 * 64), b.att_lds, c->stream, a);
+            else if (b.nw == 8) hipLaunchKernelGGL((attention_chain_kernel<8>), grid, dim3(8 * 64), b.att_lds, c->stream, a);
+            else hipLaunchKernelGGL((attention_chain_kernel<16>), grid, dim3(16 * 64), b.att_lds, c->stream, a);
+            LAUNCHCHK();
+        }
+        {   // :35-37
+            GemmChainParams p{};
+            p.w[0] = b.co + li * dd; p.nmat = 1; p.K = dim; p.rows = dim; p.x = b.XB; p.xstride = dim; p.n_tok = nt;
+            p.resid = b.X; p.rstride = dim;
+            rc = launch_gemm_chain<CEPI_RESID>(c, p); if (rc) return rc;
+        }
+        rc = launch_rmsnorm_chain(c, b.XN, b.X, w->rms_ffn_weight + li * dim, dim, nullptr, nt, dim); if (rc) return rc;      // :39
+        {   // :41-45
+            GemmChainParams p{};
+            p.w[0] = b.c13 + li * 2 * hd; p.nmat = 1; p.K = dim; p.rows = 2 * hidden; p.x = b.XN; p.xstride = dim; p.n_tok = nt;
+            p.o[0] = b.HB; p.ostride = hidden;
+            rc = launch_gemm_chain<CEPI_SWIGLU>(c, p); if (rc) return rc;
+        }
+        {   // :46-47
+            GemmChainParams p{};
+            p.w[0] = b.c2 + li * hd; p.nmat = 1; p.K = hidden; p.rows = dim; p.x = b.HB; p.xstride = hidden; p.n_tok = nt;
+            p.resid = b.X; p.rstride = dim;
+            rc = launch_gemm_chain<CEPI_RESID>(c, p); if (rc) return rc;
+        }
+    }
+    return 0;
+}
+
+// shape check, chain-order copies and scratch of the parity-mode token batches.  *ok = false: not available for this
+// shape / these weights (the caller falls back to one forward() per token).  Scratch, row-major per token: X residual
+// stream, XN its norm, Q, XB attention output, HB; att rows; token ids; the sequence table; (with_logits) LG [16][vocab]
+struct ChainScratch { ChainBatch b; int* toks; SeqSlot* seqs; float* LG; const float* ccls; };
+static int chain_batch_setup(rama_ctx* c, const rama_config* cfg, const rama_weights* w, bool with_logits, ChainScratch* out, bool* ok) {
+    *ok = false;
+    const int dim = cfg->dim, hidden = cfg->hidden_dim, hs = dim / cfg->n_heads, H = cfg->n_heads, seq = cfg->seq_len, V = cfg->vocab_size;
     if (!c->tune_chain || !c->tune_prefill_chain || dim % 16 || hidden % 16 || dim > 16000 || hidden > 16000 || !attn_chain_ok(hs, seq)) return 0;
-    if (!rmsnorm_chain_ok((size_t)dim) || n_tokens < 2) return 0;
+    if (!rmsnorm_chain_ok((size_t)dim)) return 0;
     int rc = rama_internal_model_ensure(c, w, 1); if (rc) return rc;
     const float* cq = rama_internal_chain_lookup(w->wq, dim, dim), *ck = rama_internal_chain_lookup(w->wk, dim, dim);
     const float* cv = rama_internal_chain_lookup(w->wv, dim, dim), *co = rama_internal_chain_lookup(w->wo, dim, dim);
     const float* c13 = rama_internal_chain_lookup(w->w1, 2 * hidden, dim), *c2 = rama_internal_chain_lookup(w->w2, dim, hidden);
-    if (!cq || !ck || !cv || !co || !c13 || !c2) return 0;
-    *done = true;
-    // scratch, row-major per token: X residual stream, XN its norm, Q, XB attention output, HB; att rows; token ids
+    const float* ccls = with_logits ? rama_internal_chain_lookup(w->wcls, V, dim) : nullptr;
+    if (!cq || !ck || !cv || !co || !c13 || !c2 || (with_logits && !ccls)) return 0;
     const size_t T = kGcMaxTok;
-    const size_t need = T * (4 * (size_t)dim + hidden) + T * (size_t)H * seq + 64;
+    const size_t slot_floats = (sizeof(SeqSlot) * T + sizeof(float) - 1) / sizeof(float);
+    const size_t need = T * (4 * (size_t)dim + hidden) + T * (size_t)H * seq + 64 + slot_floats + 4 + (with_logits ? T * (size_t)V : 0);
     if (need > c->pc_floats) {
         if (c->pc_blob) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->pc_blob)); c->pc_blob = nullptr; }
         HIPCHK(hipMalloc(&c->pc_blob, need * sizeof(float)));
         c->pc_floats = need;
     }
     float* X = c->pc_blob, *XN = X + T * dim, *Q = XN + T * dim, *XB = Q + T * dim, *HB = XB + T * dim, *ATT = HB + T * hidden;
-    int* toks = reinterpret_cast<int*>(ATT + T * (size_t)H * seq);
-    const size_t dd = (size_t)dim * dim, hd = (size_t)hidden * dim;
+    out->toks = reinterpret_cast<int*>(ATT + T * (size_t)H * seq);
+    out->seqs = reinterpret_cast<SeqSlot*>(out->toks + 64);                       // 8-byte aligned: every term above is a multiple of 16 floats
+    out->LG = reinterpret_cast<float*>(out->toks + 64) + slot_floats + 4 - ((slot_floats) & 3);      // 16-byte aligned
+    out->ccls = ccls;
     const int nw = attn_chain_waves(hs, false);
     const size_t att_lds = attn_chain_lds_floats(hs, seq, nw) * sizeof(float) + 16;
-    REQUIRE(att_lds <= kAttnChainMaxLds, RAMA_EUNSUP, "prefill (parity mode): context too long for the score buffer");
+    REQUIRE(att_lds <= kAttnChainMaxLds, RAMA_EUNSUP, "token batch (parity mode): context too long for the score buffer");
+    out->b = ChainBatch{X, XN, Q, XB, HB, ATT, cq, ck, cv, co, c13, c2, nw, att_lds};
+    *ok = true;
+    return 0;
+}
+
+static int prefill_chain(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s,
+                         const int32_t* tokens_host, int n_tokens, int pos0, bool* done) {
+    *done = false;
+    if (n_tokens < 2) return 0;
+    const int dim = cfg->dim;
+    ChainScratch sc{};
+    int rc = chain_batch_setup(c, cfg, w, false, &sc, done); if (rc || !*done) return rc;
+    float* X = sc.b.X; int* toks = sc.toks;
+    const ChainBatch& cb = sc.b;
     c->embedded_x = nullptr; c->host_pos = -1;
     const int n_batch = n_tokens - 1;                             // the last position runs as forward()
     for (int c0 = 0; c0 < n_batch; c0 += kGcMaxTok) {
@@ -1477,50 +1552,44 @@ static int prefill_chain(rama_ctx* c, const rama_config* cfg, const rama_weights
         HIPCHK(hipMemcpyAsync(toks, c->pinned_tok, sizeof(int) * nt, hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(embed_rows_kernel, dim3((dim + 255) / 256, nt), dim3(256), 0, c->stream, X, w->token_embedding_table, (const int*)toks, nt, dim);
         LAUNCHCHK();
-        for (int layer = 0; layer < cfg->n_layers; layer++) {
-            const size_t li = (size_t)layer;
-            float* kc = s->key_cache + li * seq * dim;
-            float* vc = s->value_cache + li * seq * dim;
-            rc = launch_rmsnorm_chain(c, XN, X, w->rms_att_weight + li * dim, dim, nullptr, nt, dim); if (rc) return rc;      // infer.rs:19
-            {   // :20-33
-                GemmChainParams p{};
-                p.w[0] = cq + li * dd; p.w[1] = ck + li * dd; p.w[2] = cv + li * dd; p.nmat = 3; p.K = dim; p.rows = dim;
-                p.x = XN; p.xstride = dim; p.o[0] = Q; p.ostride = dim; p.n_tok = nt;
-                p.pos0 = p0; p.fr = w->freq_cis_real; p.fi = w->freq_cis_imag; p.head_size = hs; p.kc = kc; p.vc = vc;
-                rc = launch_gemm_chain<CEPI_QKV>(c, p); if (rc) return rc;
-            }
-            {   // :34, one workgroup per (head, position)
-                RefAttnParams a{};
-                a.q = Q; a.kc = kc; a.vc = vc; a.att = ATT; a.xb = XB; a.ctl = nullptr; a.pos_val = p0;
-                a.dim = dim; a.head_size = hs; a.seq_len = seq; a.tok_stride = dim; a.att_stride = H * seq;
-                const dim3 grid(H, nt);
-                if (nw == 4) hipLaunchKernelGGL((attention_chain_kernel<4>), grid, dim3(4 * 64), att_lds, c->stream, a);
-                else if (nw == 8) hipLaunchKernelGGL((attention_chain_kernel<8>), grid, dim3(8 * 64), att_lds, c->stream, a);
-                else hipLaunchKernelGGL((attention_chain_kernel<16>), grid, dim3(16 * 64), att_lds, c->stream, a);
-                LAUNCHCHK();
-            }
-            {   // :35-37
-                GemmChainParams p{};
-                p.w[0] = co + li * dd; p.nmat = 1; p.K = dim; p.rows = dim; p.x = XB; p.xstride = dim; p.n_tok = nt;
-                p.resid = X; p.rstride = dim;
-                rc = launch_gemm_chain<CEPI_RESID>(c, p); if (rc) return rc;
-            }
-            rc = launch_rmsnorm_chain(c, XN, X, w->rms_ffn_weight + li * dim, dim, nullptr, nt, dim); if (rc) return rc;      // :39
-            {   // :41-45
-                GemmChainParams p{};
-                p.w[0] = c13 + li * 2 * hd; p.nmat = 1; p.K = dim; p.rows = 2 * hidden; p.x = XN; p.xstride = dim; p.n_tok = nt;
-                p.o[0] = HB; p.ostride = hidden;
-                rc = launch_gemm_chain<CEPI_SWIGLU>(c, p); if (rc) return rc;
-            }
-            {   // :46-47
-                GemmChainParams p{};
-                p.w[0] = c2 + li * hd; p.nmat = 1; p.K = hidden; p.rows = dim; p.x = HB; p.xstride = hidden; p.n_tok = nt;
-                p.resid = X; p.rstride = dim;
-                rc = launch_gemm_chain<CEPI_RESID>(c, p); if (rc) return rc;
-            }
-        }
+        rc = chain_batch_layers(c, cfg, w, cb, nt, p0, s->key_cache, s->value_cache, nullptr); if (rc) return rc;
     }
     return rama_forward(c, cfg, w, s, tokens_host[n_tokens - 1], pos0 + n_tokens - 1);
+}
+
+// rama_decode_batch in parity mode: the sequences share every weight pass, 16 at a time, through the same kernels; each
+// sequence's appended cache rows and its logits are bit for bit those of its own forward().  (x / xb / q .. of the states
+// are not maintained -- the call's contract, see the header.)
+static int decode_batch_chain(rama_ctx* c, const rama_config* cfg, const rama_weights* w, const rama_run_state* states,
+                              const int32_t* tokens_host, const int32_t* pos_host, int n_seq, bool* done) {
+    *done = false;
+    const int dim = cfg->dim, V = cfg->vocab_size;
+    if (n_seq < 2) return 0;
+    ChainScratch sc{};
+    int rc = chain_batch_setup(c, cfg, w, true, &sc, done); if (rc || !*done) return rc;
+    c->embedded_x = nullptr; c->host_pos = -1;
+    SeqSlot* slots = reinterpret_cast<SeqSlot*>(c->pinned_tok + kMfMaxTok);
+    for (int c0 = 0; c0 < n_seq; c0 += kGcMaxTok) {
+        const int nt = std::min(kGcMaxTok, n_seq - c0);
+        HIPCHK(hipStreamSynchronize(c->stream));                  // the pinned staging buffers are free again
+        for (int i = 0; i < nt; i++) {
+            c->pinned_tok[i] = tokens_host[c0 + i];
+            slots[i].kc = states[c0 + i].key_cache; slots[i].vc = states[c0 + i].value_cache; slots[i].pos = pos_host[c0 + i]; slots[i].pad = 0;
+        }
+        HIPCHK(hipMemcpyAsync(sc.toks, c->pinned_tok, sizeof(int) * nt, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(sc.seqs, slots, sizeof(SeqSlot) * nt, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(embed_rows_kernel, dim3((dim + 255) / 256, nt), dim3(256), 0, c->stream, sc.b.X, w->token_embedding_table, (const int*)sc.toks, nt, dim);
+        LAUNCHCHK();
+        rc = chain_batch_layers(c, cfg, w, sc.b, nt, 0, nullptr, nullptr, sc.seqs); if (rc) return rc;
+        // infer.rs:49-51 per sequence: x = rmsnorm(x), logits = Wcls . x
+        rc = launch_rmsnorm_chain(c, sc.b.XN, sc.b.X, w->rms_final_weight, dim, nullptr, nt, dim); if (rc) return rc;
+        GemmChainParams p{};
+        p.w[0] = sc.ccls; p.nmat = 1; p.K = dim; p.rows = V; p.x = sc.b.XN; p.xstride = dim; p.o[0] = sc.LG; p.ostride = V; p.n_tok = nt;
+        rc = launch_gemm_chain<CEPI_STORE>(c, p); if (rc) return rc;
+        for (int i = 0; i < nt; i++)
+            HIPCHK(hipMemcpyAsync(states[c0 + i].logits, sc.LG + (size_t)i * V, sizeof(float) * V, hipMemcpyDeviceToDevice, c->stream));
+    }
+    return 0;
 }
 
 int rama_prefill(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s,
@@ -1614,6 +1683,11 @@ int rama_decode_batch(rama_ctx* c, const rama_config* cfg, const rama_weights* w
     int tmax = 1;
     for (int i = 0; i < n_seq; i++) tmax = std::max(tmax, pos_host[i] + 1);
     const size_t att_floats = (size_t)attn_scratch_floats((dim / cfg->n_heads) <= 64 ? 16 : ((dim / cfg->n_heads) <= 128 ? 32 : 64)) + tmax;
+    if (c->tune_ref_order) {      // parity mode: the chain-order token-batch kernels when the shape and the copies allow
+        bool done = false;
+        rc = decode_batch_chain(c, cfg, w, states, tokens_host, pos_host, n_seq, &done);
+        if (rc || done) return rc;
+    }
     if (c->tune_ref_order || !mf_shape_ok(cfg) || V % 4 != 0 || att_floats * sizeof(float) > 64 * 1024) {   // see rama_prefill: one forward() per sequence
         for (int i = 0; i < n_seq; i++) {
             rama_run_state si = states[i];

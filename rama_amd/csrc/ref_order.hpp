@@ -182,6 +182,9 @@ struct RefAttnParams {
     // a grid of (heads, tokens) -- the parity-mode prefill pass, chain.hpp: token y sits at position pos + y, its q / xb
     // rows are y * tok_stride floats further on, its att rows y * att_stride.  (0, 0 and gridDim.y = 1: one token.)
     int tok_stride, att_stride;
+    // ... or tokens of independent sequences (rama_decode_batch in parity mode): token y reads its position and its cache
+    // bases from seqs[y] (+ layer_off floats for this layer); pos / kc / vc above are then unused
+    const SeqSlot* seqs; size_t layer_off;
 };
 
 __global__ __launch_bounds__(1024) void attention_ref_kernel(RefAttnParams p) {

@@ -400,3 +400,38 @@ def test_parity_prefill_bit_exact(dev, shape, n_tokens, pos0):
             assert_bits_equal(outs[batched][buf], orc.s[buf], f"{buf}, batched={batched}")
         eng.free()
     model.free()
+
+
+@pytest.mark.parametrize("shape,n_seq", [((64, 176, 2, 4, 96, 24), 2), ((64, 176, 2, 4, 96, 24), 5), ((128, 352, 2, 2, 250, 24), 16),
+                                         ((128, 352, 2, 2, 250, 24), 17), ((288, 768, 2, 6, 512, 24), 40)])
+def test_parity_decode_batch_bit_exact(dev, shape, n_seq):
+    """parity mode's rama_decode_batch: independent sequences at different positions share every weight pass, 16 at a
+    time, through the chain-order token-batch kernels; each sequence's logits and cache rows are the ORACLE's for its own
+    forward(), bit for bit, over several steps"""
+    import rama_amd
+    from .helpers import to_rama_cfg
+    dim, hidden, L, H, V, seq = shape
+    cfg = O.Config(dim, hidden, L, H, H, V, seq, True)
+    rope = S.rope_tables(seq, dim // H)
+    w = S.synth_weights(cfg, 9, rope=rope)
+    model = rama_amd.Model.synth(dev, to_rama_cfg(cfg), 9, rope=rope)
+    batch = [rama_amd.Engine(dev, model) for _ in range(n_seq)]
+    orcs = [O.Oracle(cfg, w) for _ in range(n_seq)]
+    rng = np.random.default_rng(n_seq)
+    cur = [int(t) for t in rng.integers(0, V, n_seq)]
+    pos = [0] * n_seq
+    for i in range(n_seq):                        # stagger: sequence i is advanced alone i % 4 times first
+        for _ in range(i % 4):
+            lo = orcs[i].forward(cur[i], pos[i]); batch[i].forward(cur[i], pos[i])
+            cur[i] = O.argmax(lo); pos[i] += 1
+    for _ in range(3):
+        rama_amd.decode_batch(batch, cur, pos)
+        for i in range(n_seq):
+            lo = orcs[i].forward(cur[i], pos[i])
+            assert_bits_equal(batch[i].logits(), lo, f"sequence {i} position {pos[i]} logits")
+            cur[i] = O.argmax(lo); pos[i] += 1
+    for i in (0, n_seq // 2, n_seq - 1):
+        for buf in ("key_cache", "value_cache"):
+            assert_bits_equal(batch[i].buffer(buf, orcs[i].s[buf].size), orcs[i].s[buf], f"sequence {i} {buf}")
+    for e in batch: e.free()
+    model.free()
