@@ -189,7 +189,8 @@ int  rama_prefill(rama_ctx *ctx, const rama_config *cfg, const rama_weights *w, 
  * prefill).  states[i] is sequence i's run state; afterwards it holds what
  * rama_forward(token_i, pos_i) would have left in it: the appended cache rows and the logits
  * (x / xb / q ... scratch is not maintained).  Sequences may sit at different positions; two entries
- * must not share a state. */
+ * must not share a state.  Parity mode ("ref_order" = 1) on a resident model: 16 sequences per weight pass through the
+ * chain-order token-batch kernels, every sequence's logits and cache rows bit for bit those of its own rama_forward. */
 int  rama_decode_batch(rama_ctx *ctx, const rama_config *cfg, const rama_weights *w,
                        const rama_run_state *states, const int32_t *tokens_host,
                        const int32_t *positions_host, int n_seq);
