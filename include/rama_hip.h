@@ -287,6 +287,18 @@ int  rama_decode_steps(rama_ctx *ctx, const rama_config *cfg, const rama_weights
                        rama_run_state *s, int n_steps);
 /* tokens produced since rama_decode_begin (synchronises) */
 int  rama_decode_tokens(rama_ctx *ctx, int32_t *out_tokens_host, int max_tokens, int *n_out);
+/* Tokens `from`.. that the chained loop has produced SO FAR, without touching the stream (mod.rs:209-248 generate_stream
+ * sends each token as it is produced): the sampling launch writes every token also to a host-visible ring (pinned,
+ * device-mapped memory, one system-scope store per token), which this call reads.  Returns at once; *n_ready may be 0.
+ * What goes wrong inside the loop is reported by rama_decode_tokens at the end. */
+int  rama_decode_stream_poll(rama_ctx *ctx, int from, int32_t *out_tokens_host, int max_tokens, int *n_ready);
+/* generate_stream (mod.rs:209-248): rama_generate with every token handed to on_token(user, index, token) on the calling
+ * thread as soon as the device has produced it; the loop itself stays chained on the device (no host round trip per
+ * token).  out_tokens_host (may be NULL) receives the whole list at the end. */
+int  rama_generate_stream(rama_ctx *ctx, const rama_config *cfg, const rama_weights *w, rama_run_state *s,
+                          const int32_t *prompt_tokens_host, int n_prompt, int steps, float temperature,
+                          float topp, float u, void (*on_token)(void *user, int index, int32_t token), void *user,
+                          int32_t *out_tokens_host);
 /* 1: replay launches from hipGraphs (default 0 = eager launches): rama_decode_steps / rama_generate capture a
  * decode step (or a few, "graph_steps") once per attention variant; rama_forward and rama_forward_stage* keep one
  * graph per (run state, stage, attention variant) -- token and position travel through the device cursor, so a

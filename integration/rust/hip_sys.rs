@@ -125,6 +125,11 @@ extern "C" {
     pub fn rama_decode_sampler(ctx: *mut rama_ctx, temperature: f32, topp: f32, u: f32) -> c_int;
     pub fn rama_decode_steps(ctx: *mut rama_ctx, cfg: *const rama_config, w: *const rama_weights, s: *mut rama_run_state, n_steps: c_int) -> c_int;
     pub fn rama_decode_tokens(ctx: *mut rama_ctx, out_tokens_host: *mut i32, max_tokens: c_int, n_out: *mut c_int) -> c_int;
+    pub fn rama_decode_stream_poll(ctx: *mut rama_ctx, from: c_int, out_tokens_host: *mut i32, max_tokens: c_int, n_ready: *mut c_int) -> c_int;
+    pub fn rama_generate_stream(ctx: *mut rama_ctx, cfg: *const rama_config, w: *const rama_weights, s: *mut rama_run_state,
+                                prompt_tokens_host: *const i32, n_prompt: c_int, steps: c_int, temperature: f32, topp: f32, u: f32,
+                                on_token: Option<unsafe extern "C" fn(user: *mut c_void, index: c_int, token: i32)>, user: *mut c_void,
+                                out_tokens_host: *mut i32) -> c_int;
     pub fn rama_state_create(ctx: *mut rama_ctx, cfg: *const rama_config, n_local_layers: c_int, out: *mut rama_run_state) -> c_int;
     pub fn rama_state_free(ctx: *mut rama_ctx, s: *mut rama_run_state) -> c_int;
     pub fn rama_model_synth(ctx: *mut rama_ctx, cfg: *const rama_config, seed: u64, stage: *const rama_stage,

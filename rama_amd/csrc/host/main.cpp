@@ -5,7 +5,7 @@
 // closing line `elapsed: S.mmm s, avg tok/s: X` with X = (step - 1) / elapsed (main.rs:96-103).
 // RAMA_PATH=ops     forward() composed from the 1:1 Device ops (the drop-in path)
 // RAMA_PATH=fused   (default) rama_forward: five fused launches per layer
-// RAMA_PATH=chained the whole loop chained on the device, text printed at the end
+// RAMA_PATH=chained the whole loop chained on the device, every token printed as it appears in the host-visible ring
 // RAMA_WORLD=N RAMA_RANK=r RAMA_PIPE_ID_FILE=path [RAMA_DEVICE=d]
 //                   layer pipeline over N processes, one GPU each (csrc/pipe.hip: RCCL send/recv of
 //                   x[dim] and the sampled token id).  Rank r loads layers [r*L/N, (r+1)*L/N) only;
@@ -177,10 +177,15 @@ int main(int argc, char** argv) {
             // the whole generate() loop on the device, argmax or top-p (no per-token host round trip)
             std::vector<int32_t> pt(prompt_tokens.begin(), prompt_tokens.end()), out(steps ? steps : 1);
             rama_config c = config.c(); rama_weights w = wv.c(); rama_run_state s = rsv.c();
-            ck(rama_generate(device.ctx, &c, &w, &s, pt.data(), (int)pt.size(), (int)steps, args.temperature, args.topp,
-                             device.topp_draw, out.data()), "rama_generate");
-            for (size_t i = 0; i < steps; i++) std::cout << decode(tokenizer.vocab[(size_t)out[i]]);
-            std::cout.flush();
+            // every token printed as soon as the device has produced it (mod.rs:196-200 prints inside the loop), the loop
+            // itself chained on the device: the host only watches the ring (rama_generate_stream)
+            struct Sink { const Tokenizer* tok; } sink{&tokenizer};
+            ck(rama_generate_stream(device.ctx, &c, &w, &s, pt.data(), (int)pt.size(), (int)steps, args.temperature, args.topp,
+                                    device.topp_draw,
+                                    [](void* user, int, int32_t token) {
+                                        std::cout << decode(static_cast<Sink*>(user)->tok->vocab[(size_t)token]);
+                                        std::cout.flush();
+                                    }, &sink, out.data()), "rama_generate_stream");
         } else {
             size_t token = 1, pos = 0;                                    // mod.rs:182-183
             while (pos < steps) {

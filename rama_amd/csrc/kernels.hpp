@@ -854,6 +854,7 @@ struct ArgmaxParams {
     int* result;          // optional device int
     Ctl* ctl;             // optional cursor to advance
     const int* forced; int* out; int out_cap;
+    int* ring;            // optional: host-visible (pinned, mapped) copy of `out`, entry = token + 1, 0 = not produced yet
     const float* emb; float* x; int dim;   // optional next-token embedding gather
 };
 
@@ -864,7 +865,11 @@ __device__ __forceinline__ int finish_step(const ArgmaxParams& p, int idx, int p
     int next = idx < 0 ? 0 : idx;
     if (p.ctl) {
         if (forced_tok >= 0) next = forced_tok;
-        if (n_out < p.out_cap) p.out[n_out] = next;
+        if (n_out < p.out_cap) {
+            p.out[n_out] = next;
+            // the host may be polling this word while the loop runs on (rama_decode_stream_poll): one system-scope store
+            if (p.ring) __hip_atomic_store(p.ring + n_out, next + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         p.ctl->n_out = n_out + 1;
         p.ctl->token = next;
         p.ctl->pos = pos + 1;

@@ -80,6 +80,9 @@ struct rama_ctx {
     int forced_cap = 0;
     int* out = nullptr;          // device produced-token list
     int out_cap = 0;
+    int* ring = nullptr;                    // host-pinned, device-mapped: ring[i] = token i of the chained loop + 1 (0: not produced yet)
+    int* ring_dev = nullptr;
+    int ring_hi = 0;                        // entries that may be non-zero
     int* argmax_result = nullptr;   // device int for rama_sample_argmax
     int* pinned_int = nullptr;      // host pinned
     int* pinned_tok = nullptr;      // host pinned staging: token ids + a SeqSlot table of a token-batch pass
@@ -198,6 +201,9 @@ int rama_ctx_create(int device, void* hip_stream, rama_ctx** out) {
     HIPCHK(hipMemset(c->ctl, 0, sizeof(Ctl)));
     c->out_cap = 1 << 16;
     HIPCHK(hipMalloc(&c->out, sizeof(int) * c->out_cap));
+    HIPCHK(hipHostMalloc(&c->ring, sizeof(int) * c->out_cap, hipHostMallocMapped));
+    memset(c->ring, 0, sizeof(int) * c->out_cap);
+    HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->ring_dev), c->ring, 0));
     c->forced_cap = 1 << 16;
     HIPCHK(hipMalloc(&c->forced, sizeof(int) * c->forced_cap));
     HIPCHK(hipMalloc(&c->argmax_result, sizeof(int)));
@@ -249,7 +255,7 @@ int rama_ctx_destroy(rama_ctx* c) {
     for (auto e : c->kp.ev) hipEventDestroy(e);
     hipFree(c->ctl); hipFree(c->out); hipFree(c->forced); hipFree(c->argmax_result); hipFree(c->pbar); hipFree(c->attn_counter); hipFree(c->attn_part);
     for (int i = 0; i < 2; i++) { hipFree(c->topp_keys[i]); hipFree(c->topp_vals[i]); }
-    hipFree(c->topp_prefix); hipFree(c->topp_m); hipFree(c->topp_err); hipFree(c->pf_blob); hipFree(c->pc_blob);
+    hipFree(c->topp_prefix); hipFree(c->topp_m); hipFree(c->topp_err); hipFree(c->pf_blob); hipFree(c->pc_blob); if (c->ring) hipHostFree(c->ring);
     hipFree(c->topp_bp); hipFree(c->topp_bi); hipFree(c->topp_bcount);
     hipFree(c->bc.toks); hipFree(c->bc.seqs); hipFree(c->bc.out);
     hipHostFree(c->pinned_int); hipHostFree(c->pinned_tok);
@@ -1859,8 +1865,19 @@ int rama_decode_batch_tokens(rama_ctx* c, int32_t* out_host, int max_per_seq, in
 
 // ---- device-chained greedy decode (generate() at T == 0, mod.rs:169-206)
 
+// a new generation: nothing of the old one may still be on its way to the ring, then the used part is cleared
+static int ring_reset(rama_ctx* c) {
+    if (c->ring_hi > 0) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        memset(c->ring, 0, sizeof(int) * (size_t)std::min(c->ring_hi, c->out_cap));
+        c->ring_hi = 0;
+    }
+    return 0;
+}
+
 int rama_decode_begin(rama_ctx* c, int token, int pos, const int32_t* forced_host, int n_forced) {
     REQUIRE(c, RAMA_EINVAL, "ctx is NULL");
+    { int rr = ring_reset(c); if (rr) return rr; }
     REQUIRE(n_forced >= 0 && n_forced <= c->forced_cap, RAMA_EINVAL, "decode_begin: too many forced tokens");
     REQUIRE(n_forced == 0 || forced_host, RAMA_EINVAL, "decode_begin: forced list is NULL");
     if (n_forced) {
@@ -1882,7 +1899,7 @@ static int enqueue_decode_step(rama_ctx* c, const rama_config* cfg, const rama_w
     if (rc) return rc;
     ArgmaxParams ap{};
     ap.logits = s->logits; ap.n = cfg->vocab_size;
-    ap.ctl = c->ctl; ap.forced = c->forced; ap.out = c->out; ap.out_cap = c->out_cap;
+    ap.ctl = c->ctl; ap.forced = c->forced; ap.out = c->out; ap.out_cap = c->out_cap; ap.ring = c->ring_dev;
     ap.emb = w->token_embedding_table; ap.x = s->x; ap.dim = cfg->dim;
     return enqueue_sample(c, ap, c->samp_T, c->samp_topp, c->samp_u);
 }
@@ -1939,6 +1956,22 @@ int rama_decode_steps(rama_ctx* c, const rama_config* cfg, const rama_weights* w
         c->host_pos += take;
         i += take;
     }
+    c->ring_hi = std::min(c->out_cap, c->ring_hi + n_steps);
+    return 0;
+}
+
+// Tokens the chained loop has produced so far, WITHOUT touching the stream: entries `from`.. of the host-visible ring the
+// sampling launch writes next to its device list (generate_stream's channel, mod.rs:209-248: each token as it is produced).
+// Returns at once; *n_ready may be 0.  Errors of the loop itself are reported by rama_decode_tokens at the end.
+int rama_decode_stream_poll(rama_ctx* c, int from, int32_t* out_host, int max_tokens, int* n_ready) {
+    REQUIRE(c && n_ready && from >= 0 && max_tokens >= 0 && (max_tokens == 0 || out_host), RAMA_EINVAL, "decode_stream_poll: bad argument");
+    int n = 0;
+    while (n < max_tokens && from + n < c->out_cap) {
+        const int v = __atomic_load_n(c->ring + from + n, __ATOMIC_ACQUIRE);
+        if (v == 0) break;
+        out_host[n++] = v - 1;
+    }
+    *n_ready = n;
     return 0;
 }
 
@@ -1975,10 +2008,13 @@ int rama_generate_greedy(rama_ctx* c, const rama_config* cfg, const rama_weights
     return rama_generate(c, cfg, w, s, prompt_host, n_prompt, steps, 0.0f, 0.9f, 0.0f, out_host);
 }
 
-int rama_generate(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s,
-                  const int32_t* prompt_host, int n_prompt, int steps, float temperature, float topp, float u,
-                  int32_t* out_host) {
-    REQUIRE(c && cfg && out_host, RAMA_EINVAL, "generate_greedy: NULL argument");
+// enqueue the whole generate() loop (mod.rs:169-206); the caller collects the tokens (all at the end, or as they appear)
+// (*deferred != NULL: the decode steps are NOT enqueued, their count is returned there -- the streaming caller feeds them
+// in pieces, see rama_generate_stream)
+static int generate_enqueue(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s,
+                            const int32_t* prompt_host, int n_prompt, int steps, float temperature, float topp, float u,
+                            int* deferred = nullptr) {
+    REQUIRE(c && cfg, RAMA_EINVAL, "generate_greedy: NULL argument");
     { int rcs = rama_decode_sampler(c, temperature, topp, u); if (rcs) return rcs; }
     REQUIRE(steps >= 0 && steps <= cfg->seq_len, RAMA_EINVAL, "generate_greedy: steps > seq_len (the reference does not bound-check, SURVEY section 5)");
     REQUIRE(steps <= c->out_cap, RAMA_EINVAL, "generate_greedy: too many steps");
@@ -1993,30 +2029,89 @@ int rama_generate(rama_ctx* c, const rama_config* cfg, const rama_weights* w, ra
         toks[0] = 1;
         for (int i = 0; i < n_prompt; i++) toks[i + 1] = prompt_host[i];
         for (int i = 0; i < n_prompt; i++) REQUIRE(prompt_host[i] >= 0 && prompt_host[i] < cfg->vocab_size, RAMA_EINVAL, "generate_greedy: prompt token outside the vocabulary");
+        rc = ring_reset(c); if (rc) return rc;
         rc = rama_prefill(c, cfg, w, s, toks.data(), n_prompt + 1, 0);
         if (rc) return rc;
         HIPCHK(hipMemcpyAsync(c->out, prompt_host, sizeof(int) * n_prompt, hipMemcpyHostToDevice, c->stream));   // forced `next`s
+        for (int i = 0; i < n_prompt; i++) __atomic_store_n(c->ring + i, prompt_host[i] + 1, __ATOMIC_RELEASE);   // ... known at once
+        c->ring_hi = n_prompt + 1;
         hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(1), 0, c->stream, c->ctl, toks[n_prompt], n_prompt, 0, n_prompt);
         LAUNCHCHK();
         ArgmaxParams ap{};
         ap.logits = s->logits; ap.n = cfg->vocab_size;
-        ap.ctl = c->ctl; ap.forced = c->forced; ap.out = c->out; ap.out_cap = c->out_cap;
+        ap.ctl = c->ctl; ap.forced = c->forced; ap.out = c->out; ap.out_cap = c->out_cap; ap.ring = c->ring_dev;
         ap.emb = w->token_embedding_table; ap.x = s->x; ap.dim = cfg->dim;
         if (c->samp_T != 0.0f) { rc = ensure_topp_scratch(c, cfg->vocab_size); if (rc) return rc; }
         rc = enqueue_sample(c, ap, c->samp_T, c->samp_topp, c->samp_u);               // out[n_prompt], cursor -> n_prompt + 1, next x
         if (rc) return rc;
         c->embedded_x = s->x;
         c->host_pos = n_prompt + 1;
+        if (deferred) { *deferred = steps - n_prompt - 1; return 0; }
         rc = rama_decode_steps(c, cfg, w, s, steps - n_prompt - 1);
         if (rc) return rc;
     } else {
         rc = rama_decode_begin(c, /*BOS*/ 1, 0, prompt_host, n_prompt);
         if (rc) return rc;
+        if (deferred) { *deferred = steps; return 0; }
         rc = rama_decode_steps(c, cfg, w, s, steps);
         if (rc) return rc;
     }
+    return 0;
+}
+
+int rama_generate(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s,
+                  const int32_t* prompt_host, int n_prompt, int steps, float temperature, float topp, float u,
+                  int32_t* out_host) {
+    REQUIRE(out_host, RAMA_EINVAL, "generate_greedy: NULL argument");
+    int rc = generate_enqueue(c, cfg, w, s, prompt_host, n_prompt, steps, temperature, topp, u);
+    if (rc) return rc;
     int n = 0;
     return rama_decode_tokens(c, out_host, steps, &n);
+}
+
+// generate_stream (mod.rs:209-248): the same loop, every token handed to `on_token(user, index, token)` on the calling
+// thread as soon as the device has produced it -- the loop itself runs on, chained on the device; the host only watches
+// the ring.  out_host (may be NULL) receives the whole list at the end, as rama_generate does.
+int rama_generate_stream(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s,
+                         const int32_t* prompt_host, int n_prompt, int steps, float temperature, float topp, float u,
+                         void (*on_token)(void* user, int index, int32_t token), void* user, int32_t* out_host) {
+    REQUIRE(on_token, RAMA_EINVAL, "generate_stream: NULL callback");
+    int todo = 0;
+    int rc = generate_enqueue(c, cfg, w, s, prompt_host, n_prompt, steps, temperature, topp, u, &todo);
+    if (rc) return rc;
+    // The steps are fed to the stream a few at a time and never more than kAhead beyond the last token seen: a whole
+    // generation enqueued at once fills the hardware queue (200 steps of llama2-7B are 32 000 packets), the enqueueing
+    // thread then sits in hipGraphLaunch and the first token is looked at half a generation late.
+    constexpr int kChunk = 8, kAhead = 24;
+    int seen = 0, fed = steps - todo;                             // tokens handed over; tokens whose production is enqueued
+    auto hand_over = [&]() -> int {
+        int32_t buf[64];
+        int n = 0;
+        int r = rama_decode_stream_poll(c, seen, buf, std::min(64, steps - seen), &n); if (r) return r;
+        for (int i = 0; i < n; i++) on_token(user, seen + i, buf[i]);
+        seen += n;
+        return 0;
+    };
+    while (seen < steps) {
+        if (fed < steps && fed - seen < kAhead) {
+            const int n = std::min(kChunk, steps - fed);
+            rc = rama_decode_steps(c, cfg, w, s, n); if (rc) return rc;
+            fed += n;
+        }
+        const int before = seen;
+        rc = hand_over(); if (rc) return rc;
+        if (seen == before && fed == steps && hipStreamQuery(c->stream) == hipSuccess) {
+            rc = hand_over(); if (rc) return rc;                  // everything has run: what is there now is all there will be
+            if (seen == before) break;
+        }
+    }
+    std::vector<int32_t> tmp;
+    if (!out_host) { tmp.resize(steps > 0 ? steps : 1); out_host = tmp.data(); }
+    int n = 0;
+    rc = rama_decode_tokens(c, out_host, steps, &n);                 // also reports what went wrong inside the loop, if anything
+    if (rc) return rc;
+    REQUIRE(seen == steps, RAMA_EINVAL, "generate_stream: the loop ended before every token had appeared");
+    return 0;
 }
 
 int rama_set_tuning(rama_ctx* c, const char* key, int value) {

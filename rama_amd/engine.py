@@ -126,6 +126,25 @@ class Engine:
                                             temperature, topp, u, out), "rama_generate")
         return [int(v) for v in out[:steps]]
 
+    def generate_stream(self, prompt_tokens, steps: int, on_token, temperature: float = 0.0, topp: float = 0.9, u: float = 0.0):
+        """generate_stream (mod.rs:209-248): on_token(index, token) is called for every token as soon as the device has
+        produced it, while the loop runs on, chained on the device (rama_generate_stream); returns the whole list"""
+        pt = (C.c_int32 * max(len(prompt_tokens), 1))(*prompt_tokens)
+        out = (C.c_int32 * max(steps, 1))()
+        cb_t = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int32)
+        cb = cb_t(lambda user, index, token: on_token(int(index), int(token)))
+        check(self.device.lib.rama_generate_stream(self.device.ctx, C.byref(self.model.ccfg), C.byref(self.model.weights),
+                                                   C.byref(self.state), pt, len(prompt_tokens), steps, temperature, topp, u,
+                                                   cb, None, out), "rama_generate_stream")
+        return [int(v) for v in out[:steps]]
+
+    def decode_stream_poll(self, start: int, max_tokens: int = 64):
+        """the tokens `start`.. the chained loop has produced so far (host-visible ring; never blocks, may be empty)"""
+        buf = (C.c_int32 * max_tokens)()
+        n = C.c_int()
+        check(self.device.lib.rama_decode_stream_poll(self.device.ctx, start, buf, max_tokens, C.byref(n)), "rama_decode_stream_poll")
+        return [int(v) for v in buf[:n.value]]
+
     def decode_sampler(self, temperature: float, topp: float = 0.9, u: float = 0.0):
         check(self.device.lib.rama_decode_sampler(self.device.ctx, temperature, topp, u), "rama_decode_sampler")
 

@@ -1090,3 +1090,56 @@ def test_v1_ak42_checkpoint_is_rejected(dev):
     assert "(-2)" in str(e.value)           # RAMA_EUNSUP
     with pytest.raises(Exception):
         O.read_checkpoint(GOLDEN / "ckpt_v1_ak42.bin")
+
+
+# ------------------------------------------------------------------ generate_stream (mod.rs:209-248): tokens as they are produced
+
+@pytest.mark.parametrize("temperature,prompt", [(0.0, []), (0.0, [5, 9, 3, 7, 11]), (1.0, [5, 9, 3]), (0.0, list(range(2, 40)))])
+def test_generate_stream_hands_over_every_token_in_order(dev, temperature, prompt):
+    """rama_generate_stream: the chained loop writes every token to a host-visible ring as well; the callback sees
+    index 0, 1, .. with exactly the tokens rama_generate returns (and the oracle's at temperature 0), prompt positions
+    included, whether the prompt went through the per-token loop or through rama_prefill"""
+    import rama_amd
+    cfg = O.Config(128, 352, 2, 4, 4, 256, 96, True)
+    rope = S.rope_tables(cfg.seq_len, cfg.head_size)
+    w = S.synth_weights(cfg, seed=21, rope=rope)
+    m = rama_amd.Model.synth(dev, to_rama_cfg(cfg), 21, rope=rope)
+    steps = 80
+    u = 0.2721174359321594
+    a, b = rama_amd.Engine(dev, m), rama_amd.Engine(dev, m)
+    want = a.generate(prompt, steps, temperature, 0.9, u)
+    seen = []
+    for graph in (False, True):
+        b.set_graph_mode(graph)
+        seen.clear()
+        got = b.generate_stream(prompt, steps, lambda i, t: seen.append((i, t)), temperature, 0.9, u)
+        assert got == want
+        assert [i for i, _ in seen] == list(range(steps))
+        assert [t for _, t in seen] == want
+    b.set_graph_mode(False)
+    if temperature == 0.0:
+        assert want == O.Oracle(cfg, w).generate_greedy(prompt, steps)
+    a.free(); b.free(); m.free()
+
+
+def test_decode_stream_poll_sees_the_loop_progress(dev):
+    """rama_decode_stream_poll never blocks: polled while rama_decode_steps' launches are still running it returns the
+    tokens produced so far (possibly none), and in the end exactly rama_decode_tokens' list; a new rama_decode_begin
+    clears the ring"""
+    import rama_amd
+    cfg = O.Config(288, 768, 4, 6, 6, 512, 256, True)
+    rope = S.rope_tables(cfg.seq_len, cfg.head_size)
+    m = rama_amd.Model.synth(dev, to_rama_cfg(cfg), 5, rope=rope)
+    e = rama_amd.Engine(dev, m)
+    for rnd in range(2):
+        e.decode_begin(1 + rnd, 0, [7, 8, 9])
+        assert e.decode_stream_poll(0) == []                     # nothing produced yet (and the previous round's tokens are gone)
+        e.decode_steps(200)
+        got, polls = [], 0
+        while len(got) < 200:
+            got += e.decode_stream_poll(len(got), 64)
+            polls += 1
+            assert polls < 10_000_000
+        assert got == e.decode_tokens()
+        assert got[:3] == [7, 8, 9]
+    e.free(); m.free()
