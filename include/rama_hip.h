@@ -205,6 +205,9 @@ int  rama_decode_batch_begin(rama_ctx *ctx, const rama_config *cfg, const rama_w
                              const int32_t *positions_host, int n_seq, int max_steps);
 int  rama_decode_batch_steps(rama_ctx *ctx, int n_steps);
 int  rama_decode_batch_tokens(rama_ctx *ctx, int32_t *out_host, int max_per_seq, int *n_per_seq);
+/* tokens `from`.. that sequence `seq` of the chained batch has produced SO FAR, without touching the stream (a host-visible
+ * ring per sequence, as rama_decode_stream_poll): a server hands each request its tokens as they appear. */
+int  rama_decode_batch_stream_poll(rama_ctx *ctx, int seq, int from, int32_t *out_tokens_host, int max_tokens, int *n_ready);
 
 /* Layer-pipeline stage variants (no reference counterpart: the reference is single-device).
  * The token id is read from / written to DEVICE memory, so a stage boundary is one RCCL

@@ -125,6 +125,7 @@ extern "C" {
     pub fn rama_decode_sampler(ctx: *mut rama_ctx, temperature: f32, topp: f32, u: f32) -> c_int;
     pub fn rama_decode_steps(ctx: *mut rama_ctx, cfg: *const rama_config, w: *const rama_weights, s: *mut rama_run_state, n_steps: c_int) -> c_int;
     pub fn rama_decode_tokens(ctx: *mut rama_ctx, out_tokens_host: *mut i32, max_tokens: c_int, n_out: *mut c_int) -> c_int;
+    pub fn rama_decode_batch_stream_poll(ctx: *mut rama_ctx, seq: c_int, from: c_int, out_tokens_host: *mut i32, max_tokens: c_int, n_ready: *mut c_int) -> c_int;
     pub fn rama_decode_stream_poll(ctx: *mut rama_ctx, from: c_int, out_tokens_host: *mut i32, max_tokens: c_int, n_ready: *mut c_int) -> c_int;
     pub fn rama_generate_stream(ctx: *mut rama_ctx, cfg: *const rama_config, w: *const rama_weights, s: *mut rama_run_state,
                                 prompt_tokens_host: *const i32, n_prompt: c_int, steps: c_int, temperature: f32, topp: f32, u: f32,

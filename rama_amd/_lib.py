@@ -103,6 +103,7 @@ SIGNATURES = {
     "rama_decode_steps": (_int, [_vp, _cfgp, _wp, _sp, _int]),
     "rama_decode_tokens": (_int, [_vp, i32p, _int, C.POINTER(_int)]),
     "rama_decode_stream_poll": (_int, [_vp, _int, i32p, _int, C.POINTER(_int)]),
+    "rama_decode_batch_stream_poll": (_int, [_vp, _int, _int, i32p, _int, C.POINTER(_int)]),
     "rama_generate_stream": (_int, [_vp, _cfgp, _wp, _sp, i32p, _int, _int, C.c_float, C.c_float, C.c_float,
                                     C.CFUNCTYPE(None, C.c_void_p, _int, C.c_int32), C.c_void_p, i32p]),
     "rama_set_graph_mode": (_int, [_vp, _int]),

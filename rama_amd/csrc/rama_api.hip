@@ -151,6 +151,8 @@ struct rama_ctx {
         int* toks = nullptr;               // [kMfMaxTok] the token each sequence feeds next
         SeqSlot* seqs = nullptr;           // [kMfMaxTok] cache bases + position of every sequence
         int* out = nullptr;                // [kMfMaxTok, out_cap] the tokens produced
+        int* ring = nullptr;               // the same, host-pinned and device-mapped: token + 1, 0 = not produced yet (rama_decode_batch_stream_poll)
+        int* ring_dev = nullptr;
         rama_config cfg{}; rama_weights w{};
         hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; int graph_bucket = -1;
     } bc;
@@ -257,7 +259,7 @@ int rama_ctx_destroy(rama_ctx* c) {
     for (int i = 0; i < 2; i++) { hipFree(c->topp_keys[i]); hipFree(c->topp_vals[i]); }
     hipFree(c->topp_prefix); hipFree(c->topp_m); hipFree(c->topp_err); hipFree(c->pf_blob); hipFree(c->pc_blob); if (c->ring) hipHostFree(c->ring);
     hipFree(c->topp_bp); hipFree(c->topp_bi); hipFree(c->topp_bcount);
-    hipFree(c->bc.toks); hipFree(c->bc.seqs); hipFree(c->bc.out);
+    hipFree(c->bc.toks); hipFree(c->bc.seqs); hipFree(c->bc.out); if (c->bc.ring) hipHostFree(c->bc.ring);
     hipHostFree(c->pinned_int); hipHostFree(c->pinned_tok);
     hipEventDestroy(c->t0); hipEventDestroy(c->t1);
     if (c->own_stream) hipStreamDestroy(c->stream);
@@ -1725,7 +1727,7 @@ int rama_decode_batch(rama_ctx* c, const rama_config* cfg, const rama_weights* w
 // one argmax per sequence that writes the next token and advances the position, and a step is one hipGraph replay --
 // no per-sequence download, no host round trip per step (rama_decode_batch costs one call and n_seq 4-byte downloads
 // per step when the tokens are fed back through the host).
-struct BatchArgmaxParams { const float* logits; int n; int* toks; SeqSlot* seqs; int* out; int out_cap; };
+struct BatchArgmaxParams { const float* logits; int n; int* toks; SeqSlot* seqs; int* out; int out_cap; int* ring; };      // ring: host-visible copy of out, token + 1 (0: not yet)
 __global__ __launch_bounds__(1024) void argmax_batch_kernel(BatchArgmaxParams p) {
     // Device::sample at temperature 0 per sequence (cpu.rs:163-167: the LAST maximal index), then mod.rs:196-203:
     // token = next, pos += 1
@@ -1765,7 +1767,10 @@ __global__ __launch_bounds__(1024) void argmax_batch_kernel(BatchArgmaxParams p)
         p.toks[b] = idx;
         p.seqs[b].pos += 1;
         const int k = p.seqs[b].pad;                              // tokens this sequence has produced so far
-        if (k < p.out_cap) p.out[(size_t)b * p.out_cap + k] = idx;
+        if (k < p.out_cap) {
+            p.out[(size_t)b * p.out_cap + k] = idx;
+            if (p.ring) __hip_atomic_store(p.ring + (size_t)b * p.out_cap + k, idx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         p.seqs[b].pad = k + 1;
     }
 }
@@ -1797,9 +1802,13 @@ int rama_decode_batch_begin(rama_ctx* c, const rama_config* cfg, const rama_weig
     if (!bc.toks) { HIPCHK(hipMalloc(&bc.toks, sizeof(int) * kMfMaxTok)); HIPCHK(hipMalloc(&bc.seqs, sizeof(SeqSlot) * kMfMaxTok)); }
     if (bc.out_cap < max_steps) {
         hipFree(bc.out); bc.out = nullptr;
+        if (bc.ring) { hipHostFree(bc.ring); bc.ring = nullptr; }
         HIPCHK(hipMalloc(&bc.out, sizeof(int) * (size_t)kMfMaxTok * max_steps));
+        HIPCHK(hipHostMalloc(&bc.ring, sizeof(int) * (size_t)kMfMaxTok * max_steps, hipHostMallocMapped));
+        HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&bc.ring_dev), bc.ring, 0));
         bc.out_cap = max_steps;
     }
+    memset(bc.ring, 0, sizeof(int) * (size_t)kMfMaxTok * bc.out_cap);      // (the stream was drained above: nothing is on its way)
     SeqSlot* slots = reinterpret_cast<SeqSlot*>(c->pinned_tok + kMfMaxTok);
     for (int i = 0; i < n_seq; i++) {
         c->pinned_tok[i] = tokens_host[i];
@@ -1827,7 +1836,7 @@ int rama_decode_batch_steps(rama_ctx* c, int n_steps) {
     for (int i = 0; i < n_steps; i++) {
         // the score buffers are sized by the longest context: one graph per bucket of 256 timesteps
         const int tmax = bc.pos_max + 1, bucket = (tmax + 255) / 256;
-        BatchArgmaxParams ap{b.LG, cfg->vocab_size, bc.toks, bc.seqs, bc.out, bc.out_cap};
+        BatchArgmaxParams ap{b.LG, cfg->vocab_size, bc.toks, bc.seqs, bc.out, bc.out_cap, bc.ring_dev};
         if (!c->graph_mode) {
             rc = enqueue_batch_pass(c, cfg, &bc.w, b, bc.n_seq, bucket * 256); if (rc) return rc;
             hipLaunchKernelGGL(argmax_batch_kernel, dim3(bc.n_seq), dim3(1024), 0, c->stream, ap);
@@ -1860,6 +1869,22 @@ int rama_decode_batch_tokens(rama_ctx* c, int32_t* out_host, int max_per_seq, in
     for (int s_ = 0; s_ < bc.n_seq && n > 0; s_++)
         HIPCHK(hipMemcpy(out_host + (size_t)s_ * max_per_seq, bc.out + (size_t)s_ * bc.out_cap, sizeof(int) * n, hipMemcpyDeviceToHost));
     *n_per_seq = n;
+    return 0;
+}
+
+// tokens `from`.. sequence `seq` of the chained batch has produced so far, without touching the stream (the host-visible
+// ring of rama_decode_stream_poll, one row per sequence): a server hands each request its tokens as they appear
+int rama_decode_batch_stream_poll(rama_ctx* c, int seq, int from, int32_t* out_host, int max_tokens, int* n_ready) {
+    REQUIRE(c && n_ready && c->bc.n_seq > 0 && c->bc.ring && seq >= 0 && seq < c->bc.n_seq && from >= 0 && max_tokens >= 0 && (max_tokens == 0 || out_host),
+            RAMA_EINVAL, "decode_batch_stream_poll: bad argument");
+    const int* row = c->bc.ring + (size_t)seq * c->bc.out_cap;
+    int n = 0;
+    while (n < max_tokens && from + n < c->bc.out_cap) {
+        const int v = __atomic_load_n(row + from + n, __ATOMIC_ACQUIRE);
+        if (v == 0) break;
+        out_host[n++] = v - 1;
+    }
+    *n_ready = n;
     return 0;
 }
 

@@ -202,9 +202,11 @@ def decode_batch(engines: Sequence["Engine"], tokens: Sequence[int], positions: 
                                           states, toks, poss, len(engines)), "rama_decode_batch")
 
 
-def decode_batch_chained(engines: Sequence["Engine"], tokens: Sequence[int], positions: Sequence[int], n_steps: int):
-    """n_steps greedy decode steps of up to 64 independent sequences chained on the device (rama_decode_batch_begin /
-    _steps / _tokens): -> per sequence the n_steps tokens it produced.  engines[i]'s caches are advanced."""
+def decode_batch_chained(engines: Sequence["Engine"], tokens: Sequence[int], positions: Sequence[int], n_steps: int, on_token=None):
+    """n_steps greedy decode steps of up to 128 independent sequences chained on the device (rama_decode_batch_begin /
+    _steps / _tokens): -> per sequence the n_steps tokens it produced.  engines[i]'s caches are advanced.
+    on_token(sequence, index, token), when given, is called for every token as it appears in the host-visible rings
+    (rama_decode_batch_stream_poll) while the steps run."""
     assert 1 <= len(engines) == len(tokens) == len(positions) <= 128
     e0 = engines[0]
     L = e0.device.lib
@@ -214,6 +216,16 @@ def decode_batch_chained(engines: Sequence["Engine"], tokens: Sequence[int], pos
     check(L.rama_decode_batch_begin(e0.device.ctx, C.byref(e0.model.ccfg), C.byref(e0.model.weights), states, toks, poss,
                                     len(engines), max(n_steps, 1)), "rama_decode_batch_begin")
     check(L.rama_decode_batch_steps(e0.device.ctx, n_steps), "rama_decode_batch_steps")
+    if on_token is not None:
+        seen = [0] * len(engines)
+        buf = (C.c_int32 * 64)()
+        k = C.c_int()
+        while min(seen) < n_steps:
+            for s_ in range(len(engines)):
+                check(L.rama_decode_batch_stream_poll(e0.device.ctx, s_, seen[s_], buf, 64, C.byref(k)), "rama_decode_batch_stream_poll")
+                for i in range(k.value):
+                    on_token(s_, seen[s_] + i, int(buf[i]))
+                seen[s_] += k.value
     out = (C.c_int32 * (len(engines) * max(n_steps, 1)))()
     n = C.c_int()
     check(L.rama_decode_batch_tokens(e0.device.ctx, out, max(n_steps, 1), C.byref(n)), "rama_decode_batch_tokens")

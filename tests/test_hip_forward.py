@@ -1122,6 +1122,26 @@ def test_generate_stream_hands_over_every_token_in_order(dev, temperature, promp
     a.free(); b.free(); m.free()
 
 
+def test_decode_batch_stream_poll_per_sequence(dev):
+    """the chained batch writes each sequence's tokens to a host-visible ring of its own: polled while the steps run,
+    every sequence's stream is, in order, what rama_decode_batch_tokens returns at the end"""
+    import rama_amd
+    cfg = O.Config(128, 352, 2, 4, 4, 256, 64, True)
+    rope = S.rope_tables(cfg.seq_len, cfg.head_size)
+    m = rama_amd.Model.synth(dev, to_rama_cfg(cfg), 4, rope=rope)
+    n_seq, steps = 5, 40
+    batch = [rama_amd.Engine(dev, m) for _ in range(n_seq)]
+    for rnd in range(2):                          # the second round re-uses (and must have cleared) the rings
+        seen = [[] for _ in range(n_seq)]
+        got = rama_amd.decode_batch_chained(batch, [3 + rnd + i for i in range(n_seq)], [0] * n_seq, steps,
+                                            on_token=lambda s_, i, t: seen[s_].append((i, t)))
+        for s_ in range(n_seq):
+            assert [i for i, _ in seen[s_]] == list(range(steps))
+            assert [t for _, t in seen[s_]] == got[s_]
+    for e in batch: e.free()
+    m.free()
+
+
 def test_decode_stream_poll_sees_the_loop_progress(dev):
     """rama_decode_stream_poll never blocks: polled while rama_decode_steps' launches are still running it returns the
     tokens produced so far (possibly none), and in the end exactly rama_decode_tokens' list; a new rama_decode_begin
