@@ -247,7 +247,7 @@ class NativeStage:
         self.dev.close()
 
 
-def _bench_line(args, cfg, world, n_seq, tok_s, dt, roofline, path, hipgraph, rccl_ranks=None):
+def _bench_line(args, cfg, world, n_seq, tok_s, dt, roofline, path, hipgraph, rccl_ranks=None, mode="fast"):
     import rama_amd
     from bench import HBM_PEAK_GBPS
     bytes_ = rama_amd.algorithmic_bytes(cfg)
@@ -258,7 +258,8 @@ def _bench_line(args, cfg, world, n_seq, tok_s, dt, roofline, path, hipgraph, rc
         "ms_per_step": round(dt * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.config} fp32 decode, layer pipeline over {world} GPUs, {n_seq} sequences in flight, greedy",
-                   "mode": "fast: fused multiply-adds, tree-shaped sums (the pipeline stages run the default kernels)",
+                   "mode": ("parity: every op of every stage in the reference CPU path's rounding order (chain-order weight copies), as the N = 1 line"
+                            if mode == "parity" else "fast: fused multiply-adds, tree-shaped sums (the pipeline stages run the default kernels)"),
                    "dim": cfg.dim, "hidden_dim": cfg.hidden_dim, "n_layers": cfg.n_layers, "n_heads": cfg.n_heads,
                    "vocab_size": cfg.vocab_size, "seq_len": cfg.seq_len, "sequences_in_flight": n_seq,
                    "parallelism": f"pp{world} (RCCL send/recv of x[dim] and the token id; {path})", "hipgraph": bool(hipgraph)},
@@ -270,7 +271,7 @@ def _bench_line(args, cfg, world, n_seq, tok_s, dt, roofline, path, hipgraph, rc
     }
 
 
-def _stage_roofline(check, lib, ctx, compute, n_local, cfg):
+def _stage_roofline(check, lib, ctx, compute, n_local, cfg, mode="fast"):
     """dominant kernel (W1|W3 SwiGLU matvec) of this rank's stage, event-bracketed per launch; traffic from
     the committed PMC pass of the same kernel (bench.pmc_traffic)"""
     import rama_amd
@@ -286,8 +287,9 @@ def _stage_roofline(check, lib, ctx, compute, n_local, cfg):
         return None
     avg_ms = tot.value / n.value
     a = bytes_["w13"] / (avg_ms * 1e-3) / 1e9
-    traffic, src = pmc_traffic("gemv_rows<4, 2, 8, true, 5>") if cfg.dim == 4096 else (None, None)
-    return {"bound": "hbm", "kernel": "rmsnorm + W1|W3 matvec + SiLU*gate, rank 0's stage",
+    traffic, src = pmc_traffic("gemv_chain_kernel<1, 16, 4, 3>" if mode == "parity" else "gemv_rows<4, 2, 8, true, 5>") if cfg.dim == 4096 else (None, None)
+    return {"bound": "hbm", "kernel": ("chain-order W1|W3 matvec in the reference's rounding order + SiLU*gate" if mode == "parity"
+                                       else "rmsnorm + W1|W3 matvec + SiLU*gate") + ", rank 0's stage",
             "achieved": round(a, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBPS, 4),
             "traffic": traffic, "traffic_source": src,
             "algorithmic_bytes_per_launch": bytes_["w13"], "avg_launch_us": round(avg_ms * 1e3, 2)}
@@ -327,22 +329,32 @@ def run_pipeline_bench_native(args, cfg, rank: int, world: int, local_rank: int)
     n_seq = world
     n_pos = args.warmup + args.steps
     st = NativeStage(cfg, rank, world, local_rank, n_seq, box[0], seed=0)
-    plan = st.plan(n_pos, PROMPT, wrap=cfg.seq_len)
-    total = st.total_ticks(plan)
+    # the headline mode is the N = 1 line's: parity (every stage in the reference's rounding order) unless --mode fast;
+    # with --mode both the fast mode is timed too and reported beside it
+    want = getattr(args, "mode", "both")
+    modes = ["parity", "fast"] if want == "both" else [want]
     t_warm, t_end = args.warmup * n_seq, (args.warmup + args.steps) * n_seq
-    st.run_ticks(plan, 0, t_warm)
-    st.dev.sync(); torch.cuda.synchronize()
-    dist.barrier()
-    t0 = time.perf_counter()
-    st.run_ticks(plan, t_warm, t_end)
-    st.dev.sync(); torch.cuda.synchronize()
-    dist.barrier()
-    dt = time.perf_counter() - t0
-    st.run_ticks(plan, t_end, total)      # drain, untimed
-    st.dev.sync()
-    tmax = torch.tensor([dt], dtype=torch.float64)
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    timed = {}
+    for mode in modes:
+        st.check(st.dev.lib.rama_set_tuning(st.dev.ctx, b"ref_order", 1 if mode == "parity" else 0), "rama_set_tuning")
+        plan = st.plan(n_pos, PROMPT, wrap=cfg.seq_len)
+        total = st.total_ticks(plan)
+        st.run_ticks(plan, 0, t_warm)
+        st.dev.sync(); torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        st.run_ticks(plan, t_warm, t_end)
+        st.dev.sync(); torch.cuda.synchronize()
+        dist.barrier()
+        dt = time.perf_counter() - t0
+        st.run_ticks(plan, t_end, total)      # drain, untimed
+        st.dev.sync()
+        tmax = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        timed[mode] = float(tmax.item())
+    head = modes[0]
+    dt = timed[head]
+    st.check(st.dev.lib.rama_set_tuning(st.dev.ctx, b"ref_order", 1 if head == "parity" else 0), "rama_set_tuning")
     roofline = None
     n_local = st.stage.layer_end - st.stage.layer_begin
     if n_local > 0 and not args.no_kprof:
@@ -354,14 +366,17 @@ def run_pipeline_bench_native(args, cfg, rank: int, world: int, local_rank: int)
                 st.check(L.rama_forward_stage(st.dev.ctx, C.byref(st.model.ccfg), C.byref(st.model.weights), C.byref(st.states[0]), BOS, 5, C.byref(st.stage)))
             else:
                 st.check(L.rama_forward_stage_devtok(st.dev.ctx, C.byref(st.model.ccfg), C.byref(st.model.weights), C.byref(st.states[0]), None, 5, C.byref(st.stage)))
-        roofline = _stage_roofline(st.check, L, st.dev.ctx, one, n_local, cfg)
+        roofline = _stage_roofline(st.check, L, st.dev.ctx, one, n_local, cfg, head)
     nr, rk = C.c_int(), C.c_int()
     st.check(st.dev.lib.rama_pipe_comm_info(st.pipe, C.byref(nr), C.byref(rk)), "rama_pipe_comm_info")
     assert nr.value == world and rk.value == rank, (nr.value, rk.value, world, rank)
     graphs = not os.environ.get("RAMA_PIPE_EAGER")
     line = _bench_line(args, cfg, world, n_seq, args.steps * n_seq / dt, dt, roofline,
                        "native: csrc/pipe.hip, tick loop in C++, one hipGraph per (sequence, stage)" if graphs else "native: csrc/pipe.hip, tick loop in C++, eager launches",
-                       graphs, rccl_ranks=nr.value)
+                       graphs, rccl_ranks=nr.value, mode=head)
+    for m_ in modes:
+        line[m_ + "_mode"] = {"tok_s": round(args.steps * n_seq / timed[m_], 3), "ms_per_step": round(timed[m_] * 1e3 / args.steps, 4)}
+    st.check(st.dev.lib.rama_set_tuning(st.dev.ctx, b"ref_order", 0), "rama_set_tuning")
     st.free()
     dist.barrier()
     dist.destroy_process_group()

@@ -53,13 +53,16 @@ def test_exchange_with_self(dev, pipe):
         check(dev.lib.rama_pipe_exchange(pipe, sx.ptr, 4096, 1, None, 0, 0, None, 0, None, 0))      # peer outside the communicator
 
 
-@pytest.mark.parametrize("n_seq,temperature,graph", [(1, 0.0, 0), (3, 0.0, 0), (2, 1.0, 0), (3, 0.0, 1), (2, 1.0, 1)])
-def test_native_tick_loop_equals_generate(dev, pipe, n_seq, temperature, graph):
+@pytest.mark.parametrize("n_seq,temperature,graph,parity", [(1, 0.0, 0, 0), (3, 0.0, 0, 0), (2, 1.0, 0, 0), (3, 0.0, 1, 0), (2, 1.0, 1, 0),
+                                                            (2, 0.0, 0, 1), (3, 0.0, 1, 1)])
+def test_native_tick_loop_equals_generate(dev, pipe, n_seq, temperature, graph, parity):
     """rama_pipe_run_ticks on a one-rank pipe = generate() (mod.rs:169-206) for every sequence in flight:
     BOS, the forced prompt tokens, then the sampled ones; the history lands in out_tokens_dev.
-    graph = 1: the stage passes are replayed from hipGraphs (one per sequence state)"""
+    graph = 1: the stage passes are replayed from hipGraphs (one per sequence state); parity = 1: the stage passes run
+    in the reference's rounding order (the mode of bench.py's headline, also for --gpus N)"""
     import rama_amd
     from rama_amd._lib import check, rama_pipe_plan, rama_run_state, rama_stage
+    check(dev.lib.rama_set_tuning(dev.ctx, b"ref_order", parity))
     cfg, w, g = load_case("synth_d288_h6")
     prompt = g["tokens"].tolist()[1:4]
     n_pos = 24
@@ -91,6 +94,7 @@ def test_native_tick_loop_equals_generate(dev, pipe, n_seq, temperature, graph):
     check(dev.lib.rama_pipe_run_ticks(pipe, C.byref(model.ccfg), C.byref(model.weights), states, tok_ptrs, C.byref(stage),
                                       C.byref(plan), total // 2, total), "rama_pipe_run_ticks")
     dev.lib.rama_set_graph_mode(dev.ctx, 0)
+    check(dev.lib.rama_set_tuning(dev.ctx, b"ref_order", 0))
     hist = dev.download(out).view(np.int32).reshape(n_seq, n_pos)
     for s in range(n_seq):
         assert hist[s].tolist() == want, (s, hist[s].tolist(), want)
@@ -99,12 +103,14 @@ def test_native_tick_loop_equals_generate(dev, pipe, n_seq, temperature, graph):
     model.free()
 
 
-@pytest.mark.parametrize("name", ["ckpt_tied", "ckpt_untied"])
-def test_load_stage_two_stages_on_one_gpu(dev, name):
+@pytest.mark.parametrize("name,parity", [("ckpt_tied", 0), ("ckpt_untied", 0), ("ckpt_untied", 1)])
+def test_load_stage_two_stages_on_one_gpu(dev, name, parity):
     """rama_model_load_stage: the checkpoint split into two stages (each holds only its tensors) gives
-    the whole model's logits when x is handed from stage 0 to stage 1"""
+    the whole model's logits when x is handed from stage 0 to stage 1 (parity = 1: bit for bit, each stage
+    streaming the chain-order copy of its own layers)"""
     import rama_amd
     from rama_amd._lib import check, rama_config, rama_stage
+    check(dev.lib.rama_set_tuning(dev.ctx, b"ref_order", parity))
     cfg, w, g = load_case(name)
     path = str(GOLDEN / f"{name}.bin").encode()
     mid = cfg.n_layers // 2
@@ -125,6 +131,9 @@ def test_load_stage_two_stages_on_one_gpu(dev, name):
         engines[1].set_buffer("x", engines[0].buffer("x", cfg.dim))
         engines[1].forward(t, pos)
         assert np.abs(engines[1].logits() - lo).max() <= 1e-4
+        if parity:
+            assert np.array_equal(engines[1].logits().view(np.uint32), lo.view(np.uint32))
+    check(dev.lib.rama_set_tuning(dev.ctx, b"ref_order", 0))
     for e in engines:
         e.free()
     for m in models + [whole]:
