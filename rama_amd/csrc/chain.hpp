@@ -849,6 +849,14 @@ __global__ __launch_bounds__(kGcThreads) void gemm_chain_kernel(GemmChainParams 
                     acc2[tp] = v;
                 }
             }
+            // the sums are pinned HERE: left alone, hipcc sinks a whole chunk's adds behind the barrier that ends the chunk
+            // (the loop body has exec-masked blocks from the guarded loads) -- 128 products wait in registers and the
+            // adds run as one dependent burst at the top of the next step
+            if constexpr (TPW == 1) asm volatile("" : "+v"(acc1));
+            else {
+#pragma unroll
+                for (int tp = 0; tp < TPW / 2; tp++) asm volatile("" : "+v"(acc2[tp]));
+            }
         };
         fetch(0, w0, xa);
 #pragma unroll
