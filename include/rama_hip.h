@@ -178,7 +178,7 @@ int  rama_forward_stage(rama_ctx *ctx, const rama_config *cfg, const rama_weight
  * dense fp32 GEMMs on the matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, csrc/prefill_mfma.hpp).
  * dim or hidden_dim not a multiple of 16: falls back to one rama_forward per token.
  * Parity mode ("ref_order" = 1) on a resident model: the positions go through token-batch kernels in the reference's
- * rounding order, 16 per weight pass, the last one through rama_forward -- cache rows, logits and run state are
+ * rounding order, 32 per weight pass, the last one through rama_forward -- cache rows, logits and run state are
  * bit for bit those of one rama_forward per position ("prefill_chain" = 0 gives exactly that loop). */
 int  rama_prefill(rama_ctx *ctx, const rama_config *cfg, const rama_weights *w, rama_run_state *s,
                   const int32_t *tokens_host, int n_tokens, int pos0);
@@ -189,7 +189,7 @@ int  rama_prefill(rama_ctx *ctx, const rama_config *cfg, const rama_weights *w, 
  * prefill).  states[i] is sequence i's run state; afterwards it holds what
  * rama_forward(token_i, pos_i) would have left in it: the appended cache rows and the logits
  * (x / xb / q ... scratch is not maintained).  Sequences may sit at different positions; two entries
- * must not share a state.  Parity mode ("ref_order" = 1) on a resident model: 16 sequences per weight pass through the
+ * must not share a state.  Parity mode ("ref_order" = 1) on a resident model: 32 sequences per weight pass through the
  * chain-order token-batch kernels, every sequence's logits and cache rows bit for bit those of its own rama_forward. */
 int  rama_decode_batch(rama_ctx *ctx, const rama_config *cfg, const rama_weights *w,
                        const rama_run_state *states, const int32_t *tokens_host,

@@ -720,7 +720,7 @@ __global__ __launch_bounds__(W * 64) void gemv_chain_kernel(ChainParams p) {
 }
 
 // ---------------------------------------------------------------- token batches in the reference's order (parity-mode prefill)
-// O[t][r] = the chain-order product of row r with activation vector t, for T = 4 TPW tokens at once: the same
+// O[t][r] = the chain-order product of row r with activation vector t, for T = 4 TPW tokens at once (TPW = 1, 2, 4, 8): the same
 // per-output sequence of roundings as gemv_chain_kernel (k ascending in each of the four lane chains k = j mod 4, separate
 // multiply and add, (v0 + v1) + (v2 + v3)), with every weight read ONCE for the T tokens.
 //   A workgroup of 4 waves owns 16 rows; wave w carries the sums of tokens w TPW .. w TPW + TPW - 1, lane = (chain j =
@@ -729,10 +729,9 @@ __global__ __launch_bounds__(W * 64) void gemv_chain_kernel(ChainParams p) {
 //   HBM / L2 -> registers -> LDS, two chunks in flight in registers, two LDS slots, ONE barrier per chunk and no branch
 //   in the loop; from LDS a lane reads a block's weights (16 bytes) and ONE activation per token; the multiplies take
 //   the activation of step i from lane i of the 16-lane row through DPP.
-//   Measured at llama2-7B, 16 positions per pass (rocprofv3): QKV 65 us, Wo / W2 50 (mean), W1|W3 121 per layer; the first
-//   version -- every lane reading its four activations, 16-block chunks -- 76 / 56 / 141.  What it is bound by is the
-//   latency of the dependent adds (two independent chains per wave, two waves per SIMD at 184 registers), not HBM
-//   (2.9 TB/s) and not the instruction count.
+//   Measured at llama2-7B, 32 positions per pass (8 per wave; rocprofv3): QKV 111 us, Wo / W2 93 (mean), W1|W3 204 per
+//   layer.  Bound by the latency of the dependent adds (four independent pair-chains per wave), not by HBM (3.5 TB/s)
+//   and not by the instruction count.
 //   Blocks behind the end of a row: weights dropped by the descriptor's range check, activations stored as zeros: + (0 * 0).
 struct GemmChainParams {
     const float* w[3];      // chain-order matrices (nmat <= 3), each [ceil(rows / 16) * 16, K]

@@ -128,7 +128,7 @@ struct rama_ctx {
     float* pf_blob = nullptr;              // token-batch scratch (tile layout): see BatchScratch
     float* pc_blob = nullptr;              // parity-mode prefill scratch (row-major token batches): see prefill_chain
     size_t pc_floats = 0;
-    int tune_prefill_chain = 1;            // parity mode: prompt positions go through the chain-order token-batch kernels (16 per weight pass); 0: one forward() each
+    int tune_prefill_chain = 1;            // parity mode: prompt positions go through the chain-order token-batch kernels (32 per weight pass); 0: one forward() each
     size_t pf_floats = 0;
     int host_pos = -1;                     // position of the next chained decode step (mirrors the device cursor)
     bool split_attn = false;               // variant the steps being enqueued / captured use
@@ -227,7 +227,7 @@ int rama_ctx_create(int device, void* hip_stream, rama_ctx** out) {
     HIPCHK(hipFuncSetAttribute((const void*)gemm_chain_kernel<TPW_, CEPI_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_chain_lds_bytes(TPW_))); \
     HIPCHK(hipFuncSetAttribute((const void*)gemm_chain_kernel<TPW_, CEPI_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_chain_lds_bytes(TPW_))); \
     HIPCHK(hipFuncSetAttribute((const void*)gemm_chain_kernel<TPW_, CEPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_chain_lds_bytes(TPW_)));
-    RAMA_GC_ATTR(1) RAMA_GC_ATTR(2) RAMA_GC_ATTR(4)
+    RAMA_GC_ATTR(1) RAMA_GC_ATTR(2) RAMA_GC_ATTR(4) RAMA_GC_ATTR(8)
 #undef RAMA_GC_ATTR
     *out = c;
     return 0;
@@ -1435,7 +1435,7 @@ static int run_layers_batched(rama_ctx* c, const rama_config* cfg, const rama_we
     return 0;
 }
 
-// ---- parity mode: the forced prompt positions in the reference's rounding order, 16 per weight pass (chain.hpp
+// ---- parity mode: the forced prompt positions in the reference's rounding order, 32 per weight pass (chain.hpp
 // gemm_chain_kernel).  Every position's cache rows are what its own forward() writes, bit for bit: the same chains per
 // output, the same exact sums in the norms and the softmax, the same attention per (head, position).  The LAST position
 // then goes through forward() itself, which leaves the run state (x, xb, q, .., logits) exactly as the reference's loop
@@ -1445,11 +1445,12 @@ static int launch_gemm_chain(rama_ctx* c, GemmChainParams& p) {
     const dim3 grid(p.nmat * ((p.rows + 15) / 16)), block(kGcThreads);
     if (p.n_tok <= 4) hipLaunchKernelGGL((gemm_chain_kernel<1, EPI>), grid, block, gemm_chain_lds_bytes(1), c->stream, p);
     else if (p.n_tok <= 8) hipLaunchKernelGGL((gemm_chain_kernel<2, EPI>), grid, block, gemm_chain_lds_bytes(2), c->stream, p);
-    else hipLaunchKernelGGL((gemm_chain_kernel<4, EPI>), grid, block, gemm_chain_lds_bytes(4), c->stream, p);      // (8 per wave, 32 per pass: 256 registers, measured 6 % slower)
+    else if (p.n_tok <= 16) hipLaunchKernelGGL((gemm_chain_kernel<4, EPI>), grid, block, gemm_chain_lds_bytes(4), c->stream, p);
+    else hipLaunchKernelGGL((gemm_chain_kernel<8, EPI>), grid, block, gemm_chain_lds_bytes(8), c->stream, p);
     LAUNCHCHK();
     return 0;
 }
-constexpr int kGcMaxTok = 4 * kGcWaves;
+constexpr int kGcMaxTok = 8 * kGcWaves;
 
 // the layers of one pass of nt <= 16 tokens whose residual rows sit in b.X: consecutive positions p0.. of one sequence
 // (key_cache / value_cache its cache bases), or -- seqs != NULL -- token t of independent sequence t (device table)
@@ -1565,7 +1566,7 @@ static int prefill_chain(rama_ctx* c, const rama_config* cfg, const rama_weights
     return rama_forward(c, cfg, w, s, tokens_host[n_tokens - 1], pos0 + n_tokens - 1);
 }
 
-// rama_decode_batch in parity mode: the sequences share every weight pass, 16 at a time, through the same kernels; each
+// rama_decode_batch in parity mode: the sequences share every weight pass, 32 at a time, through the same kernels; each
 // sequence's appended cache rows and its logits are bit for bit those of its own forward().  (x / xb / q .. of the states
 // are not maintained -- the call's contract, see the header.)
 static int decode_batch_chain(rama_ctx* c, const rama_config* cfg, const rama_weights* w, const rama_run_state* states,

@@ -13,7 +13,7 @@ from bench import SHAPES
 name = sys.argv[1] if len(sys.argv) > 1 else "llama2-7B"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 48
 d, h, L, H, V, seq, shared = SHAPES[name]
-parity = len(sys.argv) > 4 and sys.argv[4] == "parity"      # parity mode: chain-order token-batch kernels, 16 sequences per weight pass
+parity = len(sys.argv) > 4 and sys.argv[4] == "parity"      # parity mode: chain-order token-batch kernels, 32 sequences per weight pass
 if len(sys.argv) > 3: seq = int(sys.argv[3])      # a shorter context: 128 sequences x 2 048 positions of KV cache would not fit beside the model
 cfg = rama_amd.Config(d, h, L, H, H, V, seq, shared)
 dev = rama_amd.Hip(0)

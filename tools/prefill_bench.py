@@ -16,7 +16,7 @@ from bench import SHAPES
 lengths = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [64]
 shape = sys.argv[2] if len(sys.argv) > 2 else "llama2-7B"
 per_pass = int(sys.argv[3]) if len(sys.argv) > 3 else 128
-parity = len(sys.argv) > 4 and sys.argv[4] == "parity"      # parity mode: the chain-order token-batch kernels, 16 positions per pass
+parity = len(sys.argv) > 4 and sys.argv[4] == "parity"      # parity mode: the chain-order token-batch kernels, 32 positions per pass
 d, h, L, H, V, seq, shared = SHAPES[shape]
 cfg = rama_amd.Config(d, h, L, H, H, V, seq, shared)
 dev = rama_amd.Hip(0)
@@ -41,6 +41,6 @@ for n in lengths:
     for i, t in enumerate(toks): b.forward(t, i)
     dev.sync(); t_seq = time.perf_counter() - t0
     diff = float(np.abs(a.logits() - b.logits()).max())
-    print(json.dumps({"shape": shape, "positions": n, "per_pass": 16 if parity else per_pass, "mode": "parity" if parity else "fast", "prefill_ms": round(best * 1e3, 2), "sequential_ms": round(t_seq * 1e3, 2),
+    print(json.dumps({"shape": shape, "positions": n, "per_pass": 32 if parity else per_pass, "mode": "parity" if parity else "fast", "prefill_ms": round(best * 1e3, 2), "sequential_ms": round(t_seq * 1e3, 2),
                       "prefill_tok_s": round(n / best, 1), "sequential_tok_s": round(n / t_seq, 1), "speedup": round(t_seq / best, 2),
                       "max_abs_logit_diff_last_position": diff}), flush=True)
