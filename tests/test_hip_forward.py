@@ -1163,3 +1163,18 @@ def test_decode_stream_poll_sees_the_loop_progress(dev):
         assert got == e.decode_tokens()
         assert got[:3] == [7, 8, 9]
     e.free(); m.free()
+
+
+@pytest.mark.parametrize("steps,prompt", [(0, [4, 5]), (1, []), (2, [4, 5, 6]), (3, [4, 5, 6]), (4, [4, 5, 6]), (5, [4, 5, 6])])
+def test_generate_stream_edge_lengths(dev, steps, prompt):
+    """generations shorter than, equal to and just beyond the prompt: the stream hands over exactly rama_generate's list"""
+    import rama_amd
+    cfg = O.Config(64, 176, 2, 4, 4, 96, 16, True)
+    rope = S.rope_tables(cfg.seq_len, cfg.head_size)
+    m = rama_amd.Model.synth(dev, to_rama_cfg(cfg), 3, rope=rope)
+    a, b = rama_amd.Engine(dev, m), rama_amd.Engine(dev, m)
+    want = a.generate(prompt, steps) if steps else []
+    seen = []
+    got = b.generate_stream(prompt, steps, lambda i, t: seen.append((i, t)))
+    assert got == want and [t for _, t in seen] == want and [i for i, _ in seen] == list(range(steps))
+    a.free(); b.free(); m.free()
