@@ -321,6 +321,8 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *                   one chunk each per step (+1.15 % more); 3 = 16 waves x 4 chunks
  *   "prefill" = 0|1 : 1 (default) lets rama_generate_greedy push the forced prompt positions through
  *                   rama_prefill (up to 128 positions per weight pass) instead of one forward per token
+ *   "chain_norm" = 0|1 : parity mode, dim <= 512: the two rmsnorms of a layer folded into the chain-order matvecs that
+ *                   consume them (every workgroup forms the exact sum itself; default 1: +6.6 % at the stories15M shape)
  *   "prefill_chain" = 0|1 : parity mode's rama_prefill through the chain-order token-batch kernels (default 1)
  *   "prefill_tok" = 64|128 : positions per weight pass of rama_prefill (default 128; 64 = round 2's kernels)
  *   "merge" = -1|0|1 : 1 runs attention and the Wo matvec as one launch when the occupancy API says

@@ -501,6 +501,7 @@ struct ChainParams {
     const float* w[3];     // chain-order matrices (nmat <= 3), each [ceil(rows/16)*16, K]
     float* o[3];           // STORE: o[0]; RESID: o[0] = the product (xb2 / xb); QKV: q, k, v; SWIGLU: o[0] = hb, o[1] = hb2
     const float* x;        // [K] activations, row-major
+    const float* nw;       // NORM: rmsnorm gain [K]; x is then the residual stream and the kernel normalises it itself
     float* resid;          // RESID: resid[r] += product (infer.rs:37,47)
     int K, rows, nmat;     // SWIGLU: rows = 2 * hidden (interleaved W1 | W3)
     const Ctl* ctl; int pos_val;
@@ -535,7 +536,10 @@ __device__ unsigned long long g_chain_stamps[64];
 #else
 #define CHAIN_STAMP(id) do { } while (0)
 #endif
-template <int W, int D, int XD, int EPI>
+// NORM (narrow models, K <= 1024): cpu.rs:99-117's rmsnorm folded in -- every workgroup forms the exact sequential sum of
+// squares itself (wave 0 ripples through the list, 0.3 us per 64 elements: shorter than the launch it replaces up to ~1024)
+// and stages w * (v * x); the 7B kernels are the NORM = false instantiations, unchanged.
+template <int W, int D, int XD, int EPI, bool NORM = false>
 __global__ __launch_bounds__(W * 64) void gemv_chain_kernel(ChainParams p) {
     RAMA_NO_CONTRACT
     CHAIN_STAMP(0);
@@ -573,6 +577,12 @@ __global__ __launch_bounds__(W * 64) void gemv_chain_kernel(ChainParams p) {
     f4 xa[XU];
 #pragma unroll
     for (int u = 0; u < XU; u++) xa[u] = ld_c(rx, ((int)threadIdx.x + T * u) < n4 ? (unsigned)((int)threadIdx.x + T * u) * 16u : kOOB);
+    f4 ga[NORM ? XU : 1];
+    if constexpr (NORM) {
+        const __amdgpu_buffer_rsrc_t rg = make_rsrc_uniform(p.nw, (unsigned)p.K * 4u);
+#pragma unroll
+        for (int u = 0; u < XU; u++) ga[u] = ld_c(rg, ((int)threadIdx.x + T * u) < n4 ? (unsigned)((int)threadIdx.x + T * u) * 16u : kOOB);
+    }
     f4 wr[D];
 #pragma unroll
     for (int h = 0; h < D / 16; h++) {
@@ -595,6 +605,26 @@ __global__ __launch_bounds__(W * 64) void gemv_chain_kernel(ChainParams p) {
         }
     }
     CHAIN_STAMP(1);
+    if constexpr (NORM) {     // x <- w * (v * x), v = 1 / sqrt(sum(x^2) / K + 1e-5) with the sum in index order (host: K <= 64 T floats, all of x is in xa)
+        __shared__ PredShared<W> nps;
+        float* sq = xs + p.K + chain_pad_floats(W, D, XD);       // squares, scan_slot layout
+#pragma unroll
+        for (int u = 0; u < XU; u++) {
+            const int i = (int)threadIdx.x + T * u;
+            if (i < n4) {
+                float* d = sq + scan_slot(4 * i);                 // 4 i .. 4 i + 3 share a 32-element stretch of slots
+                d[0] = xa[u].x * xa[u].x; d[1] = xa[u].y * xa[u].y; d[2] = xa[u].z * xa[u].z; d[3] = xa[u].w * xa[u].w;
+            }
+        }
+        __syncthreads();
+        const float ss = seq_sum_ripples<W>(sq, p.K, nps);
+        const float v = 1.0f / sqrtf(ss / (float)p.K + 1e-5f);
+#pragma unroll
+        for (int u = 0; u < XU; u++) {
+            xa[u].x = ga[u].x * (v * xa[u].x); xa[u].y = ga[u].y * (v * xa[u].y);
+            xa[u].z = ga[u].z * (v * xa[u].z); xa[u].w = ga[u].w * (v * xa[u].w);
+        }
+    }
     // activations -> LDS in chain order: xs[16 s + 4 j + t] = x[16 s + 4 t + j]
     {
 #pragma unroll

@@ -128,6 +128,7 @@ struct rama_ctx {
     float* pf_blob = nullptr;              // token-batch scratch (tile layout): see BatchScratch
     float* pc_blob = nullptr;              // parity-mode prefill scratch (row-major token batches): see prefill_chain
     size_t pc_floats = 0;
+    int tune_chain_norm = 1;               // parity mode, dim <= 512: the layer norms folded into the matvecs that consume them
     int tune_prefill_chain = 1;            // parity mode: prompt positions go through the chain-order token-batch kernels (32 per weight pass); 0: one forward() each
     size_t pf_floats = 0;
     int host_pos = -1;                     // position of the next chained decode step (mirrors the device cursor)
@@ -466,6 +467,15 @@ static int launch_chain(rama_ctx* c, ChainParams& p) {
     const size_t lds = (size_t)(p.K + chain_pad_floats(W, D, 4)) * sizeof(float);      // x + the zeros behind it
     REQUIRE(lds <= 64 * 1024, RAMA_EUNSUP, "chain-order matvec: row longer than ~15800 floats");
     const dim3 grid(groups);
+    if (p.nw) {      // the rmsnorm folded in (narrow models): the geometries such rows get, plus room for the squares
+        REQUIRE(p.K <= 1024 && D == 16 && (W == 1 || W == 2) && (EPI == CEPI_QKV || EPI == CEPI_SWIGLU), RAMA_EUNSUP, "chain-order matvec: no norm-folding instantiation for this shape");
+        const size_t ldsn = lds + ((size_t)p.K + ((size_t)p.K >> 5) + 4) * sizeof(float);
+        constexpr int E = (EPI == CEPI_QKV || EPI == CEPI_SWIGLU) ? EPI : CEPI_QKV;
+        if (W == 1) RAMA_LAUNCH(c, (gemv_chain_kernel<1, 16, 4, E, true>), grid, dim3(64), ldsn, p);
+        else RAMA_LAUNCH(c, (gemv_chain_kernel<2, 16, 4, E, true>), grid, dim3(128), ldsn, p);
+        LAUNCHCHK();
+        return 0;
+    }
 #define RAMA_CHAIN(W_, D_) RAMA_LAUNCH(c, (gemv_chain_kernel<W_, D_, 4, EPI>), grid, dim3(W_ * 64), lds, p)
     if (W == 1 && D == 16) RAMA_CHAIN(1, 16);
     else if (W == 1 && D == 32) RAMA_CHAIN(1, 32);
@@ -931,12 +941,15 @@ static int enqueue_stage_chain(rama_ctx* c, const rama_config* cfg, const rama_w
         const size_t li = (size_t)(layer - st->layer_begin);
         float* kc = s->key_cache + li * cfg->seq_len * dim;
         float* vc = s->value_cache + li * cfg->seq_len * dim;
-        rc = launch_rmsnorm_chain(c, s->xb, s->x, w->rms_att_weight + li * dim, dim, nullptr); if (rc) return rc;       // infer.rs:19
+        // narrow models: the two norms of a layer ride in the matvecs that consume them (2 of 7 launches; "chain_norm")
+        const bool fold = c->tune_chain_norm && dim <= 512 && c->tune_chain_d <= 0;      // (measured: stories15M +6.6 %; at dim 768 the ripples cost more than the launch, -4 %)
+        if (!fold) { rc = launch_rmsnorm_chain(c, s->xb, s->x, w->rms_att_weight + li * dim, dim, nullptr); if (rc) return rc; }      // infer.rs:19
         {   // :20-33: Wq | Wk | Wv, RoPE, cache append
             KTimer kt(c, RAMA_K_QKV);
             ChainParams p{};
             p.w[0] = cq + li * dd; p.w[1] = ck + li * dd; p.w[2] = cv + li * dd;
-            p.o[0] = s->q; p.o[1] = s->k; p.o[2] = s->v; p.x = s->xb; p.K = dim; p.rows = dim; p.nmat = 3;
+            p.o[0] = s->q; p.o[1] = s->k; p.o[2] = s->v; p.x = fold ? s->x : s->xb; p.nw = fold ? w->rms_att_weight + li * dim : nullptr;
+            p.K = dim; p.rows = dim; p.nmat = 3;
             p.ctl = c->ctl; p.fr = w->freq_cis_real; p.fi = w->freq_cis_imag; p.head_size = hs; p.kc = kc; p.vc = vc;
             rc = launch_chain<CEPI_QKV>(c, p); if (rc) return rc;
         }
@@ -950,11 +963,12 @@ static int enqueue_stage_chain(rama_ctx* c, const rama_config* cfg, const rama_w
             p.w[0] = co + li * dd; p.o[0] = s->xb2; p.resid = s->x; p.x = s->xb; p.K = dim; p.rows = dim; p.nmat = 1;
             rc = launch_chain<CEPI_RESID>(c, p); if (rc) return rc;
         }
-        rc = launch_rmsnorm_chain(c, s->xb, s->x, w->rms_ffn_weight + li * dim, dim, nullptr); if (rc) return rc;        // :39
+        if (!fold) { rc = launch_rmsnorm_chain(c, s->xb, s->x, w->rms_ffn_weight + li * dim, dim, nullptr); if (rc) return rc; }       // :39
         {   // :41-45: hb = silu(W1 . xb) * (hb2 = W3 . xb)
             KTimer kt(c, RAMA_K_W13);
             ChainParams p{};
-            p.w[0] = c13 + li * 2 * hd; p.o[0] = s->hb; p.o[1] = s->hb2; p.x = s->xb; p.K = dim; p.rows = 2 * hidden; p.nmat = 1;
+            p.w[0] = c13 + li * 2 * hd; p.o[0] = s->hb; p.o[1] = s->hb2; p.x = fold ? s->x : s->xb; p.nw = fold ? w->rms_ffn_weight + li * dim : nullptr;
+            p.K = dim; p.rows = 2 * hidden; p.nmat = 1;
             rc = launch_chain<CEPI_SWIGLU>(c, p); if (rc) return rc;
         }
         {   // :46-47: xb = W2 . hb; x += xb
@@ -2200,6 +2214,13 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
     if (!strcmp(key, "tiled")) {
         REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: tiled must be 0 or 1");
         c->tune_tiled = value;
+        return 0;
+    }
+    if (!strcmp(key, "chain_norm")) {
+        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: chain_norm must be 0 or 1");
+        c->tune_chain_norm = value;
+        hipStreamSynchronize(c->stream);
+        drop_graph(c);
         return 0;
     }
     if (!strcmp(key, "prefill_chain")) {
