@@ -182,8 +182,8 @@ __device__ __forceinline__ float seq_sum_exact(const float* a, int n, SeqSumShar
 //      seq_sum_exact.  The result is the sequential sum bit for bit whenever it is returned.
 // phase time stamps for tools/seqsum_bench.hip only (100 MHz counter, thread 0)
 #ifdef RAMA_SEQ_STAMPS
-__device__ unsigned long long g_seq_stamps[16];
-#define SEQ_STAMP(id) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_seq_stamps[id] = __builtin_amdgcn_s_memrealtime(); } while (0)
+__device__ unsigned long long g_seq_stamps[40];
+#define SEQ_STAMP(id) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_seq_stamps[id] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define SEQ_STAMP(id) do { } while (0)
 #endif
@@ -1261,7 +1261,7 @@ __global__ __launch_bounds__(kSoftWaves * 64) void attn_softmax_chain_kernel(Ref
     for (int t = tid; t <= pos; t += T) att[t] = s_att[scan_slot(t)] / sum;
 }
 
-constexpr int kValCols = 32, kValRows = 256, kValWaves = 4;            // a slice's tile: 256 rows x 32 columns = 32 KiB of products
+constexpr int kValCols = 16, kValRows = 256, kValWaves = 4;            // a slice's tile: 256 rows x 16 columns = 16 KiB of products
 __global__ __launch_bounds__(kValWaves * 64) void attn_values_chain_kernel(RefAttnParams p) {
     RAMA_NO_CONTRACT
     constexpr int T = kValWaves * 64, U = kValRows * (kValCols / 4) / T;      // 8 x 16 bytes per thread and tile
@@ -1270,21 +1270,23 @@ __global__ __launch_bounds__(kValWaves * 64) void attn_values_chain_kernel(RefAt
     const int pos = p.ctl ? p.ctl->pos : p.pos_val;
     const size_t col = (size_t)h * p.head_size + (size_t)sl * kValCols;
     const float* att = p.att + (size_t)h * p.seq_len;
-    // tile element e = tid + u T: row e / 8, 16-byte column e % 8
+    // tile element e = tid + u T: row e / (kValCols / 4), 16-byte column e % (kValCols / 4)
     f4 va[U], vb[U];
     float aa[U], ab[U];
     auto vissue = [&](int t0, f4 (&vr)[U], float (&ar)[U]) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int e = tid + u * T, r = e >> 3, c4 = e & 7;
+            const int e = tid + u * T, r = e / (kValCols / 4), c4 = e % (kValCols / 4);
             const bool on = t0 + r <= pos;
             vr[u] = on ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.vc + (size_t)(t0 + r) * p.dim + col) + c4) : f4{0.f, 0.f, 0.f, 0.f};
             ar[u] = on ? att[t0 + r] : 0.0f;
         }
     };
+    SEQ_STAMP(20);
     vissue(0, va, aa);
     vissue(kValRows, vb, ab);
     float acc = 0.0f;
+    int stamp_tile = 0;
     auto vtile = [&](int t0, int buf, f4 (&vr)[U], float (&ar)[U]) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -1294,25 +1296,47 @@ __global__ __launch_bounds__(kValWaves * 64) void attn_values_chain_kernel(RefAt
             *reinterpret_cast<f4*>(&tile[buf][4 * e]) = pr;
         }
         vissue(t0 + 2 * kValRows, vr, ar);
+        if (stamp_tile < 4) SEQ_STAMP(21 + 3 * stamp_tile);
         __syncthreads();                                          // this tile is written; the other one (read last round) is free again
+        if (stamp_tile < 4) SEQ_STAMP(22 + 3 * stamp_tile);
         if (tid < kValCols) {
+            // the chain itself: one dependent add per row.  The next 16 products are read from LDS while the current 16
+            // are added (two register sets in turn) -- read-then-add in one batch left the chain waiting for LDS 16 times
+            // per tile (26 us per launch at 1900 timesteps)
             const int nt = min(kValRows, pos + 1 - t0);
+            const float* tb = &tile[buf][tid];
+            float v0[16], v1[16];
+            auto rd = [&](int r, float (&v)[16]) {                // (rows behind the tile are clamped: read, never added)
+#pragma unroll
+                for (int u = 0; u < 16; u++) v[u] = tb[min(r + u, kValRows - 1) * kValCols];
+            };
+            auto ad = [&](const float (&v)[16]) {
+#pragma unroll
+                for (int u = 0; u < 16; u++) acc = acc + v[u];
+            };
             int r = 0;
-            for (; r + 16 <= nt; r += 16) {
-                float v16[16];
-#pragma unroll
-                for (int u = 0; u < 16; u++) v16[u] = tile[buf][(r + u) * kValCols + tid];
-#pragma unroll
-                for (int u = 0; u < 16; u++) acc = acc + v16[u];
+            rd(0, v0);
+            for (; r + 32 <= nt; r += 32) {
+                rd(r + 16, v1);
+                __builtin_amdgcn_sched_barrier(0);
+                ad(v0);
+                __builtin_amdgcn_sched_barrier(0);
+                rd(r + 32, v0);
+                __builtin_amdgcn_sched_barrier(0);
+                ad(v1);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            for (; r < nt; r++) acc = acc + tile[buf][r * kValCols + tid];
+            for (; r < nt; r++) acc = acc + tb[r * kValCols];
         }
+        if (stamp_tile < 4) SEQ_STAMP(23 + 3 * stamp_tile);
+        stamp_tile++;
     };
     for (int t0 = 0; t0 <= pos; t0 += 2 * kValRows) {
         vtile(t0, 0, va, aa);
         if (t0 + kValRows <= pos) vtile(t0 + kValRows, 1, vb, ab);      // uniform
     }
     if (tid < kValCols) p.xb[col + tid] = acc;
+    SEQ_STAMP(33);
 }
 
 }  // namespace rama

@@ -55,6 +55,22 @@ int main(int argc, char** argv) {
             printf("   q %.2f | scores %.2f | max+exp %.2f | sum %.2f | divide %.2f | values %.2f us\n", (st[9] - st[8]) * 0.01 * 0 + 0.0, (st[9] - st[8]) * 0.01, (st[10] - st[9]) * 0.01,
                    (st[11] - st[10]) * 0.01, (st[12] - st[11]) * 0.01, (st[13] - st[12]) * 0.01);
         }
+        {   // the spread form of long contexts: the value chains (heads x 32-column slices), stamps of workgroup 0
+            float* att; CK(hipMalloc(&att, (size_t)H * seq * 4)); CK(hipMemset(att, 0, (size_t)H * seq * 4));
+            ap.att = att;
+            for (int rep = 0; rep < 2; rep++) {
+                CK(hipEventRecord(e0, 0));
+                for (int i = 0; i < 20; i++) hipLaunchKernelGGL(attn_values_chain_kernel, dim3(H, hs / kValCols), dim3(kValWaves * 64), 0, 0, ap);
+                CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                if (rep) printf("attn_values_chain_kernel pos %d: %.2f us per launch\n", pos, ms * 1e3 / 20);
+            }
+            unsigned long long sv[40];
+            CK(hipMemcpyFromSymbol(sv, HIP_SYMBOL(rama::g_seq_stamps), sizeof sv));
+            printf("   loads issued at 0;");
+            for (int t = 0; t < 4; t++) printf(" tile %d: products written %.2f, barrier passed %.2f, chain done %.2f |", t, (sv[21 + 3 * t] - sv[20]) * 0.01, (sv[22 + 3 * t] - sv[20]) * 0.01, (sv[23 + 3 * t] - sv[20]) * 0.01);
+            printf(" end %.2f us\n", (sv[33] - sv[20]) * 0.01);
+        }
     }
     unsigned ps[2]; CK(hipMemcpyFromSymbol(ps, HIP_SYMBOL(rama::g_pred_stats), sizeof ps));
     printf("  held %u fell back %u\n", ps[0], ps[1]);
