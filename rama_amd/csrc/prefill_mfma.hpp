@@ -42,7 +42,7 @@ namespace rama {
 
 constexpr int kMfWaves = 8;
 constexpr int kMfThreads = kMfWaves * 64;
-constexpr int kMfMaxTok = 128;               // tokens per pass (PT <= 8; PT = 8 needs the tile-order weight copy)
+constexpr int kMfMaxTok = 128;               // tokens per pass (PT <= 8; PT = 5 .. 8 need the tile-order weight copy)
 constexpr int kMfMaxTokRows = 64;            // ... with row-major weights (PT <= 4)
 
 enum { EPI_SWIGLU = 3, EPI_STORE_ROWS = 4 };
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(kMfThreads) void gemm_mfma_rows(MfParams p) {
 #pragma unroll
                 for (int pl = 0; pl < PTC; pl++)
 #pragma unroll
-                    for (int e = 0; e < 4; e++) part[wave][rt * PTC + pl][e][lane] = acc[rt][c0 + pl][e];
+                    for (int e = 0; e < 4; e++) part[wave][rt * PTC + pl][e][lane] = acc[rt][c0 + pl < PT ? c0 + pl : PT - 1][e];      // (5-7 tiles: the last round's spare slots repeat a tile; their tokens are behind n_tok)
             constexpr int UNITS = (PAIR ? PTC : NTC) * 64;      // one unit = 4 consecutive rows of one token
             constexpr int ITER = (UNITS + kMfThreads - 1) / kMfThreads;
             // EPI_QKV: the rotation coefficients and positions of my units are on their way before the barrier

@@ -1281,7 +1281,11 @@ static int launch_mf(rama_ctx* c, MfParams& p, int pt) {
         else if (pt == 2) hipLaunchKernelGGL((gemm_mfma_rows<2, RT, EPI, 2, 3>), grid, block, 0, c->stream, p);
         // MIX (loads scheduled into the MFMA stream) where tools/pf_mfma_bench.hip measures it faster: same arithmetic, same bits
         else if (pt <= 4) hipLaunchKernelGGL((gemm_mfma_rows<4, RT, EPI, 2, 3, 0, (EPI == EPI_QKV || EPI == EPI_STORE) ? 2 : 0>), grid, block, 0, c->stream, p);
-        else hipLaunchKernelGGL((gemm_mfma_rows<8, RT, EPI, 1, 3, 0, EPI == EPI_QKV ? 2 : 0>), grid, block, 0, c->stream, p);      // 128 tokens: one K-block per step
+        // 65 .. 128 tokens: one K-block per step; as many token tiles as the pass has (a pass of 70 positions pays for 80, not 128)
+        else if (pt == 5) hipLaunchKernelGGL((gemm_mfma_rows<5, RT, EPI, 1, 3, 0, EPI == EPI_QKV ? 2 : 0>), grid, block, 0, c->stream, p);
+        else if (pt == 6) hipLaunchKernelGGL((gemm_mfma_rows<6, RT, EPI, 1, 3, 0, EPI == EPI_QKV ? 2 : 0>), grid, block, 0, c->stream, p);
+        else if (pt == 7) hipLaunchKernelGGL((gemm_mfma_rows<7, RT, EPI, 1, 3, 0, EPI == EPI_QKV ? 2 : 0>), grid, block, 0, c->stream, p);
+        else hipLaunchKernelGGL((gemm_mfma_rows<8, RT, EPI, 1, 3, 0, EPI == EPI_QKV ? 2 : 0>), grid, block, 0, c->stream, p);
     } else {
         REQUIRE(pt <= 4, RAMA_EUNSUP, "token batch: more than 64 tokens per pass need the tile-order weight copy");
         if (pt == 1) hipLaunchKernelGGL((gemm_mfma_rows<1, RT, EPI>), grid, block, 0, c->stream, p);
@@ -1376,7 +1380,7 @@ static int run_layers_batched(rama_ctx* c, const rama_config* cfg, const rama_we
                               int nt, int p0, float* key_cache, float* value_cache, bool seqs, int tmax, int* nslab_out) {
     const int dim = cfg->dim, hidden = cfg->hidden_dim, hs = dim / cfg->n_heads;
     const size_t dd = (size_t)dim * dim, hd = (size_t)hidden * dim;
-    const int ntile = (nt + 15) / 16, pt = ntile <= 1 ? 1 : (ntile == 2 ? 2 : (ntile <= 4 ? 4 : 8));
+    const int ntile = (nt + 15) / 16, pt = ntile <= 1 ? 1 : (ntile == 2 ? 2 : (ntile <= 4 ? 4 : ntile));
     const int ks_wo = mf_ksplit(c, dim, dim), ks_w2 = mf_ksplit(c, dim, hidden);
     int pending = 0;      // K-slices of the previous product waiting in b.SL
     int rc;
@@ -1675,7 +1679,7 @@ static int enqueue_batch_pass(rama_ctx* c, const rama_config* cfg, const rama_we
     int rc = run_layers_batched(c, cfg, w, b, n_seq, 0, nullptr, nullptr, true, tmax, &nslab);
     if (rc) return rc;
     // infer.rs:49-51 for every sequence: fold the last product, final rmsnorm, classifier
-    const int ntile = (n_seq + 15) / 16, pt = ntile <= 1 ? 1 : (ntile == 2 ? 2 : (ntile <= 4 ? 4 : 8));
+    const int ntile = (n_seq + 15) / 16, pt = ntile <= 1 ? 1 : (ntile == 2 ? 2 : (ntile <= 4 ? 4 : ntile));
     rc = launch_rmsnorm_tile(c, b, w->rms_final_weight, dim, ntile, nslab); if (rc) return rc;
     MfParams p{};
     p.n_tok = n_seq; p.ksplit = 1; { const float* bs[1] = {w->wcls}; mf_weights(c, p, 1, bs, 0, 0); }

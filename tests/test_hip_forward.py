@@ -724,12 +724,12 @@ def test_tile_order_weight_copy_gives_identical_results(dev, shape, n_tokens):
     model.free()
 
 
-@pytest.mark.parametrize("shape,n_tokens,pos0", [((128, 352, 2, 2, 256, 320), 65, 0), ((128, 352, 2, 2, 256, 320), 100, 3), ((128, 352, 2, 2, 256, 320), 128, 0),
+@pytest.mark.parametrize("shape,n_tokens,pos0", [((128, 352, 2, 2, 256, 320), 65, 0), ((128, 352, 2, 2, 256, 320), 90, 0), ((128, 352, 2, 2, 256, 320), 100, 3), ((128, 352, 2, 2, 256, 320), 128, 0),
                                                  ((128, 352, 2, 2, 256, 320), 129, 0), ((128, 352, 2, 1, 256, 320), 300, 5), ((288, 768, 2, 6, 512, 256), 113, 0),
                                                  ((768, 2048, 1, 12, 1024, 256), 128, 17)])
 def test_prefill_128_positions_per_weight_pass(dev, shape, n_tokens, pos0):
     """with the tile-order weight copies a prefill pass takes up to 128 positions (8 token tiles per wave, one
-    K-block per step, the cross-wave fold in two rounds): every tile count 5..8, a partly filled last tile, several
+    K-block per step, the cross-wave fold in two rounds; as many token tiles as the pass has): every tile count 5..8, a partly filled last tile, several
     passes and a non-zero start give the state sequential forward() calls leave (oracle as referee), and
     the 64-position passes (rama_set_tuning "prefill_tok" = 64) agree to rounding"""
     import ctypes as C
