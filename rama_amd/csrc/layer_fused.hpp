@@ -1,0 +1,457 @@
+// layer_fused.hpp -- a whole stage (its decoder layers, infer.rs:19-47, and the classifier, :49-51) as ONE launch, for
+// models whose launches are latency-bound (the stories shapes; rama_set_tuning "fused").  Workgroups of 8 waves, in this
+// order per layer, each phase waiting for the vector the phase before it produces:
+//   nA  workgroups   q | k | v = rows of Wq | Wk | Wv times rmsnorm(x), RoPE, cache append      reads xe of layer l-1
+//   H   workgroups   xb = attention, one head each                                              reads q | k | v
+//   nC  workgroups   xc = x + Wo . xb                                                           reads xb
+//   nD  workgroups   hb = silu(W1 . xn) * (W3 . xn), xn = rmsnorm(xc)                           reads xc
+//   nE  workgroups   xe = xc + W2 . hb                                                          reads hb
+// and after the last layer the classifier's workgroups (rmsnorm folded in), which read the last xe.
+// In a matvec workgroup every wave is its own unit -- 4 weight rows, the whole width, as in gemv_rows_solo -- and
+// requests its weights BEFORE the workgroup waits: weights do not depend on activations, so while a layer computes, the
+// rows of the layers behind it are already on their way.
+// Hand-off: THE DATA CARRIES ITS OWN TAG.  Every float that crosses workgroups is one 8-byte (value, epoch) word written
+// with a single write-through store; `epoch` is a device counter the launch before this one increments, and every (layer,
+// phase) has its own vector, so a word holds either this token's value or a stale tag.  A consumer polls one word from one
+// lane, then the workgroup copies the vector to LDS checking every tag, and repeats the copy until all match.  No counter,
+// no store drain, no arrival atomic: tools/handoff_bench.hip measures 1.3 us per hand-off against 2.4 us for the
+// counter protocol of attn_wo.hpp (profiles/r03_fused_counter_handoff.txt has that version of this kernel: slower than
+// separate launches).
+// No deadlock whatever is resident: a workgroup only ever waits for workgroups with LOWER indices, which are dispatched
+// before it.  Every spin is bounded all the same, and gives up at once when another workgroup already has (error word).
+#pragma once
+#include "attn_wo.hpp"
+
+namespace rama {
+
+typedef unsigned long long tagged_t;          // low word: the float's bits, high word: the epoch it was written in
+typedef __attribute__((ext_vector_type(4))) unsigned u4;
+
+struct FusedParams {
+    int dim, hidden, n_heads, seq_len, vocab, n_layers, do_cls;
+    const float *wq, *wk, *wv, *wo, *w1, *w3, *w2;      // the stage's first layer; the others follow at the natural strides
+    const float *g_att, *g_ffn, *g_final, *wcls;
+    float *x, *q, *k, *v, *xb, *hb, *logits;             // run-state buffers: x is read by the first layer; all are left as the separate launches leave them
+    float *kc, *vc;                                      // the stage's cache slabs [layers, seq, dim]
+    const float *fr, *fi;
+    const Ctl* ctl;
+    tagged_t* hand;                                      // per layer: q|k|v [3 dim], xb [dim], xc [dim], hb [hidden], xe [dim]
+    const unsigned* epoch;
+    unsigned long long* err;
+    int nA, nC, nD, nE;                                  // workgroups per matvec phase
+};
+constexpr unsigned long long kFusedErr = 0x3000ull;
+constexpr int kFusedMaxLayers = 128, kFusedMaxDim = 1024, kFusedMaxHidden = 8192;
+__host__ __device__ constexpr size_t fused_hand_words(int dim, int hidden) { return (size_t)6 * dim + hidden; }
+
+#ifdef RAMA_FUSED_STAMPS      // tools/fused_stamps.hip: where a layer's time goes (100 MHz clock), first workgroup of every phase
+__device__ unsigned long long g_fused_stamps[8][6][8];
+#define FUSED_STAMP(first, layer, phase, i) do { if ((first) && threadIdx.x == 0 && (layer) < 8) g_fused_stamps[layer][phase][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FUSED_STAMP(first, layer, phase, i) do { } while (0)
+#endif
+
+// the launch before: x = the token's embedding row (infer.rs:13-14), the next epoch
+__global__ __launch_bounds__(256) void fused_embed_kernel(float* x, const float* table, const Ctl* ctl, int dim, int do_embed, unsigned* epoch) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (do_embed && i < dim) x[i] = table[(size_t)ctl->token * dim + i];
+    if (i == 0) *epoch = *epoch + 1u;
+}
+
+__device__ __forceinline__ void put_tagged(tagged_t* p, float v, unsigned epoch) {
+    __hip_atomic_store(p, ((tagged_t)epoch << 32) | (tagged_t)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float get_tagged(const tagged_t* p) {      // a word some phase before the awaited one wrote
+    return __uint_as_float((unsigned)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// one lane: wait (sleeping) until the word at p carries `epoch` -- the cheap wait of workgroups far ahead of the data
+__device__ __forceinline__ void fused_watch(const tagged_t* p, unsigned epoch, unsigned long long* err) {
+    long spins = 0;
+    while ((unsigned)(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) != epoch) {
+        __builtin_amdgcn_s_sleep(2);
+        ++spins;
+        if ((spins & 255) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        if (spins > (1L << 22)) { __hip_atomic_store(err, kFusedErr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+}
+
+// The whole workgroup: x_s[0..n) = the n floats of `src` (n even, src 16-byte aligned), once every one of them carries
+// `epoch`: the vector is copied to LDS, every tag checked, again and again until all match.  `early`: a word of the vector
+// the producers of `src` themselves wait for -- one lane sleeps on it first, so that only the workgroups whose input is
+// being produced right now poll whole vectors.  src == nullptr: the vector is `plain`, an ordinary float array of an
+// earlier launch.
+__device__ __forceinline__ void fused_fetch(const tagged_t* src, const float* plain, int n, const tagged_t* early, unsigned epoch, float* x_s,
+                                            unsigned long long* err) {
+    const int tid = threadIdx.x;
+    if (!src) {
+        for (int i = tid * 4; i < n; i += kPThreads * 4) *reinterpret_cast<f4*>(x_s + i) = *reinterpret_cast<const f4*>(plain + i);
+        __syncthreads();
+        return;
+    }
+    if (early) {
+        if (tid == 0) fused_watch(early, epoch, err);
+        __syncthreads();
+    }
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(src, (unsigned)n * 8u);
+    for (int tries = 0;; tries++) {
+        bool ok = true;
+        for (int i = tid * 2; i < n; i += kPThreads * 2) {
+            const u4 p = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(rs, i * 8, 0, 16));      // sc1: two words
+            ok = ok && p.y == epoch && p.w == epoch;
+            x_s[i] = __uint_as_float(p.x); x_s[i + 1] = __uint_as_float(p.z);
+        }
+        if (__syncthreads_and(ok)) break;
+        if ((tries & 63) == 63 &&
+            __syncthreads_or(tries >= (1 << 20) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {      // one verdict for the workgroup
+            if (tid == 0) __hip_atomic_store(err, kFusedErr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+}
+
+// one wave's weights: 4 rows, the first CH 256-float chunks of each -- rows r0..r0+3 of Wa, or (PAIR) rows r0, r0+1 of Wa and
+// of Wb interleaved (0/2 = Wa, 1/3 = Wb)
+template <int CH, bool NORM, bool PAIR>
+struct FusedUnit {
+    __amdgpu_buffer_rsrc_t ra, rb, rg;
+    unsigned rowoff[4], kbytes;
+    int nch, lane;
+    f4 w[4][CH], gv[CH];
+    __device__ __forceinline__ unsigned kb_of(int c) const { const unsigned o = (unsigned)(c * 1024 + lane * 16); return (c < nch && o < kbytes) ? o : kOOB; }
+    __device__ __forceinline__ f4 wload(int s, unsigned kb) const {
+        const unsigned o = (kb == kOOB || rowoff[s] == kOOB) ? kOOB : rowoff[s] + kb;
+        return ld_nt((PAIR && (s & 1)) ? rb : ra, o);
+    }
+    // request the weights (and the rmsnorm gain): nothing here depends on this token
+    __device__ __forceinline__ void request(const float* Wa, const float* Wb, const float* gain, int rows, int K, int r0, bool valid) {
+        lane = threadIdx.x & 63;
+        nch = (K + 255) >> 8;
+        kbytes = (unsigned)K * 4u;
+        ra = make_rsrc(Wa, (unsigned)rows * kbytes);
+        rb = make_rsrc(PAIR ? Wb : Wa, (unsigned)rows * kbytes);
+        rg = make_rsrc(NORM ? gain : Wa, kbytes);
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int r = PAIR ? r0 + (s >> 1) : r0 + s;
+            rowoff[s] = (valid && r < rows) ? (unsigned)r * kbytes : kOOB;
+        }
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) w[s][j] = wload(s, kb_of(j));
+            if (NORM) gv[j] = ld_c(rg, kb_of(j));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // the four dot products with x_s (LDS, K floats); NORM: x is scaled by the gain here and `scale` = 1 / sqrt(mean(x^2) + eps)
+    // comes back (cpu.rs:99-117)
+    __device__ __forceinline__ void dots(const float* x_s, int K, float (&acc)[4], float& scale) {
+        float ss = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 4; s++) acc[s] = 0.0f;
+        auto xload = [&](int c) { const f4 z = {0.f, 0.f, 0.f, 0.f}; return kb_of(c) == kOOB ? z : *reinterpret_cast<const f4*>(x_s + c * 256 + lane * 4); };
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            f4 xv = xload(j);
+            if (NORM) { ss = dot4(xv, xv, ss); xv = xv * gv[j]; }
+#pragma unroll
+            for (int s = 0; s < 4; s++) acc[s] = dot4(w[s][j], xv, acc[s]);
+        }
+        for (int c0 = CH; c0 < nch; c0 += CH) {        // rows wider than the requested part (W2 of the wider models)
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) w[s][j] = wload(s, kb_of(c0 + j));
+                if (NORM) gv[j] = ld_c(rg, kb_of(c0 + j));
+            }
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+                f4 xv = xload(c0 + j);
+                if (NORM) { ss = dot4(xv, xv, ss); xv = xv * gv[j]; }
+#pragma unroll
+                for (int s = 0; s < 4; s++) acc[s] = dot4(w[s][j], xv, acc[s]);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; s++) acc[s] = wave_sum(acc[s]);
+        scale = 1.0f;
+        if (NORM) scale = rms_scale(wave_sum(ss), K);
+    }
+};
+
+// attention for head h (infer.rs:34, the arithmetic of attention_kernel / p_attention): the cache rows before `pos` are an
+// earlier launch's, row `pos` and q are this launch's -- cur = q | k | v of this head in LDS.  Writes xb as tagged words
+// (and plainly, `xb_plain`, for the run state).
+template <int G>
+__device__ __forceinline__ void fused_attention(int dim, int n_heads, int seq_len, const float* kc, const float* vc, int h, int pos,
+                                                const tagged_t* t_qkv, const tagged_t* early, float* cur, float* lds, tagged_t* xb_t, float* xb_plain,
+                                                unsigned epoch, unsigned long long* err, int st_layer = 0) {
+    float* s_max = lds;
+    float* s_sum = lds + kPWaves;
+    float* s_acc = lds + 2 * kPWaves;
+    float* s_att = lds + 2 * kPWaves + kPWaves * G * 4;
+    constexpr int U = kPAttnU;
+    constexpr int TPW = 64 / G;
+    constexpr int TILE = kPWaves * TPW * U;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hs = dim / n_heads;
+    const int li = lane % G, tg = lane / G;
+    const bool lane_ok = li * 4 < hs;
+    const unsigned cache_bytes = (unsigned)seq_len * (unsigned)dim * 4u;
+    const __amdgpu_buffer_rsrc_t rk = make_rsrc(kc, cache_bytes);
+    const __amdgpu_buffer_rsrc_t rv = make_rsrc(vc, cache_bytes);
+    const unsigned col = (unsigned)(h * hs + li * 4) * 4u;
+    const unsigned rowb = (unsigned)dim * 4u;
+    auto t_of = [&](int base, int u) { return base + (u * kPWaves + wave) * TPW + tg; };
+    auto off_of = [&](int t) { return (lane_ok && t < pos) ? (unsigned)t * rowb + col : kOOB; };
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    const float div = sqrtf((float)hs);
+    f4 kt[U], vt[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) kt[u] = ld_c(rk, off_of(t_of(0, u)));      // rows of earlier launches: on their way before the wait
+#pragma unroll
+    for (int u = 0; u < U; u++) vt[u] = ld_c(rv, off_of(t_of(0, u)));
+    __builtin_amdgcn_sched_barrier(0);
+    {   // cur = this head's slices of the q | k | v vector, 3 hs words, once all carry the epoch
+        if (early) {
+            if (tid == 0) fused_watch(early, epoch, err);
+            __syncthreads();
+        }
+        for (int tries = 0;; tries++) {
+            bool ok = true;
+            for (int i = tid; i < 3 * hs; i += kPThreads) {
+                const int m = i / hs, j = i - m * hs;
+                const tagged_t p = __hip_atomic_load(t_qkv + m * dim + h * hs + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = ok && (unsigned)(p >> 32) == epoch;
+                cur[m * hs + j] = __uint_as_float((unsigned)p);
+            }
+            if (__syncthreads_and(ok)) break;
+            if ((tries & 63) == 63 && __syncthreads_or(tries >= (1 << 20) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                if (tid == 0) __hip_atomic_store(err, kFusedErr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    FUSED_STAMP(h == 0, st_layer, 1, 1);
+    const f4 q4 = lane_ok ? *reinterpret_cast<const f4*>(cur + li * 4) : zero;
+    const f4 k4 = lane_ok ? *reinterpret_cast<const f4*>(cur + hs + li * 4) : zero;
+    const f4 v4 = lane_ok ? *reinterpret_cast<const f4*>(cur + 2 * hs + li * 4) : zero;
+    for (int base = 0; base <= pos; base += TILE) {
+        if (base > 0) {
+#pragma unroll
+            for (int u = 0; u < U; u++) kt[u] = ld_c(rk, off_of(t_of(base, u)));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int t = t_of(base, u);
+            float d = dot4(q4, t == pos ? k4 : kt[u], 0.0f);
+            d = row16_sum(d);
+            if (G == 32) d += __shfl_xor(d, 16);
+            if (G == 64) { d += __shfl_xor(d, 16); d += __shfl_xor(d, 32); }
+            if (li == 0 && t <= pos) s_att[t] = d / div;
+        }
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int t = tid; t <= pos; t += kPThreads) mx = fmaxf(mx, s_att[t]);
+    mx = wave_max(mx);
+    if (lane == 0) s_max[wave] = mx;
+    __syncthreads();
+    mx = s_max[0];
+#pragma unroll
+    for (int w = 1; w < kPWaves; w++) mx = fmaxf(mx, s_max[w]);
+    float sum = 0.0f;
+    for (int t = tid; t <= pos; t += kPThreads) {
+        const float e = expf(s_att[t] - mx);
+        s_att[t] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) s_sum[wave] = sum;
+    __syncthreads();
+    {
+        float t8[kPWaves];
+#pragma unroll
+        for (int w = 0; w < kPWaves; w++) t8[w] = s_sum[w];
+#pragma unroll
+        for (int n = kPWaves; n > 1; n >>= 1)
+#pragma unroll
+            for (int w = 0; w < n / 2; w++) t8[w] = t8[2 * w] + t8[2 * w + 1];
+        sum = t8[0];
+    }
+    for (int t = tid; t <= pos; t += kPThreads) s_att[t] = s_att[t] / sum;
+    __syncthreads();
+    f4 acc = zero;
+    for (int base = 0; base <= pos; base += TILE) {
+        if (base > 0) {
+#pragma unroll
+            for (int u = 0; u < U; u++) vt[u] = ld_c(rv, off_of(t_of(base, u)));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int t = t_of(base, u);
+            const float a = (t <= pos) ? s_att[t] : 0.0f;
+            const f4 vv = t == pos ? v4 : vt[u];
+            acc.x = fmaf(a, vv.x, acc.x); acc.y = fmaf(a, vv.y, acc.y);
+            acc.z = fmaf(a, vv.z, acc.z); acc.w = fmaf(a, vv.w, acc.w);
+        }
+    }
+#pragma unroll
+    for (int m = G; m < 64; m <<= 1) {
+        acc.x += __shfl_xor(acc.x, m); acc.y += __shfl_xor(acc.y, m);
+        acc.z += __shfl_xor(acc.z, m); acc.w += __shfl_xor(acc.w, m);
+    }
+    if (lane < G) *reinterpret_cast<f4*>(s_acc + (wave * G + lane) * 4) = acc;
+    __syncthreads();
+    if (tid < G && tid * 4 < hs) {
+        f4 t8[kPWaves];
+#pragma unroll
+        for (int w = 0; w < kPWaves; w++) t8[w] = *reinterpret_cast<f4*>(s_acc + (w * G + tid) * 4);
+#pragma unroll
+        for (int n = kPWaves; n > 1; n >>= 1)
+#pragma unroll
+            for (int w = 0; w < n / 2; w++) t8[w] = t8[2 * w] + t8[2 * w + 1];
+        const int o = h * hs + tid * 4;
+        put_tagged(xb_t + o, t8[0].x, epoch); put_tagged(xb_t + o + 1, t8[0].y, epoch);
+        put_tagged(xb_t + o + 2, t8[0].z, epoch); put_tagged(xb_t + o + 3, t8[0].w, epoch);
+        if (xb_plain) *reinterpret_cast<f4*>(xb_plain + o) = t8[0];
+    }
+}
+
+__host__ __device__ constexpr int fused_lds_floats(int G, int seq_len, int dim, int hidden) {
+    const int attn = p_attn_lds_floats(G, seq_len) + 3 * 256, vec = hidden > dim ? hidden : dim;
+    return attn > vec ? attn : vec;
+}
+
+// G: lanes per cache row in the attention phase (head_size / 4 rounded up to 16 | 32 | 64); CD / CHH: chunks requested ahead of
+// a row as wide as dim / hidden_dim
+template <int G, int CD, int CHH>
+__global__ __launch_bounds__(kPThreads, 4) void stage_fused_kernel(FusedParams a) {
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dim = a.dim, hidden = a.hidden, H = a.n_heads, hs = dim / H;
+    const int per_layer = a.nA + H + a.nC + a.nD + a.nE;
+    const int layer = blockIdx.x / per_layer;
+    const size_t hw = fused_hand_words(dim, hidden);
+    float acc[4], scale;
+    if (layer >= a.n_layers) {                         // ---- infer.rs:49-51: logits = Wcls . rmsnorm(x)
+        const int r0 = ((blockIdx.x - a.n_layers * per_layer) * kPWaves + wave) * 4;
+        FusedUnit<CD, true, false> u;
+        u.request(a.wcls, nullptr, a.g_final, a.vocab, dim, r0, r0 < a.vocab);
+        const unsigned epoch = *a.epoch;
+        const tagged_t* hlast = a.hand + (size_t)(a.n_layers ? a.n_layers - 1 : 0) * hw;
+        fused_fetch(a.n_layers ? hlast + 5 * dim + hidden : nullptr, a.x, dim, hlast + 5 * dim + hidden - 1, epoch, lds, a.err);
+        u.dots(lds, dim, acc, scale);
+        if (lane < 4 && r0 + lane < a.vocab) a.logits[r0 + lane] = pick<4>(acc, lane) * scale;
+        return;
+    }
+    int b = blockIdx.x - layer * per_layer;
+    const bool last = layer == a.n_layers - 1;
+    const size_t dd = (size_t)dim * dim, hd = (size_t)hidden * dim;
+    tagged_t* hl = a.hand + (size_t)layer * hw;
+    tagged_t *t_qkv = hl, *t_xb = hl + 3 * dim, *t_xc = hl + 4 * dim, *t_hb = hl + 5 * dim, *t_xe = hl + 5 * dim + hidden;
+    const tagged_t* t_in = layer ? hl - dim : nullptr;                  // xe of the layer before
+    float* kc = a.kc + (size_t)layer * a.seq_len * dim;
+    float* vc = a.vc + (size_t)layer * a.seq_len * dim;
+    if (b < a.nA) {                                    // ---- infer.rs:19-33: rmsnorm, Wq | Wk | Wv, RoPE, cache append
+        const int upm = (dim + 3) >> 2, un = b * kPWaves + wave, m = un / upm, r0 = (un - m * upm) * 4;
+        FUSED_STAMP(b == 0, layer, 0, 0);
+        FusedUnit<CD, true, false> u;
+        u.request((m == 0 ? a.wq : (m == 1 ? a.wk : a.wv)) + layer * dd, nullptr, a.g_att + (size_t)layer * dim, dim, dim, r0, m < 3);
+        const unsigned epoch = *a.epoch;
+        const int pos = a.ctl->pos;
+        const bool mine = lane < 2 && m < 3 && r0 + 2 * lane < dim;
+        float rc = 1.0f, rs = 0.0f;                    // cpu.rs:45-62: the rotation of this lane's pair
+        if (mine && m < 2) {
+            const int i = ((r0 + 2 * lane) % hs) >> 1;
+            rc = a.fr[(size_t)pos * (hs >> 1) + i]; rs = a.fi[(size_t)pos * (hs >> 1) + i];
+        }
+        fused_fetch(t_in, a.x, dim, layer ? hl - dim - 1 : nullptr, epoch, lds, a.err);      // early: the last word of hb of the layer before
+        FUSED_STAMP(b == 0, layer, 0, 1);
+        u.dots(lds, dim, acc, scale);
+        if (mine) {
+            const int r = r0 + 2 * lane;
+            float va = pick<4>(acc, 2 * lane) * scale, vb = pick<4>(acc, 2 * lane + 1) * scale;
+            if (m < 2) {
+                const float ra = va * rc - vb * rs, rb = va * rs + vb * rc;
+                va = ra; vb = rb;
+            }
+            put_tagged(t_qkv + m * dim + r, va, epoch); put_tagged(t_qkv + m * dim + r + 1, vb, epoch);
+            if (m == 1) { kc[(size_t)pos * dim + r] = va; kc[(size_t)pos * dim + r + 1] = vb; }
+            else if (m == 2) { vc[(size_t)pos * dim + r] = va; vc[(size_t)pos * dim + r + 1] = vb; }
+            if (last) { float* o = m == 0 ? a.q : (m == 1 ? a.k : a.v); o[r] = va; o[r + 1] = vb; }
+        }
+        FUSED_STAMP(b == 0, layer, 0, 2);
+        return;
+    }
+    b -= a.nA;
+    if (b < H) {                                       // ---- infer.rs:34: one head
+        FUSED_STAMP(b == 0, layer, 1, 0);
+        const unsigned epoch = *a.epoch;
+        float* cur = lds + p_attn_lds_floats(G, a.seq_len);           // q | k | v of this head, hs floats each (hs <= 256)
+        fused_attention<G>(dim, H, a.seq_len, kc, vc, b, a.ctl->pos, t_qkv, t_in ? t_in + dim - 1 : nullptr, cur, lds, t_xb, last ? a.xb : nullptr, epoch,
+                           a.err, layer);
+        FUSED_STAMP(b == 0, layer, 1, 2);
+        return;
+    }
+    b -= H;
+    if (b < a.nC) {                                    // ---- infer.rs:35-37: xc = x + Wo . xb
+        const int r0 = (b * kPWaves + wave) * 4;
+        FUSED_STAMP(b == 0, layer, 2, 0);
+        FusedUnit<CD, false, false> u;
+        u.request(a.wo + layer * dd, nullptr, nullptr, dim, dim, r0, r0 < dim);
+        const unsigned epoch = *a.epoch;
+        fused_fetch(t_xb, nullptr, dim, t_qkv + 3 * dim - 1, epoch, lds, a.err);
+        FUSED_STAMP(b == 0, layer, 2, 1);
+        float resid = 0.0f;                            // complete since before this layer's first phase
+        if (lane < 4 && r0 + lane < dim) resid = t_in ? get_tagged(t_in + r0 + lane) : a.x[r0 + lane];
+        u.dots(lds, dim, acc, scale);
+        if (lane < 4 && r0 + lane < dim) put_tagged(t_xc + r0 + lane, resid + pick<4>(acc, lane), epoch);
+        FUSED_STAMP(b == 0, layer, 2, 2);
+        return;
+    }
+    b -= a.nC;
+    if (b < a.nD) {                                    // ---- infer.rs:39-45: rmsnorm, W1 | W3, SiLU * gate
+        const int r0 = (b * kPWaves + wave) * 2;
+        FUSED_STAMP(b == 0, layer, 3, 0);
+        FusedUnit<CD, true, true> u;
+        u.request(a.w1 + layer * hd, a.w3 + layer * hd, a.g_ffn + (size_t)layer * dim, hidden, dim, r0, r0 < hidden);
+        const unsigned epoch = *a.epoch;
+        fused_fetch(t_xc, nullptr, dim, t_xb + dim - 1, epoch, lds, a.err);
+        FUSED_STAMP(b == 0, layer, 3, 1);
+        u.dots(lds, dim, acc, scale);
+        if (lane < 2 && r0 + lane < hidden) {
+            const float va = pick<4>(acc, 2 * lane) * scale, vb = pick<4>(acc, 2 * lane + 1) * scale;
+            const float g = va * (1.0f / (1.0f + expf(-va))) * vb;
+            put_tagged(t_hb + r0 + lane, g, epoch);
+            if (last) a.hb[r0 + lane] = g;
+        }
+        FUSED_STAMP(b == 0, layer, 3, 2);
+        return;
+    }
+    b -= a.nD;
+    {                                                  // ---- infer.rs:46-47: xe = xc + W2 . hb
+        const int r0 = (b * kPWaves + wave) * 4;
+        FUSED_STAMP(b == 0, layer, 4, 0);
+        FusedUnit<CHH, false, false> u;
+        u.request(a.w2 + layer * hd, nullptr, nullptr, dim, hidden, r0, r0 < dim);
+        const unsigned epoch = *a.epoch;
+        fused_fetch(t_hb, nullptr, hidden, t_xc + dim - 1, epoch, lds, a.err);
+        FUSED_STAMP(b == 0, layer, 4, 1);
+        float resid = 0.0f;                            // complete since before the phase before this one
+        if (lane < 4 && r0 + lane < dim) resid = get_tagged(t_xc + r0 + lane);
+        u.dots(lds, hidden, acc, scale);
+        if (lane < 4 && r0 + lane < dim) {
+            const float o = resid + pick<4>(acc, lane);
+            put_tagged(t_xe + r0 + lane, o, epoch);
+            if (last) a.x[r0 + lane] = o;
+        }
+        FUSED_STAMP(b == 0, layer, 4, 2);
+    }
+}
+
+}  // namespace rama

@@ -3,6 +3,7 @@
 #include "../../include/rama_hip.h"
 #include "kernels.hpp"
 #include "attn_wo.hpp"
+#include "layer_fused.hpp"
 #include "topp_sort.hpp"
 #include "prefill_attn.hpp"
 #include "prefill_mfma.hpp"
@@ -120,6 +121,9 @@ struct rama_ctx {
     int tune_prefill = 1;                  // 1: rama_generate_greedy runs the forced prompt positions through rama_prefill
     int tune_merge = -1;                   // attention + Wo in one launch: 1 on, 0 off, -1 by model size (on for dim <= 1024:
                                            // +4..8 % at the stories shapes; at llama2-7B +0.9 % short / -2.5 % long contexts)
+    int tune_fused = 0;                    // a stage's layers (+ classifier) as one launch (layer_fused.hpp): 1 on, 0 off, -1 on for dim <= 1024
+    tagged_t* fused_hand = nullptr;        // device: its hand-off vectors (tagged words), room for the largest shape it takes
+    unsigned* fused_epoch = nullptr;       // device: the tag of the current token
     int merge_blocks_per_cu[3] = {-1, -1, -1};   // occupancy of attn_wo_kernel<16|32|64> at the LDS size below
     size_t merge_lds[3] = {0, 0, 0};
     unsigned* attn_counter = nullptr;      // device: arrivals of the attention workgroups
@@ -212,6 +216,10 @@ int rama_ctx_create(int device, void* hip_stream, rama_ctx** out) {
     HIPCHK(hipMalloc(&c->argmax_result, sizeof(int)));
     HIPCHK(hipMalloc(&c->attn_counter, sizeof(unsigned)));
     HIPCHK(hipMemset(c->attn_counter, 0, sizeof(unsigned)));
+    HIPCHK(hipMalloc(&c->fused_hand, (size_t)kFusedMaxLayers * fused_hand_words(kFusedMaxDim, kFusedMaxHidden) * sizeof(tagged_t)));
+    HIPCHK(hipMemset(c->fused_hand, 0, (size_t)kFusedMaxLayers * fused_hand_words(kFusedMaxDim, kFusedMaxHidden) * sizeof(tagged_t)));
+    HIPCHK(hipMalloc(&c->fused_epoch, sizeof(unsigned)));
+    HIPCHK(hipMemset(c->fused_epoch, 0, sizeof(unsigned)));
     HIPCHK(hipMalloc(&c->pbar, 4 * sizeof(unsigned long long)));
     HIPCHK(hipMemset(c->pbar, 0, 4 * sizeof(unsigned long long)));
     HIPCHK(hipHostMalloc(&c->pinned_int, sizeof(int) * 4));
@@ -256,7 +264,7 @@ int rama_ctx_destroy(rama_ctx* c) {
     hipStreamSynchronize(c->stream);
     drop_graph(c);
     for (auto e : c->kp.ev) hipEventDestroy(e);
-    hipFree(c->ctl); hipFree(c->out); hipFree(c->forced); hipFree(c->argmax_result); hipFree(c->pbar); hipFree(c->attn_counter); hipFree(c->attn_part);
+    hipFree(c->ctl); hipFree(c->out); hipFree(c->forced); hipFree(c->argmax_result); hipFree(c->pbar); hipFree(c->attn_counter); hipFree(c->attn_part); hipFree(c->fused_hand); hipFree(c->fused_epoch);
     for (int i = 0; i < 2; i++) { hipFree(c->topp_keys[i]); hipFree(c->topp_vals[i]); }
     hipFree(c->topp_prefix); hipFree(c->topp_m); hipFree(c->topp_err); hipFree(c->pf_blob); hipFree(c->pc_blob); if (c->ring) hipHostFree(c->ring);
     hipFree(c->topp_bp); hipFree(c->topp_bi); hipFree(c->topp_bcount);
@@ -862,6 +870,46 @@ static int try_launch_attn_wo(rama_ctx* c, const rama_config* cfg, const rama_we
     return 0;
 }
 
+// a whole stage as two launches (layer_fused.hpp): embedding + counter reset, then every layer and the classifier chained by
+// arrival counters.  *launched = false: the shape is not one it takes, the caller enqueues the separate launches.
+static bool fused_wanted(const rama_ctx* c, int dim) { return c->tune_fused < 0 ? dim <= 1024 : c->tune_fused != 0; }
+static int try_launch_fused(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s, const rama_stage* st, bool* launched) {
+    *launched = false;
+    const int dim = cfg->dim, hidden = cfg->hidden_dim, H = cfg->n_heads, hs = dim / H, V = cfg->vocab_size;
+    const int nl = st->layer_end - st->layer_begin;
+    if (nl <= 0 && !st->do_cls) return 0;
+    if (dim > kFusedMaxDim || hidden > kFusedMaxHidden || nl > kFusedMaxLayers || dim % 4 || hidden % 4 || hs % 4 || hs > 256 || cfg->seq_len % 4) return 0;
+    const int G = hs <= 64 ? 16 : (hs <= 128 ? 32 : 64);
+    const size_t lds = (size_t)fused_lds_floats(G, cfg->seq_len, dim, hidden) * sizeof(float);
+    if (lds > 64 * 1024) return 0;
+    if ((double)hidden * dim * 4.0 >= 2147483648.0 || (double)V * dim * 4.0 >= 2147483648.0 || (double)cfg->seq_len * dim * 4.0 >= 2147483648.0) return 0;
+    if (!aligned16(s->x) || !aligned16(s->q) || !aligned16(s->xb) || !aligned16(s->hb) || !aligned16(s->key_cache) || !aligned16(s->value_cache) ||
+        !aligned16(w->wq) || !aligned16(w->wk) || !aligned16(w->wv) || !aligned16(w->wo) || !aligned16(w->w1) || !aligned16(w->w2) || !aligned16(w->w3) ||
+        !aligned16(w->wcls) || !aligned16(w->rms_att_weight) || !aligned16(w->rms_ffn_weight) || !aligned16(w->rms_final_weight)) return 0;
+    hipLaunchKernelGGL(fused_embed_kernel, dim3(st->do_embed ? (dim + 255) / 256 : 1), dim3(256), 0, c->stream, s->x, w->token_embedding_table, (const Ctl*)c->ctl, dim,
+                       st->do_embed ? 1 : 0, c->fused_epoch);
+    LAUNCHCHK();
+    auto wgs = [](int units) { return (units + kPWaves - 1) / kPWaves; };
+    FusedParams a{};
+    a.dim = dim; a.hidden = hidden; a.n_heads = H; a.seq_len = cfg->seq_len; a.vocab = V; a.n_layers = nl; a.do_cls = st->do_cls ? 1 : 0;
+    a.wq = w->wq; a.wk = w->wk; a.wv = w->wv; a.wo = w->wo; a.w1 = w->w1; a.w3 = w->w3; a.w2 = w->w2;
+    a.g_att = w->rms_att_weight; a.g_ffn = w->rms_ffn_weight; a.g_final = w->rms_final_weight; a.wcls = w->wcls;
+    a.x = s->x; a.q = s->q; a.k = s->k; a.v = s->v; a.xb = s->xb; a.hb = s->hb; a.logits = s->logits;
+    a.kc = s->key_cache; a.vc = s->value_cache; a.fr = w->freq_cis_real; a.fi = w->freq_cis_imag;
+    a.ctl = c->ctl; a.hand = c->fused_hand; a.epoch = c->fused_epoch; a.err = c->pbar + 1;
+    a.nA = wgs(3 * ((dim + 3) / 4)); a.nC = wgs((dim + 3) / 4); a.nD = wgs((hidden + 1) / 2); a.nE = a.nC;
+    const long grid = (long)nl * (a.nA + H + a.nC + a.nD + a.nE) + (st->do_cls ? wgs((V + 3) / 4) : 0);
+    const bool cd2 = dim <= 512;
+#define RAMA_FUSED(G_, CD_) hipLaunchKernelGGL((stage_fused_kernel<G_, CD_, 4>), dim3((unsigned)grid), dim3(kPThreads), lds, c->stream, a)
+    if (G == 16) { if (cd2) RAMA_FUSED(16, 2); else RAMA_FUSED(16, 4); }
+    else if (G == 32) { if (cd2) RAMA_FUSED(32, 2); else RAMA_FUSED(32, 4); }
+    else { if (cd2) RAMA_FUSED(64, 2); else RAMA_FUSED(64, 4); }
+#undef RAMA_FUSED
+    LAUNCHCHK();
+    *launched = true;
+    return 0;
+}
+
 // infer.rs:8-53 op by op in the reference's rounding order (ref_order.hpp); leaves EVERY RunState
 // buffer as the CPU path does (x, xb, xb2, hb, hb2, q, k, v, att, logits, caches)
 static int enqueue_stage_ref(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s, const rama_stage* st) {
@@ -998,6 +1046,11 @@ static int enqueue_stage(rama_ctx* c, const rama_config* cfg, const rama_weights
     }
     const int dim = cfg->dim, hidden = cfg->hidden_dim, hs = dim / cfg->n_heads;
     const size_t dd = (size_t)dim * dim, hd = (size_t)hidden * dim;
+    if (fused_wanted(c, dim) && !c->split_attn && !c->small_attn && c->kp.kernel_id < 0) {
+        bool launched = false;
+        const int rc = try_launch_fused(c, cfg, w, s, st, &launched);
+        if (rc || launched) return rc;
+    }
     const float* w13i = (st->layer_end > st->layer_begin && (double)hidden * dim * 8.0 < 2147483648.0) ? rama_internal_w13_lookup(w->w1, w->w3) : nullptr;
     if (st->do_embed) {
         hipLaunchKernelGGL(embed_kernel, dim3((dim + 255) / 256), dim3(256), 0, c->stream, s->x, w->token_embedding_table, (const Ctl*)c->ctl, 0, dim);
@@ -2177,6 +2230,13 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
     if (!strcmp(key, "prefill")) {
         REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: prefill must be 0 or 1");
         c->tune_prefill = value;
+        return 0;
+    }
+    if (!strcmp(key, "fused")) {
+        REQUIRE(value >= -1 && value <= 1, RAMA_EINVAL, "set_tuning: fused must be -1, 0 or 1");
+        c->tune_fused = value;
+        hipStreamSynchronize(c->stream);
+        drop_graph(c);
         return 0;
     }
     if (!strcmp(key, "merge")) {
