@@ -42,13 +42,16 @@ struct FusedParams {
 };
 constexpr unsigned long long kFusedErr = 0x3000ull;
 constexpr int kFusedMaxLayers = 128, kFusedMaxDim = 1024, kFusedMaxHidden = 8192;
+constexpr size_t kFusedSoloLds = 88 * 1024;       // more than half a CU's LDS: one workgroup per CU
 __host__ __device__ constexpr size_t fused_hand_words(int dim, int hidden) { return (size_t)6 * dim + hidden; }
 
 #ifdef RAMA_FUSED_STAMPS      // tools/fused_stamps.hip: where a layer's time goes (100 MHz clock), first workgroup of every phase
 __device__ unsigned long long g_fused_stamps[8][6][8];
 #define FUSED_STAMP(first, layer, phase, i) do { if ((first) && threadIdx.x == 0 && (layer) < 8) g_fused_stamps[layer][phase][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define FUSED_STAMP_MAX(layer, phase) do { if (threadIdx.x == 0 && (layer) < 8) atomicMax(&g_fused_stamps[layer][phase][3], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
 #else
 #define FUSED_STAMP(first, layer, phase, i) do { } while (0)
+#define FUSED_STAMP_MAX(layer, phase) do { } while (0)
 #endif
 
 // the launch before: x = the token's embedding row (infer.rs:13-14), the next epoch
@@ -110,14 +113,14 @@ __device__ __forceinline__ void fused_fetch(const tagged_t* src, const float* pl
     }
 }
 
-// one wave's weights: 4 rows, the first CH 256-float chunks of each -- rows r0..r0+3 of Wa, or (PAIR) rows r0, r0+1 of Wa and
-// of Wb interleaved (0/2 = Wa, 1/3 = Wb)
-template <int CH, bool NORM, bool PAIR>
+// one wave's weights: R rows, the first CH 256-float chunks of each -- rows r0..r0+R-1 of Wa, or (PAIR, R = 4) rows r0, r0+1 of
+// Wa and of Wb interleaved (0/2 = Wa, 1/3 = Wb)
+template <int R, int CH, bool NORM, bool PAIR>
 struct FusedUnit {
     __amdgpu_buffer_rsrc_t ra, rb, rg;
-    unsigned rowoff[4], kbytes;
+    unsigned rowoff[R], kbytes;
     int nch, lane;
-    f4 w[4][CH], gv[CH];
+    f4 w[R][CH], gv[CH];
     __device__ __forceinline__ unsigned kb_of(int c) const { const unsigned o = (unsigned)(c * 1024 + lane * 16); return (c < nch && o < kbytes) ? o : kOOB; }
     __device__ __forceinline__ f4 wload(int s, unsigned kb) const {
         const unsigned o = (kb == kOOB || rowoff[s] == kOOB) ? kOOB : rowoff[s] + kb;
@@ -132,37 +135,42 @@ struct FusedUnit {
         rb = make_rsrc(PAIR ? Wb : Wa, (unsigned)rows * kbytes);
         rg = make_rsrc(NORM ? gain : Wa, kbytes);
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
+        for (int s = 0; s < R; s++) {
             const int r = PAIR ? r0 + (s >> 1) : r0 + s;
             rowoff[s] = (valid && r < rows) ? (unsigned)r * kbytes : kOOB;
         }
 #pragma unroll
         for (int j = 0; j < CH; j++) {
 #pragma unroll
-            for (int s = 0; s < 4; s++) w[s][j] = wload(s, kb_of(j));
+            for (int s = 0; s < R; s++) w[s][j] = wload(s, kb_of(j));
             if (NORM) gv[j] = ld_c(rg, kb_of(j));
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    // the four dot products with x_s (LDS, K floats); NORM: x is scaled by the gain here and `scale` = 1 / sqrt(mean(x^2) + eps)
+    // the R dot products with x_s (LDS, K floats); NORM: x is scaled by the gain here and `scale` = 1 / sqrt(mean(x^2) + eps)
     // comes back (cpu.rs:99-117)
-    __device__ __forceinline__ void dots(const float* x_s, int K, float (&acc)[4], float& scale) {
+    __device__ __forceinline__ void dots(const float* x_s, int K, float (&acc)[R], float& scale) {
         float ss = 0.0f;
 #pragma unroll
-        for (int s = 0; s < 4; s++) acc[s] = 0.0f;
-        auto xload = [&](int c) { const f4 z = {0.f, 0.f, 0.f, 0.f}; return kb_of(c) == kOOB ? z : *reinterpret_cast<const f4*>(x_s + c * 256 + lane * 4); };
+        for (int s = 0; s < R; s++) acc[s] = 0.0f;
+        auto xload = [&](int c) {      // no branch: a lane past the end reads float 0.. and drops it
+            const f4 z = {0.f, 0.f, 0.f, 0.f};
+            const bool in = kb_of(c) != kOOB;
+            const f4 v = *reinterpret_cast<const f4*>(x_s + (in ? c * 256 + lane * 4 : 0));
+            return in ? v : z;
+        };
 #pragma unroll
         for (int j = 0; j < CH; j++) {
             f4 xv = xload(j);
             if (NORM) { ss = dot4(xv, xv, ss); xv = xv * gv[j]; }
 #pragma unroll
-            for (int s = 0; s < 4; s++) acc[s] = dot4(w[s][j], xv, acc[s]);
+            for (int s = 0; s < R; s++) acc[s] = dot4(w[s][j], xv, acc[s]);
         }
-        for (int c0 = CH; c0 < nch; c0 += CH) {        // rows wider than the requested part (W2 of the wider models)
+        for (int c0 = CH; c0 < nch; c0 += CH) {        // rows wider than the requested part
 #pragma unroll
             for (int j = 0; j < CH; j++) {
 #pragma unroll
-                for (int s = 0; s < 4; s++) w[s][j] = wload(s, kb_of(c0 + j));
+                for (int s = 0; s < R; s++) w[s][j] = wload(s, kb_of(c0 + j));
                 if (NORM) gv[j] = ld_c(rg, kb_of(c0 + j));
             }
 #pragma unroll
@@ -170,11 +178,11 @@ struct FusedUnit {
                 f4 xv = xload(c0 + j);
                 if (NORM) { ss = dot4(xv, xv, ss); xv = xv * gv[j]; }
 #pragma unroll
-                for (int s = 0; s < 4; s++) acc[s] = dot4(w[s][j], xv, acc[s]);
+                for (int s = 0; s < R; s++) acc[s] = dot4(w[s][j], xv, acc[s]);
             }
         }
 #pragma unroll
-        for (int s = 0; s < 4; s++) acc[s] = wave_sum(acc[s]);
+        for (int s = 0; s < R; s++) acc[s] = wave_sum(acc[s]);
         scale = 1.0f;
         if (NORM) scale = rms_scale(wave_sum(ss), K);
     }
@@ -326,9 +334,9 @@ __host__ __device__ constexpr int fused_lds_floats(int G, int seq_len, int dim, 
     return attn > vec ? attn : vec;
 }
 
-// G: lanes per cache row in the attention phase (head_size / 4 rounded up to 16 | 32 | 64); CD / CHH: chunks requested ahead of
-// a row as wide as dim / hidden_dim
-template <int G, int CD, int CHH>
+// G: lanes per cache row in the attention phase (head_size / 4 rounded up to 16 | 32 | 64); CD: chunks requested ahead of a row
+// as wide as dim; a W2 unit is RE rows, CHH chunks of each requested ahead (4 x 4 up to hidden_dim 1024, 2 x 8 beyond)
+template <int G, int CD, int RE, int CHH>
 __global__ __launch_bounds__(kPThreads, 4) void stage_fused_kernel(FusedParams a) {
     extern __shared__ float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -340,7 +348,7 @@ __global__ __launch_bounds__(kPThreads, 4) void stage_fused_kernel(FusedParams a
     float acc[4], scale;
     if (layer >= a.n_layers) {                         // ---- infer.rs:49-51: logits = Wcls . rmsnorm(x)
         const int r0 = ((blockIdx.x - a.n_layers * per_layer) * kPWaves + wave) * 4;
-        FusedUnit<CD, true, false> u;
+        FusedUnit<4, CD, true, false> u;
         u.request(a.wcls, nullptr, a.g_final, a.vocab, dim, r0, r0 < a.vocab);
         const unsigned epoch = *a.epoch;
         const tagged_t* hlast = a.hand + (size_t)(a.n_layers ? a.n_layers - 1 : 0) * hw;
@@ -360,7 +368,7 @@ __global__ __launch_bounds__(kPThreads, 4) void stage_fused_kernel(FusedParams a
     if (b < a.nA) {                                    // ---- infer.rs:19-33: rmsnorm, Wq | Wk | Wv, RoPE, cache append
         const int upm = (dim + 3) >> 2, un = b * kPWaves + wave, m = un / upm, r0 = (un - m * upm) * 4;
         FUSED_STAMP(b == 0, layer, 0, 0);
-        FusedUnit<CD, true, false> u;
+        FusedUnit<4, CD, true, false> u;
         u.request((m == 0 ? a.wq : (m == 1 ? a.wk : a.wv)) + layer * dd, nullptr, a.g_att + (size_t)layer * dim, dim, dim, r0, m < 3);
         const unsigned epoch = *a.epoch;
         const int pos = a.ctl->pos;
@@ -386,6 +394,7 @@ __global__ __launch_bounds__(kPThreads, 4) void stage_fused_kernel(FusedParams a
             if (last) { float* o = m == 0 ? a.q : (m == 1 ? a.k : a.v); o[r] = va; o[r + 1] = vb; }
         }
         FUSED_STAMP(b == 0, layer, 0, 2);
+        FUSED_STAMP_MAX(layer, 0);
         return;
     }
     b -= a.nA;
@@ -396,29 +405,32 @@ __global__ __launch_bounds__(kPThreads, 4) void stage_fused_kernel(FusedParams a
         fused_attention<G>(dim, H, a.seq_len, kc, vc, b, a.ctl->pos, t_qkv, t_in ? t_in + dim - 1 : nullptr, cur, lds, t_xb, last ? a.xb : nullptr, epoch,
                            a.err, layer);
         FUSED_STAMP(b == 0, layer, 1, 2);
+        FUSED_STAMP_MAX(layer, 1);
         return;
     }
     b -= H;
     if (b < a.nC) {                                    // ---- infer.rs:35-37: xc = x + Wo . xb
         const int r0 = (b * kPWaves + wave) * 4;
         FUSED_STAMP(b == 0, layer, 2, 0);
-        FusedUnit<CD, false, false> u;
+        FusedUnit<4, CD, false, false> u;
         u.request(a.wo + layer * dd, nullptr, nullptr, dim, dim, r0, r0 < dim);
         const unsigned epoch = *a.epoch;
         fused_fetch(t_xb, nullptr, dim, t_qkv + 3 * dim - 1, epoch, lds, a.err);
         FUSED_STAMP(b == 0, layer, 2, 1);
         float resid = 0.0f;                            // complete since before this layer's first phase
         if (lane < 4 && r0 + lane < dim) resid = t_in ? get_tagged(t_in + r0 + lane) : a.x[r0 + lane];
+        __builtin_amdgcn_sched_barrier(0);
         u.dots(lds, dim, acc, scale);
         if (lane < 4 && r0 + lane < dim) put_tagged(t_xc + r0 + lane, resid + pick<4>(acc, lane), epoch);
         FUSED_STAMP(b == 0, layer, 2, 2);
+        FUSED_STAMP_MAX(layer, 2);
         return;
     }
     b -= a.nC;
     if (b < a.nD) {                                    // ---- infer.rs:39-45: rmsnorm, W1 | W3, SiLU * gate
         const int r0 = (b * kPWaves + wave) * 2;
         FUSED_STAMP(b == 0, layer, 3, 0);
-        FusedUnit<CD, true, true> u;
+        FusedUnit<4, CD, true, true> u;
         u.request(a.w1 + layer * hd, a.w3 + layer * hd, a.g_ffn + (size_t)layer * dim, hidden, dim, r0, r0 < hidden);
         const unsigned epoch = *a.epoch;
         fused_fetch(t_xc, nullptr, dim, t_xb + dim - 1, epoch, lds, a.err);
@@ -431,26 +443,31 @@ __global__ __launch_bounds__(kPThreads, 4) void stage_fused_kernel(FusedParams a
             if (last) a.hb[r0 + lane] = g;
         }
         FUSED_STAMP(b == 0, layer, 3, 2);
+        FUSED_STAMP_MAX(layer, 3);
         return;
     }
     b -= a.nD;
     {                                                  // ---- infer.rs:46-47: xe = xc + W2 . hb
-        const int r0 = (b * kPWaves + wave) * 4;
+        const int r0 = (b * kPWaves + wave) * RE;
         FUSED_STAMP(b == 0, layer, 4, 0);
-        FusedUnit<CHH, false, false> u;
+        FusedUnit<RE, CHH, false, false> u;
         u.request(a.w2 + layer * hd, nullptr, nullptr, dim, hidden, r0, r0 < dim);
         const unsigned epoch = *a.epoch;
         fused_fetch(t_hb, nullptr, hidden, t_xc + dim - 1, epoch, lds, a.err);
         FUSED_STAMP(b == 0, layer, 4, 1);
         float resid = 0.0f;                            // complete since before the phase before this one
-        if (lane < 4 && r0 + lane < dim) resid = get_tagged(t_xc + r0 + lane);
-        u.dots(lds, hidden, acc, scale);
-        if (lane < 4 && r0 + lane < dim) {
-            const float o = resid + pick<4>(acc, lane);
+        if (lane < RE && r0 + lane < dim) resid = get_tagged(t_xc + r0 + lane);
+        __builtin_amdgcn_sched_barrier(0);
+        float accE[RE];
+        u.dots(lds, hidden, accE, scale);
+        FUSED_STAMP(b == 0, layer, 4, 5);
+        if (lane < RE && r0 + lane < dim) {
+            const float o = resid + pick<RE>(accE, lane);
             put_tagged(t_xe + r0 + lane, o, epoch);
             if (last) a.x[r0 + lane] = o;
         }
         FUSED_STAMP(b == 0, layer, 4, 2);
+        FUSED_STAMP_MAX(layer, 4);
     }
 }
 

@@ -121,7 +121,10 @@ struct rama_ctx {
     int tune_prefill = 1;                  // 1: rama_generate_greedy runs the forced prompt positions through rama_prefill
     int tune_merge = -1;                   // attention + Wo in one launch: 1 on, 0 off, -1 by model size (on for dim <= 1024:
                                            // +4..8 % at the stories shapes; at llama2-7B +0.9 % short / -2.5 % long contexts)
-    int tune_fused = 0;                    // a stage's layers (+ classifier) as one launch (layer_fused.hpp): 1 on, 0 off, -1 on for dim <= 1024
+    int tune_fused = -1;                   // a stage's layers (+ classifier) as one launch (layer_fused.hpp): 1 on, 0 off, -1 on for dim <= 1024
+                                           // (stories15M +4 %, stories110M +25 % tokens/s over the separate launches)
+    int tune_fused_solo = -1;              // its workgroups alone on their CU (LDS request padded): 1, 0, -1 = for dim > 512 (stories110M: 216 -> 200 us
+                                           // per token, a consumer's polls do not queue behind a neighbour's weight requests; stories15M: 89 -> 92)
     tagged_t* fused_hand = nullptr;        // device: its hand-off vectors (tagged words), room for the largest shape it takes
     unsigned* fused_epoch = nullptr;       // device: the tag of the current token
     int merge_blocks_per_cu[3] = {-1, -1, -1};   // occupancy of attn_wo_kernel<16|32|64> at the LDS size below
@@ -228,6 +231,11 @@ int rama_ctx_create(int device, void* hip_stream, rama_ctx** out) {
     HIPCHK(hipGetDeviceProperties(&prop, device));
     c->cu_count = prop.multiProcessorCount;
     // parity mode's attention keeps two product tiles + the scores of a whole context in LDS: more than the 64 KiB a kernel gets by default
+#define RAMA_FUSED_ATTR(G_, CD_) \
+    HIPCHK(hipFuncSetAttribute((const void*)stage_fused_kernel<G_, CD_, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedSoloLds)); \
+    HIPCHK(hipFuncSetAttribute((const void*)stage_fused_kernel<G_, CD_, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedSoloLds));
+    RAMA_FUSED_ATTR(16, 2) RAMA_FUSED_ATTR(16, 4) RAMA_FUSED_ATTR(32, 2) RAMA_FUSED_ATTR(32, 4) RAMA_FUSED_ATTR(64, 2) RAMA_FUSED_ATTR(64, 4)
+#undef RAMA_FUSED_ATTR
     HIPCHK(hipFuncSetAttribute((const void*)attention_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnChainMaxLds));
     HIPCHK(hipFuncSetAttribute((const void*)attention_chain_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnChainMaxLds));
     HIPCHK(hipFuncSetAttribute((const void*)attention_chain_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnChainMaxLds));
@@ -880,8 +888,9 @@ static int try_launch_fused(rama_ctx* c, const rama_config* cfg, const rama_weig
     if (nl <= 0 && !st->do_cls) return 0;
     if (dim > kFusedMaxDim || hidden > kFusedMaxHidden || nl > kFusedMaxLayers || dim % 4 || hidden % 4 || hs % 4 || hs > 256 || cfg->seq_len % 4) return 0;
     const int G = hs <= 64 ? 16 : (hs <= 128 ? 32 : 64);
-    const size_t lds = (size_t)fused_lds_floats(G, cfg->seq_len, dim, hidden) * sizeof(float);
+    size_t lds = (size_t)fused_lds_floats(G, cfg->seq_len, dim, hidden) * sizeof(float);
     if (lds > 64 * 1024) return 0;
+    if (c->tune_fused_solo < 0 ? dim > 512 : c->tune_fused_solo != 0) lds = kFusedSoloLds;
     if ((double)hidden * dim * 4.0 >= 2147483648.0 || (double)V * dim * 4.0 >= 2147483648.0 || (double)cfg->seq_len * dim * 4.0 >= 2147483648.0) return 0;
     if (!aligned16(s->x) || !aligned16(s->q) || !aligned16(s->xb) || !aligned16(s->hb) || !aligned16(s->key_cache) || !aligned16(s->value_cache) ||
         !aligned16(w->wq) || !aligned16(w->wk) || !aligned16(w->wv) || !aligned16(w->wo) || !aligned16(w->w1) || !aligned16(w->w2) || !aligned16(w->w3) ||
@@ -897,13 +906,17 @@ static int try_launch_fused(rama_ctx* c, const rama_config* cfg, const rama_weig
     a.x = s->x; a.q = s->q; a.k = s->k; a.v = s->v; a.xb = s->xb; a.hb = s->hb; a.logits = s->logits;
     a.kc = s->key_cache; a.vc = s->value_cache; a.fr = w->freq_cis_real; a.fi = w->freq_cis_imag;
     a.ctl = c->ctl; a.hand = c->fused_hand; a.epoch = c->fused_epoch; a.err = c->pbar + 1;
-    a.nA = wgs(3 * ((dim + 3) / 4)); a.nC = wgs((dim + 3) / 4); a.nD = wgs((hidden + 1) / 2); a.nE = a.nC;
+    const bool wide = hidden > 1024;             // W2 units: 2 rows x 8 chunks ahead instead of 4 x 4
+    a.nA = wgs(3 * ((dim + 3) / 4)); a.nC = wgs((dim + 3) / 4); a.nD = wgs((hidden + 1) / 2); a.nE = wide ? wgs((dim + 1) / 2) : a.nC;
     const long grid = (long)nl * (a.nA + H + a.nC + a.nD + a.nE) + (st->do_cls ? wgs((V + 3) / 4) : 0);
     const bool cd2 = dim <= 512;
-#define RAMA_FUSED(G_, CD_) hipLaunchKernelGGL((stage_fused_kernel<G_, CD_, 4>), dim3((unsigned)grid), dim3(kPThreads), lds, c->stream, a)
+#define RAMA_FUSED_(G_, CD_) do { if (wide) hipLaunchKernelGGL((stage_fused_kernel<G_, CD_, 2, 8>), dim3((unsigned)grid), dim3(kPThreads), lds, c->stream, a); \
+                                  else hipLaunchKernelGGL((stage_fused_kernel<G_, CD_, 4, 4>), dim3((unsigned)grid), dim3(kPThreads), lds, c->stream, a); } while (0)
+#define RAMA_FUSED(G_, CD_) RAMA_FUSED_(G_, CD_)
     if (G == 16) { if (cd2) RAMA_FUSED(16, 2); else RAMA_FUSED(16, 4); }
     else if (G == 32) { if (cd2) RAMA_FUSED(32, 2); else RAMA_FUSED(32, 4); }
     else { if (cd2) RAMA_FUSED(64, 2); else RAMA_FUSED(64, 4); }
+#undef RAMA_FUSED_
 #undef RAMA_FUSED
     LAUNCHCHK();
     *launched = true;
@@ -2232,9 +2245,9 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
         c->tune_prefill = value;
         return 0;
     }
-    if (!strcmp(key, "fused")) {
-        REQUIRE(value >= -1 && value <= 1, RAMA_EINVAL, "set_tuning: fused must be -1, 0 or 1");
-        c->tune_fused = value;
+    if (!strcmp(key, "fused") || !strcmp(key, "fused_solo")) {
+        REQUIRE(value >= -1 && value <= 1, RAMA_EINVAL, "set_tuning: fused / fused_solo must be -1, 0 or 1");
+        if (key[5]) c->tune_fused_solo = value; else c->tune_fused = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
         return 0;
