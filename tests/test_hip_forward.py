@@ -276,6 +276,81 @@ def test_stage_split_equals_whole(dev):
         e.free(); e.model.free()
 
 
+@pytest.mark.parametrize("shape,solo", [
+    ((64, 176, 2, 4, 4, 96, 300, True), -1),          # a quarter of a chunk per row
+    ((288, 768, 3, 6, 6, 512, 64, True), -1),          # stories15M's layer: 2 chunks, the second nearly empty
+    ((288, 768, 3, 6, 6, 512, 64, True), 1),           # ... one workgroup per CU
+    ((768, 2048, 2, 12, 12, 300, 40, False), -1),      # stories110M's layer: 2-row W2 units, 8 chunks ahead, alone on the CU
+    ((768, 2048, 2, 12, 12, 300, 40, False), 0),       # ... two workgroups per CU
+    ((512, 1408, 2, 2, 2, 200, 24, True), -1),         # head_size 256 (64 lanes per cache row), W2 rows of 5.5 chunks
+    ((1024, 2752, 1, 8, 8, 128, 16, True), -1),        # head_size 128; W2 rows wider than what is requested ahead (11 chunks)
+    ((132, 360, 2, 3, 3, 77, 20, False), -1),          # head_size 44, ragged everything
+])
+def test_one_launch_stage_equals_separate_launches(dev, shape, solo):
+    """layer_fused.hpp (tuning "fused", default for dim <= 1024): every layer and the classifier of a step in one launch, the
+    phases chained through tagged vectors.  Against the oracle -- greedy tokens, logits, caches -- and against the separate
+    launches: every run-state buffer the two leave behind (x, xb, hb, q, k, v, logits, caches) agrees within the bar.  Eager
+    and replayed from a graph, and run twice over (the second pass meets the first pass's tags in every vector)."""
+    import rama_amd
+    from rama_amd._lib import check
+    cfg = O.Config(*shape)
+    w = S.synth_weights(cfg, seed=31)
+    prompt, steps = [3, 1, 4], min(cfg.seq_len, 24)
+    orc = O.Oracle(cfg, w)
+    want = orc.generate_greedy(prompt, steps)
+    rcfg, ws, wv, rs, rsv = gpu_views(dev, cfg, w)
+    state = {}
+    try:
+        check(dev.lib.rama_set_tuning(dev.ctx, b"fused_solo", solo))
+        for fused, graph in ((0, 0), (1, 0), (1, 1), (1, 0)):
+            check(dev.lib.rama_set_tuning(dev.ctx, b"fused", fused))
+            dev.lib.rama_set_graph_mode(dev.ctx, graph)
+            got = rama_amd.generate_greedy_device(rcfg, prompt, steps, wv, rsv, dev)
+            assert got == want, (fused, graph)
+            bufs = {b: dev.download(getattr(rsv, b)) for b in ("x", "xb", "hb", "q", "k", "v", "logits", "key_cache", "value_cache")}
+            assert np.abs(bufs["logits"] - orc.s["logits"]).max() <= LOGIT_ATOL
+            for b in ("key_cache", "value_cache"):
+                assert np.abs(bufs[b] - orc.s[b]).max() <= STATE_ATOL, b
+            if fused == 0:
+                state = bufs
+            else:
+                for b, v in bufs.items():
+                    assert np.abs(v - state[b]).max() <= (LOGIT_ATOL if b == "logits" else STATE_ATOL), (b, fused, graph)
+    finally:
+        dev.lib.rama_set_graph_mode(dev.ctx, 0)
+        check(dev.lib.rama_set_tuning(dev.ctx, b"fused", -1))
+        check(dev.lib.rama_set_tuning(dev.ctx, b"fused_solo", -1))
+    rs.free(); ws.free()
+
+
+def test_one_launch_stage_on_layer_ranges(dev):
+    """the one-launch stage on pipeline stages: [0,2) without classifier, [2,L) without embedding, x handed over, against
+    the whole model's separate launches and the oracle"""
+    import rama_amd
+    from rama_amd._lib import rama_stage, check
+    cfg, w, g = load_case("synth_d288_h6")
+    rcfg = to_rama_cfg(cfg)
+    seed, rope = int(g["seed"]), (g["freq_cis_real"], g["freq_cis_imag"])
+    full = rama_amd.Engine(dev, rama_amd.Model.synth(dev, rcfg, seed, rope=rope))
+    s0 = rama_amd.Engine(dev, rama_amd.Model.synth(dev, rcfg, seed, rama_stage(0, 2, 1, 0), rope))
+    s1 = rama_amd.Engine(dev, rama_amd.Model.synth(dev, rcfg, seed, rama_stage(2, cfg.n_layers, 0, 1), rope))
+    orc = O.Oracle(cfg, w)
+    try:
+        for pos, tok in enumerate(g["tokens"].tolist()[:12]):
+            check(dev.lib.rama_set_tuning(dev.ctx, b"fused", 0))
+            full.forward(tok, pos)
+            check(dev.lib.rama_set_tuning(dev.ctx, b"fused", 1))
+            s0.forward(tok, pos)
+            s1.set_buffer("x", s0.buffer("x", cfg.dim))
+            s1.forward(tok, pos)
+            assert np.abs(full.logits() - s1.logits()).max() <= LOGIT_ATOL
+            assert np.abs(s1.logits() - orc.forward(tok, pos)).max() <= LOGIT_ATOL
+    finally:
+        check(dev.lib.rama_set_tuning(dev.ctx, b"fused", -1))
+    for e in (full, s0, s1):
+        e.free(); e.model.free()
+
+
 def test_forward_argument_errors(dev):
     import rama_amd
     cfg, w, g = load_case("synth_d64_h4")
@@ -339,14 +414,16 @@ def rnd_vec(n, seed):
 
 # ------------------------------------------------------------------ opt-in launch structures
 
-@pytest.mark.parametrize("key", [b"merge", b"small_attn", b"solo"])
+@pytest.mark.parametrize("key", [b"merge", b"small_attn", b"solo", b"fused"])
 @pytest.mark.parametrize("name,graph", [("synth_d64_h4", False), ("synth_d288_h6", False), ("synth_d288_h6", True),
                                         ("synth_d768_h12", False), ("ckpt_untied", False), ("synth_d128_h1", False),
                                         ("synth_7bshape_l1", False)])
 def test_launch_structures_equal_default_path(dev, name, graph, key):
     """the opt-in launch structures -- rama_set_tuning("merge", 1): attention + Wo as one launch
     (attn_wo.hpp); ("small_attn", 1): 4-wave attention workgroups; ("solo", 1): one wave per row group
-    in every matvec -- must give the oracle's greedy tokens, logits within the bar, the same KV cache."""
+    in every matvec; ("fused", 0): none of them and no one-launch stage either (layer_fused.hpp takes the narrow models
+    by default and is switched off for the other three) -- must give the oracle's greedy tokens, logits within the bar,
+    the same KV cache."""
     import rama_amd
     cfg, w, g = load_case(name)
     prompt = g["tokens"].tolist()[1:4]
@@ -354,13 +431,16 @@ def test_launch_structures_equal_default_path(dev, name, graph, key):
     orc = O.Oracle(cfg, w)
     want = orc.generate_greedy(prompt, steps)
     rcfg, ws, wv, rs, rsv = gpu_views(dev, cfg, w)
-    rama_amd._lib.check(dev.lib.rama_set_tuning(dev.ctx, key, 1))
+    rama_amd._lib.check(dev.lib.rama_set_tuning(dev.ctx, b"fused", 0))
+    if key != b"fused":
+        rama_amd._lib.check(dev.lib.rama_set_tuning(dev.ctx, key, 1))
     dev.lib.rama_set_graph_mode(dev.ctx, int(graph))
     try:
         got = rama_amd.generate_greedy_device(rcfg, prompt, steps, wv, rsv, dev)
     finally:
         dev.lib.rama_set_graph_mode(dev.ctx, 0)
-        rama_amd._lib.check(dev.lib.rama_set_tuning(dev.ctx, key, {b"merge": -1, b"small_attn": -1, b"solo": -1}[key]))
+        rama_amd._lib.check(dev.lib.rama_set_tuning(dev.ctx, key, -1))
+        rama_amd._lib.check(dev.lib.rama_set_tuning(dev.ctx, b"fused", -1))
     assert got == want
     assert np.abs(dev.download(rsv.logits) - orc.s["logits"]).max() <= LOGIT_ATOL
     for buf in ("key_cache", "value_cache"):
@@ -383,6 +463,7 @@ def test_multi_step_graphs_across_the_attention_variant_boundary(dev, graph_step
     rcfg, ws, wv, rs, rsv = gpu_views(dev, cfg, w)
     check(dev.lib.rama_set_tuning(dev.ctx, b"graph_steps", graph_steps))
     check(dev.lib.rama_set_tuning(dev.ctx, b"merge", merge))
+    check(dev.lib.rama_set_tuning(dev.ctx, b"fused", 0))       # the separate launches are what this test is about
     dev.lib.rama_set_graph_mode(dev.ctx, 1)
     try:
         got = rama_amd.generate_greedy_device(rcfg, prompt, steps, wv, rsv, dev)
@@ -390,15 +471,18 @@ def test_multi_step_graphs_across_the_attention_variant_boundary(dev, graph_step
         dev.lib.rama_set_graph_mode(dev.ctx, 0)
         check(dev.lib.rama_set_tuning(dev.ctx, b"graph_steps", -1))
         check(dev.lib.rama_set_tuning(dev.ctx, b"merge", -1))
+        check(dev.lib.rama_set_tuning(dev.ctx, b"fused", -1))
     assert got == want
     rs.free(); ws.free()
 
 
-def test_forward_in_graph_mode_replays_the_same_launches(dev):
+@pytest.mark.parametrize("fused", [0, -1])
+def test_forward_in_graph_mode_replays_the_same_launches(dev, fused):
     """rama_forward with rama_set_graph_mode(1): the step is captured once per (state, stage, attention
     variant) and replayed -- token and position travel through the device cursor -- and must leave
     bit-identical logits and caches, across the position where the launch structure changes (256
-    with attention as its own launch) and for two states in turn"""
+    with attention as its own launch) and for two states in turn.  fused -1: the one-launch stage, whose
+    hand-off vectors the two states share (the epoch moves on with every replay)"""
     import rama_amd
     from rama_amd._lib import check
     cfg = O.Config(64, 176, 2, 4, 4, 96, 300, True)
@@ -406,6 +490,7 @@ def test_forward_in_graph_mode_replays_the_same_launches(dev):
     rng = np.random.default_rng(5)
     toks = [1] + [int(t) for t in rng.integers(0, cfg.vocab_size, 269)]
     check(dev.lib.rama_set_tuning(dev.ctx, b"merge", 0))
+    check(dev.lib.rama_set_tuning(dev.ctx, b"fused", fused))
     try:
         rcfg, ws, wv, rs_a, rsv_a = gpu_views(dev, cfg, w)
         _, ws_b, wv_b, rs_b, rsv_b = gpu_views(dev, cfg, w)
@@ -426,6 +511,7 @@ def test_forward_in_graph_mode_replays_the_same_launches(dev):
     finally:
         dev.lib.rama_set_graph_mode(dev.ctx, 0)
         check(dev.lib.rama_set_tuning(dev.ctx, b"merge", -1))
+        check(dev.lib.rama_set_tuning(dev.ctx, b"fused", -1))
     for r in (rs_a, rs_b, rs_c, ws, ws_b, ws_c):
         r.free()
 
