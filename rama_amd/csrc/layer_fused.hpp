@@ -188,9 +188,32 @@ struct FusedUnit {
     }
 };
 
-// attention for head h (infer.rs:34, the arithmetic of attention_kernel / p_attention): the cache rows before `pos` are an
-// earlier launch's, row `pos` and q are this launch's -- cur = q | k | v of this head in LDS.  Writes xb as tagged words
-// (and plainly, `xb_plain`, for the run state).
+// v[l] (+ | max) v[l ^ 16] and v[l] (+ | max) v[l ^ 32] as VALU lane swaps (gfx950's v_permlane16_swap / v_permlane32_swap): a
+// ds_bpermute shuffle goes through the LDS pipeline and costs its latency every time
+template <int MASK>
+__device__ __forceinline__ void xor_pair(float v, float& a, float& b) {
+    static_assert(MASK == 16 || MASK == 32, "rows or halves");
+    const unsigned u = __float_as_uint(v);
+    if (MASK == 16) { const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false); a = __uint_as_float(r[0]); b = __uint_as_float(r[1]); }
+    else { const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false); a = __uint_as_float(r[0]); b = __uint_as_float(r[1]); }
+}
+template <int MASK> __device__ __forceinline__ float xor_sum(float v) { float a, b; xor_pair<MASK>(v, a, b); return a + b; }
+template <int MASK> __device__ __forceinline__ float xor_max(float v) { float a, b; xor_pair<MASK>(v, a, b); return fmaxf(a, b); }
+// over the 64 / G groups of G lanes each
+template <int G> __device__ __forceinline__ float groups_sum(float v) {
+    if (G <= 16) v = xor_sum<16>(v);
+    if (G <= 32) v = xor_sum<32>(v);
+    return v;
+}
+template <int G> __device__ __forceinline__ float groups_max(float v) {
+    if (G <= 16) v = xor_max<16>(v);
+    if (G <= 32) v = xor_max<32>(v);
+    return v;
+}
+
+// attention for head h (infer.rs:34): the cache rows before `pos` are an earlier launch's and are requested before the wait;
+// row `pos` and q are this launch's -- cur = q | k | v of this head, fetched into LDS here.  Writes xb as tagged words (and
+// plainly, `xb_plain`, for the run state).
 template <int G>
 __device__ __forceinline__ void fused_attention(int dim, int n_heads, int seq_len, const float* kc, const float* vc, int h, int pos,
                                                 const tagged_t* t_qkv, const tagged_t* early, float* cur, float* lds, tagged_t* xb_t, float* xb_plain,
@@ -198,7 +221,6 @@ __device__ __forceinline__ void fused_attention(int dim, int n_heads, int seq_le
     float* s_max = lds;
     float* s_sum = lds + kPWaves;
     float* s_acc = lds + 2 * kPWaves;
-    float* s_att = lds + 2 * kPWaves + kPWaves * G * 4;
     constexpr int U = kPAttnU;
     constexpr int TPW = 64 / G;
     constexpr int TILE = kPWaves * TPW * U;
@@ -214,7 +236,7 @@ __device__ __forceinline__ void fused_attention(int dim, int n_heads, int seq_le
     auto t_of = [&](int base, int u) { return base + (u * kPWaves + wave) * TPW + tg; };
     auto off_of = [&](int t) { return (lane_ok && t < pos) ? (unsigned)t * rowb + col : kOOB; };
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
-    const float div = sqrtf((float)hs);
+    const float inv_div = 1.0f / sqrtf((float)hs);       // one rounding more than cpu.rs:75 (a division): within the fast path's bar
     f4 kt[U], vt[U];
 #pragma unroll
     for (int u = 0; u < U; u++) kt[u] = ld_c(rk, off_of(t_of(0, u)));      // rows of earlier launches: on their way before the wait
@@ -245,87 +267,72 @@ __device__ __forceinline__ void fused_attention(int dim, int n_heads, int seq_le
     const f4 q4 = lane_ok ? *reinterpret_cast<const f4*>(cur + li * 4) : zero;
     const f4 k4 = lane_ok ? *reinterpret_cast<const f4*>(cur + hs + li * 4) : zero;
     const f4 v4 = lane_ok ? *reinterpret_cast<const f4*>(cur + 2 * hs + li * 4) : zero;
-    for (int base = 0; base <= pos; base += TILE) {
-        if (base > 0) {
-#pragma unroll
-            for (int u = 0; u < U; u++) kt[u] = ld_c(rk, off_of(t_of(base, u)));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int t = t_of(base, u);
-            float d = dot4(q4, t == pos ? k4 : kt[u], 0.0f);
-            d = row16_sum(d);
-            if (G == 32) d += __shfl_xor(d, 16);
-            if (G == 64) { d += __shfl_xor(d, 16); d += __shfl_xor(d, 32); }
-            if (li == 0 && t <= pos) s_att[t] = d / div;
-        }
-    }
-    __syncthreads();
-    float mx = -INFINITY;
-    for (int t = tid; t <= pos; t += kPThreads) mx = fmaxf(mx, s_att[t]);
-    mx = wave_max(mx);
-    if (lane == 0) s_max[wave] = mx;
-    __syncthreads();
-    mx = s_max[0];
-#pragma unroll
-    for (int w = 1; w < kPWaves; w++) mx = fmaxf(mx, s_max[w]);
-    float sum = 0.0f;
-    for (int t = tid; t <= pos; t += kPThreads) {
-        const float e = expf(s_att[t] - mx);
-        s_att[t] = e;
-        sum += e;
-    }
-    sum = wave_sum(sum);
-    if (lane == 0) s_sum[wave] = sum;
-    __syncthreads();
-    {
-        float t8[kPWaves];
-#pragma unroll
-        for (int w = 0; w < kPWaves; w++) t8[w] = s_sum[w];
-#pragma unroll
-        for (int n = kPWaves; n > 1; n >>= 1)
-#pragma unroll
-            for (int w = 0; w < n / 2; w++) t8[w] = t8[2 * w] + t8[2 * w + 1];
-        sum = t8[0];
-    }
-    for (int t = tid; t <= pos; t += kPThreads) s_att[t] = s_att[t] / sum;
-    __syncthreads();
+    // Every wave runs the softmax of ITS timesteps on its own -- running maximum m, sum l of exp(score - m), acc = the
+    // values weighted by them (cpu.rs:64-97 rescaled) -- and the eight partial results meet once, behind one barrier.
+    float m = -INFINITY, l = 0.0f;
     f4 acc = zero;
     for (int base = 0; base <= pos; base += TILE) {
         if (base > 0) {
 #pragma unroll
+            for (int u = 0; u < U; u++) kt[u] = ld_c(rk, off_of(t_of(base, u)));
+#pragma unroll
             for (int u = 0; u < U; u++) vt[u] = ld_c(rv, off_of(t_of(base, u)));
             __builtin_amdgcn_sched_barrier(0);
         }
+        float d[U], tm = -INFINITY;
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int t = t_of(base, u);
-            const float a = (t <= pos) ? s_att[t] : 0.0f;
-            const f4 vv = t == pos ? v4 : vt[u];
-            acc.x = fmaf(a, vv.x, acc.x); acc.y = fmaf(a, vv.y, acc.y);
-            acc.z = fmaf(a, vv.z, acc.z); acc.w = fmaf(a, vv.w, acc.w);
+            float dd = dot4(q4, t == pos ? k4 : kt[u], 0.0f);
+            dd = row16_sum(dd);
+            if (G >= 32) dd = xor_sum<16>(dd);
+            if (G == 64) dd = xor_sum<32>(dd);
+            d[u] = dd * inv_div;
+            if (t <= pos) tm = fmaxf(tm, d[u]);
+        }
+        tm = groups_max<G>(tm);
+        const float m_new = fmaxf(m, tm);                       // the same in every lane of the wave
+        if (m_new > -INFINITY) {
+            const float sc = m > -INFINITY ? __expf(m - m_new) : 0.0f;
+            l *= sc; acc.x *= sc; acc.y *= sc; acc.z *= sc; acc.w *= sc;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int t = t_of(base, u);
+                const float e = t <= pos ? __expf(d[u] - m_new) : 0.0f;
+                const f4 vv = t == pos ? v4 : vt[u];
+                l += e;
+                acc.x = fmaf(e, vv.x, acc.x); acc.y = fmaf(e, vv.y, acc.y);
+                acc.z = fmaf(e, vv.z, acc.z); acc.w = fmaf(e, vv.w, acc.w);
+            }
+            m = m_new;
         }
     }
-#pragma unroll
-    for (int m = G; m < 64; m <<= 1) {
-        acc.x += __shfl_xor(acc.x, m); acc.y += __shfl_xor(acc.y, m);
-        acc.z += __shfl_xor(acc.z, m); acc.w += __shfl_xor(acc.w, m);
-    }
+    FUSED_STAMP(h == 0, st_layer, 1, 5);
+    l = groups_sum<G>(l);                      // the wave's 64 / G timestep groups
+    acc.x = groups_sum<G>(acc.x); acc.y = groups_sum<G>(acc.y); acc.z = groups_sum<G>(acc.z); acc.w = groups_sum<G>(acc.w);
+    if (lane == 0) { s_max[wave] = m; s_sum[wave] = l; }
     if (lane < G) *reinterpret_cast<f4*>(s_acc + (wave * G + lane) * 4) = acc;
     __syncthreads();
+    FUSED_STAMP(h == 0, st_layer, 1, 6);
     if (tid < G && tid * 4 < hs) {
-        f4 t8[kPWaves];
+        float M = s_max[0];
 #pragma unroll
-        for (int w = 0; w < kPWaves; w++) t8[w] = *reinterpret_cast<f4*>(s_acc + (w * G + tid) * 4);
+        for (int w = 1; w < kPWaves; w++) M = fmaxf(M, s_max[w]);
+        float L = 0.0f;
+        f4 o4 = zero;
 #pragma unroll
-        for (int n = kPWaves; n > 1; n >>= 1)
-#pragma unroll
-            for (int w = 0; w < n / 2; w++) t8[w] = t8[2 * w] + t8[2 * w + 1];
+        for (int w = 0; w < kPWaves; w++) {
+            const float f = s_max[w] > -INFINITY ? __expf(s_max[w] - M) : 0.0f;
+            const f4 a = *reinterpret_cast<f4*>(s_acc + (w * G + tid) * 4);
+            L = fmaf(s_sum[w], f, L);
+            o4.x = fmaf(a.x, f, o4.x); o4.y = fmaf(a.y, f, o4.y); o4.z = fmaf(a.z, f, o4.z); o4.w = fmaf(a.w, f, o4.w);
+        }
+        const float rl = 1.0f / L;
+        o4.x *= rl; o4.y *= rl; o4.z *= rl; o4.w *= rl;
         const int o = h * hs + tid * 4;
-        put_tagged(xb_t + o, t8[0].x, epoch); put_tagged(xb_t + o + 1, t8[0].y, epoch);
-        put_tagged(xb_t + o + 2, t8[0].z, epoch); put_tagged(xb_t + o + 3, t8[0].w, epoch);
-        if (xb_plain) *reinterpret_cast<f4*>(xb_plain + o) = t8[0];
+        put_tagged(xb_t + o, o4.x, epoch); put_tagged(xb_t + o + 1, o4.y, epoch);
+        put_tagged(xb_t + o + 2, o4.z, epoch); put_tagged(xb_t + o + 3, o4.w, epoch);
+        if (xb_plain) *reinterpret_cast<f4*>(xb_plain + o) = o4;
     }
 }
 
@@ -347,14 +354,16 @@ __global__ __launch_bounds__(kPThreads, 4) void stage_fused_kernel(FusedParams a
     const size_t hw = fused_hand_words(dim, hidden);
     float acc[4], scale;
     if (layer >= a.n_layers) {                         // ---- infer.rs:49-51: logits = Wcls . rmsnorm(x)
-        const int r0 = ((blockIdx.x - a.n_layers * per_layer) * kPWaves + wave) * 4;
-        FusedUnit<4, CD, true, false> u;
+        constexpr int RC = CD == 2 ? 8 : 4;            // rows per unit: as many as fit the registers
+        const int r0 = ((blockIdx.x - a.n_layers * per_layer) * kPWaves + wave) * RC;
+        FusedUnit<RC, CD, true, false> u;
         u.request(a.wcls, nullptr, a.g_final, a.vocab, dim, r0, r0 < a.vocab);
         const unsigned epoch = *a.epoch;
         const tagged_t* hlast = a.hand + (size_t)(a.n_layers ? a.n_layers - 1 : 0) * hw;
         fused_fetch(a.n_layers ? hlast + 5 * dim + hidden : nullptr, a.x, dim, hlast + 5 * dim + hidden - 1, epoch, lds, a.err);
-        u.dots(lds, dim, acc, scale);
-        if (lane < 4 && r0 + lane < a.vocab) a.logits[r0 + lane] = pick<4>(acc, lane) * scale;
+        float accC[RC];
+        u.dots(lds, dim, accC, scale);
+        if (lane < RC && r0 + lane < a.vocab) a.logits[r0 + lane] = pick<RC>(accC, lane) * scale;
         return;
     }
     int b = blockIdx.x - layer * per_layer;

@@ -908,8 +908,8 @@ static int try_launch_fused(rama_ctx* c, const rama_config* cfg, const rama_weig
     a.ctl = c->ctl; a.hand = c->fused_hand; a.epoch = c->fused_epoch; a.err = c->pbar + 1;
     const bool wide = hidden > 1024;             // W2 units: 2 rows x 8 chunks ahead instead of 4 x 4
     a.nA = wgs(3 * ((dim + 3) / 4)); a.nC = wgs((dim + 3) / 4); a.nD = wgs((hidden + 1) / 2); a.nE = wide ? wgs((dim + 1) / 2) : a.nC;
-    const long grid = (long)nl * (a.nA + H + a.nC + a.nD + a.nE) + (st->do_cls ? wgs((V + 3) / 4) : 0);
     const bool cd2 = dim <= 512;
+    const long grid = (long)nl * (a.nA + H + a.nC + a.nD + a.nE) + (st->do_cls ? (cd2 ? wgs((V + 7) / 8) : wgs((V + 3) / 4)) : 0);
 #define RAMA_FUSED_(G_, CD_) do { if (wide) hipLaunchKernelGGL((stage_fused_kernel<G_, CD_, 2, 8>), dim3((unsigned)grid), dim3(kPThreads), lds, c->stream, a); \
                                   else hipLaunchKernelGGL((stage_fused_kernel<G_, CD_, 4, 4>), dim3((unsigned)grid), dim3(kPThreads), lds, c->stream, a); } while (0)
 #define RAMA_FUSED(G_, CD_) RAMA_FUSED_(G_, CD_)

@@ -23,7 +23,7 @@ int main(int argc, char** argv) {
     a.hand = zalloc<tagged_t>((size_t)L * fused_hand_words(dim, hidden)); unsigned* epoch = zalloc<unsigned>(1); a.epoch = epoch; a.err = zalloc<unsigned long long>(1);
     auto wgs = [](int u) { return (u + kPWaves - 1) / kPWaves; };
     a.nA = wgs(3 * (dim / 4)); a.nC = wgs(dim / 4); a.nD = wgs(hidden / 2); a.nE = big ? wgs(dim / 2) : a.nC;
-    const int per_layer = a.nA + H + a.nC + a.nD + a.nE, grid = L * per_layer + wgs(V / 4);
+    const int per_layer = a.nA + H + a.nC + a.nD + a.nE, grid = L * per_layer + (big ? wgs(V / 4) : wgs(V / 8));
     size_t lds = (size_t)fused_lds_floats(16, seq, dim, hidden) * 4;
     if (argc > 3 && atoi(argv[3]) > 0) {        // pad the LDS request: fewer workgroups per CU
         lds = (size_t)atoi(argv[3]) * 1024;
@@ -59,5 +59,7 @@ int main(int argc, char** argv) {
                    (double)(long long)(st[l][p][1] - t0) * 0.01, (double)(long long)(st[l][p][5] - t0) * 0.01,
                    (double)(long long)(st[l][p][2] - t0) * 0.01, (double)(long long)(st[l][p][3] - t0) * 0.01);
     }
+    printf("attention of layer 1, head 0 (us after q | k | v were in LDS): timesteps done %.2f, partial results exchanged %.2f, xb stored %.2f\n",
+           (double)(long long)(st[1][1][5] - st[1][1][1]) * 0.01, (double)(long long)(st[1][1][6] - st[1][1][1]) * 0.01, (double)(long long)(st[1][1][2] - st[1][1][1]) * 0.01);
     return 0;
 }
