@@ -856,12 +856,14 @@ struct ArgmaxParams {
     const int* forced; int* out; int out_cap;
     int* ring;            // optional: host-visible (pinned, mapped) copy of `out`, entry = token + 1, 0 = not produced yet
     const float* emb; float* x; int dim;   // optional next-token embedding gather
+    unsigned* epoch;      // optional: the one-launch stage's epoch (layer_fused.hpp), advanced once per step
 };
 
 // what ends a chained decode step once the sampled index is known (mod.rs:187-201): the result
 // word, the forced prompt token overriding the sample, the output list and the cursor
 __device__ __forceinline__ int finish_step(const ArgmaxParams& p, int idx, int pos, int n_forced, int n_out, int forced_tok) {
     if (p.result) *p.result = idx;          // -1: the top-p sampler found no candidate
+    if (p.epoch) *p.epoch = *p.epoch + 1u;
     int next = idx < 0 ? 0 : idx;
     if (p.ctl) {
         if (forced_tok >= 0) next = forced_tok;

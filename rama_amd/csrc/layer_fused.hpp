@@ -6,12 +6,13 @@
 //   nC  workgroups   xc = x + Wo . xb                                                           reads xb
 //   nD  workgroups   hb = silu(W1 . xn) * (W3 . xn), xn = rmsnorm(xc)                           reads xc
 //   nE  workgroups   xe = xc + W2 . hb                                                          reads hb
-// and after the last layer the classifier's workgroups (rmsnorm folded in), which read the last xe.
+// and after the last layer the classifier's workgroups (rmsnorm folded in), which read the last xe.  The first layer reads
+// the token's embedding row itself (infer.rs:13-14) when the stage starts there.
 // In a matvec workgroup every wave is its own unit -- 4 weight rows, the whole width, as in gemv_rows_solo -- and
 // requests its weights BEFORE the workgroup waits: weights do not depend on activations, so while a layer computes, the
 // rows of the layers behind it are already on their way.
 // Hand-off: THE DATA CARRIES ITS OWN TAG.  Every float that crosses workgroups is one 8-byte (value, epoch) word written
-// with a single write-through store; `epoch` is a device counter the launch before this one increments, and every (layer,
+// with a single write-through store; `epoch` is a device counter incremented after every launch of this kernel, and every (layer,
 // phase) has its own vector, so a word holds either this token's value or a stale tag.  A consumer polls one word from one
 // lane, then the workgroup copies the vector to LDS checking every tag, and repeats the copy until all match.  No counter,
 // no store drain, no arrival atomic: tools/handoff_bench.hip measures 1.3 us per hand-off against 2.4 us for the
@@ -31,7 +32,8 @@ struct FusedParams {
     int dim, hidden, n_heads, seq_len, vocab, n_layers, do_cls;
     const float *wq, *wk, *wv, *wo, *w1, *w3, *w2;      // the stage's first layer; the others follow at the natural strides
     const float *g_att, *g_ffn, *g_final, *wcls;
-    float *x, *q, *k, *v, *xb, *hb, *logits;             // run-state buffers: x is read by the first layer; all are left as the separate launches leave them
+    const float* emb;                                    // the embedding table if the stage starts from the token (infer.rs:13-14), else it starts from x
+    float *x, *q, *k, *v, *xb, *hb, *logits;             // run-state buffers; all are left as the separate launches leave them
     float *kc, *vc;                                      // the stage's cache slabs [layers, seq, dim]
     const float *fr, *fi;
     const Ctl* ctl;
@@ -54,12 +56,9 @@ __device__ unsigned long long g_fused_stamps[8][6][8];
 #define FUSED_STAMP_MAX(layer, phase) do { } while (0)
 #endif
 
-// the launch before: x = the token's embedding row (infer.rs:13-14), the next epoch
-__global__ __launch_bounds__(256) void fused_embed_kernel(float* x, const float* table, const Ctl* ctl, int dim, int do_embed, unsigned* epoch) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (do_embed && i < dim) x[i] = table[(size_t)ctl->token * dim + i];
-    if (i == 0) *epoch = *epoch + 1u;
-}
+// Every launch of the stage kernel is FOLLOWED by one increment of the epoch, so the epoch a launch reads was never used
+// before: by the sampler's last thread in the chained decode loop (kernels.hpp finish_step), by this kernel otherwise.
+__global__ void fused_epoch_kernel(unsigned* epoch) { *epoch = *epoch + 1u; }
 
 __device__ __forceinline__ void put_tagged(tagged_t* p, float v, unsigned epoch) {
     __hip_atomic_store(p, ((tagged_t)epoch << 32) | (tagged_t)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -356,14 +355,19 @@ __global__ __launch_bounds__(kPThreads, 4) void stage_fused_kernel(FusedParams a
     if (layer >= a.n_layers) {                         // ---- infer.rs:49-51: logits = Wcls . rmsnorm(x)
         constexpr int RC = CD == 2 ? 8 : 4;            // rows per unit: as many as fit the registers
         const int r0 = ((blockIdx.x - a.n_layers * per_layer) * kPWaves + wave) * RC;
+        FUSED_STAMP(blockIdx.x == a.n_layers * per_layer, 0, 5, 0);
+        FUSED_STAMP(blockIdx.x == gridDim.x - 1, 0, 5, 4);
         FusedUnit<RC, CD, true, false> u;
         u.request(a.wcls, nullptr, a.g_final, a.vocab, dim, r0, r0 < a.vocab);
         const unsigned epoch = *a.epoch;
         const tagged_t* hlast = a.hand + (size_t)(a.n_layers ? a.n_layers - 1 : 0) * hw;
         fused_fetch(a.n_layers ? hlast + 5 * dim + hidden : nullptr, a.x, dim, hlast + 5 * dim + hidden - 1, epoch, lds, a.err);
+        FUSED_STAMP(blockIdx.x == a.n_layers * per_layer, 0, 5, 1);
         float accC[RC];
         u.dots(lds, dim, accC, scale);
         if (lane < RC && r0 + lane < a.vocab) a.logits[r0 + lane] = pick<RC>(accC, lane) * scale;
+        FUSED_STAMP(blockIdx.x == a.n_layers * per_layer, 0, 5, 2);
+        FUSED_STAMP_MAX(0, 5);
         return;
     }
     int b = blockIdx.x - layer * per_layer;
@@ -372,6 +376,7 @@ __global__ __launch_bounds__(kPThreads, 4) void stage_fused_kernel(FusedParams a
     tagged_t* hl = a.hand + (size_t)layer * hw;
     tagged_t *t_qkv = hl, *t_xb = hl + 3 * dim, *t_xc = hl + 4 * dim, *t_hb = hl + 5 * dim, *t_xe = hl + 5 * dim + hidden;
     const tagged_t* t_in = layer ? hl - dim : nullptr;                  // xe of the layer before
+    const float* x_in = a.emb ? a.emb + (size_t)a.ctl->token * dim : a.x;   // ... or what the stage starts from
     float* kc = a.kc + (size_t)layer * a.seq_len * dim;
     float* vc = a.vc + (size_t)layer * a.seq_len * dim;
     if (b < a.nA) {                                    // ---- infer.rs:19-33: rmsnorm, Wq | Wk | Wv, RoPE, cache append
@@ -387,7 +392,7 @@ __global__ __launch_bounds__(kPThreads, 4) void stage_fused_kernel(FusedParams a
             const int i = ((r0 + 2 * lane) % hs) >> 1;
             rc = a.fr[(size_t)pos * (hs >> 1) + i]; rs = a.fi[(size_t)pos * (hs >> 1) + i];
         }
-        fused_fetch(t_in, a.x, dim, layer ? hl - dim - 1 : nullptr, epoch, lds, a.err);      // early: the last word of hb of the layer before
+        fused_fetch(t_in, x_in, dim, layer ? hl - dim - 1 : nullptr, epoch, lds, a.err);      // early: the last word of hb of the layer before
         FUSED_STAMP(b == 0, layer, 0, 1);
         u.dots(lds, dim, acc, scale);
         if (mine) {
@@ -427,7 +432,7 @@ __global__ __launch_bounds__(kPThreads, 4) void stage_fused_kernel(FusedParams a
         fused_fetch(t_xb, nullptr, dim, t_qkv + 3 * dim - 1, epoch, lds, a.err);
         FUSED_STAMP(b == 0, layer, 2, 1);
         float resid = 0.0f;                            // complete since before this layer's first phase
-        if (lane < 4 && r0 + lane < dim) resid = t_in ? get_tagged(t_in + r0 + lane) : a.x[r0 + lane];
+        if (lane < 4 && r0 + lane < dim) resid = t_in ? get_tagged(t_in + r0 + lane) : x_in[r0 + lane];
         __builtin_amdgcn_sched_barrier(0);
         u.dots(lds, dim, acc, scale);
         if (lane < 4 && r0 + lane < dim) put_tagged(t_xc + r0 + lane, resid + pick<4>(acc, lane), epoch);

@@ -126,7 +126,9 @@ struct rama_ctx {
     int tune_fused_solo = -1;              // its workgroups alone on their CU (LDS request padded): 1, 0, -1 = for dim > 512 (stories110M: 216 -> 200 us
                                            // per token, a consumer's polls do not queue behind a neighbour's weight requests; stories15M: 89 -> 92)
     tagged_t* fused_hand = nullptr;        // device: its hand-off vectors (tagged words), room for the largest shape it takes
-    unsigned* fused_epoch = nullptr;       // device: the tag of the current token
+    unsigned* fused_epoch = nullptr;       // device: the tag of the current token, advanced after every launch of the stage kernel
+    bool fused_chained = false;            // the step being enqueued ends in a sampler launch, which advances the epoch
+    bool fused_epoch_owed = false;         // ... and the stage launch just enqueued relies on that
     int merge_blocks_per_cu[3] = {-1, -1, -1};   // occupancy of attn_wo_kernel<16|32|64> at the LDS size below
     size_t merge_lds[3] = {0, 0, 0};
     unsigned* attn_counter = nullptr;      // device: arrivals of the attention workgroups
@@ -222,7 +224,7 @@ int rama_ctx_create(int device, void* hip_stream, rama_ctx** out) {
     HIPCHK(hipMalloc(&c->fused_hand, (size_t)kFusedMaxLayers * fused_hand_words(kFusedMaxDim, kFusedMaxHidden) * sizeof(tagged_t)));
     HIPCHK(hipMemset(c->fused_hand, 0, (size_t)kFusedMaxLayers * fused_hand_words(kFusedMaxDim, kFusedMaxHidden) * sizeof(tagged_t)));
     HIPCHK(hipMalloc(&c->fused_epoch, sizeof(unsigned)));
-    HIPCHK(hipMemset(c->fused_epoch, 0, sizeof(unsigned)));
+    { const unsigned one = 1; HIPCHK(hipMemcpy(c->fused_epoch, &one, sizeof one, hipMemcpyHostToDevice)); }      // the zeroed vectors carry tag 0
     HIPCHK(hipMalloc(&c->pbar, 4 * sizeof(unsigned long long)));
     HIPCHK(hipMemset(c->pbar, 0, 4 * sizeof(unsigned long long)));
     HIPCHK(hipHostMalloc(&c->pinned_int, sizeof(int) * 4));
@@ -885,7 +887,7 @@ static int try_launch_fused(rama_ctx* c, const rama_config* cfg, const rama_weig
     *launched = false;
     const int dim = cfg->dim, hidden = cfg->hidden_dim, H = cfg->n_heads, hs = dim / H, V = cfg->vocab_size;
     const int nl = st->layer_end - st->layer_begin;
-    if (nl <= 0 && !st->do_cls) return 0;
+    if (nl <= 0 && (!st->do_cls || st->do_embed)) return 0;
     if (dim > kFusedMaxDim || hidden > kFusedMaxHidden || nl > kFusedMaxLayers || dim % 4 || hidden % 4 || hs % 4 || hs > 256 || cfg->seq_len % 4) return 0;
     const int G = hs <= 64 ? 16 : (hs <= 128 ? 32 : 64);
     size_t lds = (size_t)fused_lds_floats(G, cfg->seq_len, dim, hidden) * sizeof(float);
@@ -895,14 +897,12 @@ static int try_launch_fused(rama_ctx* c, const rama_config* cfg, const rama_weig
     if (!aligned16(s->x) || !aligned16(s->q) || !aligned16(s->xb) || !aligned16(s->hb) || !aligned16(s->key_cache) || !aligned16(s->value_cache) ||
         !aligned16(w->wq) || !aligned16(w->wk) || !aligned16(w->wv) || !aligned16(w->wo) || !aligned16(w->w1) || !aligned16(w->w2) || !aligned16(w->w3) ||
         !aligned16(w->wcls) || !aligned16(w->rms_att_weight) || !aligned16(w->rms_ffn_weight) || !aligned16(w->rms_final_weight)) return 0;
-    hipLaunchKernelGGL(fused_embed_kernel, dim3(st->do_embed ? (dim + 255) / 256 : 1), dim3(256), 0, c->stream, s->x, w->token_embedding_table, (const Ctl*)c->ctl, dim,
-                       st->do_embed ? 1 : 0, c->fused_epoch);
-    LAUNCHCHK();
     auto wgs = [](int units) { return (units + kPWaves - 1) / kPWaves; };
     FusedParams a{};
     a.dim = dim; a.hidden = hidden; a.n_heads = H; a.seq_len = cfg->seq_len; a.vocab = V; a.n_layers = nl; a.do_cls = st->do_cls ? 1 : 0;
     a.wq = w->wq; a.wk = w->wk; a.wv = w->wv; a.wo = w->wo; a.w1 = w->w1; a.w3 = w->w3; a.w2 = w->w2;
     a.g_att = w->rms_att_weight; a.g_ffn = w->rms_ffn_weight; a.g_final = w->rms_final_weight; a.wcls = w->wcls;
+    a.emb = st->do_embed ? w->token_embedding_table : nullptr;
     a.x = s->x; a.q = s->q; a.k = s->k; a.v = s->v; a.xb = s->xb; a.hb = s->hb; a.logits = s->logits;
     a.kc = s->key_cache; a.vc = s->value_cache; a.fr = w->freq_cis_real; a.fi = w->freq_cis_imag;
     a.ctl = c->ctl; a.hand = c->fused_hand; a.epoch = c->fused_epoch; a.err = c->pbar + 1;
@@ -920,6 +920,9 @@ static int try_launch_fused(rama_ctx* c, const rama_config* cfg, const rama_weig
 #undef RAMA_FUSED
     LAUNCHCHK();
     *launched = true;
+    if (c->fused_chained) { c->fused_epoch_owed = true; return 0; }      // the sampler that follows advances the epoch
+    hipLaunchKernelGGL(fused_epoch_kernel, dim3(1), dim3(1), 0, c->stream, c->fused_epoch);
+    LAUNCHCHK();
     return 0;
 }
 
@@ -2005,12 +2008,15 @@ int rama_decode_begin(rama_ctx* c, int token, int pos, const int32_t* forced_hos
 // gather).  x already holds emb[token] on entry (rama_decode_steps primes it once).
 static int enqueue_decode_step(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s) {
     rama_stage st{0, cfg->n_layers, 0, 1};
+    c->fused_chained = true; c->fused_epoch_owed = false;
     int rc = enqueue_stage(c, cfg, w, s, &st);
+    c->fused_chained = false;
     if (rc) return rc;
     ArgmaxParams ap{};
     ap.logits = s->logits; ap.n = cfg->vocab_size;
     ap.ctl = c->ctl; ap.forced = c->forced; ap.out = c->out; ap.out_cap = c->out_cap; ap.ring = c->ring_dev;
     ap.emb = w->token_embedding_table; ap.x = s->x; ap.dim = cfg->dim;
+    if (c->fused_epoch_owed) ap.epoch = c->fused_epoch;
     return enqueue_sample(c, ap, c->samp_T, c->samp_topp, c->samp_u);
 }
 

@@ -20,7 +20,7 @@ int main(int argc, char** argv) {
     a.logits = zalloc<float>(V); a.kc = zalloc<float>((size_t)L * seq * dim); a.vc = zalloc<float>((size_t)L * seq * dim);
     a.fr = zalloc<float>((size_t)seq * dim); a.fi = zalloc<float>((size_t)seq * dim);
     Ctl* ctl = zalloc<Ctl>(1); Ctl h{}; h.pos = pos; h.token = 1; CK(hipMemcpy(ctl, &h, sizeof h, hipMemcpyHostToDevice)); a.ctl = ctl;
-    a.hand = zalloc<tagged_t>((size_t)L * fused_hand_words(dim, hidden)); unsigned* epoch = zalloc<unsigned>(1); a.epoch = epoch; a.err = zalloc<unsigned long long>(1);
+    a.hand = zalloc<tagged_t>((size_t)L * fused_hand_words(dim, hidden)); unsigned* epoch = zalloc<unsigned>(1); { const unsigned one = 1; CK(hipMemcpy(epoch, &one, 4, hipMemcpyHostToDevice)); } a.epoch = epoch; a.err = zalloc<unsigned long long>(1);
     auto wgs = [](int u) { return (u + kPWaves - 1) / kPWaves; };
     a.nA = wgs(3 * (dim / 4)); a.nC = wgs(dim / 4); a.nD = wgs(hidden / 2); a.nE = big ? wgs(dim / 2) : a.nC;
     const int per_layer = a.nA + H + a.nC + a.nD + a.nE, grid = L * per_layer + (big ? wgs(V / 4) : wgs(V / 8));
@@ -31,20 +31,20 @@ int main(int argc, char** argv) {
         CK(hipFuncSetAttribute((const void*)stage_fused_kernel<16, 2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         printf("LDS per workgroup padded to %zu bytes\n", lds);
     }
-    float* table = zalloc<float>((size_t)V * dim);
+    float* table = zalloc<float>((size_t)V * dim); a.emb = table;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     printf("dim %d hidden %d layers %d: %d workgroups per layer (A %d, heads %d, C %d, D %d, E %d), grid %d\n", dim, hidden, L, per_layer, a.nA, H, a.nC, a.nD, a.nE, grid);
     for (int rep = 0; rep < 3; rep++) {
         CK(hipEventRecord(e0, 0));
         { static unsigned long long z[8][6][8]; CK(hipMemcpyToSymbol(HIP_SYMBOL(rama::g_fused_stamps), z, sizeof z)); }
         for (int i = 0; i < (rep == 2 ? 1 : 50); i++) {
-            hipLaunchKernelGGL(fused_embed_kernel, dim3((dim + 255) / 256), dim3(256), 0, 0, a.x, table, ctl, dim, 1, epoch);
             if (big) hipLaunchKernelGGL((stage_fused_kernel<16, 4, 2, 8>), dim3(grid), dim3(kPThreads), lds, 0, a);
             else hipLaunchKernelGGL((stage_fused_kernel<16, 2, 4, 4>), dim3(grid), dim3(kPThreads), lds, 0, a);
+            hipLaunchKernelGGL(fused_epoch_kernel, dim3(1), dim3(1), 0, 0, epoch);
         }
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        if (rep < 2) printf("embed + stage: %.2f us per token\n", ms * 1e3 / 50);
+        if (rep < 2) printf("stage + epoch: %.2f us per token\n", ms * 1e3 / 50);
     }
     unsigned long long st[8][6][8], err;
     CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(rama::g_fused_stamps), sizeof st));
@@ -58,6 +58,14 @@ int main(int argc, char** argv) {
             printf("  %-7s started %8.2f | input in LDS %7.2f | (E: dots done %7.2f) | outputs stored %7.2f | the slowest workgroup's %7.2f\n", ph[p], (double)(long long)(st[l][p][0] - t0) * 0.01,
                    (double)(long long)(st[l][p][1] - t0) * 0.01, (double)(long long)(st[l][p][5] - t0) * 0.01,
                    (double)(long long)(st[l][p][2] - t0) * 0.01, (double)(long long)(st[l][p][3] - t0) * 0.01);
+    }
+    {
+        const unsigned long long t0 = st[0][0][0], tl = st[L - 1 < 8 ? L - 1 : 7][4][3];
+        printf("classifier (us since the launch's first workgroup started): first workgroup started %.2f, the last one started %.2f; x in LDS %.2f, its logits stored %.2f, the last workgroup's %.2f",
+               (double)(long long)(st[0][5][0] - t0) * 0.01, (double)(long long)(st[0][5][4] - t0) * 0.01, (double)(long long)(st[0][5][1] - t0) * 0.01,
+               (double)(long long)(st[0][5][2] - t0) * 0.01, (double)(long long)(st[0][5][3] - t0) * 0.01);
+        if (L <= 8) printf("; the last layer's W2 phase ended %.2f", (double)(long long)(tl - t0) * 0.01);
+        printf("\n");
     }
     printf("attention of layer 1, head 0 (us after q | k | v were in LDS): timesteps done %.2f, partial results exchanged %.2f, xb stored %.2f\n",
            (double)(long long)(st[1][1][5] - st[1][1][1]) * 0.01, (double)(long long)(st[1][1][6] - st[1][1][1]) * 0.01, (double)(long long)(st[1][1][2] - st[1][1][1]) * 0.01);
