@@ -78,13 +78,24 @@ __device__ __forceinline__ void fused_watch(const tagged_t* p, unsigned epoch, u
     }
 }
 
+// `ok` of every thread of the workgroup, with one barrier: a wave vote, eight LDS words, two slots taken in turn (a wave can
+// be one round ahead of the slowest reader, never two).  __syncthreads_and costs three barriers and a DPP reduction.
+__device__ __forceinline__ bool fused_all(bool ok, int round, int* s_ok) {
+    const bool wave_ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
+    int* slot = s_ok + (round & 1) * kPWaves;
+    if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = wave_ok ? 1 : 0;
+    __syncthreads();
+    const int4 a = *reinterpret_cast<const int4*>(slot), b = *reinterpret_cast<const int4*>(slot + 4);
+    return (a.x & a.y & a.z & a.w & b.x & b.y & b.z & b.w) != 0;
+}
+
 // The whole workgroup: x_s[0..n) = the n floats of `src` (n even, src 16-byte aligned), once every one of them carries
 // `epoch`: the vector is copied to LDS, every tag checked, again and again until all match.  `early`: a word of the vector
 // the producers of `src` themselves wait for -- one lane sleeps on it first, so that only the workgroups whose input is
 // being produced right now poll whole vectors.  src == nullptr: the vector is `plain`, an ordinary float array of an
 // earlier launch.
 __device__ __forceinline__ void fused_fetch(const tagged_t* src, const float* plain, int n, const tagged_t* early, unsigned epoch, float* x_s,
-                                            unsigned long long* err) {
+                                            int* s_ok, unsigned long long* err) {
     const int tid = threadIdx.x;
     if (!src) {
         for (int i = tid * 4; i < n; i += kPThreads * 4) *reinterpret_cast<f4*>(x_s + i) = *reinterpret_cast<const f4*>(plain + i);
@@ -103,7 +114,7 @@ __device__ __forceinline__ void fused_fetch(const tagged_t* src, const float* pl
             ok = ok && p.y == epoch && p.w == epoch;
             x_s[i] = __uint_as_float(p.x); x_s[i + 1] = __uint_as_float(p.z);
         }
-        if (__syncthreads_and(ok)) break;
+        if (fused_all(ok, tries, s_ok)) break;
         if ((tries & 63) == 63 &&
             __syncthreads_or(tries >= (1 << 20) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {      // one verdict for the workgroup
             if (tid == 0) __hip_atomic_store(err, kFusedErr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -215,7 +226,7 @@ template <int G> __device__ __forceinline__ float groups_max(float v) {
 // plainly, `xb_plain`, for the run state).
 template <int G>
 __device__ __forceinline__ void fused_attention(int dim, int n_heads, int seq_len, const float* kc, const float* vc, int h, int pos,
-                                                const tagged_t* t_qkv, const tagged_t* early, float* cur, float* lds, tagged_t* xb_t, float* xb_plain,
+                                                const tagged_t* t_qkv, const tagged_t* early, float* cur, float* lds, int* s_ok, tagged_t* xb_t, float* xb_plain,
                                                 unsigned epoch, unsigned long long* err, int st_layer = 0) {
     float* s_max = lds;
     float* s_sum = lds + kPWaves;
@@ -255,7 +266,7 @@ __device__ __forceinline__ void fused_attention(int dim, int n_heads, int seq_le
                 ok = ok && (unsigned)(p >> 32) == epoch;
                 cur[m * hs + j] = __uint_as_float((unsigned)p);
             }
-            if (__syncthreads_and(ok)) break;
+            if (fused_all(ok, tries, s_ok)) break;
             if ((tries & 63) == 63 && __syncthreads_or(tries >= (1 << 20) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
                 if (tid == 0) __hip_atomic_store(err, kFusedErr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
@@ -345,6 +356,7 @@ __host__ __device__ constexpr int fused_lds_floats(int G, int seq_len, int dim, 
 template <int G, int CD, int RE, int CHH>
 __global__ __launch_bounds__(kPThreads, 4) void stage_fused_kernel(FusedParams a) {
     extern __shared__ float lds[];
+    __shared__ __attribute__((aligned(16))) int s_ok[2 * kPWaves];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int dim = a.dim, hidden = a.hidden, H = a.n_heads, hs = dim / H;
@@ -361,7 +373,7 @@ __global__ __launch_bounds__(kPThreads, 4) void stage_fused_kernel(FusedParams a
         u.request(a.wcls, nullptr, a.g_final, a.vocab, dim, r0, r0 < a.vocab);
         const unsigned epoch = *a.epoch;
         const tagged_t* hlast = a.hand + (size_t)(a.n_layers ? a.n_layers - 1 : 0) * hw;
-        fused_fetch(a.n_layers ? hlast + 5 * dim + hidden : nullptr, a.x, dim, hlast + 5 * dim + hidden - 1, epoch, lds, a.err);
+        fused_fetch(a.n_layers ? hlast + 5 * dim + hidden : nullptr, a.x, dim, hlast + 5 * dim + hidden - 1, epoch, lds, s_ok, a.err);
         FUSED_STAMP(blockIdx.x == a.n_layers * per_layer, 0, 5, 1);
         float accC[RC];
         u.dots(lds, dim, accC, scale);
@@ -392,7 +404,7 @@ __global__ __launch_bounds__(kPThreads, 4) void stage_fused_kernel(FusedParams a
             const int i = ((r0 + 2 * lane) % hs) >> 1;
             rc = a.fr[(size_t)pos * (hs >> 1) + i]; rs = a.fi[(size_t)pos * (hs >> 1) + i];
         }
-        fused_fetch(t_in, x_in, dim, layer ? hl - dim - 1 : nullptr, epoch, lds, a.err);      // early: the last word of hb of the layer before
+        fused_fetch(t_in, x_in, dim, layer ? hl - dim - 1 : nullptr, epoch, lds, s_ok, a.err);      // early: the last word of hb of the layer before
         FUSED_STAMP(b == 0, layer, 0, 1);
         u.dots(lds, dim, acc, scale);
         if (mine) {
@@ -416,7 +428,7 @@ __global__ __launch_bounds__(kPThreads, 4) void stage_fused_kernel(FusedParams a
         FUSED_STAMP(b == 0, layer, 1, 0);
         const unsigned epoch = *a.epoch;
         float* cur = lds + p_attn_lds_floats(G, a.seq_len);           // q | k | v of this head, hs floats each (hs <= 256)
-        fused_attention<G>(dim, H, a.seq_len, kc, vc, b, a.ctl->pos, t_qkv, t_in ? t_in + dim - 1 : nullptr, cur, lds, t_xb, last ? a.xb : nullptr, epoch,
+        fused_attention<G>(dim, H, a.seq_len, kc, vc, b, a.ctl->pos, t_qkv, t_in ? t_in + dim - 1 : nullptr, cur, lds, s_ok, t_xb, last ? a.xb : nullptr, epoch,
                            a.err, layer);
         FUSED_STAMP(b == 0, layer, 1, 2);
         FUSED_STAMP_MAX(layer, 1);
@@ -429,7 +441,7 @@ __global__ __launch_bounds__(kPThreads, 4) void stage_fused_kernel(FusedParams a
         FusedUnit<4, CD, false, false> u;
         u.request(a.wo + layer * dd, nullptr, nullptr, dim, dim, r0, r0 < dim);
         const unsigned epoch = *a.epoch;
-        fused_fetch(t_xb, nullptr, dim, t_qkv + 3 * dim - 1, epoch, lds, a.err);
+        fused_fetch(t_xb, nullptr, dim, t_qkv + 3 * dim - 1, epoch, lds, s_ok, a.err);
         FUSED_STAMP(b == 0, layer, 2, 1);
         float resid = 0.0f;                            // complete since before this layer's first phase
         if (lane < 4 && r0 + lane < dim) resid = t_in ? get_tagged(t_in + r0 + lane) : x_in[r0 + lane];
@@ -447,7 +459,7 @@ __global__ __launch_bounds__(kPThreads, 4) void stage_fused_kernel(FusedParams a
         FusedUnit<4, CD, true, true> u;
         u.request(a.w1 + layer * hd, a.w3 + layer * hd, a.g_ffn + (size_t)layer * dim, hidden, dim, r0, r0 < hidden);
         const unsigned epoch = *a.epoch;
-        fused_fetch(t_xc, nullptr, dim, t_xb + dim - 1, epoch, lds, a.err);
+        fused_fetch(t_xc, nullptr, dim, t_xb + dim - 1, epoch, lds, s_ok, a.err);
         FUSED_STAMP(b == 0, layer, 3, 1);
         u.dots(lds, dim, acc, scale);
         if (lane < 2 && r0 + lane < hidden) {
@@ -467,7 +479,7 @@ __global__ __launch_bounds__(kPThreads, 4) void stage_fused_kernel(FusedParams a
         FusedUnit<RE, CHH, false, false> u;
         u.request(a.w2 + layer * hd, nullptr, nullptr, dim, hidden, r0, r0 < dim);
         const unsigned epoch = *a.epoch;
-        fused_fetch(t_hb, nullptr, hidden, t_xc + dim - 1, epoch, lds, a.err);
+        fused_fetch(t_hb, nullptr, hidden, t_xc + dim - 1, epoch, lds, s_ok, a.err);
         FUSED_STAMP(b == 0, layer, 4, 1);
         float resid = 0.0f;                            // complete since before the phase before this one
         if (lane < RE && r0 + lane < dim) resid = get_tagged(t_xc + r0 + lane);
