@@ -325,6 +325,12 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *                   consume them (every workgroup forms the exact sum itself; default 1: +6.6 % at the stories15M shape)
  *   "prefill_chain" = 0|1 : parity mode's rama_prefill through the chain-order token-batch kernels (default 1)
  *   "prefill_tok" = 64|128 : positions per weight pass of rama_prefill (default 128; 64 = round 2's kernels)
+ *   "fused" = -1|0|1 : 1 runs a whole stage of rama_forward* / the chained decode loop -- every layer and the classifier --
+ *                   as ONE launch (csrc/layer_fused.hpp: the phases wait for each other's output vectors, whose floats
+ *                   carry their own tags; weights are requested before the wait); -1 (default) = for dim <= 1024:
+ *                   12 190 vs 9 640 tok/s at the stories15M shape, 5 262 vs 3 700 at stories110M.  Same results within
+ *                   the fast path's bar; long contexts that split attention, per-kernel timing and wider models take
+ *                   the separate launches.  "fused_solo" = -1|0|1: its workgroups alone on their CU (-1 = for dim > 512)
  *   "merge" = -1|0|1 : 1 runs attention and the Wo matvec as one launch when the occupancy API says
  *                   its whole grid is resident (Wo's weights stream while attention runs); -1
  *                   (default) turns it on for dim <= 1024 only: measured +4.2 % / +7.7 % tokens/s at
