@@ -2098,9 +2098,9 @@ int rama_decode_tokens(rama_ctx* c, int32_t* out_host, int max_tokens, int* n_ou
     unsigned long long perr = 0;
     HIPCHK(hipMemcpyAsync(&perr, c->pbar + 1, sizeof perr, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (perr != 0) {   // the bounded spin of a merged attention+Wo launch gave up: its results are invalid
+    if (perr != 0) {   // a bounded wait inside a launch gave up (attn_wo.hpp's counter, layer_fused.hpp's tagged vectors: 0x3000 / 0x3001): the results are invalid
         hipMemsetAsync(c->pbar, 0, 4 * sizeof(unsigned long long), c->stream);   // counter, error word, base: start over
-        return fail(RAMA_EINVAL, "attention+Wo launch: hand-off timed out", __FILE__, __LINE__);
+        return fail(RAMA_EINVAL, perr >= kFusedErr ? "one-launch stage: a hand-off timed out" : "attention+Wo launch: hand-off timed out", __FILE__, __LINE__);
     }
     if (c->topp_err) {
         unsigned terr = 0;
