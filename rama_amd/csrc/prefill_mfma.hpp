@@ -440,15 +440,16 @@ constexpr int kRmsParts = 16;
 // X += pending K-slices; partial sums of squares per (token tile, part, token) -> ssp; and, with a gain
 // vector, XN = X * gain (infer.rs:19/39/50's rmsnorm without its per-token scale, which the consuming
 // GEMM applies to its outputs: W (v g x) = v W (g x), as the decode matvecs do)
-__global__ __launch_bounds__(256) void rms_fold_kernel(float* X, float* ssp, int dim, const float* slabs, int nslab, size_t slab_floats,
-                                                       float* XN = nullptr, const float* gain = nullptr) {
-    __shared__ float red[4][16];
+constexpr int kRmsFoldWaves = 16;      // a part of llama2-7B's rows is 16 column blocks: one per wave, every load of the launch in flight at once
+__global__ __launch_bounds__(kRmsFoldWaves * 64) void rms_fold_kernel(float* X, float* ssp, int dim, const float* slabs, int nslab, size_t slab_floats,
+                                                                      float* XN = nullptr, const float* gain = nullptr) {
+    __shared__ float red[kRmsFoldWaves][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nblk = dim >> 4, per = (nblk + kRmsParts - 1) / kRmsParts;
     const int jb0 = blockIdx.y * per, jb1 = min(jb0 + per, nblk);
     const size_t tbase = (size_t)blockIdx.x * nblk * 256;
     float ss = 0.0f;
-    for (int jb = jb0 + wave; jb < jb1; jb += 4) {
+    for (int jb = jb0 + wave; jb < jb1; jb += kRmsFoldWaves) {
         const size_t o = tbase + (size_t)jb * 256 + lane * 4;
         f4 x = *reinterpret_cast<const f4*>(X + o);
         if (nslab > 0) {
@@ -467,7 +468,16 @@ __global__ __launch_bounds__(256) void rms_fold_kernel(float* X, float* ssp, int
     ss += __shfl_xor(ss, 32);
     if (lane < 16) red[wave][lane] = ss;
     __syncthreads();
-    if (tid < 16) ssp[((size_t)blockIdx.x * kRmsParts + blockIdx.y) * 16 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    if (tid < 16) {
+        float t[kRmsFoldWaves];
+#pragma unroll
+        for (int q = 0; q < kRmsFoldWaves; q++) t[q] = red[q][tid];
+#pragma unroll
+        for (int n = kRmsFoldWaves; n > 1; n >>= 1)      // fixed pairwise tree
+#pragma unroll
+            for (int q = 0; q < n / 2; q++) t[q] = t[2 * q] + t[2 * q + 1];
+        ssp[((size_t)blockIdx.x * kRmsParts + blockIdx.y) * 16 + tid] = t[0];
+    }
 }
 
 __global__ __launch_bounds__(256) void rms_scale_kernel(float* O, const float* X, const float* w, const float* ssp, int dim) {

@@ -1417,11 +1417,11 @@ static int ensure_batch_scratch(rama_ctx* c, const rama_config* cfg, bool with_l
 // b.XN scales its outputs per token from the partial sums in b.SSP (MfParams::ssp = norm_ssp(c, b)).
 static int launch_rmsnorm_tile(rama_ctx* c, const BatchScratch& b, const float* gain, int dim, int ntile, int nslab) {
     if (c->tune_norm_in_gemm) {
-        hipLaunchKernelGGL(rms_fold_kernel, dim3(ntile, kRmsParts), dim3(256), 0, c->stream, b.X, b.SSP, dim, (const float*)b.SL, nslab, b.slab, b.XN, gain);
+        hipLaunchKernelGGL(rms_fold_kernel, dim3(ntile, kRmsParts), dim3(kRmsFoldWaves * 64), 0, c->stream, b.X, b.SSP, dim, (const float*)b.SL, nslab, b.slab, b.XN, gain);
         LAUNCHCHK();
         return 0;
     }
-    hipLaunchKernelGGL(rms_fold_kernel, dim3(ntile, kRmsParts), dim3(256), 0, c->stream, b.X, b.SSP, dim, (const float*)b.SL, nslab, b.slab, (float*)nullptr, (const float*)nullptr);
+    hipLaunchKernelGGL(rms_fold_kernel, dim3(ntile, kRmsParts), dim3(kRmsFoldWaves * 64), 0, c->stream, b.X, b.SSP, dim, (const float*)b.SL, nslab, b.slab, (float*)nullptr, (const float*)nullptr);
     LAUNCHCHK();
     hipLaunchKernelGGL(rms_scale_kernel, dim3(ntile, kRmsParts), dim3(256), 0, c->stream, b.XN, (const float*)b.X, gain, (const float*)b.SSP, dim);
     LAUNCHCHK();
