@@ -123,6 +123,32 @@ __device__ __forceinline__ void fused_fetch(const tagged_t* src, const float* pl
     }
 }
 
+// v[l] (+ | max) v[l ^ 16] and v[l] (+ | max) v[l ^ 32] as VALU lane swaps (gfx950's v_permlane16_swap / v_permlane32_swap): a
+// ds_bpermute shuffle goes through the LDS pipeline and costs its latency every time
+template <int MASK>
+__device__ __forceinline__ void xor_pair(float v, float& a, float& b) {
+    static_assert(MASK == 16 || MASK == 32, "rows or halves");
+    const unsigned u = __float_as_uint(v);
+    if (MASK == 16) { const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false); a = __uint_as_float(r[0]); b = __uint_as_float(r[1]); }
+    else { const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false); a = __uint_as_float(r[0]); b = __uint_as_float(r[1]); }
+}
+template <int MASK> __device__ __forceinline__ float xor_sum(float v) { float a, b; xor_pair<MASK>(v, a, b); return a + b; }
+template <int MASK> __device__ __forceinline__ float xor_max(float v) { float a, b; xor_pair<MASK>(v, a, b); return fmaxf(a, b); }
+// over the 64 / G groups of G lanes each
+template <int G> __device__ __forceinline__ float groups_sum(float v) {
+    if (G <= 16) v = xor_sum<16>(v);
+    if (G <= 32) v = xor_sum<32>(v);
+    return v;
+}
+template <int G> __device__ __forceinline__ float groups_max(float v) {
+    if (G <= 16) v = xor_max<16>(v);
+    if (G <= 32) v = xor_max<32>(v);
+    return v;
+}
+
+// wave_sum's tree -- (r0 + r1) + (r2 + r3) over the four row sums -- without the trip through the scalar registers
+__device__ __forceinline__ float wave_sum_swap(float v) { return xor_sum<32>(xor_sum<16>(row16_sum(v))); }
+
 // one wave's weights: R rows, the first CH 256-float chunks of each -- rows r0..r0+R-1 of Wa, or (PAIR, R = 4) rows r0, r0+1 of
 // Wa and of Wb interleaved (0/2 = Wa, 1/3 = Wb)
 template <int R, int CH, bool NORM, bool PAIR>
@@ -192,34 +218,11 @@ struct FusedUnit {
             }
         }
 #pragma unroll
-        for (int s = 0; s < R; s++) acc[s] = wave_sum(acc[s]);
+        for (int s = 0; s < R; s++) acc[s] = wave_sum_swap(acc[s]);
         scale = 1.0f;
-        if (NORM) scale = rms_scale(wave_sum(ss), K);
+        if (NORM) scale = rms_scale(wave_sum_swap(ss), K);
     }
 };
-
-// v[l] (+ | max) v[l ^ 16] and v[l] (+ | max) v[l ^ 32] as VALU lane swaps (gfx950's v_permlane16_swap / v_permlane32_swap): a
-// ds_bpermute shuffle goes through the LDS pipeline and costs its latency every time
-template <int MASK>
-__device__ __forceinline__ void xor_pair(float v, float& a, float& b) {
-    static_assert(MASK == 16 || MASK == 32, "rows or halves");
-    const unsigned u = __float_as_uint(v);
-    if (MASK == 16) { const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false); a = __uint_as_float(r[0]); b = __uint_as_float(r[1]); }
-    else { const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false); a = __uint_as_float(r[0]); b = __uint_as_float(r[1]); }
-}
-template <int MASK> __device__ __forceinline__ float xor_sum(float v) { float a, b; xor_pair<MASK>(v, a, b); return a + b; }
-template <int MASK> __device__ __forceinline__ float xor_max(float v) { float a, b; xor_pair<MASK>(v, a, b); return fmaxf(a, b); }
-// over the 64 / G groups of G lanes each
-template <int G> __device__ __forceinline__ float groups_sum(float v) {
-    if (G <= 16) v = xor_sum<16>(v);
-    if (G <= 32) v = xor_sum<32>(v);
-    return v;
-}
-template <int G> __device__ __forceinline__ float groups_max(float v) {
-    if (G <= 16) v = xor_max<16>(v);
-    if (G <= 32) v = xor_max<32>(v);
-    return v;
-}
 
 // attention for head h (infer.rs:34): the cache rows before `pos` are an earlier launch's and are requested before the wait;
 // row `pos` and q are this launch's -- cur = q | k | v of this head, fetched into LDS here.  Writes xb as tagged words (and
