@@ -73,10 +73,19 @@ __device__ __forceinline__ float row16_sum(float v) {
     v += dpp_mov<0x140>(v);   // row_mirror
     return v;
 }
-// sum over all 64 lanes, fixed order, wave-uniform result
+// sum over all 64 lanes, fixed order -- (r0 + r1) + (r2 + r3) over the four row sums -- the same in every lane.  The rows meet
+// through gfx950's lane swaps (v_permlane16_swap: rows 0|1 and 2|3, v_permlane32_swap: the halves): two VALU instructions
+// each instead of four v_readlane and the trip through the scalar registers.
 __device__ __forceinline__ float wave_sum(float v) {
     v = row16_sum(v);
-    return (lane_f(v, 0) + lane_f(v, 16)) + (lane_f(v, 32) + lane_f(v, 48));
+    {
+        const unsigned u = __float_as_uint(v);
+        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, dpp_mov<0xB1>(v));

@@ -146,9 +146,6 @@ template <int G> __device__ __forceinline__ float groups_max(float v) {
     return v;
 }
 
-// wave_sum's tree -- (r0 + r1) + (r2 + r3) over the four row sums -- without the trip through the scalar registers
-__device__ __forceinline__ float wave_sum_swap(float v) { return xor_sum<32>(xor_sum<16>(row16_sum(v))); }
-
 // one wave's weights: R rows, the first CH 256-float chunks of each -- rows r0..r0+R-1 of Wa, or (PAIR, R = 4) rows r0, r0+1 of
 // Wa and of Wb interleaved (0/2 = Wa, 1/3 = Wb)
 template <int R, int CH, bool NORM, bool PAIR>
@@ -218,9 +215,9 @@ struct FusedUnit {
             }
         }
 #pragma unroll
-        for (int s = 0; s < R; s++) acc[s] = wave_sum_swap(acc[s]);
+        for (int s = 0; s < R; s++) acc[s] = wave_sum(acc[s]);
         scale = 1.0f;
-        if (NORM) scale = rms_scale(wave_sum_swap(ss), K);
+        if (NORM) scale = rms_scale(wave_sum(ss), K);
     }
 };
 
