@@ -328,7 +328,7 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *   "fused" = -1|0|1 : 1 runs a whole stage of rama_forward* / the chained decode loop -- every layer and the classifier --
  *                   as ONE launch (csrc/layer_fused.hpp: the phases wait for each other's output vectors, whose floats
  *                   carry their own tags; weights are requested before the wait); -1 (default) = for dim <= 1024:
- *                   12 190 vs 9 640 tok/s at the stories15M shape, 5 262 vs 3 700 at stories110M.  Same results within
+ *                   12 315 vs 9 640 tok/s at the stories15M shape, 5 299 vs 3 700 at stories110M.  Same results within
  *                   the fast path's bar; long contexts that split attention, per-kernel timing and wider models take
  *                   the separate launches.  "fused_solo" = -1|0|1: its workgroups alone on their CU (-1 = for dim > 512)
  *   "merge" = -1|0|1 : 1 runs attention and the Wo matvec as one launch when the occupancy API says
