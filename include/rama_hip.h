@@ -387,7 +387,9 @@ int  rama_timer_stop(rama_ctx *ctx, float *elapsed_ms);      /* synchronises */
 #define RAMA_K_W13   3   /* rmsnorm + W1|W3 matvec + SiLU*gate */
 #define RAMA_K_W2    4   /* W2 matvec + residual */
 #define RAMA_K_CLS   5   /* final rmsnorm + classifier matvec */
-#define RAMA_K_COUNT 6
+#define RAMA_K_NORM  6   /* an rmsnorm launch of its own (parity mode: the exact sequential sum of squares) */
+#define RAMA_K_SAMPLE 7  /* Device::sample on the device: argmax, or the top-p sampler's launches (event records around them) */
+#define RAMA_K_COUNT 8
 int  rama_kprof_enable(rama_ctx *ctx, int kernel_id, int max_records);
 int  rama_kprof_read(rama_ctx *ctx, int *n_launches, double *total_ms);  /* synchronises, disables */
 

@@ -536,10 +536,16 @@ __device__ unsigned long long g_chain_stamps[64];
 #else
 #define CHAIN_STAMP(id) do { } while (0)
 #endif
-// NORM (narrow models, K <= 1024): cpu.rs:99-117's rmsnorm folded in -- every workgroup forms the exact sequential sum of
-// squares itself (wave 0 ripples through the list, 0.3 us per 64 elements: shorter than the launch it replaces up to ~1024)
-// and stages w * (v * x); the 7B kernels are the NORM = false instantiations, unchanged.
-template <int W, int D, int XD, int EPI, bool NORM = false>
+// NORM: cpu.rs:99-117's rmsnorm folded in -- every workgroup forms the sum of squares itself and stages w * (v * x).
+//   CNORM_EXACT (parity mode, narrow models, K <= 1024): the exact sequential sum -- wave 0 ripples through the list, 0.3 us
+//     per 64 elements: shorter than the launch it replaces up to ~1024 -- the bits of cpu.rs:112.
+//   CNORM_TREE (tolerance mode, K <= 64 x threads): every thread sums the squares of the <= 64 elements it holds, a wave sum,
+//     the waves through LDS: a fixed tree, the same bits in every workgroup, ~1e-7 relative from the sequential sum -- the
+//     matvec behind it keeps the reference's rounding sequence.  ~0.3 us per workgroup while its first weights are on their
+//     way, instead of a launch of its own (8 us for the exact sum at dim 4096).
+// The parity-mode 7B kernels are the CNORM_NONE instantiations, unchanged.
+enum { CNORM_NONE = 0, CNORM_EXACT = 1, CNORM_TREE = 2 };
+template <int W, int D, int XD, int EPI, int NORM = CNORM_NONE>
 __global__ __launch_bounds__(W * 64) void gemv_chain_kernel(ChainParams p) {
     RAMA_NO_CONTRACT
     CHAIN_STAMP(0);
@@ -577,8 +583,8 @@ __global__ __launch_bounds__(W * 64) void gemv_chain_kernel(ChainParams p) {
     f4 xa[XU];
 #pragma unroll
     for (int u = 0; u < XU; u++) xa[u] = ld_c(rx, ((int)threadIdx.x + T * u) < n4 ? (unsigned)((int)threadIdx.x + T * u) * 16u : kOOB);
-    f4 ga[NORM ? XU : 1];
-    if constexpr (NORM) {
+    f4 ga[NORM != CNORM_NONE ? XU : 1];
+    if constexpr (NORM != CNORM_NONE) {
         const __amdgpu_buffer_rsrc_t rg = make_rsrc_uniform(p.nw, (unsigned)p.K * 4u);
 #pragma unroll
         for (int u = 0; u < XU; u++) ga[u] = ld_c(rg, ((int)threadIdx.x + T * u) < n4 ? (unsigned)((int)threadIdx.x + T * u) * 16u : kOOB);
@@ -605,7 +611,27 @@ __global__ __launch_bounds__(W * 64) void gemv_chain_kernel(ChainParams p) {
         }
     }
     CHAIN_STAMP(1);
-    if constexpr (NORM) {     // x <- w * (v * x), v = 1 / sqrt(sum(x^2) / K + 1e-5) with the sum in index order (host: K <= 64 T floats, all of x is in xa)
+    if constexpr (NORM == CNORM_TREE) {     // x <- w * (v * x) with the sum of squares as a fixed tree (host: K <= 64 T floats, all of x is in xa)
+        float ssl = 0.0f;
+#pragma unroll
+        for (int u = 0; u < XU; u++) ssl = ssl + ((xa[u].x * xa[u].x + xa[u].y * xa[u].y) + (xa[u].z * xa[u].z + xa[u].w * xa[u].w));
+        ssl = wave_sum(ssl);
+        if (W > 1) {
+            __shared__ float wss[W];
+            if (lane == 0) wss[wave] = ssl;
+            __syncthreads();
+            ssl = wss[0];
+#pragma unroll
+            for (int w_ = 1; w_ < W; w_++) ssl = ssl + wss[w_];
+        }
+        const float v = 1.0f / sqrtf(ssl / (float)p.K + 1e-5f);
+#pragma unroll
+        for (int u = 0; u < XU; u++) {
+            xa[u].x = ga[u].x * (v * xa[u].x); xa[u].y = ga[u].y * (v * xa[u].y);
+            xa[u].z = ga[u].z * (v * xa[u].z); xa[u].w = ga[u].w * (v * xa[u].w);
+        }
+    }
+    if constexpr (NORM == CNORM_EXACT) {     // x <- w * (v * x), v = 1 / sqrt(sum(x^2) / K + 1e-5) with the sum in index order (host: K <= 64 T floats, all of x is in xa)
         __shared__ PredShared<W> nps;
         float* sq = xs + p.K + chain_pad_floats(W, D, XD);       // squares, scan_slot layout
 #pragma unroll

@@ -99,6 +99,9 @@ struct rama_ctx {
     int tune_w13i = 1;                     // 1: the fused W1|W3 launch streams the model's row-interleaved copy when there is one
     int tune_solo = -1;                    // small-K matvecs, one wave per row group: 1 on, 0 off, -1 = rows of <= 2048 floats
     int tune_ref_order = 0;                // 1: every op in the reference's own rounding order: bit-comparable with the CPU path ("parity mode")
+    int tune_tol = 0;                      // "ref_order" = 2, tolerance mode: the chain-order matvecs (the reference's rounding sequence, where its 1.5e-4 lives) with
+                                           // the layer norms folded into them as tree-shaped sums and the fast attention: within 1e-4 of the CPU path, not bit-identical
+    int tune_tol_mask = 0;                 // tolerance mode, A/B: ops swapped for the fast path's (1 qkv, 2 wo, 4 w13, 8 w2, 16 cls) or parity mode's (32 attention, 64 norms)
     int tune_chain = 1;                    // parity mode streams the model's chain-order weight copy (chain.hpp); 0: ref_order.hpp's one-thread-per-row kernels
     int tune_chain_d = 0;                  // chain-order matvec geometry: 0 = by row groups per CU, else 100 W + D (waves per group, blocks per wave in flight)
     // device top-p sampler (Device::sample for temperature != 0); temperature 0 = argmax
@@ -470,7 +473,7 @@ static int launch_attention_ref(rama_ctx* c, float* xb, float* att, const float*
 // W waves per 16 rows, D blocks per wave in flight: by how many row groups share a CU (few groups -> more waves
 // and deeper rings per group, so that >= ~128 KiB per CU are on the way); tune_chain_d = 100 W + D overrides
 template <int EPI>
-static int launch_chain(rama_ctx* c, ChainParams& p) {
+static int launch_chain(rama_ctx* c, ChainParams& p, bool tree_norm = false) {
     REQUIRE(p.K % 16 == 0 && p.K > 0 && p.rows > 0, RAMA_EINVAL, "chain-order matvec: width must be a multiple of 16");
     const int groups = p.nmat * ((p.rows + 15) / 16);
     int W, D;
@@ -485,12 +488,22 @@ static int launch_chain(rama_ctx* c, ChainParams& p) {
     const size_t lds = (size_t)(p.K + chain_pad_floats(W, D, 4)) * sizeof(float);      // x + the zeros behind it
     REQUIRE(lds <= 64 * 1024, RAMA_EUNSUP, "chain-order matvec: row longer than ~15800 floats");
     const dim3 grid(groups);
+    if (p.nw && tree_norm) {      // tolerance mode: the rmsnorm folded in with a tree-shaped sum of squares; all of x must sit in the workgroup's registers (K <= 64 x threads)
+        if (c->tune_chain_d <= 0 && W == 1 && p.K > 4096) W = 2;
+        REQUIRE(p.K <= 4096 * W && D == 16 && (W == 1 || W == 2) && EPI != CEPI_RESID, RAMA_EUNSUP, "chain-order matvec: no tree-norm instantiation for this shape");
+        const size_t ldst = (size_t)(p.K + chain_pad_floats(W, D, 4)) * sizeof(float);
+        constexpr int E = EPI != CEPI_RESID ? EPI : CEPI_QKV;
+        if (W == 1) RAMA_LAUNCH(c, (gemv_chain_kernel<1, 16, 4, E, CNORM_TREE>), grid, dim3(64), ldst, p);
+        else RAMA_LAUNCH(c, (gemv_chain_kernel<2, 16, 4, E, CNORM_TREE>), grid, dim3(128), ldst, p);
+        LAUNCHCHK();
+        return 0;
+    }
     if (p.nw) {      // the rmsnorm folded in (narrow models): the geometries such rows get, plus room for the squares
         REQUIRE(p.K <= 1024 && D == 16 && (W == 1 || W == 2) && (EPI == CEPI_QKV || EPI == CEPI_SWIGLU), RAMA_EUNSUP, "chain-order matvec: no norm-folding instantiation for this shape");
         const size_t ldsn = lds + ((size_t)p.K + ((size_t)p.K >> 5) + 4) * sizeof(float);
         constexpr int E = (EPI == CEPI_QKV || EPI == CEPI_SWIGLU) ? EPI : CEPI_QKV;
-        if (W == 1) RAMA_LAUNCH(c, (gemv_chain_kernel<1, 16, 4, E, true>), grid, dim3(64), ldsn, p);
-        else RAMA_LAUNCH(c, (gemv_chain_kernel<2, 16, 4, E, true>), grid, dim3(128), ldsn, p);
+        if (W == 1) RAMA_LAUNCH(c, (gemv_chain_kernel<1, 16, 4, E, CNORM_EXACT>), grid, dim3(64), ldsn, p);
+        else RAMA_LAUNCH(c, (gemv_chain_kernel<2, 16, 4, E, CNORM_EXACT>), grid, dim3(128), ldsn, p);
         LAUNCHCHK();
         return 0;
     }
@@ -510,7 +523,7 @@ static int launch_chain(rama_ctx* c, ChainParams& p) {
 static bool rmsnorm_chain_ok(size_t n) { return n <= (size_t)kNormMax && (n + (n >> 5) + 2) * sizeof(float) <= 64 * 1024; }
 static int launch_rmsnorm_chain(rama_ctx* c, float* o, const float* x, const float* w, int n, float* copy_to, int batch = 1, int stride = 0) {
     const size_t lds = ((size_t)n + ((size_t)n >> 5) + 2) * sizeof(float);
-    hipLaunchKernelGGL(rmsnorm_chain_kernel, dim3(batch), dim3(kNormThreads), lds, c->stream, o, x, w, n, copy_to, stride);
+    RAMA_LAUNCH(c, rmsnorm_chain_kernel, dim3(batch), dim3(kNormThreads), lds, o, x, w, n, copy_to, stride);
     LAUNCHCHK();
     return 0;
 }
@@ -691,7 +704,7 @@ static bool small_attn_at(const rama_ctx* c, int pos, bool split, int dim) {
 // 1 = split-T (long contexts), 2 = fewer waves per head (short contexts); parity mode 0 = 4 waves per head, 1 = 8 (pos >= 256),
 // 2 = three launches spread over the chip (pos >= 1024)
 static int attn_variant(const rama_ctx* c, const rama_config* cfg, int pos) {
-    if (c->tune_ref_order) return pos >= kSpreadAttnPos ? 2 : (pos >= kLongAttnPos ? 1 : 0);
+    if (c->tune_ref_order && !c->tune_tol) return pos >= kSpreadAttnPos ? 2 : (pos >= kLongAttnPos ? 1 : 0);
     const bool split = pos >= split_threshold(c, cfg);
     return split ? 1 : (small_attn_at(c, pos, split, cfg->dim) ? 2 : 0);
 }
@@ -926,6 +939,63 @@ static int try_launch_fused(rama_ctx* c, const rama_config* cfg, const rama_weig
     return 0;
 }
 
+// the fast path's norm-folding launches of a layer (also what tolerance mode's "tol_mask" swaps in for A/B runs)
+// infer.rs:19-33: rmsnorm, Wq|Wk|Wv, RoPE, cache append
+static int launch_fast_qkv(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s, size_t li, float* kc, float* vc) {
+    const int dim = cfg->dim, hs = dim / cfg->n_heads;
+    const size_t dd = (size_t)dim * dim;
+    KTimer kt(c, RAMA_K_QKV);
+    GemvParams p{};
+    p.w[0] = w->wq + li * dd; p.w[1] = w->wk + li * dd; p.w[2] = w->wv + li * dd;
+    p.x = s->x; p.nw = w->rms_att_weight + li * dim;
+    p.o[0] = s->q; p.o[1] = s->k; p.o[2] = s->v;
+    p.K = dim; p.rows = dim; p.nmat = 3;
+    p.ctl = c->ctl; p.fr = w->freq_cis_real; p.fi = w->freq_cis_imag; p.head_size = hs;
+    p.kc = kc; p.vc = vc;
+    p.zero_me = c->attn_counter;
+    if (use_solo(c, dim)) {
+        const dim3 grid((3 * ((dim + 3) / 4) + kSoloWaves - 1) / kSoloWaves), block(kSoloWaves * 64);
+        if (dim <= 512) RAMA_LAUNCH(c, (gemv_rows_solo<4, 2, true, EPI_QKV>), grid, block, 0, p);
+        else RAMA_LAUNCH(c, (gemv_rows_solo<4, 4, true, EPI_QKV>), grid, block, 0, p);
+    } else {
+        DISPATCH_GEOM(c, RAMA_LAUNCH(c, (gemv_rows<R_, CH_, NW_, true, EPI_QKV>), dim3(3 * (dim / R_)), dim3(NW_ * 64), 0, p));
+    }
+    LAUNCHCHK();
+    return 0;
+}
+// infer.rs:39-45: rmsnorm, W1|W3, SiLU * gate (w13i: the model's row-interleaved copy, or NULL)
+static int launch_fast_w13(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s, size_t li, const float* w13i) {
+    const int dim = cfg->dim, hidden = cfg->hidden_dim;
+    const size_t hd = (size_t)hidden * dim;
+    KTimer kt(c, RAMA_K_W13);
+    if (w13i && c->tune_w13i) {
+        // the model's row-interleaved copy: one [2 hidden, dim] matrix, rows (2i, 2i + 1) = (W1 row i, W3 row i)
+        GemvParams p{};
+        p.w[0] = w13i + li * 2 * hd; p.x = s->x; p.nw = w->rms_ffn_weight + li * dim; p.o[0] = s->hb;
+        p.K = dim; p.rows = 2 * hidden; p.nmat = 1;
+        if (use_solo(c, dim)) {
+            const dim3 grid(((2 * hidden + 3) / 4 + kSoloWaves - 1) / kSoloWaves), block(kSoloWaves * 64);
+            if (dim <= 512) RAMA_LAUNCH(c, (gemv_rows_solo<4, 2, true, EPI_SWIGLU_PAIR>), grid, block, 0, p);
+            else RAMA_LAUNCH(c, (gemv_rows_solo<4, 4, true, EPI_SWIGLU_PAIR>), grid, block, 0, p);
+        } else {
+            RAMA_LAUNCH(c, (gemv_rows<4, 2, 8, true, EPI_SWIGLU_PAIR>), dim3((2 * hidden + 3) / 4), dim3(8 * 64), 0, p);
+        }
+    } else {
+        SwigluParams p{};
+        p.w1 = w->w1 + li * hd; p.w3 = w->w3 + li * hd; p.x = s->x; p.nw = w->rms_ffn_weight + li * dim;
+        p.hb = s->hb; p.K = dim; p.rows = hidden;
+        if (use_solo(c, dim)) {
+            const dim3 grid(((hidden + 1) / 2 + kSoloWaves - 1) / kSoloWaves), block(kSoloWaves * 64);
+            if (dim <= 512) RAMA_LAUNCH(c, (gemv_swiglu_solo<2, 2>), grid, block, 0, p);
+            else RAMA_LAUNCH(c, (gemv_swiglu_solo<2, 4>), grid, block, 0, p);
+        } else {
+            DISPATCH_GEOM(c, RAMA_LAUNCH(c, (gemv_swiglu<R2_, CH_, NW_>), dim3((hidden + R2_ - 1) / R2_), dim3(NW_ * 64), 0, p));
+        }
+    }
+    LAUNCHCHK();
+    return 0;
+}
+
 // infer.rs:8-53 op by op in the reference's rounding order (ref_order.hpp); leaves EVERY RunState
 // buffer as the CPU path does (x, xb, xb2, hb, hb2, q, k, v, att, logits, caches)
 static int enqueue_stage_ref(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s, const rama_stage* st) {
@@ -996,6 +1066,14 @@ static int enqueue_stage_chain(rama_ctx* c, const rama_config* cfg, const rama_w
     REQUIRE(s->xb2 && s->hb2 && s->k && s->v, RAMA_EINVAL, "forward (reference order): xb2 / hb2 / k / v buffers are required");
     *done = true;
     const size_t dd = (size_t)dim * dim, hd = (size_t)hidden * dim;                 // chain-order copies keep the row-major sizes (rows are multiples of 16)
+    // tolerance mode ("ref_order" = 2): the matvecs as in parity mode, the norms folded into them as tree-shaped sums (dim <= 8192: all of x
+    // in a workgroup's registers; wider models keep the exact-sum norm launches), the fast path's attention
+    // "tol_mask" (A/B runs that say which op carries how much of the distance to the CPU path): 1 / 2 / 4 / 8 / 16 = the fast path's
+    // Wq|Wk|Wv / Wo / W1|W3 / W2 / classifier launch instead of the chain-order one, 32 = parity mode's attention, 64 = its exact-sum norm launches
+    const bool tol = c->tune_tol != 0;
+    const int mask = tol ? c->tune_tol_mask : 0;
+    const bool tol_fold = tol && dim <= 8192 && c->tune_chain_d <= 0 && !(mask & 64);
+    const float* w13i = (tol && (mask & 4) && st->layer_end > st->layer_begin && (double)hidden * dim * 8.0 < 2147483648.0) ? rama_internal_w13_lookup(w->w1, w->w3) : nullptr;
     int rc;
     if (st->do_embed) {
         hipLaunchKernelGGL(embed_kernel, dim3((dim + 255) / 256), dim3(256), 0, c->stream, s->x, w->token_embedding_table, (const Ctl*)c->ctl, 0, dim);
@@ -1006,36 +1084,42 @@ static int enqueue_stage_chain(rama_ctx* c, const rama_config* cfg, const rama_w
         float* kc = s->key_cache + li * cfg->seq_len * dim;
         float* vc = s->value_cache + li * cfg->seq_len * dim;
         // narrow models: the two norms of a layer ride in the matvecs that consume them (2 of 7 launches; "chain_norm")
-        const bool fold = c->tune_chain_norm && dim <= 512 && c->tune_chain_d <= 0;      // (measured: stories15M +6.6 %; at dim 768 the ripples cost more than the launch, -4 %)
-        if (!fold) { rc = launch_rmsnorm_chain(c, s->xb, s->x, w->rms_att_weight + li * dim, dim, nullptr); if (rc) return rc; }      // infer.rs:19
-        {   // :20-33: Wq | Wk | Wv, RoPE, cache append
+        const bool fold = tol ? tol_fold : (c->tune_chain_norm && dim <= 512 && c->tune_chain_d <= 0);      // (measured: stories15M +6.6 %; at dim 768 the ripples cost more than the launch, -4 %)
+        if (!fold && !(mask & 1)) { KTimer kt(c, RAMA_K_NORM); rc = launch_rmsnorm_chain(c, s->xb, s->x, w->rms_att_weight + li * dim, dim, nullptr); if (rc) return rc; }      // infer.rs:19
+        if (mask & 1) { rc = launch_fast_qkv(c, cfg, w, s, li, kc, vc); if (rc) return rc; }
+        else {   // :20-33: Wq | Wk | Wv, RoPE, cache append
             KTimer kt(c, RAMA_K_QKV);
             ChainParams p{};
             p.w[0] = cq + li * dd; p.w[1] = ck + li * dd; p.w[2] = cv + li * dd;
             p.o[0] = s->q; p.o[1] = s->k; p.o[2] = s->v; p.x = fold ? s->x : s->xb; p.nw = fold ? w->rms_att_weight + li * dim : nullptr;
             p.K = dim; p.rows = dim; p.nmat = 3;
             p.ctl = c->ctl; p.fr = w->freq_cis_real; p.fi = w->freq_cis_imag; p.head_size = hs; p.kc = kc; p.vc = vc;
-            rc = launch_chain<CEPI_QKV>(c, p); if (rc) return rc;
+            rc = launch_chain<CEPI_QKV>(c, p, tol); if (rc) return rc;
         }
         {   // :34
             KTimer kt(c, RAMA_K_ATTN);
-            rc = launch_attention_chain(c, s->xb, s->att, s->q, kc, vc, c->ctl, 0, dim, hs, cfg->seq_len, cfg->n_heads, c->long_attn, c->spread_attn); if (rc) return rc;
+            if (tol && !(mask & 32)) rc = launch_attention(c, s->xb, s->att, s->q, kc, vc, c->ctl, 0, dim, hs, cfg->seq_len, cfg->n_heads, c->split_attn);
+            else rc = launch_attention_chain(c, s->xb, s->att, s->q, kc, vc, c->ctl, 0, dim, hs, cfg->seq_len, cfg->n_heads, c->long_attn, c->spread_attn);
+            if (rc) return rc;
         }
-        {   // :35-37: xb2 = Wo . xb; x += xb2
+        if (mask & 2) { KTimer kt(c, RAMA_K_WO); rc = launch_rows<false, EPI_RESID>(c, s->x, w->wo + li * dd, s->xb, nullptr, dim, dim); if (rc) return rc; }
+        else {   // :35-37: xb2 = Wo . xb; x += xb2
             KTimer kt(c, RAMA_K_WO);
             ChainParams p{};
             p.w[0] = co + li * dd; p.o[0] = s->xb2; p.resid = s->x; p.x = s->xb; p.K = dim; p.rows = dim; p.nmat = 1;
             rc = launch_chain<CEPI_RESID>(c, p); if (rc) return rc;
         }
-        if (!fold) { rc = launch_rmsnorm_chain(c, s->xb, s->x, w->rms_ffn_weight + li * dim, dim, nullptr); if (rc) return rc; }       // :39
-        {   // :41-45: hb = silu(W1 . xb) * (hb2 = W3 . xb)
+        if (!fold && !(mask & 4)) { KTimer kt(c, RAMA_K_NORM); rc = launch_rmsnorm_chain(c, s->xb, s->x, w->rms_ffn_weight + li * dim, dim, nullptr); if (rc) return rc; }       // :39
+        if (mask & 4) { rc = launch_fast_w13(c, cfg, w, s, li, w13i); if (rc) return rc; }
+        else {   // :41-45: hb = silu(W1 . xb) * (hb2 = W3 . xb)
             KTimer kt(c, RAMA_K_W13);
             ChainParams p{};
             p.w[0] = c13 + li * 2 * hd; p.o[0] = s->hb; p.o[1] = s->hb2; p.x = fold ? s->x : s->xb; p.nw = fold ? w->rms_ffn_weight + li * dim : nullptr;
             p.K = dim; p.rows = 2 * hidden; p.nmat = 1;
-            rc = launch_chain<CEPI_SWIGLU>(c, p); if (rc) return rc;
+            rc = launch_chain<CEPI_SWIGLU>(c, p, tol); if (rc) return rc;
         }
-        {   // :46-47: xb = W2 . hb; x += xb
+        if (mask & 8) { KTimer kt(c, RAMA_K_W2); rc = launch_rows<false, EPI_RESID>(c, s->x, w->w2 + li * hd, s->hb, nullptr, hidden, dim); if (rc) return rc; }
+        else {   // :46-47: xb = W2 . hb; x += xb
             KTimer kt(c, RAMA_K_W2);
             ChainParams p{};
             p.w[0] = c2 + li * hd; p.o[0] = s->xb; p.resid = s->x; p.x = s->hb; p.K = hidden; p.rows = dim; p.nmat = 1;
@@ -1043,11 +1127,15 @@ static int enqueue_stage_chain(rama_ctx* c, const rama_config* cfg, const rama_w
         }
     }
     if (st->do_cls) {   // :49-51: xb = x; x = rmsnorm(xb); logits = Wcls . x
-        rc = launch_rmsnorm_chain(c, s->x, s->x, w->rms_final_weight, dim, s->xb); if (rc) return rc;
+        // (tolerance mode with the norm folded into the classifier leaves x and xb as the fast path does: the residual stream,
+        // not its normalised copy)
+        if (mask & 16) { KTimer kt(c, RAMA_K_CLS); return launch_rows<true, EPI_STORE>(c, s->logits, w->wcls, s->x, w->rms_final_weight, dim, V); }
+        if (!tol_fold) { KTimer kt(c, RAMA_K_NORM); rc = launch_rmsnorm_chain(c, s->x, s->x, w->rms_final_weight, dim, s->xb); if (rc) return rc; }
         KTimer kt(c, RAMA_K_CLS);
         ChainParams p{};
         p.w[0] = ccls; p.o[0] = s->logits; p.x = s->x; p.K = dim; p.rows = V; p.nmat = 1;
-        rc = launch_chain<CEPI_STORE>(c, p); if (rc) return rc;
+        if (tol_fold) p.nw = w->rms_final_weight;
+        rc = launch_chain<CEPI_STORE>(c, p, tol); if (rc) return rc;
     }
     return 0;
 }
@@ -1076,25 +1164,7 @@ static int enqueue_stage(rama_ctx* c, const rama_config* cfg, const rama_weights
         const size_t li = (size_t)(layer - st->layer_begin);
         float* kc = s->key_cache + li * cfg->seq_len * dim;
         float* vc = s->value_cache + li * cfg->seq_len * dim;
-        {   // infer.rs:19-33: rmsnorm, Wq|Wk|Wv, RoPE, cache append
-            KTimer kt(c, RAMA_K_QKV);
-            GemvParams p{};
-            p.w[0] = w->wq + li * dd; p.w[1] = w->wk + li * dd; p.w[2] = w->wv + li * dd;
-            p.x = s->x; p.nw = w->rms_att_weight + li * dim;
-            p.o[0] = s->q; p.o[1] = s->k; p.o[2] = s->v;
-            p.K = dim; p.rows = dim; p.nmat = 3;
-            p.ctl = c->ctl; p.fr = w->freq_cis_real; p.fi = w->freq_cis_imag; p.head_size = hs;
-            p.kc = kc; p.vc = vc;
-            p.zero_me = c->attn_counter;
-            if (use_solo(c, dim)) {
-                const dim3 grid((3 * ((dim + 3) / 4) + kSoloWaves - 1) / kSoloWaves), block(kSoloWaves * 64);
-                if (dim <= 512) RAMA_LAUNCH(c, (gemv_rows_solo<4, 2, true, EPI_QKV>), grid, block, 0, p);
-                else RAMA_LAUNCH(c, (gemv_rows_solo<4, 4, true, EPI_QKV>), grid, block, 0, p);
-            } else {
-                DISPATCH_GEOM(c, RAMA_LAUNCH(c, (gemv_rows<R_, CH_, NW_, true, EPI_QKV>), dim3(3 * (dim / R_)), dim3(NW_ * 64), 0, p));
-            }
-            LAUNCHCHK();
-        }
+        { const int rcq = launch_fast_qkv(c, cfg, w, s, li, kc, vc); if (rcq) return rcq; }      // infer.rs:19-33
         bool merged = false;
         const bool want_merge = merge_wanted(c, dim);
         if (want_merge && !c->split_attn && !c->small_attn && c->kp.kernel_id < 0) {   // infer.rs:34-37 as one launch (per-kernel timing keeps them apart)
@@ -1113,34 +1183,7 @@ static int enqueue_stage(rama_ctx* c, const rama_config* cfg, const rama_weights
                 if (rc) return rc;
             }
         }
-        {   // infer.rs:39-45: rmsnorm, W1|W3, SiLU * gate
-            KTimer kt(c, RAMA_K_W13);
-            if (w13i && c->tune_w13i) {
-                // the model's row-interleaved copy: one [2 hidden, dim] matrix, rows (2i, 2i + 1) = (W1 row i, W3 row i)
-                GemvParams p{};
-                p.w[0] = w13i + li * 2 * hd; p.x = s->x; p.nw = w->rms_ffn_weight + li * dim; p.o[0] = s->hb;
-                p.K = dim; p.rows = 2 * hidden; p.nmat = 1;
-                if (use_solo(c, dim)) {
-                    const dim3 grid(((2 * hidden + 3) / 4 + kSoloWaves - 1) / kSoloWaves), block(kSoloWaves * 64);
-                    if (dim <= 512) RAMA_LAUNCH(c, (gemv_rows_solo<4, 2, true, EPI_SWIGLU_PAIR>), grid, block, 0, p);
-                    else RAMA_LAUNCH(c, (gemv_rows_solo<4, 4, true, EPI_SWIGLU_PAIR>), grid, block, 0, p);
-                } else {
-                    RAMA_LAUNCH(c, (gemv_rows<4, 2, 8, true, EPI_SWIGLU_PAIR>), dim3((2 * hidden + 3) / 4), dim3(8 * 64), 0, p);
-                }
-            } else {
-                SwigluParams p{};
-                p.w1 = w->w1 + li * hd; p.w3 = w->w3 + li * hd; p.x = s->x; p.nw = w->rms_ffn_weight + li * dim;
-                p.hb = s->hb; p.K = dim; p.rows = hidden;
-                if (use_solo(c, dim)) {
-                    const dim3 grid(((hidden + 1) / 2 + kSoloWaves - 1) / kSoloWaves), block(kSoloWaves * 64);
-                    if (dim <= 512) RAMA_LAUNCH(c, (gemv_swiglu_solo<2, 2>), grid, block, 0, p);
-                    else RAMA_LAUNCH(c, (gemv_swiglu_solo<2, 4>), grid, block, 0, p);
-                } else {
-                    DISPATCH_GEOM(c, RAMA_LAUNCH(c, (gemv_swiglu<R2_, CH_, NW_>), dim3((hidden + R2_ - 1) / R2_), dim3(NW_ * 64), 0, p));
-                }
-            }
-            LAUNCHCHK();
-        }
+        { const int rcw = launch_fast_w13(c, cfg, w, s, li, w13i); if (rcw) return rcw; }        // infer.rs:39-45
         {   // infer.rs:46-47: x += W2 . hb
             KTimer kt(c, RAMA_K_W2);
             int rc = launch_rows<false, EPI_RESID>(c, s->x, w->w2 + li * hd, s->hb, nullptr, hidden, dim);
@@ -1265,7 +1308,17 @@ static int ensure_topp_scratch(rama_ctx* c, int n) {
 
 // the sampling tail of a step: argmax (temperature 0) or top-p, then whatever `fin` asks for
 // (result word, cursor advance, next embedding gather)
+static int enqueue_sample_launches(rama_ctx* c, ArgmaxParams fin, float temperature, float topp, float u);
 static int enqueue_sample(rama_ctx* c, ArgmaxParams fin, float temperature, float topp, float u) {
+    // kernel class RAMA_K_SAMPLE: up to three launches, so the bracket is a pair of event records around them (eager mode only)
+    KProf& k = c->kp;
+    const bool timed = k.kernel_id == RAMA_K_SAMPLE && k.used < k.max_records;
+    if (timed) HIPCHK(hipEventRecord(k.ev[2 * k.used], c->stream));
+    const int rc = enqueue_sample_launches(c, fin, temperature, topp, u);
+    if (timed) { HIPCHK(hipEventRecord(k.ev[2 * k.used + 1], c->stream)); k.used++; }
+    return rc;
+}
+static int enqueue_sample_launches(rama_ctx* c, ArgmaxParams fin, float temperature, float topp, float u) {
     if (temperature == 0.0f) {
         hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, c->stream, fin);
         LAUNCHCHK();
@@ -2371,8 +2424,15 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
         return 0;
     }
     if (!strcmp(key, "ref_order")) {
-        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: ref_order must be 0 or 1");
-        c->tune_ref_order = value;
+        REQUIRE(value >= 0 && value <= 2, RAMA_EINVAL, "set_tuning: ref_order must be 0, 1 or 2");
+        c->tune_ref_order = value != 0; c->tune_tol = value == 2;
+        hipStreamSynchronize(c->stream);
+        drop_graph(c);
+        return 0;
+    }
+    if (!strcmp(key, "tol_mask")) {
+        REQUIRE(value >= 0 && value < 128, RAMA_EINVAL, "set_tuning: tol_mask must be 0..127");
+        c->tune_tol_mask = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
         return 0;

@@ -11,7 +11,7 @@ import numpy as np
 from ._lib import check, rama_config, rama_run_state, rama_stage, rama_weights
 from .transformer import Config, Hip
 
-KERNEL_IDS = dict(qkv=0, attn=1, wo=2, w13=3, w2=4, cls=5)
+KERNEL_IDS = dict(qkv=0, attn=1, wo=2, w13=3, w2=4, cls=5, norm=6, sample=7)
 
 
 def algorithmic_bytes(cfg: Config) -> dict:
@@ -180,7 +180,7 @@ class Engine:
     def kprof(self, kernel: str, n_steps: int):
         """average device time (ms) of one launch of a kernel class over n_steps decode steps"""
         L = self.device.lib
-        check(L.rama_kprof_enable(self.device.ctx, KERNEL_IDS[kernel], n_steps * max(self.cfg.n_layers, 1)))
+        check(L.rama_kprof_enable(self.device.ctx, KERNEL_IDS[kernel], n_steps * (2 * max(self.cfg.n_layers, 1) + 1)))
         self.decode_steps(n_steps)
         n, tot = C.c_int(), C.c_double()
         check(L.rama_kprof_read(self.device.ctx, C.byref(n), C.byref(tot)))

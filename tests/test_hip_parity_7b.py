@@ -2,8 +2,11 @@
 generated bit-identically on both sides, the generate() loop of transformer/mod.rs:169-206 on
 'once upon a time' for 200 positions (the README bench length, README.md:80-83).
 
-Per position four logit vectors are compared:
+Per position five logit vectors are compared:
     HIP      the product's fast path (rama_forward through the C ABI)
+    HIP-tol  the same entry in TOLERANCE mode (rama_set_tuning "ref_order" = 2; bench.py's `value`): the chain-order
+             matvecs of parity mode -- the reference's rounding sequence, where its 1.5e-4 lives -- with the rmsnorm
+             sums tree-shaped and folded into them and the fast path's attention
     HIP-ref  the same entry in reference-order mode (rama_set_tuning "ref_order" = 1,
              csrc/ref_order.hpp): every sum in the reference's own order, glibc's expf restated
     oracle   oracle/rama_oracle.c, the line-by-line restatement of engine/src/device/cpu.rs
@@ -12,7 +15,7 @@ Per position four logit vectors are compared:
              that says how far each fp32 path sits from the exact result
 All four are fed the SAME token sequence (the oracle's greedy choice), so caches stay comparable.
 
-The per-position numbers are written to gpurun_out/r03_parity_llama2_7b_200pos.json (copied to
+The per-position numbers are written to gpurun_out/r04_parity_llama2_7b_200pos.json (copied to
 profiles/ by the builder) whatever the outcome; the assertions come last.
 
 What is asserted, and why not simply "fast path within 1e-4 of the oracle": the reference arithmetic
@@ -21,6 +24,8 @@ terms, 32 layers), the fast path ~2e-5; their difference is therefore the refere
 error and crosses 1e-4 from about position 50 on.  So:
   * HIP-ref vs oracle <= 1e-4 at every position -- the north_star bar, met by reproducing the
     reference's rounding (expected: identical bits);
+  * HIP-tol vs oracle <= 1e-4 at every position -- the same bar as a TOLERANCE, at >= 0.70 of the HBM roofline
+    (expected ~1e-5), greedy tokens identical to the oracle's;
   * HIP (fast) vs f64 <= 1e-4 and never worse than oracle vs f64; greedy tokens identical to the
     oracle's at every position;
   * HIP (fast) vs oracle is recorded per position, positions over 1e-4 are listed in the JSON, and it
@@ -85,8 +90,9 @@ def test_llama2_7b_full_depth_200_positions(dev):
     model = rama_amd.Model.synth(dev, to_rama_cfg(cfg), 0, rope=rope)
     eng = rama_amd.Engine(dev, model)
     eng_ref = rama_amd.Engine(dev, model)
+    eng_tol = rama_amd.Engine(dev, model)
 
-    rows, toks_cpu, toks_hip = [], [], []
+    rows, toks_cpu, toks_hip, toks_tol = [], [], [], []
     token = 1
     t_cpu = t_f64 = 0.0
     for pos in range(n_pos):
@@ -105,7 +111,15 @@ def test_llama2_7b_full_depth_200_positions(dev):
             lr = eng_ref.logits()
         finally:
             eng_ref.set_tuning("ref_order", 0)
+        eng_tol.set_tuning("ref_order", 2)
+        try:
+            eng_tol.forward(token, pos)
+            lt = eng_tol.logits()
+        finally:
+            eng_tol.set_tuning("ref_order", 0)
         rows.append({"pos": pos, "token": int(token),
+                     "hip_tolerance_vs_oracle": float(np.abs(lt - lo).max()),
+                     "hip_tolerance_vs_f64": float(np.abs(lt - l64).max()),
                      "hip_ref_order_vs_oracle": float(np.abs(lr - lo).max()),
                      "hip_ref_order_bits_equal": bool(np.array_equal(lr.view(np.uint32), lo.view(np.uint32))),
                      "hip_vs_oracle": float(np.abs(lg - lo).max()),
@@ -113,6 +127,7 @@ def test_llama2_7b_full_depth_200_positions(dev):
                      "oracle_vs_f64": float(np.abs(lo - l64).max())})
         toks_cpu.append(int(O.argmax(lo)))
         toks_hip.append(int(np.flatnonzero(lg == lg.max())[-1]))
+        toks_tol.append(int(np.flatnonzero(lt == lt.max())[-1]))
         token = PROMPT[pos] if pos < len(PROMPT) else toks_cpu[-1]
 
     worst = max(r["hip_vs_oracle"] for r in rows)
@@ -122,6 +137,9 @@ def test_llama2_7b_full_depth_200_positions(dev):
         "positions": n_pos, "bar": LOGIT_ATOL,
         "worst_hip_ref_order_vs_oracle": max(r["hip_ref_order_vs_oracle"] for r in rows),
         "positions_ref_order_bit_identical": sum(r["hip_ref_order_bits_equal"] for r in rows),
+        "worst_hip_tolerance_vs_oracle": max(r["hip_tolerance_vs_oracle"] for r in rows),
+        "positions_tolerance_over_bar": [r["pos"] for r in rows if r["hip_tolerance_vs_oracle"] > LOGIT_ATOL],
+        "greedy_tokens_equal_tolerance": toks_cpu == toks_tol,
         "worst_hip_vs_oracle": worst,
         "worst_hip_vs_f64": max(r["hip_vs_f64"] for r in rows),
         "worst_oracle_vs_f64": max(r["oracle_vs_f64"] for r in rows),
@@ -132,7 +150,7 @@ def test_llama2_7b_full_depth_200_positions(dev):
         "f64_s_per_token": round(t_f64 / n_pos, 3), "oracle_threads": threads,
         "per_position": rows,
     }
-    path = Path(os.environ.get("RAMA_PARITY_JSON", REPO / "gpurun_out" / "r03_parity_llama2_7b_200pos.json"))
+    path = Path(os.environ.get("RAMA_PARITY_JSON", REPO / "gpurun_out" / "r04_parity_llama2_7b_200pos.json"))
     try:
         path.parent.mkdir(parents=True, exist_ok=True)
         path.write_text(json.dumps(out, indent=1))
@@ -141,9 +159,12 @@ def test_llama2_7b_full_depth_200_positions(dev):
     print(json.dumps({k: v for k, v in out.items() if k != "per_position"}))
     eng.free()
 
-    eng_ref.free(); model.free()
+    eng_ref.free(); eng_tol.free(); model.free()
     # the north_star bar, literally: logits within 1e-4 of the CPU reference path at every position
     assert out["worst_hip_ref_order_vs_oracle"] <= LOGIT_ATOL, out["worst_hip_ref_order_vs_oracle"]
+    # ... and as a tolerance, by the mode bench.py times as `value`
+    assert out["worst_hip_tolerance_vs_oracle"] <= LOGIT_ATOL, (out["worst_hip_tolerance_vs_oracle"], out["positions_tolerance_over_bar"])
+    assert toks_cpu == toks_tol
     # the fast path: within 1e-4 of the exact logits, never further from them than the reference is
     assert out["worst_hip_vs_f64"] <= LOGIT_ATOL, out["worst_hip_vs_f64"]
     assert all(r["hip_vs_f64"] <= r["oracle_vs_f64"] for r in rows)
