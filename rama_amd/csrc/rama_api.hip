@@ -101,6 +101,8 @@ struct rama_ctx {
     int tune_ref_order = 0;                // 1: every op in the reference's own rounding order: bit-comparable with the CPU path ("parity mode")
     int tune_tol = 0;                      // "ref_order" = 2, tolerance mode: the chain-order matvecs (the reference's rounding sequence, where its 1.5e-4 lives) with
                                            // the layer norms folded into them as tree-shaped sums and the fast attention: within 1e-4 of the CPU path, not bit-identical
+    int tune_seqsum_wave = 0;              // tests: rama_rmsnorm in parity mode runs rmsnorm_wave_kernel (seq_sum_wave) for n <= 4096
+    int tune_tol_delay = 0;                // experiment: dependent vector instructions in front of the staging of a norm-folding chain matvec
     int tune_tol_mask = 0;                 // tolerance mode, A/B: ops swapped for the fast path's (1 qkv, 2 wo, 4 w13, 8 w2, 16 cls) or parity mode's (32 attention, 64 norms)
     int tune_chain = 1;                    // parity mode streams the model's chain-order weight copy (chain.hpp); 0: ref_order.hpp's one-thread-per-row kernels
     int tune_chain_d = 0;                  // chain-order matvec geometry: 0 = by row groups per CU, else 100 W + D (waves per group, blocks per wave in flight)
@@ -472,9 +474,13 @@ static int launch_attention_ref(rama_ctx* c, float* xb, float* att, const float*
 
 // W waves per 16 rows, D blocks per wave in flight: by how many row groups share a CU (few groups -> more waves
 // and deeper rings per group, so that >= ~128 KiB per CU are on the way); tune_chain_d = 100 W + D overrides
+// norm: how the rmsnorm in front of the product is folded in when p.nw is given -- CNORM_WAVE (parity mode: the exact sequential sum by one
+// wave, K <= 4096), CNORM_TREE (tolerance mode: a tree-shaped sum, K <= 8192), CNORM_EXACT (round 3's lane ripples, K <= 1024)
+static bool chain_norm_fits(int K, int norm) { return K % 16 == 0 && K <= (norm == CNORM_WAVE ? 4096 : (norm == CNORM_TREE ? 8192 : 1024)); }
 template <int EPI>
-static int launch_chain(rama_ctx* c, ChainParams& p, bool tree_norm = false) {
+static int launch_chain(rama_ctx* c, ChainParams& p, int norm = CNORM_NONE) {
     REQUIRE(p.K % 16 == 0 && p.K > 0 && p.rows > 0, RAMA_EINVAL, "chain-order matvec: width must be a multiple of 16");
+    REQUIRE((p.nw != nullptr) == (norm != CNORM_NONE), RAMA_EINVAL, "chain-order matvec: a folded norm needs its gain vector");
     const int groups = p.nmat * ((p.rows + 15) / 16);
     int W, D;
     if (c->tune_chain_d > 0) { W = c->tune_chain_d / 100; D = c->tune_chain_d % 100; }
@@ -487,23 +493,25 @@ static int launch_chain(rama_ctx* c, ChainParams& p, bool tree_norm = false) {
     if ((size_t)(p.K + chain_pad_floats(W, D, 4)) * sizeof(float) > 64 * 1024) { W = 1; D = 16; }
     const size_t lds = (size_t)(p.K + chain_pad_floats(W, D, 4)) * sizeof(float);      // x + the zeros behind it
     REQUIRE(lds <= 64 * 1024, RAMA_EUNSUP, "chain-order matvec: row longer than ~15800 floats");
+    p.delay = c->tune_tol_delay;
     const dim3 grid(groups);
-    if (p.nw && tree_norm) {      // tolerance mode: the rmsnorm folded in with a tree-shaped sum of squares; all of x must sit in the workgroup's registers (K <= 64 x threads)
+    if (norm != CNORM_NONE) {      // the rmsnorm folded in: all of x sits in the workgroup's registers (K <= 64 x threads)
         if (c->tune_chain_d <= 0 && W == 1 && p.K > 4096) W = 2;
-        REQUIRE(p.K <= 4096 * W && D == 16 && (W == 1 || W == 2) && EPI != CEPI_RESID, RAMA_EUNSUP, "chain-order matvec: no tree-norm instantiation for this shape");
-        const size_t ldst = (size_t)(p.K + chain_pad_floats(W, D, 4)) * sizeof(float);
+        REQUIRE(chain_norm_fits(p.K, norm) && p.K <= 4096 * W && D == 16 && (W == 1 || W == 2) && EPI != CEPI_RESID, RAMA_EUNSUP, "chain-order matvec: no norm-folding instantiation for this shape");
+        size_t ldsn = (size_t)(p.K + chain_pad_floats(W, D, 4)) * sizeof(float);
+        if (norm == CNORM_EXACT) ldsn += ((size_t)p.K + ((size_t)p.K >> 5) + 4) * sizeof(float);      // + the squares, scan_slot layout
+        if (norm == CNORM_WAVE) ldsn = std::max(ldsn, (size_t)chain_nat_floats(p.K) * sizeof(float));
         constexpr int E = EPI != CEPI_RESID ? EPI : CEPI_QKV;
-        if (W == 1) RAMA_LAUNCH(c, (gemv_chain_kernel<1, 16, 4, E, CNORM_TREE>), grid, dim3(64), ldst, p);
-        else RAMA_LAUNCH(c, (gemv_chain_kernel<2, 16, 4, E, CNORM_TREE>), grid, dim3(128), ldst, p);
-        LAUNCHCHK();
-        return 0;
-    }
-    if (p.nw) {      // the rmsnorm folded in (narrow models): the geometries such rows get, plus room for the squares
-        REQUIRE(p.K <= 1024 && D == 16 && (W == 1 || W == 2) && (EPI == CEPI_QKV || EPI == CEPI_SWIGLU), RAMA_EUNSUP, "chain-order matvec: no norm-folding instantiation for this shape");
-        const size_t ldsn = lds + ((size_t)p.K + ((size_t)p.K >> 5) + 4) * sizeof(float);
-        constexpr int E = (EPI == CEPI_QKV || EPI == CEPI_SWIGLU) ? EPI : CEPI_QKV;
-        if (W == 1) RAMA_LAUNCH(c, (gemv_chain_kernel<1, 16, 4, E, CNORM_EXACT>), grid, dim3(64), ldsn, p);
-        else RAMA_LAUNCH(c, (gemv_chain_kernel<2, 16, 4, E, CNORM_EXACT>), grid, dim3(128), ldsn, p);
+#define RAMA_CHAIN_N(W_, N_) RAMA_LAUNCH(c, (gemv_chain_kernel<W_, 16, 4, E, N_>), grid, dim3(W_ * 64), ldsn, p)
+        if (norm == CNORM_WAVE) { if (W == 1) RAMA_CHAIN_N(1, CNORM_WAVE); else RAMA_CHAIN_N(2, CNORM_WAVE); }
+        else if (norm == CNORM_TREE) { if (W == 1) RAMA_CHAIN_N(1, CNORM_TREE); else RAMA_CHAIN_N(2, CNORM_TREE); }
+        else {
+            REQUIRE(EPI == CEPI_QKV || EPI == CEPI_SWIGLU, RAMA_EUNSUP, "chain-order matvec: the lane-ripple norm folds into Wq|Wk|Wv and W1|W3 only");
+            constexpr int E2 = (EPI == CEPI_QKV || EPI == CEPI_SWIGLU) ? EPI : CEPI_QKV;
+            if (W == 1) RAMA_LAUNCH(c, (gemv_chain_kernel<1, 16, 4, E2, CNORM_EXACT>), grid, dim3(64), ldsn, p);
+            else RAMA_LAUNCH(c, (gemv_chain_kernel<2, 16, 4, E2, CNORM_EXACT>), grid, dim3(128), ldsn, p);
+        }
+#undef RAMA_CHAIN_N
         LAUNCHCHK();
         return 0;
     }
@@ -598,6 +606,10 @@ int rama_copy_from_slice(rama_ctx* c, float* t, const float* s, size_t n) {
 }
 int rama_rmsnorm(rama_ctx* c, float* o, const float* x, const float* w, size_t n) {
     REQUIRE(c && o && x && w && n > 0, RAMA_EINVAL, "rmsnorm: bad argument");
+    if (c->tune_ref_order && c->tune_seqsum_wave && n <= 4096 && o != x) {      // tests: the one-wave exact sum the norm-folding matvecs use
+        hipLaunchKernelGGL(rmsnorm_wave_kernel, dim3(1), dim3(64), 0, c->stream, o, x, w, (int)n);
+        LAUNCHCHK(); return 0;
+    }
     if (c->tune_ref_order) return c->tune_chain && rmsnorm_chain_ok(n) ? launch_rmsnorm_chain(c, o, x, w, (int)n, nullptr) : launch_rmsnorm_ref(c, o, x, w, (int)n);
     hipLaunchKernelGGL(rmsnorm_kernel, dim3(1), dim3(1024), 0, c->stream, o, x, w, (int)n);
     LAUNCHCHK(); return 0;
@@ -1073,6 +1085,11 @@ static int enqueue_stage_chain(rama_ctx* c, const rama_config* cfg, const rama_w
     const bool tol = c->tune_tol != 0;
     const int mask = tol ? c->tune_tol_mask : 0;
     const bool tol_fold = tol && dim <= 8192 && c->tune_chain_d <= 0 && !(mask & 64);
+    // parity mode: the exact norms ride in the matvecs that consume them ("chain_norm": 1 = seq_sum_wave, dim <= 4096; 2 = round 3's
+    // lane ripples, dim <= 512; 0 = launches of their own)
+    const int par_norm = (!tol && c->tune_chain_d <= 0) ? (c->tune_chain_norm == 1 && chain_norm_fits(dim, CNORM_WAVE) ? CNORM_WAVE
+                                                            : (c->tune_chain_norm == 2 && dim <= 512 ? CNORM_EXACT : CNORM_NONE)) : CNORM_NONE;
+    const int lnorm = tol ? (tol_fold ? CNORM_TREE : CNORM_NONE) : par_norm;      // how the layer norms are folded
     const float* w13i = (tol && (mask & 4) && st->layer_end > st->layer_begin && (double)hidden * dim * 8.0 < 2147483648.0) ? rama_internal_w13_lookup(w->w1, w->w3) : nullptr;
     int rc;
     if (st->do_embed) {
@@ -1084,7 +1101,7 @@ static int enqueue_stage_chain(rama_ctx* c, const rama_config* cfg, const rama_w
         float* kc = s->key_cache + li * cfg->seq_len * dim;
         float* vc = s->value_cache + li * cfg->seq_len * dim;
         // narrow models: the two norms of a layer ride in the matvecs that consume them (2 of 7 launches; "chain_norm")
-        const bool fold = tol ? tol_fold : (c->tune_chain_norm && dim <= 512 && c->tune_chain_d <= 0);      // (measured: stories15M +6.6 %; at dim 768 the ripples cost more than the launch, -4 %)
+        const bool fold = lnorm != CNORM_NONE;
         if (!fold && !(mask & 1)) { KTimer kt(c, RAMA_K_NORM); rc = launch_rmsnorm_chain(c, s->xb, s->x, w->rms_att_weight + li * dim, dim, nullptr); if (rc) return rc; }      // infer.rs:19
         if (mask & 1) { rc = launch_fast_qkv(c, cfg, w, s, li, kc, vc); if (rc) return rc; }
         else {   // :20-33: Wq | Wk | Wv, RoPE, cache append
@@ -1094,7 +1111,7 @@ static int enqueue_stage_chain(rama_ctx* c, const rama_config* cfg, const rama_w
             p.o[0] = s->q; p.o[1] = s->k; p.o[2] = s->v; p.x = fold ? s->x : s->xb; p.nw = fold ? w->rms_att_weight + li * dim : nullptr;
             p.K = dim; p.rows = dim; p.nmat = 3;
             p.ctl = c->ctl; p.fr = w->freq_cis_real; p.fi = w->freq_cis_imag; p.head_size = hs; p.kc = kc; p.vc = vc;
-            rc = launch_chain<CEPI_QKV>(c, p, tol); if (rc) return rc;
+            rc = launch_chain<CEPI_QKV>(c, p, fold ? lnorm : CNORM_NONE); if (rc) return rc;
         }
         {   // :34
             KTimer kt(c, RAMA_K_ATTN);
@@ -1116,7 +1133,7 @@ static int enqueue_stage_chain(rama_ctx* c, const rama_config* cfg, const rama_w
             ChainParams p{};
             p.w[0] = c13 + li * 2 * hd; p.o[0] = s->hb; p.o[1] = s->hb2; p.x = fold ? s->x : s->xb; p.nw = fold ? w->rms_ffn_weight + li * dim : nullptr;
             p.K = dim; p.rows = 2 * hidden; p.nmat = 1;
-            rc = launch_chain<CEPI_SWIGLU>(c, p, tol); if (rc) return rc;
+            rc = launch_chain<CEPI_SWIGLU>(c, p, fold ? lnorm : CNORM_NONE); if (rc) return rc;
         }
         if (mask & 8) { KTimer kt(c, RAMA_K_W2); rc = launch_rows<false, EPI_RESID>(c, s->x, w->w2 + li * hd, s->hb, nullptr, hidden, dim); if (rc) return rc; }
         else {   // :46-47: xb = W2 . hb; x += xb
@@ -1135,7 +1152,7 @@ static int enqueue_stage_chain(rama_ctx* c, const rama_config* cfg, const rama_w
         ChainParams p{};
         p.w[0] = ccls; p.o[0] = s->logits; p.x = s->x; p.K = dim; p.rows = V; p.nmat = 1;
         if (tol_fold) p.nw = w->rms_final_weight;
-        rc = launch_chain<CEPI_STORE>(c, p, tol); if (rc) return rc;
+        rc = launch_chain<CEPI_STORE>(c, p, tol_fold ? CNORM_TREE : CNORM_NONE); if (rc) return rc;
     }
     return 0;
 }
@@ -2353,7 +2370,7 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
         return 0;
     }
     if (!strcmp(key, "chain_norm")) {
-        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: chain_norm must be 0 or 1");
+        REQUIRE(value >= 0 && value <= 2, RAMA_EINVAL, "set_tuning: chain_norm must be 0, 1 or 2");
         c->tune_chain_norm = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
@@ -2426,6 +2443,18 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
     if (!strcmp(key, "ref_order")) {
         REQUIRE(value >= 0 && value <= 2, RAMA_EINVAL, "set_tuning: ref_order must be 0, 1 or 2");
         c->tune_ref_order = value != 0; c->tune_tol = value == 2;
+        hipStreamSynchronize(c->stream);
+        drop_graph(c);
+        return 0;
+    }
+    if (!strcmp(key, "seqsum_wave")) {
+        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: seqsum_wave must be 0 or 1");
+        c->tune_seqsum_wave = value;
+        return 0;
+    }
+    if (!strcmp(key, "tol_delay")) {
+        REQUIRE(value >= 0 && value <= 100000, RAMA_EINVAL, "set_tuning: tol_delay must be 0..100000");
+        c->tune_tol_delay = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
         return 0;
