@@ -6,16 +6,17 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 N = 1: one decode step = one forward() (infer.rs:8-53) + greedy sample, chained on the device,
-starting at pos 0 like generate() (BOS, then the Rama-BPE ids of 'once upon a time').  Three modes of
+starting at pos 0 like generate() (BOS, then the Rama-BPE ids of 'once upon a time').  Two modes of
 the SAME entry points are timed in one run:
-  * tolerance mode (`value`): the matvecs in the reference CPU path's own rounding order on the model's
-    chain-order weight copy (csrc/chain.hpp) -- that is where the reference's 1.5e-4 of rounding error
-    lives -- with the rmsnorm sums tree-shaped and folded into them and the fast path's attention:
-    logits within 1e-4 of engine/src/device/cpu.rs (north_star's bar, asserted over 200 full-depth
-    positions by tests/test_hip_parity_7b.py and checked against the oracle in this run);
-  * parity mode (`parity_mode`): EVERY op in the reference's rounding order -- logits bit-identical;
+  * parity mode (`value`): every op in the reference CPU path's own rounding order, on the model's
+    chain-order weight copy (csrc/chain.hpp) -- logits bit-identical to engine/src/device/cpu.rs, the
+    only way to stay within north_star's 1e-4 over a 200-token generation at llama2-7B depth (checked
+    against the oracle in this run; 200 positions by tests/test_hip_parity_7b.py);
   * fast mode (`fast_mode`): fused multiply-adds and tree-shaped sums (csrc/kernels.hpp) -- closer to
     the exact logits than the reference itself, but up to 1.5e-4 from it at full depth.
+`--mode tol` / `--mode all` adds the tolerance-mode experiment (chain-order matvecs with tree-summed
+norms folded in and the fast attention: 0.72 of the roofline, but 1.4e-4 from the CPU path -- a sum of
+squares in another order is enough to leave the bar; profiles/r04_tolerance_sweep_7b_200pos.jsonl).
 Then stories15M / stories110M (BASELINE.json configs 2-3) in both modes (`other_configs`).
 N > 1: the layer stack is pipeline-sharded over the N ranks with N sequences in flight; a step advances
 every sequence by one token (rama_amd/pipeline.py, csrc/pipe.hip).
@@ -56,10 +57,10 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--config", default="llama2-7B", choices=list(SHAPES))
     ap.add_argument("--graph", type=int, default=1, help="replay each decode step from a hipGraph")
-    ap.add_argument("--mode", default="all", choices=["all", "both", "tol", "parity", "fast"],
-                    help="tol: chain-order matvecs + folded tree norms + fast attention (within 1e-4 of the CPU path; the headline); "
-                         "parity: every op in the reference's rounding order (bit-identical logits); fast: fused/tree sums; "
-                         "all: the three of them; both: tol + fast")
+    ap.add_argument("--mode", default="both", choices=["both", "all", "tol", "parity", "fast"],
+                    help="parity: every op in the reference's rounding order (bit-identical logits; the headline); fast: fused/tree sums; "
+                         "tol: chain-order matvecs + folded tree-summed norms + fast attention (an experiment: 1.4e-4 from the CPU path at 7B); "
+                         "both: parity + fast; all: the three of them")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="rama_set_tuning(KEY, VALUE) on every engine before timing (A/B runs under the profiler); repeatable")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -268,8 +269,8 @@ def kernel_times(eng, cfg_seq, pos, tokens, bytes_, ksteps=16):
 TUNE = []      # (key, value) pairs of --tune
 REF_ORDER = {"fast": 0, "parity": 1, "tol": 2}      # rama_set_tuning("ref_order", .)
 MODE_TEXT = {
-    "tol": "tolerance: chain-order matvecs in the reference CPU path's rounding order (cpu.rs:127-153), rmsnorm sums tree-shaped and folded "
-           "into them, the fast path's attention -- logits within 1e-4 of cpu.rs",
+    "tol": "tolerance (experiment): chain-order matvecs in the reference CPU path's rounding order (cpu.rs:127-153), rmsnorm sums tree-shaped and folded "
+           "into them, the fast path's attention -- 1.4e-4 from cpu.rs over 200 full-depth positions",
     "parity": "parity: every op in the reference CPU path's rounding order (chain-order weight copy), logits bit-identical to cpu.rs",
     "fast": "fast: fused multiply-adds, tree-shaped sums",
 }
@@ -353,8 +354,8 @@ def single_gpu(args, local_rank):
     import rama_amd
     TUNE[:] = [(kv.split("=")[0], int(kv.split("=")[1])) for kv in args.tune]
     dev = rama_amd.Hip(local_rank)
-    modes = {"all": ["fast", "parity", "tol"], "both": ["fast", "tol"]}.get(args.mode, [args.mode])
-    head = "tol" if "tol" in modes else ("parity" if "parity" in modes else "fast")
+    modes = {"all": ["fast", "tol", "parity"], "both": ["fast", "parity"]}.get(args.mode, [args.mode])
+    head = "parity" if "parity" in modes else modes[-1]
     cfg, model, bytes_, res = run_shape(dev, args.config, args.steps, args.warmup, args.pos0, args.graph, modes, not args.no_kprof,
                                         sampled=() if args.no_sampled else (head,))
     d, h, L, H, V, seq, shared = SHAPES[args.config]

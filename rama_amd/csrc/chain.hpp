@@ -400,138 +400,6 @@ __device__ __forceinline__ float seq_sum_ripples(const float* a, int n, PredShar
     return ps.result;
 }
 
-// ---------------------------------------------------------------- the same sum by ONE wave, everything in registers
-// For the matvec kernels that fold the rmsnorm in (gemv_chain_kernel<..., CNORM_WAVE>): every workgroup forms the exact sum
-// of squares itself while its first weights are on their way from HBM, so the sum must cost about one memory round trip
-// on a single wave -- no LDS traffic, no barriers, as few vector instructions as possible (a lone wave issues one per ~4
-// cycles).  Lane t holds the 64 consecutive elements a[64 t .. 64 t + 63] (zeros behind the list), as four sub-runs of 16:
-//   1. approximate prefix sums at the sub-run borders (tree sums + one DPP scan over the lane totals);
-//   2. a sub-run whose borders, widened by 2^-13, lie in ONE binade e is a MAP sub-run: its 16 increments for U = ulp(2^e)
-//      are summed (v_rndne of a / U; the parity-dependent tie corrections are applied in a branch the wave only takes when
-//      some lane has a tie at that element, ~10 times per sum) into one map c -> c + D[c & 1]; any other sub-run is a SEQ
-//      sub-run (the sum may change binade inside it: about one per crossing, plus the head of the list);
-//   3. a lane whose four sub-runs are MAP sub-runs of one binade is PLAIN: its four maps are composed, and a segmented DPP
-//      scan composes neighbouring plain lanes;
-//   4. the walk, in the scalar unit, visits the other lanes in order with the true sum: the map of the plain lanes in front
-//      of it (checked: the true sum IS in the predicted binade and still is behind the segment), then its four sub-runs --
-//      a MAP sub-run's map, checked the same way, or 16 fp32 adds by the owning lane.
-// A failed check (never seen; it takes an approximate prefix sum 1e-4 off) redoes the walk with every sub-run SEQ: the
-// plain sequential sum.  The result is the sequential fp32 sum bit for bit (tests/test_hip_ref_order.py, "seqsum_wave").
-struct WaveMap { int conf, e, d0, d1; };
-__device__ __forceinline__ int rl(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
-// s <- the map (e, d0, d1) applied to the exact sum s (its bits), or bad |= 1 when s is not in binade e before or behind it
-__device__ __forceinline__ unsigned wave_map_apply(unsigned sb, int e, int d0, int d1, int& bad) {
-    const int c0 = (int)((sb & 0x7FFFFFu) | 0x800000u);
-    const int c = c0 + ((c0 & 1) ? d1 : d0);
-    bad |= ((int)(sb >> 23) != e || c > (1 << 24) - 1) ? 1 : 0;
-    return ((unsigned)e << 23) | ((unsigned)c & 0x7FFFFFu);
-}
-// the squares of sub-run k of this lane's run (`run`: the lane's 64 list elements x_i in LDS, 16-byte aligned; `nv`: how many of
-// them are inside the list -- a multiple of 4 -- the rest count as zeros)
-__device__ __forceinline__ void wave_sub_squares(const float* run, int nv, int k, float (&sq)[16]) {
-    RAMA_NO_CONTRACT
-#pragma unroll
-    for (int m_ = 0; m_ < 4; m_++) {
-        const f4 t4 = 16 * k + 4 * m_ < nv ? *reinterpret_cast<const f4*>(run + 16 * k + 4 * m_) : f4{0.f, 0.f, 0.f, 0.f};
-        sq[4 * m_] = t4.x * t4.x; sq[4 * m_ + 1] = t4.y * t4.y; sq[4 * m_ + 2] = t4.z * t4.z; sq[4 * m_ + 3] = t4.w * t4.w;
-    }
-}
-__device__ __forceinline__ void wave_sub_map(const float (&sq)[16], float lo, float hi, WaveMap& m) {
-    RAMA_NO_CONTRACT
-    const int el = (int)(__float_as_uint(lo * (1.0f - 0x1p-13f)) >> 23), eh = (int)(__float_as_uint(hi * (1.0f + 0x1p-13f)) >> 23);
-    const bool conf = lo > 0.0f && el == eh && el >= 24 && el <= 253;     // (a sign bit, inf or nan makes the exponents differ or leave the range)
-    m.conf = conf ? 1 : 0; m.e = conf ? el : -1;
-    const float invU = __uint_as_float((unsigned)(277 - (conf ? el : 127)) << 23);
-    int B = 0, o0 = 0, o1 = 0;
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const float q = fminf(sq[i] * invU, 33554432.0f);      // exact (a power of two); a MAP sub-run's elements are below 2^25 ulps, anything else is not used
-        const float r = rintf(q);
-        const bool tie = __builtin_amdgcn_fractf(q) == 0.5f;
-        if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {       // uniform; rare
-            const int t = tie ? (r == floorf(q) ? 1 : -1) : 0;      // an odd c takes the other neighbour on a tie
-            o0 += ((B + o0) & 1) ? t : 0;
-            o1 += ((1 + B + o1) & 1) ? t : 0;
-        }
-        B += (int)r;
-    }
-    m.d0 = min(B + o0, kScanClamp); m.d1 = min(B + o1, kScanClamp);
-}
-// every lane returns the sum of the squares of the 64 x 64 list elements the lanes' runs hold, in index order
-__device__ __forceinline__ float seq_sum_wave(const float* run, int nv, int lane) {
-    RAMA_NO_CONTRACT
-    // 1. approximate prefix sums
-    float ps[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        float sq[16], t8[8];
-        wave_sub_squares(run, nv, k, sq);
-#pragma unroll
-        for (int i = 0; i < 8; i++) t8[i] = sq[2 * i] + sq[2 * i + 1];
-        ps[k] = ((t8[0] + t8[1]) + (t8[2] + t8[3])) + ((t8[4] + t8[5]) + (t8[6] + t8[7]));
-    }
-    const float lt = (ps[0] + ps[1]) + (ps[2] + ps[3]);
-    float inc = lt;
-    inc = fadd_dpp<0x111, 0xF>(inc); inc = fadd_dpp<0x112, 0xF>(inc); inc = fadd_dpp<0x114, 0xF>(inc); inc = fadd_dpp<0x118, 0xF>(inc);
-    inc = fadd_dpp<0x142, 0xA>(inc); inc = fadd_dpp<0x143, 0xC>(inc);
-    float b[5];
-    b[0] = inc - lt; b[1] = b[0] + ps[0]; b[2] = b[1] + ps[1]; b[3] = b[2] + ps[2]; b[4] = b[3] + ps[3];
-    // 2. the sub-runs' maps (the elements once more from LDS: 64 squares per lane never sit in registers together --
-    // the weights of the first chunk and the norm gains are on their way into ~130 of them)
-    WaveMap m[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        float sq[16];
-        wave_sub_squares(run, nv, k, sq);
-        wave_sub_map(sq, b[k], b[k + 1], m[k]);
-    }
-    // 3. plain lanes and the segmented scan over them
-    bool plain = m[0].conf && m[1].conf && m[2].conf && m[3].conf && m[0].e == m[1].e && m[1].e == m[2].e && m[2].e == m[3].e;
-    const int e = plain ? m[0].e : -1;
-    const int eprev = __builtin_amdgcn_update_dpp(-2, e, 0x138, 0xF, 0xF, false);      // wave_shr:1; lane 0 keeps -2
-    // (two plain neighbours of different binades: an approximate border a rounding away from a power of two -- the later one is walked)
-    const bool special = !plain || (lane != 0 && eprev >= 0 && eprev != e);
-    SegInc sv{special ? 1 : 0, Inc{0, 0}};
-    if (!special) sv.m = inc_then(inc_then(Inc{m[0].d0, m[0].d1}, Inc{m[1].d0, m[1].d1}), inc_then(Inc{m[2].d0, m[2].d1}, Inc{m[3].d0, m[3].d1}));
-    sv = seg_then(seg_dpp<0x111, 0xF>(sv), sv);
-    sv = seg_then(seg_dpp<0x112, 0xF>(sv), sv);
-    sv = seg_then(seg_dpp<0x114, 0xF>(sv), sv);
-    sv = seg_then(seg_dpp<0x118, 0xF>(sv), sv);
-    sv = seg_then(seg_dpp<0x142, 0xA>(sv), sv);
-    sv = seg_then(seg_dpp<0x143, 0xC>(sv), sv);
-    // 4. the walk (uniform: scalar registers)
-    unsigned long long todo = __builtin_amdgcn_ballot_w64(special);
-    unsigned sb = 0u;
-    for (int attempt = 0; attempt < 2; attempt++) {
-        sb = 0u;                                                  // the sum so far: +0.0
-        int bad = 0, prev = -1;
-        unsigned long long mask = todo;
-        while (mask != 0ull) {
-            const int L = (int)__builtin_ctzll(mask);
-            mask &= mask - 1ull;
-            if (L - 1 > prev && attempt == 0)                     // plain lanes prev + 1 .. L - 1: their composed map sits in lane L - 1
-                sb = wave_map_apply(sb, rl(e, L - 1), rl(sv.m.d0, L - 1), rl(sv.m.d1, L - 1), bad);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (attempt == 0 && rl(m[k].conf, L)) sb = wave_map_apply(sb, rl(m[k].e, L), rl(m[k].d0, L), rl(m[k].d1, L), bad);
-                else {                                            // 16 fp32 adds, by every lane on its own sub-run; lane L's count
-                    float sq[16];
-                    wave_sub_squares(run, nv, k, sq);
-                    float t_ = __uint_as_float(sb);
-#pragma unroll
-                    for (int i = 0; i < 16; i++) t_ = t_ + sq[i];
-                    sb = (unsigned)rl((int)__float_as_uint(t_), L);
-                }
-            }
-            prev = L;
-        }
-        if (prev < 63 && attempt == 0) sb = wave_map_apply(sb, rl(e, 63), rl(sv.m.d0, 63), rl(sv.m.d1, 63), bad);
-        if (!bad) break;
-        todo = ~0ull;                                             // a wrong prediction: every lane walked, every sub-run added
-    }
-    return __uint_as_float(sb);
-}
-
 template <int NW>
 __device__ __forceinline__ bool seq_sum_predict(const float* a, int n, PredShared<NW>& ps, float* out) {
     if (n <= kRippleMax) { *out = seq_sum_ripples<NW>(a, n, ps); return true; }     // uniform
@@ -608,20 +476,6 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_chain_kernel(float* o, c
     }
 }
 
-// the same rmsnorm by ONE wave with seq_sum_wave (n <= 4096): what gemv_chain_kernel<..., CNORM_WAVE> does in front of its
-// product, as a kernel of its own for the exactness tests (rama_set_tuning "seqsum_wave" = 1 routes rama_rmsnorm here)
-__global__ __launch_bounds__(64) void rmsnorm_wave_kernel(float* o, const float* x, const float* w, int n) {
-    RAMA_NO_CONTRACT
-    __shared__ __attribute__((aligned(16))) float nat[4096 + 4 * 64 + 4];
-    const int lane = threadIdx.x;
-    const int n4 = (n + 3) & ~3;
-    for (int i = lane; i < n4; i += 64) nat[i + 4 * (i >> 6)] = i < n ? x[i] : 0.0f;
-    __syncthreads();
-    const float ss = seq_sum_wave(nat + 68 * lane, min(max(n4 - 64 * lane, 0), 64), lane);
-    const float v = 1.0f / sqrtf(ss / (float)n + 1e-5f);
-    for (int i = lane; i < n; i += 64) o[i] = w[i] * (v * x[i]);
-}
-
 // cpu.rs:119-125 Device::softmax over a whole view (n <= kNormMax), the oracle's order: max, exp, sequential sum, divide
 __global__ __launch_bounds__(kNormThreads) void softmax_chain_kernel(float* x, int n) {
     RAMA_NO_CONTRACT
@@ -653,7 +507,6 @@ struct ChainParams {
     const Ctl* ctl; int pos_val;
     const float* fr; const float* fi; int head_size;
     float* kc; float* vc;  // this layer's cache slabs [seq, dim]
-    int delay;             // experiment ("tol_delay"): dependent vector instructions every wave executes before it stages x
 };
 
 // a descriptor whose inputs the compiler must take as wave-uniform (they are: kernel arguments and blockIdx)
@@ -690,15 +543,11 @@ __device__ unsigned long long g_chain_stamps[64];
 //     the waves through LDS: a fixed tree, the same bits in every workgroup, ~1e-7 relative from the sequential sum -- the
 //     matvec behind it keeps the reference's rounding sequence.  ~0.3 us per workgroup while its first weights are on their
 //     way, instead of a launch of its own (8 us for the exact sum at dim 4096).
-//   CNORM_WAVE (parity mode, K <= 4096): the exact sequential sum by seq_sum_wave -- wave 0 holds the squares in registers,
-//     64 consecutive ones per lane (transposed through the LDS the activations are staged in anyway), ~2.5 us while the
-//     workgroup's first weights are on their way from HBM -- instead of rmsnorm_chain_kernel's launch (8 us at dim 4096,
-//     65 times per llama2-7B token).  The bits of cpu.rs:112.
-// CNORM_NONE: the activations come normalised (a norm launch in front; rows wider than 4096).
-enum { CNORM_NONE = 0, CNORM_EXACT = 1, CNORM_TREE = 2, CNORM_WAVE = 3 };
-// natural-order staging of x for CNORM_WAVE: element i at i + 4 (i / 64) -- a lane's run of 64 starts 68 floats after its
-// neighbour's, so the 16-byte reads of a run and the coalesced 16-byte accesses are both conflict-free
-__host__ __device__ constexpr int chain_nat_floats(int K) { return K + 4 * ((K + 63) / 64) + 4; }
+// CNORM_NONE: the activations come normalised (parity mode at dim > 512: rmsnorm_chain_kernel in front).
+// (Round 4 also folded the EXACT sum in for K <= 4096 -- one wave, 64 consecutive squares per lane, predicted binades, a scalar
+// walk; bit-exact -- and measured it slower than the launch it replaced: every workgroup of a CU repeats ~2000 vector
+// instructions, +8..10 us per matvec at llama2-7B against 9.4 us for the norm launch; profiles/r04_norm_fold_experiments.json.)
+enum { CNORM_NONE = 0, CNORM_EXACT = 1, CNORM_TREE = 2 };
 template <int W, int D, int XD, int EPI, int NORM = CNORM_NONE>
 __global__ __launch_bounds__(W * 64) void gemv_chain_kernel(ChainParams p) {
     RAMA_NO_CONTRACT
@@ -770,7 +619,6 @@ __global__ __launch_bounds__(W * 64) void gemv_chain_kernel(ChainParams p) {
 #pragma unroll
         for (int u = 0; u < XU; u++) ssl = ssl + ((xa[u].x * xa[u].x + xa[u].y * xa[u].y) + (xa[u].z * xa[u].z + xa[u].w * xa[u].w));
         ssl = wave_sum(ssl);
-        for (int i = 0; i < p.delay; i++) asm volatile("v_add_f32 %0, %0, %0" : "+v"(xold));
         if (W > 1) {
             __shared__ float wss[W];
             if (lane == 0) wss[wave] = ssl;
@@ -785,30 +633,6 @@ __global__ __launch_bounds__(W * 64) void gemv_chain_kernel(ChainParams p) {
             xa[u].x = ga[u].x * (v * xa[u].x); xa[u].y = ga[u].y * (v * xa[u].y);
             xa[u].z = ga[u].z * (v * xa[u].z); xa[u].w = ga[u].w * (v * xa[u].w);
         }
-    }
-    if constexpr (NORM == CNORM_WAVE) {     // x <- w * (v * x) with the EXACT sequential sum of squares (host: K <= 4096, K <= 64 T: all of x is in xa)
-        __shared__ float s_ss;
-        // raw x -> LDS in natural order (padded); the chain-order staging below overwrites it once everybody has read it back
-#pragma unroll
-        for (int u = 0; u < XU; u++) {
-            const int i = (int)threadIdx.x + T * u;
-            if (i < n4) *reinterpret_cast<f4*>(xs + 4 * i + 4 * (i >> 4)) = xa[u];
-        }
-        __syncthreads();
-        if (wave == 0) {
-            const float ss = seq_sum_wave(xs + 68 * lane, min(max(p.K - 64 * lane, 0), 64), lane);
-            if (lane == 0) s_ss = ss;
-        }
-        __syncthreads();
-        const float v = 1.0f / sqrtf(s_ss / (float)p.K + 1e-5f);
-#pragma unroll
-        for (int u = 0; u < XU; u++) {
-            const int i = (int)threadIdx.x + T * u;
-            const f4 t4 = i < n4 ? *reinterpret_cast<const f4*>(xs + 4 * i + 4 * (i >> 4)) : f4{0.f, 0.f, 0.f, 0.f};
-            xa[u].x = ga[u].x * (v * t4.x); xa[u].y = ga[u].y * (v * t4.y);
-            xa[u].z = ga[u].z * (v * t4.z); xa[u].w = ga[u].w * (v * t4.w);
-        }
-        __syncthreads();                                          // every read of the natural-order copy is done
     }
     if constexpr (NORM == CNORM_EXACT) {     // x <- w * (v * x), v = 1 / sqrt(sum(x^2) / K + 1e-5) with the sum in index order (host: K <= 64 T floats, all of x is in xa)
         __shared__ PredShared<W> nps;

