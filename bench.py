@@ -456,15 +456,24 @@ def spawn_ranks(argv, n, timeout, python=sys.executable, script=None, extra_env=
     non-zero exit code.  Returns the exit code."""
     script = script or str(Path(__file__).resolve())
     port = _free_port()
+    import threading
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RAMA_SELF_SPAWNED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # RCCL / NCCL log to STDOUT unless told otherwise: a debug level passed through would land in the one JSON line
+        if env.get("NCCL_DEBUG", "").upper() in ("INFO", "TRACE") or env.get("RAMA_NCCL_DEBUG", "").upper() in ("INFO", "TRACE"):
+            env.setdefault("NCCL_DEBUG_FILE", f"/tmp/rama_rccl_{os.getpid()}_rank%h_%p.log")
         if extra_env:
             env.update(extra_env)
         procs.append(subprocess.Popen([python, script] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None))
+    # rank 0's stdout is drained WHILE it runs: a child that writes more than the pipe holds (64 KiB) would otherwise block in
+    # write() until the timeout
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     deadline = time.time() + timeout
     rc = 0
     try:
@@ -492,7 +501,8 @@ def spawn_ranks(argv, n, timeout, python=sys.executable, script=None, extra_env=
                 p.wait(timeout=10)
             except subprocess.TimeoutExpired:
                 p.kill()
-    out = procs[0].stdout.read().decode() if procs[0].stdout else ""
+    reader.join(timeout=10)
+    out = b"".join(chunks).decode(errors="replace")
     if rc == 0:
         sys.stdout.write(out)
         sys.stdout.flush()

@@ -46,7 +46,10 @@ typedef struct rama_model rama_model;
  * existing hipStream_t to adopt (e.g. a framework's current stream). */
 int  rama_ctx_create(int device, void *hip_stream, rama_ctx **out);
 int  rama_ctx_destroy(rama_ctx *ctx);
-int  rama_sync(rama_ctx *ctx);                       /* hipStreamSynchronize */
+int  rama_sync(rama_ctx *ctx);                       /* hipStreamSynchronize; also reports an in-kernel hand-off that timed out (one-launch stage, attention+Wo) */
+/* Non-blocking: 0 = everything enqueued on the context's stream has run, 1 = still running, anything else = the
+ * stream has failed (what a host loop polling rama_decode_stream_poll / rama_decode_batch_stream_poll ends on). */
+int  rama_stream_query(rama_ctx *ctx);
 const char *rama_last_error(void);
 /* name (<= 63 chars), compute units, total HBM bytes of the context's device */
 int  rama_device_info(rama_ctx *ctx, char name[64], int *compute_units, size_t *hbm_bytes);
@@ -150,6 +153,10 @@ int  rama_model_save(rama_ctx *ctx, const rama_model *model, const char *path);
 int  rama_model_config(const rama_model *m, rama_config *cfg);
 int  rama_model_weights(const rama_model *m, rama_weights *w);
 size_t rama_model_bytes(const rama_model *m);
+/* Give the derived copies back (they are made again on the next call that wants them): mask 1 = the chain-order
+ * copy parity mode streams, 2 = the tile-order copy of the token-batch passes, 3 = both -- llama2-7B: 92 GB -> 38 GB.
+ * Synchronises the context's stream and drops its captured graphs (they hold the copies' addresses). */
+int  rama_model_release_copies(rama_ctx *ctx, rama_model *m, int mask);
 int  rama_model_free(rama_ctx *ctx, rama_model *m);
 
 int  rama_state_create(rama_ctx *ctx, const rama_config *cfg, int n_local_layers, rama_run_state *out);
@@ -361,14 +368,27 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *                   top of its kernels; 4 steps per graph: +5.3 % tokens/s at stories15M, +1.4 % at 110M, +0.1 % at
  *                   llama2-7B; 8 and more are slower again.  -1 (default): 4 for dim <= 1024, else 1
  *   "topp_sort" = 0|1 : ordering step of the top-p sampler for vocabularies <= 32768: 1 (default) = block sorts in
- *                   LDS + ranks by binary search (2 launches, csrc/topp_sort.hpp); 0 = the library radix sort of all
- *                   n pairs (what larger vocabularies always take).  Same token either way.
+ *                   LDS + ranks by binary search with all sorted blocks in one workgroup's LDS (csrc/topp_sort.hpp);
+ *                   0 = the ranks through global memory (topp_rank_global_kernel) and the staged lane ripple for the
+ *                   sums -- what larger vocabularies always take.  Same token either way; no library kernel in either.
  *   "topp_keep_sums" = 0|1 : 1 makes the top-p sampler also store its running sums in device scratch (tests)
- *   "ref_order" = 0|1 : 1 computes every op in the REFERENCE'S OWN rounding order (csrc/ref_order.hpp: 4-lane
- *                   sequential matvec sums with separate multiply and add, sequential rmsnorm / softmax
- *                   sums, glibc's expf restated) so results can be compared with the reference CPU path
- *                   bit for bit; ~8 ms per llama2-7B token.  Default 0: the fast path, which differs from
- *                   the CPU path by the CPU path's own rounding error (1.5e-4 in llama2-7B logits) */
+ *   "ref_order" = 0|1|2 : 0 (default) = the fast path (fused multiply-adds, tree-shaped sums), which differs from the
+ *                   CPU path by the CPU path's own rounding error (1.5e-4 in llama2-7B logits over 200 positions).
+ *                   1 = PARITY MODE: every op in the REFERENCE'S OWN rounding order (4-lane sequential matvec sums with
+ *                   separate multiply and add, sequential rmsnorm / softmax sums, glibc's expf restated), results
+ *                   bit-identical to the reference CPU path.  A resident model streams its chain-order weight copy
+ *                   (csrc/chain.hpp; made on first use, +27 GB at llama2-7B): 5.2 ms per llama2-7B token, the dominant
+ *                   matvec at 0.80 of the HBM roofline; weights uploaded tensor by tensor take csrc/ref_order.hpp's
+ *                   one-thread-per-row kernels (~23 ms per token).
+ *                   2 = the tolerance-mode EXPERIMENT: parity mode's chain-order matvecs with the rmsnorm sums
+ *                   tree-shaped and folded into them and the fast path's attention: 218 tok/s at llama2-7B, but 1.4e-4
+ *                   from the CPU path, no closer than the fast path (profiles/r04_tolerance_sweep_7b_200pos.jsonl).
+ *   "tol_mask" = 0..127 : with "ref_order" = 2, ops swapped for A/B runs: 1 / 2 / 4 / 8 / 16 = the FAST Wq|Wk|Wv / Wo /
+ *                   W1|W3 / W2 / classifier launch, 32 = parity mode's attention, 64 = its exact-sum norm launches
+ *                   (tools/tol_sweep.py: which op carries how much of the distance to the CPU path)
+ *   "chain" = 0|1, "chain_d" = 0 | 100 W + D, "chain_norm" = 0|1, "prefill_chain" = 0|1 : parity mode's kernels -- the
+ *                   chain-order copy on/off, the matvec geometry (waves per 16 rows, blocks in flight), the exact norms
+ *                   folded into the matvecs (dim <= 512), prompt positions through the chain-order token-batch kernels */
 int  rama_set_tuning(rama_ctx *ctx, const char *key, int value);
 
 /* glibc 2.35 expf (the exp the reference's f32::exp calls on Linux) as the reference-order kernels

@@ -35,6 +35,7 @@ extern "C" {
     pub fn rama_ctx_create(device: c_int, stream: *mut c_void, out: *mut *mut rama_ctx) -> c_int;
     pub fn rama_ctx_destroy(ctx: *mut rama_ctx) -> c_int;
     pub fn rama_sync(ctx: *mut rama_ctx) -> c_int;
+    pub fn rama_stream_query(ctx: *mut rama_ctx) -> c_int;
     pub fn rama_last_error() -> *const c_char;
 
     pub fn rama_alloc_f32(ctx: *mut rama_ctx, n: usize, out: *mut *mut f32) -> c_int;
@@ -83,6 +84,7 @@ extern "C" {
     pub fn rama_model_config(m: *const rama_model, cfg: *mut rama_config) -> c_int;
     pub fn rama_model_weights(m: *const rama_model, w: *mut rama_weights) -> c_int;
     pub fn rama_model_free(ctx: *mut rama_ctx, m: *mut rama_model) -> c_int;
+    pub fn rama_model_release_copies(ctx: *mut rama_ctx, m: *mut rama_model, mask: c_int) -> c_int;
     /// one pipeline stage's tensors only (layers [layer_begin, layer_end), embedding / classifier as flagged)
     pub fn rama_model_load_stage(ctx: *mut rama_ctx, path: *const c_char, stage: *const rama_stage,
                                  out: *mut *mut rama_model) -> c_int;

@@ -57,6 +57,7 @@ SIGNATURES = {
     "rama_ctx_create": (_int, [_int, _vp, C.POINTER(_vp)]),
     "rama_ctx_destroy": (_int, [_vp]),
     "rama_sync": (_int, [_vp]),
+    "rama_stream_query": (_int, [_vp]),
     "rama_last_error": (C.c_char_p, []),
     "rama_device_info": (_int, [_vp, C.c_char_p, C.POINTER(_int), C.POINTER(_sz)]),
     "rama_alloc_f32": (_int, [_vp, _sz, C.POINTER(_vp)]),
@@ -83,6 +84,7 @@ SIGNATURES = {
     "rama_model_weights": (_int, [_vp, _wp]),
     "rama_model_bytes": (_sz, [_vp]),
     "rama_model_free": (_int, [_vp, _vp]),
+    "rama_model_release_copies": (_int, [_vp, _vp, _int]),
     "rama_state_create": (_int, [_vp, _cfgp, _int, _sp]),
     "rama_state_free": (_int, [_vp, _sp]),
     "rama_fill_synth": (_int, [_vp, _vp, _sz, C.c_uint64, C.c_uint64, C.c_uint64, C.c_float, C.c_float]),

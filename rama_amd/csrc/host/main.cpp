@@ -83,6 +83,11 @@ static int run_pipeline_stage(const Args& args, int world, int rank) {
     // the communicator: rank 0 publishes the id through RAMA_PIPE_ID_FILE, tagged with RAMA_PIPE_RUN_ID (host/pipe_id.hpp)
     unsigned char id[RAMA_PIPE_ID_BYTES];
     const char* run_id = std::getenv("RAMA_PIPE_RUN_ID");
+    if (world > 1 && (!run_id || !*run_id)) {
+        // without a run id a rank > 0 can pick up the id file of an EARLIER launch before rank 0 has cleared it
+        std::fprintf(stderr, "RAMA_WORLD > 1 needs RAMA_PIPE_RUN_ID: the same string for every rank of this launch, a new one per launch\n");
+        return 2;
+    }
     if (rank == 0) {
         rama_host::pipe_id_prepare(id_file);                 // a file left by an earlier run must not meet this run's readers
         ck(rama_pipe_unique_id(id), "rama_pipe_unique_id");

@@ -27,6 +27,7 @@ struct rama_model {
     float* tiled = nullptr;     // every matrix once more in MFMA tile order, for the token-batch GEMMs (see below); made on first use
     float* chain = nullptr;     // every matrix once more in chain order, for parity mode (chain.hpp); made on first use
     bool tiled_tried = false, chain_tried = false;
+    std::mutex build_mu;        // held while a derived copy is being made: a second caller waits for the copy instead of missing it
     float* blob = nullptr;      // one allocation holding every tensor
     size_t blob_floats = 0;
     rama_stage stage{};
@@ -254,6 +255,20 @@ void drop_chain(rama_ctx* ctx, rama_model* m) {
     m->chain = nullptr;
 }
 
+void drop_tiled(rama_ctx* ctx, rama_model* m) {
+    if (!m->tiled) return;
+    {
+        std::lock_guard<std::mutex> lk(g_tiled_mu);
+        const float* lo = m->tiled;
+        for (size_t i = g_tiled.size(); i-- > 0;)      // every entry of this model points into its one allocation
+            if (g_tiled[i].src == m->w.wq || g_tiled[i].src == m->w.wk || g_tiled[i].src == m->w.wv || g_tiled[i].src == m->w.wo ||
+                g_tiled[i].src == m->w.w1 || g_tiled[i].src == m->w.w3 || g_tiled[i].src == m->w.w2 || g_tiled[i].src == m->w.wcls)
+                if (g_tiled[i].tiled >= lo) g_tiled.erase(g_tiled.begin() + (long)i);
+    }
+    rama_free(ctx, m->tiled);
+    m->tiled = nullptr;
+}
+
 // the live model that owns these weights (matched on its first layer tensor, or the classifier of a layerless stage)
 rama_model* model_of(const rama_weights* w) {
     for (rama_model* m : g_models)
@@ -300,10 +315,13 @@ extern "C" int rama_internal_model_ensure(rama_ctx* ctx, const rama_weights* w, 
         std::lock_guard<std::mutex> lk(g_models_mu);
         m = model_of(w);
         if (!m) return 0;
-        if (what == 1) { if (m->chain_tried) return 0; m->chain_tried = true; }
-        else { if (m->tiled_tried) return 0; m->tiled_tried = true; }
     }
-    return what == 1 ? make_chain(ctx, m) : make_tiled(ctx, m);
+    std::lock_guard<std::mutex> bl(m->build_mu);
+    bool& tried = what == 1 ? m->chain_tried : m->tiled_tried;
+    if (tried) return 0;
+    const int rc = what == 1 ? make_chain(ctx, m) : make_tiled(ctx, m);
+    tried = true;       // set once the copy exists (or cannot): nobody sees "tried" and then misses the registry entry
+    return rc;
 }
 // the same for the model whose weight blob contains `p` (the 1:1 trait ops see views, not a rama_weights)
 extern "C" int rama_internal_model_ensure_ptr(rama_ctx* ctx, const float* p, int what) {
@@ -523,6 +541,23 @@ extern "C" int rama_model_weights(const rama_model* m, rama_weights* w) {
     return 0;
 }
 extern "C" size_t rama_model_bytes(const rama_model* m) { return m ? m->blob_floats * sizeof(float) : 0; }
+
+extern "C" void rama_internal_drop_graphs(rama_ctx* ctx);      // rama_api.hip: captured graphs hold the copies' addresses
+
+// Give the derived weight copies back: mask bit 0 (1) = the chain-order copy (parity mode), bit 1 (2) = the tile-order copy (token-batch
+// passes).  A server that only decodes in fast mode holds 38 GB for llama2-7B instead of up to 92.  They are made again on the
+// next call that wants them.
+extern "C" int rama_model_release_copies(rama_ctx* ctx, rama_model* m, int mask) {
+    if (!ctx || !m) return bad(RAMA_EINVAL, "rama_model_release_copies: NULL argument");
+    if (mask & ~3) return bad(RAMA_EINVAL, "rama_model_release_copies: mask must be a combination of 1 (chain order) and 2 (tile order)");
+    std::lock_guard<std::mutex> bl(m->build_mu);
+    int rc = rama_sync(ctx);
+    if (rc) return rc;
+    rama_internal_drop_graphs(ctx);
+    if (mask & 1) { drop_chain(ctx, m); m->chain_tried = false; }
+    if (mask & 2) { drop_tiled(ctx, m); m->tiled_tried = false; }
+    return 0;
+}
 extern "C" int rama_model_free(rama_ctx* ctx, rama_model* m) {
     if (!m) return 0;
     { std::lock_guard<std::mutex> lk(g_models_mu); g_models.erase(std::remove(g_models.begin(), g_models.end(), m), g_models.end()); }
@@ -534,17 +569,7 @@ extern "C" int rama_model_free(rama_ctx* ctx, rama_model* m) {
         }
         rama_free(ctx, m->w13i);
     }
-    if (m->tiled) {
-        {
-            std::lock_guard<std::mutex> lk(g_tiled_mu);
-            const float* lo = m->tiled;
-            for (size_t i = g_tiled.size(); i-- > 0;)      // every entry of this model points into its one allocation
-                if (g_tiled[i].src == m->w.wq || g_tiled[i].src == m->w.wk || g_tiled[i].src == m->w.wv || g_tiled[i].src == m->w.wo ||
-                    g_tiled[i].src == m->w.w1 || g_tiled[i].src == m->w.w3 || g_tiled[i].src == m->w.w2 || g_tiled[i].src == m->w.wcls)
-                    if (g_tiled[i].tiled >= lo) g_tiled.erase(g_tiled.begin() + (long)i);
-        }
-        rama_free(ctx, m->tiled);
-    }
+    drop_tiled(ctx, m);
     int rc = rama_free(ctx, m->blob);
     delete m;
     return rc;

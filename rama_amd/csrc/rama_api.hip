@@ -157,6 +157,7 @@ struct rama_ctx {
     int tune_small_attn = -1;              // fewer-wave attention in the decode step: -1 (default) below tune_small_pos where attention
                                            // is not merged with Wo, 0 never, 1 always (below the split threshold)
     unsigned long long* pbar = nullptr;    // device: [1] = error word of the merged attention+Wo launch's bounded spin
+    bool handoff_dirty = false;            // a launch with an in-kernel hand-off (attention+Wo, the one-launch stage) has been enqueued since the error word was last read
     const float* embedded_x = nullptr;   // run-state x that already holds emb[ctl.token] (chained decode)
     // rama_decode_batch_begin / _steps: the sequences' cursors live on the device
     struct BatchChain {
@@ -271,6 +272,8 @@ static void drop_graph(rama_ctx* c) {
     c->sg.clear();
 }
 
+extern "C" void rama_internal_drop_graphs(rama_ctx* c) { if (c) drop_graph(c); }      // model.hip: before a derived weight copy is freed
+
 int rama_ctx_destroy(rama_ctx* c) {
     if (!c) return 0;
     hipSetDevice(c->device);
@@ -289,10 +292,37 @@ int rama_ctx_destroy(rama_ctx* c) {
     return 0;
 }
 
+// The launches that hand data over INSIDE a kernel (attention+Wo, the one-launch stage) bound every wait and report a wait that gave up
+// through the error word at pbar[1]; their results are then invalid.  Every synchronising exit reads the word -- once the stream is idle
+// -- fails the call and clears it, so that neither garbage logits leave with rc 0 nor a stale word makes every later launch give up.
+static int handoff_check(rama_ctx* c) {
+    if (!c->handoff_dirty || !c->pbar) return 0;
+    unsigned long long perr = 0;
+    HIPCHK(hipMemcpyAsync(&perr, c->pbar + 1, sizeof perr, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->handoff_dirty = false;
+    if (perr != 0) {
+        hipMemsetAsync(c->pbar, 0, 4 * sizeof(unsigned long long), c->stream);   // counter, error word, base: start over
+        hipStreamSynchronize(c->stream);
+        return fail(RAMA_EINVAL, perr >= 0x3000ull ? "one-launch stage: a hand-off timed out" : "attention+Wo launch: hand-off timed out", __FILE__, __LINE__);
+    }
+    return 0;
+}
+
 int rama_sync(rama_ctx* c) {
     REQUIRE(c, RAMA_EINVAL, "rama_sync: ctx is NULL");
     HIPCHK(hipStreamSynchronize(c->stream));
-    return 0;
+    return handoff_check(c);
+}
+
+// 0: everything enqueued on the context's stream has run; 1: work is still running; anything else: the stream has failed (the error
+// is also recorded for rama_last_error).  Never blocks -- what a host loop that polls the token rings uses to know when to stop.
+int rama_stream_query(rama_ctx* c) {
+    REQUIRE(c, RAMA_EINVAL, "rama_stream_query: ctx is NULL");
+    const hipError_t e = hipStreamQuery(c->stream);
+    if (e == hipSuccess) return 0;
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); return 1; }
+    return fail((int)e, "hipStreamQuery", __FILE__, __LINE__);
 }
 
 int rama_device_info(rama_ctx* c, char name[64], int* cus, size_t* hbm) {
@@ -339,7 +369,7 @@ int rama_download_f32(rama_ctx* c, const float* src, size_t n, float* host) {
     if (n == 0) return 0;
     HIPCHK(hipMemcpyAsync(host, src, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    return 0;
+    return handoff_check(c);
 }
 
 int rama_free(rama_ctx* c, void* p) {
@@ -893,6 +923,7 @@ static int try_launch_attn_wo(rama_ctx* c, const rama_config* cfg, const rama_we
     else hipLaunchKernelGGL(attn_wo_kernel<64>, dim3(grid), dim3(kPThreads), lds, c->stream, a);
     LAUNCHCHK();
     *launched = true;
+    c->handoff_dirty = true;
     return 0;
 }
 
@@ -936,6 +967,7 @@ static int try_launch_fused(rama_ctx* c, const rama_config* cfg, const rama_weig
 #undef RAMA_FUSED
     LAUNCHCHK();
     *launched = true;
+    c->handoff_dirty = true;
     if (c->fused_chained) { c->fused_epoch_owed = true; return 0; }      // the sampler that follows advances the epoch
     hipLaunchKernelGGL(fused_epoch_kernel, dim3(1), dim3(1), 0, c->stream, c->fused_epoch);
     LAUNCHCHK();
@@ -1455,6 +1487,10 @@ static int ensure_batch_scratch(rama_ctx* c, const rama_config* cfg, bool with_l
     const size_t need = T * (8 * dim + hidden) + ssp + ints + 64 + (with_logits ? T * (size_t)cfg->vocab_size : 0);
     if (need > c->pf_floats) {
         if (c->pf_blob) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->pf_blob)); c->pf_blob = nullptr; }
+        // the chained-batch graph has the old scratch pointers baked in: it must not be replayed on freed memory
+        if (c->bc.exec) { hipGraphExecDestroy(c->bc.exec); c->bc.exec = nullptr; }
+        if (c->bc.graph) { hipGraphDestroy(c->bc.graph); c->bc.graph = nullptr; }
+        c->bc.graph_bucket = -1;
         if (set_device(c)) return 1;
         HIPCHK(hipMalloc(&c->pf_blob, need * sizeof(float)));
         // stale tokens of a partly filled 16-token tile flow through the GEMMs as extra columns (never
@@ -2077,7 +2113,13 @@ static int enqueue_decode_step(rama_ctx* c, const rama_config* cfg, const rama_w
     ap.ctl = c->ctl; ap.forced = c->forced; ap.out = c->out; ap.out_cap = c->out_cap; ap.ring = c->ring_dev;
     ap.emb = w->token_embedding_table; ap.x = s->x; ap.dim = cfg->dim;
     if (c->fused_epoch_owed) ap.epoch = c->fused_epoch;
-    return enqueue_sample(c, ap, c->samp_T, c->samp_topp, c->samp_u);
+    rc = enqueue_sample(c, ap, c->samp_T, c->samp_topp, c->samp_u);
+    if (rc && c->fused_epoch_owed) {      // the stage launch is enqueued and counted on the sampler to advance the epoch: do it here, or the next
+        hipLaunchKernelGGL(fused_epoch_kernel, dim3(1), dim3(1), 0, c->stream, c->fused_epoch);      // launch would take this one's tagged vectors for its own
+        (void)hipGetLastError();
+    }
+    c->fused_epoch_owed = false;
+    return rc;
 }
 
 static bool same_capture(const GraphCache& g, const rama_config* cfg, const rama_weights* w, const rama_run_state* s) {
@@ -2158,6 +2200,7 @@ int rama_decode_tokens(rama_ctx* c, int32_t* out_host, int max_tokens, int* n_ou
     unsigned long long perr = 0;
     HIPCHK(hipMemcpyAsync(&perr, c->pbar + 1, sizeof perr, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    c->handoff_dirty = false;
     if (perr != 0) {   // a bounded wait inside a launch gave up (attn_wo.hpp's counter, layer_fused.hpp's tagged vectors: 0x3000 / 0x3001): the results are invalid
         hipMemsetAsync(c->pbar, 0, 4 * sizeof(unsigned long long), c->stream);   // counter, error word, base: start over
         return fail(RAMA_EINVAL, perr >= kFusedErr ? "one-launch stage: a hand-off timed out" : "attention+Wo launch: hand-off timed out", __FILE__, __LINE__);
@@ -2276,7 +2319,10 @@ int rama_generate_stream(rama_ctx* c, const rama_config* cfg, const rama_weights
         }
         const int before = seen;
         rc = hand_over(); if (rc) return rc;
-        if (seen == before && fed == steps && hipStreamQuery(c->stream) == hipSuccess) {
+        if (seen == before && fed == steps) {
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipErrorNotReady) { (void)hipGetLastError(); continue; }
+            if (q != hipSuccess) return fail((int)q, "generate_stream: the stream failed while tokens were outstanding", __FILE__, __LINE__);
             rc = hand_over(); if (rc) return rc;                  // everything has run: what is there now is all there will be
             if (seen == before) break;
         }
@@ -2352,11 +2398,15 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
     if (!strcmp(key, "norm_in_gemm")) {
         REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: norm_in_gemm must be 0 or 1");
         c->tune_norm_in_gemm = value;
+        hipStreamSynchronize(c->stream);
+        drop_graph(c);
         return 0;
     }
     if (!strcmp(key, "tiled")) {
         REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: tiled must be 0 or 1");
         c->tune_tiled = value;
+        hipStreamSynchronize(c->stream);
+        drop_graph(c);
         return 0;
     }
     if (!strcmp(key, "chain_norm")) {
@@ -2374,6 +2424,8 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
     if (!strcmp(key, "prefill_tok")) {
         REQUIRE(value == 64 || value == 128, RAMA_EINVAL, "set_tuning: prefill_tok must be 64 or 128");
         c->tune_prefill_tok = value;
+        hipStreamSynchronize(c->stream);
+        drop_graph(c);
         return 0;
     }
     if (!strcmp(key, "prefill_attn")) {

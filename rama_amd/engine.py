@@ -73,6 +73,10 @@ class Model:
         check(self.device.lib.rama_download_f32(self.device.ctx, getattr(self.weights, name) + 4 * offset, n, out.ctypes.data))
         return out
 
+    def release_copies(self, mask: int = 3):
+        """give the chain-order (1) / tile-order (2) weight copies back; they are made again on demand"""
+        check(self.device.lib.rama_model_release_copies(self.device.ctx, self.handle, mask), "rama_model_release_copies")
+
     def free(self):
         if self.handle:
             check(self.device.lib.rama_model_free(self.device.ctx, self.handle))
@@ -217,15 +221,31 @@ def decode_batch_chained(engines: Sequence["Engine"], tokens: Sequence[int], pos
                                     len(engines), max(n_steps, 1)), "rama_decode_batch_begin")
     check(L.rama_decode_batch_steps(e0.device.ctx, n_steps), "rama_decode_batch_steps")
     if on_token is not None:
+        import time
         seen = [0] * len(engines)
         buf = (C.c_int32 * 64)()
         k = C.c_int()
+        idle_after_done = 0
         while min(seen) < n_steps:
+            progress = 0
             for s_ in range(len(engines)):
                 check(L.rama_decode_batch_stream_poll(e0.device.ctx, s_, seen[s_], buf, 64, C.byref(k)), "rama_decode_batch_stream_poll")
                 for i in range(k.value):
                     on_token(s_, seen[s_] + i, int(buf[i]))
                 seen[s_] += k.value
+                progress += k.value
+            if progress:
+                continue
+            # nothing new: is the stream still working on it?  (1 = yes; 0 = everything has run -- one more sweep collects what is there;
+            # anything else is a failed stream: the check raises instead of spinning for ever)
+            q = L.rama_stream_query(e0.device.ctx)
+            if q == 1:
+                time.sleep(0.0002)
+                continue
+            check(q, "rama_stream_query")
+            idle_after_done += 1
+            if idle_after_done > 1:
+                raise RuntimeError(f"decode_batch_chained: the steps have run but only {min(seen)} of {n_steps} tokens appeared")
     out = (C.c_int32 * (len(engines) * max(n_steps, 1)))()
     n = C.c_int()
     check(L.rama_decode_batch_tokens(e0.device.ctx, out, max(n_steps, 1), C.byref(n)), "rama_decode_batch_tokens")

@@ -226,10 +226,11 @@ class NativeStage:
         check(lib.rama_pipe_unique_id(buf), "rama_pipe_unique_id")
         return bytes(buf.raw)
 
-    def plan(self, n_pos: int, prompt, wrap: int = 0, temperature: float = 0.0, topp: float = 0.9, u: float = 0.0, out=None):
+    def plan(self, n_pos: int, prompt, wrap: int = 0, temperature: float = 0.0, topp: float = 0.9, u: float = 0.0, out=None, n_seq=None):
+        """n_seq: sequences in flight (default: all this stage holds states for); 1 = a single stream, N - 1 of N ticks idle per stage"""
         from rama_amd._lib import rama_pipe_plan
         self._prompt = (C.c_int32 * max(len(prompt), 1))(*prompt)
-        return rama_pipe_plan(self.n_seq, n_pos, wrap, self._prompt, len(prompt), temperature, topp, u, out)
+        return rama_pipe_plan(self.n_seq if n_seq is None else n_seq, n_pos, wrap, self._prompt, len(prompt), temperature, topp, u, out)
 
     def total_ticks(self, plan) -> int:
         return self.dev.lib.rama_pipe_total_ticks(self.pipe, C.byref(plan))
@@ -359,6 +360,27 @@ def run_pipeline_bench_native(args, cfg, rank: int, world: int, local_rank: int)
     head = modes[0]
     dt = timed[head]
     st.check(st.dev.lib.rama_set_tuning(st.dev.ctx, b"ref_order", REF_ORDER[head]), "rama_set_tuning")
+    # SURVEY 8e asks for both figures: the aggregate over the N sequences in flight (`value`) and what ONE sequence gets
+    # from the pipeline -- its stages take turns, N - 1 of N ticks idle each, plus a hop per boundary: no faster than N = 1
+    single_dt = None
+    if world > 1 or os.environ.get("RAMA_FORCE_PIPELINE"):
+        ss_steps = max(8, min(args.steps, 32))
+        S1 = max(1, world)                                    # ticks per position with one sequence
+        plan1 = st.plan(args.warmup + ss_steps, PROMPT, wrap=cfg.seq_len, n_seq=1)
+        total1 = st.total_ticks(plan1)
+        st.run_ticks(plan1, 0, args.warmup * S1)
+        st.dev.sync(); torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        st.run_ticks(plan1, args.warmup * S1, (args.warmup + ss_steps) * S1)
+        st.dev.sync(); torch.cuda.synchronize()
+        dist.barrier()
+        d1 = time.perf_counter() - t0
+        st.run_ticks(plan1, (args.warmup + ss_steps) * S1, total1)
+        st.dev.sync()
+        t1 = torch.tensor([d1], dtype=torch.float64)
+        dist.all_reduce(t1, op=dist.ReduceOp.MAX)
+        single_dt = (float(t1.item()), ss_steps)
     roofline = None
     n_local = st.stage.layer_end - st.stage.layer_begin
     if n_local > 0 and not args.no_kprof:
@@ -380,6 +402,10 @@ def run_pipeline_bench_native(args, cfg, rank: int, world: int, local_rank: int)
                        graphs, rccl_ranks=nr.value, mode=head)
     for m_ in modes:
         line[("tolerance" if m_ == "tol" else m_) + "_mode"] = {"tok_s": round(args.steps * n_seq / timed[m_], 3), "ms_per_step": round(timed[m_] * 1e3 / args.steps, 4)}
+    if single_dt:
+        line["single_stream_tok_s"] = round(single_dt[1] / single_dt[0], 3)       # one sequence in flight through the N stages (same mode as `value`)
+        line["single_stream_ms_per_token"] = round(single_dt[0] * 1e3 / single_dt[1], 4)
+        line["single_stream_steps"] = single_dt[1]
     st.check(st.dev.lib.rama_set_tuning(st.dev.ctx, b"ref_order", 0), "rama_set_tuning")
     st.free()
     dist.barrier()

@@ -655,6 +655,58 @@ def test_full_shape_logits_vs_oracle(dev, shape):
     eng.free(); eng2.free(); model.free()
 
 
+@pytest.mark.parametrize("shape", ["stories15M", "stories110M"])
+def test_stories_fast_mode_readme_length(dev, shape):
+    """BASELINE config 2 / 3 as the README ran them (README.md:80-83: a 200-token generation on 'once upon a time'): the
+    FAST mode -- what the stories tok/s figures of bench.py are quoted for, the whole token in one launch (layer_fused.hpp) --
+    against the oracle at every one of the 200 positions: |dlogit| <= 1e-4, greedy tokens identical, and the device-chained
+    generate() (one-launch stage + sampler, replayed from hipGraphs) producing the oracle's 200 tokens.  The per-position
+    record goes to gpurun_out/r04_parity_<shape>_200pos.json (copied to profiles/ by the builder)."""
+    import json
+    from pathlib import Path
+    import rama_amd
+    d, h, L, H, V, seq, shared = FULL_SHAPES[shape]
+    n_pos = min(200, seq)
+    cfg = O.Config(d, h, L, H, H, V, seq, shared)
+    rope = S.rope_tables(seq, d // H)
+    w = S.synth_weights(cfg, 0, rope=rope)
+    orc = O.Oracle(cfg, w)
+    model = rama_amd.Model.synth(dev, to_rama_cfg(cfg), 0, rope=rope)
+    eng = rama_amd.Engine(dev, model)
+    prompt = [10646, 2501, 263, 931]
+    token, rows, toks_cpu, toks_hip = 1, [], [], []
+    for pos in range(n_pos):
+        lo = orc.forward(token, pos)
+        eng.forward(token, pos)
+        lg = eng.logits()
+        rows.append({"pos": pos, "token": int(token), "hip_fast_vs_oracle": float(np.abs(lg - lo).max())})
+        toks_cpu.append(int(O.argmax(lo)))
+        toks_hip.append(int(np.flatnonzero(lg == lg.max())[-1]))
+        token = prompt[pos] if pos < len(prompt) else toks_cpu[-1]
+    eng2 = rama_amd.Engine(dev, model)
+    eng2.set_graph_mode(True)
+    try:
+        chained = eng2.generate_greedy(prompt, n_pos)
+    finally:
+        eng2.set_graph_mode(False)
+    want = O.Oracle(cfg, w).generate_greedy(prompt, n_pos)
+    out = {"shape": f"{shape} fp32, synthetic weights seed 0 (bit-identical on both sides)", "mode": "fast (one launch per token: csrc/layer_fused.hpp)",
+           "prompt": "BOS + 'once upon a time' (Rama-BPE), greedy continuation chosen by the oracle", "positions": n_pos, "bar": LOGIT_ATOL,
+           "worst_hip_fast_vs_oracle": max(r["hip_fast_vs_oracle"] for r in rows),
+           "positions_over_bar": [r["pos"] for r in rows if r["hip_fast_vs_oracle"] > LOGIT_ATOL],
+           "greedy_tokens_equal": toks_cpu == toks_hip, "chained_generate_equals_oracle": chained == want, "per_position": rows}
+    path = Path(__file__).resolve().parent.parent / "gpurun_out" / f"r04_parity_{shape}_200pos.json"
+    try:
+        path.parent.mkdir(parents=True, exist_ok=True)
+        path.write_text(json.dumps(out, indent=1))
+    except OSError:
+        pass
+    eng.free(); eng2.free(); model.free()
+    assert out["worst_hip_fast_vs_oracle"] <= LOGIT_ATOL, (shape, out["worst_hip_fast_vs_oracle"], out["positions_over_bar"][:8])
+    assert toks_cpu == toks_hip
+    assert chained == want
+
+
 # ------------------------------------------------------------------ batched-prompt prefill (f3)
 
 def _prefill(dev, rcfg, wv, rsv, tokens, pos0):

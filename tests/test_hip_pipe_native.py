@@ -138,3 +138,32 @@ def test_load_stage_two_stages_on_one_gpu(dev, name, parity):
         e.free()
     for m in models + [whole]:
         m.free()
+
+
+def test_n1_pipeline_rehearsal_agrees_with_the_plain_n1_line():
+    """`RAMA_FORCE_PIPELINE=1 python bench.py --gpus 1` runs every line of the N > 1 path on a one-rank communicator.
+    Its `value` must agree with the plain N = 1 line's (the driver divides the per-N values of a SCALE run by the N = 1
+    one: they have to be like for like), and it must carry the single-stream figure SURVEY 8e asks for beside the
+    aggregate.  Two child processes (the bench owns its GPU context); llama2-7B, parity mode, 48 steps."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parent.parent
+    cmd = [sys.executable, str(repo / "bench.py"), "--gpus", "1", "--mode", "parity", "--steps", "48", "--warmup", "8",
+           "--no-other-configs", "--no-cpu-baseline", "--no-prefill", "--no-kprof", "--no-sampled"]
+
+    def run(extra_env):
+        env = dict(os.environ, **extra_env)
+        r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+
+    plain = run({})
+    pipe_line = run({"RAMA_FORCE_PIPELINE": "1"})
+    assert plain["config"]["mode"].startswith("parity") and pipe_line["config"]["mode"].startswith("parity")
+    assert abs(pipe_line["value"] / plain["value"] - 1.0) <= 0.02, (pipe_line["value"], plain["value"])
+    assert pipe_line["rccl_ranks"] == 1
+    # one sequence in flight on one stage IS the whole job: the single-stream figure equals the aggregate
+    assert abs(pipe_line["single_stream_tok_s"] / pipe_line["value"] - 1.0) <= 0.03, (pipe_line["single_stream_tok_s"], pipe_line["value"])

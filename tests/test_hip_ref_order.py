@@ -435,3 +435,33 @@ def test_parity_decode_batch_bit_exact(dev, shape, n_seq):
             assert_bits_equal(batch[i].buffer(buf, orcs[i].s[buf].size), orcs[i].s[buf], f"sequence {i} {buf}")
     for e in batch: e.free()
     model.free()
+
+
+def test_release_copies_and_rebuild(dev):
+    """rama_model_release_copies gives the chain-order / tile-order copies back (92 -> 38 GB at llama2-7B for a server that
+    only decodes in fast mode); the next parity-mode call makes the chain-order copy again and produces the same bits;
+    rama_stream_query reports an idle stream as 0"""
+    import rama_amd
+    from rama_amd._lib import check
+    from .helpers import to_rama_cfg
+    cfg, w, g = load_case("synth_d288_h6")
+    toks = g["tokens"].tolist()[:6]
+    orc = O.Oracle(cfg, w)
+    model = rama_amd.Model.synth(dev, to_rama_cfg(cfg), int(g["seed"]), rope=(g["freq_cis_real"], g["freq_cis_imag"]))
+    eng = rama_amd.Engine(dev, model)
+    eng.set_graph_mode(True)
+    try:
+        for rnd_ in range(3):
+            orc = O.Oracle(cfg, w)
+            for pos, t in enumerate(toks):
+                lo = orc.forward(t, pos)
+                eng.forward(t, pos)
+                assert_bits_equal(eng.logits(), lo, f"round {rnd_} pos {pos}")
+            model.release_copies(3 if rnd_ == 0 else 1)
+            dev.sync()
+            assert dev.lib.rama_stream_query(dev.ctx) == 0
+    finally:
+        eng.set_graph_mode(False)
+    with pytest.raises(rama_amd.RamaError):
+        check(dev.lib.rama_model_release_copies(dev.ctx, model.handle, 8))
+    eng.free(); model.free()
