@@ -1052,34 +1052,6 @@ __global__ __launch_bounds__(NW * 64) void attention_chain_kernel(RefAttnParams 
     region = reinterpret_cast<float*>(((uintptr_t)region + 15) & ~(uintptr_t)15);
     const size_t col = (size_t)h * hs;
     SEQ_STAMP(8);
-    // Requested before anything else: the first two tiles of cache VALUE rows (they do not depend on the scores) and, with one
-    // round of timesteps per thread (NW = 4: positions below 256), this thread's whole KEY row -- the launch is a chain of
-    // dependent phases on one workgroup per head, and every memory round trip taken out of the chain is ~1-2 us of it.
-    constexpr int U = 8;
-    const int tile4 = kAttTile * hs4;                             // f4 elements of a tile
-    int er[U], ec[U];                                             // tile element e = tid + u T: its row and 16-byte column (one division each, here)
-#pragma unroll
-    for (int u = 0; u < U; u++) { const int e = tid + u * T; er[u] = e / hs4; ec[u] = e - er[u] * hs4; }
-    auto vissue = [&](int t0, f4 (&vr)[U]) {
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int e = tid + u * T;
-            const int r = er[u], c4 = ec[u];
-            const bool on = e < tile4 && t0 + r <= pos;
-            vr[u] = on ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.vc + (size_t)(t0 + r) * p.dim + col) + c4) : f4{0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    constexpr bool kEarlyK = NW == 4;                             // 128 registers for the row: fine at one wave per SIMD
-    f4 kfirst[kEarlyK ? 32 : 1];
-    const bool early_k = kEarlyK && hs4 >= 32 && pos < 1024;      // uniform
-    if (kEarlyK && early_k) {
-        const f4* k4 = reinterpret_cast<const f4*>(p.kc + (size_t)min(tid, pos) * p.dim + col);
-#pragma unroll
-        for (int u = 0; u < 32; u++) kfirst[u] = k4[u];
-    }
-    constexpr bool kEarlyV = NW <= 8;                             // (16 waves: 128 registers per thread, the tiles would spill)
-    f4 va[U], vb[U];                                              // two tiles on their way while a third is added up
-    if (kEarlyV) { vissue(0, va); vissue(kAttTile, vb); }
     for (int i = tid; i < hs; i += T) s_q[i] = p.q[col + i];
     __syncthreads();
     const float scale_div = sqrtf((float)hs);
@@ -1138,13 +1110,8 @@ __global__ __launch_bounds__(NW * 64) void attention_chain_kernel(RefAttnParams 
             int i = 0;
             for (; i + 32 <= hs4; i += 32) {
                 f4 kk[32];
-                if (kEarlyK && early_k && t == tid && i == 0) {   // (t == tid: the first round; every thread of it holds its row already)
 #pragma unroll
-                    for (int u = 0; u < 32; u++) kk[u] = kfirst[u];
-                } else {
-#pragma unroll
-                    for (int u = 0; u < 32; u++) kk[u] = k4[i + u];
-                }
+                for (int u = 0; u < 32; u++) kk[u] = k4[i + u];
 #pragma unroll
                 for (int u = 0; u < 32; u++) {
                     const f4 qq = q4[i + u];
@@ -1186,9 +1153,25 @@ __global__ __launch_bounds__(NW * 64) void attention_chain_kernel(RefAttnParams 
         if (p.att) p.att[(size_t)h * p.seq_len + t] = a;
     }
     // xb[i] = sum_t att[t] * v[t][i], t ascending (cpu.rs:43-49)
+    constexpr int U = 8;
+    const int tile4 = kAttTile * hs4;                             // f4 elements of a tile
+    int er[U], ec[U];                                             // tile element e = tid + u T: its row and 16-byte column (one division each, here)
+#pragma unroll
+    for (int u = 0; u < U; u++) { const int e = tid + u * T; er[u] = e / hs4; ec[u] = e - er[u] * hs4; }
+    auto vissue = [&](int t0, f4 (&vr)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int e = tid + u * T;
+            const int r = er[u], c4 = ec[u];
+            const bool on = e < tile4 && t0 + r <= pos;
+            vr[u] = on ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.vc + (size_t)(t0 + r) * p.dim + col) + c4) : f4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
     float acc = 0.0f;
     SEQ_STAMP(12);
-    if (!kEarlyV) { vissue(0, va); vissue(kAttTile, vb); }
+    f4 va[U], vb[U];                                              // two tiles on their way while a third is added up
+    vissue(0, va);
+    vissue(kAttTile, vb);
     __syncthreads();                                              // the probabilities are final; the staging region is free
     auto vtile = [&](int t0, int buf, f4 (&vr)[U]) {
         float* tile = region + buf * (kAttTile * hs);
