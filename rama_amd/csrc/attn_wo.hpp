@@ -173,7 +173,7 @@ struct AttnWoParams {
 // (dim 4096 / 4 rows) is resident at once on 256 CUs; it caps the kernel at 64 VGPRs.
 template <int G>
 __global__ __launch_bounds__(kPThreads, 8) void attn_wo_kernel(AttnWoParams a) {
-    extern __shared__ float lds[];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int R = 4, CH = 2, NW = kPWaves;
     float (*part)[R] = reinterpret_cast<float (*)[R]>(lds);     // [NW][R]
     float* scratch = lds + NW * R;                              // attention scratch

@@ -566,7 +566,7 @@ __host__ __device__ constexpr int attn_scratch_floats(int G, int W = kAttnWaves)
 template <int G, bool SPLIT, int W = kAttnWaves, bool NT = false, int UU = 8>
 __global__ __launch_bounds__(W * 64) void attention_kernel(AttnParams p) {
     constexpr int kAttnWaves = W, kAttnThreads = W * 64;       // shadow the 16-wave defaults
-    extern __shared__ float sm[];
+    extern __shared__ __attribute__((aligned(16))) float sm[];
     float* s_max = sm;
     float* s_sum = sm + kAttnWaves;
     float* s_acc = sm + 2 * kAttnWaves;

@@ -355,7 +355,9 @@ __host__ __device__ constexpr int fused_lds_floats(int G, int seq_len, int dim, 
 // as wide as dim; a W2 unit is RE rows, CHH chunks of each requested ahead (4 x 4 up to hidden_dim 1024, 2 x 8 beyond)
 template <int G, int CD, int RE, int CHH>
 __global__ __launch_bounds__(kPThreads, 4) void stage_fused_kernel(FusedParams a) {
-    extern __shared__ float lds[];
+    // (16-byte aligned whatever static LDS sits in front of it: the vectors in it are read 16 bytes at a time and a misaligned
+    // ds_read_b128 is split -- round 4 found out when 68 more bytes of static LDS cost 18 % of a stories110M token)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ __attribute__((aligned(16))) int s_ok[2 * kPWaves];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64) void matvec_ref_kernel(RefMatParams p) {
 // ---------------------------------------------------------------- cpu.rs:99-117 rmsnorm
 __global__ __launch_bounds__(1024) void rmsnorm_ref_kernel(float* o, const float* x, const float* w, int n) {
     RAMA_NO_CONTRACT
-    extern __shared__ float s_x[];
+    extern __shared__ __attribute__((aligned(16))) float s_x[];
     __shared__ float s_vv;
     for (int i = threadIdx.x; i < n; i += blockDim.x) s_x[i] = x[i];
     __syncthreads();
@@ -189,7 +189,7 @@ struct RefAttnParams {
 
 __global__ __launch_bounds__(1024) void attention_ref_kernel(RefAttnParams p) {
     RAMA_NO_CONTRACT
-    extern __shared__ float s_att[];
+    extern __shared__ __attribute__((aligned(16))) float s_att[];
     __shared__ float red[16];
     __shared__ float s_sum;
     const int h = blockIdx.x, tid = threadIdx.x;
