@@ -414,7 +414,10 @@ __device__ __forceinline__ bool seq_sum_predict(const float* a, int n, PredShare
 // o[i] = w[i] * (v * x[i]), v = 1 / sqrt(sum(x^2) / n + 1e-5) with the sum in index order.  copy_to, when
 // given, receives x unchanged first (infer.rs:49: xb = x before the final norm writes x in place).
 constexpr int kNormMax = 16384;
-constexpr int kNormWaves = 4, kNormThreads = kNormWaves * 64;     // one wave per SIMD: the scan rounds are bound by instruction issue
+#ifndef RAMA_NORM_WAVES
+#define RAMA_NORM_WAVES 4
+#endif
+constexpr int kNormWaves = RAMA_NORM_WAVES, kNormThreads = kNormWaves * 64;     // one wave per SIMD: the scan rounds are bound by instruction issue
 // (a grid of several workgroups: vector b of a token batch, `stride` floats after the one before it)
 __global__ __launch_bounds__(kNormThreads) void rmsnorm_chain_kernel(float* o, const float* x, const float* w, int n, float* copy_to, int stride = 0) {
     RAMA_NO_CONTRACT
