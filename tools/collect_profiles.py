@@ -26,13 +26,13 @@ REPO = Path(__file__).resolve().parent.parent
 ap = argparse.ArgumentParser()
 ap.add_argument("--round", type=int, default=1)
 ap.add_argument("--out", default=str(REPO / "gpurun_out" / "profiles"))
-ap.add_argument("--mode", default="fast", choices=["fast", "parity"], help="which decode mode of bench.py to profile")
+ap.add_argument("--mode", default="fast", choices=["fast", "parity", "tol"], help="which decode mode of bench.py to profile")
 ap.add_argument("--config", default="llama2-7B", help="shape of bench.py to profile (files are named ..._bench_7b... for llama2-7B, ..._bench_<shape>... otherwise)")
 a = ap.parse_args()
 out = Path(a.out).resolve()
 out.mkdir(parents=True, exist_ok=True)
 tag = f"r{a.round:02d}"
-suffix = "_parity" if a.mode == "parity" else ""
+suffix = {"parity": "_parity", "tol": "_tol"}.get(a.mode, "")
 mode_args = ["--mode", a.mode, "--no-other-configs", "--no-prefill", "--config", a.config]
 short = "7b" if a.config == "llama2-7B" else a.config
 env = dict(os.environ, TMPDIR="/tmp")
@@ -49,7 +49,7 @@ def run(cmd, workdir):
 d1 = out / "_trace"
 shutil.rmtree(d1, ignore_errors=True)
 cmd1 = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", str(d1), "-o", "bench", "--",
-        "python3", bench, "--steps", "32", "--warmup", "4", "--graph", "0", "--no-cpu-baseline", "--no-kprof"] + mode_args     # long graph replays crash rocprofv3 (ROCm 7.2): eager launches, same kernels
+        "python3", bench, "--steps", "32", "--warmup", "4", "--graph", "0", "--no-cpu-baseline", "--no-kprof", "--no-sampled"] + mode_args     # long graph replays crash rocprofv3 (ROCm 7.2): eager launches, same kernels
 run(cmd1, d1)
 stats = glob.glob(str(d1 / "**" / "*kernel_stats.csv"), recursive=True)
 assert stats, "rocprofv3 wrote no kernel_stats.csv"
@@ -59,7 +59,7 @@ shutil.copy(stats[0], out / f"{tag}_bench_{short}{suffix}_kernel_stats.csv")
 d2 = out / "_pmc"
 shutil.rmtree(d2, ignore_errors=True)
 cmd2 = ["rocprofv3", "--kernel-trace", "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", str(d2), "-o", "pmc", "--",
-        "python3", bench, "--steps", "16", "--warmup", "2", "--no-cpu-baseline", "--no-kprof", "--graph", "0"] + mode_args
+        "python3", bench, "--steps", "16", "--warmup", "2", "--no-cpu-baseline", "--no-kprof", "--no-sampled", "--graph", "0"] + mode_args
 run(cmd2, d2)
 cc = glob.glob(str(d2 / "**" / "*counter_collection.csv"), recursive=True)
 assert cc, "rocprofv3 wrote no counter_collection.csv"
