@@ -149,7 +149,11 @@ int  rama_model_save(rama_ctx *ctx, const rama_model *model, const char *path);
  * And every matrix once more in MFMA tile order (+27 GB at llama2-7B; skipped when fewer than 16 GiB of
  * HBM would remain, or with RAMA_NO_TILED=1 in the environment): rama_prefill / rama_decode_batch read
  * that copy -- one contiguous 1-KiB weight read per wave -- found the same way ("tiled" = 0: off).
- * rama_model_bytes counts the checkpoint tensors only. */
+ * rama_model_bytes counts the checkpoint tensors only.
+ * The tile-order and the chain-order copies are made on FIRST USE (rama_prefill / rama_decode_batch*; "ref_order" != 0):
+ * that call allocates and synchronises the device, so it must not sit inside the caller's own stream capture --
+ * a caller that captures sets RAMA_EAGER_COPIES=1 in the environment (the copies are then made by rama_model_load /
+ * rama_model_synth) or makes one warm-up call first.  rama_model_release_copies gives them back. */
 int  rama_model_config(const rama_model *m, rama_config *cfg);
 int  rama_model_weights(const rama_model *m, rama_weights *w);
 size_t rama_model_bytes(const rama_model *m);
