@@ -535,7 +535,11 @@ __host__ __device__ constexpr int chain_pad_floats(int W, int D, int XD) { retur
 // time stamps of one wave for tools/chain_bench.hip only (100 MHz counter; lane 0 of wave 0 of block RAMA_CHAIN_STAMP_BLOCK)
 #ifdef RAMA_CHAIN_STAMPS
 __device__ unsigned long long g_chain_stamps[64];
-#define CHAIN_STAMP(id) do { if (threadIdx.x == 0 && blockIdx.x == RAMA_CHAIN_STAMP_BLOCK) g_chain_stamps[id] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// ... and, per workgroup, [start, staged, loop done] of its wave 0 (how evenly the groups finish: g_chain_all[3 b + 0 | 1 | 2])
+__device__ unsigned long long g_chain_all[3 * 4096];
+#define CHAIN_STAMP(id) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); \
+        if (blockIdx.x == RAMA_CHAIN_STAMP_BLOCK) g_chain_stamps[id] = t_; \
+        if (blockIdx.x < 4096 && ((id) == 0 || (id) == 2 || (id) == 4)) g_chain_all[3 * blockIdx.x + (id) / 2] = t_; } } while (0)
 #else
 #define CHAIN_STAMP(id) do { } while (0)
 #endif

@@ -3,6 +3,7 @@
 #include "../rama_amd/csrc/chain.hpp"
 #include <cstdio>
 #include <vector>
+#include <algorithm>
 using namespace rama;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 template <int W, int D>
@@ -24,6 +25,18 @@ static int run(const char* name, int rows, int K, int nbuf, std::vector<float*>&
     printf("   loads issued %.2f | staged+barrier %.2f | first products %.2f | loop done %.2f us;  turns (start-end):", us_of(1), us_of(2), us_of(3), us_of(4));
     for (int c = 0; c < 24; c++) if (st[8 + 2 * c] > st[0] && st[9 + 2 * c] >= st[8 + 2 * c]) printf(" [%.2f-%.2f]", us_of(8 + 2 * c), us_of(9 + 2 * c));
     printf("\n");
+    {   // how evenly the row groups start and finish (the last launch): per workgroup, relative to the earliest start
+        const int groups = (rows + 15) / 16;
+        std::vector<unsigned long long> all(3 * 4096);
+        CK(hipMemcpyFromSymbol(all.data(), HIP_SYMBOL(rama::g_chain_all), all.size() * sizeof(unsigned long long)));
+        unsigned long long t0 = ~0ull;
+        for (int b = 0; b < groups && b < 4096; b++) t0 = all[3 * b] < t0 ? all[3 * b] : t0;
+        std::vector<double> st_, sg_, dn_;
+        for (int b = 0; b < groups && b < 4096; b++) { st_.push_back((all[3 * b] - t0) * 0.01); sg_.push_back((all[3 * b + 1] - t0) * 0.01); dn_.push_back((all[3 * b + 2] - t0) * 0.01); }
+        auto q = [](std::vector<double> v, double f) { std::sort(v.begin(), v.end()); return v[(size_t)(f * (v.size() - 1))]; };
+        printf("   all %d groups, us after the first start: start min/med/max %.2f %.2f %.2f | staged %.2f %.2f %.2f | loop done %.2f %.2f %.2f (p90 %.2f, p99 %.2f)\n", groups,
+               q(st_, 0), q(st_, .5), q(st_, 1), q(sg_, 0), q(sg_, .5), q(sg_, 1), q(dn_, 0), q(dn_, .5), q(dn_, 1), q(dn_, .9), q(dn_, .99));
+    }
     unsigned long long z[64] = {0}; CK(hipMemcpyToSymbol(HIP_SYMBOL(rama::g_chain_stamps), z, sizeof z));
     return 0;
 }
