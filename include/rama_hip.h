@@ -375,6 +375,10 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *                   LDS + ranks by binary search with all sorted blocks in one workgroup's LDS (csrc/topp_sort.hpp);
  *                   0 = the ranks through global memory (topp_rank_global_kernel) and the staged lane ripple for the
  *                   sums -- what larger vocabularies always take.  Same token either way; no library kernel in either.
+ *   "topp_pairs" = 0|1 : how the sorted blocks are merged into one order (vocabularies <= 32768): 1 (default) = one workgroup
+ *                   per (block, block) pair, every entry of a block does ONE binary search in the other block and adds the
+ *                   count to its accumulator, then a scatter launch (5.8 + 2.6 us on 32 000 flat logits); 0 = round 3's
+ *                   launch, every workgroup searching all 15 other blocks in its own LDS (23.1 us: 32 CUs, LDS-conflict-bound)
  *   "topp_keep_sums" = 0|1 : 1 makes the top-p sampler also store its running sums in device scratch (tests)
  *   "ref_order" = 0|1|2 : 0 (default) = the fast path (fused multiply-adds, tree-shaped sums), which differs from the
  *                   CPU path by the CPU path's own rounding error (1.5e-4 in llama2-7B logits over 200 positions).

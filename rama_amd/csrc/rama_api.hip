@@ -111,6 +111,8 @@ struct rama_ctx {
     float* topp_prefix = nullptr; int* topp_m = nullptr; unsigned* topp_err = nullptr;
     int topp_cap = 0;
     float* topp_bp = nullptr; int* topp_bi = nullptr; int* topp_bcount = nullptr;       // topp_sort.hpp
+    int* topp_racc = nullptr;               // pair-wise ranking: the accumulators, one per block slot
+    int tune_topp_pairs = 1;                // 1: the ranking as (block, block) pairs spread over the chip + a scatter launch; 0: one workgroup searches all blocks in its LDS
     int tune_norm_in_gemm = 1;              // token-batch passes: the rmsnorm's per-token scale is applied by the consuming GEMM (one launch per norm instead of two)
     int tune_tiled = 1;                     // token-batch GEMMs read the model's tile-order weight copy when it exists
     int tune_prefill_tok = kMfMaxTok;       // prompt positions per weight pass of rama_prefill: 128 (needs the tile-order copies) or 64
@@ -284,7 +286,7 @@ int rama_ctx_destroy(rama_ctx* c) {
     hipFree(c->ctl); hipFree(c->out); hipFree(c->forced); hipFree(c->argmax_result); hipFree(c->pbar); hipFree(c->attn_counter); hipFree(c->attn_part); hipFree(c->fused_hand); hipFree(c->fused_epoch);
     for (int i = 0; i < 2; i++) { hipFree(c->topp_keys[i]); hipFree(c->topp_vals[i]); }
     hipFree(c->topp_prefix); hipFree(c->topp_m); hipFree(c->topp_err); hipFree(c->pf_blob); hipFree(c->pc_blob); if (c->ring) hipHostFree(c->ring);
-    hipFree(c->topp_bp); hipFree(c->topp_bi); hipFree(c->topp_bcount);
+    hipFree(c->topp_bp); hipFree(c->topp_bi); hipFree(c->topp_bcount); hipFree(c->topp_racc);
     hipFree(c->bc.toks); hipFree(c->bc.seqs); hipFree(c->bc.out); if (c->bc.ring) hipHostFree(c->bc.ring);
     hipHostFree(c->pinned_int); hipHostFree(c->pinned_tok);
     hipEventDestroy(c->t0); hipEventDestroy(c->t1);
@@ -1338,7 +1340,8 @@ static int ensure_topp_scratch(rama_ctx* c, int n) {
     HIPCHK(hipMalloc(&c->topp_vals[1], sizeof(int) * n));
     hipFree(c->topp_prefix); HIPCHK(hipMalloc(&c->topp_prefix, sizeof(float) * n));
     if (!c->topp_m) { HIPCHK(hipMalloc(&c->topp_m, sizeof(int))); HIPCHK(hipMalloc(&c->topp_err, sizeof(unsigned))); HIPCHK(hipMemset(c->topp_err, 0, sizeof(unsigned))); }
-    hipFree(c->topp_bp); hipFree(c->topp_bi); hipFree(c->topp_bcount);
+    hipFree(c->topp_bp); hipFree(c->topp_bi); hipFree(c->topp_bcount); hipFree(c->topp_racc);
+    HIPCHK(hipMalloc(&c->topp_racc, sizeof(int) * kToppBlock * std::max<size_t>(nblk, kToppMaxBlocks)));
     HIPCHK(hipMalloc(&c->topp_bp, sizeof(float) * kToppBlock * std::max<size_t>(nblk, kToppMaxBlocks)));
     HIPCHK(hipMalloc(&c->topp_bi, sizeof(int) * kToppBlock * std::max<size_t>(nblk, kToppMaxBlocks)));
     HIPCHK(hipMalloc(&c->topp_bcount, sizeof(int) * std::max<size_t>(nblk, kToppMaxBlocks)));
@@ -1375,10 +1378,16 @@ static int enqueue_sample_launches(rama_ctx* c, ArgmaxParams fin, float temperat
     sp.logits = fin.logits; sp.n = fin.n; sp.temperature = temperature; sp.topp = topp;
     sp.bp = c->topp_bp; sp.bi = c->topp_bi; sp.bcount = c->topp_bcount; sp.keys = c->topp_keys[1]; sp.vals = c->topp_vals[1];
     sp.m = c->topp_m; sp.err = c->topp_err; sp.nblk = (fin.n + kToppBlock - 1) / kToppBlock;
+    const bool pairs = lds_path && c->tune_topp_pairs && sp.nblk > 1;
+    if (pairs) sp.racc = c->topp_racc;
     if (fin.n <= kToppBlock * kToppMaxBlocks) hipLaunchKernelGGL(topp_blocksort_kernel<false>, dim3(sp.nblk), dim3(1024), 0, c->stream, sp);
     else hipLaunchKernelGGL(topp_blocksort_kernel<true>, dim3(sp.nblk), dim3(1024), 0, c->stream, sp);
     LAUNCHCHK();
-    if (lds_path) hipLaunchKernelGGL(topp_rank_kernel<kToppMaxBlocks>, dim3(sp.nblk * (kToppBlock / kRankThreads)), dim3(kRankThreads), 0, c->stream, sp);
+    if (pairs) {
+        hipLaunchKernelGGL(topp_rank_pairs_kernel, dim3(sp.nblk, sp.nblk), dim3(1024), 0, c->stream, sp);
+        LAUNCHCHK();
+        hipLaunchKernelGGL(topp_rank_scatter_kernel, dim3(sp.nblk * (kToppBlock / 1024)), dim3(1024), 0, c->stream, sp);
+    } else if (lds_path) hipLaunchKernelGGL(topp_rank_kernel<kToppMaxBlocks>, dim3(sp.nblk * (kToppBlock / kRankThreads)), dim3(kRankThreads), 0, c->stream, sp);
     else hipLaunchKernelGGL(topp_rank_global_kernel, dim3(sp.nblk * (kToppBlock / 256)), dim3(256), 0, c->stream, sp);
     LAUNCHCHK();
     if (lds_path && !c->tune_topp_keep_sums) tp.prefix = nullptr;
@@ -2462,9 +2471,9 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
         drop_graph(c);
         return 0;
     }
-    if (!strcmp(key, "topp_sort") || !strcmp(key, "topp_keep_sums")) {
-        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: topp_sort / topp_keep_sums must be 0 or 1");
-        if (!strcmp(key, "topp_sort")) c->tune_topp_sort = value; else c->tune_topp_keep_sums = value;
+    if (!strcmp(key, "topp_sort") || !strcmp(key, "topp_keep_sums") || !strcmp(key, "topp_pairs")) {
+        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: topp_sort / topp_keep_sums / topp_pairs must be 0 or 1");
+        if (!strcmp(key, "topp_sort")) c->tune_topp_sort = value; else if (!strcmp(key, "topp_pairs")) c->tune_topp_pairs = value; else c->tune_topp_keep_sums = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
         return 0;

@@ -1,5 +1,7 @@
 // Ordering step of the device top-p sampler (Device::sample, cpu.rs:168-178 + sample_top_q,
-// infer.rs:55-85): two launches, any vocabulary size, no library sort.
+// infer.rs:55-85): any vocabulary size, no library sort.
+// [r4] n <= 32768: block sort, then topp_rank_pairs_kernel + topp_rank_scatter_kernel (the ranking spread over the chip as (block, block)
+// pairs: 5.8 + 2.6 us where topp_rank_kernel's one-workgroup-holds-all-blocks search took 23.1 us; "topp_pairs" = 0 selects the latter).
 //
 //   topp_blocksort_kernel   one workgroup per 2048 logits.  Every workgroup repeats the softmax
 //                           statistics over the whole vector (max, then sum of exp in the same
@@ -40,6 +42,7 @@ struct ToppSortParams {
     int* m;                             // out: number of kept entries
     unsigned* err;                      // set to 1 when nothing is kept
     int nblk;
+    int* racc;                          // [nblk * 2048] pair-wise ranking (topp_rank_pairs_kernel): entries of OTHER blocks that precede block b's entry s; zeroed by the block sort
 };
 
 __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int mask) {
@@ -123,6 +126,7 @@ __global__ __launch_bounds__(1024) void topp_blocksort_kernel(ToppSortParams p) 
     __syncthreads();
     const int cnt = s_n;
     TOPP_STAMP(3);
+    if (p.racc) { p.racc[(size_t)base + tid] = 0; p.racc[(size_t)base + 1024 + tid] = 0; }      // the pair-wise ranking adds into these
     if (tid == 0) p.bcount[blockIdx.x] = cnt;
     if (cnt == 0) return;                                          // uniform
     int P = 2;
@@ -239,6 +243,55 @@ __global__ __launch_bounds__(kRankThreads) void topp_rank_kernel(ToppSortParams 
     for (int o = 0; o < NB; o++) rank += pos[o];
     TOPP_STAMP(10);
     p.keys[rank] = __uint_as_float(key);
+    p.vals[rank] = p.bi[(size_t)b * kToppBlock + s];
+}
+
+// The ranking spread over the chip (round 4).  topp_rank_kernel holds ALL sorted blocks in one workgroup's LDS and lets each of its
+// 1 024 threads search the 15 other blocks: 169 000 conflicting LDS probes on ONE CU per workgroup, 32 CUs busy, the last wave out at
+// 21.8 us (tools/topp_bench.hip).  Here a workgroup is a PAIR (b, o): it stages block o alone (8 KB), every entry of block b does ONE
+// binary search in it, and the count goes into the entry's accumulator with an integer atomic -- nblk x (nblk - 1) workgroups of
+// 22 000 probes each, all CUs busy; topp_rank_scatter_kernel then puts (p, index) at place = own place in the block + the sum.
+__global__ __launch_bounds__(1024) void topp_rank_pairs_kernel(ToppSortParams p) {
+    __shared__ unsigned s_o[kToppBlock];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x, o = blockIdx.y;
+    if (b == o) return;
+    const int cb = p.bcount[b], co = p.bcount[o];
+    if (cb == 0 || co == 0) return;                                // uniform
+    const unsigned k0 = tid < cb ? __float_as_uint(p.bp[(size_t)b * kToppBlock + tid]) : 0u;
+    const unsigned k1 = tid + 1024 < cb ? __float_as_uint(p.bp[(size_t)b * kToppBlock + 1024 + tid]) : 0u;
+    {
+        const unsigned v0 = tid < co ? __float_as_uint(p.bp[(size_t)o * kToppBlock + tid]) : 0u;
+        const unsigned v1 = tid + 1024 < co ? __float_as_uint(p.bp[(size_t)o * kToppBlock + 1024 + tid]) : 0u;
+        s_o[tid] = v0; s_o[tid + 1024] = v1;
+    }
+    __syncthreads();
+    // entries of block o that precede mine: "precedes" holds on a prefix of the sorted block, so the count grows by every power of
+    // two whose last covered entry still precedes (equal probabilities: the earlier block's entry comes first)
+    int top = 1;
+    while (top <= co) top <<= 1;                                   // uniform
+    int p0 = 0, p1 = 0;
+    for (int step = top >> 1; step >= 1; step >>= 1) {
+        const unsigned q0 = s_o[min(p0 + step - 1, kToppBlock - 1)], q1 = s_o[min(p1 + step - 1, kToppBlock - 1)];
+        const bool pr0 = o < b ? q0 >= k0 : q0 > k0, pr1 = o < b ? q1 >= k1 : q1 > k1;
+        p0 += (p0 + step <= co && pr0) ? step : 0;
+        p1 += (p1 + step <= co && pr1) ? step : 0;
+    }
+    if (tid < cb && p0) atomicAdd(&p.racc[(size_t)b * kToppBlock + tid], p0);
+    if (tid + 1024 < cb && p1) atomicAdd(&p.racc[(size_t)b * kToppBlock + 1024 + tid], p1);
+}
+__global__ __launch_bounds__(1024) void topp_rank_scatter_kernel(ToppSortParams p) {
+    const int g = blockIdx.x * 1024 + threadIdx.x;
+    const int b = g / kToppBlock, s = g % kToppBlock;
+    if (g == 0) {
+        int total = 0;
+        for (int o = 0; o < p.nblk; o++) total += p.bcount[o];
+        *p.m = total;
+        if (total == 0 && p.err) *p.err = 1u;
+    }
+    if (b >= p.nblk || s >= p.bcount[b]) return;
+    const int rank = s + p.racc[(size_t)b * kToppBlock + s];
+    p.keys[rank] = p.bp[(size_t)b * kToppBlock + s];
     p.vals[rank] = p.bi[(size_t)b * kToppBlock + s];
 }
 

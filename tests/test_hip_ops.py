@@ -299,6 +299,31 @@ def test_sample_topp_dev_matches_oracle(dev, n, scale, seed, temperature, topp, 
         assert u * min(topp, 1.0) > 0.9, "a mismatch away from the tail is a bug"
 
 
+@pytest.mark.parametrize("n", [2, 65, 2047, 2048, 2049, 4097, 20000, 32000, 32768])
+def test_sample_topp_dev_pair_ranking_equals_lds_ranking(dev, n):
+    """the sorted blocks are merged into one order either by topp_rank_kernel (every workgroup searches all other blocks in its
+    LDS, "topp_pairs" = 0) or by one workgroup per (block, block) pair + integer atomics + a scatter launch (default): the same
+    token as each other and as the oracle for every draw -- flat, ordinary and peaked lists, lists of a few distinct values (equal
+    probabilities across blocks: the earlier block's entry first), a block with nothing kept, nothing kept at all"""
+    from rama_amd._lib import check
+    rng = np.random.default_rng(n)
+    spike = np.full(n, -30.0, np.float32); spike[rng.integers(0, n, 5)] = 4.0
+    half = rnd(n, n + 5, 2.0); half[: n // 2] = -40.0                                       # the first blocks keep nothing
+    lists = [rnd(n, n + 1, 0.05), rnd(n, n + 2, 1.0), rnd(n, n + 3, 3.0), rnd(n, n + 4, 9.0), np.zeros(n, np.float32),
+             (rng.integers(0, 4, n).astype(np.float32) * np.float32(0.6931472)), spike, half]
+    draws = [(1.0, 0.9, 0.2721174359321594), (1.0, 0.9, 0.0), (1.0, 0.9, 0.999999), (0.6, 0.95, 0.5), (1.0, 0.05, 0.7), (1.0, 1.0, 0.93)]
+    try:
+        for li, x in enumerate(lists):
+            for temperature, topp, u in draws:
+                got = {}
+                for mode in (1, 0):
+                    check(dev.lib.rama_set_tuning(dev.ctx, b"topp_pairs", mode))
+                    got[mode] = _topp_dev(dev, x, temperature, topp, u)
+                assert got[1] == got[0], (n, li, temperature, topp, u, got)
+    finally:
+        check(dev.lib.rama_set_tuning(dev.ctx, b"topp_pairs", 1))
+
+
 def test_sample_topp_dev_ties_keep_index_order(dev):
     """equal probabilities: the reference's stable sort keeps ascending index order among them"""
     x = np.full(1000, -3.0, dtype=np.float32)

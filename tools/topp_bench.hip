@@ -37,7 +37,7 @@ int main(int argc, char** argv) {
         sp.keys = keys; sp.vals = vals; sp.m = m; sp.err = err; sp.nblk = (n + kToppBlock - 1) / kToppBlock;
         ToppParams tp{}; tp.logits = logits; tp.n = n; tp.temperature = 1.0f; tp.topp = 0.9f; tp.u = 0.27211744f; tp.keys = keys; tp.vals = vals; tp.prefix = nullptr; tp.m = m; tp.err = err;
         ArgmaxParams fin{}; fin.logits = logits; fin.n = n; fin.result = result;
-        auto k1 = [&] { hipLaunchKernelGGL(topp_blocksort_kernel, dim3(sp.nblk), dim3(1024), 0, st, sp); };
+        auto k1 = [&] { hipLaunchKernelGGL(topp_blocksort_kernel<false>, dim3(sp.nblk), dim3(1024), 0, st, sp); };
         auto k2 = [&] { hipLaunchKernelGGL(topp_rank_kernel<kToppMaxBlocks>, dim3(sp.nblk * (kToppBlock / kRankThreads)), dim3(kRankThreads), 0, st, sp); };
         auto k3 = [&] { hipLaunchKernelGGL(topp_pick_scan_kernel, dim3(1), dim3(1024), 0, st, tp, fin); };
         k1(); k2(); k3(); CK(hipStreamSynchronize(st));
@@ -53,6 +53,18 @@ int main(int argc, char** argv) {
         unsigned long long prev = s[18];
         for (int r = 0; r < 31 && s[24 + r] > s[18] && s[24 + r] <= s[19]; r++) { printf(" %.1f", (double)(long long)(s[24 + r] - prev) / 100.0); prev = s[24 + r]; }
         printf("\n");
+        {   // round 4: the ranking as (block, block) pairs over the whole chip + a scatter launch
+            int* racc; CK(hipMalloc(&racc, 32768 * 4));
+            ToppSortParams sq = sp; sq.racc = racc;
+            auto k1p = [&] { hipLaunchKernelGGL(topp_blocksort_kernel<false>, dim3(sp.nblk), dim3(1024), 0, st, sq); };
+            auto k2a = [&] { hipLaunchKernelGGL(topp_rank_pairs_kernel, dim3(sp.nblk, sp.nblk), dim3(1024), 0, st, sq); };
+            auto k2b = [&] { hipLaunchKernelGGL(topp_rank_scatter_kernel, dim3(sp.nblk * 2), dim3(1024), 0, st, sq); };
+            k1p(); k2a(); k2b(); k3(); CK(hipStreamSynchronize(st));
+            int hr2; CK(hipMemcpy(&hr2, result, 4, hipMemcpyDeviceToHost));
+            const double ta = time_us(st, reps, [&] { k1p(); k2a(); }) - time_us(st, reps, k1p), tb = time_us(st, reps, k2b), tall4 = time_us(st, reps, [&] { k1p(); k2a(); k2b(); k3(); });
+            printf("   ranking by pairs: pairs %.1f us (behind the block sort), scatter %.1f us, all four %.1f us (token %d)\n", ta, tb, tall4, hr2);
+            CK(hipFree(racc));
+        }
     }
     return 0;
 }
