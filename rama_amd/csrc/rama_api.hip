@@ -112,6 +112,8 @@ struct rama_ctx {
     int topp_cap = 0;
     float* topp_bp = nullptr; int* topp_bi = nullptr; int* topp_bcount = nullptr;       // topp_sort.hpp
     int* topp_racc = nullptr;               // pair-wise ranking: the accumulators, one per block slot
+    ToppStats* topp_stats = nullptr;        // small-block path: partial softmax statistics, one per 1024 logits
+    int tune_topp_block = 1024;             // entries per sorted block on the pair-ranking path: 1024 or 512 (statistics once + 8- / 4-wave sorts) or 2048 (round 3's block sort)
     int tune_topp_pairs = 1;                // 1: the ranking as (block, block) pairs spread over the chip + a scatter launch; 0: one workgroup searches all blocks in its LDS
     int tune_norm_in_gemm = 1;              // token-batch passes: the rmsnorm's per-token scale is applied by the consuming GEMM (one launch per norm instead of two)
     int tune_tiled = 1;                     // token-batch GEMMs read the model's tile-order weight copy when it exists
@@ -1344,7 +1346,8 @@ static int ensure_topp_scratch(rama_ctx* c, int n) {
     HIPCHK(hipMalloc(&c->topp_racc, sizeof(int) * kToppBlock * std::max<size_t>(nblk, kToppMaxBlocks)));
     HIPCHK(hipMalloc(&c->topp_bp, sizeof(float) * kToppBlock * std::max<size_t>(nblk, kToppMaxBlocks)));
     HIPCHK(hipMalloc(&c->topp_bi, sizeof(int) * kToppBlock * std::max<size_t>(nblk, kToppMaxBlocks)));
-    HIPCHK(hipMalloc(&c->topp_bcount, sizeof(int) * std::max<size_t>(nblk, kToppMaxBlocks)));
+    HIPCHK(hipMalloc(&c->topp_bcount, sizeof(int) * std::max<size_t>(((size_t)n + 511) / 512 + 1, std::max<size_t>(nblk, kToppMaxBlocks))));
+    hipFree(c->topp_stats); HIPCHK(hipMalloc(&c->topp_stats, sizeof(ToppStats) * (((size_t)n + 1023) / 1024 + 1)));
     c->topp_cap = n;
     return 0;
 }
@@ -1361,6 +1364,21 @@ static int enqueue_sample(rama_ctx* c, ArgmaxParams fin, float temperature, floa
     if (timed) { HIPCHK(hipEventRecord(k.ev[2 * k.used + 1], c->stream)); k.used++; }
     return rc;
 }
+// [r4] the small-block ordering: partial statistics, BS-entry block sorts, (block, OB blocks) pair ranking, scatter
+template <int BS, int OB>
+static int enqueue_small_blocks(rama_ctx* c, ToppSortParams sp, int nstat) {
+    sp.nblk = (sp.n + BS - 1) / BS;
+    hipLaunchKernelGGL(topp_stats_kernel, dim3(nstat), dim3(1024), 0, c->stream, sp, c->topp_stats);
+    LAUNCHCHK();
+    hipLaunchKernelGGL(topp_blocksort_bs_kernel<BS>, dim3(sp.nblk), dim3(BS / 2), 0, c->stream, sp, (const ToppStats*)c->topp_stats, nstat);
+    LAUNCHCHK();
+    hipLaunchKernelGGL((topp_rank_pairs_bs_kernel<BS, OB>), dim3(sp.nblk, (sp.nblk + OB - 1) / OB), dim3(BS / 2), 0, c->stream, sp);
+    LAUNCHCHK();
+    hipLaunchKernelGGL(topp_rank_scatter_bs_kernel<BS>, dim3((sp.nblk * BS + 1023) / 1024), dim3(1024), 0, c->stream, sp);
+    LAUNCHCHK();
+    return 0;
+}
+
 static int enqueue_sample_launches(rama_ctx* c, ArgmaxParams fin, float temperature, float topp, float u) {
     if (temperature == 0.0f) {
         hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, c->stream, fin);
@@ -1380,6 +1398,13 @@ static int enqueue_sample_launches(rama_ctx* c, ArgmaxParams fin, float temperat
     sp.m = c->topp_m; sp.err = c->topp_err; sp.nblk = (fin.n + kToppBlock - 1) / kToppBlock;
     const bool pairs = lds_path && c->tune_topp_pairs && sp.nblk > 1;
     if (pairs) sp.racc = c->topp_racc;
+    if (pairs && c->tune_topp_block != kToppBlock) {
+        // small blocks (topp_sort.hpp [r4]): the statistics once per 1024 logits, 1024-entry sorts on 8 waves (or 512 on 4), the ranking by
+        // (block, block) pairs over the whole chip, a scatter launch
+        const int nstat = (fin.n + 1023) / 1024;
+        if (c->tune_topp_block == 1024) { if (int rc = enqueue_small_blocks<1024, 1>(c, sp, nstat)) return rc; }
+        else if (int rc = enqueue_small_blocks<512, 4>(c, sp, nstat)) return rc;
+    } else {
     if (fin.n <= kToppBlock * kToppMaxBlocks) hipLaunchKernelGGL(topp_blocksort_kernel<false>, dim3(sp.nblk), dim3(1024), 0, c->stream, sp);
     else hipLaunchKernelGGL(topp_blocksort_kernel<true>, dim3(sp.nblk), dim3(1024), 0, c->stream, sp);
     LAUNCHCHK();
@@ -1390,6 +1415,7 @@ static int enqueue_sample_launches(rama_ctx* c, ArgmaxParams fin, float temperat
     } else if (lds_path) hipLaunchKernelGGL(topp_rank_kernel<kToppMaxBlocks>, dim3(sp.nblk * (kToppBlock / kRankThreads)), dim3(kRankThreads), 0, c->stream, sp);
     else hipLaunchKernelGGL(topp_rank_global_kernel, dim3(sp.nblk * (kToppBlock / 256)), dim3(256), 0, c->stream, sp);
     LAUNCHCHK();
+    }
     if (lds_path && !c->tune_topp_keep_sums) tp.prefix = nullptr;
     // the running sums: the exact parallel scan with the list in LDS, or (longer lists) the staged lane ripple
     if (lds_path) hipLaunchKernelGGL(topp_pick_scan_kernel, dim3(1), dim3(1024), 0, c->stream, tp, fin);
@@ -2467,6 +2493,13 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
     if (!strcmp(key, "small_attn")) {
         REQUIRE(value >= -1 && value <= 1, RAMA_EINVAL, "set_tuning: small_attn must be -1, 0 or 1");
         c->tune_small_attn = value;
+        hipStreamSynchronize(c->stream);
+        drop_graph(c);
+        return 0;
+    }
+    if (!strcmp(key, "topp_block")) {
+        REQUIRE(value == 512 || value == 1024 || value == 2048, RAMA_EINVAL, "set_tuning: topp_block must be 512, 1024 or 2048");
+        c->tune_topp_block = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
         return 0;

@@ -177,6 +177,183 @@ __global__ __launch_bounds__(1024) void topp_blocksort_kernel(ToppSortParams p) 
     }
 }
 
+// ---------------------------------------------------------------- [r4] small blocks: statistics once, 512-entry sorts on 4 waves
+// topp_blocksort_kernel is 16 workgroups of 16 waves: each repeats the softmax statistics over all n logits (7.6 us) and runs a
+// 66-stage bitonic network whose every stage is a turn of 16 waves through one CU (18 us).  With the ranking spread over the chip
+// (topp_rank_pairs_kernel) many small sorted blocks cost nothing, so:
+//   topp_stats_kernel          one workgroup per 1024 logits: its maximum and the sum of exp(x - that maximum)
+//   topp_blocksort_bs_kernel   BS = 512 entries per workgroup of 4 waves: folds the partial statistics (the same order in every
+//                              workgroup: the same bits), keeps and sorts its slice -- 45 stages, only 5 of them across waves
+struct ToppStats { float mx, sum; };
+__global__ __launch_bounds__(1024) void topp_stats_kernel(ToppSortParams p, ToppStats* st) {
+    __shared__ float s_r[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool scale = p.temperature < 1.0f;                       // cpu.rs:170-172: T > 1 has no effect
+    const int i = blockIdx.x * 1024 + tid;
+    const float v = i < p.n ? p.logits[i] : -INFINITY;
+    const float x = scale ? v / p.temperature : v;
+    float mx = wave_max(x);
+    if (lane == 0) s_r[wave] = mx;
+    __syncthreads();
+    mx = s_r[0];
+#pragma unroll
+    for (int w = 1; w < 16; w++) mx = fmaxf(mx, s_r[w]);
+    __syncthreads();
+    float sum = wave_sum(i < p.n ? expf(x - mx) : 0.0f);
+    if (lane == 0) s_r[wave] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        float t[16];
+#pragma unroll
+        for (int w = 0; w < 16; w++) t[w] = s_r[w];
+#pragma unroll
+        for (int n = 16; n > 1; n >>= 1)
+#pragma unroll
+            for (int w = 0; w < n / 2; w++) t[w] = t[2 * w] + t[2 * w + 1];
+        st[blockIdx.x] = ToppStats{mx, t[0]};
+    }
+}
+
+template <int BS>
+__global__ __launch_bounds__(BS / 2) void topp_blocksort_bs_kernel(ToppSortParams p, const ToppStats* st, int nstat) {
+    constexpr int NT = BS / 2;
+    __shared__ unsigned long long s_k[2][BS];
+    __shared__ int s_n;
+    const int tid = threadIdx.x;
+    const bool scale = p.temperature < 1.0f;
+    if (tid == 0) s_n = 0;
+    // the whole vector's maximum and sum of exponentials from the partial ones, in index order (every workgroup: the same bits)
+    // (one partial per lane, nstat <= 64: one load, then the wave trees -- a loop over them is 2 nstat dependent L2 round trips, 12 us)
+    const int lane = tid & 63;
+    const ToppStats part = lane < nstat ? st[lane] : ToppStats{-INFINITY, 0.0f};
+    const float mx = wave_max(part.mx);
+    const float sum = wave_sum(lane < nstat ? part.sum * expf(part.mx - mx) : 0.0f);
+    const float cutoff = (1.0f - p.topp) / (float)(p.n - 1);      // infer.rs:56
+    const int base = blockIdx.x * BS;
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int i = base + h * NT + tid;
+        if (i < p.n) {
+            const float v = p.logits[i];
+            const float pr = expf((scale ? v / p.temperature : v) - mx) / sum;
+            if (pr > cutoff) {
+                const int slot = atomicAdd(&s_n, 1);
+                s_k[0][slot] = ((unsigned long long)__float_as_uint(pr) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+            }
+        }
+    }
+    __syncthreads();
+    const int cnt = s_n;
+    if (p.racc) { p.racc[(size_t)base + tid] = 0; p.racc[(size_t)base + NT + tid] = 0; }
+    if (tid == 0) p.bcount[blockIdx.x] = cnt;
+    if (cnt == 0) return;                                          // uniform
+    int P = 2;
+    while (P < cnt) P <<= 1;                                       // uniform
+    const int H = P >> 1;
+    // the bitonic network of topp_blocksort_kernel on BS / 2 threads (thread t < P / 2 holds elements t and t + P / 2)
+    unsigned long long A = tid < H && tid < cnt ? s_k[0][tid] : 0ull;             // zero padding sorts last
+    unsigned long long B = tid < H && tid + H < cnt ? s_k[0][tid + H] : 0ull;
+    int buf = 1;
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j == H) {                                          // only in the last merge: always descending
+                if (A < B) { const unsigned long long t = A; A = B; B = t; }
+                continue;
+            }
+            unsigned long long oa, ob;
+            if (j < 64) {
+                oa = shfl_xor_u64(A, j); ob = shfl_xor_u64(B, j);
+            } else {
+                if (tid < H) { s_k[buf][tid] = A; s_k[buf][tid + H] = B; }
+                __syncthreads();
+                oa = tid < H ? s_k[buf][tid ^ j] : 0ull;
+                ob = tid < H ? s_k[buf][(tid ^ j) + H] : 0ull;
+                buf ^= 1;
+            }
+            const bool lower = (tid & j) == 0;
+            const bool descA = (tid & k) == 0, descB = ((tid + H) & k) == 0;
+            A = (lower == descA) ? (A > oa ? A : oa) : (A < oa ? A : oa);
+            B = (lower == descB) ? (B > ob ? B : ob) : (B < ob ? B : ob);
+        }
+    }
+    if (tid < H) {
+        if (tid < cnt) {
+            p.bp[(size_t)base + tid] = __uint_as_float((unsigned)(A >> 32));
+            p.bi[(size_t)base + tid] = (int)(0xFFFFFFFFu - (unsigned)(A & 0xFFFFFFFFull));
+        }
+        if (tid + H < cnt) {
+            p.bp[(size_t)base + tid + H] = __uint_as_float((unsigned)(B >> 32));
+            p.bi[(size_t)base + tid + H] = (int)(0xFFFFFFFFu - (unsigned)(B & 0xFFFFFFFFull));
+        }
+    }
+}
+
+// the pair-wise ranking for blocks of BS entries: a workgroup of BS / 2 threads takes block b against OB other blocks at once
+template <int BS, int OB>
+__global__ __launch_bounds__(BS / 2) void topp_rank_pairs_bs_kernel(ToppSortParams p) {
+    constexpr int NT = BS / 2;
+    __shared__ unsigned s_o[OB * BS];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x, o0 = blockIdx.y * OB;
+    const int cb = p.bcount[b];
+    if (cb == 0) return;                                           // uniform
+    int co[OB], most = 0;
+#pragma unroll
+    for (int q = 0; q < OB; q++) { const int o = o0 + q; co[q] = (o < p.nblk && o != b) ? p.bcount[o] : 0; most = max(most, co[q]); }
+    if (most == 0) return;                                         // uniform
+    const unsigned k0 = tid < cb ? __float_as_uint(p.bp[(size_t)b * BS + tid]) : 0u;
+    const unsigned k1 = tid + NT < cb ? __float_as_uint(p.bp[(size_t)b * BS + NT + tid]) : 0u;
+    {
+        unsigned v[2 * OB];
+#pragma unroll
+        for (int q = 0; q < OB; q++) {
+            v[2 * q] = tid < co[q] ? __float_as_uint(p.bp[(size_t)(o0 + q) * BS + tid]) : 0u;
+            v[2 * q + 1] = tid + NT < co[q] ? __float_as_uint(p.bp[(size_t)(o0 + q) * BS + NT + tid]) : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < OB; q++) { s_o[q * BS + tid] = v[2 * q]; s_o[q * BS + NT + tid] = v[2 * q + 1]; }
+    }
+    __syncthreads();
+    int top = 1;
+    while (top <= most) top <<= 1;                                 // uniform
+    int p0[OB], p1[OB];
+#pragma unroll
+    for (int q = 0; q < OB; q++) { p0[q] = 0; p1[q] = 0; }
+    for (int step = top >> 1; step >= 1; step >>= 1) {
+        unsigned q0[OB], q1[OB];
+#pragma unroll
+        for (int q = 0; q < OB; q++) { q0[q] = s_o[q * BS + min(p0[q] + step - 1, BS - 1)]; q1[q] = s_o[q * BS + min(p1[q] + step - 1, BS - 1)]; }
+#pragma unroll
+        for (int q = 0; q < OB; q++) {
+            const bool before = o0 + q < b;                        // equal probabilities: the earlier block's entry comes first
+            const bool pr0 = before ? q0[q] >= k0 : q0[q] > k0, pr1 = before ? q1[q] >= k1 : q1[q] > k1;
+            p0[q] += (p0[q] + step <= co[q] && pr0) ? step : 0;
+            p1[q] += (p1[q] + step <= co[q] && pr1) ? step : 0;
+        }
+    }
+    int a0 = 0, a1 = 0;
+#pragma unroll
+    for (int q = 0; q < OB; q++) { a0 += p0[q]; a1 += p1[q]; }
+    if (tid < cb && a0) atomicAdd(&p.racc[(size_t)b * BS + tid], a0);
+    if (tid + NT < cb && a1) atomicAdd(&p.racc[(size_t)b * BS + NT + tid], a1);
+}
+template <int BS>
+__global__ __launch_bounds__(1024) void topp_rank_scatter_bs_kernel(ToppSortParams p) {
+    const int g = blockIdx.x * 1024 + threadIdx.x;
+    const int b = g / BS, s = g % BS;
+    if (g == 0) {
+        int total = 0;
+        for (int o = 0; o < p.nblk; o++) total += p.bcount[o];
+        *p.m = total;
+        if (total == 0 && p.err) *p.err = 1u;
+    }
+    if (b >= p.nblk || s >= p.bcount[b]) return;
+    const int rank = s + p.racc[(size_t)b * BS + s];
+    p.keys[rank] = p.bp[(size_t)b * BS + s];
+    p.vals[rank] = p.bi[(size_t)b * BS + s];
+}
+
 // Blocks are index ranges, so among equal probabilities an entry of an earlier block comes first:
 // the rank needs the other blocks' PROBABILITIES only -- all of them fit in one workgroup's LDS.
 constexpr int kRankThreads = 1024;

@@ -316,12 +316,25 @@ def test_sample_topp_dev_pair_ranking_equals_lds_ranking(dev, n):
         for li, x in enumerate(lists):
             for temperature, topp, u in draws:
                 got = {}
-                for mode in (1, 0):
+                for mode, block in ((1, 1024), (1, 512), (1, 2048), (0, 2048)):       # small blocks + statistics once (default: 1024) | round 3's blocks, ranked by pairs | round 3
                     check(dev.lib.rama_set_tuning(dev.ctx, b"topp_pairs", mode))
-                    got[mode] = _topp_dev(dev, x, temperature, topp, u)
-                assert got[1] == got[0], (n, li, temperature, topp, u, got)
+                    check(dev.lib.rama_set_tuning(dev.ctx, b"topp_block", block))
+                    got[(mode, block)] = _topp_dev(dev, x, temperature, topp, u)
+                assert got[(1, 2048)] == got[(0, 2048)], (n, li, temperature, topp, u, got)
+                assert got[(1, 1024)] == got[(1, 512)], (n, li, temperature, topp, u, got)       # the same statistics, another block size
+                if got[(1, 512)] != got[(1, 2048)]:
+                    # the small-block path folds the softmax sum from per-1024 partial sums: another (equally unpinned) summation
+                    # order, so the sum may differ in its last bit and with it a pick that sits on a boundary; both must then be neighbours
+                    z = x.astype(np.float64) / (temperature if temperature < 1.0 else 1.0)
+                    pr = np.exp(z - z.max()); pr /= pr.sum()
+                    order = np.argsort(-pr, kind="stable")
+                    cum = np.cumsum(pr[order])
+                    rank = {int(t): i for i, t in enumerate(order)}
+                    a, b_ = got[(1, 512)], got[(1, 2048)]
+                    assert a >= 0 and b_ >= 0 and abs(cum[rank[a]] - cum[rank[b_]]) < 2e-6, (n, li, temperature, topp, u, got)
     finally:
         check(dev.lib.rama_set_tuning(dev.ctx, b"topp_pairs", 1))
+        check(dev.lib.rama_set_tuning(dev.ctx, b"topp_block", 1024))
 
 
 def test_sample_topp_dev_ties_keep_index_order(dev):

@@ -21,6 +21,24 @@ static double time_us(hipStream_t st, int reps, F f) {
     return ms * 1000.0 / reps;
 }
 
+// [r4] small blocks: statistics once (topp_stats_kernel), BS-entry sorts, the pairs against OB blocks at a time, scatter, pick
+template <int BS, int OB, class K3>
+static void small_blocks(hipStream_t st, int reps, const ToppSortParams& sq, int n, K3 k3, int* result) {
+    ToppStats* stt; CK(hipMalloc(&stt, 64 * sizeof(ToppStats)));
+    ToppSortParams s5 = sq; s5.nblk = (n + BS - 1) / BS;
+    const int nstat = (n + 1023) / 1024;
+    auto j0 = [&] { hipLaunchKernelGGL(topp_stats_kernel, dim3(nstat), dim3(1024), 0, st, s5, stt); };
+    auto j1 = [&] { hipLaunchKernelGGL(topp_blocksort_bs_kernel<BS>, dim3(s5.nblk), dim3(BS / 2), 0, st, s5, (const ToppStats*)stt, nstat); };
+    auto j2 = [&] { hipLaunchKernelGGL((topp_rank_pairs_bs_kernel<BS, OB>), dim3(s5.nblk, (s5.nblk + OB - 1) / OB), dim3(BS / 2), 0, st, s5); };
+    auto j3 = [&] { hipLaunchKernelGGL(topp_rank_scatter_bs_kernel<BS>, dim3((s5.nblk * BS + 1023) / 1024), dim3(1024), 0, st, s5); };
+    j0(); j1(); j2(); j3(); k3(); CK(hipStreamSynchronize(st));
+    int hr3; CK(hipMemcpy(&hr3, result, 4, hipMemcpyDeviceToHost));
+    const double t0_ = time_us(st, reps, j0), t01 = time_us(st, reps, [&] { j0(); j1(); }), t012 = time_us(st, reps, [&] { j0(); j1(); j2(); }),
+                 t0123 = time_us(st, reps, [&] { j0(); j1(); j2(); j3(); }), t5 = time_us(st, reps, [&] { j0(); j1(); j2(); j3(); k3(); });
+    printf("   blocks of %4d x %d: stats %.1f, + sort %.1f, + pairs %.1f, + scatter %.1f, all five %.1f us (token %d)\n", BS, OB, t0_, t01 - t0_, t012 - t01, t0123 - t012, t5, hr3);
+    CK(hipFree(stt));
+}
+
 int main(int argc, char** argv) {
     const int n = 32000, reps = argc > 1 ? atoi(argv[1]) : 100;
     hipStream_t st; CK(hipStreamCreate(&st));
@@ -63,6 +81,11 @@ int main(int argc, char** argv) {
             int hr2; CK(hipMemcpy(&hr2, result, 4, hipMemcpyDeviceToHost));
             const double ta = time_us(st, reps, [&] { k1p(); k2a(); }) - time_us(st, reps, k1p), tb = time_us(st, reps, k2b), tall4 = time_us(st, reps, [&] { k1p(); k2a(); k2b(); k3(); });
             printf("   ranking by pairs: pairs %.1f us (behind the block sort), scatter %.1f us, all four %.1f us (token %d)\n", ta, tb, tall4, hr2);
+            small_blocks<512, 8>(st, reps, sq, n, k3, result);
+            small_blocks<512, 4>(st, reps, sq, n, k3, result);
+            small_blocks<1024, 4>(st, reps, sq, n, k3, result);
+            small_blocks<1024, 2>(st, reps, sq, n, k3, result);
+            small_blocks<1024, 1>(st, reps, sq, n, k3, result);
             CK(hipFree(racc));
         }
     }
