@@ -177,6 +177,34 @@ __global__ __launch_bounds__(1024) void topp_blocksort_kernel(ToppSortParams p) 
     }
 }
 
+// The value of lane (l ^ J) for a constant J < 64 without the LDS crossbar: DPP moves inside a row of 16 lanes (two for J = 4: half
+// mirror i -> 7 - i, then reversed quads i -> i ^ 3), gfx950's row / half swaps across rows.  ~8 cycles each where ds_bpermute is a
+// 100-cycle round trip -- what a 4- or 8-wave sorting workgroup (one or two waves per SIMD, nothing to hide latency behind) is bound by.
+template <int J>
+__device__ __forceinline__ unsigned lane_xor_u32(unsigned v) {
+    static_assert(J == 1 || J == 2 || J == 4 || J == 8 || J == 16 || J == 32, "lane_xor_u32: J");
+    if constexpr (J == 1) return (unsigned)dpp_movi<0xB1>((int)v);                         // quad_perm [1,0,3,2]
+    else if constexpr (J == 2) return (unsigned)dpp_movi<0x4E>((int)v);                    // quad_perm [2,3,0,1]
+    else if constexpr (J == 4) return (unsigned)dpp_movi<0x1B>(dpp_movi<0x141>((int)v));   // row_half_mirror, quad_perm [3,2,1,0]
+    else if constexpr (J == 8) return (unsigned)dpp_movi<0x128>((int)v);                   // row_ror:8
+    else if constexpr (J == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);               // r[0] = rows {0,0,2,2}, r[1] = rows {1,1,3,3}
+        return (threadIdx.x & 16) ? r[0] : r[1];
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);               // r[0] = the lower half twice, r[1] = the upper half
+        return (threadIdx.x & 32) ? r[0] : r[1];
+    }
+}
+// one compare-exchange stage of the bitonic network between lanes l and l ^ J: keep the larger key where (lower lane) == (descending)
+template <int J>
+__device__ __forceinline__ void lane_stage(unsigned long long& A, unsigned long long& B, bool descA, bool descB) {
+    const unsigned long long oa = ((unsigned long long)lane_xor_u32<J>((unsigned)(A >> 32)) << 32) | lane_xor_u32<J>((unsigned)A);
+    const unsigned long long ob = ((unsigned long long)lane_xor_u32<J>((unsigned)(B >> 32)) << 32) | lane_xor_u32<J>((unsigned)B);
+    const bool lower = (threadIdx.x & J) == 0;
+    A = ((oa > A) == (lower == descA)) ? oa : A;
+    B = ((ob > B) == (lower == descB)) ? ob : B;
+}
+
 // ---------------------------------------------------------------- [r4] small blocks: statistics once, 512-entry sorts on 4 waves
 // topp_blocksort_kernel is 16 workgroups of 16 waves: each repeats the softmax statistics over all n logits (7.6 us) and runs a
 // 66-stage bitonic network whose every stage is a turn of 16 waves through one CU (18 us).  With the ranking spread over the chip
@@ -251,31 +279,34 @@ __global__ __launch_bounds__(BS / 2) void topp_blocksort_bs_kernel(ToppSortParam
     int P = 2;
     while (P < cnt) P <<= 1;                                       // uniform
     const int H = P >> 1;
-    // the bitonic network of topp_blocksort_kernel on BS / 2 threads (thread t < P / 2 holds elements t and t + P / 2)
+    // the bitonic network of topp_blocksort_kernel on BS / 2 threads (thread t < P / 2 holds elements t and t + P / 2): a stage's partner
+    // is in the same thread (j = P/2), another wave (j >= 64: LDS, two buffers in turn, one barrier per stage) or the same wave (j < 64:
+    // lane_stage -- 45 of the 55 stages at P = 1024)
     unsigned long long A = tid < H && tid < cnt ? s_k[0][tid] : 0ull;             // zero padding sorts last
     unsigned long long B = tid < H && tid + H < cnt ? s_k[0][tid + H] : 0ull;
     int buf = 1;
     for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j == H) {                                          // only in the last merge: always descending
-                if (A < B) { const unsigned long long t = A; A = B; B = t; }
-                continue;
-            }
-            unsigned long long oa, ob;
-            if (j < 64) {
-                oa = shfl_xor_u64(A, j); ob = shfl_xor_u64(B, j);
-            } else {
-                if (tid < H) { s_k[buf][tid] = A; s_k[buf][tid + H] = B; }
-                __syncthreads();
-                oa = tid < H ? s_k[buf][tid ^ j] : 0ull;
-                ob = tid < H ? s_k[buf][(tid ^ j) + H] : 0ull;
-                buf ^= 1;
-            }
-            const bool lower = (tid & j) == 0;
-            const bool descA = (tid & k) == 0, descB = ((tid + H) & k) == 0;
-            A = (lower == descA) ? (A > oa ? A : oa) : (A < oa ? A : oa);
-            B = (lower == descB) ? (B > ob ? B : ob) : (B < ob ? B : ob);
+        const bool descA = (tid & k) == 0, descB = ((tid + H) & k) == 0;
+        int j = k >> 1;
+        if (j == H) {                                              // only in the last merge: always descending
+            if (A < B) { const unsigned long long t = A; A = B; B = t; }
+            j >>= 1;
         }
+        for (; j >= 64; j >>= 1) {
+            if (tid < H) { s_k[buf][tid] = A; s_k[buf][tid + H] = B; }
+            __syncthreads();
+            const unsigned long long oa = tid < H ? s_k[buf][tid ^ j] : 0ull, ob = tid < H ? s_k[buf][(tid ^ j) + H] : 0ull;
+            buf ^= 1;
+            const bool lower = (tid & j) == 0;
+            A = ((oa > A) == (lower == descA)) ? oa : A;
+            B = ((ob > B) == (lower == descB)) ? ob : B;
+        }
+        if (j >= 32) lane_stage<32>(A, B, descA, descB);
+        if (j >= 16) lane_stage<16>(A, B, descA, descB);
+        if (j >= 8) lane_stage<8>(A, B, descA, descB);
+        if (j >= 4) lane_stage<4>(A, B, descA, descB);
+        if (j >= 2) lane_stage<2>(A, B, descA, descB);
+        if (j >= 1) lane_stage<1>(A, B, descA, descB);
     }
     if (tid < H) {
         if (tid < cnt) {
