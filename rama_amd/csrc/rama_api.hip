@@ -9,6 +9,7 @@
 #include "prefill_mfma.hpp"
 #include "ref_order.hpp"
 #include "chain.hpp"
+#include "topp_pick.hpp"
 
 #include <hip/hip_ext.h>   // hipExtLaunchKernelGGL: start/stop events carried by the dispatch itself
 
@@ -112,6 +113,11 @@ struct rama_ctx {
     int topp_cap = 0;
     float* topp_bp = nullptr; int* topp_bi = nullptr; int* topp_bcount = nullptr;       // topp_sort.hpp
     int* topp_racc = nullptr;               // pair-wise ranking: the accumulators, one per block slot
+    unsigned long long* topp_rk = nullptr;  // small-block path: count << 48 | mass accumulators, one per block slot
+    unsigned long long* topp_bm = nullptr;  // ... the blocks' running masses
+    float* topp_approx = nullptr;           // ... the mass in front of every entry of the whole order
+    void* topp_dist = nullptr;              // topp_pick_dist_kernel's hand-off words: items | hdr | cross | epoch | bad
+    int tune_topp_dist = 1;                 // 1: the running sums by up to 32 workgroups in one launch (topp_pick.hpp); 0: one workgroup's scan rounds
     ToppStats* topp_stats = nullptr;        // small-block path: partial softmax statistics, one per 1024 logits
     int tune_topp_block = 1024;             // entries per sorted block on the pair-ranking path: 1024 or 512 (statistics once + 8- / 4-wave sorts) or 2048 (round 3's block sort)
     int tune_topp_pairs = 1;                // 1: the ranking as (block, block) pairs spread over the chip + a scatter launch; 0: one workgroup searches all blocks in its LDS
@@ -289,6 +295,7 @@ int rama_ctx_destroy(rama_ctx* c) {
     for (int i = 0; i < 2; i++) { hipFree(c->topp_keys[i]); hipFree(c->topp_vals[i]); }
     hipFree(c->topp_prefix); hipFree(c->topp_m); hipFree(c->topp_err); hipFree(c->pf_blob); hipFree(c->pc_blob); if (c->ring) hipHostFree(c->ring);
     hipFree(c->topp_bp); hipFree(c->topp_bi); hipFree(c->topp_bcount); hipFree(c->topp_racc);
+    hipFree(c->topp_rk); hipFree(c->topp_bm); hipFree(c->topp_approx); hipFree(c->topp_dist); hipFree(c->topp_stats);
     hipFree(c->bc.toks); hipFree(c->bc.seqs); hipFree(c->bc.out); if (c->bc.ring) hipHostFree(c->bc.ring);
     hipHostFree(c->pinned_int); hipHostFree(c->pinned_tok);
     hipEventDestroy(c->t0); hipEventDestroy(c->t1);
@@ -1331,6 +1338,29 @@ int rama_forward_stage_devtok(rama_ctx* c, const rama_config* cfg, const rama_we
 
 // ---- device top-p sampler (topp_sort.hpp: block sorts + ranks + the exact running sum; every kernel hand-written)
 
+// topp_pick_dist_kernel's hand-off words in one allocation: items | hdr | cross | epoch | bad
+constexpr size_t kToppDistItems = sizeof(PickItem) * kPickChunk * kPickMaxChunks;
+constexpr size_t kToppDistBytes = kToppDistItems + 8 * kPickMaxChunks + 16 + 16;
+static ToppDistParams topp_dist_params(rama_ctx* c) {
+    char* b = (char*)c->topp_dist;
+    ToppDistParams d{};
+    d.approx = c->topp_approx;
+    d.items = (PickItem*)b;
+    d.hdr = (unsigned long long*)(b + kToppDistItems);
+    d.cross = d.hdr + kPickMaxChunks;
+    d.epoch = (const unsigned*)(d.cross + 2);
+    d.bad = (unsigned*)(d.cross + 2) + 1;
+    return d;
+}
+// diagnostics (not in the C ABI header): bit 0 a hand-off wait of topp_pick_dist_kernel timed out, bit 1 a predicted binade did not hold
+extern "C" int rama_internal_topp_dist_bad(rama_ctx* c, unsigned* bad) {
+    if (!c || !bad) return 1;
+    *bad = 0;
+    if (!c->topp_dist) return 0;
+    hipStreamSynchronize(c->stream);
+    return hipMemcpy(bad, topp_dist_params(c).bad, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess;
+}
+
 // scratch for n logits; called outside any stream capture
 static int ensure_topp_scratch(rama_ctx* c, int n) {
     if (n <= c->topp_cap) return 0;
@@ -1348,6 +1378,11 @@ static int ensure_topp_scratch(rama_ctx* c, int n) {
     HIPCHK(hipMalloc(&c->topp_bi, sizeof(int) * kToppBlock * std::max<size_t>(nblk, kToppMaxBlocks)));
     HIPCHK(hipMalloc(&c->topp_bcount, sizeof(int) * std::max<size_t>(((size_t)n + 511) / 512 + 1, std::max<size_t>(nblk, kToppMaxBlocks))));
     hipFree(c->topp_stats); HIPCHK(hipMalloc(&c->topp_stats, sizeof(ToppStats) * (((size_t)n + 1023) / 1024 + 1)));
+    hipFree(c->topp_rk); hipFree(c->topp_bm); hipFree(c->topp_approx);
+    HIPCHK(hipMalloc(&c->topp_rk, sizeof(unsigned long long) * kToppBlock * std::max<size_t>(nblk, kToppMaxBlocks)));
+    HIPCHK(hipMalloc(&c->topp_bm, sizeof(unsigned long long) * kToppBlock * std::max<size_t>(nblk, kToppMaxBlocks)));
+    HIPCHK(hipMalloc(&c->topp_approx, sizeof(float) * n));
+    if (!c->topp_dist) { HIPCHK(hipMalloc(&c->topp_dist, kToppDistBytes)); HIPCHK(hipMemset(c->topp_dist, 0, kToppDistBytes)); }
     c->topp_cap = n;
     return 0;
 }
@@ -1398,7 +1433,11 @@ static int enqueue_sample_launches(rama_ctx* c, ArgmaxParams fin, float temperat
     sp.m = c->topp_m; sp.err = c->topp_err; sp.nblk = (fin.n + kToppBlock - 1) / kToppBlock;
     const bool pairs = lds_path && c->tune_topp_pairs && sp.nblk > 1;
     if (pairs) sp.racc = c->topp_racc;
+    bool dist = false;
     if (pairs && c->tune_topp_block != kToppBlock) {
+        sp.rk = c->topp_rk; sp.bm = c->topp_bm; sp.approx = c->topp_approx;
+        dist = c->tune_topp_dist != 0;
+        if (dist) sp.epoch = (unsigned*)topp_dist_params(c).epoch;
         // small blocks (topp_sort.hpp [r4]): the statistics once per 1024 logits, 1024-entry sorts on 8 waves (or 512 on 4), the ranking by
         // (block, block) pairs over the whole chip, a scatter launch
         const int nstat = (fin.n + 1023) / 1024;
@@ -1418,7 +1457,8 @@ static int enqueue_sample_launches(rama_ctx* c, ArgmaxParams fin, float temperat
     }
     if (lds_path && !c->tune_topp_keep_sums) tp.prefix = nullptr;
     // the running sums: the exact parallel scan with the list in LDS, or (longer lists) the staged lane ripple
-    if (lds_path) hipLaunchKernelGGL(topp_pick_scan_kernel, dim3(1), dim3(1024), 0, c->stream, tp, fin);
+    if (dist) hipLaunchKernelGGL(topp_pick_dist_kernel, dim3(kPickMaxChunks), dim3(1024), 0, c->stream, tp, topp_dist_params(c), fin);
+    else if (lds_path) hipLaunchKernelGGL(topp_pick_scan_kernel, dim3(1), dim3(1024), 0, c->stream, tp, fin);
     else hipLaunchKernelGGL(topp_pick_kernel, dim3(1), dim3(1024), 0, c->stream, tp, fin);
     LAUNCHCHK();
     return 0;
@@ -2504,9 +2544,10 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
         drop_graph(c);
         return 0;
     }
-    if (!strcmp(key, "topp_sort") || !strcmp(key, "topp_keep_sums") || !strcmp(key, "topp_pairs")) {
-        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: topp_sort / topp_keep_sums / topp_pairs must be 0 or 1");
-        if (!strcmp(key, "topp_sort")) c->tune_topp_sort = value; else if (!strcmp(key, "topp_pairs")) c->tune_topp_pairs = value; else c->tune_topp_keep_sums = value;
+    if (!strcmp(key, "topp_sort") || !strcmp(key, "topp_keep_sums") || !strcmp(key, "topp_pairs") || !strcmp(key, "topp_dist")) {
+        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: topp_sort / topp_keep_sums / topp_pairs / topp_dist must be 0 or 1");
+        if (!strcmp(key, "topp_sort")) c->tune_topp_sort = value; else if (!strcmp(key, "topp_pairs")) c->tune_topp_pairs = value;
+        else if (!strcmp(key, "topp_dist")) c->tune_topp_dist = value; else c->tune_topp_keep_sums = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
         return 0;

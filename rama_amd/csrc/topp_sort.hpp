@@ -43,7 +43,35 @@ struct ToppSortParams {
     unsigned* err;                      // set to 1 when nothing is kept
     int nblk;
     int* racc;                          // [nblk * 2048] pair-wise ranking (topp_rank_pairs_kernel): entries of OTHER blocks that precede block b's entry s; zeroed by the block sort
+    // small-block path (topp_*_bs_kernel): count and probability mass in one 64-bit accumulator, see topp_fixed()
+    unsigned long long* rk;             // [nblk * BS] entries of other blocks that precede the entry (bits 48..63) and their mass (bits 0..47); zeroed by the block sort
+    unsigned long long* bm;             // [nblk * BS] mass of a block's entries up to and including each one (the block sort's output)
+    float* approx;                      // [n] out: the mass in front of every entry of the whole order (what topp_pick_dist_kernel predicts binades from)
+    unsigned* epoch;                    // the pick launch's hand-off tag (topp_pick.hpp), advanced by the scatter launch
 };
+// Probability mass as a 48-bit fixed-point number, unit 2^-47, truncated: integer sums are exact in any order, so the mass in front of an
+// entry -- gathered from 32 blocks by atomics -- is the same number however the adds arrive, and differs from the real-number sum by less
+// than 2^-47 per entry.  p <= 1 (the softmax sum contains the maximum's exp(0) = 1), so a sum over the whole list stays below 2^48.
+constexpr int kMassBits = 48;
+constexpr unsigned long long kMassMask = (1ull << kMassBits) - 1ull;
+__device__ __forceinline__ unsigned long long topp_fixed(float p) {
+    const unsigned b = __float_as_uint(p);
+    const int e = (int)(b >> 23);                                  // p = mant 2^(e - 150): p 2^47 = mant 2^(e - 103)
+    const unsigned long long mant = (unsigned long long)((b & 0x7FFFFFu) | 0x800000u);
+    const int sh = e - 103;
+    return e == 0 ? 0ull : (sh >= 0 ? mant << min(sh, 24) : (sh > -24 ? mant >> (-sh) : 0ull));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {                 // lanes without a source get 0
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, ROW_MASK, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, ROW_MASK, 0xF, true);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long wave_scan_u64(unsigned long long v) {           // inclusive, lane order
+    v += dpp_u64<0x111, 0xF>(v); v += dpp_u64<0x112, 0xF>(v); v += dpp_u64<0x114, 0xF>(v); v += dpp_u64<0x118, 0xF>(v);
+    v += dpp_u64<0x142, 0xA>(v); v += dpp_u64<0x143, 0xC>(v);
+    return v;
+}
 
 __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int mask) {
     const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, mask), hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), mask);
@@ -273,7 +301,7 @@ __global__ __launch_bounds__(BS / 2) void topp_blocksort_bs_kernel(ToppSortParam
     }
     __syncthreads();
     const int cnt = s_n;
-    if (p.racc) { p.racc[(size_t)base + tid] = 0; p.racc[(size_t)base + NT + tid] = 0; }
+    p.rk[(size_t)base + tid] = 0ull; p.rk[(size_t)base + NT + tid] = 0ull;
     if (tid == 0) p.bcount[blockIdx.x] = cnt;
     if (cnt == 0) return;                                          // uniform
     int P = 2;
@@ -318,13 +346,29 @@ __global__ __launch_bounds__(BS / 2) void topp_blocksort_bs_kernel(ToppSortParam
             p.bi[(size_t)base + tid + H] = (int)(0xFFFFFFFFu - (unsigned)(B & 0xFFFFFFFFull));
         }
     }
+    // the block's running mass in sorted order (fixed point: exact integer sums): thread t takes positions 2t and 2t + 1
+    __syncthreads();
+    unsigned long long* s_f = s_k[0];
+    if (tid < H) { s_f[tid] = topp_fixed(__uint_as_float((unsigned)(A >> 32))); s_f[tid + H] = topp_fixed(__uint_as_float((unsigned)(B >> 32))); }
+    __syncthreads();
+    const int wave = tid >> 6;
+    const unsigned long long f0 = 2 * tid < cnt ? s_f[2 * tid] : 0ull, f1 = 2 * tid + 1 < cnt ? s_f[2 * tid + 1] : 0ull;
+    unsigned long long run = wave_scan_u64(f0 + f1);
+    if (lane == 63) s_k[1][wave] = run;
+    __syncthreads();
+    for (int w = 0; w < wave; w++) run += s_k[1][w];               // NT / 64 <= 8 waves
+    if (2 * tid < cnt) p.bm[(size_t)base + 2 * tid] = run - f1;
+    if (2 * tid + 1 < cnt) p.bm[(size_t)base + 2 * tid + 1] = run;
 }
 
-// the pair-wise ranking for blocks of BS entries: a workgroup of BS / 2 threads takes block b against OB other blocks at once
+// the pair-wise ranking for blocks of BS entries: a workgroup of BS / 2 threads takes block b against OB other blocks at once.  Besides the
+// COUNT of block o's entries that precede an entry it looks up their MASS (the block's running mass at that place) and adds both to the
+// entry's accumulator in one 64-bit integer atomic: count << 48 | mass.
 template <int BS, int OB>
 __global__ __launch_bounds__(BS / 2) void topp_rank_pairs_bs_kernel(ToppSortParams p) {
     constexpr int NT = BS / 2;
     __shared__ unsigned s_o[OB * BS];
+    __shared__ unsigned long long s_m[OB * BS];
     const int tid = threadIdx.x;
     const int b = blockIdx.x, o0 = blockIdx.y * OB;
     const int cb = p.bcount[b];
@@ -337,13 +381,19 @@ __global__ __launch_bounds__(BS / 2) void topp_rank_pairs_bs_kernel(ToppSortPara
     const unsigned k1 = tid + NT < cb ? __float_as_uint(p.bp[(size_t)b * BS + NT + tid]) : 0u;
     {
         unsigned v[2 * OB];
+        unsigned long long f[2 * OB];
 #pragma unroll
         for (int q = 0; q < OB; q++) {
             v[2 * q] = tid < co[q] ? __float_as_uint(p.bp[(size_t)(o0 + q) * BS + tid]) : 0u;
             v[2 * q + 1] = tid + NT < co[q] ? __float_as_uint(p.bp[(size_t)(o0 + q) * BS + NT + tid]) : 0u;
+            f[2 * q] = tid < co[q] ? p.bm[(size_t)(o0 + q) * BS + tid] : 0ull;
+            f[2 * q + 1] = tid + NT < co[q] ? p.bm[(size_t)(o0 + q) * BS + NT + tid] : 0ull;
         }
 #pragma unroll
-        for (int q = 0; q < OB; q++) { s_o[q * BS + tid] = v[2 * q]; s_o[q * BS + NT + tid] = v[2 * q + 1]; }
+        for (int q = 0; q < OB; q++) {
+            s_o[q * BS + tid] = v[2 * q]; s_o[q * BS + NT + tid] = v[2 * q + 1];
+            s_m[q * BS + tid] = f[2 * q]; s_m[q * BS + NT + tid] = f[2 * q + 1];
+        }
     }
     __syncthreads();
     int top = 1;
@@ -363,26 +413,34 @@ __global__ __launch_bounds__(BS / 2) void topp_rank_pairs_bs_kernel(ToppSortPara
             p1[q] += (p1[q] + step <= co[q] && pr1) ? step : 0;
         }
     }
-    int a0 = 0, a1 = 0;
+    unsigned long long a0 = 0, a1 = 0;
 #pragma unroll
-    for (int q = 0; q < OB; q++) { a0 += p0[q]; a1 += p1[q]; }
-    if (tid < cb && a0) atomicAdd(&p.racc[(size_t)b * BS + tid], a0);
-    if (tid + NT < cb && a1) atomicAdd(&p.racc[(size_t)b * BS + NT + tid], a1);
+    for (int q = 0; q < OB; q++) {
+        a0 += ((unsigned long long)p0[q] << kMassBits) + (p0[q] > 0 ? s_m[q * BS + p0[q] - 1] : 0ull);
+        a1 += ((unsigned long long)p1[q] << kMassBits) + (p1[q] > 0 ? s_m[q * BS + p1[q] - 1] : 0ull);
+    }
+    if (tid < cb && a0) atomicAdd(&p.rk[(size_t)b * BS + tid], a0);
+    if (tid + NT < cb && a1) atomicAdd(&p.rk[(size_t)b * BS + NT + tid], a1);
 }
+// place = own place in the block + the count; the mass in front of the entry = the accumulated mass + the own block's mass before it
 template <int BS>
 __global__ __launch_bounds__(1024) void topp_rank_scatter_bs_kernel(ToppSortParams p) {
     const int g = blockIdx.x * 1024 + threadIdx.x;
     const int b = g / BS, s = g % BS;
     if (g == 0) {
+        if (p.epoch) *p.epoch = *p.epoch + 1u;
         int total = 0;
         for (int o = 0; o < p.nblk; o++) total += p.bcount[o];
         *p.m = total;
         if (total == 0 && p.err) *p.err = 1u;
     }
     if (b >= p.nblk || s >= p.bcount[b]) return;
-    const int rank = s + p.racc[(size_t)b * BS + s];
+    const unsigned long long acc = p.rk[(size_t)b * BS + s];
+    const int rank = s + (int)(acc >> kMassBits);
+    const unsigned long long mass = (acc & kMassMask) + (s > 0 ? p.bm[(size_t)b * BS + s - 1] : 0ull);
     p.keys[rank] = p.bp[(size_t)b * BS + s];
     p.vals[rank] = p.bi[(size_t)b * BS + s];
+    if (p.approx) p.approx[rank] = (float)mass * 0x1p-47f;
 }
 
 // Blocks are index ranges, so among equal probabilities an entry of an earlier block comes first:

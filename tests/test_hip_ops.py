@@ -411,8 +411,20 @@ TOPP_SUM_CASES = [("flat", 32000, 0.05, 0.9), ("flat", 32000, 0.05, 1.0), ("ordi
                   ("flat", 2049, 0.1, 0.9), ("ordinary", 4097, 2.0, 0.999), ("flat", 100, 0.1, 0.5), ("steps", 32000, 0.0, 0.97)]
 
 
+def _dist_bad(dev):
+    """diagnostic word of topp_pick_dist_kernel: bit 0 a hand-off wait timed out, bit 1 a predicted binade did not hold"""
+    import ctypes as C
+    bad = C.c_uint(0)
+    f = dev.lib.rama_internal_topp_dist_bad
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.POINTER(C.c_uint)]
+    assert f(dev.ctx, C.byref(bad)) == 0
+    return bad.value
+
+
+@pytest.mark.parametrize("dist", [1, 0])
 @pytest.mark.parametrize("kind,n,scale,topp", TOPP_SUM_CASES)
-def test_sample_topp_dev_running_sums_are_the_sequential_ones(dev, kind, n, scale, topp):
+def test_sample_topp_dev_running_sums_are_the_sequential_ones(dev, kind, n, scale, topp, dist):
     """the sampler's sorted order and every running sum up to the crossing, bit for bit against a
     sequential fp32 accumulation of the device's own sorted probabilities (csrc/topp_sort.hpp forms
     them with a parallel scan over integer increments): flat lists where cum walks through ~15
@@ -430,10 +442,13 @@ def test_sample_topp_dev_running_sums_are_the_sequential_ones(dev, kind, n, scal
         x = rnd(n, 7 + n % 13, scale)
     from rama_amd._lib import check
     check(dev.lib.rama_set_tuning(dev.ctx, b"topp_keep_sums", 1))
+    check(dev.lib.rama_set_tuning(dev.ctx, b"topp_dist", dist))       # the sums by 32 workgroups in one launch (default) | one workgroup's scan rounds
     try:
         _topp_dev(dev, x, 1.0, topp, 0.5)
     finally:
         check(dev.lib.rama_set_tuning(dev.ctx, b"topp_keep_sums", 0))
+        check(dev.lib.rama_set_tuning(dev.ctx, b"topp_dist", 1))
+    assert _dist_bad(dev) == 0
     m, ps, idx, prefix = _topp_scratch(dev, n)
     assert m > 0
     # order: descending probability, equal ones by ascending index (stable sort of the index-ordered list)
@@ -444,8 +459,9 @@ def test_sample_topp_dev_running_sums_are_the_sequential_ones(dev, kind, n, scal
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (kind, int(np.nonzero(got != want)[0][0]), last, m)
 
 
+@pytest.mark.parametrize("dist", [1, 0])
 @pytest.mark.parametrize("seed", range(40))
-def test_sample_topp_dev_running_sums_random_structures(dev, seed):
+def test_sample_topp_dev_running_sums_random_structures(dev, seed, dist):
     """the exact parallel running sum on randomly structured lists: mixtures of plateaus (equal
     probabilities: ties in every binade or in none), exact powers of two (adds that are exact until
     they tie), geometric tails and noise, random sizes up to the LDS path's 32768 and random topp"""
@@ -466,10 +482,13 @@ def test_sample_topp_dev_running_sums_random_structures(dev, seed):
         x = np.where(rng.random(n) < 0.1, 3.0, 0.0).astype(np.float32) + (rng.standard_normal(n) * 1e-6).astype(np.float32)
     topp = float(rng.choice([0.5, 0.9, 0.95, 0.999, 1.0]))
     check(dev.lib.rama_set_tuning(dev.ctx, b"topp_keep_sums", 1))
+    check(dev.lib.rama_set_tuning(dev.ctx, b"topp_dist", dist))
     try:
         got_tok = _topp_dev(dev, x, 1.0, topp, 0.37)
     finally:
         check(dev.lib.rama_set_tuning(dev.ctx, b"topp_keep_sums", 0))
+        check(dev.lib.rama_set_tuning(dev.ctx, b"topp_dist", 1))
+    assert _dist_bad(dev) == 0
     m, ps, idx, prefix = _topp_scratch(dev, n)
     if m == 0:
         assert got_tok == -1
@@ -482,6 +501,35 @@ def test_sample_topp_dev_running_sums_random_structures(dev, seed):
     r = np.float32(0.37) * want[last]
     below = int(np.count_nonzero(~(r < want[:last])))
     assert got_tok == int(idx[min(below, last)])
+
+
+@pytest.mark.parametrize("n", [2049, 3000, 4097, 9000, 20000, 32000, 32768])
+def test_sample_topp_dev_dist_pick_equals_scan_pick(dev, n):
+    """csrc/topp_pick.hpp (the running sums by up to 32 workgroups in one launch: binades predicted from the exact fixed-point mass in
+    front of every entry, integer maps, a lane ripple over the chunks' items) against topp_pick_scan_kernel (one workgroup, a scan
+    round per binade): the same token for every draw -- u = 0, u next to 1, topp 1.0 (the whole list, up to the binade of 1.0), a
+    tiny topp (the crossing in the first chunk), lists of equal probabilities (every add of a binade rounds the same way: the
+    largest drift between the real-number mass and the fp32 sum), two plateaus, a steep geometric tail -- and no prediction that
+    failed, no wait that timed out"""
+    from rama_amd._lib import check
+    rng = np.random.default_rng(7 * n)
+    geo = (-np.arange(n) * 0.01).astype(np.float32); rng.shuffle(geo)
+    lists = [rnd(n, n + 11, 0.05), rnd(n, n + 12, 1.0), rnd(n, n + 13, 3.0), rnd(n, n + 14, 8.0), np.full(n, 0.125, np.float32),
+             np.where(rng.random(n) < 0.3, 2.0, 0.0).astype(np.float32), geo,
+             (rng.integers(0, 3, n).astype(np.float32) * np.float32(0.6931472))]
+    draws = [(1.0, 0.9, 0.2721174359321594), (1.0, 0.9, 0.0), (1.0, 0.9, 0.99999994), (1.0, 1.0, 0.5), (1.0, 1.0, 0.99999994), (1.0, 0.01, 0.6),
+             (0.5, 0.95, 0.41), (1.0, 0.5, 0.999)]
+    try:
+        for li, x in enumerate(lists):
+            for temperature, topp, u in draws:
+                got = {}
+                for dist in (1, 0):
+                    check(dev.lib.rama_set_tuning(dev.ctx, b"topp_dist", dist))
+                    got[dist] = _topp_dev(dev, x, temperature, topp, u)
+                assert got[1] == got[0], (n, li, temperature, topp, u, got)
+    finally:
+        check(dev.lib.rama_set_tuning(dev.ctx, b"topp_dist", 1))
+    assert _dist_bad(dev) == 0
 
 
 def test_sample_topp_dev_temperature_zero_is_argmax(dev):

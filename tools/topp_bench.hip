@@ -2,7 +2,7 @@
 // microseconds per launch (HIP events around back-to-back launches) and where the time goes inside
 // each (100 MHz time stamps of workgroup 0).  Not part of the product.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DRAMA_TOPP_STAMPS -o build/topp_bench tools/topp_bench.hip
-#include "../rama_amd/csrc/topp_sort.hpp"
+#include "../rama_amd/csrc/topp_pick.hpp"
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -21,22 +21,50 @@ static double time_us(hipStream_t st, int reps, F f) {
     return ms * 1000.0 / reps;
 }
 
-// [r4] small blocks: statistics once (topp_stats_kernel), BS-entry sorts, the pairs against OB blocks at a time, scatter, pick
+// [r4] small blocks: statistics once (topp_stats_kernel), BS-entry sorts, the pairs against OB blocks at a time, scatter, then the
+// running sums by one workgroup's scan rounds (topp_pick_scan_kernel) or by 32 workgroups in one launch (topp_pick_dist_kernel)
 template <int BS, int OB, class K3>
-static void small_blocks(hipStream_t st, int reps, const ToppSortParams& sq, int n, K3 k3, int* result) {
+static void small_blocks(hipStream_t st, int reps, const ToppSortParams& sq, const ToppParams& tp, const ArgmaxParams& fin, int n, K3 k3, int* result) {
     ToppStats* stt; CK(hipMalloc(&stt, 64 * sizeof(ToppStats)));
     ToppSortParams s5 = sq; s5.nblk = (n + BS - 1) / BS;
+    CK(hipMalloc(&s5.rk, 32768 * 8)); CK(hipMalloc(&s5.bm, 32768 * 8)); CK(hipMalloc(&s5.approx, 32768 * 4));
+    const size_t items = sizeof(PickItem) * kPickChunk * kPickMaxChunks, bytes = items + 8 * kPickMaxChunks + 32;
+    char* blob; CK(hipMalloc(&blob, bytes)); CK(hipMemset(blob, 0, bytes));
+    ToppDistParams d{}; d.approx = s5.approx; d.items = (PickItem*)blob; d.hdr = (unsigned long long*)(blob + items); d.cross = d.hdr + kPickMaxChunks;
+    d.epoch = (const unsigned*)(d.cross + 2); d.bad = (unsigned*)(d.cross + 2) + 1;
+    s5.epoch = (unsigned*)d.epoch;
     const int nstat = (n + 1023) / 1024;
     auto j0 = [&] { hipLaunchKernelGGL(topp_stats_kernel, dim3(nstat), dim3(1024), 0, st, s5, stt); };
     auto j1 = [&] { hipLaunchKernelGGL(topp_blocksort_bs_kernel<BS>, dim3(s5.nblk), dim3(BS / 2), 0, st, s5, (const ToppStats*)stt, nstat); };
     auto j2 = [&] { hipLaunchKernelGGL((topp_rank_pairs_bs_kernel<BS, OB>), dim3(s5.nblk, (s5.nblk + OB - 1) / OB), dim3(BS / 2), 0, st, s5); };
     auto j3 = [&] { hipLaunchKernelGGL(topp_rank_scatter_bs_kernel<BS>, dim3((s5.nblk * BS + 1023) / 1024), dim3(1024), 0, st, s5); };
+    auto j4 = [&] { hipLaunchKernelGGL(topp_pick_dist_kernel, dim3(kPickMaxChunks), dim3(1024), 0, st, tp, d, fin); };
     j0(); j1(); j2(); j3(); k3(); CK(hipStreamSynchronize(st));
     int hr3; CK(hipMemcpy(&hr3, result, 4, hipMemcpyDeviceToHost));
+    j0(); j1(); j2(); j3(); j4(); CK(hipStreamSynchronize(st));
+    int hr4; CK(hipMemcpy(&hr4, result, 4, hipMemcpyDeviceToHost));
     const double t0_ = time_us(st, reps, j0), t01 = time_us(st, reps, [&] { j0(); j1(); }), t012 = time_us(st, reps, [&] { j0(); j1(); j2(); }),
-                 t0123 = time_us(st, reps, [&] { j0(); j1(); j2(); j3(); }), t5 = time_us(st, reps, [&] { j0(); j1(); j2(); j3(); k3(); });
-    printf("   blocks of %4d x %d: stats %.1f, + sort %.1f, + pairs %.1f, + scatter %.1f, all five %.1f us (token %d)\n", BS, OB, t0_, t01 - t0_, t012 - t01, t0123 - t012, t5, hr3);
-    CK(hipFree(stt));
+                 t0123 = time_us(st, reps, [&] { j0(); j1(); j2(); j3(); }), t5 = time_us(st, reps, [&] { j0(); j1(); j2(); j3(); k3(); }),
+                 t6 = time_us(st, reps, [&] { j0(); j1(); j2(); j3(); j4(); });
+    unsigned bad; CK(hipMemcpy(&bad, d.bad, 4, hipMemcpyDeviceToHost));
+    printf("   blocks of %4d x %d: stats %.1f, + sort %.1f, + pairs %.1f, + scatter %.1f | + scan pick: %.1f us (token %d) | + dist pick %.1f: %.1f us (token %d, bad %u)\n",
+           BS, OB, t0_, t01 - t0_, t012 - t01, t0123 - t012, t5, hr3, t6 - t0123, t6, hr4, bad);
+    unsigned long long ps[kPickMaxChunks][12]; CK(hipMemcpyFromSymbol(ps, HIP_SYMBOL(g_pick_stamps), sizeof ps));
+    unsigned hdr[2 * kPickMaxChunks]; CK(hipMemcpy(hdr, d.hdr, sizeof hdr, hipMemcpyDeviceToHost));
+    int ni = 0; for (int c = 0; c < kPickMaxChunks; c++) ni += (int)hdr[2 * c];
+    printf("      items per chunk:"); for (int c = 0; c < kPickMaxChunks; c++) printf(" %u", hdr[2 * c]); printf("\n");
+    {   // kinds of chunk 0's and chunk 16's items
+        std::vector<unsigned long long> it(2 * kPickChunk * kPickMaxChunks); CK(hipMemcpy(it.data(), d.items, it.size() * 8, hipMemcpyDeviceToHost));
+        for (int c : {0, 15, 16}) { printf("      chunk %d kinds:", c); for (unsigned q = 0; q < hdr[2 * c] && q < 80; q++) printf(" %llu", (it[2 * ((size_t)c * kPickChunk + q)] >> 32) & 0xFF); printf("\n"); }
+    }
+    printf("      dist pick, items %d; workgroup: load classify+scan+publish headers items+walk own-walk sums+cross finish (us)\n", ni);
+    for (int c : {0, 1, 8, 16, 24, 28, 31}) {
+        printf("      wg %2d:", c);
+        for (int q = 1; q < 7; q++) printf(" %5.1f", ps[c][q] > ps[c][q - 1] ? (double)(long long)(ps[c][q] - ps[c][q - 1]) / 100.0 : 0.0);
+        printf("   (ripples %.2f;", ps[c][9] > ps[c][8] ? (double)(long long)(ps[c][9] - ps[c][8]) / 100.0 : 0.0);
+        printf(" items fetched %.1f after the headers; from wg 0's start %.1f)\n", ps[c][7] > ps[c][2] ? (double)(long long)(ps[c][7] - ps[c][2]) / 100.0 : 0.0, (double)(long long)(ps[c][0] - ps[0][0]) / 100.0);
+    }
+    CK(hipFree(stt)); CK(hipFree(s5.rk)); CK(hipFree(s5.bm)); CK(hipFree(s5.approx)); CK(hipFree(blob));
 }
 
 int main(int argc, char** argv) {
@@ -81,11 +109,7 @@ int main(int argc, char** argv) {
             int hr2; CK(hipMemcpy(&hr2, result, 4, hipMemcpyDeviceToHost));
             const double ta = time_us(st, reps, [&] { k1p(); k2a(); }) - time_us(st, reps, k1p), tb = time_us(st, reps, k2b), tall4 = time_us(st, reps, [&] { k1p(); k2a(); k2b(); k3(); });
             printf("   ranking by pairs: pairs %.1f us (behind the block sort), scatter %.1f us, all four %.1f us (token %d)\n", ta, tb, tall4, hr2);
-            small_blocks<512, 8>(st, reps, sq, n, k3, result);
-            small_blocks<512, 4>(st, reps, sq, n, k3, result);
-            small_blocks<1024, 4>(st, reps, sq, n, k3, result);
-            small_blocks<1024, 2>(st, reps, sq, n, k3, result);
-            small_blocks<1024, 1>(st, reps, sq, n, k3, result);
+            small_blocks<1024, 1>(st, reps, sq, tp, fin, n, k3, result);
             CK(hipFree(racc));
         }
     }
