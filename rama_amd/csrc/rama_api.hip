@@ -1441,7 +1441,7 @@ static int enqueue_sample_launches(rama_ctx* c, ArgmaxParams fin, float temperat
         // small blocks (topp_sort.hpp [r4]): the statistics once per 1024 logits, 1024-entry sorts on 8 waves (or 512 on 4), the ranking by
         // (block, block) pairs over the whole chip, a scatter launch
         const int nstat = (fin.n + 1023) / 1024;
-        if (c->tune_topp_block == 1024) { if (int rc = enqueue_small_blocks<1024, 1>(c, sp, nstat)) return rc; }
+        if (c->tune_topp_block == 1024) { if (int rc = enqueue_small_blocks<1024, 2>(c, sp, nstat)) return rc; }
         else if (int rc = enqueue_small_blocks<512, 4>(c, sp, nstat)) return rc;
     } else {
     if (fin.n <= kToppBlock * kToppMaxBlocks) hipLaunchKernelGGL(topp_blocksort_kernel<false>, dim3(sp.nblk), dim3(1024), 0, c->stream, sp);

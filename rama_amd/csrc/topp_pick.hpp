@@ -33,6 +33,8 @@ namespace rama {
 constexpr int kPickChunk = 1024;           // elements per workgroup, one per thread
 constexpr int kPickMaxChunks = 32;         // n <= 32768
 constexpr long kPickSpinLimit = 1L << 22;
+constexpr int kPickScanMax = 8192;         // lists up to this length are left to ONE workgroup's scan rounds (topp_sort.hpp): 5.4 us for 79 entries,
+                                           // 8.5 for 7 000, where the phases below cost 7.4 and 9.5 (barriers of 16 waves, two hand-offs)
 
 // 16 bytes as two tagged words: w0 = epoch (24 bits) << 40 | kind << 32 | bits of f0,  w1 = epoch (32 bits) << 32 | bits of f1.
 // kind (statistics only) = the binade's biased exponent E (24..253) for a MAP segment (f = d0 U, d1 U); 0 for one SEQ element (f0 = f1 = p)
@@ -108,12 +110,17 @@ __device__ __forceinline__ float pick_ripple(float cum, float f0, float f1, int 
 }
 
 __global__ __launch_bounds__(1024) void topp_pick_dist_kernel(ToppParams p, ToppDistParams d, ArgmaxParams fin) {
-    __shared__ PickShared sh;
+    __shared__ union { PickShared pick; ScanSharedT<kPickScanMax> scan; } shu;
+    PickShared& sh = shu.pick;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = blockIdx.x;
     int cpos = 0, n_forced = 0, n_out = 0, forced_tok = -1;
     const int i = g * kPickChunk + tid;
     // (the element is requested before m is known: the list and its length arrive together)
     const int m_raw = *p.m;
+    if (m_raw <= kPickScanMax) {                                   // uniform over the launch
+        if (g == 0) topp_pick_scan_body(p, fin, shu.scan);
+        return;
+    }
     const unsigned epoch = *d.epoch;
     const float pv_ = p.keys[min(i, p.n - 1)], av_ = d.approx[min(i, p.n - 1)];
     if (fin.ctl && tid == 0) {

@@ -651,19 +651,21 @@ __device__ __forceinline__ int elem_apply(int c, int e) { return c + (e & 0x0FFF
 // hold probabilities for the next round).  Round state is kept twice and used in turn, so a round
 // costs three barriers.
 struct ScanState { int pos, done, last; float cum; };
-struct ScanShared {
-    float x[32768 + 1024];
+template <int CAP>                        // the longest list (a multiple of 1024)
+struct ScanSharedT {
+    float x[CAP + CAP / 32];
     Inc w[2][16];
     int ev[2][16];
     ScanState st[2];
     int next;
 };
+using ScanShared = ScanSharedT<32768>;
 __device__ __forceinline__ int scan_slot(int i) { return i + (i >> 5); }
 
 // One round: the sums of elements [pos, pos + 64 NW R) as long as cum stays in its binade.  Short
 // windows run on 4 waves -- one per SIMD; the other waves only keep the barriers company.
-template <int R, int NW>
-__device__ __forceinline__ void scan_round(const ToppParams& p, ScanShared& sh, int m, int par) {
+template <int R, int NW, int CAP>
+__device__ __forceinline__ void scan_round(const ToppParams& p, ScanSharedT<CAP>& sh, int m, int par) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const ScanState st = sh.st[par];
     const int pos = st.pos;
@@ -684,7 +686,7 @@ __device__ __forceinline__ void scan_round(const ToppParams& p, ScanShared& sh, 
 #pragma unroll
         for (int k = 0; k < R; k++) {
             const int i = i0 + k;
-            const float pk = sh.x[scan_slot(min(i, 32767))];       // no branch around the read
+            const float pk = sh.x[scan_slot(min(i, CAP - 1))];       // no branch around the read
             e[k] = elem_of(i < m ? pk : 0.0f, invU);
             x0 = elem_apply(x0, e[k]);
             x1 = elem_apply(x1, e[k]);
@@ -751,8 +753,9 @@ __device__ __forceinline__ void scan_round(const ToppParams& p, ScanShared& sh, 
     __syncthreads();
 }
 
-__global__ __launch_bounds__(1024) void topp_pick_scan_kernel(ToppParams p, ArgmaxParams fin) {
-    __shared__ ScanShared sh;
+// the pick of one workgroup for a list of at most CAP entries (the launch below; topp_pick.hpp takes it for short lists)
+template <int CAP>
+__device__ __forceinline__ void topp_pick_scan_body(const ToppParams& p, const ArgmaxParams& fin, ScanSharedT<CAP>& sh) {
     const int tid = threadIdx.x;
     int cpos = 0, n_forced = 0, n_out = 0, forced_tok = -1;
     if (fin.ctl && tid == 0) {
@@ -760,13 +763,13 @@ __global__ __launch_bounds__(1024) void topp_pick_scan_kernel(ToppParams p, Argm
         if (cpos < n_forced) forced_tok = fin.forced[cpos];
     }
     TOPP_STAMP(16);
-    const int m = min(*p.m, 32768);
+    const int m = min(*p.m, CAP);
     {
-        float v[32];
+        float v[CAP / 1024];
 #pragma unroll
-        for (int j = 0; j < 32; j++) { const int i = j * 1024 + tid; v[j] = i < m ? p.keys[i] : 0.0f; }
+        for (int j = 0; j < CAP / 1024; j++) { const int i = j * 1024 + tid; v[j] = i < m ? p.keys[i] : 0.0f; }
 #pragma unroll
-        for (int j = 0; j < 32; j++) { const int i = j * 1024 + tid; sh.x[scan_slot(i)] = v[j]; }       // zeros behind the list
+        for (int j = 0; j < CAP / 1024; j++) { const int i = j * 1024 + tid; sh.x[scan_slot(i)] = v[j]; }       // zeros behind the list
     }
     __syncthreads();
     TOPP_STAMP(17);
@@ -797,12 +800,12 @@ __global__ __launch_bounds__(1024) void topp_pick_scan_kernel(ToppParams p, Argm
         const ScanState st = sh.st[par];
         if (st.done || st.pos >= m) break;                         // uniform
         const int want = min(st.pos, m - st.pos);                  // binades double in length; never beyond the list
-        if (want <= 1024) scan_round<4, 4>(p, sh, m, par);
-        else if (want <= 2048) scan_round<8, 4>(p, sh, m, par);
-        else if (want <= 4096) scan_round<4, 16>(p, sh, m, par);
-        else if (want <= 8192) scan_round<8, 16>(p, sh, m, par);
-        else if (want <= 16384) scan_round<16, 16>(p, sh, m, par);
-        else scan_round<kScanRun, 16>(p, sh, m, par);
+        if (want <= 1024) scan_round<4, 4, CAP>(p, sh, m, par);
+        else if (want <= 2048) scan_round<8, 4, CAP>(p, sh, m, par);
+        else if (want <= 4096) scan_round<4, 16, CAP>(p, sh, m, par);
+        else if (want <= 8192) scan_round<8, 16, CAP>(p, sh, m, par);
+        else if (want <= 16384) scan_round<16, 16, CAP>(p, sh, m, par);
+        else scan_round<kScanRun, 16, CAP>(p, sh, m, par);
         TOPP_STAMP(24 + min(rounds, 30));
         par ^= 1; rounds++;
     }
@@ -823,6 +826,10 @@ __global__ __launch_bounds__(1024) void topp_pick_scan_kernel(ToppParams p, Argm
     gather_next_embedding(fin, &sh.next);
     TOPP_STAMP(20);
     (void)rounds;
+}
+__global__ __launch_bounds__(1024) void topp_pick_scan_kernel(ToppParams p, ArgmaxParams fin) {
+    __shared__ ScanShared sh;
+    topp_pick_scan_body(p, fin, sh);
 }
 
 }  // namespace rama

@@ -109,7 +109,8 @@ int main(int argc, char** argv) {
             int hr2; CK(hipMemcpy(&hr2, result, 4, hipMemcpyDeviceToHost));
             const double ta = time_us(st, reps, [&] { k1p(); k2a(); }) - time_us(st, reps, k1p), tb = time_us(st, reps, k2b), tall4 = time_us(st, reps, [&] { k1p(); k2a(); k2b(); k3(); });
             printf("   ranking by pairs: pairs %.1f us (behind the block sort), scatter %.1f us, all four %.1f us (token %d)\n", ta, tb, tall4, hr2);
-            small_blocks<1024, 1>(st, reps, sq, tp, fin, n, k3, result);
+            small_blocks<1024, 2>(st, reps, sq, tp, fin, n, k3, result);
+            if (getenv("TOPP_BENCH_SWEEP")) { small_blocks<1024, 1>(st, reps, sq, tp, fin, n, k3, result); small_blocks<1024, 4>(st, reps, sq, tp, fin, n, k3, result); small_blocks<512, 1>(st, reps, sq, tp, fin, n, k3, result); small_blocks<512, 2>(st, reps, sq, tp, fin, n, k3, result); }
             CK(hipFree(racc));
         }
     }
