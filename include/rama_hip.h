@@ -372,13 +372,22 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *                   top of its kernels; 4 steps per graph: +5.3 % tokens/s at stories15M, +1.4 % at 110M, +0.1 % at
  *                   llama2-7B; 8 and more are slower again.  -1 (default): 4 for dim <= 1024, else 1
  *   "topp_sort" = 0|1 : ordering step of the top-p sampler for vocabularies <= 32768: 1 (default) = block sorts in
- *                   LDS + ranks by binary search with all sorted blocks in one workgroup's LDS (csrc/topp_sort.hpp);
+ *                   LDS + ranks by binary searches in the other sorted blocks staged in LDS (csrc/topp_sort.hpp);
  *                   0 = the ranks through global memory (topp_rank_global_kernel) and the staged lane ripple for the
  *                   sums -- what larger vocabularies always take.  Same token either way; no library kernel in either.
  *   "topp_pairs" = 0|1 : how the sorted blocks are merged into one order (vocabularies <= 32768): 1 (default) = one workgroup
- *                   per (block, block) pair, every entry of a block does ONE binary search in the other block and adds the
- *                   count to its accumulator, then a scatter launch (5.8 + 2.6 us on 32 000 flat logits); 0 = round 3's
+ *                   per (block, blocks) pair, every entry of a block does ONE binary search in each other block and adds the
+ *                   count (and the mass in front of that place) to its accumulator, then a scatter launch; 0 = round 3's
  *                   launch, every workgroup searching all 15 other blocks in its own LDS (23.1 us: 32 CUs, LDS-conflict-bound)
+ *   "topp_block" = 1024|512|2048 : entries per sorted block on the pair-ranking path.  1024 (default) / 512: the softmax
+ *                   statistics once (a launch of its own, one partial per 1024 logits), block sorts on 8 / 4 waves with the
+ *                   in-wave stages by DPP moves and lane swaps, every block's running mass as a 48-bit fixed-point sum;
+ *                   2048 = round 3's block sort (every workgroup repeats the statistics), without masses
+ *   "topp_dist" = 0|1 : the running sums of the sorted probabilities (blocks of 1024 / 512 only): 1 (default) = by up to 32
+ *                   workgroups in one launch (csrc/topp_pick.hpp: binades predicted from the exact mass in front of every
+ *                   entry, integer maps, a lane ripple over the chunks' items; lists up to 8192 entries are left to one
+ *                   workgroup); 0 = one workgroup's scan rounds, one per binade (round 2).  Same sums bit for bit.
+ *                   32 000 flat logits: 37 us per token (r3: 81), 109 kept entries: 17 us (26) -- profiles/r04_sampler_bench.json
  *   "topp_keep_sums" = 0|1 : 1 makes the top-p sampler also store its running sums in device scratch (tests)
  *   "ref_order" = 0|1|2 : 0 (default) = the fast path (fused multiply-adds, tree-shaped sums), which differs from the
  *                   CPU path by the CPU path's own rounding error (1.5e-4 in llama2-7B logits over 200 positions).
