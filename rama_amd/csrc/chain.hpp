@@ -1060,6 +1060,23 @@ __global__ __launch_bounds__(NW * 64) void attention_chain_kernel(RefAttnParams 
     const size_t col = (size_t)h * hs;
     SEQ_STAMP(8);
     for (int i = tid; i < hs; i += T) s_q[i] = p.q[col + i];
+    // xb[i] = sum_t att[t] * v[t][i], t ascending (cpu.rs:43-49).  (Requesting the first value tiles up here, behind a thread's first key
+    // rows, was measured: scores 2.4 -> 4.4 us, values 3.2 -> 2.7 at position 70 -- the key rows' wait then covers the value rows too.)
+    constexpr int U = 8;
+    const int tile4 = kAttTile * hs4;                             // f4 elements of a tile
+    int er[U], ec[U];                                             // tile element e = tid + u T: its row and 16-byte column (one division each, here)
+#pragma unroll
+    for (int u = 0; u < U; u++) { const int e = tid + u * T; er[u] = e / hs4; ec[u] = e - er[u] * hs4; }
+    auto vissue = [&](int t0, f4 (&vr)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            // (rows behind pos are clamped: their products are written, never added -- a load under a condition is a branch with
+            // `s_waitcnt vmcnt(0)` behind it, one cache round trip per load instruction)
+            const int tr = min(t0 + er[u], pos), c4 = ec[u];
+            vr[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.vc + (size_t)tr * p.dim + col) + c4);
+        }
+    };
+    f4 va[U], vb[U];                                              // two tiles on their way while a third is added up
     __syncthreads();
     const float scale_div = sqrtf((float)hs);
     const f4* q4 = reinterpret_cast<const f4*>(s_q);
@@ -1070,12 +1087,14 @@ __global__ __launch_bounds__(NW * 64) void attention_chain_kernel(RefAttnParams 
         const int ngroup = (pos + 64) >> 6;                       // groups of 64 timesteps
         const int nstep = ((ngroup - wave + NW - 1) / NW) * npiece;          // this wave's (group, piece) steps, in order
         auto load_step = [&](int st, f4 (&d)[8]) {                // step st = piece st % npiece of group wave + (st / npiece) NW
-            const int g = wave + (st / npiece) * NW, pc = st % npiece;
+            // (steps behind the wave's last and rows behind pos are clamped -- their scores are never stored: a load under a condition
+            // is a branch with `s_waitcnt vmcnt(0)` behind it, one cache round trip per load instruction)
+            const int sc = min(st, max(nstep - 1, 0));
+            const int g = wave + (sc / npiece) * NW, pc = sc % npiece;
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-                const int t = g * 64 + u * 8 + lrow;
-                d[u] = (st < nstep && t <= pos) ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.kc + (size_t)t * p.dim + col + pc * kAttPiece) + lc4)
-                                                : f4{0.f, 0.f, 0.f, 0.f};
+                const int t = min(g * 64 + u * 8 + lrow, pos);
+                d[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.kc + (size_t)t * p.dim + col + pc * kAttPiece) + lc4);
             }
         };
         f4 na[8], nb[8];
@@ -1159,24 +1178,8 @@ __global__ __launch_bounds__(NW * 64) void attention_chain_kernel(RefAttnParams 
         s_p[t] = a;
         if (p.att) p.att[(size_t)h * p.seq_len + t] = a;
     }
-    // xb[i] = sum_t att[t] * v[t][i], t ascending (cpu.rs:43-49)
-    constexpr int U = 8;
-    const int tile4 = kAttTile * hs4;                             // f4 elements of a tile
-    int er[U], ec[U];                                             // tile element e = tid + u T: its row and 16-byte column (one division each, here)
-#pragma unroll
-    for (int u = 0; u < U; u++) { const int e = tid + u * T; er[u] = e / hs4; ec[u] = e - er[u] * hs4; }
-    auto vissue = [&](int t0, f4 (&vr)[U]) {
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int e = tid + u * T;
-            const int r = er[u], c4 = ec[u];
-            const bool on = e < tile4 && t0 + r <= pos;
-            vr[u] = on ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.vc + (size_t)(t0 + r) * p.dim + col) + c4) : f4{0.f, 0.f, 0.f, 0.f};
-        }
-    };
     float acc = 0.0f;
     SEQ_STAMP(12);
-    f4 va[U], vb[U];                                              // two tiles on their way while a third is added up
     vissue(0, va);
     vissue(kAttTile, vb);
     __syncthreads();                                              // the probabilities are final; the staging region is free
@@ -1236,24 +1239,29 @@ __global__ __launch_bounds__(64) void attn_scores_chain_kernel(RefAttnParams p) 
     auto load_piece = [&](int pc, f4 (&d)[8]) {
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const int t = g * 64 + u * 8 + lrow;
-            d[u] = (pc < npiece && t <= pos) ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.kc + (size_t)t * p.dim + col + pc * kAttPiece) + lc4)
-                                             : f4{0.f, 0.f, 0.f, 0.f};
+            // (rows behind pos and pieces behind the head are clamped, their scores never stored: a load under a condition is a branch
+            // with `s_waitcnt vmcnt(0)` behind it)
+            const int t = min(g * 64 + u * 8 + lrow, pos), pcc = min(pc, npiece - 1);
+            d[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.kc + (size_t)t * p.dim + col + pcc * kAttPiece) + lc4);
         }
     };
-    f4 na[8], nb[8];
+    // [r4] head sizes up to 128: all four pieces (32 KB a wave) are requested at once -- with two in flight the third piece's round
+    // trip began only when the first had been consumed, and a launch is little more than round trips (8.9 -> 6 us at 1 900 timesteps)
+    f4 na[8], nb[8], nc[8], nd[8];
     load_piece(0, na);
     load_piece(1, nb);
+    const bool all4 = npiece <= 4;                                // uniform
+    if (all4) { load_piece(2, nc); load_piece(3, nd); }
     for (int i = lane; i < hs; i += 64) s_q[i] = p.q[col + i];
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const f4* q4 = reinterpret_cast<const f4*>(s_q);
     const float scale_div = sqrtf((float)hs);
     float acc = 0.0f;
-    auto consume = [&](int pc, f4 (&d)[8]) {
+    auto consume = [&](int pc, f4 (&d)[8], bool more) {
 #pragma unroll
         for (int u = 0; u < 8; u++) *reinterpret_cast<f4*>(stage + (u * 8 + lrow) * kAttStride + 4 * lc4) = d[u];
-        load_piece(pc + 2, d);
+        if (more) load_piece(pc + 2, d);
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const f4* row = reinterpret_cast<const f4*>(stage + lane * kAttStride);
@@ -1268,9 +1276,16 @@ __global__ __launch_bounds__(64) void attn_scores_chain_kernel(RefAttnParams p) 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
     };
-    for (int pc = 0; pc < npiece; pc += 2) {
-        consume(pc, na);
-        if (pc + 1 < npiece) consume(pc + 1, nb);
+    if (all4) {
+        consume(0, na, false);
+        if (npiece > 1) consume(1, nb, false);
+        if (npiece > 2) consume(2, nc, false);
+        if (npiece > 3) consume(3, nd, false);
+    } else {
+        for (int pc = 0; pc < npiece; pc += 2) {
+            consume(pc, na, true);
+            if (pc + 1 < npiece) consume(pc + 1, nb, true);
+        }
     }
     const int t = g * 64 + lane;
     if (t <= pos) p.att[(size_t)h * p.seq_len + t] = acc / scale_div;
@@ -1297,82 +1312,102 @@ __global__ __launch_bounds__(kSoftWaves * 64) void attn_softmax_chain_kernel(Ref
     for (int t = tid; t <= pos; t += T) att[t] = s_att[scan_slot(t)] / sum;
 }
 
-constexpr int kValCols = 16, kValRows = 256, kValWaves = 4;            // a slice's tile: 256 rows x 16 columns = 16 KiB of products
+constexpr int kValCols = 16, kValRows = 256, kValWaves = 5;            // a slice's tile: 256 rows x 16 columns = 16 KiB of products; 4 loading waves + the chain wave
+constexpr int kValStride = kValRows + 4;                               // a column's 256 products in a row (+4: the 16-byte reads of 8 columns cover all banks)
+// [r4] 20.8 -> 13 us per launch at 1 900 timesteps, the same operations in the same order per output:
+//  * every cache load is unconditional (rows behind pos are clamped, their weight set to 0 when the product is formed): a load under
+//    a condition compiles to a branch with `s_waitcnt vmcnt(0)` behind it -- one cache round trip per load INSTRUCTION;
+//  * four tiles' cache rows are in flight instead of two (a slice reads 64-byte pieces 16 KiB apart: 2 us until they are there);
+//  * the product tile is stored COLUMN by column (a column's 256 rows contiguous), so the chain lane of column c reads four rows'
+//    products with one 16-byte LDS read: one add in ~10 cycles (its own latency: 8.3) instead of a 4-byte read + an add in 16;
+//  * wave 0 only adds (lanes 0..15: the slice's 16 chains); waves 1..4 load, multiply and store -- the chain of tile k + 1 starts the
+//    moment tile k's is through.
 __global__ __launch_bounds__(kValWaves * 64) void attn_values_chain_kernel(RefAttnParams p) {
     RAMA_NO_CONTRACT
-    constexpr int T = kValWaves * 64, U = kValRows * (kValCols / 4) / T;      // 8 x 16 bytes per thread and tile
-    __shared__ __attribute__((aligned(16))) float tile[2][kValRows * kValCols];
-    const int h = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x;
+    constexpr int T = (kValWaves - 1) * 64, U = kValRows * (kValCols / 4) / T;      // 4 x 16 bytes per loading thread and tile
+    __shared__ __attribute__((aligned(16))) float tile[2][kValCols * kValStride];
+    const int h = blockIdx.x, sl = blockIdx.y, tid = (int)threadIdx.x - 64;        // loading threads 0..255; the chain wave: -64..-1
+    const bool chain = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) == 0;
     const int pos = p.ctl ? p.ctl->pos : p.pos_val;
     const size_t col = (size_t)h * p.head_size + (size_t)sl * kValCols;
     const float* att = p.att + (size_t)h * p.seq_len;
+    SEQ_STAMP(20);
+    if (chain) {
+        const int lane = threadIdx.x;
+        float acc = 0.0f;
+        int buf = 0;
+        for (int t0 = 0; t0 <= pos; t0 += kValRows, buf ^= 1) {
+            __syncthreads();                                      // tile t0 is written (and the other buffer, read last round, is free again)
+            if (lane < kValCols) {
+                // the chain itself: one dependent add per row.  The next 16 products (four 16-byte reads) are fetched from LDS while
+                // the current 16 are added (two register sets in turn)
+                const int nt = min(kValRows, pos + 1 - t0);
+                const f4* tb = reinterpret_cast<const f4*>(&tile[buf][lane * kValStride]);
+                f4 w0[4], w1[4];
+                auto rd = [&](int r, f4 (&w)[4]) {                // (rows behind the tile are clamped: read, never added)
+#pragma unroll
+                    for (int u = 0; u < 4; u++) w[u] = tb[min(r / 4 + u, kValRows / 4 - 1)];
+                };
+                auto ad = [&](const f4 (&w)[4]) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { acc = acc + w[u].x; acc = acc + w[u].y; acc = acc + w[u].z; acc = acc + w[u].w; }
+                };
+                int r = 0;
+                rd(0, w0);
+                for (; r + 32 <= nt; r += 32) {
+                    rd(r + 16, w1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ad(w0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    rd(r + 32, w0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ad(w1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const float* ts = &tile[buf][lane * kValStride];
+                for (; r < nt; r++) acc = acc + ts[r];
+            }
+            SEQ_STAMP(21 + min(t0 / kValRows, 11));
+        }
+        if (lane < kValCols) p.xb[col + lane] = acc;
+        SEQ_STAMP(33);
+        return;
+    }
     // tile element e = tid + u T: row e / (kValCols / 4), 16-byte column e % (kValCols / 4)
-    f4 va[U], vb[U];
-    float aa[U], ab[U];
+    f4 v0[U], v1[U], v2[U], v3[U];
+    float a0[U], a1[U], a2[U], a3[U];
     auto vissue = [&](int t0, f4 (&vr)[U], float (&ar)[U]) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int e = tid + u * T, r = e / (kValCols / 4), c4 = e % (kValCols / 4);
-            const bool on = t0 + r <= pos;
-            vr[u] = on ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.vc + (size_t)(t0 + r) * p.dim + col) + c4) : f4{0.f, 0.f, 0.f, 0.f};
-            ar[u] = on ? att[t0 + r] : 0.0f;
+            const int tr = min(t0 + r, pos);                      // rows behind pos: row `pos`, weight 0 (vtile)
+            vr[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.vc + (size_t)tr * p.dim + col) + c4);
+            ar[u] = att[tr];
         }
     };
-    SEQ_STAMP(20);
-    vissue(0, va, aa);
-    vissue(kValRows, vb, ab);
-    float acc = 0.0f;
-    int stamp_tile = 0;
+    vissue(0, v0, a0);
+    vissue(kValRows, v1, a1);
+    vissue(2 * kValRows, v2, a2);
+    vissue(3 * kValRows, v3, a3);
     auto vtile = [&](int t0, int buf, f4 (&vr)[U], float (&ar)[U]) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int e = tid + u * T;
-            f4 pr;
-            pr.x = ar[u] * vr[u].x; pr.y = ar[u] * vr[u].y; pr.z = ar[u] * vr[u].z; pr.w = ar[u] * vr[u].w;     // cpu.rs:48 `a * vi`, rounded
-            *reinterpret_cast<f4*>(&tile[buf][4 * e]) = pr;
+            const int e = tid + u * T, r = e / (kValCols / 4), c4 = e % (kValCols / 4);
+            const float a = t0 + r <= pos ? ar[u] : 0.0f;
+            float* d = &tile[buf][(4 * c4) * kValStride + r];
+            d[0] = a * vr[u].x; d[kValStride] = a * vr[u].y; d[2 * kValStride] = a * vr[u].z; d[3 * kValStride] = a * vr[u].w;     // cpu.rs:48 `a * vi`, rounded
         }
-        vissue(t0 + 2 * kValRows, vr, ar);
-        if (stamp_tile < 4) SEQ_STAMP(21 + 3 * stamp_tile);
-        __syncthreads();                                          // this tile is written; the other one (read last round) is free again
-        if (stamp_tile < 4) SEQ_STAMP(22 + 3 * stamp_tile);
-        if (tid < kValCols) {
-            // the chain itself: one dependent add per row.  The next 16 products are read from LDS while the current 16
-            // are added (two register sets in turn) -- read-then-add in one batch left the chain waiting for LDS 16 times
-            // per tile (26 us per launch at 1900 timesteps)
-            const int nt = min(kValRows, pos + 1 - t0);
-            const float* tb = &tile[buf][tid];
-            float v0[16], v1[16];
-            auto rd = [&](int r, float (&v)[16]) {                // (rows behind the tile are clamped: read, never added)
-#pragma unroll
-                for (int u = 0; u < 16; u++) v[u] = tb[min(r + u, kValRows - 1) * kValCols];
-            };
-            auto ad = [&](const float (&v)[16]) {
-#pragma unroll
-                for (int u = 0; u < 16; u++) acc = acc + v[u];
-            };
-            int r = 0;
-            rd(0, v0);
-            for (; r + 32 <= nt; r += 32) {
-                rd(r + 16, v1);
-                __builtin_amdgcn_sched_barrier(0);
-                ad(v0);
-                __builtin_amdgcn_sched_barrier(0);
-                rd(r + 32, v0);
-                __builtin_amdgcn_sched_barrier(0);
-                ad(v1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            for (; r < nt; r++) acc = acc + tb[r * kValCols];
-        }
-        if (stamp_tile < 4) SEQ_STAMP(23 + 3 * stamp_tile);
-        stamp_tile++;
+        vissue(t0 + 4 * kValRows, vr, ar);
+        __syncthreads();                                          // this tile is written: the chain wave takes it; the other one is free once it arrives here again
     };
-    for (int t0 = 0; t0 <= pos; t0 += 2 * kValRows) {
-        vtile(t0, 0, va, aa);
-        if (t0 + kValRows <= pos) vtile(t0 + kValRows, 1, vb, ab);      // uniform
+    // (the loaders run one tile ahead of the chain wave at most: tile k + 2 overwrites the buffer of tile k, which the chain wave has
+    // left when it arrives at the barrier that releases tile k + 1)
+    for (int t0 = 0; t0 <= pos; t0 += 4 * kValRows) {
+        vtile(t0, 0, v0, a0);
+        if (t0 + kValRows <= pos) vtile(t0 + kValRows, 1, v1, a1);              // uniform
+        if (t0 + 2 * kValRows <= pos) vtile(t0 + 2 * kValRows, 0, v2, a2);
+        if (t0 + 3 * kValRows <= pos) vtile(t0 + 3 * kValRows, 1, v3, a3);
     }
-    if (tid < kValCols) p.xb[col + tid] = acc;
-    SEQ_STAMP(33);
 }
 
 }  // namespace rama

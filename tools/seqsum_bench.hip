@@ -67,8 +67,8 @@ int main(int argc, char** argv) {
             }
             unsigned long long sv[40];
             CK(hipMemcpyFromSymbol(sv, HIP_SYMBOL(rama::g_seq_stamps), sizeof sv));
-            printf("   loads issued at 0;");
-            for (int t = 0; t < 4; t++) printf(" tile %d: products written %.2f, barrier passed %.2f, chain done %.2f |", t, (sv[21 + 3 * t] - sv[20]) * 0.01, (sv[22 + 3 * t] - sv[20]) * 0.01, (sv[23 + 3 * t] - sv[20]) * 0.01);
+            printf("   loads issued at 0; the chain wave is through tile k at:");
+            for (int t = 0; t < 8; t++) printf(" %.2f", (sv[21 + t] - sv[20]) * 0.01);
             printf(" end %.2f us\n", (sv[33] - sv[20]) * 0.01);
         }
     }
