@@ -1410,4 +1410,114 @@ __global__ __launch_bounds__(kValWaves * 64) void attn_values_chain_kernel(RefAt
     }
 }
 
+// [r4] The softmax and the value chains of long contexts as ONE launch: grid (heads x slices of 16 columns), 4 waves.  Every slice
+// workgroup of a head repeats the head's softmax (max, glibc expf, the exact sequential sum: ~5 us of LDS work, the same bits in all 8
+// of them) while its first four tiles of value rows are on their way -- the launch between (3 us), the round trip of the
+// probabilities through memory and the value launch's 2.8 us until its first tile is there fall away; the weights are read from
+// LDS.  Then as attn_values_chain_kernel: wave 0 adds (lanes 0..15), waves 1..3 load, multiply and store tiles of 192 rows.
+constexpr int kFvRows = 192, kFvStride = kFvRows + 4, kFvWaves = 4;
+__host__ __device__ constexpr size_t attn_fused_values_lds_floats(int seq_len) { return (size_t)seq_len + ((size_t)seq_len >> 5) + 4 + (((size_t)seq_len + 3) & ~(size_t)3); }
+__global__ __launch_bounds__(kFvWaves * 64) void attn_softmax_values_chain_kernel(RefAttnParams p) {
+    RAMA_NO_CONTRACT
+    constexpr int TS = kFvWaves * 64;                              // softmax: all four waves
+    constexpr int T = (kFvWaves - 1) * 64, U = kFvRows * (kValCols / 4) / T;      // products: 4 x 16 bytes per loading thread and tile
+    extern __shared__ __attribute__((aligned(16))) float fv_sm[];
+    __shared__ __attribute__((aligned(16))) float tile[2][kValCols * kFvStride];
+    __shared__ SeqSumShared<kFvWaves> sh;
+    __shared__ PredShared<kFvWaves> ps;
+    __shared__ float red[16];
+    float* s_att = fv_sm;                                          // [scan_slot(seq_len)] scores -> exponentials
+    float* s_p = fv_sm + p.seq_len + (p.seq_len >> 5) + 4;         // [seq_len] the probabilities, unskewed
+    const int h = blockIdx.x, sl = blockIdx.y, tid0 = threadIdx.x, tid = (int)threadIdx.x - 64;      // loading threads 0..191; the chain wave: -64..-1
+    const bool chain = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) == 0;
+    const int pos = p.ctl ? p.ctl->pos : p.pos_val;
+    const size_t col = (size_t)h * p.head_size + (size_t)sl * kValCols;
+    float* att = p.att + (size_t)h * p.seq_len;
+    // the scores first (their wait then leaves the value rows outstanding), then four tiles of value rows
+    constexpr int kSc = 8;                                         // scores per thread and round
+    float sc[kSc];
+#pragma unroll
+    for (int k = 0; k < kSc; k++) sc[k] = att[min(tid0 + k * TS, pos)];
+    f4 v0[U], v1[U], v2[U], v3[U];
+    auto vissue = [&](int t0, f4 (&vr)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int e = max(tid, 0) + u * T, r = e / (kValCols / 4), c4 = e % (kValCols / 4);
+            const int tr = min(t0 + r, pos);                      // rows behind pos: row `pos`, weight 0 (vtile)
+            vr[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.vc + (size_t)tr * p.dim + col) + c4);
+        }
+    };
+    if (!chain) { vissue(0, v0); vissue(kFvRows, v1); vissue(2 * kFvRows, v2); vissue(3 * kFvRows, v3); }     // uniform per wave
+    // softmax_num (cpu.rs:187-192), as attn_softmax_chain_kernel
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < kSc; k++) { const int t = tid0 + k * TS; if (t <= pos) { s_att[scan_slot(t)] = sc[k]; mx = fmaxf(mx, sc[k]); } }
+    for (int t = tid0 + kSc * TS; t <= pos; t += TS) { const float a = att[t]; s_att[scan_slot(t)] = a; mx = fmaxf(mx, a); }
+    mx = block_max(mx, red);
+    for (int t = tid0; t <= pos; t += TS) s_att[scan_slot(t)] = expf_glibc(s_att[scan_slot(t)] - mx);
+    __syncthreads();
+    float sum;
+    if (!seq_sum_predict<kFvWaves>(s_att, pos + 1, ps, &sum)) sum = seq_sum_exact<kFvWaves>(s_att, pos + 1, sh);
+    for (int t = tid0; t <= pos; t += TS) {
+        const float a = s_att[scan_slot(t)] / sum;
+        s_p[t] = a;
+        if (sl == 0) att[t] = a;                                   // the probabilities as the launches before this one left them (tests read them)
+    }
+    __syncthreads();
+    if (chain) {
+        const int lane = threadIdx.x;
+        float acc = 0.0f;
+        int buf = 0;
+        for (int t0 = 0; t0 <= pos; t0 += kFvRows, buf ^= 1) {
+            __syncthreads();                                      // tile t0 is written (and the other buffer, read last round, is free again)
+            if (lane < kValCols) {
+                const int nt = min(kFvRows, pos + 1 - t0);
+                const f4* tb = reinterpret_cast<const f4*>(&tile[buf][lane * kFvStride]);
+                f4 w0[4], w1[4];
+                auto rd = [&](int r, f4 (&w)[4]) {                // (rows behind the tile are clamped: read, never added)
+#pragma unroll
+                    for (int u = 0; u < 4; u++) w[u] = tb[min(r / 4 + u, kFvRows / 4 - 1)];
+                };
+                auto ad = [&](const f4 (&w)[4]) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { acc = acc + w[u].x; acc = acc + w[u].y; acc = acc + w[u].z; acc = acc + w[u].w; }
+                };
+                int r = 0;
+                rd(0, w0);
+                for (; r + 32 <= nt; r += 32) {
+                    rd(r + 16, w1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ad(w0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    rd(r + 32, w0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ad(w1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const float* ts = &tile[buf][lane * kFvStride];
+                for (; r < nt; r++) acc = acc + ts[r];
+            }
+        }
+        if (lane < kValCols) p.xb[col + lane] = acc;
+        return;
+    }
+    auto vtile = [&](int t0, int buf, f4 (&vr)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int e = tid + u * T, r = e / (kValCols / 4), c4 = e % (kValCols / 4);
+            const float a = t0 + r <= pos ? s_p[min(t0 + r, pos)] : 0.0f;
+            float* d = &tile[buf][(4 * c4) * kFvStride + r];
+            d[0] = a * vr[u].x; d[kFvStride] = a * vr[u].y; d[2 * kFvStride] = a * vr[u].z; d[3 * kFvStride] = a * vr[u].w;     // cpu.rs:48 `a * vi`, rounded
+        }
+        vissue(t0 + 4 * kFvRows, vr);
+        __syncthreads();                                          // this tile is written: the chain wave takes it
+    };
+    for (int t0 = 0; t0 <= pos; t0 += 4 * kFvRows) {
+        vtile(t0, 0, v0);
+        if (t0 + kFvRows <= pos) vtile(t0 + kFvRows, 1, v1);                    // uniform
+        if (t0 + 2 * kFvRows <= pos) vtile(t0 + 2 * kFvRows, 0, v2);
+        if (t0 + 3 * kFvRows <= pos) vtile(t0 + 3 * kFvRows, 1, v3);
+    }
+}
+
 }  // namespace rama

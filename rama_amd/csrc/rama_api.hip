@@ -117,6 +117,7 @@ struct rama_ctx {
     unsigned long long* topp_bm = nullptr;  // ... the blocks' running masses
     float* topp_approx = nullptr;           // ... the mass in front of every entry of the whole order
     void* topp_dist = nullptr;              // topp_pick_dist_kernel's hand-off words: items | hdr | cross | epoch | bad
+    int tune_attn_fv = 1;                   // parity mode, long contexts: softmax + value chains as one launch (0: two launches)
     int tune_topp_dist = 1;                 // 1: the running sums by up to 32 workgroups in one launch (topp_pick.hpp); 0: one workgroup's scan rounds
     ToppStats* topp_stats = nullptr;        // small-block path: partial softmax statistics, one per 1024 logits
     int tune_topp_block = 1024;             // entries per sorted block on the pair-ranking path: 1024 or 512 (statistics once + 8- / 4-wave sorts) or 2048 (round 3's block sort)
@@ -596,6 +597,12 @@ static int launch_attention_chain(rama_ctx* c, float* xb, float* att, const floa
         const int ngroups = (seq_len + 63) / 64;
         RAMA_LAUNCH(c, attn_scores_chain_kernel, dim3(n_heads, ngroups), dim3(64), 0, p);
         LAUNCHCHK();
+        const size_t fv_lds = attn_fused_values_lds_floats(seq_len) * sizeof(float);
+        if (c->tune_attn_fv && fv_lds <= 32 * 1024) {             // the softmax repeated by every slice workgroup, one launch (chain.hpp [r4])
+            hipLaunchKernelGGL(attn_softmax_values_chain_kernel, dim3(n_heads, head_size / kValCols), dim3(kFvWaves * 64), fv_lds, c->stream, p);
+            LAUNCHCHK();
+            return 0;
+        }
         hipLaunchKernelGGL(attn_softmax_chain_kernel, dim3(n_heads), dim3(kSoftWaves * 64), ((size_t)seq_len + ((size_t)seq_len >> 5) + 4) * sizeof(float), c->stream, p);
         LAUNCHCHK();
         hipLaunchKernelGGL(attn_values_chain_kernel, dim3(n_heads, head_size / kValCols), dim3(kValWaves * 64), 0, c->stream, p);
@@ -2540,6 +2547,13 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
     if (!strcmp(key, "topp_block")) {
         REQUIRE(value == 512 || value == 1024 || value == 2048, RAMA_EINVAL, "set_tuning: topp_block must be 512, 1024 or 2048");
         c->tune_topp_block = value;
+        hipStreamSynchronize(c->stream);
+        drop_graph(c);
+        return 0;
+    }
+    if (!strcmp(key, "attn_fv")) {
+        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: attn_fv must be 0 or 1");
+        c->tune_attn_fv = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
         return 0;
