@@ -51,7 +51,7 @@ static int fail(int code, const char* what, const char* file, int line) {
 
 constexpr int kSmallAttnPosDefault = 256;
 constexpr size_t kAttnChainMaxLds = 136 * 1024;      // dynamic LDS attention_chain_kernel may ask for (allowed once per device in rama_ctx_create)
-constexpr int kSpreadAttnPos = 1024;       // parity mode: from this position on attention is three launches spread over the chip (chain.hpp)
+constexpr int kSpreadAttnPos = 128;        // parity mode: from this position on the attention is two launches spread over the chip (chain.hpp; "spread_pos": 187 against 184 tok/s at positions 124..179, 178 against 152 at 800)
 constexpr int kLongAttnPos = 256;          // parity mode: attention_chain_kernel runs 16 waves per head from this position on
 
 struct KProf {
@@ -117,6 +117,7 @@ struct rama_ctx {
     unsigned long long* topp_bm = nullptr;  // ... the blocks' running masses
     float* topp_approx = nullptr;           // ... the mass in front of every entry of the whole order
     void* topp_dist = nullptr;              // topp_pick_dist_kernel's hand-off words: items | hdr | cross | epoch | bad
+    int tune_spread_pos = kSpreadAttnPos;   // parity mode: from this position on the attention is spread over the chip (scores | softmax + values)
     int tune_attn_fv = 1;                   // parity mode, long contexts: softmax + value chains as one launch (0: two launches)
     int tune_topp_dist = 1;                 // 1: the running sums by up to 32 workgroups in one launch (topp_pick.hpp); 0: one workgroup's scan rounds
     ToppStats* topp_stats = nullptr;        // small-block path: partial softmax statistics, one per 1024 logits
@@ -756,7 +757,7 @@ static bool small_attn_at(const rama_ctx* c, int pos, bool split, int dim) {
 // 1 = split-T (long contexts), 2 = fewer waves per head (short contexts); parity mode 0 = 4 waves per head, 1 = 8 (pos >= 256),
 // 2 = three launches spread over the chip (pos >= 1024)
 static int attn_variant(const rama_ctx* c, const rama_config* cfg, int pos) {
-    if (c->tune_ref_order && !c->tune_tol) return pos >= kSpreadAttnPos ? 2 : (pos >= kLongAttnPos ? 1 : 0);
+    if (c->tune_ref_order && !c->tune_tol) return pos >= c->tune_spread_pos ? 2 : (pos >= kLongAttnPos ? 1 : 0);
     const bool split = pos >= split_threshold(c, cfg);
     return split ? 1 : (small_attn_at(c, pos, split, cfg->dim) ? 2 : 0);
 }
@@ -764,7 +765,7 @@ static int apply_attn_variant(rama_ctx* c, const rama_config* cfg, int pos) {
     c->split_attn = pos >= split_threshold(c, cfg);
     c->small_attn = small_attn_at(c, pos, c->split_attn, cfg->dim);
     c->long_attn = pos >= kLongAttnPos;
-    c->spread_attn = pos >= kSpreadAttnPos;
+    c->spread_attn = pos >= c->tune_spread_pos;
     return c->variant = attn_variant(c, cfg, pos);
 }
 
@@ -845,7 +846,7 @@ int rama_multi_head_attention(rama_ctx* c, float* xb, float* att, const float* q
     REQUIRE(pos >= 0 && pos < seq_len && layer >= 0 && n_heads > 0 && n_heads * head_size == dim, RAMA_EINVAL, "multi_head_attention: bad shape");
     const size_t lo = (size_t)layer * seq_len * dim;   // cpu.rs:28
     if (c->tune_ref_order && c->tune_chain && attn_chain_ok(head_size, seq_len) && aligned16(q) && aligned16(key_cache + lo) && aligned16(value_cache + lo) && dim % 4 == 0)
-        return launch_attention_chain(c, xb, att, q, key_cache + lo, value_cache + lo, nullptr, pos, dim, head_size, seq_len, n_heads, pos >= kLongAttnPos, pos >= kSpreadAttnPos);
+        return launch_attention_chain(c, xb, att, q, key_cache + lo, value_cache + lo, nullptr, pos, dim, head_size, seq_len, n_heads, pos >= kLongAttnPos, pos >= c->tune_spread_pos);
     if (c->tune_ref_order) return launch_attention_ref(c, xb, att, q, key_cache + lo, value_cache + lo, nullptr, pos, dim, head_size, seq_len, n_heads);
     c->small_attn = small_attn_at(c, pos, false, dim);
     return launch_attention(c, xb, att, q, key_cache + lo, value_cache + lo, nullptr, pos, dim, head_size, seq_len, n_heads);
@@ -2547,6 +2548,13 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
     if (!strcmp(key, "topp_block")) {
         REQUIRE(value == 512 || value == 1024 || value == 2048, RAMA_EINVAL, "set_tuning: topp_block must be 512, 1024 or 2048");
         c->tune_topp_block = value;
+        hipStreamSynchronize(c->stream);
+        drop_graph(c);
+        return 0;
+    }
+    if (!strcmp(key, "spread_pos")) {
+        REQUIRE(value >= 64 && value <= (1 << 20), RAMA_EINVAL, "set_tuning: spread_pos must be 64 .. 2^20");
+        c->tune_spread_pos = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
         return 0;
