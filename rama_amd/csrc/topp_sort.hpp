@@ -281,8 +281,9 @@ __global__ __launch_bounds__(BS / 2) void topp_blocksort_bs_kernel(ToppSortParam
     // the whole vector's maximum and sum of exponentials from the partial ones, in index order (every workgroup: the same bits)
     // (one partial per lane, nstat <= 64: one load, then the wave trees -- a loop over them is 2 nstat dependent L2 round trips, 12 us)
     const int lane = tid & 63;
-    const ToppStats part = lane < nstat ? st[lane] : ToppStats{-INFINITY, 0.0f};
-    const float mx = wave_max(part.mx);
+    const float lg[2] = {p.logits[min((int)blockIdx.x * BS + tid, p.n - 1)], p.logits[min((int)blockIdx.x * BS + NT + tid, p.n - 1)]};       // (requested with the statistics)
+    const ToppStats part = st[min(lane, nstat - 1)];
+    const float mx = wave_max(part.mx);                            // (lanes behind the last partial repeat it: the maximum does not mind)
     const float sum = wave_sum(lane < nstat ? part.sum * expf(part.mx - mx) : 0.0f);
     const float cutoff = (1.0f - p.topp) / (float)(p.n - 1);      // infer.rs:56
     const int base = blockIdx.x * BS;
@@ -290,13 +291,11 @@ __global__ __launch_bounds__(BS / 2) void topp_blocksort_bs_kernel(ToppSortParam
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         const int i = base + h * NT + tid;
-        if (i < p.n) {
-            const float v = p.logits[i];
-            const float pr = expf((scale ? v / p.temperature : v) - mx) / sum;
-            if (pr > cutoff) {
-                const int slot = atomicAdd(&s_n, 1);
-                s_k[0][slot] = ((unsigned long long)__float_as_uint(pr) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
-            }
+        const float v = lg[h];
+        const float pr = expf((scale ? v / p.temperature : v) - mx) / sum;
+        if (i < p.n && pr > cutoff) {
+            const int slot = atomicAdd(&s_n, 1);
+            s_k[0][slot] = ((unsigned long long)__float_as_uint(pr) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
         }
     }
     __syncthreads();
@@ -377,24 +376,25 @@ __global__ __launch_bounds__(BS / 2) void topp_rank_pairs_bs_kernel(ToppSortPara
 #pragma unroll
     for (int q = 0; q < OB; q++) { const int o = o0 + q; co[q] = (o < p.nblk && o != b) ? p.bcount[o] : 0; most = max(most, co[q]); }
     if (most == 0) return;                                         // uniform
-    const unsigned k0 = tid < cb ? __float_as_uint(p.bp[(size_t)b * BS + tid]) : 0u;
-    const unsigned k1 = tid + NT < cb ? __float_as_uint(p.bp[(size_t)b * BS + NT + tid]) : 0u;
+    // every slot of bp / bm exists (nblk x BS): all loads go out unconditionally and what lies behind a block's count is zeroed
+    // afterwards -- `cond ? load : 0` is a branch with s_waitcnt vmcnt(0) behind it, one cache round trip per load instruction
+    const unsigned k0r = __float_as_uint(p.bp[(size_t)b * BS + tid]), k1r = __float_as_uint(p.bp[(size_t)b * BS + NT + tid]);
     {
         unsigned v[2 * OB];
         unsigned long long f[2 * OB];
 #pragma unroll
         for (int q = 0; q < OB; q++) {
-            v[2 * q] = tid < co[q] ? __float_as_uint(p.bp[(size_t)(o0 + q) * BS + tid]) : 0u;
-            v[2 * q + 1] = tid + NT < co[q] ? __float_as_uint(p.bp[(size_t)(o0 + q) * BS + NT + tid]) : 0u;
-            f[2 * q] = tid < co[q] ? p.bm[(size_t)(o0 + q) * BS + tid] : 0ull;
-            f[2 * q + 1] = tid + NT < co[q] ? p.bm[(size_t)(o0 + q) * BS + NT + tid] : 0ull;
+            const size_t ob = (size_t)min(o0 + q, p.nblk - 1) * BS;
+            v[2 * q] = __float_as_uint(p.bp[ob + tid]); v[2 * q + 1] = __float_as_uint(p.bp[ob + NT + tid]);
+            f[2 * q] = p.bm[ob + tid]; f[2 * q + 1] = p.bm[ob + NT + tid];
         }
 #pragma unroll
         for (int q = 0; q < OB; q++) {
-            s_o[q * BS + tid] = v[2 * q]; s_o[q * BS + NT + tid] = v[2 * q + 1];
-            s_m[q * BS + tid] = f[2 * q]; s_m[q * BS + NT + tid] = f[2 * q + 1];
+            s_o[q * BS + tid] = tid < co[q] ? v[2 * q] : 0u; s_o[q * BS + NT + tid] = tid + NT < co[q] ? v[2 * q + 1] : 0u;
+            s_m[q * BS + tid] = tid < co[q] ? f[2 * q] : 0ull; s_m[q * BS + NT + tid] = tid + NT < co[q] ? f[2 * q + 1] : 0ull;
         }
     }
+    const unsigned k0 = tid < cb ? k0r : 0u, k1 = tid + NT < cb ? k1r : 0u;
     __syncthreads();
     int top = 1;
     while (top <= most) top <<= 1;                                 // uniform
@@ -434,12 +434,18 @@ __global__ __launch_bounds__(1024) void topp_rank_scatter_bs_kernel(ToppSortPara
         *p.m = total;
         if (total == 0 && p.err) *p.err = 1u;
     }
-    if (b >= p.nblk || s >= p.bcount[b]) return;
-    const unsigned long long acc = p.rk[(size_t)b * BS + s];
+    if (b >= p.nblk) return;
+    // (all five loads together: the count, the accumulator, the mass before the entry -- slot s - 1, clamped -- and the entry itself)
+    const size_t at = (size_t)b * BS + s;
+    const int cnt = p.bcount[b];
+    const unsigned long long acc = p.rk[at], before = p.bm[at - (at > 0 ? 1 : 0)];
+    const float pr = p.bp[at];
+    const int ix = p.bi[at];
+    if (s >= cnt) return;
     const int rank = s + (int)(acc >> kMassBits);
-    const unsigned long long mass = (acc & kMassMask) + (s > 0 ? p.bm[(size_t)b * BS + s - 1] : 0ull);
-    p.keys[rank] = p.bp[(size_t)b * BS + s];
-    p.vals[rank] = p.bi[(size_t)b * BS + s];
+    const unsigned long long mass = (acc & kMassMask) + (s > 0 ? before : 0ull);
+    p.keys[rank] = pr;
+    p.vals[rank] = ix;
     if (p.approx) p.approx[rank] = (float)mass * 0x1p-47f;
 }
 
