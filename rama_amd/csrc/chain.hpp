@@ -429,18 +429,14 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_chain_kernel(float* o, c
     SEQ_STAMP(0);
     const bool vec = n % 4 == 0 && ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)o | (uintptr_t)copy_to) & 15) == 0) && n <= 16 * kNormThreads;
     if (vec) {     // up to 4 x 16 bytes per thread, everything requested up front
+        // ([r4] really up front: the index is clamped instead of the load being conditional -- `i < n4 ? load : 0` is a branch with
+        // s_waitcnt vmcnt(0) behind it, eight cache round trips one after the other; what a lane past the end reads is never used)
         const int n4 = n >> 2;
         f4 xv[4], wv[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int i = tid + kNormThreads * k;
-            xv[k] = i < n4 ? reinterpret_cast<const f4*>(x)[i] : f4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int k = 0; k < 4; k++) xv[k] = reinterpret_cast<const f4*>(x)[min(tid + kNormThreads * k, n4 - 1)];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int i = tid + kNormThreads * k;
-            wv[k] = i < n4 ? reinterpret_cast<const f4*>(w)[i] : f4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int k = 0; k < 4; k++) wv[k] = reinterpret_cast<const f4*>(w)[min(tid + kNormThreads * k, n4 - 1)];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int i = tid + kNormThreads * k;
