@@ -595,18 +595,24 @@ static int launch_attention_chain(rama_ctx* c, float* xb, float* att, const floa
     p.dim = dim; p.head_size = head_size; p.seq_len = seq_len;
     if (spread) {
         // three launches over the whole chip (chain.hpp): needs att (the scores / probabilities travel through it)
+        // (an armed kernel-class timer brackets the whole attention: its start event rides on the first launch, its stop event on the last)
         const int ngroups = (seq_len + 63) / 64;
-        RAMA_LAUNCH(c, attn_scores_chain_kernel, dim3(n_heads, ngroups), dim3(64), 0, p);
+        hipEvent_t ev_start = c->cur_start, ev_stop = c->cur_start ? c->cur_stop : nullptr;
+        c->cur_start = nullptr;
+        if (ev_start) hipExtLaunchKernelGGL(attn_scores_chain_kernel, dim3(n_heads, ngroups), dim3(64), 0, c->stream, ev_start, nullptr, 0, p);
+        else hipLaunchKernelGGL(attn_scores_chain_kernel, dim3(n_heads, ngroups), dim3(64), 0, c->stream, p);
         LAUNCHCHK();
         const size_t fv_lds = attn_fused_values_lds_floats(seq_len) * sizeof(float);
         if (c->tune_attn_fv && fv_lds <= 32 * 1024) {             // the softmax repeated by every slice workgroup, one launch (chain.hpp [r4])
-            hipLaunchKernelGGL(attn_softmax_values_chain_kernel, dim3(n_heads, head_size / kValCols), dim3(kFvWaves * 64), fv_lds, c->stream, p);
+            if (ev_stop) hipExtLaunchKernelGGL(attn_softmax_values_chain_kernel, dim3(n_heads, head_size / kValCols), dim3(kFvWaves * 64), fv_lds, c->stream, nullptr, ev_stop, 0, p);
+            else hipLaunchKernelGGL(attn_softmax_values_chain_kernel, dim3(n_heads, head_size / kValCols), dim3(kFvWaves * 64), fv_lds, c->stream, p);
             LAUNCHCHK();
             return 0;
         }
         hipLaunchKernelGGL(attn_softmax_chain_kernel, dim3(n_heads), dim3(kSoftWaves * 64), ((size_t)seq_len + ((size_t)seq_len >> 5) + 4) * sizeof(float), c->stream, p);
         LAUNCHCHK();
-        hipLaunchKernelGGL(attn_values_chain_kernel, dim3(n_heads, head_size / kValCols), dim3(kValWaves * 64), 0, c->stream, p);
+        if (ev_stop) hipExtLaunchKernelGGL(attn_values_chain_kernel, dim3(n_heads, head_size / kValCols), dim3(kValWaves * 64), 0, c->stream, nullptr, ev_stop, 0, p);
+        else hipLaunchKernelGGL(attn_values_chain_kernel, dim3(n_heads, head_size / kValCols), dim3(kValWaves * 64), 0, c->stream, p);
         LAUNCHCHK();
         return 0;
     }
