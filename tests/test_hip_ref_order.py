@@ -343,18 +343,33 @@ def test_model_long_context_bit_exact(dev, n_heads, hs):
     orc = O.Oracle(cfg, w)
     model = rama_amd.Model.synth(dev, to_rama_cfg(cfg), 11, rope=rope)
     eng = rama_amd.Engine(dev, model)
-    for graph in (False, True):
-        eng.set_graph_mode(graph)
-        for pos in (255, 256, 257, 1000, 1023, 1024, 1025, 2047):     # 4 waves per head | 8 waves | three launches over the chip
-            orc.s["key_cache"][:] = kc; orc.s["value_cache"][:] = vc
-            eng.set_buffer("key_cache", kc); eng.set_buffer("value_cache", vc)
-            lo = orc.forward(5, pos).copy()
-            eng.forward(5, pos)
-            assert_bits_equal(eng.logits(), lo, f"long context pos {pos} graph {graph}")
-            assert_bits_equal(eng.buffer("xb2", dim), orc.s["xb2"], f"long context pos {pos} xb2")
-            att = eng.buffer("att", n_heads * seq).reshape(n_heads, seq)[:, :pos + 1]
-            assert_bits_equal(att, orc.s["att"].reshape(n_heads, seq)[:, :pos + 1], f"long context pos {pos} att")
-    eng.set_graph_mode(False)
+    # [r4] the exact attention is spread over the chip from position 128 on (scores | softmax + value chains in one launch); the
+    # forms it replaced stay selectable: "attn_fv" = 0 (softmax and value chains as two launches), "spread_pos" (one workgroup per
+    # head below it: 4 waves, 8 from position 256 on)
+    variants = [({}, (100, 127, 128, 129, 191, 192, 193, 255, 256, 257, 383, 384, 385, 1000, 1023, 1024, 1025, 2047)),
+                ({"attn_fv": 0}, (128, 200, 1024, 2047)),
+                ({"spread_pos": 1024}, (255, 256, 257, 1000, 1023, 1024, 1025)),
+                ({"spread_pos": 1 << 20}, (1500, 2047))]
+    try:
+        for tune, positions in variants:
+            for k, v in tune.items():
+                eng.set_tuning(k, v)
+            for graph in (False, True):
+                eng.set_graph_mode(graph)
+                for pos in positions:
+                    orc.s["key_cache"][:] = kc; orc.s["value_cache"][:] = vc
+                    eng.set_buffer("key_cache", kc); eng.set_buffer("value_cache", vc)
+                    lo = orc.forward(5, pos).copy()
+                    eng.forward(5, pos)
+                    assert_bits_equal(eng.logits(), lo, f"long context pos {pos} graph {graph} {tune}")
+                    assert_bits_equal(eng.buffer("xb2", dim), orc.s["xb2"], f"long context pos {pos} xb2 {tune}")
+                    att = eng.buffer("att", n_heads * seq).reshape(n_heads, seq)[:, :pos + 1]
+                    assert_bits_equal(att, orc.s["att"].reshape(n_heads, seq)[:, :pos + 1], f"long context pos {pos} att {tune}")
+            eng.set_graph_mode(False)
+            eng.set_tuning("attn_fv", 1); eng.set_tuning("spread_pos", 128)
+    finally:
+        eng.set_graph_mode(False)
+        eng.set_tuning("attn_fv", 1); eng.set_tuning("spread_pos", 128)
     eng.free(); model.free()
 
 
