@@ -26,6 +26,11 @@ while time.time() - t0 < budget:
     got = eng.generate(PROMPT, steps, T, 0.9, 0.2721174359321594)
     reps += 1
     bad += got != ref
+import ctypes as C
+dist_bad = C.c_uint(0)                                    # diagnostics of the distributed top-p pick (csrc/topp_pick.hpp): a wait that timed out, a prediction that failed
+f = dev.lib.rama_internal_topp_dist_bad
+f.restype = C.c_int; f.argtypes = [C.c_void_p, C.POINTER(C.c_uint)]
+f(dev.ctx, C.byref(dist_bad))
 print(json.dumps({"config": name, "mode": "parity" if parity else "fast", "temperature": T, "steps": steps, "repeats": reps, "mismatches": bad,
-                  "tokens": reps * steps, "tok_s": round(reps * steps / (time.time() - t0), 1)}))
-sys.exit(1 if bad else 0)
+                  "tokens": reps * steps, "tok_s": round(reps * steps / (time.time() - t0), 1), "topp_dist_bad": dist_bad.value}))
+sys.exit(1 if bad or dist_bad.value else 0)
