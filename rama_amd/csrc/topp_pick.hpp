@@ -10,7 +10,7 @@
 //
 //   * the sequential fp32 sum s_{i-1} differs from the real-number sum by at most (i - 1) 2^-24 relative (i - 1 positive adds), the
 //     fixed-point mass A_i by less than i 2^-47 absolute plus one rounding; with eps_i = (i + 128) 2^-23 (twice that) element i is
-//     SAFE for binade E when  2^E <= A_i (1 - eps_i) - i 2^-47  and  (A_i (1 + eps_i) + i 2^-47 + p_i)(1 + 2^-22) < 2^(E+1):
+//     SAFE for binade E when  2^E <= A_i (1 - eps_i) - i 2^-47  and  (A_i (1 + eps_i) + i 2^-47 + p_i)(1 + 2^-20) < 2^(E+1):
 //     then s_{i-1} is in binade E and s_i still is.  Everything else -- the first element, the elements around a power of two -- is SEQ;
 //   * workgroup g takes elements [1024 g, 1024 g + 1024), one per thread: SAFE elements become integer maps for their binade's ulp,
 //     neighbouring ones are composed by a segmented scan, and the chunk becomes a short list of ITEMS (a MAP segment: E, d0, d1;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(1024) void topp_pick_dist_kernel(ToppParams p, Topp
     PICK_STAMP(0);
     // ---- 1. SAFE for one binade, or SEQ
     const float eps = (float)(i + 128) * 0x1p-23f, absm = (float)i * 0x1p-47f;
-    const float lo = av * (1.0f - eps) - absm, hi = (av * (1.0f + eps) + absm + pv) * (1.0f + 0x1p-22f);
+    const float lo = av * (1.0f - eps) - absm, hi = (av * (1.0f + eps) + absm + pv) * (1.0f + 0x1p-20f);
     const int el = (int)(__float_as_uint(lo) >> 23), eh = (int)(__float_as_uint(hi) >> 23);       // (a sign bit makes el > 253)
     const bool safe = real && lo > 0.0f && el == eh && el >= 24 && el <= 253;
     const int E = !real ? -1 : (safe ? el : 0);
