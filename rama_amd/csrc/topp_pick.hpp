@@ -78,12 +78,9 @@ struct PickShared {
 // v_readlane issues ten instructions an item: 72 cycles).  A window without a tie (f0 == f1 everywhere) is a plain ripple of adds, 16
 // cycles a step.  Returns the sum behind the last item; `c` = the sum behind the item of every lane (lane 0: the incoming sum).
 constexpr int kRippleItems = 63;
-#ifndef RAMA_PICK_FORCE_FAST
-#define RAMA_PICK_FORCE_FAST 0
-#endif
 __device__ __forceinline__ float pick_ripple(float cum, float f0, float f1, int nl, float& c) {
     c = cum;
-    if (RAMA_PICK_FORCE_FAST || __ballot(f0 != f1) == 0ull) {
+    if (__ballot(f0 != f1) == 0ull) {
         // no item of the window depends on the parity (no tie in any segment: the rule, not the exception): one add a step
         for (int k = 0; k < nl; k += 8) {                          // (steps beyond nl repeat finished lanes: same inputs, same values)
 #pragma unroll
