@@ -917,7 +917,8 @@ __global__ __launch_bounds__(1024) void argmax_kernel(ArgmaxParams p) {
     for (int i0 = tid; i0 < n4; i0 += 8 * 1024) {
         f4 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const int i = i0 + u * 1024; v[u] = i < n4 ? l4[i] : f4{-INFINITY, -INFINITY, -INFINITY, -INFINITY}; }
+        for (int u = 0; u < 8; u++) v[u] = l4[min(i0 + u * 1024, n4 - 1)];      // ([r4] clamped, not conditional: `i < n4 ? load : x` is a branch with
+                                                                                  // s_waitcnt vmcnt(0) behind it -- the eight loads went out one by one)
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int i = i0 + u * 1024;
