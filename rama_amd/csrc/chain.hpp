@@ -1130,26 +1130,25 @@ __global__ __launch_bounds__(NW * 64) void attention_chain_kernel(RefAttnParams 
             const f4* k4 = reinterpret_cast<const f4*>(p.kc + (size_t)t * p.dim + col);
             float acc = 0.0f;
             int i = 0;
-            for (; i + 32 <= hs4; i += 32) {
-                f4 kk[32];
+            // batches of 32, 16, 8, 4 x 16 bytes, each requested at once ([r4]: 16 and 8 are new -- head size 64 took four round
+            // trips of 4, head size 48 three)
+            auto batch = [&](auto nb) {
+                constexpr int NB = decltype(nb)::value;
+                for (; i + NB <= hs4; i += NB) {
+                    f4 kk[NB];
 #pragma unroll
-                for (int u = 0; u < 32; u++) kk[u] = k4[i + u];
+                    for (int u = 0; u < NB; u++) kk[u] = k4[i + u];
 #pragma unroll
-                for (int u = 0; u < 32; u++) {
-                    const f4 qq = q4[i + u];
-                    acc = acc + qq.x * kk[u].x; acc = acc + qq.y * kk[u].y; acc = acc + qq.z * kk[u].z; acc = acc + qq.w * kk[u].w;
+                    for (int u = 0; u < NB; u++) {
+                        const f4 qq = q4[i + u];
+                        acc = acc + qq.x * kk[u].x; acc = acc + qq.y * kk[u].y; acc = acc + qq.z * kk[u].z; acc = acc + qq.w * kk[u].w;
+                    }
                 }
-            }
-            for (; i + 4 <= hs4; i += 4) {
-                f4 kk[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) kk[u] = k4[i + u];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const f4 qq = q4[i + u];
-                    acc = acc + qq.x * kk[u].x; acc = acc + qq.y * kk[u].y; acc = acc + qq.z * kk[u].z; acc = acc + qq.w * kk[u].w;
-                }
-            }
+            };
+            batch(std::integral_constant<int, 32>{});
+            batch(std::integral_constant<int, 16>{});
+            batch(std::integral_constant<int, 8>{});
+            batch(std::integral_constant<int, 4>{});
             for (; i < hs4; i++) {
                 const f4 kk = k4[i], qq = q4[i];
                 acc = acc + qq.x * kk.x; acc = acc + qq.y * kk.y; acc = acc + qq.z * kk.z; acc = acc + qq.w * kk.w;
