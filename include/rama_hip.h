@@ -371,7 +371,11 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *                   lives on the device, so consecutive steps are the same launches).  A graph launch costs ~7 us on
  *                   top of its kernels; 4 steps per graph: +5.3 % tokens/s at stories15M, +1.4 % at 110M, +0.1 % at
  *                   llama2-7B; 8 and more are slower again.  -1 (default): 4 for dim <= 1024, else 1
- *   "attn_fv" = 0|1 : parity mode beyond position 1024 (the attention spread over the chip): 1 (default) = the softmax and the value
+ *   "spread_pos" = 64..2^20 : parity mode: the position from which the exact attention runs spread over the chip (scores over
+ *                   heads x groups of 64 timesteps, then softmax + value chains over heads x 16-column slices) instead of one
+ *                   workgroup per head.  Default 128 (round 3: 1024): llama2-7B 187 against 184 tok/s at positions 124..179,
+ *                   178 against 152 at 800.  Head sizes that are no multiple of 32 always take one workgroup per head
+ *   "attn_fv" = 0|1 : parity mode from "spread_pos" on (the attention spread over the chip): 1 (default) = the softmax and the value
  *                   chains as ONE launch, every 16-column slice workgroup of a head repeating the head's softmax while its value rows
  *                   are on their way (22.2 us at 1 900 timesteps); 0 = two launches (9.5 + 16.0 us).  Same bits.
  *   "topp_sort" = 0|1 : ordering step of the top-p sampler for vocabularies <= 32768: 1 (default) = block sorts in
