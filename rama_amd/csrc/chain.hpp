@@ -1215,7 +1215,8 @@ __global__ __launch_bounds__(NW * 64) void attention_chain_kernel(RefAttnParams 
 
 // ---------------------------------------------------------------- the same attention spread over the chip (long contexts)
 // One workgroup per head leaves 224 CUs idle, and a CU takes ~64 KiB of loads in flight: at 1 900 timesteps K and V
-// arrive at ~1 TB/s and the launch lasts 81 us.  From position 1 024 on the three phases are three launches:
+// arrive at ~1 TB/s and the launch lasts 81 us.  From position 128 on ([r4]; round 3: 1 024) the phases are launches of their own
+// -- the last two as ONE since round 4 (attn_softmax_values_chain_kernel below; "attn_fv" = 0 keeps them apart):
 //   attn_scores_chain_kernel   grid (heads x groups of 64 timesteps), one wave each: the staged q.k chains -> att (scores)
 //   attn_softmax_chain_kernel  grid heads: max, glibc expf, the exact sequential sum, divide -> att (probabilities)
 //   attn_values_chain_kernel   grid (heads x slices of 32 head columns): product tiles of 256 rows x 32 columns, the 32

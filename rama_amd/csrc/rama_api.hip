@@ -159,7 +159,7 @@ struct rama_ctx {
     int host_pos = -1;                     // position of the next chained decode step (mirrors the device cursor)
     bool split_attn = false;               // variant the steps being enqueued / captured use
     bool long_attn = false;                // parity mode: the position is >= 256 (16 waves per head in attention_chain_kernel)
-    bool spread_attn = false;              // parity mode: the position is >= 1024 (attention as three launches over the whole chip)
+    bool spread_attn = false;              // parity mode: the position is >= tune_spread_pos (the exact attention as launches spread over the whole chip)
     int variant = 0;                       // attn_variant() of the steps being enqueued / captured
     bool small_attn = false;               // 4-wave attention workgroups (contexts of <= kSmallAttnPos timesteps)
     int tune_small_waves = 8, tune_small_pos = kSmallAttnPosDefault;   // waves per head and position limit of the small-attention variant
@@ -594,7 +594,7 @@ static int launch_attention_chain(rama_ctx* c, float* xb, float* att, const floa
     p.q = q; p.kc = kc_layer; p.vc = vc_layer; p.att = att; p.xb = xb; p.ctl = ctl; p.pos_val = pos;
     p.dim = dim; p.head_size = head_size; p.seq_len = seq_len;
     if (spread) {
-        // three launches over the whole chip (chain.hpp): needs att (the scores / probabilities travel through it)
+        // two launches over the whole chip (chain.hpp; three with "attn_fv" = 0): needs att (the scores / probabilities travel through it)
         // (an armed kernel-class timer brackets the whole attention: its start event rides on the first launch, its stop event on the last)
         const int ngroups = (seq_len + 63) / 64;
         hipEvent_t ev_start = c->cur_start, ev_stop = c->cur_start ? c->cur_stop : nullptr;
@@ -761,7 +761,7 @@ static bool small_attn_at(const rama_ctx* c, int pos, bool split, int dim) {
 
 // Which launches a step at `pos` consists of (one hipGraph per variant): fast mode 0 = one 16-wave workgroup per head,
 // 1 = split-T (long contexts), 2 = fewer waves per head (short contexts); parity mode 0 = 4 waves per head, 1 = 8 (pos >= 256),
-// 2 = three launches spread over the chip (pos >= 1024)
+// 2 = launches spread over the chip (pos >= tune_spread_pos)
 static int attn_variant(const rama_ctx* c, const rama_config* cfg, int pos) {
     if (c->tune_ref_order && !c->tune_tol) return pos >= c->tune_spread_pos ? 2 : (pos >= kLongAttnPos ? 1 : 0);
     const bool split = pos >= split_threshold(c, cfg);
@@ -1405,7 +1405,7 @@ static int ensure_topp_scratch(rama_ctx* c, int n) {
 // (result word, cursor advance, next embedding gather)
 static int enqueue_sample_launches(rama_ctx* c, ArgmaxParams fin, float temperature, float topp, float u);
 static int enqueue_sample(rama_ctx* c, ArgmaxParams fin, float temperature, float topp, float u) {
-    // kernel class RAMA_K_SAMPLE: up to three launches, so the bracket is a pair of event records around them (eager mode only)
+    // kernel class RAMA_K_SAMPLE: up to five launches, so the bracket is a pair of event records around them (eager mode only)
     KProf& k = c->kp;
     const bool timed = k.kernel_id == RAMA_K_SAMPLE && k.used < k.max_records;
     if (timed) HIPCHK(hipEventRecord(k.ev[2 * k.used], c->stream));

@@ -23,7 +23,8 @@
 //   * the chunk that holds the crossing of topp (or the list's end) publishes (last, cum_last); the chunk that holds the first
 //     i with u cum_last < cum_i finishes the step (token, cursor, next embedding: kernels.hpp finish_step).
 //
-// A flat 32 000-entry list is ~45 MAP items and ~90 SEQ elements (61 of them around 1/2, where eps is 2e-3): 9.5 us instead of 29.
+// A flat 32 000-entry list is ~45 MAP items and ~90 SEQ elements in front of the crossing (61 of them around 1/2, where eps is
+// 2e-3): the launch takes 12.5 us where the scan rounds took 29.  Lists up to kPickScanMax entries are left to the scan rounds.
 // Every wait is bounded (kPickSpinLimit): a timeout raises ToppDistParams::bad and the launch drains.
 #pragma once
 #include "chain.hpp"
