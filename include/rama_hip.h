@@ -394,7 +394,7 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *                   workgroups in one launch (csrc/topp_pick.hpp: binades predicted from the exact mass in front of every
  *                   entry, integer maps, a lane ripple over the chunks' items; lists up to 8192 entries are left to one
  *                   workgroup); 0 = one workgroup's scan rounds, one per binade (round 2).  Same sums bit for bit.
- *                   32 000 flat logits: 37 us per token (r3: 81), 109 kept entries: 17 us (26) -- profiles/r04_sampler_bench.json
+ *                   32 000 flat logits: 36 us per token (r3: 81), 109 kept entries: 17.6 us (26) -- profiles/r04_sampler_bench.json
  *   "topp_keep_sums" = 0|1 : 1 makes the top-p sampler also store its running sums in device scratch (tests)
  *   "ref_order" = 0|1|2 : 0 (default) = the fast path (fused multiply-adds, tree-shaped sums), which differs from the
  *                   CPU path by the CPU path's own rounding error (1.5e-4 in llama2-7B logits over 200 positions).

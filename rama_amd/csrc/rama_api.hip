@@ -1419,7 +1419,7 @@ static int enqueue_small_blocks(rama_ctx* c, ToppSortParams sp, int nstat) {
     sp.nblk = (sp.n + BS - 1) / BS;
     hipLaunchKernelGGL(topp_stats_kernel, dim3(nstat), dim3(1024), 0, c->stream, sp, c->topp_stats);
     LAUNCHCHK();
-    hipLaunchKernelGGL(topp_blocksort_bs_kernel<BS>, dim3(sp.nblk), dim3(BS / 2), 0, c->stream, sp, (const ToppStats*)c->topp_stats, nstat);
+    hipLaunchKernelGGL(topp_blocksort_bs_kernel<BS>, dim3(sp.nblk), dim3(BS), 0, c->stream, sp, (const ToppStats*)c->topp_stats, nstat);
     LAUNCHCHK();
     hipLaunchKernelGGL((topp_rank_pairs_bs_kernel<BS, OB>), dim3(sp.nblk, (sp.nblk + OB - 1) / OB), dim3(BS / 2), 0, c->stream, sp);
     LAUNCHCHK();

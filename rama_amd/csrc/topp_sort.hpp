@@ -223,23 +223,14 @@ __device__ __forceinline__ unsigned lane_xor_u32(unsigned v) {
         return (threadIdx.x & 32) ? r[0] : r[1];
     }
 }
-// one compare-exchange stage of the bitonic network between lanes l and l ^ J: keep the larger key where (lower lane) == (descending)
-template <int J>
-__device__ __forceinline__ void lane_stage(unsigned long long& A, unsigned long long& B, bool descA, bool descB) {
-    const unsigned long long oa = ((unsigned long long)lane_xor_u32<J>((unsigned)(A >> 32)) << 32) | lane_xor_u32<J>((unsigned)A);
-    const unsigned long long ob = ((unsigned long long)lane_xor_u32<J>((unsigned)(B >> 32)) << 32) | lane_xor_u32<J>((unsigned)B);
-    const bool lower = (threadIdx.x & J) == 0;
-    A = ((oa > A) == (lower == descA)) ? oa : A;
-    B = ((ob > B) == (lower == descB)) ? ob : B;
-}
-
-// ---------------------------------------------------------------- [r4] small blocks: statistics once, 512-entry sorts on 4 waves
+// ---------------------------------------------------------------- [r4] small blocks: statistics once, 1024-entry sorts
 // topp_blocksort_kernel is 16 workgroups of 16 waves: each repeats the softmax statistics over all n logits (7.6 us) and runs a
-// 66-stage bitonic network whose every stage is a turn of 16 waves through one CU (18 us).  With the ranking spread over the chip
-// (topp_rank_pairs_kernel) many small sorted blocks cost nothing, so:
+// 66-stage bitonic network with ds_bpermute exchanges (18 us).  With the ranking spread over the chip (topp_rank_pairs_bs_kernel)
+// smaller sorted blocks cost little, so:
 //   topp_stats_kernel          one workgroup per 1024 logits: its maximum and the sum of exp(x - that maximum)
-//   topp_blocksort_bs_kernel   BS = 512 entries per workgroup of 4 waves: folds the partial statistics (the same order in every
-//                              workgroup: the same bits), keeps and sorts its slice -- 45 stages, only 5 of them across waves
+//   topp_blocksort_bs_kernel   BS = 1024 (or 512) entries per workgroup, one key per thread: folds the partial statistics (the same
+//                              order in every workgroup: the same bits), keeps and sorts its slice -- 55 stages, 45 of them inside a
+//                              wave by DPP moves / lane swaps -- and leaves the block's running mass
 struct ToppStats { float mx, sum; };
 __global__ __launch_bounds__(1024) void topp_stats_kernel(ToppSortParams p, ToppStats* st) {
     __shared__ float s_r[16];
@@ -270,29 +261,34 @@ __global__ __launch_bounds__(1024) void topp_stats_kernel(ToppSortParams p, Topp
     }
 }
 
+// BS entries per workgroup, ONE key per thread (16 waves at BS = 1024, four per SIMD): the bitonic network on 64-bit keys is bound by
+// instruction issue -- a stage is a short dependent chain (exchange, 64-bit compare, two selects) -- and four waves per SIMD
+// interleave better than two (two keys per thread on BS / 2 threads: 5.9 us for the network of 1 024 keys, sort launch 9.2 us;
+// this way 8.2 us, although ten stages instead of nine cross waves through LDS: two buffers in turn, one barrier per stage).
+// The 45 in-wave stages (j < 64) are lane_stage<J>.  Then the block's running mass in sorted order as fixed-point integers.
+template <int J>
+__device__ __forceinline__ void lane_stage(unsigned long long& A, bool desc) {
+    const unsigned long long oa = ((unsigned long long)lane_xor_u32<J>((unsigned)(A >> 32)) << 32) | lane_xor_u32<J>((unsigned)A);
+    const bool lower = (threadIdx.x & J) == 0;
+    A = ((oa > A) == (lower == desc)) ? oa : A;
+}
 template <int BS>
-__global__ __launch_bounds__(BS / 2) void topp_blocksort_bs_kernel(ToppSortParams p, const ToppStats* st, int nstat) {
-    constexpr int NT = BS / 2;
+__global__ __launch_bounds__(BS) void topp_blocksort_bs_kernel(ToppSortParams p, const ToppStats* st, int nstat) {
     __shared__ unsigned long long s_k[2][BS];
+    __shared__ unsigned long long s_w[BS / 64];
     __shared__ int s_n;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool scale = p.temperature < 1.0f;
     if (tid == 0) s_n = 0;
-    // the whole vector's maximum and sum of exponentials from the partial ones, in index order (every workgroup: the same bits)
-    // (one partial per lane, nstat <= 64: one load, then the wave trees -- a loop over them is 2 nstat dependent L2 round trips, 12 us)
-    const int lane = tid & 63;
-    const float lg[2] = {p.logits[min((int)blockIdx.x * BS + tid, p.n - 1)], p.logits[min((int)blockIdx.x * BS + NT + tid, p.n - 1)]};       // (requested with the statistics)
+    const int base = blockIdx.x * BS, i = base + tid;
+    const float lg = p.logits[min(i, p.n - 1)];                   // (requested with the statistics)
     const ToppStats part = st[min(lane, nstat - 1)];
     const float mx = wave_max(part.mx);                            // (lanes behind the last partial repeat it: the maximum does not mind)
     const float sum = wave_sum(lane < nstat ? part.sum * expf(part.mx - mx) : 0.0f);
     const float cutoff = (1.0f - p.topp) / (float)(p.n - 1);      // infer.rs:56
-    const int base = blockIdx.x * BS;
     __syncthreads();
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        const int i = base + h * NT + tid;
-        const float v = lg[h];
-        const float pr = expf((scale ? v / p.temperature : v) - mx) / sum;
+    {
+        const float pr = expf((scale ? lg / p.temperature : lg) - mx) / sum;
         if (i < p.n && pr > cutoff) {
             const int slot = atomicAdd(&s_n, 1);
             s_k[0][slot] = ((unsigned long long)__float_as_uint(pr) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
@@ -300,64 +296,43 @@ __global__ __launch_bounds__(BS / 2) void topp_blocksort_bs_kernel(ToppSortParam
     }
     __syncthreads();
     const int cnt = s_n;
-    p.rk[(size_t)base + tid] = 0ull; p.rk[(size_t)base + NT + tid] = 0ull;
+    p.rk[(size_t)base + tid] = 0ull;
     if (tid == 0) p.bcount[blockIdx.x] = cnt;
     if (cnt == 0) return;                                          // uniform
     int P = 2;
     while (P < cnt) P <<= 1;                                       // uniform
-    const int H = P >> 1;
-    // the bitonic network of topp_blocksort_kernel on BS / 2 threads (thread t < P / 2 holds elements t and t + P / 2): a stage's partner
-    // is in the same thread (j = P/2), another wave (j >= 64: LDS, two buffers in turn, one barrier per stage) or the same wave (j < 64:
-    // lane_stage -- 45 of the 55 stages at P = 1024)
-    unsigned long long A = tid < H && tid < cnt ? s_k[0][tid] : 0ull;             // zero padding sorts last
-    unsigned long long B = tid < H && tid + H < cnt ? s_k[0][tid + H] : 0ull;
+    unsigned long long A = tid < cnt ? s_k[0][tid] : 0ull;         // zero padding sorts last
     int buf = 1;
     for (int k = 2; k <= P; k <<= 1) {
-        const bool descA = (tid & k) == 0, descB = ((tid + H) & k) == 0;
+        const bool desc = (tid & k) == 0;                          // (the last merge, k = P: every thread below P descending)
         int j = k >> 1;
-        if (j == H) {                                              // only in the last merge: always descending
-            if (A < B) { const unsigned long long t = A; A = B; B = t; }
-            j >>= 1;
-        }
         for (; j >= 64; j >>= 1) {
-            if (tid < H) { s_k[buf][tid] = A; s_k[buf][tid + H] = B; }
+            s_k[buf][tid] = A;
             __syncthreads();
-            const unsigned long long oa = tid < H ? s_k[buf][tid ^ j] : 0ull, ob = tid < H ? s_k[buf][(tid ^ j) + H] : 0ull;
+            const unsigned long long oa = s_k[buf][tid ^ j];
             buf ^= 1;
             const bool lower = (tid & j) == 0;
-            A = ((oa > A) == (lower == descA)) ? oa : A;
-            B = ((ob > B) == (lower == descB)) ? ob : B;
+            A = ((oa > A) == (lower == desc)) ? oa : A;
         }
-        if (j >= 32) lane_stage<32>(A, B, descA, descB);
-        if (j >= 16) lane_stage<16>(A, B, descA, descB);
-        if (j >= 8) lane_stage<8>(A, B, descA, descB);
-        if (j >= 4) lane_stage<4>(A, B, descA, descB);
-        if (j >= 2) lane_stage<2>(A, B, descA, descB);
-        if (j >= 1) lane_stage<1>(A, B, descA, descB);
+        if (j >= 32) lane_stage<32>(A, desc);
+        if (j >= 16) lane_stage<16>(A, desc);
+        if (j >= 8) lane_stage<8>(A, desc);
+        if (j >= 4) lane_stage<4>(A, desc);
+        if (j >= 2) lane_stage<2>(A, desc);
+        if (j >= 1) lane_stage<1>(A, desc);
     }
-    if (tid < H) {
-        if (tid < cnt) {
-            p.bp[(size_t)base + tid] = __uint_as_float((unsigned)(A >> 32));
-            p.bi[(size_t)base + tid] = (int)(0xFFFFFFFFu - (unsigned)(A & 0xFFFFFFFFull));
-        }
-        if (tid + H < cnt) {
-            p.bp[(size_t)base + tid + H] = __uint_as_float((unsigned)(B >> 32));
-            p.bi[(size_t)base + tid + H] = (int)(0xFFFFFFFFu - (unsigned)(B & 0xFFFFFFFFull));
-        }
+    // (threads at and above P took part with zeros among themselves: tid ^ j stays on their side of P for every j < P)
+    const float pr = __uint_as_float((unsigned)(A >> 32));
+    if (tid < cnt) {
+        p.bp[(size_t)base + tid] = pr;
+        p.bi[(size_t)base + tid] = (int)(0xFFFFFFFFu - (unsigned)(A & 0xFFFFFFFFull));
     }
-    // the block's running mass in sorted order (fixed point: exact integer sums): thread t takes positions 2t and 2t + 1
+    // the block's running mass in sorted order (fixed point: exact integer sums)
+    unsigned long long run = wave_scan_u64(tid < cnt ? topp_fixed(pr) : 0ull);
+    if (lane == 63) s_w[wave] = run;
     __syncthreads();
-    unsigned long long* s_f = s_k[0];
-    if (tid < H) { s_f[tid] = topp_fixed(__uint_as_float((unsigned)(A >> 32))); s_f[tid + H] = topp_fixed(__uint_as_float((unsigned)(B >> 32))); }
-    __syncthreads();
-    const int wave = tid >> 6;
-    const unsigned long long f0 = 2 * tid < cnt ? s_f[2 * tid] : 0ull, f1 = 2 * tid + 1 < cnt ? s_f[2 * tid + 1] : 0ull;
-    unsigned long long run = wave_scan_u64(f0 + f1);
-    if (lane == 63) s_k[1][wave] = run;
-    __syncthreads();
-    for (int w = 0; w < wave; w++) run += s_k[1][w];               // NT / 64 <= 8 waves
-    if (2 * tid < cnt) p.bm[(size_t)base + 2 * tid] = run - f1;
-    if (2 * tid + 1 < cnt) p.bm[(size_t)base + 2 * tid + 1] = run;
+    for (int w = 0; w < wave; w++) run += s_w[w];
+    if (tid < cnt) p.bm[(size_t)base + tid] = run;
 }
 
 // the pair-wise ranking for blocks of BS entries: a workgroup of BS / 2 threads takes block b against OB other blocks at once.  Besides the

@@ -35,7 +35,7 @@ static void small_blocks(hipStream_t st, int reps, const ToppSortParams& sq, con
     s5.epoch = (unsigned*)d.epoch;
     const int nstat = (n + 1023) / 1024;
     auto j0 = [&] { hipLaunchKernelGGL(topp_stats_kernel, dim3(nstat), dim3(1024), 0, st, s5, stt); };
-    auto j1 = [&] { hipLaunchKernelGGL(topp_blocksort_bs_kernel<BS>, dim3(s5.nblk), dim3(BS / 2), 0, st, s5, (const ToppStats*)stt, nstat); };
+    auto j1 = [&] { hipLaunchKernelGGL(topp_blocksort_bs_kernel<BS>, dim3(s5.nblk), dim3(BS), 0, st, s5, (const ToppStats*)stt, nstat); };
     auto j2 = [&] { hipLaunchKernelGGL((topp_rank_pairs_bs_kernel<BS, OB>), dim3(s5.nblk, (s5.nblk + OB - 1) / OB), dim3(BS / 2), 0, st, s5); };
     auto j3 = [&] { hipLaunchKernelGGL(topp_rank_scatter_bs_kernel<BS>, dim3((s5.nblk * BS + 1023) / 1024), dim3(1024), 0, st, s5); };
     auto j4 = [&] { hipLaunchKernelGGL(topp_pick_dist_kernel, dim3(kPickMaxChunks), dim3(1024), 0, st, tp, d, fin); };
