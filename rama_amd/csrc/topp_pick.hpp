@@ -66,6 +66,7 @@ struct PickShared {
     float cum[kPickChunk + 1];             // the sum in front of own item k; [n_items]: behind the last
     int kind[kPickChunk];                  // per element: E, 0 (SEQ) or -1 (behind the list)
     int wf[16], wd0[16], wd1[16], wends[16];
+    int cf[16], cd0[16], cd1[16], coff[16], n_items;       // per wave: the composed map of the waves in front, the items in front
     int off[kPickMaxChunks + 1];           // items in front of chunk c's
     float start;                           // the sum in front of the chunk
     int state;                             // 0 go on, 1 the chunk lies behind the crossing, 2 a wait timed out
@@ -165,17 +166,23 @@ __global__ __launch_bounds__(1024) void topp_pick_dist_kernel(ToppParams p, Topp
     if (lane == 63) { sh.wf[wave] = sv.f; sh.wd0[wave] = sv.m.d0; sh.wd1[wave] = sv.m.d1; }
     if (lane == 0) sh.wends[wave] = __popcll(endmask);
     __syncthreads();
-    int my_item = __popcll(endmask & ((1ull << lane) - 1ull)), n_items = 0;
-    {
-        SegInc carry{0, Inc{0, 0}};
-#pragma unroll
-        for (int w = 0; w < 16; w++) {
-            const int we = sh.wends[w];
-            if (w < wave) { carry = seg_then(carry, SegInc{sh.wf[w], Inc{sh.wd0[w], sh.wd1[w]}}); my_item += we; }
-            n_items += we;
-        }
-        if (!sv.f) sv.m = inc_then(carry.m, sv.m);
+    // ... the 16 waves' totals by ONE wave (a row of 16 lanes: four DPP steps) instead of a 16-step loop in every thread: that loop was
+    // ~320 of this phase's ~500 instructions per thread, on four waves per SIMD
+    if (wave == 0) {
+        SegInc t{lane < 16 ? sh.wf[lane & 15] : 0, Inc{lane < 16 ? sh.wd0[lane & 15] : 0, lane < 16 ? sh.wd1[lane & 15] : 0}};
+        const int we = lane < 16 ? sh.wends[lane & 15] : 0;
+        int ie = we;
+        t = seg_then(seg_dpp<0x111, 0xF>(t), t); ie += __builtin_amdgcn_update_dpp(0, ie, 0x111, 0xF, 0xF, true);
+        t = seg_then(seg_dpp<0x112, 0xF>(t), t); ie += __builtin_amdgcn_update_dpp(0, ie, 0x112, 0xF, 0xF, true);
+        t = seg_then(seg_dpp<0x114, 0xF>(t), t); ie += __builtin_amdgcn_update_dpp(0, ie, 0x114, 0xF, 0xF, true);
+        t = seg_then(seg_dpp<0x118, 0xF>(t), t); ie += __builtin_amdgcn_update_dpp(0, ie, 0x118, 0xF, 0xF, true);
+        const SegInc ex = seg_dpp<0x111, 0xF>(t);                  // exclusive: the waves in front (lane 0: identity)
+        if (lane < 16) { sh.cf[lane] = ex.f; sh.cd0[lane] = ex.m.d0; sh.cd1[lane] = ex.m.d1; sh.coff[lane] = ie - we; }
+        if (lane == 15) sh.n_items = ie;
     }
+    __syncthreads();
+    const int my_item = __popcll(endmask & ((1ull << lane) - 1ull)) + sh.coff[wave], n_items = sh.n_items;
+    if (!sv.f) sv.m = inc_then(Inc{sh.cd0[wave], sh.cd1[wave]}, sv.m);
     // ---- 3. the chunk's items, to the other workgroups and to this one's walk
     if (end) {
         const float U = __uint_as_float((unsigned)(max(E, 24) - 23) << 23);
