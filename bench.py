@@ -45,7 +45,7 @@ SHAPES = {   # dim, hidden, layers, heads, vocab, seq_len, 
     "stories15M": (288, 768, 6, 6, 32000, 256, True),
 }
 PROMPT = [10646, 2501, 263, 931]   # Rama-BPE of 'once upon a time' 
-TOPP_U = 0.2721174359321594        # the reference re-seeds ChaCha20 (seed 100, cpu.rs:161-162) on every call: the draw is this constant
+from rama_amd.sampler_const import TOPP_U_CPU as TOPP_U   # the reference re-seeds ChaCha20 (seed 100, cpu.rs:161-162) on every call: the draw is this constant (derived there)
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 METRIC_1GPU = "tokens/sec decode + matvec achieved-HBM-GB/s vs roofline, llama2-7B fp32 1xMI355X"
 

@@ -83,6 +83,8 @@ def lib() -> C.CDLL:
     L.oracle_argmax.restype = C.c_int
     L.oracle_sample.argtypes = [_f32p, sz, C.c_float, C.c_float, C.c_float]
     L.oracle_sample.restype = C.c_int
+    L.oracle_sample_top_q.argtypes = [_f32p, sz, C.c_float, C.c_float]
+    L.oracle_sample_top_q.restype = C.c_int
     L.oracle_forward.argtypes = [C.POINTER(OracleConfig), C.POINTER(OracleWeights), C.POINTER(OracleState), C.c_int, C.c_int]
     L.oracle_forward_range.argtypes = L.oracle_forward.argtypes + [C.c_int] * 4
     L.oracle_forward_f64.argtypes = L.oracle_forward.argtypes
@@ -134,6 +136,11 @@ def matmul(o, a, b, width, o_rows, o_cols=1):
 
 def sample(logits, temperature, topp, u) -> int:
     return lib().oracle_sample(_p(logits), logits.size, temperature, topp, u)
+
+
+def sample_top_q(probabilities, num, topp, u) -> int:
+    p = np.ascontiguousarray(probabilities, np.float32)
+    return lib().oracle_sample_top_q(_p(p), num, topp, u)
 
 
 def fill_synth(n: int, seed: int, tag: int, scale: float, bias: float = 0.0, offset: int = 0) -> np.ndarray:

@@ -221,6 +221,9 @@ static int sample_top_q(const float *p, size_t num, float topp, float u) {
     return out;
 }
 
+/* the same on given probabilities (for the hand-worked vectors of tests/test_sampler_const.py) */
+int oracle_sample_top_q(const float *p, size_t num, float topp, float u) { return sample_top_q(p, num, topp, u); }
+
 /* Device::sample cpu.rs:155-179 */
 int oracle_sample(float *logits, size_t n, float temperature, float topp, float u) {
     if (temperature == 0.0f) return oracle_argmax(logits, n);

@@ -96,6 +96,8 @@ int  oracle_argmax(const float *logits, size_t n);
  * `rng.gen::<f32>()`, which is the same constant every call because the generator is
  * re-seeded per call (cpu.rs:161-162).  Mutates logits like the reference. */
 int  oracle_sample(float *logits, size_t n, float temperature, float topp, float u);
+/* infer.rs:55-85 on given probabilities; `u` in place of rng.gen::<f32>() */
+int  oracle_sample_top_q(const float *p, size_t num, float topp, float u);
 
 /* ---- engine/src/transformer/infer.rs:8-53 ---- */
 void oracle_forward(const oracle_config *cfg, const oracle_weights *w,

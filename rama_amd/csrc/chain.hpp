@@ -31,6 +31,8 @@
 #include "kernels.hpp"
 #include "ref_order.hpp"
 #include "topp_sort.hpp"
+#include "seqsum_fast.hpp"
+#include "layer_fused.hpp"      // put_tagged, the epoch / error-word conventions of in-launch hand-offs
 
 namespace rama {
 
@@ -506,6 +508,9 @@ struct ChainParams {
     const Ctl* ctl; int pos_val;
     const float* fr; const float* fi; int head_size;
     float* kc; float* vc;  // this layer's cache slabs [seq, dim]
+    // CNORM_LEAD: workgroup 0 of the launch forms v = 1 / sqrt(sum(x^2) / K + 1e-5) (the sum in index order) and publishes it as ONE tagged word;
+    // the others request their weights, then wait for it (layer_fused.hpp's put_tagged / epoch / error word)
+    unsigned long long* lead; const unsigned* epoch; unsigned long long* err;
 };
 
 // a descriptor whose inputs the compiler must take as wave-uniform (they are: kernel arguments and blockIdx)
@@ -550,8 +555,14 @@ __device__ unsigned long long g_chain_all[3 * 4096];
 // (Round 4 also folded the EXACT sum in for K <= 4096 -- one wave, 64 consecutive squares per lane, predicted binades, a scalar
 // walk; bit-exact -- and measured it slower than the launch it replaced: every workgroup of a CU repeats ~2000 vector
 // instructions, +8..10 us per matvec at llama2-7B against 9.4 us for the norm launch; profiles/r04_norm_fold_experiments.json.)
-enum { CNORM_NONE = 0, CNORM_EXACT = 1, CNORM_TREE = 2 };
-template <int W, int D, int XD, int EPI, int NORM = CNORM_NONE>
+//   CNORM_LEAD ([r5] parity mode, K <= 64 x threads x ... : the host picks LR with 64 W LR >= K): ONE workgroup of the launch -- block 0, a grid
+//     of groups + 1 -- forms the exact sum (seqsum_fast.hpp: ~2 us on one wave for 4096 squares) and publishes v as a tagged word; every other
+//     workgroup requests x, the gain and its first ring of weights, waits for the word and stages w * (v * x) itself.  What a norm launch of its
+//     own costs (its 7.8 us + a launch boundary on either side + the consumer's cold first round trip behind it) shrinks to the leader's
+//     x round trip + the sum + one hand-off, with the consumers' first weights already in registers when v arrives.
+enum { CNORM_NONE = 0, CNORM_EXACT = 1, CNORM_TREE = 2, CNORM_LEAD = 3 };
+constexpr unsigned long long kLeadErr = 0x3100ull;                // error word: a wait for the leader's word gave up
+template <int W, int D, int XD, int EPI, int NORM = CNORM_NONE, int LR = 64>
 __global__ __launch_bounds__(W * 64) void gemv_chain_kernel(ChainParams p) {
     RAMA_NO_CONTRACT
     CHAIN_STAMP(0);
@@ -562,9 +573,50 @@ __global__ __launch_bounds__(W * 64) void gemv_chain_kernel(ChainParams p) {
     const int wave = W == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 3, rr = lane >> 2;
     const int groups = (p.rows + 15) >> 4;
+    if constexpr (NORM == CNORM_LEAD) {
+        if (blockIdx.x == 0) {      // the leader: thread t holds x[t LR .. t LR + LR) (zeros behind K: the descriptor's range check)
+            FastSumShared<W>& fs = *reinterpret_cast<FastSumShared<W>*>(xs);        // (host: the dynamic LDS holds it)
+#ifdef RAMA_CHAIN_STAMPS
+            if (threadIdx.x == 0) g_chain_stamps[40] = __builtin_amdgcn_s_memrealtime();
+#endif
+            const unsigned ep = *p.epoch;
+            const __amdgpu_buffer_rsrc_t rxl = make_rsrc_uniform(p.x, (unsigned)p.K * 4u);
+            seq_sum_fast_prepare<W>(fs);
+            float a[LR];
+#pragma unroll
+            for (int u = 0; u < LR / 4; u++) {
+                const f4 xv = ld_c(rxl, ((unsigned)threadIdx.x * (unsigned)LR + 4u * (unsigned)u) * 4u);
+                a[4 * u] = xv.x * xv.x; a[4 * u + 1] = xv.y * xv.y; a[4 * u + 2] = xv.z * xv.z; a[4 * u + 3] = xv.w * xv.w;
+            }
+#ifdef RAMA_CHAIN_STAMPS
+            { float t_ = 0.0f;
+#pragma unroll
+              for (int k = 0; k < LR; k++) t_ += a[k];
+              asm volatile("" :: "v"(t_)); }
+            if (threadIdx.x == 0) g_chain_stamps[41] = __builtin_amdgcn_s_memrealtime();
+#endif
+            float ss;
+            if (!seq_sum_fast<W, LR>(a, fs, &ss)) {      // (uniform) the prediction did not hold: the plain loop over the squares
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < LR; k++) { const int i = (int)threadIdx.x * LR + k; if (i < p.K) xs[i] = a[k]; }
+                __syncthreads();
+                if (threadIdx.x == 0) { float s_ = 0.0f; for (int i = 0; i < p.K; i++) s_ = s_ + xs[i]; xs[p.K] = s_; }
+                __syncthreads();
+                ss = xs[p.K];
+            }
+            const float v = 1.0f / sqrtf(ss / (float)p.K + 1e-5f);
+            if (threadIdx.x == 0) put_tagged(p.lead, v, ep);
+#ifdef RAMA_CHAIN_STAMPS
+            if (threadIdx.x == 0) g_chain_stamps[42] = __builtin_amdgcn_s_memrealtime();
+#endif
+            return;
+        }
+    }
+    const int bid = NORM == CNORM_LEAD ? (int)blockIdx.x - 1 : (int)blockIdx.x;
     // (the quotient comes out of the vector ALU: without readfirstlane everything derived from it -- the buffer
     // descriptors above all -- counts as divergent and every load turns into a waterfall loop)
-    const int m = __builtin_amdgcn_readfirstlane(blockIdx.x / groups), g = blockIdx.x - m * groups;
+    const int m = __builtin_amdgcn_readfirstlane(bid / groups), g = bid - m * groups;
     const float* Wm = m == 0 ? p.w[0] : (m == 1 ? p.w[1] : p.w[2]);
     const int nblk = p.K >> 4;
     const int nchunk = (nblk + D - 1) / D;
@@ -631,6 +683,30 @@ __global__ __launch_bounds__(W * 64) void gemv_chain_kernel(ChainParams p) {
             for (int w_ = 1; w_ < W; w_++) ssl = ssl + wss[w_];
         }
         const float v = 1.0f / sqrtf(ssl / (float)p.K + 1e-5f);
+#pragma unroll
+        for (int u = 0; u < XU; u++) {
+            xa[u].x = ga[u].x * (v * xa[u].x); xa[u].y = ga[u].y * (v * xa[u].y);
+            xa[u].z = ga[u].z * (v * xa[u].z); xa[u].w = ga[u].w * (v * xa[u].w);
+        }
+    }
+    if constexpr (NORM == CNORM_LEAD) {     // x <- w * (v * x) with the leader's v: every wave watches the word itself (no barrier), bounded
+        float v = 0.0f;
+        {
+            const unsigned ep = *p.epoch;
+            unsigned long long word = 0;
+            long spins = 0;
+            while (true) {
+                if (lane == 0) word = __hip_atomic_load(p.lead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                word = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(word >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)word);
+                if ((unsigned)(word >> 32) == ep) break;
+                __builtin_amdgcn_s_sleep(1);
+                ++spins;
+                if ((spins & 255) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                if (spins > (1L << 22)) { if (lane == 0) __hip_atomic_store(p.err, kLeadErr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+            v = __uint_as_float((unsigned)word);
+        }
+        CHAIN_STAMP(5);
 #pragma unroll
         for (int u = 0; u < XU; u++) {
             xa[u].x = ga[u].x * (v * xa[u].x); xa[u].y = ga[u].y * (v * xa[u].y);
@@ -1284,7 +1360,7 @@ __global__ __launch_bounds__(64) void attn_scores_chain_kernel(RefAttnParams p) 
         }
     }
     const int t = g * 64 + lane;
-    if (t <= pos) p.att[(size_t)h * p.seq_len + t] = acc / scale_div;
+    if (t <= pos) p.sc[(size_t)h * p.seq_len + t] = acc / scale_div;
 }
 
 constexpr int kSoftWaves = 4;
@@ -1428,12 +1504,15 @@ __global__ __launch_bounds__(kFvWaves * 64) void attn_softmax_values_chain_kerne
     const bool chain = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) == 0;
     const int pos = p.ctl ? p.ctl->pos : p.pos_val;
     const size_t col = (size_t)h * p.head_size + (size_t)sl * kValCols;
+    // the scores come from p.sc, the probabilities go to p.att: DIFFERENT buffers (the host sees to it) -- the eight slice workgroups of a
+    // head all read the scores, and nothing orders the workgroups of one launch, so none of them may write what the others read
+    const float* scores = p.sc + (size_t)h * p.seq_len;
     float* att = p.att + (size_t)h * p.seq_len;
     // the scores first (their wait then leaves the value rows outstanding), then four tiles of value rows
     constexpr int kSc = 8;                                         // scores per thread and round
     float sc[kSc];
 #pragma unroll
-    for (int k = 0; k < kSc; k++) sc[k] = att[min(tid0 + k * TS, pos)];
+    for (int k = 0; k < kSc; k++) sc[k] = scores[min(tid0 + k * TS, pos)];
     f4 v0[U], v1[U], v2[U], v3[U];
     auto vissue = [&](int t0, f4 (&vr)[U]) {
 #pragma unroll
@@ -1448,7 +1527,7 @@ __global__ __launch_bounds__(kFvWaves * 64) void attn_softmax_values_chain_kerne
     float mx = -INFINITY;
 #pragma unroll
     for (int k = 0; k < kSc; k++) { const int t = tid0 + k * TS; if (t <= pos) { s_att[scan_slot(t)] = sc[k]; mx = fmaxf(mx, sc[k]); } }
-    for (int t = tid0 + kSc * TS; t <= pos; t += TS) { const float a = att[t]; s_att[scan_slot(t)] = a; mx = fmaxf(mx, a); }
+    for (int t = tid0 + kSc * TS; t <= pos; t += TS) { const float a = scores[t]; s_att[scan_slot(t)] = a; mx = fmaxf(mx, a); }
     mx = block_max(mx, red);
     for (int t = tid0; t <= pos; t += TS) s_att[scan_slot(t)] = expf_glibc(s_att[scan_slot(t)] - mx);
     __syncthreads();

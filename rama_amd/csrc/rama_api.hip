@@ -52,6 +52,7 @@ static int fail(int code, const char* what, const char* file, int line) {
 constexpr int kSmallAttnPosDefault = 256;
 constexpr size_t kAttnChainMaxLds = 136 * 1024;      // dynamic LDS attention_chain_kernel may ask for (allowed once per device in rama_ctx_create)
 constexpr int kSpreadAttnPos = 128;        // parity mode: from this position on the attention is two launches spread over the chip (chain.hpp; "spread_pos": 187 against 184 tok/s at positions 124..179, 178 against 152 at 800)
+constexpr int kLeadSlots = 2 * 256 + 2;       // tagged words of the leader-workgroup norms: two per layer of a stage (<= 256 layers), one for the final norm
 constexpr int kLongAttnPos = 256;          // parity mode: attention_chain_kernel runs 16 waves per head from this position on
 
 struct KProf {
@@ -150,9 +151,13 @@ struct rama_ctx {
     unsigned* attn_counter = nullptr;      // device: arrivals of the attention workgroups
     float* attn_part = nullptr;            // split-T partials [n_heads, nsplit, head_size + 4]
     size_t attn_part_floats = 0;
+    float* attn_scores = nullptr;          // parity mode, spread attention: the raw scores [n_heads, seq_len] (the softmax+values launch reads them here and
+    size_t attn_scores_floats = 0;         // writes the probabilities to the caller's att: no workgroup reads a buffer another one of the launch writes)
     float* pf_blob = nullptr;              // token-batch scratch (tile layout): see BatchScratch
     float* pc_blob = nullptr;              // parity-mode prefill scratch (row-major token batches): see prefill_chain
     size_t pc_floats = 0;
+    int tune_chain_lead = 1;               // parity mode, dim > 512: the layer norms' exact sums by a leader workgroup INSIDE the consuming matvec's launch (chain.hpp CNORM_LEAD)
+    unsigned long long* lead_slots = nullptr;   // device: one tagged word per (layer, norm), 256 bytes apart
     int tune_chain_norm = 1;               // parity mode, dim <= 512: the layer norms folded into the matvecs that consume them
     int tune_prefill_chain = 1;            // parity mode: prompt positions go through the chain-order token-batch kernels (32 per weight pass); 0: one forward() each
     size_t pf_floats = 0;
@@ -210,6 +215,21 @@ extern "C" int rama_internal_pred_stats(rama_ctx* c, unsigned* held, unsigned* f
     return 0;
 }
 
+// test entry (not in the C ABI header): seqsum_fast.hpp's sum of a_dev[0..n) on nw waves; out_dev[0..3] = sum, held, items, 100 MHz ticks
+extern "C" int rama_internal_seqsum_fast(rama_ctx* c, const float* a_dev, int n, int nw, float* out_dev) {
+    REQUIRE(c && a_dev && out_dev && n > 0, RAMA_EINVAL, "seqsum_fast: bad argument");
+    const int per = (n + 64 * nw - 1) / (64 * nw);
+#define RAMA_FS(NW_, R_) hipLaunchKernelGGL((seqsum_fast_test_kernel<NW_, R_>), dim3(1), dim3(NW_ * 64), 0, c->stream, a_dev, n, out_dev)
+#define RAMA_FS_R(NW_) do { if (per <= 8) RAMA_FS(NW_, 8); else if (per <= 16) RAMA_FS(NW_, 16); else if (per <= 32) RAMA_FS(NW_, 32); else if (per <= 64) RAMA_FS(NW_, 64); \
+                            else return fail(RAMA_EINVAL, "seqsum_fast: list too long for this many waves", __FILE__, __LINE__); } while (0)
+    if (nw == 1) RAMA_FS_R(1); else if (nw == 2) RAMA_FS_R(2); else if (nw == 4) RAMA_FS_R(4);
+    else return fail(RAMA_EINVAL, "seqsum_fast: nw must be 1, 2 or 4", __FILE__, __LINE__);
+#undef RAMA_FS_R
+#undef RAMA_FS
+    LAUNCHCHK();
+    return 0;
+}
+
 int rama_ctx_create(int device, void* hip_stream, rama_ctx** out) {
     REQUIRE(out, RAMA_EINVAL, "rama_ctx_create: out is NULL");
     int n = 0;
@@ -242,6 +262,8 @@ int rama_ctx_create(int device, void* hip_stream, rama_ctx** out) {
     HIPCHK(hipMemset(c->fused_hand, 0, (size_t)kFusedMaxLayers * fused_hand_words(kFusedMaxDim, kFusedMaxHidden) * sizeof(tagged_t)));
     HIPCHK(hipMalloc(&c->fused_epoch, sizeof(unsigned)));
     { const unsigned one = 1; HIPCHK(hipMemcpy(c->fused_epoch, &one, sizeof one, hipMemcpyHostToDevice)); }      // the zeroed vectors carry tag 0
+    HIPCHK(hipMalloc(&c->lead_slots, kLeadSlots * 32 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(c->lead_slots, 0, kLeadSlots * 32 * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&c->pbar, 4 * sizeof(unsigned long long)));
     HIPCHK(hipMemset(c->pbar, 0, 4 * sizeof(unsigned long long)));
     HIPCHK(hipHostMalloc(&c->pinned_int, sizeof(int) * 4));
@@ -293,7 +315,7 @@ int rama_ctx_destroy(rama_ctx* c) {
     hipStreamSynchronize(c->stream);
     drop_graph(c);
     for (auto e : c->kp.ev) hipEventDestroy(e);
-    hipFree(c->ctl); hipFree(c->out); hipFree(c->forced); hipFree(c->argmax_result); hipFree(c->pbar); hipFree(c->attn_counter); hipFree(c->attn_part); hipFree(c->fused_hand); hipFree(c->fused_epoch);
+    hipFree(c->ctl); hipFree(c->out); hipFree(c->forced); hipFree(c->argmax_result); hipFree(c->pbar); hipFree(c->attn_counter); hipFree(c->attn_part); hipFree(c->attn_scores); hipFree(c->fused_hand); hipFree(c->fused_epoch); hipFree(c->lead_slots);
     for (int i = 0; i < 2; i++) { hipFree(c->topp_keys[i]); hipFree(c->topp_vals[i]); }
     hipFree(c->topp_prefix); hipFree(c->topp_m); hipFree(c->topp_err); hipFree(c->pf_blob); hipFree(c->pc_blob); if (c->ring) hipHostFree(c->ring);
     hipFree(c->topp_bp); hipFree(c->topp_bi); hipFree(c->topp_bcount); hipFree(c->topp_racc);
@@ -536,6 +558,22 @@ static int launch_chain(rama_ctx* c, ChainParams& p, int norm = CNORM_NONE) {
     const size_t lds = (size_t)(p.K + chain_pad_floats(W, D, 4)) * sizeof(float);      // x + the zeros behind it
     REQUIRE(lds <= 64 * 1024, RAMA_EUNSUP, "chain-order matvec: row longer than ~15800 floats");
     const dim3 grid(groups);
+    if (norm == CNORM_LEAD) {      // the exact sum by a leader workgroup of this launch (grid + 1); geometry as without a norm
+        REQUIRE(D == 16 && (W == 1 || W == 2) && p.K % 8 == 0 && p.K <= 4096 * W && (EPI == CEPI_QKV || EPI == CEPI_SWIGLU || EPI == CEPI_STORE) && p.lead && p.epoch && p.err,
+                RAMA_EUNSUP, "chain-order matvec: no leader-norm instantiation for this shape");
+        constexpr int E3 = (EPI == CEPI_QKV || EPI == CEPI_SWIGLU || EPI == CEPI_STORE) ? EPI : CEPI_QKV;
+        const int per = (p.K + 64 * W - 1) / (64 * W);
+        const size_t ldsl = std::max(lds, W == 1 ? sizeof(FastSumShared<1>) : sizeof(FastSumShared<2>));
+        const dim3 gridl(groups + 1);
+#define RAMA_CHAIN_L(W_, LR_) RAMA_LAUNCH(c, (gemv_chain_kernel<W_, 16, 4, E3, CNORM_LEAD, LR_>), gridl, dim3(W_ * 64), ldsl, p)
+#define RAMA_CHAIN_LW(W_) do { if (per <= 8) RAMA_CHAIN_L(W_, 8); else if (per <= 16) RAMA_CHAIN_L(W_, 16); else if (per <= 32) RAMA_CHAIN_L(W_, 32); else RAMA_CHAIN_L(W_, 64); } while (0)
+        if (W == 1) RAMA_CHAIN_LW(1); else RAMA_CHAIN_LW(2);
+#undef RAMA_CHAIN_LW
+#undef RAMA_CHAIN_L
+        LAUNCHCHK();
+        c->handoff_dirty = true;
+        return 0;
+    }
     if (norm != CNORM_NONE) {      // the rmsnorm folded in: all of x sits in the workgroup's registers (K <= 64 x threads)
         if (c->tune_chain_d <= 0 && W == 1 && p.K > 4096) W = 2;
         REQUIRE(chain_norm_fits(p.K, norm) && p.K <= 4096 * W && D == 16 && (W == 1 || W == 2) && EPI != CEPI_RESID, RAMA_EUNSUP, "chain-order matvec: no norm-folding instantiation for this shape");
@@ -582,6 +620,19 @@ static bool attn_chain_ok(int head_size, int seq_len) {      // the largest vari
     if (head_size % 4 || !attn_chain_fits(head_size, 16)) return false;
     return attn_chain_lds_floats(head_size, seq_len, attn_chain_waves(head_size, true)) * sizeof(float) + 16 <= kAttnChainMaxLds;
 }
+// the score scratch of parity mode's spread attention; inside a stream capture nothing is allocated (the caller then keeps
+// the three-launch form, whose softmax rewrites each head's row from ONE workgroup)
+static int ensure_attn_scores(rama_ctx* c, int n_heads, int seq_len) {
+    const size_t need = (size_t)n_heads * (size_t)seq_len;
+    if (need <= c->attn_scores_floats) return 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(c->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return 0; }
+    if (c->attn_scores) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->attn_scores)); c->attn_scores = nullptr; c->attn_scores_floats = 0; }
+    HIPCHK(hipMalloc(&c->attn_scores, need * sizeof(float)));
+    c->attn_scores_floats = need;
+    return 0;
+}
+
 // long_ctx: 8 waves per head (twice the timesteps per score round, twice the loaders of the value tiles) -- from position 256 on
 static int launch_attention_chain(rama_ctx* c, float* xb, float* att, const float* q, const float* kc_layer, const float* vc_layer,
                                   const Ctl* ctl, int pos, int dim, int head_size, int seq_len, int n_heads, bool long_ctx = false, bool spread_wanted = false) {
@@ -597,13 +648,21 @@ static int launch_attention_chain(rama_ctx* c, float* xb, float* att, const floa
         // two launches over the whole chip (chain.hpp; three with "attn_fv" = 0): needs att (the scores / probabilities travel through it)
         // (an armed kernel-class timer brackets the whole attention: its start event rides on the first launch, its stop event on the last)
         const int ngroups = (seq_len + 63) / 64;
+        // the one-launch softmax + values form reads the scores in every (head, slice) workgroup while the slice-0 workgroup of the head writes
+        // the probabilities: the scores therefore travel through a scratch of their own, never through the buffer that receives the probabilities
+        const size_t fv_lds = attn_fused_values_lds_floats(seq_len) * sizeof(float);
+        bool fv = c->tune_attn_fv && fv_lds <= 32 * 1024;
+        if (fv) {
+            const int rs = ensure_attn_scores(c, n_heads, seq_len); if (rs) return rs;
+            fv = c->attn_scores_floats >= (size_t)n_heads * (size_t)seq_len;
+        }
+        p.sc = fv ? c->attn_scores : att;
         hipEvent_t ev_start = c->cur_start, ev_stop = c->cur_start ? c->cur_stop : nullptr;
         c->cur_start = nullptr;
         if (ev_start) hipExtLaunchKernelGGL(attn_scores_chain_kernel, dim3(n_heads, ngroups), dim3(64), 0, c->stream, ev_start, nullptr, 0, p);
         else hipLaunchKernelGGL(attn_scores_chain_kernel, dim3(n_heads, ngroups), dim3(64), 0, c->stream, p);
         LAUNCHCHK();
-        const size_t fv_lds = attn_fused_values_lds_floats(seq_len) * sizeof(float);
-        if (c->tune_attn_fv && fv_lds <= 32 * 1024) {             // the softmax repeated by every slice workgroup, one launch (chain.hpp [r4])
+        if (fv) {             // the softmax repeated by every slice workgroup, one launch (chain.hpp [r4])
             if (ev_stop) hipExtLaunchKernelGGL(attn_softmax_values_chain_kernel, dim3(n_heads, head_size / kValCols), dim3(kFvWaves * 64), fv_lds, c->stream, nullptr, ev_stop, 0, p);
             else hipLaunchKernelGGL(attn_softmax_values_chain_kernel, dim3(n_heads, head_size / kValCols), dim3(kFvWaves * 64), fv_lds, c->stream, p);
             LAUNCHCHK();
@@ -726,6 +785,7 @@ static int ensure_attn_part(rama_ctx* c, const rama_config* cfg) {
         HIPCHK(hipMalloc(&c->attn_part, need * sizeof(float)));
         c->attn_part_floats = need;
     }
+    if (c->tune_ref_order) { const int rs = ensure_attn_scores(c, cfg->n_heads, cfg->seq_len); if (rs) return rs; }
     return 0;
 }
 
@@ -1137,7 +1197,12 @@ static int enqueue_stage_chain(rama_ctx* c, const rama_config* cfg, const rama_w
     // parity mode, narrow models: the exact norms ride in the matvecs that consume them ("chain_norm"; measured: stories15M +6.6 %; at dim
     // 768 the ripples cost more than the launch, -4 %)
     const int par_norm = (!tol && c->tune_chain_d <= 0 && c->tune_chain_norm && dim <= 512) ? CNORM_EXACT : CNORM_NONE;
-    const int lnorm = tol ? (tol_fold ? CNORM_TREE : CNORM_NONE) : par_norm;      // how the layer norms are folded
+    // parity mode, wider models ([r5]): the exact sum by a leader workgroup inside the consuming launch ("chain_lead"; x of <= 4096 floats per wave of the
+    // matvec's workgroups, layer ranges of <= 256 layers)
+    const bool lead_ok = !tol && par_norm == CNORM_NONE && c->tune_chain_lead && c->tune_chain_d <= 0 && dim % 8 == 0 && dim <= 4096 && dim / 16 > 32 &&
+                         st->layer_end - st->layer_begin <= 256 && c->kp.kernel_id != RAMA_K_NORM;
+    const int lnorm = tol ? (tol_fold ? CNORM_TREE : CNORM_NONE) : (lead_ok ? CNORM_LEAD : par_norm);      // how the layer norms are folded
+    bool led = false;
     const float* w13i = (tol && (mask & 4) && st->layer_end > st->layer_begin && (double)hidden * dim * 8.0 < 2147483648.0) ? rama_internal_w13_lookup(w->w1, w->w3) : nullptr;
     int rc;
     if (st->do_embed) {
@@ -1159,6 +1224,7 @@ static int enqueue_stage_chain(rama_ctx* c, const rama_config* cfg, const rama_w
             p.o[0] = s->q; p.o[1] = s->k; p.o[2] = s->v; p.x = fold ? s->x : s->xb; p.nw = fold ? w->rms_att_weight + li * dim : nullptr;
             p.K = dim; p.rows = dim; p.nmat = 3;
             p.ctl = c->ctl; p.fr = w->freq_cis_real; p.fi = w->freq_cis_imag; p.head_size = hs; p.kc = kc; p.vc = vc;
+            if (lnorm == CNORM_LEAD) { p.lead = c->lead_slots + 32 * (2 * li); p.epoch = c->fused_epoch; p.err = c->pbar + 1; led = true; }
             rc = launch_chain<CEPI_QKV>(c, p, fold ? lnorm : CNORM_NONE); if (rc) return rc;
         }
         {   // :34
@@ -1181,6 +1247,7 @@ static int enqueue_stage_chain(rama_ctx* c, const rama_config* cfg, const rama_w
             ChainParams p{};
             p.w[0] = c13 + li * 2 * hd; p.o[0] = s->hb; p.o[1] = s->hb2; p.x = fold ? s->x : s->xb; p.nw = fold ? w->rms_ffn_weight + li * dim : nullptr;
             p.K = dim; p.rows = 2 * hidden; p.nmat = 1;
+            if (lnorm == CNORM_LEAD) { p.lead = c->lead_slots + 32 * (2 * li + 1); p.epoch = c->fused_epoch; p.err = c->pbar + 1; led = true; }
             rc = launch_chain<CEPI_SWIGLU>(c, p, fold ? lnorm : CNORM_NONE); if (rc) return rc;
         }
         if (mask & 8) { KTimer kt(c, RAMA_K_W2); rc = launch_rows<false, EPI_RESID>(c, s->x, w->w2 + li * hd, s->hb, nullptr, hidden, dim); if (rc) return rc; }
@@ -1201,6 +1268,10 @@ static int enqueue_stage_chain(rama_ctx* c, const rama_config* cfg, const rama_w
         p.w[0] = ccls; p.o[0] = s->logits; p.x = s->x; p.K = dim; p.rows = V; p.nmat = 1;
         if (tol_fold) p.nw = w->rms_final_weight;
         rc = launch_chain<CEPI_STORE>(c, p, tol_fold ? CNORM_TREE : CNORM_NONE); if (rc) return rc;
+    }
+    if (led) {      // the leaders' words carry the epoch: it advances after every stage that used them (layer_fused.hpp's convention)
+        if (c->fused_chained) c->fused_epoch_owed = true;      // the sampler that follows advances it
+        else { hipLaunchKernelGGL(fused_epoch_kernel, dim3(1), dim3(1), 0, c->stream, c->fused_epoch); LAUNCHCHK(); }
     }
     return 0;
 }
@@ -2495,6 +2566,13 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
     if (!strcmp(key, "tiled")) {
         REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: tiled must be 0 or 1");
         c->tune_tiled = value;
+        hipStreamSynchronize(c->stream);
+        drop_graph(c);
+        return 0;
+    }
+    if (!strcmp(key, "chain_lead")) {
+        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: chain_lead must be 0 or 1");
+        c->tune_chain_lead = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
         return 0;

@@ -179,6 +179,7 @@ struct RefAttnParams {
     float* att; float* xb;
     const Ctl* ctl; int pos_val;
     int dim, head_size, seq_len;
+    float* sc = nullptr;      // spread attention (chain.hpp): where the scores launch leaves the raw scores ([n_heads, seq_len]; == att for the three-launch form)
     // a grid of (heads, tokens) -- the parity-mode prefill pass, chain.hpp: token y sits at position pos + y, its q / xb
     // rows are y * tok_stride floats further on, its att rows y * att_stride.  (0, 0 and gridDim.y = 1: one token.)
     int tok_stride, att_stride;

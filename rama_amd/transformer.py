@@ -22,6 +22,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import RamaError, S_FIELDS, W_FIELDS, check, rama_config, rama_run_state, rama_stage, rama_weights
+from .sampler_const import TOPP_U_CPU      # the reference's constant draw (seed 100, cpu.rs:161-162), derived in sampler_const.py
 
 
 # ------------------------------------------------------------------ Storage / View / MutView
@@ -200,7 +201,7 @@ class Hip:
     def softmax(self, x: MutView, n: int):
         check(self.lib.rama_softmax(self.ctx, x.ptr, n), "softmax")
 
-    def sample(self, cfg: Config, rsv: "RunStateView", temperature: float, topp: float, u: float = 0.2721174359321594) -> int:
+    def sample(self, cfg: Config, rsv: "RunStateView", temperature: float, topp: float, u: float = TOPP_U_CPU) -> int:
         """device.rs:16.  `u`: the reference's draw is one constant because ChaCha20 is re-seeded
         on every call (cpu.rs:161-162); the default is the value derived for seed 100 (SURVEY 8c,
         provisional -- no Rust toolchain here to confirm it)."""
@@ -370,7 +371,7 @@ def generate(cfg: Config, prompt_tokens, temperature: float, steps: int, topp: f
 
 
 def generate_device(cfg: Config, prompt_tokens, temperature: float, steps: int, topp: float,
-                    wv: TransformerWeightsView, rsv: RunStateView, device: Hip, u: float = 0.2721174359321594):
+                    wv: TransformerWeightsView, rsv: RunStateView, device: Hip, u: float = TOPP_U_CPU):
     """generate() chained on the device for any temperature (rama_generate): argmax or top-p sampling
     without the per-token logits download; one D2H of the token list at the end."""
     rs = rama_run_state(*[getattr(rsv, k).ptr for k in S_FIELDS])

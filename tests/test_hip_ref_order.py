@@ -327,6 +327,53 @@ def test_exact_sequential_sums(dev, n, scale):
         assert_bits_equal(dev.download(ts), s, f"softmax n={n} variant {vi}")
 
 
+def _seq_sum(a):
+    return np.add.accumulate(np.ascontiguousarray(a, np.float32), dtype=np.float32)[-1] if len(a) else np.float32(0)
+
+
+def fast_sum_lists(n, seed):
+    """non-negative lists that exercise seqsum_fast.hpp: squares of activations at several scales, all-equal terms (every add a
+    tie or none), powers of two, zeros, a spike, a ramp, terms that are exact half-ulps of the running sum, tiny and huge magnitudes"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for scale in (1.0, 0.02, 37.0, 1e-12, 3e15):
+        x = (rng.standard_normal(n) * scale).astype(np.float32)
+        out.append((x * x).astype(np.float32))
+    out.append(np.full(n, 0.75, np.float32))
+    out.append(np.full(n, 1.0, np.float32))
+    out.append((2.0 ** rng.integers(-8, 8, n)).astype(np.float32))
+    out.append(np.where(rng.random(n) < 0.5, 0.0, 1.3).astype(np.float32))
+    spike = (rng.random(n).astype(np.float32)); spike[n // 2] = np.float32(5000.0); out.append(spike)
+    out.append((np.arange(1, n + 1, dtype=np.float32) * np.float32(1.0 / n)))
+    half = rng.random(n).astype(np.float32); half[::7] = np.float32(2.0 ** -13); half[::11] = np.float32(3 * 2.0 ** -14); out.append(half)   # half-ulps of sums in [2^10, 2^11)
+    out.append(np.zeros(n, np.float32))
+    z = np.zeros(n, np.float32); z[-1] = 2.5; out.append(z)
+    out.append((rng.random(n) ** 8).astype(np.float32) * np.float32(100.0))       # a long tail: few large terms
+    return out
+
+
+@pytest.mark.parametrize("n", [1, 7, 64, 65, 288, 512, 768, 1000, 2048, 4096, 4097, 8192, 11008, 16384])
+def test_fast_sequential_sum(dev, n):
+    """seqsum_fast.hpp (the leader workgroup's exact sum of squares, [r5]): the sequential fp32 sum bit for bit on 1, 2 and 4 waves, and it
+    must HOLD (no fallback) on ordinary data"""
+    from rama_amd._lib import check
+    f = dev.lib.rama_internal_seqsum_fast
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    to = up(dev, np.zeros(4, np.float32))
+    for li, a in enumerate(fast_sum_lists(n, n)):
+        want = _seq_sum(a)
+        ta = up(dev, a)
+        for nw in (1, 2, 4):
+            if n > 64 * 64 * nw:
+                continue
+            check(f(dev.ctx, ta.ptr, n, nw, to.ptr))
+            got = dev.download(to)
+            assert_bits_equal(got[:1], np.array([want], np.float32), f"fast sum n={n} list {li} waves {nw}")
+            if li < 3 and n >= 64:
+                assert got[1] == 1.0, f"fast sum n={n} list {li} waves {nw}: fell back on ordinary data"
+
+
 @pytest.mark.parametrize("n_heads,hs", [(2, 128), (3, 64)])
 def test_model_long_context_bit_exact(dev, n_heads, hs):
     """parity mode over a pre-filled cache at positions around the 4-wave / 16-wave switch (256) and deep into the
