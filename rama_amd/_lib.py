@@ -6,10 +6,12 @@ this raises.  Nothing here imports the CPU oracle.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "librama_hip.so"
+# (RAMA_HIP_LIB: another build of the same library -- A/B runs of compile-time variants, tools/ab_lib.sh; never a fallback)
+LIB_PATH = Path(os.environ["RAMA_HIP_LIB"]) if os.environ.get("RAMA_HIP_LIB") else _HERE / "librama_hip.so"
 
 f32p = C.POINTER(C.c_float)
 i32p = C.POINTER(C.c_int32)

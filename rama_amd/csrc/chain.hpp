@@ -33,6 +33,7 @@
 #include "topp_sort.hpp"
 #include "seqsum_fast.hpp"
 #include "layer_fused.hpp"      // put_tagged, the epoch / error-word conventions of in-launch hand-offs
+#include "attn_wo.hpp"          // st_sc1 / ld4_sc1: write-through stores and L1-bypassing loads of in-launch hand-offs
 
 namespace rama {
 
@@ -510,7 +511,13 @@ struct ChainParams {
     float* kc; float* vc;  // this layer's cache slabs [seq, dim]
     // CNORM_LEAD: workgroup 0 of the launch forms v = 1 / sqrt(sum(x^2) / K + 1e-5) (the sum in index order) and publishes it as ONE tagged word;
     // the others request their weights, then wait for it (layer_fused.hpp's put_tagged / epoch / error word)
+    // ([r5] measured and not kept, profiles/r05_experiments.md: 16 copies of the word on different channels -1.8 %; the leader's compute unit kept free of
+    // other workgroups and its waves at priority 3: the word is there 1.1-2 us earlier, the launch no shorter)
     unsigned long long* lead; const unsigned* epoch; unsigned long long* err;
+    // WAIT ([r5] a consumer phase of a merged launch): x is written by OTHER workgroups of this launch (write-through stores); each of the wait_n
+    // producers leaves a tagged word {1, epoch} in wait_flags once its stores have left.  The group requests its ring of weights, then waits, then
+    // reads x with sc1 loads only (cdna_hip_programming.md Guideline 16 R1: sc1 payload, drained producer, sc1 flag, one polling wave, barrier)
+    const unsigned long long* wait_flags; int wait_n;
 };
 
 // a descriptor whose inputs the compiler must take as wave-uniform (they are: kernel arguments and blockIdx)
@@ -561,12 +568,16 @@ __device__ unsigned long long g_chain_all[3 * 4096];
 //     own costs (its 7.8 us + a launch boundary on either side + the consumer's cold first round trip behind it) shrinks to the leader's
 //     x round trip + the sum + one hand-off, with the consumers' first weights already in registers when v arrives.
 enum { CNORM_NONE = 0, CNORM_EXACT = 1, CNORM_TREE = 2, CNORM_LEAD = 3 };
+
 constexpr unsigned long long kLeadErr = 0x3100ull;                // error word: a wait for the leader's word gave up
-template <int W, int D, int XD, int EPI, int NORM = CNORM_NONE, int LR = 64>
-__global__ __launch_bounds__(W * 64) void gemv_chain_kernel(ChainParams p) {
+constexpr unsigned long long kWaitErr = 0x3200ull;                // error word: a wait for a merged launch's producers gave up
+// (the body of gemv_chain_kernel; `bid_in` = the workgroup's index within its phase -- merged launches run it behind other phases' workgroups)
+template <int W, int D, int XD, int EPI, int NORM = CNORM_NONE, int LR = 64, bool WAIT = false>
+__device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in) {
     RAMA_NO_CONTRACT
     CHAIN_STAMP(0);
     static_assert(D % XD == 0, "the x ring must divide the weight ring");
+    static_assert(!WAIT || NORM == CNORM_NONE, "a waiting phase takes its activations as they come");
     extern __shared__ __attribute__((aligned(16))) float xs[];
     __shared__ float relay[64];
     const int lane = threadIdx.x & 63;
@@ -574,7 +585,7 @@ __global__ __launch_bounds__(W * 64) void gemv_chain_kernel(ChainParams p) {
     const int j = lane & 3, rr = lane >> 2;
     const int groups = (p.rows + 15) >> 4;
     if constexpr (NORM == CNORM_LEAD) {
-        if (blockIdx.x == 0) {      // the leader: thread t holds x[t LR .. t LR + LR) (zeros behind K: the descriptor's range check)
+        if (bid_in == 0) {      // the leader: thread t holds x[t LR .. t LR + LR) (zeros behind K: the descriptor's range check)
             FastSumShared<W>& fs = *reinterpret_cast<FastSumShared<W>*>(xs);        // (host: the dynamic LDS holds it)
 #ifdef RAMA_CHAIN_STAMPS
             if (threadIdx.x == 0) g_chain_stamps[40] = __builtin_amdgcn_s_memrealtime();
@@ -613,7 +624,7 @@ __global__ __launch_bounds__(W * 64) void gemv_chain_kernel(ChainParams p) {
             return;
         }
     }
-    const int bid = NORM == CNORM_LEAD ? (int)blockIdx.x - 1 : (int)blockIdx.x;
+    const int bid = NORM == CNORM_LEAD ? bid_in - 1 : bid_in;
     // (the quotient comes out of the vector ALU: without readfirstlane everything derived from it -- the buffer
     // descriptors above all -- counts as divergent and every load turns into a waterfall loop)
     const int m = __builtin_amdgcn_readfirstlane(bid / groups), g = bid - m * groups;
@@ -634,13 +645,18 @@ __global__ __launch_bounds__(W * 64) void gemv_chain_kernel(ChainParams p) {
     for (int k = 0; k < 4; k++) vo[k] = lane16 + (unsigned)k * 4096u;
     // The activations are requested FIRST (they come from L2), then this wave's first chunk of weights (from HBM):
     // a wave's loads complete in order, so x asked for behind the weights would wait for the whole first HBM round
-    // trip before the staging below could even begin.
+    // trip before the staging below could even begin.  ([r5] behind a leader's norm the other order -- ring first, so that ~1000 workgroups asking
+    // for the same 32 KiB of x and gain do not keep the leader's own read of x waiting -- measured equal: 39.1 us either way.)
     const __amdgpu_buffer_rsrc_t rx = make_rsrc_uniform(p.x, (unsigned)p.K * 4u);
     const int n4 = p.K >> 2;
-    constexpr int T = W * 64, XU = 16;
+    // (a waiting phase folds no norm: whatever of x does not fit the registers follows behind the weights.  [r5] 24 x 16 bytes per thread up front for
+    // the residual products -- llama2-7B's W2 reads 11 008 floats on 128 threads, the last 2 816 in a second round trip -- measured: 33.70 against 33.77 us)
+    constexpr int T = W * 64, XU = WAIT ? 16 / W : 16;
     f4 xa[XU];
+    if constexpr (!WAIT) {
 #pragma unroll
-    for (int u = 0; u < XU; u++) xa[u] = ld_c(rx, ((int)threadIdx.x + T * u) < n4 ? (unsigned)((int)threadIdx.x + T * u) * 16u : kOOB);
+        for (int u = 0; u < XU; u++) xa[u] = ld_c(rx, ((int)threadIdx.x + T * u) < n4 ? (unsigned)((int)threadIdx.x + T * u) * 16u : kOOB);
+    }
     f4 ga[NORM != CNORM_NONE ? XU : 1];
     if constexpr (NORM != CNORM_NONE) {
         const __amdgpu_buffer_rsrc_t rg = make_rsrc_uniform(p.nw, (unsigned)p.K * 4u);
@@ -669,6 +685,24 @@ __global__ __launch_bounds__(W * 64) void gemv_chain_kernel(ChainParams p) {
         }
     }
     CHAIN_STAMP(1);
+    if constexpr (WAIT) {      // the ring is on its way: now the producers' words (wave 0 polls, lane i < wait_n the word of producer i), then x, sc1
+        const unsigned ep = *p.epoch;
+        if (wave == 0) {
+            long spins = 0;
+            while (true) {
+                unsigned long long word = (unsigned long long)ep << 32;
+                if (lane < p.wait_n) word = __hip_atomic_load(p.wait_flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__builtin_amdgcn_ballot_w64((unsigned)(word >> 32) == ep) == ~0ull) break;
+                __builtin_amdgcn_s_sleep(2);
+                ++spins;
+                if ((spins & 255) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                if (spins > (1L << 22)) { if (lane == 0) __hip_atomic_store(p.err, kWaitErr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < XU; u++) xa[u] = ld4_sc1(rx, ((int)threadIdx.x + T * u) < n4 ? (unsigned)((int)threadIdx.x + T * u) * 16u : kOOB);
+    }
     if constexpr (NORM == CNORM_TREE) {     // x <- w * (v * x) with the sum of squares as a fixed tree (host: K <= 64 T floats, all of x is in xa)
         float ssl = 0.0f;
 #pragma unroll
@@ -746,7 +780,7 @@ __global__ __launch_bounds__(W * 64) void gemv_chain_kernel(ChainParams p) {
         for (int i0 = (int)threadIdx.x + T * XU; i0 < n4; i0 += T * 8) {      // rows longer than 64 T floats: the rest, behind the weights
             f4 a[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) a[u] = ld_c(rx, (i0 + T * u) < n4 ? (unsigned)(i0 + T * u) * 16u : kOOB);
+            for (int u = 0; u < 8; u++) a[u] = WAIT ? ld4_sc1(rx, (i0 + T * u) < n4 ? (unsigned)(i0 + T * u) * 16u : kOOB) : ld_c(rx, (i0 + T * u) < n4 ? (unsigned)(i0 + T * u) * 16u : kOOB);
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int i = i0 + T * u;
@@ -798,6 +832,8 @@ __global__ __launch_bounds__(W * 64) void gemv_chain_kernel(ChainParams p) {
             for (int u = 0; u < D; u++) {
                 const f4 xv = xc[4 * u];
                 wr[u].x = wr[u].x * xv.x; wr[u].y = wr[u].y * xv.y; wr[u].z = wr[u].z * xv.z; wr[u].w = wr[u].w * xv.w;
+                // (deep rings: the LDS reads of eight blocks at a time -- all 32 at once are 128 registers beside the ring's 128)
+                if constexpr (D > 16) { if ((u & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
             }
         };
         if (wave == 0) premultiply(0);
@@ -855,6 +891,11 @@ __global__ __launch_bounds__(W * 64) void gemv_chain_kernel(ChainParams p) {
             p.o[1][row >> 1] = h3;
         }
     }
+}
+
+template <int W, int D, int XD, int EPI, int NORM = CNORM_NONE, int LR = 64>
+__global__ __launch_bounds__(W * 64) void gemv_chain_kernel(ChainParams p) {
+    gemv_chain_body<W, D, XD, EPI, NORM, LR>(p, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------- token batches in the reference's order (parity-mode prefill)
@@ -1109,25 +1150,28 @@ __host__ __device__ constexpr size_t attn_chain_lds_floats(int head_size, int se
 // the value tiles are loaded with 8 x 16 bytes per thread
 __host__ __device__ constexpr bool attn_chain_fits(int head_size, int nw) { return kAttTile * (head_size / 4) <= 8 * 64 * nw; }
 
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void attention_chain_kernel(RefAttnParams p) {
+// (the body of attention_chain_kernel: head h of token y.  lds_seq = the timesteps the LDS arrays are laid out for (seq_len; a merged launch that
+// only runs below some position passes that bound).  HANDOFF ([r5] attn_wo_chain_kernel): xb leaves with write-through stores and, once they
+// have left, the head's tagged word {1, epoch} -- the Wo groups of the same launch wait for the n_heads words)
+template <int NW, bool HANDOFF = false>
+__device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int y, int lds_seq, unsigned long long* flags = nullptr, const unsigned* epoch = nullptr) {
     RAMA_NO_CONTRACT
     constexpr int T = NW * 64;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ SeqSumShared<NW> sh;
     __shared__ PredShared<NW> ps;
     __shared__ float red[16];
-    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pos = p.seqs ? p.seqs[blockIdx.y].pos : (p.ctl ? p.ctl->pos : p.pos_val) + (int)blockIdx.y;
-    if (p.seqs) { p.kc = p.seqs[blockIdx.y].kc + p.layer_off; p.vc = p.seqs[blockIdx.y].vc + p.layer_off; }
-    p.q += (size_t)blockIdx.y * p.tok_stride; p.xb += (size_t)blockIdx.y * p.tok_stride;
-    if (p.att) p.att += (size_t)blockIdx.y * p.att_stride;
+    const int pos = p.seqs ? p.seqs[y].pos : (p.ctl ? p.ctl->pos : p.pos_val) + y;
+    if (p.seqs) { p.kc = p.seqs[y].kc + p.layer_off; p.vc = p.seqs[y].vc + p.layer_off; }
+    p.q += (size_t)y * p.tok_stride; p.xb += (size_t)y * p.tok_stride;
+    if (p.att) p.att += (size_t)y * p.att_stride;
     const int hs = p.head_size, hs4 = hs >> 2;
     float* s_q = sm;                                              // [hs]
-    float* s_p = sm + ((hs + 3) & ~3);                            // [seq_len] the probabilities, unskewed (read 4 at a time)
-    float* s_att = s_p + ((p.seq_len + 3) & ~3);                  // [scan_slot(seq_len)] scores -> exponentials
-    float* region = s_att + p.seq_len + (p.seq_len >> 5) + 4;     // score staging, then the product tiles
+    float* s_p = sm + ((hs + 3) & ~3);                            // [lds_seq] the probabilities, unskewed (read 4 at a time)
+    float* s_att = s_p + ((lds_seq + 3) & ~3);                    // [scan_slot(lds_seq)] scores -> exponentials
+    float* region = s_att + lds_seq + (lds_seq >> 5) + 4;         // score staging, then the product tiles
     region = reinterpret_cast<float*>(((uintptr_t)region + 15) & ~(uintptr_t)15);
     const size_t col = (size_t)h * hs;
     SEQ_STAMP(8);
@@ -1285,8 +1329,48 @@ __global__ __launch_bounds__(NW * 64) void attention_chain_kernel(RefAttnParams 
         vtile(t0, 0, va);
         if (t0 + kAttTile <= pos) vtile(t0 + kAttTile, 1, vb);    // uniform
     }
-    if (tid < hs) p.xb[col + tid] = acc;
+    if constexpr (HANDOFF) {
+        const unsigned ep = *epoch;
+        if (tid < hs) st_sc1(p.xb + col + tid, acc);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave: its stores have left
+        __syncthreads();
+        if (tid == 0) put_tagged(flags + h, 1.0f, ep);
+    } else {
+        if (tid < hs) p.xb[col + tid] = acc;
+    }
     SEQ_STAMP(13);
+}
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attention_chain_kernel(RefAttnParams p) {
+    attention_chain_body<NW>(p, (int)blockIdx.x, (int)blockIdx.y, p.seq_len);
+}
+
+// ---------------------------------------------------------------- [r5] attention + the Wo product as ONE launch (infer.rs:34-37), parity mode
+// One workgroup per head keeps 32 of 256 compute units busy for ~8 us while HBM idles, and the Wo launch behind it pays a boundary, a cold
+// first round trip and its tail: 15.1 us for 67 MB.  Here the grid is n_heads attention workgroups followed by Wo's dim / 16 row groups (four
+// waves each, a ring of D blocks per wave): the groups request the first 4 D KiB of their 16 rows' stream -- half of it at D = 32 -- while
+// the attention runs, wait for the n_heads tagged words, read xb with sc1 loads and run the chain as gemv_chain_kernel does: the same
+// operations in the same order per output, the same bits.  A workgroup only waits for workgroups with lower indices (the attention's, which
+// wait for nobody); every wait is bounded (error word, read by the host at its synchronising exits).
+__host__ __device__ constexpr size_t attn_chain_lds_floats_for(int head_size, int lds_seq, int nw) {
+    return (size_t)((head_size + 3) & ~3) + (size_t)lds_seq + (size_t)(lds_seq >> 5) + 4 + (size_t)((lds_seq + 3) & ~3) + attn_chain_region_floats(head_size, nw);
+}
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn_wo_chain_kernel(RefAttnParams a, ChainParams p, int n_heads, int lds_seq) {
+    if ((int)blockIdx.x < n_heads) {
+        attention_chain_body<4, true>(a, (int)blockIdx.x, 0, lds_seq, const_cast<unsigned long long*>(p.wait_flags), p.epoch);
+        return;
+    }
+    gemv_chain_body<4, D, 4, CEPI_RESID, CNORM_NONE, 64, true>(p, (int)blockIdx.x - n_heads);
+}
+// The same with ONE workgroup per compute unit (a grid of dim / 16 <= the CU count; the kernel's > 256 registers per lane see to the placement):
+// workgroup b < n_heads runs head b's attention FIRST (a wave's loads return in order: its cache rows must not queue behind a ring of weights)
+// and requests its ring afterwards; every other workgroup has its whole ring -- at D = 64 all 16 rows of Wo, 256 KiB -- on the way or in
+// registers when the heads' words arrive.
+template <int D>
+__global__ __launch_bounds__(256) void attn_wo_chain_solo_kernel(RefAttnParams a, ChainParams p, int n_heads, int lds_seq) {
+    if ((int)blockIdx.x < n_heads) attention_chain_body<4, true>(a, (int)blockIdx.x, 0, lds_seq, const_cast<unsigned long long*>(p.wait_flags), p.epoch);
+    gemv_chain_body<4, D, 4, CEPI_RESID, CNORM_NONE, 64, true>(p, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------- the same attention spread over the chip (long contexts)

@@ -53,6 +53,8 @@ constexpr int kSmallAttnPosDefault = 256;
 constexpr size_t kAttnChainMaxLds = 136 * 1024;      // dynamic LDS attention_chain_kernel may ask for (allowed once per device in rama_ctx_create)
 constexpr int kSpreadAttnPos = 128;        // parity mode: from this position on the attention is two launches spread over the chip (chain.hpp; "spread_pos": 187 against 184 tok/s at positions 124..179, 178 against 152 at 800)
 constexpr int kLeadSlots = 2 * 256 + 2;       // tagged words of the leader-workgroup norms: two per layer of a stage (<= 256 layers), one for the final norm
+constexpr int kAwoLayers = 256, kAwoHeads = 64;       // merged attention + Wo launches (chain.hpp attn_wo_chain_kernel): one tagged word per (layer of a stage, head)
+constexpr size_t kAwoMaxLds = 80 * 1024;      // ... whose workgroups must fit two to a compute unit (n_heads + dim / 16 of them on 256 CUs)
 constexpr int kLongAttnPos = 256;          // parity mode: attention_chain_kernel runs 16 waves per head from this position on
 
 struct KProf {
@@ -158,6 +160,8 @@ struct rama_ctx {
     size_t pc_floats = 0;
     int tune_chain_lead = 1;               // parity mode, dim > 512: the layer norms' exact sums by a leader workgroup INSIDE the consuming matvec's launch (chain.hpp CNORM_LEAD)
     unsigned long long* lead_slots = nullptr;   // device: one tagged word per (layer, norm), 256 bytes apart
+    int tune_chain_awo = 0;                // parity mode, short contexts: attention + Wo as one launch, the Wo groups' first 4 x this many KiB requested while the attention runs (0: two launches)
+    unsigned long long* awo_flags = nullptr;    // device: [kAwoLayers][kAwoHeads] tagged words
     int tune_chain_norm = 1;               // parity mode, dim <= 512: the layer norms folded into the matvecs that consume them
     int tune_prefill_chain = 1;            // parity mode: prompt positions go through the chain-order token-batch kernels (32 per weight pass); 0: one forward() each
     size_t pf_floats = 0;
@@ -264,6 +268,8 @@ int rama_ctx_create(int device, void* hip_stream, rama_ctx** out) {
     { const unsigned one = 1; HIPCHK(hipMemcpy(c->fused_epoch, &one, sizeof one, hipMemcpyHostToDevice)); }      // the zeroed vectors carry tag 0
     HIPCHK(hipMalloc(&c->lead_slots, kLeadSlots * 32 * sizeof(unsigned long long)));
     HIPCHK(hipMemset(c->lead_slots, 0, kLeadSlots * 32 * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&c->awo_flags, (size_t)kAwoLayers * kAwoHeads * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(c->awo_flags, 0, (size_t)kAwoLayers * kAwoHeads * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&c->pbar, 4 * sizeof(unsigned long long)));
     HIPCHK(hipMemset(c->pbar, 0, 4 * sizeof(unsigned long long)));
     HIPCHK(hipHostMalloc(&c->pinned_int, sizeof(int) * 4));
@@ -280,6 +286,10 @@ int rama_ctx_create(int device, void* hip_stream, rama_ctx** out) {
     HIPCHK(hipFuncSetAttribute((const void*)attention_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnChainMaxLds));
     HIPCHK(hipFuncSetAttribute((const void*)attention_chain_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnChainMaxLds));
     HIPCHK(hipFuncSetAttribute((const void*)attention_chain_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnChainMaxLds));
+    HIPCHK(hipFuncSetAttribute((const void*)attn_wo_chain_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAwoMaxLds));
+    HIPCHK(hipFuncSetAttribute((const void*)attn_wo_chain_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAwoMaxLds));
+    HIPCHK(hipFuncSetAttribute((const void*)attn_wo_chain_solo_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnChainMaxLds));
+    HIPCHK(hipFuncSetAttribute((const void*)attn_wo_chain_solo_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnChainMaxLds));
 #define RAMA_GC_ATTR(TPW_) \
     HIPCHK(hipFuncSetAttribute((const void*)gemm_chain_kernel<TPW_, CEPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_chain_lds_bytes(TPW_))); \
     HIPCHK(hipFuncSetAttribute((const void*)gemm_chain_kernel<TPW_, CEPI_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_chain_lds_bytes(TPW_))); \
@@ -315,7 +325,7 @@ int rama_ctx_destroy(rama_ctx* c) {
     hipStreamSynchronize(c->stream);
     drop_graph(c);
     for (auto e : c->kp.ev) hipEventDestroy(e);
-    hipFree(c->ctl); hipFree(c->out); hipFree(c->forced); hipFree(c->argmax_result); hipFree(c->pbar); hipFree(c->attn_counter); hipFree(c->attn_part); hipFree(c->attn_scores); hipFree(c->fused_hand); hipFree(c->fused_epoch); hipFree(c->lead_slots);
+    hipFree(c->ctl); hipFree(c->out); hipFree(c->forced); hipFree(c->argmax_result); hipFree(c->pbar); hipFree(c->attn_counter); hipFree(c->attn_part); hipFree(c->attn_scores); hipFree(c->fused_hand); hipFree(c->fused_epoch); hipFree(c->lead_slots); hipFree(c->awo_flags);
     for (int i = 0; i < 2; i++) { hipFree(c->topp_keys[i]); hipFree(c->topp_vals[i]); }
     hipFree(c->topp_prefix); hipFree(c->topp_m); hipFree(c->topp_err); hipFree(c->pf_blob); hipFree(c->pc_blob); if (c->ring) hipHostFree(c->ring);
     hipFree(c->topp_bp); hipFree(c->topp_bi); hipFree(c->topp_bcount); hipFree(c->topp_racc);
@@ -684,6 +694,36 @@ static int launch_attention_chain(rama_ctx* c, float* xb, float* att, const floa
     else RAMA_ATTN_CHAIN(16);
 #undef RAMA_ATTN_CHAIN
     LAUNCHCHK();
+    return 0;
+}
+
+// [r5] infer.rs:34-37 as one launch in parity mode (chain.hpp attn_wo_chain_kernel): positions below the spread attention's switch and below 256 (the
+// four-wave attention), head sizes whose value tiles four waves can load, <= 64 heads, <= 256 layers per stage, workgroups that fit two to a CU.
+// *merged = false: nothing was enqueued, the caller launches the two kernels.
+static int try_launch_attn_wo_chain(rama_ctx* c, const rama_config* cfg, rama_run_state* s, size_t li, const float* kc, const float* vc, const float* co_layer, bool* merged) {
+    *merged = false;
+    const int dim = cfg->dim, hs = dim / cfg->n_heads, D = c->tune_chain_awo, groups = (dim + 15) / 16;
+    if (D <= 0 || c->spread_attn || c->long_attn || c->kp.kernel_id >= 0 || c->tune_chain_d > 0) return 0;
+    if (cfg->n_heads > kAwoHeads || li >= (size_t)kAwoLayers || hs % 4 || attn_chain_waves(hs, false) != 4 || dim % 16 || dim / 16 <= 64) return 0;
+    const bool solo = D > 32;      // one workgroup per compute unit, the attention workgroups double as Wo groups
+    if (solo && (groups > c->cu_count || cfg->n_heads > groups)) return 0;
+    const int lds_seq = solo ? cfg->seq_len : std::min(cfg->seq_len, std::max(kLongAttnPos, 1));      // the launch only runs below position 256
+    const size_t lds = std::max(attn_chain_lds_floats_for(hs, lds_seq, 4) * sizeof(float) + 16, (size_t)(dim + chain_pad_floats(4, D, 4)) * sizeof(float));
+    if (lds > (solo ? kAttnChainMaxLds : kAwoMaxLds) || !aligned16(s->q) || !aligned16(kc) || !aligned16(vc) || !aligned16(s->xb)) return 0;
+    RefAttnParams a{};
+    a.q = s->q; a.kc = kc; a.vc = vc; a.att = s->att; a.xb = s->xb; a.ctl = c->ctl; a.pos_val = 0;
+    a.dim = dim; a.head_size = hs; a.seq_len = cfg->seq_len;
+    ChainParams p{};
+    p.w[0] = co_layer; p.o[0] = s->xb2; p.resid = s->x; p.x = s->xb; p.K = dim; p.rows = dim; p.nmat = 1;
+    p.wait_flags = c->awo_flags + li * kAwoHeads; p.wait_n = cfg->n_heads; p.epoch = c->fused_epoch; p.err = c->pbar + 1;
+    const dim3 grid(solo ? groups : cfg->n_heads + groups);
+    if (D == 16) hipLaunchKernelGGL((attn_wo_chain_kernel<16>), grid, dim3(256), lds, c->stream, a, p, cfg->n_heads, lds_seq);
+    else if (D == 32) hipLaunchKernelGGL((attn_wo_chain_kernel<32>), grid, dim3(256), lds, c->stream, a, p, cfg->n_heads, lds_seq);
+    else if (D == 48) hipLaunchKernelGGL((attn_wo_chain_solo_kernel<48>), grid, dim3(256), lds, c->stream, a, p, cfg->n_heads, lds_seq);
+    else hipLaunchKernelGGL((attn_wo_chain_solo_kernel<64>), grid, dim3(256), lds, c->stream, a, p, cfg->n_heads, lds_seq);
+    LAUNCHCHK();
+    c->handoff_dirty = true;
+    *merged = true;
     return 0;
 }
 
@@ -1227,13 +1267,16 @@ static int enqueue_stage_chain(rama_ctx* c, const rama_config* cfg, const rama_w
             if (lnorm == CNORM_LEAD) { p.lead = c->lead_slots + 32 * (2 * li); p.epoch = c->fused_epoch; p.err = c->pbar + 1; led = true; }
             rc = launch_chain<CEPI_QKV>(c, p, fold ? lnorm : CNORM_NONE); if (rc) return rc;
         }
-        {   // :34
+        bool awo = false;      // :34-37 as one launch ([r5] "chain_awo")
+        if (!tol && lead_ok) { rc = try_launch_attn_wo_chain(c, cfg, s, li, kc, vc, co + li * dd, &awo); if (rc) return rc; led = led || awo; }
+        if (!awo) {   // :34
             KTimer kt(c, RAMA_K_ATTN);
             if (tol && !(mask & 32)) rc = launch_attention(c, s->xb, s->att, s->q, kc, vc, c->ctl, 0, dim, hs, cfg->seq_len, cfg->n_heads, c->split_attn);
             else rc = launch_attention_chain(c, s->xb, s->att, s->q, kc, vc, c->ctl, 0, dim, hs, cfg->seq_len, cfg->n_heads, c->long_attn, c->spread_attn);
             if (rc) return rc;
         }
-        if (mask & 2) { KTimer kt(c, RAMA_K_WO); rc = launch_rows<false, EPI_RESID>(c, s->x, w->wo + li * dd, s->xb, nullptr, dim, dim); if (rc) return rc; }
+        if (awo) { }
+        else if (mask & 2) { KTimer kt(c, RAMA_K_WO); rc = launch_rows<false, EPI_RESID>(c, s->x, w->wo + li * dd, s->xb, nullptr, dim, dim); if (rc) return rc; }
         else {   // :35-37: xb2 = Wo . xb; x += xb2
             KTimer kt(c, RAMA_K_WO);
             ChainParams p{};
@@ -2573,6 +2616,13 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
     if (!strcmp(key, "chain_lead")) {
         REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: chain_lead must be 0 or 1");
         c->tune_chain_lead = value;
+        hipStreamSynchronize(c->stream);
+        drop_graph(c);
+        return 0;
+    }
+    if (!strcmp(key, "chain_awo")) {
+        REQUIRE(value == 0 || value == 16 || value == 32 || value == 48 || value == 64, RAMA_EINVAL, "set_tuning: chain_awo must be 0, 16, 32, 48 or 64");
+        c->tune_chain_awo = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
         return 0;

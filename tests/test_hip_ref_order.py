@@ -374,6 +374,45 @@ def test_fast_sequential_sum(dev, n):
                 assert got[1] == 1.0, f"fast sum n={n} list {li} waves {nw}: fell back on ordinary data"
 
 
+@pytest.mark.parametrize("dim,hidden,heads,layers,seq,steps", [(4096, 11008, 32, 2, 512, 140), (1296, 1600, 27, 3, 160, 40), (2048, 2048, 16, 2, 300, 270)])
+def test_attention_wo_merged_launch_bit_exact(dev, dim, hidden, heads, layers, seq, steps):
+    """[r5] attention + Wo as ONE launch in parity mode (chain.hpp attn_wo_chain_kernel, "chain_awo" = 32 | 16): the Wo groups request half (a
+    quarter) of their rows' stream while the attention runs, wait for the heads' tagged words and read xb with sc1 loads.  Every position
+    -- through the switches to the spread attention (128) and to 256, where the launch is two again -- leaves xb, xb2, x, the probabilities
+    and the logits as the oracle's, bit for bit, and as the two-launch form's (llama2-7B's width; a width whose last chunk is ragged with 27
+    heads of 48; 16 heads of 128 across both switches)"""
+    import rama_amd
+    from .helpers import to_rama_cfg
+    cfg = O.Config(dim, hidden, layers, heads, heads, 320, seq, False)
+    rope = S.rope_tables(seq, dim // heads)
+    w = S.synth_weights(cfg, 11, rope=rope)
+    orc = O.Oracle(cfg, w)
+    model = rama_amd.Model.synth(dev, to_rama_cfg(cfg), 11, rope=rope)
+    engs = {}
+    try:
+        for awo in (64, 32, 0):
+            engs[awo] = rama_amd.Engine(dev, model)
+        token = 1
+        for pos in range(steps):
+            lo = orc.forward(token, pos)
+            for awo, eng in engs.items():
+                eng.set_tuning("chain_awo", awo)
+                eng.forward(token, pos)
+                if awo == 0 and pos % 8:
+                    continue
+                assert_bits_equal(eng.logits(), lo, f"awo {awo} pos {pos} logits")
+                for buf, n in (("x", dim), ("xb", dim), ("xb2", dim)):
+                    assert_bits_equal(eng.buffer(buf, n), orc.s[buf], f"awo {awo} pos {pos} {buf}")
+                att = eng.buffer("att", heads * seq).reshape(heads, seq)[:, :pos + 1]
+                assert_bits_equal(att, orc.s["att"].reshape(heads, seq)[:, :pos + 1], f"awo {awo} pos {pos} att")
+            token = O.argmax(lo)
+    finally:
+        dev.lib.rama_set_tuning(dev.ctx, b"chain_awo", 32)
+        for eng in engs.values():
+            eng.free()
+        model.free()
+
+
 @pytest.mark.parametrize("n_heads,hs", [(2, 128), (3, 64)])
 def test_model_long_context_bit_exact(dev, n_heads, hs):
     """parity mode over a pre-filled cache at positions around the 4-wave / 16-wave switch (256) and deep into the
