@@ -2,6 +2,7 @@
 //! (device/device.rs).  Each method is one call into librama_hip.so; a non-zero return panics,
 //! which is what the reference's CUDA backend does through `.unwrap()` on every driver call.
 use std::ffi::CStr;
+use std::os::raw::{c_char, c_int};
 use std::ptr;
 
 use rand::{Rng, SeedableRng};
@@ -46,6 +47,10 @@ impl Hip {
     pub fn new() -> Self {
         let mut ctx = ptr::null_mut();
         ck(unsafe { rama_ctx_create(0, ptr::null_mut(), &mut ctx) });
+        // parity mode unless RAMA_REF_ORDER says otherwise (0 = fast, 2 = tolerance experiment): the reference CPU path's rounding order in
+        // every op, logits bit-identical to cpu.rs (mirrors rama_amd/csrc/host/engine.hpp Hip::Hip)
+        let mode: c_int = std::env::var("RAMA_REF_ORDER").ok().and_then(|v| v.parse().ok()).unwrap_or(1);
+        ck(unsafe { rama_set_tuning(ctx, b"ref_order\0".as_ptr() as *const c_char, mode) });
         Hip { ctx }
     }
     /// htod_sync_copy (hbm.rs:14-16)

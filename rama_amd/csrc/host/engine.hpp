@@ -158,7 +158,16 @@ struct Hip final : Device {
     // overrides it (e.g. with the CUDA backend's value).
     float topp_draw = std::getenv("RAMA_TOPP_U") ? std::strtof(std::getenv("RAMA_TOPP_U"), nullptr) : 0.2721174359321594f;
 
-    explicit Hip(int device = 0) { ck(rama_ctx_create(device, nullptr, &ctx), "rama_ctx_create"); }   // GPU::new, gpu.rs:213-234
+    // GPU::new, gpu.rs:213-234.  The host runs PARITY mode unless told otherwise: every op in the reference CPU path's rounding order, logits
+    // bit-identical to cpu.rs -- the only mode inside the 1e-4 bar at llama2-7B's depth.  RAMA_REF_ORDER=0 selects the fast
+    // path (fused multiply-adds, tree-shaped sums: ~20 % faster, ~1.5e-4 from the CPU path at 32 layers x 200 positions), 2 the tolerance experiment.
+    explicit Hip(int device = 0) {
+        ck(rama_ctx_create(device, nullptr, &ctx), "rama_ctx_create");
+        const char* ro = std::getenv("RAMA_REF_ORDER");
+        const int mode = ro ? std::atoi(ro) : 1;
+        if (mode < 0 || mode > 2) { std::fprintf(stderr, "RAMA_REF_ORDER must be 0 (fast), 1 (parity, the default) or 2 (tolerance experiment)\n"); std::exit(2); }
+        ck(rama_set_tuning(ctx, "ref_order", mode), "rama_set_tuning(ref_order)");
+    }
     ~Hip() override { rama_ctx_destroy(ctx); }
 
     HipSlice allocate(const std::vector<float>& data) const {     // hbm.rs:14-16 (htod_sync_copy)

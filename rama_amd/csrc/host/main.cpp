@@ -3,6 +3,8 @@
 // Same flags (main.rs:20-50), same loop (generate(), transformer/mod.rs:169-206: BOS at pos 0,
 // forced prompt tokens, Device::sample afterwards, every `next` printed, no EOS stop), same
 // closing line `elapsed: S.mmm s, avg tok/s: X` with X = (step - 1) / elapsed (main.rs:96-103).
+// RAMA_REF_ORDER=1  (default) parity mode: every op in the reference CPU path's rounding order, logits bit-identical to cpu.rs;
+//                   0 = the fast path (fused multiply-adds, tree sums), 2 = the tolerance experiment (host/engine.hpp Hip::Hip)
 // RAMA_PATH=ops     forward() composed from the 1:1 Device ops (the drop-in path)
 // RAMA_PATH=fused   (default) rama_forward: five fused launches per layer
 // RAMA_PATH=chained the whole loop chained on the device, every token printed as it appears in the host-visible ring
@@ -36,7 +38,8 @@ static void usage() {
         "  -s, --step <STEP>                Number of steps to run [default: 255]\n"
         "  -r, --temperature <TEMPERATURE>  The temperature [0, inf] [default: 1]\n"
         "  -l, --topp <TOPP>                p value in top-p sampling [default: 0.9]\n"
-        "  -o, --mode <MODE>                generate or chat [default: generate]\n");
+        "  -o, --mode <MODE>                generate or chat [default: generate]\n"
+        "environment: RAMA_REF_ORDER=1|0|2 parity (default) | fast | tolerance arithmetic; RAMA_PATH=fused|ops|chained; RAMA_TOPP_U=<draw>\n");
 }
 
 static Args parse(int argc, char** argv) {

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fcntl.h>
+#include <map>
 #include <mutex>
 #include <string>
 #include <sys/mman.h>
@@ -28,9 +29,10 @@ struct rama_model {
     float* chain = nullptr;     // every matrix once more in chain order, for parity mode (chain.hpp); made on first use
     bool tiled_tried = false, chain_tried = false;
     std::mutex build_mu;        // held while a derived copy is being made: a second caller waits for the copy instead of missing it
-    float* blob = nullptr;      // one allocation holding every tensor
+    float* blob = nullptr;      // one allocation holding every tensor (NULL: an ADOPTED model -- tensors uploaded one by one, owned by the caller)
     size_t blob_floats = 0;
     rama_stage stage{};
+    bool adopted = false;
 };
 
 namespace {
@@ -197,9 +199,23 @@ __global__ void chain_weights_kernel(float* dst, const float* src, const float* 
 
 
 // registry of the chain-order copies: a row-major tensor [nmat][rows][K] (or the (w1, w3) pair, rows = 2 hidden) -> its copy
-struct ChainEntry { const float* src; const float* src2; size_t per_src; size_t nmat; int rows, K; const float* chain; };
+// (own: a copy made for a VIEW -- rama_internal_chain_view, weights that belong to no model -- is an allocation of its own)
+struct ChainEntry { const float* src; const float* src2; size_t per_src; size_t nmat; int rows, K; const float* chain; float* own; };
 std::vector<ChainEntry> g_chain;
 std::mutex g_chain_mu;
+
+// every live rama_alloc_f32 allocation (base -> floats): lets a view of a tensor that was uploaded by itself (hbm.rs:14-16) be traced to its tensor
+std::map<const float*, size_t> g_allocs;
+std::mutex g_allocs_mu;
+bool alloc_of(const float* p, const float** base, size_t* n) {
+    std::lock_guard<std::mutex> lk(g_allocs_mu);
+    auto it = g_allocs.upper_bound(p);
+    if (it == g_allocs.begin()) return false;
+    --it;
+    if (p >= it->first + it->second) return false;
+    *base = it->first; *n = it->second;
+    return true;
+}
 
 std::vector<rama_model*> g_models;     // every live model: lets the lazily made copies be found from a rama_weights
 std::mutex g_models_mu;
@@ -232,7 +248,7 @@ int make_chain(rama_ctx* ctx, rama_model* m) {
     for (const T& t : ts) {
         if (t.src2) hipLaunchKernelGGL(chain_weights_kernel<true>, dim3(4096), dim3(256), 0, 0, dst, t.src, t.src2, t.nmat, t.rows, t.K);
         else hipLaunchKernelGGL(chain_weights_kernel<false>, dim3(4096), dim3(256), 0, 0, dst, t.src, t.src2, t.nmat, t.rows, t.K);
-        mine.push_back({t.src, t.src2, (size_t)(t.src2 ? t.rows / 2 : t.rows) * t.K, t.nmat, t.rows, t.K, dst});
+        mine.push_back({t.src, t.src2, (size_t)(t.src2 ? t.rows / 2 : t.rows) * t.K, t.nmat, t.rows, t.K, dst, nullptr});
         dst += t.nmat * r16(t.rows) * (size_t)t.K;
     }
     if (hipDeviceSynchronize() != hipSuccess) { rama_free(ctx, m->chain); m->chain = nullptr; return bad(RAMA_EIO, "chain-ordering the weights failed"); }
@@ -247,7 +263,7 @@ void drop_chain(rama_ctx* ctx, rama_model* m) {
         std::lock_guard<std::mutex> lk(g_chain_mu);
         const float* lo = m->chain;
         for (size_t i = g_chain.size(); i-- > 0;)
-            if (g_chain[i].chain >= lo && (g_chain[i].src == m->w.wq || g_chain[i].src == m->w.wk || g_chain[i].src == m->w.wv || g_chain[i].src == m->w.wo ||
+            if (!g_chain[i].own && g_chain[i].chain >= lo && (g_chain[i].src == m->w.wq || g_chain[i].src == m->w.wk || g_chain[i].src == m->w.wv || g_chain[i].src == m->w.wo ||
                                            g_chain[i].src == m->w.w1 || g_chain[i].src == m->w.w2 || g_chain[i].src == m->w.wcls))
                 g_chain.erase(g_chain.begin() + (long)i);
     }
@@ -274,6 +290,20 @@ rama_model* model_of(const rama_weights* w) {
     for (rama_model* m : g_models)
         if ((w->wq && m->w.wq == w->wq) || (!w->wq && w->wcls && m->w.wcls == w->wcls && !m->w.wq)) return m;
     return nullptr;
+}
+
+// the matrices of a model as (tensor, floats): what an adopted model must keep alive, what a freed allocation may take away
+std::vector<std::pair<const float*, size_t>> model_tensors(const rama_model* m) {
+    const size_t nl = (size_t)(m->stage.layer_end - m->stage.layer_begin), d = (size_t)m->cfg.dim, h = (size_t)m->cfg.hidden_dim, V = (size_t)m->cfg.vocab_size;
+    std::vector<std::pair<const float*, size_t>> t;
+    if (nl) { t = {{m->w.wq, nl * d * d}, {m->w.wk, nl * d * d}, {m->w.wv, nl * d * d}, {m->w.wo, nl * d * d}, {m->w.w1, nl * h * d}, {m->w.w2, nl * d * h}, {m->w.w3, nl * h * d}}; }
+    if (m->stage.do_cls && m->w.wcls) t.push_back({m->w.wcls, V * d});
+    return t;
+}
+// does [p, p + n) touch one of the model's matrices?
+bool model_holds(const rama_model* m, const float* p, size_t n) {
+    for (auto& t : model_tensors(m)) if (t.first && p < t.first + t.second && t.first < p + n) return true;
+    return false;
 }
 
 }  // namespace
@@ -330,11 +360,94 @@ extern "C" int rama_internal_model_ensure_ptr(rama_ctx* ctx, const float* p, int
     {
         std::lock_guard<std::mutex> lk(g_models_mu);
         const rama_model* hit = nullptr;
-        for (rama_model* m : g_models) if (p >= m->blob && p < m->blob + m->blob_floats) { hit = m; break; }
+        for (rama_model* m : g_models) if (m->adopted ? model_holds(m, p, 1) : (p >= m->blob && p < m->blob + m->blob_floats)) { hit = m; break; }
         if (!hit) return 0;
         w = hit->w;
     }
     return rama_internal_model_ensure(ctx, &w, what);
+}
+
+// ---------------------------------------------------------------- weights that were uploaded tensor by tensor (hbm.rs:55-90)
+// internal (rama_api.hip's rama_alloc_f32 / rama_free): the allocation table
+extern "C" void rama_internal_note_alloc(const float* base, size_t n) {
+    std::lock_guard<std::mutex> lk(g_allocs_mu);
+    g_allocs[base] = n;
+}
+extern "C" void rama_internal_drop_graphs(rama_ctx* ctx);      // rama_api.hip: captured graphs hold the copies' addresses
+// internal: [base, base + n) is about to be freed or overwritten -- every derived copy made from it goes (an adopted model that holds a tensor
+// in the range is dissolved, a view's chain-order copy is freed); `freed`: the allocation itself leaves the table.  Cheap when nothing was derived.
+extern "C" int rama_internal_forget_range(rama_ctx* ctx, const float* base, size_t n, int freed) {
+    if (freed) {      // (the caller knows the base only: the table knows how far the allocation reaches)
+        std::lock_guard<std::mutex> lk(g_allocs_mu);
+        auto it = g_allocs.find(base);
+        if (it != g_allocs.end()) { n = it->second; g_allocs.erase(it); }
+    }
+    std::vector<rama_model*> gone;
+    {
+        std::lock_guard<std::mutex> lk(g_models_mu);
+        for (size_t i = g_models.size(); i-- > 0;)
+            if (g_models[i]->adopted && model_holds(g_models[i], base, n)) { gone.push_back(g_models[i]); g_models.erase(g_models.begin() + (long)i); }
+    }
+    std::vector<float*> views;
+    {
+        std::lock_guard<std::mutex> lk(g_chain_mu);
+        for (size_t i = g_chain.size(); i-- > 0;) {
+            const ChainEntry& e = g_chain[i];
+            if (e.own && e.src < base + n && base < e.src + e.nmat * e.per_src) { views.push_back(e.own); g_chain.erase(g_chain.begin() + (long)i); }
+        }
+    }
+    if (gone.empty() && views.empty()) return 0;
+    int rc = ctx ? rama_sync(ctx) : 0;
+    if (ctx) rama_internal_drop_graphs(ctx);
+    for (rama_model* m : gone) { drop_chain(ctx, m); drop_tiled(ctx, m); delete m; }
+    for (float* v : views) { std::lock_guard<std::mutex> lk(g_allocs_mu); g_allocs.erase(v); }
+    for (float* v : views) if (hipFree(v) != hipSuccess && !rc) rc = RAMA_EIO;
+    return rc;
+}
+
+// internal: weights that belong to no model (uploaded tensor by tensor and passed to rama_forward* as a rama_weights) are ADOPTED -- a model
+// record that owns nothing but the derived copies it will make (the chain-order copy of parity mode, the tile-order copy of the token-batch
+// passes), so that the reference's own upload path (hbm.rs:55-90, integration/rust/hbm_hip.rs) runs the same kernels as a resident model.
+// Every matrix must lie inside a live rama_alloc_f32 / rama_upload_f32 allocation that is large enough; freeing or overwriting (rama_free,
+// rama_copy_h2d_f32) any of them dissolves the record.  Nothing happens when the weights already belong to a model.
+extern "C" int rama_internal_adopt(rama_ctx* ctx, const rama_config* cfg, const rama_stage* st, const rama_weights* w) {
+    if (!ctx || !cfg || !w || !st) return 0;
+    std::lock_guard<std::mutex> lk(g_models_mu);
+    if (model_of(w)) return 0;
+    rama_model* m = new rama_model();
+    m->cfg = *cfg; m->w = *w; m->stage = *st; m->adopted = true;
+    if (cfg->shared_weight && st->do_cls && !m->w.wcls) m->w.wcls = m->w.token_embedding_table;
+    for (auto& t : model_tensors(m)) {
+        const float* base; size_t n;
+        if (!t.first || !alloc_of(t.first, &base, &n) || t.first + t.second > base + n) { delete m; return 0; }
+    }
+    g_models.push_back(m);
+    return 0;
+}
+
+// internal: the chain-order copy of the row-major [rows, K] matrix at `a` -- a model's (resident or adopted), or one made for this VIEW on first
+// use: the whole tensor when `a` sits a whole number of matrices into an allocation that holds whole matrices (wq of hbm.rs: every layer at
+// once), else the one matrix.  NULL: no room (16 GiB are kept free), `a` is in no known allocation, or a stream capture is running and the
+// copy does not exist yet.
+extern "C" const float* rama_internal_chain_view(rama_ctx* ctx, const float* a, int rows, int K, int capturing) {
+    if (const float* hit = rama_internal_chain_lookup(a, rows, K)) return hit;
+    if (capturing || getenv("RAMA_NO_CHAIN") || K % 16) return nullptr;
+    const float* base; size_t n;
+    if (!alloc_of(a, &base, &n)) return nullptr;
+    const size_t per = (size_t)rows * K, off = (size_t)(a - base);
+    const float* src = a; size_t nmat = 1;
+    if (off % per == 0 && n % per == 0) { src = base; nmat = n / per; }
+    else if (off + per > n) return nullptr;
+    const size_t per_dst = (size_t)((rows + 15) / 16) * 16 * K, total = nmat * per_dst;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < total * 4 + ((size_t)16 << 30)) return nullptr;
+    float* dst = nullptr;
+    if (rama_alloc_f32(ctx, total, &dst)) return nullptr;
+    rama_sync(ctx);
+    hipLaunchKernelGGL(chain_weights_kernel<false>, dim3(4096), dim3(256), 0, 0, dst, src, (const float*)nullptr, nmat, rows, K);
+    if (hipDeviceSynchronize() != hipSuccess) { rama_free(ctx, dst); return nullptr; }
+    { std::lock_guard<std::mutex> lk(g_chain_mu); g_chain.push_back({src, nullptr, per, nmat, rows, K, dst, dst}); }
+    return rama_internal_chain_lookup(a, rows, K);
 }
 
 extern "C" int rama_model_load_stage(rama_ctx* ctx, const char* path, const rama_stage* stage, rama_model** out) {
@@ -570,7 +683,7 @@ extern "C" int rama_model_free(rama_ctx* ctx, rama_model* m) {
         rama_free(ctx, m->w13i);
     }
     drop_tiled(ctx, m);
-    int rc = rama_free(ctx, m->blob);
+    int rc = m->blob ? rama_free(ctx, m->blob) : 0;
     delete m;
     return rc;
 }

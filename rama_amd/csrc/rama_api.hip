@@ -27,6 +27,10 @@ extern "C" const float* rama_internal_tiled_lookup(const float* src);           
 extern "C" const float* rama_internal_chain_lookup(const float* a, int rows, int K);     // model.hip
 extern "C" int rama_internal_model_ensure(rama_ctx* ctx, const rama_weights* w, int what);       // model.hip: 1 = chain order, 2 = tile order
 extern "C" int rama_internal_model_ensure_ptr(rama_ctx* ctx, const float* p, int what);
+extern "C" void rama_internal_note_alloc(const float* base, size_t n);                                   // model.hip: the allocation table
+extern "C" int rama_internal_forget_range(rama_ctx* ctx, const float* base, size_t n, int freed);      // ... the copies derived from a range go
+extern "C" int rama_internal_adopt(rama_ctx* ctx, const rama_config* cfg, const rama_stage* st, const rama_weights* w);
+extern "C" const float* rama_internal_chain_view(rama_ctx* ctx, const float* a, int rows, int K, int capturing);
 
 // ---------------------------------------------------------------- error plumbing
 
@@ -163,6 +167,7 @@ struct rama_ctx {
     int tune_chain_awo = 0;                // parity mode, short contexts: attention + Wo as one launch, the Wo groups' first 4 x this many KiB requested while the attention runs (0: two launches)
     unsigned long long* awo_flags = nullptr;    // device: [kAwoLayers][kAwoHeads] tagged words
     int tune_chain_norm = 1;               // parity mode, dim <= 512: the layer norms folded into the matvecs that consume them
+    int tune_chain_views = 1;              // parity mode, Device::matmul on a matrix of no model: a chain-order copy of the tensor is made on first use
     int tune_prefill_chain = 1;            // parity mode: prompt positions go through the chain-order token-batch kernels (32 per weight pass); 0: one forward() each
     size_t pf_floats = 0;
     int host_pos = -1;                     // position of the next chained decode step (mirrors the device cursor)
@@ -393,12 +398,14 @@ int rama_alloc_f32(rama_ctx* c, size_t n, float** out) {
     HIPCHK(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(float)));
     HIPCHK(hipMemsetAsync(p, 0, std::max<size_t>(n, 1) * sizeof(float), c->stream));
     *out = (float*)p;
+    rama_internal_note_alloc((const float*)p, std::max<size_t>(n, 1));
     return 0;
 }
 
 int rama_copy_h2d_f32(rama_ctx* c, float* dst, const float* host, size_t n) {
     REQUIRE(c && (n == 0 || (dst && host)), RAMA_EINVAL, "rama_copy_h2d_f32: NULL argument");
     if (n == 0) return 0;
+    { const int rf = rama_internal_forget_range(c, dst, n, 0); if (rf) return rf; }      // copies derived from what is overwritten here
     HIPCHK(hipMemcpyAsync(dst, host, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));   // htod_sync_copy semantics (hbm.rs:14-16)
     return 0;
@@ -422,6 +429,7 @@ int rama_free(rama_ctx* c, void* p) {
     REQUIRE(c, RAMA_EINVAL, "ctx is NULL");
     if (!p) return 0;
     HIPCHK(hipStreamSynchronize(c->stream));
+    { const int rf = rama_internal_forget_range(c, (const float*)p, 1, 1); if (rf) return rf; }      // (any range inside the allocation: entries are matched by overlap with it below)
     HIPCHK(hipFree(p));
     return 0;
 }
@@ -780,7 +788,11 @@ int rama_matmul(rama_ctx* c, float* o, const float* a, const float* b, size_t wi
         // a layer-aligned view of a resident model's matrix streams the model's chain-order copy
         if (c->tune_chain && width % 16 == 0 && width <= 16000 && aligned16(b)) {
             rc = rama_internal_model_ensure_ptr(c, a, 1); if (rc) return rc;
-            if (const float* ch = rama_internal_chain_lookup(a, (int)o_rows, (int)width)) {
+            // ... and a matrix that belongs to no model -- uploaded by itself (hbm.rs:14-16), or a view no model copy covers (w1, w3: a model keeps
+            // them interleaved) -- gets a chain-order copy of its own on first use ("chain_views"; freed with the tensor: rama_free)
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            const bool capturing = hipStreamIsCapturing(c->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+            if (const float* ch = c->tune_chain_views ? rama_internal_chain_view(c, a, (int)o_rows, (int)width, capturing ? 1 : 0) : rama_internal_chain_lookup(a, (int)o_rows, (int)width)) {
                 ChainParams p{};
                 p.w[0] = ch; p.o[0] = o; p.x = b; p.K = (int)width; p.rows = (int)o_rows; p.nmat = 1;
                 return launch_chain<CEPI_STORE>(c, p);
@@ -1427,6 +1439,14 @@ static int check_stage(const rama_config* cfg, const rama_weights* w, const rama
     return 0;
 }
 
+// parity mode's chain-order weight copy: made on first use for a resident model -- and for weights that were uploaded tensor by tensor (hbm.rs:55-90),
+// which are adopted first (model.hip rama_internal_adopt): the reference's own upload path then runs the same kernels as rama_model_load
+static int ensure_chain_copy(rama_ctx* c, const rama_config* cfg, const rama_weights* w, const rama_stage* st) {
+    const rama_stage full{0, cfg->n_layers, 1, 1};
+    const int rc = rama_internal_adopt(c, cfg, st ? st : &full, w);
+    return rc ? rc : rama_internal_model_ensure(c, w, 1);
+}
+
 int rama_forward_stage(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s,
                        int token, int pos, const rama_stage* st) {
     REQUIRE(c, RAMA_EINVAL, "ctx is NULL");
@@ -1436,7 +1456,7 @@ int rama_forward_stage(rama_ctx* c, const rama_config* cfg, const rama_weights* 
     REQUIRE(pos >= 0 && pos < cfg->seq_len, RAMA_EINVAL, "forward: pos outside [0, seq_len)");
     REQUIRE(token >= 0 && token < cfg->vocab_size, RAMA_EINVAL, "forward: token outside the vocabulary");
     rc = ensure_attn_part(c, cfg); if (rc) return rc;
-    if (c->tune_ref_order && c->tune_chain) { rc = rama_internal_model_ensure(c, w, 1); if (rc) return rc; }
+    if (c->tune_ref_order && c->tune_chain) { rc = ensure_chain_copy(c, cfg, w, st); if (rc) return rc; }
     hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(1), 0, c->stream, c->ctl, token, pos, 0, 0);
     LAUNCHCHK();
     c->embedded_x = nullptr;
@@ -1455,7 +1475,7 @@ int rama_forward_stage_devtok(rama_ctx* c, const rama_config* cfg, const rama_we
     REQUIRE(pos >= 0 && pos < cfg->seq_len, RAMA_EINVAL, "forward: pos outside [0, seq_len)");
     REQUIRE(token_dev || !st->do_embed, RAMA_EINVAL, "forward: an embedding stage needs a token");
     rc = ensure_attn_part(c, cfg); if (rc) return rc;
-    if (c->tune_ref_order && c->tune_chain) { rc = rama_internal_model_ensure(c, w, 1); if (rc) return rc; }
+    if (c->tune_ref_order && c->tune_chain) { rc = ensure_chain_copy(c, cfg, w, st); if (rc) return rc; }
     hipLaunchKernelGGL(set_ctl_dev_kernel, dim3(1), dim3(1), 0, c->stream, c->ctl, (const int*)token_dev, pos, cfg->vocab_size);
     LAUNCHCHK();
     c->embedded_x = nullptr;
@@ -1903,7 +1923,7 @@ static int chain_batch_setup(rama_ctx* c, const rama_config* cfg, const rama_wei
     const int dim = cfg->dim, hidden = cfg->hidden_dim, hs = dim / cfg->n_heads, H = cfg->n_heads, seq = cfg->seq_len, V = cfg->vocab_size;
     if (!c->tune_chain || !c->tune_prefill_chain || dim % 16 || hidden % 16 || dim > 16000 || hidden > 16000 || !attn_chain_ok(hs, seq)) return 0;
     if (!rmsnorm_chain_ok((size_t)dim)) return 0;
-    int rc = rama_internal_model_ensure(c, w, 1); if (rc) return rc;
+    int rc = ensure_chain_copy(c, cfg, w, nullptr); if (rc) return rc;
     const float* cq = rama_internal_chain_lookup(w->wq, dim, dim), *ck = rama_internal_chain_lookup(w->wk, dim, dim);
     const float* cv = rama_internal_chain_lookup(w->wv, dim, dim), *co = rama_internal_chain_lookup(w->wo, dim, dim);
     const float* c13 = rama_internal_chain_lookup(w->w1, 2 * hidden, dim), *c2 = rama_internal_chain_lookup(w->w2, dim, hidden);
@@ -2345,7 +2365,7 @@ int rama_decode_steps(rama_ctx* c, const rama_config* cfg, const rama_weights* w
     }
     REQUIRE(c->host_pos >= 0, RAMA_EINVAL, "decode_steps: call rama_decode_begin first");
     rc = ensure_attn_part(c, cfg); if (rc) return rc;
-    if (c->tune_ref_order && c->tune_chain) { rc = rama_internal_model_ensure(c, w, 1); if (rc) return rc; }
+    if (c->tune_ref_order && c->tune_chain) { rc = ensure_chain_copy(c, cfg, w, nullptr); if (rc) return rc; }
     if (c->samp_T != 0.0f) { rc = ensure_topp_scratch(c, cfg->vocab_size); if (rc) return rc; }
     REQUIRE(c->host_pos + n_steps <= cfg->seq_len, RAMA_EINVAL, "decode_steps: would run past seq_len");
     const bool graphs = c->graph_mode && c->kp.kernel_id < 0;
@@ -2625,6 +2645,11 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
         c->tune_chain_awo = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
+        return 0;
+    }
+    if (!strcmp(key, "chain_views")) {
+        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: chain_views must be 0 or 1");
+        c->tune_chain_views = value;
         return 0;
     }
     if (!strcmp(key, "chain_norm")) {

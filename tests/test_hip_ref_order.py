@@ -374,6 +374,50 @@ def test_fast_sequential_sum(dev, n):
                 assert got[1] == 1.0, f"fast sum n={n} list {li} waves {nw}: fell back on ordinary data"
 
 
+def _chain_lookup(dev, ptr, rows, K):
+    f = dev.lib.rama_internal_chain_lookup
+    f.restype = C.c_void_p
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    return f(ptr, rows, K)
+
+
+@pytest.mark.parametrize("dim,hidden,heads,layers,vocab,seq,shared", [(4096, 11008, 32, 2, 640, 64, False), (288, 768, 6, 3, 512, 48, True)])
+def test_uploaded_weights_run_the_chain_kernels(dev, dim, hidden, heads, layers, vocab, seq, shared):
+    """[r5] weights uploaded tensor by tensor (hbm.rs:55-90, what the Rust shim does) are ADOPTED by the fused entry in parity mode -- the same
+    chain-order copies and launches as a resident model -- and Device::matmul on a matrix of no model (the 1:1 path's w1 / w3 views too) makes a
+    chain-order copy of the tensor on first use: logits and run state bit for bit the oracle's on both paths; the copies go when a tensor is
+    freed or overwritten, and a new upload at the same address is not served from a stale copy"""
+    import rama_amd
+    cfg = O.Config(dim, hidden, layers, heads, heads, vocab, seq, shared)
+    rope = S.rope_tables(seq, dim // heads)
+    token = 1
+    for seed in (21, 22):      # the second round re-uploads other weights, most likely at the same addresses
+        w = S.synth_weights(cfg, seed, rope=rope)
+        orc = O.Oracle(cfg, w)
+        rcfg, ws, wv, rs, rsv = gpu_views(dev, cfg, w)
+        rs2 = rama_amd.RunState.from_config(rcfg, dev); rsv2 = rama_amd.RunStateView.from_rs(rs2)
+        assert not _chain_lookup(dev, wv.wq.ptr, dim, dim), "a chain-order copy of a tensor that was just uploaded"
+        for pos in range(5):
+            lo = orc.forward(token, pos)
+            rama_amd.forward_fused(rcfg, wv, rsv, token, pos, dev)
+            rama_amd.forward(rcfg, wv, rsv2, token, pos, dev)
+            for buf in ("logits", "x", "xb", "hb", "q", "key_cache"):
+                assert_bits_equal(dev.download(getattr(rsv, buf)), orc.s[buf], f"adopted, fused pos {pos} {buf}")
+                assert_bits_equal(dev.download(getattr(rsv2, buf)), orc.s[buf], f"uploaded, 1:1 ops pos {pos} {buf}")
+            token = O.argmax(lo)
+        # the fused entry adopted the tensors (every matrix, W1|W3 interleaved); the 1:1 ops made copies of w1 and w3 by themselves
+        assert _chain_lookup(dev, wv.wq.ptr, dim, dim) and _chain_lookup(dev, wv.w2.ptr, dim, hidden) and _chain_lookup(dev, wv.w1.ptr, 2 * hidden, dim)
+        assert _chain_lookup(dev, wv.w1.ptr + 4 * hidden * dim, hidden, dim) and _chain_lookup(dev, wv.w3.ptr, hidden, dim)
+        wq_ptr, w3_ptr = wv.wq.ptr, wv.w3.ptr
+        # overwriting a tensor dissolves what was derived from it ...
+        dev.upload_into(ws.w3, w["w3"])
+        assert not _chain_lookup(dev, w3_ptr, hidden, dim) and not _chain_lookup(dev, wq_ptr, dim, dim)
+        rama_amd.forward_fused(rcfg, wv, rsv, 1, 5, dev)      # ... and the next call makes it again
+        assert _chain_lookup(dev, wq_ptr, dim, dim)
+        rs.free(); rs2.free(); ws.free()
+        assert not _chain_lookup(dev, wq_ptr, dim, dim), "a chain-order copy outlived its tensor"
+
+
 @pytest.mark.parametrize("dim,hidden,heads,layers,seq,steps", [(4096, 11008, 32, 2, 512, 140), (1296, 1600, 27, 3, 160, 40), (2048, 2048, 16, 2, 300, 270)])
 def test_attention_wo_merged_launch_bit_exact(dev, dim, hidden, heads, layers, seq, steps):
     """[r5] attention + Wo as ONE launch in parity mode (chain.hpp attn_wo_chain_kernel, "chain_awo" = 32 | 16): the Wo groups request half (a

@@ -123,8 +123,11 @@ def cli_vocab(vocab_size):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ref_order", [None, "0", "7"])
 @pytest.mark.parametrize("path", ["fused", "ops", "chained"])
-def test_engine_cli_text_parity(tmp_path, path):
+def test_engine_cli_text_parity(tmp_path, path, ref_order):
+    """the CLI runs PARITY mode by default (RAMA_REF_ORDER unset: every op in cpu.rs's rounding order, on weights it uploads tensor by
+    tensor like hbm.rs:55-90); RAMA_REF_ORDER=0 selects the fast path; anything outside 0..2 is refused"""
     name = "ckpt_untied"
     cfg, w, g = load_case(name)
     entries = cli_vocab(cfg.vocab_size)
@@ -138,8 +141,14 @@ def test_engine_cli_text_parity(tmp_path, path):
     want_text = "".join(decode(tok.vocab[i]) if i != 0 else None for i in want_ids) if 0 not in want_ids else None
     import os
     env = dict(os.environ, RAMA_PATH=path)
+    env.pop("RAMA_REF_ORDER", None)
+    if ref_order is not None:
+        env["RAMA_REF_ORDER"] = ref_order
     r = subprocess.run([str(ENGINE), "-m", str(GOLDEN / f"{name}.bin"), "-t", str(tokp), "-p", prompt, "-s", str(steps), "-r", "0"],
                        capture_output=True, text=True, env=env, timeout=120)
+    if ref_order == "7":
+        assert r.returncode == 2 and "RAMA_REF_ORDER" in r.stderr
+        return
     if want_text is None:
         assert r.returncode == 101
         return
