@@ -68,6 +68,8 @@ def parse(argv=None):
     ap.add_argument("--no-prefill", action="store_true", help="skip the prompt-ingestion (rama_prefill) figures")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the stories15M / stories110M lines")
     ap.add_argument("--no-sampled", action="store_true", help="skip the `-r 1` (top-p sampled) timings")
+    ap.add_argument("--no-by-position", action="store_true", help="skip the timings at 200 / 1 000 / 1 900 positions of context")
+    ap.add_argument("--no-trait-ops", action="store_true", help="skip the 1:1 Device-op path on tensor-by-tensor uploads")
     ap.add_argument("--no-placement-tuning", action="store_true", help="accepted and ignored (round-1 flag: the tuner is gone)")
     ap.add_argument("--pos0", type=int, default=0,
                     help="start the timed generation at this position over a pre-filled (zero) cache: long-context timing, "
@@ -248,6 +250,80 @@ def time_prefill(dev, model, mode, n_positions, V):
     return {"positions": n_positions, "ms": round(best * 1e3, 2), "prompt_tok_s": round(n_positions / best, 1)}
 
 
+def by_position(dev, model, modes, graph, seq, points=(200, 1000, 1900), steps=32, warmup=4):
+    """tokens/s with the context already `p` positions long (README.md:80-83 generates 200 tokens; the cache holds 2 048): the attention of
+    cpu.rs:23-52 grows with the position, the matvecs do not.  The cache rows in front are zeros -- the launches and their traffic are those of
+    a real context.  {mode: {p: {tok_s, ms_per_step, positions}}}"""
+    import rama_amd
+    out = {}
+    for mode in modes:
+        eng = rama_amd.Engine(dev, model)
+        eng.set_tuning("ref_order", REF_ORDER[mode])
+        for k_, v_ in TUNE:
+            eng.set_tuning(k_, v_)
+        eng.set_graph_mode(bool(graph))
+        d = {}
+        for p in points:
+            pos0 = max(0, min(p, seq - steps) - warmup)
+            wall_ms, _, _, _ = time_decode(eng, dev, seq, steps, warmup, pos0, PROMPT if pos0 == 0 else [])
+            d[str(p)] = {"tok_s": round(steps / (wall_ms * 1e-3), 2), "ms_per_step": round(wall_ms / steps, 4),
+                         "positions": f"{pos0 + warmup}..{pos0 + warmup + steps - 1}"}
+        eng.set_tuning("ref_order", 0)
+        eng.free()
+        out[mode] = d
+    return out
+
+
+def trait_ops_path(dev, name, model, modes, graph, n_fwd=8):
+    """The boundary as the reference drives it: weights uploaded TENSOR BY TENSOR (hbm.rs:55-90; here filled on the device with the
+    resident model's values), then per token either forward() composed from the 1:1 Device ops (infer.rs:8-53 op for op, ~1 700 calls per token
+    through ctypes at llama2-7B: 32 apply_position calls per layer) or the fused entry rama_forward on the same tensors -- which adopts them and
+    runs the resident model's kernels.  Host-driven loops, no sampling; logits compared bit for bit with the resident model's."""
+    import numpy as np
+    import rama_amd
+    from rama_amd._lib import check
+    d, h, L, H, V, seq, shared = SHAPES[name]
+    cfg = rama_amd.Config(d, h, L, H, H, V, seq, shared)
+    ws = rama_amd.TransformerWeights.synth(cfg, 0, dev)
+    wv = rama_amd.TransformerWeightsView.from_gpu_ws(ws)
+    rs = rama_amd.RunState.from_config(cfg, dev)
+    rsv = rama_amd.RunStateView.from_rs(rs)
+    ref = rama_amd.Engine(dev, model)
+    out = {"calls_per_token_1to1": 2 + L * (17 + H) + 3, "host": "python/ctypes"}
+    try:
+        for mode in modes:
+            check(dev.lib.rama_set_tuning(dev.ctx, b"ref_order", REF_ORDER[mode]))
+            for k_, v_ in TUNE:
+                check(dev.lib.rama_set_tuning(dev.ctx, k_.encode(), v_))
+            same, worst = True, 0.0
+            for path, fwd in (("ops", rama_amd.forward), ("fused_entry", rama_amd.forward_fused)):
+                check(dev.lib.rama_set_graph_mode(dev.ctx, 1 if (graph and path == "fused_entry") else 0))
+                token = 1
+                for pos in range(3):      # warm-up (the chain-order copies are made here) and the check against the resident model
+                    fwd(cfg, wv, rsv, token, pos, dev)
+                    ref.forward(token, pos)
+                    lg = dev.download(rsv.logits)
+                    rl = ref.logits()
+                    same = same and np.array_equal(lg.view(np.uint32), rl.view(np.uint32))
+                    worst = max(worst, float(np.abs(lg - rl).max()))
+                    token = int(np.flatnonzero(lg == lg.max())[-1])
+                dev.sync()
+                t0 = time.perf_counter()
+                for pos in range(3, 3 + n_fwd):
+                    fwd(cfg, wv, rsv, token, pos, dev)
+                dev.sync()
+                out[f"{mode}_{path}_tok_s"] = round(n_fwd / (time.perf_counter() - t0), 2)
+            # (parity mode: the same bits whatever the path; fast mode: W1 and W3 as two tensors sum in another order than the resident model's
+            # row-interleaved copy -- a few 1e-6 apart)
+            out[f"{mode}_logits_bit_identical_to_resident_model"] = bool(same)
+            out[f"{mode}_worst_vs_resident_model"] = worst
+            check(dev.lib.rama_set_graph_mode(dev.ctx, 0))
+    finally:
+        check(dev.lib.rama_set_tuning(dev.ctx, b"ref_order", 0))
+        ref.free(); rs.free(); ws.free()
+    return out
+
+
 def kernel_times(eng, cfg_seq, pos, tokens, bytes_, ksteps=16):
     """per-launch device time of every kernel class over `ksteps` eager decode steps (events carried by the dispatch;
     `sample`: event records around Device::sample's launches); us_per_step = avg_us x launches per step, so the classes
@@ -375,6 +451,8 @@ def single_gpu(args, local_rank):
     if not args.no_prefill:
         prefill = {m_: time_prefill(dev, model, m_, min(256, seq), V) for m_ in modes}
     cpu, check = (None, {}) if args.no_cpu_baseline else baseline_for(args.config, model, args.cpu_tokens)
+    bypos = None if (args.no_by_position or seq < 512) else by_position(dev, model, modes, args.graph, seq)
+    trait = None if args.no_trait_ops else trait_ops_path(dev, args.config, model, modes, args.graph)
     model.free()
 
     others = {}
@@ -433,6 +511,12 @@ def single_gpu(args, local_rank):
     if full:
         line["worst_vs_oracle_200_positions"] = full[head]
         line["worst_vs_oracle_200_positions_source"] = full["source"]
+    if bypos:
+        for m_ in modes:
+            line[("tolerance" if m_ == "tol" else m_) + "_mode"]["by_position"] = bypos[m_]
+        line["by_position"] = bypos[head]      # the headline mode with 200 / 1 000 / 1 900 positions of context in front
+    if trait:
+        line["trait_ops_path"] = trait
     if prefill:
         line["prefill"] = prefill      # prompt ingestion (rama_prefill), the same resident model; not part of `value`
     if others:

@@ -381,6 +381,28 @@ def run_pipeline_bench_native(args, cfg, rank: int, world: int, local_rank: int)
         t1 = torch.tensor([d1], dtype=torch.float64)
         dist.all_reduce(t1, op=dist.ReduceOp.MAX)
         single_dt = (float(t1.item()), ss_steps)
+    # ... and the aggregate with 200 / 1 000 / 1 900 positions of context in front (bench.py by_position, the same points as the N = 1 line): ONE
+    # generation of the N sequences to position 1 932, three timed windows of 32 positions on the way (barrier + synchronize on either side of each)
+    bypos = None
+    if not getattr(args, "no_by_position", False) and cfg.seq_len >= 512:
+        points, win = [p for p in (200, 1000, 1900) if p + 32 <= cfg.seq_len], 32
+        planp = st.plan(points[-1] + win, PROMPT, wrap=cfg.seq_len)
+        totalp = st.total_ticks(planp)
+        bypos, at = {}, 0
+        for p in points:
+            st.run_ticks(planp, at, p * n_seq)
+            st.dev.sync(); torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            st.run_ticks(planp, p * n_seq, (p + win) * n_seq)
+            st.dev.sync(); torch.cuda.synchronize()
+            dist.barrier()
+            tp = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+            dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+            at = (p + win) * n_seq
+            bypos[str(p)] = {"tok_s": round(win * n_seq / float(tp.item()), 2), "ms_per_step": round(float(tp.item()) * 1e3 / win, 4), "positions": f"{p}..{p + win - 1}"}
+        st.run_ticks(planp, at, totalp)       # drain, untimed
+        st.dev.sync()
     roofline = None
     n_local = st.stage.layer_end - st.stage.layer_begin
     if n_local > 0 and not args.no_kprof:
@@ -402,6 +424,8 @@ def run_pipeline_bench_native(args, cfg, rank: int, world: int, local_rank: int)
                        graphs, rccl_ranks=nr.value, mode=head)
     for m_ in modes:
         line[("tolerance" if m_ == "tol" else m_) + "_mode"] = {"tok_s": round(args.steps * n_seq / timed[m_], 3), "ms_per_step": round(timed[m_] * 1e3 / args.steps, 4)}
+    if bypos:
+        line["by_position"] = bypos
     if single_dt:
         line["single_stream_tok_s"] = round(single_dt[1] / single_dt[0], 3)       # one sequence in flight through the N stages (same mode as `value`)
         line["single_stream_ms_per_token"] = round(single_dt[0] * 1e3 / single_dt[1], 4)

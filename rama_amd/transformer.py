@@ -278,6 +278,33 @@ class TransformerWeights:
         return TransformerWeights(cfg, t, not cfg.shared_weight)
 
     @staticmethod
+    def synth(cfg: Config, seed: int, device: Hip) -> "TransformerWeights":
+        """the synthetic weights of rama_model_synth (csrc/model.hip: same tags, scales and RoPE tables, so the same bits), but ONE ALLOCATION
+        PER TENSOR like hbm.rs:55-90 and filled on the device -- what bench.py's `trait_ops_path` runs at llama2-7B without 27 GB of host memory"""
+        ih4_std = np.sqrt(4.0 * (65536.0 * 65536.0 - 1.0) / 12.0)
+        res = 0.02 / np.sqrt(2.0 * cfg.n_layers)
+        spec = {"token_embedding_table": (1, 0.02, 0.0), "rms_att_weight": (2, 0.05, 1.0), "wq": (3, 0.02, 0.0), "wk": (4, 0.02, 0.0),
+                "wv": (5, 0.02, 0.0), "wo": (6, res, 0.0), "rms_ffn_weight": (7, 0.05, 1.0), "w1": (8, 0.02, 0.0), "w2": (9, 0.02, 0.0),
+                "w3": (10, res, 0.0), "rms_final_weight": (11, 0.05, 1.0), "wcls": (12, 0.02, 0.0)}
+        hs = cfg.head_size
+        f = 1.0 / np.power(10000.0, (2.0 * np.arange(hs // 2)) / hs)
+        ang = np.arange(cfg.seq_len, dtype=np.float64)[:, None] * f[None, :]
+        t = {}
+        for name, shp in weight_shapes(cfg):
+            n = int(np.prod(shp))
+            if name.startswith("freq_cis"):
+                t[name] = device.allocate((np.cos(ang) if name.endswith("real") else np.sin(ang)).astype(np.float32))
+                continue
+            p = C.c_void_p()
+            check(device.lib.rama_alloc_f32(device.ctx, n, C.byref(p)), "rama_alloc_f32")
+            tag, std, bias = spec[name]
+            check(device.lib.rama_fill_synth(device.ctx, p, n, seed, tag, 0, float(std / ih4_std), bias), "rama_fill_synth")
+            t[name] = HipSlice(device, p.value, n)
+        if cfg.shared_weight:
+            t["wcls"] = device.allocate(np.array([1.0], dtype=np.float32))   # ram.rs:46 placeholder
+        return TransformerWeights(cfg, t, not cfg.shared_weight)
+
+    @staticmethod
     def from_file(path, cfg: Config, device: Hip) -> "TransformerWeights":
         """ram.rs:28-51 order; tensors read from a memory map, then uploaded."""
         body = np.memmap(path, dtype="<f4", mode="r", offset=28)

@@ -152,7 +152,7 @@ def test_n1_pipeline_rehearsal_agrees_with_the_plain_n1_line():
     from pathlib import Path
     repo = Path(__file__).resolve().parent.parent
     cmd = [sys.executable, str(repo / "bench.py"), "--gpus", "1", "--mode", "parity", "--steps", "48", "--warmup", "8",
-           "--no-other-configs", "--no-cpu-baseline", "--no-prefill", "--no-kprof", "--no-sampled"]
+           "--no-other-configs", "--no-cpu-baseline", "--no-prefill", "--no-kprof", "--no-sampled", "--no-by-position", "--no-trait-ops"]
 
     def run(extra_env):
         env = dict(os.environ, **extra_env)

@@ -5,7 +5,7 @@ name=$1; shift
 i=0
 for t in "$@"; do
   args=""; if [ "$t" != "-" ]; then for kv in $t; do args="$args --tune $kv"; done; fi
-  python bench.py --mode parity --steps 64 --warmup 8 --no-cpu-baseline --no-prefill --no-other-configs --no-sampled $args > gpurun_out/${name}_$i.json 2> gpurun_out/${name}_$i.err || exit 1
+  python bench.py --mode parity --steps 64 --warmup 8 --no-cpu-baseline --no-prefill --no-other-configs --no-sampled --no-by-position --no-trait-ops $args > gpurun_out/${name}_$i.json 2> gpurun_out/${name}_$i.err || exit 1
   python - <<PY
 import json
 d = json.load(open("gpurun_out/${name}_$i.json"))

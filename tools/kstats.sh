@@ -8,7 +8,7 @@ out=$repo/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/_ks_$name
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/_ks_$name -o t -- python3 $repo/bench.py --steps 32 --warmup 4 --graph 0 --no-cpu-baseline --no-kprof --no-prefill "$@" > $out/${name}_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/_ks_$name -o t -- python3 $repo/bench.py --steps 32 --warmup 4 --graph 0 --no-cpu-baseline --no-kprof --no-prefill --no-by-position --no-trait-ops "$@" > $out/${name}_bench.log 2>&1
 cp $(find /tmp/_ks_$name -name '*kernel_stats.csv' | head -1) $out/${name}_kernel_stats.csv
 python3 - $out/${name}_kernel_stats.csv <<'PY'
 import csv, sys
