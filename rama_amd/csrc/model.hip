@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -217,6 +218,11 @@ bool alloc_of(const float* p, const float** base, size_t* n) {
     return true;
 }
 
+// advances whenever a derived copy (chain order, tile order, a view's) is freed: captured graphs hold the copies' addresses, and the context that
+// frees them (rama_model_release_copies, rama_model_free, rama_free of an adopted tensor) drops only its OWN graphs -- every other context
+// compares its graphs' generation with this one before a replay (rama_api.hip same_capture) and captures again
+std::atomic<unsigned long long> g_copies_gen{1};
+
 std::vector<rama_model*> g_models;     // every live model: lets the lazily made copies be found from a rama_weights
 std::mutex g_models_mu;
 
@@ -259,6 +265,7 @@ int make_chain(rama_ctx* ctx, rama_model* m) {
 
 void drop_chain(rama_ctx* ctx, rama_model* m) {
     if (!m->chain) return;
+    g_copies_gen++;
     {
         std::lock_guard<std::mutex> lk(g_chain_mu);
         const float* lo = m->chain;
@@ -273,6 +280,7 @@ void drop_chain(rama_ctx* ctx, rama_model* m) {
 
 void drop_tiled(rama_ctx* ctx, rama_model* m) {
     if (!m->tiled) return;
+    g_copies_gen++;
     {
         std::lock_guard<std::mutex> lk(g_tiled_mu);
         const float* lo = m->tiled;
@@ -307,6 +315,8 @@ bool model_holds(const rama_model* m, const float* p, size_t n) {
 }
 
 }  // namespace
+
+extern "C" unsigned long long rama_internal_copies_generation() { return g_copies_gen.load(); }
 
 // internal: the tile-order copy of a row-major weight tensor (by its base address) a model registered, or NULL
 extern "C" const float* rama_internal_tiled_lookup(const float* src) {
@@ -397,6 +407,7 @@ extern "C" int rama_internal_forget_range(rama_ctx* ctx, const float* base, size
         }
     }
     if (gone.empty() && views.empty()) return 0;
+    g_copies_gen++;
     int rc = ctx ? rama_sync(ctx) : 0;
     if (ctx) rama_internal_drop_graphs(ctx);
     for (rama_model* m : gone) { drop_chain(ctx, m); drop_tiled(ctx, m); delete m; }
@@ -673,7 +684,9 @@ extern "C" int rama_model_release_copies(rama_ctx* ctx, rama_model* m, int mask)
 }
 extern "C" int rama_model_free(rama_ctx* ctx, rama_model* m) {
     if (!m) return 0;
-    { std::lock_guard<std::mutex> lk(g_models_mu); g_models.erase(std::remove(g_models.begin(), g_models.end(), m), g_models.end()); }
+    { std::lock_guard<std::mutex> lk(g_models_mu); g_models.erase(std::remove(g_models.begin(), g_models.end(), m), g_models.end()); }      // nobody finds it any more
+    { std::lock_guard<std::mutex> bl(m->build_mu); }      // ... and whoever found it before and is making a copy right now has finished
+    if (ctx) { rama_sync(ctx); rama_internal_drop_graphs(ctx); }
     drop_chain(ctx, m);
     if (m->w13i) {
         {

@@ -27,6 +27,7 @@ extern "C" const float* rama_internal_tiled_lookup(const float* src);           
 extern "C" const float* rama_internal_chain_lookup(const float* a, int rows, int K);     // model.hip
 extern "C" int rama_internal_model_ensure(rama_ctx* ctx, const rama_weights* w, int what);       // model.hip: 1 = chain order, 2 = tile order
 extern "C" int rama_internal_model_ensure_ptr(rama_ctx* ctx, const float* p, int what);
+extern "C" unsigned long long rama_internal_copies_generation();                                           // model.hip: advances whenever a derived weight copy is freed
 extern "C" void rama_internal_note_alloc(const float* base, size_t n);                                   // model.hip: the allocation table
 extern "C" int rama_internal_forget_range(rama_ctx* ctx, const float* base, size_t n, int freed);      // ... the copies derived from a range go
 extern "C" int rama_internal_adopt(rama_ctx* ctx, const rama_config* cfg, const rama_stage* st, const rama_weights* w);
@@ -77,6 +78,7 @@ struct GraphCache {
     rama_run_state s{};
     bool valid = false;
     int steps = 1;                     // decode steps in the captured graph
+    unsigned long long copies_gen = 0; // model.hip's generation of derived weight copies at capture: a graph holds their addresses, and ANOTHER context may free them
 };
 
 struct rama_ctx {
@@ -346,7 +348,9 @@ int rama_ctx_destroy(rama_ctx* c) {
 // The launches that hand data over INSIDE a kernel (attention+Wo, the one-launch stage) bound every wait and report a wait that gave up
 // through the error word at pbar[1]; their results are then invalid.  Every synchronising exit reads the word -- once the stream is idle
 // -- fails the call and clears it, so that neither garbage logits leave with rc 0 nor a stale word makes every later launch give up.
+static int topp_dist_check(rama_ctx* c);
 static int handoff_check(rama_ctx* c) {
+    { const int rt = topp_dist_check(c); if (rt) return rt; }
     if (!c->handoff_dirty || !c->pbar) return 0;
     unsigned long long perr = 0;
     HIPCHK(hipMemcpyAsync(&perr, c->pbar + 1, sizeof perr, hipMemcpyDeviceToHost, c->stream));
@@ -1418,7 +1422,7 @@ static int run_stage(rama_ctx* c, const rama_config* cfg, const rama_weights* w,
         if (rc) { if (e.g.graph) hipGraphDestroy(e.g.graph); return rc; }
         HIPCHK(err);
         HIPCHK(hipGraphInstantiate(&e.g.exec, e.g.graph, nullptr, nullptr, 0));
-        e.g.cfg = *cfg; e.g.w = *w; e.g.s = *s; e.g.valid = true; e.st = *st; e.variant = variant;
+        e.g.cfg = *cfg; e.g.w = *w; e.g.s = *s; e.g.valid = true; e.g.copies_gen = rama_internal_copies_generation(); e.st = *st; e.variant = variant;
         c->sg.push_back(e);
         hit = &c->sg.back();
     }
@@ -1499,6 +1503,26 @@ static ToppDistParams topp_dist_params(rama_ctx* c) {
     d.epoch = (const unsigned*)(d.cross + 2);
     d.bad = (unsigned*)(d.cross + 2) + 1;
     return d;
+}
+// The error word of the distributed top-p pick (topp_pick.hpp ToppDistParams::bad; bit 0: a bounded wait gave up -- the launch then drained without
+// ending the step: no token, the cursor not advanced; bit 1: a predicted binade did not hold -- the token came from wrong sums) is read at every
+// synchronising exit like the hand-off word above: the call fails and the word is cleared, so that one hiccup neither leaves with rc 0 nor
+// makes every later launch give up its waits after 1 024 spins (bit 0 is what the waiting workgroups watch).  The stream is idle when this runs.
+static int topp_dist_check(rama_ctx* c) {
+    if (!c->topp_dist) return 0;
+    unsigned bad = 0;
+    unsigned* word = topp_dist_params(c).bad;
+    HIPCHK(hipMemcpy(&bad, word, sizeof bad, hipMemcpyDeviceToHost));
+    if (!bad) return 0;
+    HIPCHK(hipMemset(word, 0, sizeof bad));
+    return fail(RAMA_EINVAL, (bad & 1u) ? "top-p sampler: a hand-off of the distributed pick timed out (no token was produced)"
+                                        : "top-p sampler: a predicted binade of the running sum did not hold (the token is not trustworthy)", __FILE__, __LINE__);
+}
+// test entry (not in the C ABI header): set the word, as a launch whose wait gave up would
+extern "C" int rama_internal_topp_dist_poke(rama_ctx* c, unsigned value) {
+    if (!c || !c->topp_dist) return 1;
+    hipStreamSynchronize(c->stream);
+    return hipMemcpy(topp_dist_params(c).bad, &value, sizeof value, hipMemcpyHostToDevice) != hipSuccess;
 }
 // diagnostics (not in the C ABI header): bit 0 a hand-off wait of topp_pick_dist_kernel timed out, bit 1 a predicted binade did not hold
 extern "C" int rama_internal_topp_dist_bad(rama_ctx* c, unsigned* bad) {
@@ -2274,6 +2298,7 @@ int rama_decode_batch_tokens(rama_ctx* c, int32_t* out_host, int max_per_seq, in
     auto& bc = c->bc;
     const int n = std::min(bc.steps_done, max_per_seq);
     HIPCHK(hipStreamSynchronize(c->stream));
+    { const int rh = handoff_check(c); if (rh) return rh; }
     for (int s_ = 0; s_ < bc.n_seq && n > 0; s_++)
         HIPCHK(hipMemcpy(out_host + (size_t)s_ * max_per_seq, bc.out + (size_t)s_ * bc.out_cap, sizeof(int) * n, hipMemcpyDeviceToHost));
     *n_per_seq = n;
@@ -2347,7 +2372,7 @@ static int enqueue_decode_step(rama_ctx* c, const rama_config* cfg, const rama_w
 }
 
 static bool same_capture(const GraphCache& g, const rama_config* cfg, const rama_weights* w, const rama_run_state* s) {
-    return g.valid && !memcmp(&g.cfg, cfg, sizeof *cfg) && !memcmp(&g.w, w, sizeof *w) && !memcmp(&g.s, s, sizeof *s);
+    return g.valid && g.copies_gen == rama_internal_copies_generation() && !memcmp(&g.cfg, cfg, sizeof *cfg) && !memcmp(&g.w, w, sizeof *w) && !memcmp(&g.s, s, sizeof *s);
 }
 
 int rama_decode_steps(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s, int n_steps) {
@@ -2388,7 +2413,7 @@ int rama_decode_steps(rama_ctx* c, const rama_config* cfg, const rama_weights* w
                 if (rc) return rc;
                 HIPCHK(e);
                 HIPCHK(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
-                g.cfg = *cfg; g.w = *w; g.s = *s; g.valid = true; g.steps = take;
+                g.cfg = *cfg; g.w = *w; g.s = *s; g.valid = true; g.copies_gen = rama_internal_copies_generation(); g.steps = take;
             }
             HIPCHK(hipGraphLaunch(g.exec, c->stream));
         } else {
@@ -2429,6 +2454,7 @@ int rama_decode_tokens(rama_ctx* c, int32_t* out_host, int max_tokens, int* n_ou
         hipMemsetAsync(c->pbar, 0, 4 * sizeof(unsigned long long), c->stream);   // counter, error word, base: start over
         return fail(RAMA_EINVAL, perr >= kFusedErr ? "one-launch stage: a hand-off timed out" : "attention+Wo launch: hand-off timed out", __FILE__, __LINE__);
     }
+    { const int rt = topp_dist_check(c); if (rt) return rt; }
     if (c->topp_err) {
         unsigned terr = 0;
         HIPCHK(hipMemcpy(&terr, c->topp_err, sizeof terr, hipMemcpyDeviceToHost));

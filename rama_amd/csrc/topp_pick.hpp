@@ -100,7 +100,7 @@ __device__ __forceinline__ float pick_ripple(float cum, float f0, float f1, int 
                              "v_and_b32_dpp %2, %3, %6 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
                              "v_add_f32_dpp %0, %3, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
                              "v_add_f32_dpp %1, %3, %5 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                             : "+v"(x0), "+v"(x1), "+v"(par) : "v"(c), "v"(f0), "v"(f1), "v"(one));
+                             : "+&v"(x0), "+&v"(x1), "+&v"(par) : "v"(c), "v"(f0), "v"(f1), "v"(one));      // (early-clobber: %3 is read after %0 and %2 are written)
                 c = par ? x1 : x0;
             }
         }

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(1024) void topp_stats_kernel(ToppSortParams p, Topp
 #pragma unroll
     for (int w = 1; w < 16; w++) mx = fmaxf(mx, s_r[w]);
     __syncthreads();
-    float sum = wave_sum(i < p.n ? expf(x - mx) : 0.0f);
+    float sum = wave_sum((i < p.n && mx != -INFINITY) ? expf(x - mx) : 0.0f);      // (a chunk of -inf logits -- a masked vocabulary -- has no mass, not exp(nan))
     if (lane == 0) s_r[wave] = sum;
     __syncthreads();
     if (tid == 0) {
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(BS) void topp_blocksort_bs_kernel(ToppSortParams p,
     const float lg = p.logits[min(i, p.n - 1)];                   // (requested with the statistics)
     const ToppStats part = st[min(lane, nstat - 1)];
     const float mx = wave_max(part.mx);                            // (lanes behind the last partial repeat it: the maximum does not mind)
-    const float sum = wave_sum(lane < nstat ? part.sum * expf(part.mx - mx) : 0.0f);
+    const float sum = wave_sum((lane < nstat && part.mx != -INFINITY) ? part.sum * expf(part.mx - mx) : 0.0f);
     const float cutoff = (1.0f - p.topp) / (float)(p.n - 1);      // infer.rs:56
     __syncthreads();
     {

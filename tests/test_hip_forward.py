@@ -661,7 +661,7 @@ def test_stories_fast_mode_readme_length(dev, shape):
     FAST mode -- what the stories tok/s figures of bench.py are quoted for, the whole token in one launch (layer_fused.hpp) --
     against the oracle at every one of the 200 positions: |dlogit| <= 1e-4, greedy tokens identical, and the device-chained
     generate() (one-launch stage + sampler, replayed from hipGraphs) producing the oracle's 200 tokens.  The per-position
-    record goes to gpurun_out/r04_parity_<shape>_200pos.json (copied to profiles/ by the builder)."""
+    record goes to gpurun_out/r05_parity_<shape>_200pos.json (copied to profiles/ by the builder)."""
     import json
     from pathlib import Path
     import rama_amd
@@ -695,7 +695,7 @@ def test_stories_fast_mode_readme_length(dev, shape):
            "worst_hip_fast_vs_oracle": max(r["hip_fast_vs_oracle"] for r in rows),
            "positions_over_bar": [r["pos"] for r in rows if r["hip_fast_vs_oracle"] > LOGIT_ATOL],
            "greedy_tokens_equal": toks_cpu == toks_hip, "chained_generate_equals_oracle": chained == want, "per_position": rows}
-    path = Path(__file__).resolve().parent.parent / "gpurun_out" / f"r04_parity_{shape}_200pos.json"
+    path = Path(__file__).resolve().parent.parent / "gpurun_out" / f"r05_parity_{shape}_200pos.json"
     try:
         path.parent.mkdir(parents=True, exist_ok=True)
         path.write_text(json.dumps(out, indent=1))

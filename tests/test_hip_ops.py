@@ -299,6 +299,27 @@ def test_sample_topp_dev_matches_oracle(dev, n, scale, seed, temperature, topp, 
         assert u * min(topp, 1.0) > 0.9, "a mismatch away from the tail is a bug"
 
 
+@pytest.mark.parametrize("n", [32000, 5000, 2500])
+@pytest.mark.parametrize("temperature,topp,u", [(1.0, 0.9, 0.2721174359321594), (0.7, 0.95, 0.5)])
+def test_sample_topp_dev_masked_vocabulary(dev, n, temperature, topp, u):
+    """[r5] whole 1 024-entry stretches of -inf logits: the per-stretch softmax partial has no mass (it was exp(-inf - -inf) = nan, and every
+    probability with it); the oracle's token on every path"""
+    from rama_amd._lib import check
+    x = rnd(n, 31 + n % 7, 1.5)
+    x[1024:2048] = -np.inf
+    if n > 4096:
+        x[3072:4096] = -np.inf
+    x[n - 1100:] = -np.inf
+    want = O.sample(x.copy(), temperature, topp, u)
+    assert want >= 0
+    for key, val in ((b"topp_block", 1024), (b"topp_block", 512), (b"topp_block", 2048)):      # (2 048: round 3's sort, every workgroup its own statistics)
+        check(dev.lib.rama_set_tuning(dev.ctx, key, val))
+        try:
+            assert _topp_dev(dev, x, temperature, topp, u) == want, (key, val)
+        finally:
+            check(dev.lib.rama_set_tuning(dev.ctx, b"topp_block", 1024))
+
+
 @pytest.mark.parametrize("n", [2, 65, 2047, 2048, 2049, 4097, 20000, 32000, 32768])
 def test_sample_topp_dev_pair_ranking_equals_lds_ranking(dev, n):
     """the sorted blocks are merged into one order either by topp_rank_kernel (every workgroup searches all other blocks in its
@@ -408,7 +429,8 @@ def _seq_cumsum_until(p, topp):
 
 TOPP_SUM_CASES = [("flat", 32000, 0.05, 0.9), ("flat", 32000, 0.05, 1.0), ("ordinary", 32000, 3.0, 0.9), ("peaked", 32000, 12.0, 0.95),
                   ("equal", 32000, 0.0, 0.9), ("equal", 30011, 0.0, 0.99), ("two_levels", 32000, 0.0, 0.9), ("pow2", 32768, 0.0, 0.9),
-                  ("flat", 2049, 0.1, 0.9), ("ordinary", 4097, 2.0, 0.999), ("flat", 100, 0.1, 0.5), ("steps", 32000, 0.0, 0.97)]
+                  ("flat", 2049, 0.1, 0.9), ("ordinary", 4097, 2.0, 0.999), ("flat", 100, 0.1, 0.5), ("steps", 32000, 0.0, 0.97),
+                  ("masked", 32000, 1.0, 0.9), ("masked", 5000, 0.1, 0.95)]
 
 
 def _dist_bad(dev):
@@ -420,6 +442,31 @@ def _dist_bad(dev):
     f.argtypes = [C.c_void_p, C.POINTER(C.c_uint)]
     assert f(dev.ctx, C.byref(bad)) == 0
     return bad.value
+
+
+def test_topp_dist_error_word_fails_the_next_synchronising_call_and_is_cleared(dev):
+    """[r5] the distributed pick's error word (a wait that gave up / a prediction that did not hold) is read at the synchronising exits like the
+    in-launch hand-offs' word: the call fails, the word is cleared -- a hiccup neither leaves with rc 0 nor poisons the context"""
+    import ctypes as C
+    import rama_amd
+    from rama_amd._lib import check
+    x = (np.random.default_rng(5).standard_normal(32000) * 0.05).astype(np.float32)
+    tl = rama_amd.MutView(dev.allocate(x))
+    res = rama_amd.MutView(dev.allocate(np.zeros(4, np.float32)))
+    check(dev.lib.rama_sample_topp_dev(dev.ctx, tl.ptr, x.size, 1.0, 0.9, 0.3, res.ptr))      # makes the scratch, runs the distributed pick
+    dev.sync()
+    assert _dist_bad(dev) == 0
+    want = int(dev.download(res).view(np.int32)[0])
+    poke = dev.lib.rama_internal_topp_dist_poke
+    poke.restype = C.c_int
+    poke.argtypes = [C.c_void_p, C.c_uint]
+    for word in (1, 2):
+        assert poke(dev.ctx, word) == 0
+        assert dev.lib.rama_sync(dev.ctx) != 0, "a raised error word left rama_sync with rc 0"
+        assert b"top-p sampler" in dev.lib.rama_last_error()
+        assert dev.lib.rama_sync(dev.ctx) == 0 and _dist_bad(dev) == 0, "the word was not cleared"
+        check(dev.lib.rama_sample_topp_dev(dev.ctx, tl.ptr, x.size, 1.0, 0.9, 0.3, res.ptr))
+        assert int(dev.download(res).view(np.int32)[0]) == want
 
 
 @pytest.mark.parametrize("dist", [1, 0])
@@ -440,6 +487,8 @@ def test_sample_topp_dev_running_sums_are_the_sequential_ones(dev, kind, n, scal
         x = (np.arange(n) // 1000).astype(np.float32) * np.float32(0.6931472)       # 32 plateaus, each twice the last
     else:
         x = rnd(n, 7 + n % 13, scale)
+        if kind == "masked":                                  # [r5] whole 1 024-entry stretches of -inf logits (a masked vocabulary): no mass, no nan
+            x[1024:3072] = -np.inf; x[n - 900:] = -np.inf
     from rama_amd._lib import check
     check(dev.lib.rama_set_tuning(dev.ctx, b"topp_keep_sums", 1))
     check(dev.lib.rama_set_tuning(dev.ctx, b"topp_dist", dist))       # the sums by 32 workgroups in one launch (default) | one workgroup's scan rounds

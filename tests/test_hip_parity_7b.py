@@ -18,7 +18,7 @@ Per position five logit vectors are compared:
              that says how far each fp32 path sits from the exact result
 All four are fed the SAME token sequence (the oracle's greedy choice), so caches stay comparable.
 
-The per-position numbers are written to gpurun_out/r04_parity_llama2_7b_200pos.json (copied to
+The per-position numbers are written to gpurun_out/r05_parity_llama2_7b_200pos.json (copied to
 profiles/ by the builder) whatever the outcome; the assertions come last.
 
 What is asserted, and why not simply "fast path within 1e-4 of the oracle": the reference arithmetic
@@ -153,7 +153,7 @@ def test_llama2_7b_full_depth_200_positions(dev):
         "f64_s_per_token": round(t_f64 / n_pos, 3), "oracle_threads": threads,
         "per_position": rows,
     }
-    path = Path(os.environ.get("RAMA_PARITY_JSON", REPO / "gpurun_out" / "r04_parity_llama2_7b_200pos.json"))
+    path = Path(os.environ.get("RAMA_PARITY_JSON", REPO / "gpurun_out" / "r05_parity_llama2_7b_200pos.json"))
     try:
         path.parent.mkdir(parents=True, exist_ok=True)
         path.write_text(json.dumps(out, indent=1))
