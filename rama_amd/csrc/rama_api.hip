@@ -169,6 +169,7 @@ struct rama_ctx {
     int tune_chain_awo = 0;                // parity mode, short contexts: attention + Wo as one launch, the Wo groups' first 4 x this many KiB requested while the attention runs (0: two launches)
     unsigned long long* awo_flags = nullptr;    // device: [kAwoLayers][kAwoHeads] tagged words
     int tune_chain_norm = 1;               // parity mode, dim <= 512: the layer norms folded into the matvecs that consume them
+    int tune_chain_resid_d = -1;           // parity mode: 100 W + D for the residual products (Wo, W2) only; 0: by the number of row groups like the others; -1: W = 1, D = 32 when a CU holds one group
     int tune_chain_views = 1;              // parity mode, Device::matmul on a matrix of no model: a chain-order copy of the tensor is made on first use
     int tune_prefill_chain = 1;            // parity mode: prompt positions go through the chain-order token-batch kernels (32 per weight pass); 0: one forward() each
     size_t pf_floats = 0;
@@ -570,6 +571,12 @@ static int launch_chain(rama_ctx* c, ChainParams& p, int norm = CNORM_NONE) {
     const int groups = p.nmat * ((p.rows + 15) / 16);
     int W, D;
     if (c->tune_chain_d > 0) { W = c->tune_chain_d / 100; D = c->tune_chain_d % 100; }
+    else if (EPI == CEPI_RESID && norm == CNORM_NONE && c->tune_chain_resid_d > 0) { W = c->tune_chain_resid_d / 100; D = c->tune_chain_resid_d % 100; }
+    else if (EPI == CEPI_RESID && norm == CNORM_NONE && c->tune_chain_resid_d < 0 && groups <= std::max(c->cu_count, 1) && p.K / 16 > 64) {
+        // [r5] the residual products with at most one row group per compute unit (llama2-7B's Wo and W2): ONE wave with a ring of 32 blocks -- no relay
+        // through LDS, no barrier per chunk -- Wo 15.2 -> 13.6 us, W2 33.7 -> 32.7 (profiles/r05_experiments.md)
+        W = 1; D = 32;
+    }
     else {
         const int cus = std::max(c->cu_count, 1);
         if (groups >= 5 * cus) { W = 1; D = 16; }   // W1 | W3, classifier: several groups per SIMD, each with its own ring
@@ -2669,6 +2676,13 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
     if (!strcmp(key, "chain_awo")) {
         REQUIRE(value == 0 || value == 16 || value == 32 || value == 48 || value == 64, RAMA_EINVAL, "set_tuning: chain_awo must be 0, 16, 32, 48 or 64");
         c->tune_chain_awo = value;
+        hipStreamSynchronize(c->stream);
+        drop_graph(c);
+        return 0;
+    }
+    if (!strcmp(key, "chain_resid_d")) {
+        REQUIRE(value == 0 || value == -1 || ((value / 100 == 1 || value / 100 == 2 || value / 100 == 4) && (value % 100 == 16 || value % 100 == 32)), RAMA_EINVAL, "set_tuning: chain_resid_d must be -1, 0 or 100 W + D, W in {1, 2, 4}, D in {16, 32}");
+        c->tune_chain_resid_d = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
         return 0;
