@@ -401,9 +401,14 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *                   1 = PARITY MODE: every op in the REFERENCE'S OWN rounding order (4-lane sequential matvec sums with
  *                   separate multiply and add, sequential rmsnorm / softmax sums, glibc's expf restated), results
  *                   bit-identical to the reference CPU path.  A resident model streams its chain-order weight copy
- *                   (csrc/chain.hpp; made on first use, +27 GB at llama2-7B): 5.2 ms per llama2-7B token, the dominant
- *                   matvec at 0.80 of the HBM roofline; weights uploaded tensor by tensor take csrc/ref_order.hpp's
- *                   one-thread-per-row kernels (~23 ms per token).
+ *                   (csrc/chain.hpp; made on first use, +27 GB at llama2-7B): 4.8 ms per llama2-7B token, the dominant
+ *                   matvec at 0.80 of the HBM roofline.  [r5] Weights uploaded tensor by tensor (hbm.rs:55-90) run the same
+ *                   kernels: the fused entries (rama_forward*, rama_decode_*, rama_generate*, rama_prefill) ADOPT a
+ *                   rama_weights whose matrices lie in rama_alloc_f32 / rama_upload_f32 allocations -- the same chain-order
+ *                   copies as a resident model's -- and rama_matmul makes a chain-order copy of a matrix that belongs to no
+ *                   model on first use ("chain_views").  Freeing (rama_free) or overwriting (rama_copy_h2d_f32) a tensor
+ *                   drops what was derived from it.  The host mirrors (C++ CLI, Rust shim) select this mode by default
+ *                   (RAMA_REF_ORDER=0 for the fast path); the library's own default stays 0.
  *                   2 = the tolerance-mode EXPERIMENT: parity mode's chain-order matvecs with the rmsnorm sums
  *                   tree-shaped and folded into them and the fast path's attention: 218 tok/s at llama2-7B, but 1.4e-4
  *                   from the CPU path, no closer than the fast path (profiles/r04_tolerance_sweep_7b_200pos.jsonl).
@@ -412,7 +417,18 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *                   (tools/tol_sweep.py: which op carries how much of the distance to the CPU path)
  *   "chain" = 0|1, "chain_d" = 0 | 100 W + D, "chain_norm" = 0|1, "prefill_chain" = 0|1 : parity mode's kernels -- the
  *                   chain-order copy on/off, the matvec geometry (waves per 16 rows, blocks in flight), the exact norms
- *                   folded into the matvecs (dim <= 512), prompt positions through the chain-order token-batch kernels */
+ *                   folded into the matvecs (dim <= 512), prompt positions through the chain-order token-batch kernels
+ *   "chain_lead" = 0|1 : [r5] parity mode, 512 < dim <= 4096: the layer norms' exact sums by a LEADER workgroup inside the
+ *                   consuming matvec's launch (it publishes 1 / sqrt(mean(x^2) + eps) as one tagged word; the others request
+ *                   their weights, then wait for it) instead of a launch of their own: 193 -> 204 tok/s at llama2-7B (default 1)
+ *   "chain_lead_w" = 0|1|2 : waves per row group of those launches (0 = by the number of row groups)
+ *   "chain_resid_d" = -1 | 0 | 100 W + D : [r5] geometry of parity mode's residual products (Wo, W2) alone; -1 (default) = one
+ *                   wave with a ring of 32 blocks when a compute unit holds at most one row group (llama2-7B: Wo 15.1 -> 13.5 us,
+ *                   W2 33.6 -> 32.1), 0 = like the other products
+ *   "chain_awo" = 0|16|32|48|64 : [r5] parity mode below position 128: attention + Wo as ONE launch, the Wo row groups requesting
+ *                   4 x this many KiB of their rows while the attention runs.  Bit-identical, measured SLOWER at llama2-7B
+ *                   (194 / 186 / 188 / 185 against 200 tok/s: the attention's round trips lengthen under the traffic): default 0
+ *   "chain_views" = 0|1 : parity mode's rama_matmul makes a chain-order copy of a matrix of no model on first use (default 1) */
 int  rama_set_tuning(rama_ctx *ctx, const char *key, int value);
 
 /* glibc 2.35 expf (the exp the reference's f32::exp calls on Linux) as the reference-order kernels

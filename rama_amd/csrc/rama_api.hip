@@ -169,6 +169,7 @@ struct rama_ctx {
     int tune_chain_awo = 0;                // parity mode, short contexts: attention + Wo as one launch, the Wo groups' first 4 x this many KiB requested while the attention runs (0: two launches)
     unsigned long long* awo_flags = nullptr;    // device: [kAwoLayers][kAwoHeads] tagged words
     int tune_chain_norm = 1;               // parity mode, dim <= 512: the layer norms folded into the matvecs that consume them
+    int tune_chain_lead_w = 0;             // parity mode: waves per row group of the launches with a leader norm (0: by the number of row groups)
     int tune_chain_resid_d = -1;           // parity mode: 100 W + D for the residual products (Wo, W2) only; 0: by the number of row groups like the others; -1: W = 1, D = 32 when a CU holds one group
     int tune_chain_views = 1;              // parity mode, Device::matmul on a matrix of no model: a chain-order copy of the tensor is made on first use
     int tune_prefill_chain = 1;            // parity mode: prompt positions go through the chain-order token-batch kernels (32 per weight pass); 0: one forward() each
@@ -583,6 +584,7 @@ static int launch_chain(rama_ctx* c, ChainParams& p, int norm = CNORM_NONE) {
         else { W = 2; D = 16; }                     // one to three groups per CU (tools/chain_sweep.py: 216 best or equal everywhere)
         if (p.K / 16 <= 2 * D) { W = 1; D = 16; }   // a row of a few blocks: nothing to relay
     }
+    if (norm == CNORM_LEAD && c->tune_chain_lead_w > 0 && c->tune_chain_d <= 0) { W = c->tune_chain_lead_w; D = 16; }      // ("chain_lead_w": the leader launches' waves per row group)
     if ((size_t)(p.K + chain_pad_floats(W, D, 4)) * sizeof(float) > 64 * 1024) { W = 1; D = 16; }
     const size_t lds = (size_t)(p.K + chain_pad_floats(W, D, 4)) * sizeof(float);      // x + the zeros behind it
     REQUIRE(lds <= 64 * 1024, RAMA_EUNSUP, "chain-order matvec: row longer than ~15800 floats");
@@ -2676,6 +2678,13 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
     if (!strcmp(key, "chain_awo")) {
         REQUIRE(value == 0 || value == 16 || value == 32 || value == 48 || value == 64, RAMA_EINVAL, "set_tuning: chain_awo must be 0, 16, 32, 48 or 64");
         c->tune_chain_awo = value;
+        hipStreamSynchronize(c->stream);
+        drop_graph(c);
+        return 0;
+    }
+    if (!strcmp(key, "chain_lead_w")) {
+        REQUIRE(value >= 0 && value <= 2, RAMA_EINVAL, "set_tuning: chain_lead_w must be 0, 1 or 2");
+        c->tune_chain_lead_w = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
         return 0;

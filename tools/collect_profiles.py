@@ -33,7 +33,7 @@ out = Path(a.out).resolve()
 out.mkdir(parents=True, exist_ok=True)
 tag = f"r{a.round:02d}"
 suffix = {"parity": "_parity", "tol": "_tol"}.get(a.mode, "")
-mode_args = ["--mode", a.mode, "--no-other-configs", "--no-prefill", "--config", a.config]
+mode_args = ["--mode", a.mode, "--no-other-configs", "--no-prefill", "--no-by-position", "--no-trait-ops", "--config", a.config]
 short = "7b" if a.config == "llama2-7B" else a.config
 env = dict(os.environ, TMPDIR="/tmp")
 bench = str(REPO / "bench.py")
