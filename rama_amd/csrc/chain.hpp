@@ -421,6 +421,28 @@ constexpr int kNormMax = 16384;
 #define RAMA_NORM_WAVES 4
 #endif
 constexpr int kNormWaves = RAMA_NORM_WAVES, kNormThreads = kNormWaves * 64;     // one wave per SIMD: the scan rounds are bound by instruction issue
+
+// [r5] seqsum_fast.hpp's sum (the leader workgroups') for a list that sits in LDS in scan_slot layout: thread t takes terms t R .. t R + R - 1 into
+// registers.  Lists of >= 1024 terms only (below that the ripples of seq_sum_predict are as fast); false: the list is too short or too long,
+// or a prediction did not hold -- the caller then takes seq_sum_predict / seq_sum_exact as before.  All NW waves call it.
+constexpr int kFastSumMin = 1024;
+template <int NW, int R>
+__device__ __forceinline__ bool seq_sum_lds_fast_r(const float* a, int n, FastSumShared<NW>& fs, float* out) {
+    float v[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) { const int i = (int)threadIdx.x * R + k; const float t = a[scan_slot(min(i, n - 1))]; v[k] = i < n ? t : 0.0f; }
+    return seq_sum_fast<NW, R>(v, fs, out);
+}
+template <int NW>
+__device__ __forceinline__ bool seq_sum_lds_fast(const float* a, int n, FastSumShared<NW>& fs, float* out) {
+    const int per = (n + 64 * NW - 1) / (64 * NW);                 // uniform
+    if (n < kFastSumMin || per > 64) return false;
+    seq_sum_fast_prepare<NW>(fs);
+    if (per <= 8) return seq_sum_lds_fast_r<NW, 8>(a, n, fs, out);
+    if (per <= 16) return seq_sum_lds_fast_r<NW, 16>(a, n, fs, out);
+    if (per <= 32) return seq_sum_lds_fast_r<NW, 32>(a, n, fs, out);
+    return seq_sum_lds_fast_r<NW, 64>(a, n, fs, out);
+}
 // (a grid of several workgroups: vector b of a token batch, `stride` floats after the one before it)
 __global__ __launch_bounds__(kNormThreads) void rmsnorm_chain_kernel(float* o, const float* x, const float* w, int n, float* copy_to, int stride = 0) {
     RAMA_NO_CONTRACT
@@ -428,6 +450,7 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_chain_kernel(float* o, c
     extern __shared__ __attribute__((aligned(16))) float s_sq[];
     __shared__ SeqSumShared<kNormWaves> sh;
     __shared__ PredShared<kNormWaves> ps;
+    __shared__ FastSumShared<kNormWaves> fsn;
     const int tid = threadIdx.x;
     SEQ_STAMP(0);
     const bool vec = n % 4 == 0 && ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)o | (uintptr_t)copy_to) & 15) == 0) && n <= 16 * kNormThreads;
@@ -450,7 +473,7 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_chain_kernel(float* o, c
         }
         __syncthreads();
         float ss;
-        if (!seq_sum_predict<kNormWaves>(s_sq, n, ps, &ss)) ss = seq_sum_exact<kNormWaves>(s_sq, n, sh);
+        if (!seq_sum_lds_fast<kNormWaves>(s_sq, n, fsn, &ss)) { __syncthreads(); if (!seq_sum_predict<kNormWaves>(s_sq, n, ps, &ss)) ss = seq_sum_exact<kNormWaves>(s_sq, n, sh); }
         const float v = 1.0f / sqrtf(ss / (float)n + 1e-5f);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -468,7 +491,7 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_chain_kernel(float* o, c
     for (int i = tid; i < n; i += kNormThreads) { const float a = x[i]; s_sq[scan_slot(i)] = a * a; }
     __syncthreads();
     float ss;
-    if (!seq_sum_predict<kNormWaves>(s_sq, n, ps, &ss)) ss = seq_sum_exact<kNormWaves>(s_sq, n, sh);
+    if (!seq_sum_lds_fast<kNormWaves>(s_sq, n, fsn, &ss)) { __syncthreads(); if (!seq_sum_predict<kNormWaves>(s_sq, n, ps, &ss)) ss = seq_sum_exact<kNormWaves>(s_sq, n, sh); }
     const float v = 1.0f / sqrtf(ss / (float)n + 1e-5f);
     // every thread rewrites only the indices it reads (o may alias x: infer.rs:49-50)
     for (int i = tid; i < n; i += kNormThreads) {
@@ -484,6 +507,7 @@ __global__ __launch_bounds__(kNormThreads) void softmax_chain_kernel(float* x, i
     extern __shared__ __attribute__((aligned(16))) float s_e[];
     __shared__ SeqSumShared<kNormWaves> sh;
     __shared__ PredShared<kNormWaves> ps;
+    __shared__ FastSumShared<kNormWaves> fsn;
     __shared__ float red[16];
     const int tid = threadIdx.x;
     float mx = -INFINITY;
@@ -492,7 +516,7 @@ __global__ __launch_bounds__(kNormThreads) void softmax_chain_kernel(float* x, i
     for (int i = tid; i < n; i += kNormThreads) s_e[scan_slot(i)] = expf_glibc(x[i] - mx);
     __syncthreads();
     float sum;
-    if (!seq_sum_predict<kNormWaves>(s_e, n, ps, &sum)) sum = seq_sum_exact<kNormWaves>(s_e, n, sh);
+    if (!seq_sum_lds_fast<kNormWaves>(s_e, n, fsn, &sum)) { __syncthreads(); if (!seq_sum_predict<kNormWaves>(s_e, n, ps, &sum)) sum = seq_sum_exact<kNormWaves>(s_e, n, sh); }
     for (int i = tid; i < n; i += kNormThreads) x[i] = s_e[scan_slot(i)] / sum;
 }
 
@@ -1160,6 +1184,7 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ SeqSumShared<NW> sh;
     __shared__ PredShared<NW> ps;
+    __shared__ FastSumShared<NW> fsn;
     __shared__ float red[16];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1286,7 +1311,7 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
     __syncthreads();
     SEQ_STAMP(10);
     float sum;
-    if (!seq_sum_predict<NW>(s_att, pos + 1, ps, &sum)) sum = seq_sum_exact<NW>(s_att, pos + 1, sh);
+    if (!seq_sum_lds_fast<NW>(s_att, pos + 1, fsn, &sum)) { __syncthreads(); if (!seq_sum_predict<NW>(s_att, pos + 1, ps, &sum)) sum = seq_sum_exact<NW>(s_att, pos + 1, sh); }
     SEQ_STAMP(11);
     for (int t = tid; t <= pos; t += T) {
         const float a = s_att[scan_slot(t)] / sum;
@@ -1454,6 +1479,7 @@ __global__ __launch_bounds__(kSoftWaves * 64) void attn_softmax_chain_kernel(Ref
     extern __shared__ __attribute__((aligned(16))) float s_att[];      // [scan_slot(seq_len)]
     __shared__ SeqSumShared<kSoftWaves> sh;
     __shared__ PredShared<kSoftWaves> ps;
+    __shared__ FastSumShared<kSoftWaves> fsn;
     __shared__ float red[16];
     const int h = blockIdx.x, tid = threadIdx.x;
     const int pos = p.ctl ? p.ctl->pos : p.pos_val;
@@ -1464,7 +1490,7 @@ __global__ __launch_bounds__(kSoftWaves * 64) void attn_softmax_chain_kernel(Ref
     for (int t = tid; t <= pos; t += T) s_att[scan_slot(t)] = expf_glibc(s_att[scan_slot(t)] - mx);
     __syncthreads();
     float sum;
-    if (!seq_sum_predict<kSoftWaves>(s_att, pos + 1, ps, &sum)) sum = seq_sum_exact<kSoftWaves>(s_att, pos + 1, sh);
+    if (!seq_sum_lds_fast<kSoftWaves>(s_att, pos + 1, fsn, &sum)) { __syncthreads(); if (!seq_sum_predict<kSoftWaves>(s_att, pos + 1, ps, &sum)) sum = seq_sum_exact<kSoftWaves>(s_att, pos + 1, sh); }
     for (int t = tid; t <= pos; t += T) att[t] = s_att[scan_slot(t)] / sum;
 }
 
@@ -1581,6 +1607,7 @@ __global__ __launch_bounds__(kFvWaves * 64) void attn_softmax_values_chain_kerne
     __shared__ __attribute__((aligned(16))) float tile[2][kValCols * kFvStride];
     __shared__ SeqSumShared<kFvWaves> sh;
     __shared__ PredShared<kFvWaves> ps;
+    __shared__ FastSumShared<kFvWaves> fsn;
     __shared__ float red[16];
     float* s_att = fv_sm;                                          // [scan_slot(seq_len)] scores -> exponentials
     float* s_p = fv_sm + p.seq_len + (p.seq_len >> 5) + 4;         // [seq_len] the probabilities, unskewed
@@ -1616,7 +1643,7 @@ __global__ __launch_bounds__(kFvWaves * 64) void attn_softmax_values_chain_kerne
     for (int t = tid0; t <= pos; t += TS) s_att[scan_slot(t)] = expf_glibc(s_att[scan_slot(t)] - mx);
     __syncthreads();
     float sum;
-    if (!seq_sum_predict<kFvWaves>(s_att, pos + 1, ps, &sum)) sum = seq_sum_exact<kFvWaves>(s_att, pos + 1, sh);
+    if (!seq_sum_lds_fast<kFvWaves>(s_att, pos + 1, fsn, &sum)) { __syncthreads(); if (!seq_sum_predict<kFvWaves>(s_att, pos + 1, ps, &sum)) sum = seq_sum_exact<kFvWaves>(s_att, pos + 1, sh); }
     for (int t = tid0; t <= pos; t += TS) {
         const float a = s_att[scan_slot(t)] / sum;
         s_p[t] = a;
