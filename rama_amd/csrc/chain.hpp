@@ -1177,8 +1177,14 @@ __host__ __device__ constexpr bool attn_chain_fits(int head_size, int nw) { retu
 // (the body of attention_chain_kernel: head h of token y.  lds_seq = the timesteps the LDS arrays are laid out for (seq_len; a merged launch that
 // only runs below some position passes that bound).  HANDOFF ([r5] attn_wo_chain_kernel): xb leaves with write-through stores and, once they
 // have left, the head's tagged word {1, epoch} -- the Wo groups of the same launch wait for the n_heads words)
-template <int NW, bool HANDOFF = false>
-__device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int y, int lds_seq, unsigned long long* flags = nullptr, const unsigned* epoch = nullptr) {
+// INL ([r5] layer_chain_fused.hpp, the parity-mode one-launch stage): q | k | v of this position were produced by OTHER workgroups of the launch and come
+// as tagged words (inl.qkv: [3 dim], layer_fused.hpp's convention) -- the head's three slices are awaited, q goes to LDS from them, and since every
+// producer drains its write-through cache-row stores before it tags, the cache (row `pos` included) is then read with sc1 loads; xb leaves as tagged
+// words (inl.xb_t) and, when p.xb is given, plainly.
+struct AttnInl { const unsigned long long* qkv; const unsigned long long* early; unsigned long long* xb_t; unsigned long long* err; unsigned epoch; int* s_ok; };
+template <int NW, bool HANDOFF = false, bool INL = false>
+__device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int y, int lds_seq, unsigned long long* flags = nullptr, const unsigned* epoch = nullptr,
+                                                     AttnInl inl = AttnInl{}) {
     RAMA_NO_CONTRACT
     constexpr int T = NW * 64;
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -1200,7 +1206,30 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
     region = reinterpret_cast<float*>(((uintptr_t)region + 15) & ~(uintptr_t)15);
     const size_t col = (size_t)h * hs;
     SEQ_STAMP(8);
-    for (int i = tid; i < hs; i += T) s_q[i] = p.q[col + i];
+    const unsigned cache_bytes = (unsigned)p.seq_len * (unsigned)p.dim * 4u;
+    const __amdgpu_buffer_rsrc_t rkc = make_rsrc(p.kc, INL ? cache_bytes : 0u), rvc = make_rsrc(p.vc, INL ? cache_bytes : 0u);
+    if constexpr (INL) {
+        if (inl.early) {
+            if (tid == 0) fused_watch(inl.early, inl.epoch, inl.err);
+            __syncthreads();
+        }
+        for (int tries = 0;; tries++) {
+            bool ok = true;
+            for (int i = tid; i < 3 * hs; i += T) {
+                const int m = i / hs, jj = i - m * hs;
+                const unsigned long long w_ = __hip_atomic_load(inl.qkv + (size_t)m * p.dim + col + jj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = ok && (unsigned)(w_ >> 32) == inl.epoch;
+                if (m == 0) s_q[jj] = __uint_as_float((unsigned)w_);
+            }
+            if (fused_all(ok, tries, inl.s_ok)) break;
+            if ((tries & 63) == 63 && __syncthreads_or(tries >= (1 << 20) || __hip_atomic_load(inl.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                if (tid == 0) __hip_atomic_store(inl.err, kFusedErr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    } else {
+        for (int i = tid; i < hs; i += T) s_q[i] = p.q[col + i];
+    }
     // xb[i] = sum_t att[t] * v[t][i], t ascending (cpu.rs:43-49).  (Requesting the first value tiles up here, behind a thread's first key
     // rows, was measured: scores 2.4 -> 4.4 us, values 3.2 -> 2.7 at position 70 -- the key rows' wait then covers the value rows too.)
     constexpr int U = 8;
@@ -1214,7 +1243,8 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
             // (rows behind pos are clamped: their products are written, never added -- a load under a condition is a branch with
             // `s_waitcnt vmcnt(0)` behind it, one cache round trip per load instruction)
             const int tr = min(t0 + er[u], pos), c4 = ec[u];
-            vr[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.vc + (size_t)tr * p.dim + col) + c4);
+            if constexpr (INL) vr[u] = ld4_sc1(rvc, ((unsigned)tr * (unsigned)p.dim + (unsigned)col + 4u * (unsigned)c4) * 4u);
+            else vr[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.vc + (size_t)tr * p.dim + col) + c4);
         }
     };
     f4 va[U], vb[U];                                              // two tiles on their way while a third is added up
@@ -1282,7 +1312,10 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
                 for (; i + NB <= hs4; i += NB) {
                     f4 kk[NB];
 #pragma unroll
-                    for (int u = 0; u < NB; u++) kk[u] = k4[i + u];
+                    for (int u = 0; u < NB; u++) {
+                        if constexpr (INL) kk[u] = ld4_sc1(rkc, ((unsigned)t * (unsigned)p.dim + (unsigned)col + 4u * (unsigned)(i + u)) * 4u);
+                        else kk[u] = k4[i + u];
+                    }
 #pragma unroll
                     for (int u = 0; u < NB; u++) {
                         const f4 qq = q4[i + u];
@@ -1295,7 +1328,7 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
             batch(std::integral_constant<int, 8>{});
             batch(std::integral_constant<int, 4>{});
             for (; i < hs4; i++) {
-                const f4 kk = k4[i], qq = q4[i];
+                const f4 kk = INL ? ld4_sc1(rkc, ((unsigned)t * (unsigned)p.dim + (unsigned)col + 4u * (unsigned)i) * 4u) : k4[i], qq = q4[i];
                 acc = acc + qq.x * kk.x; acc = acc + qq.y * kk.y; acc = acc + qq.z * kk.z; acc = acc + qq.w * kk.w;
             }
             s_att[scan_slot(t)] = acc / scale_div;
@@ -1354,7 +1387,9 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
         vtile(t0, 0, va);
         if (t0 + kAttTile <= pos) vtile(t0 + kAttTile, 1, vb);    // uniform
     }
-    if constexpr (HANDOFF) {
+    if constexpr (INL) {
+        if (tid < hs) { put_tagged(inl.xb_t + col + tid, acc, inl.epoch); if (p.xb) p.xb[col + tid] = acc; }
+    } else if constexpr (HANDOFF) {
         const unsigned ep = *epoch;
         if (tid < hs) st_sc1(p.xb + col + tid, acc);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave: its stores have left

@@ -3,6 +3,7 @@
 #include "../../include/rama_hip.h"
 #include "kernels.hpp"
 #include "attn_wo.hpp"
+#include "layer_chain_fused.hpp"
 #include "layer_fused.hpp"
 #include "topp_sort.hpp"
 #include "prefill_attn.hpp"
@@ -59,6 +60,7 @@ constexpr size_t kAttnChainMaxLds = 136 * 1024;      // dynamic LDS attention_ch
 constexpr int kSpreadAttnPos = 128;        // parity mode: from this position on the attention is two launches spread over the chip (chain.hpp; "spread_pos": 187 against 184 tok/s at positions 124..179, 178 against 152 at 800)
 constexpr int kLeadSlots = 2 * 256 + 2;       // tagged words of the leader-workgroup norms: two per layer of a stage (<= 256 layers), one for the final norm
 constexpr int kAwoLayers = 256, kAwoHeads = 64;       // merged attention + Wo launches (chain.hpp attn_wo_chain_kernel): one tagged word per (layer of a stage, head)
+constexpr size_t kChainFusedMaxLds = 120 * 1024;      // dynamic LDS of parity mode's one-launch stage (layer_chain_fused.hpp): one workgroup per CU
 constexpr size_t kAwoMaxLds = 80 * 1024;      // ... whose workgroups must fit two to a compute unit (n_heads + dim / 16 of them on 256 CUs)
 constexpr int kLongAttnPos = 256;          // parity mode: attention_chain_kernel runs 16 waves per head from this position on
 
@@ -169,6 +171,7 @@ struct rama_ctx {
     int tune_chain_awo = 0;                // parity mode, short contexts: attention + Wo as one launch, the Wo groups' first 4 x this many KiB requested while the attention runs (0: two launches)
     unsigned long long* awo_flags = nullptr;    // device: [kAwoLayers][kAwoHeads] tagged words
     int tune_chain_norm = 1;               // parity mode, dim <= 512: the layer norms folded into the matvecs that consume them
+    int tune_chain_fused = 0;              // parity mode: a whole stage as ONE launch (layer_chain_fused.hpp; opt-in: stories15M +6 %, stories110M -40 %); -1: for dim <= 1024
     int tune_chain_lead_w = 0;             // parity mode: waves per row group of the launches with a leader norm (0: by the number of row groups)
     int tune_chain_resid_d = -1;           // parity mode: 100 W + D for the residual products (Wo, W2) only; 0: by the number of row groups like the others; -1: W = 1, D = 32 when a CU holds one group
     int tune_chain_views = 1;              // parity mode, Device::matmul on a matrix of no model: a chain-order copy of the tensor is made on first use
@@ -295,6 +298,9 @@ int rama_ctx_create(int device, void* hip_stream, rama_ctx** out) {
     HIPCHK(hipFuncSetAttribute((const void*)attention_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnChainMaxLds));
     HIPCHK(hipFuncSetAttribute((const void*)attention_chain_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnChainMaxLds));
     HIPCHK(hipFuncSetAttribute((const void*)attention_chain_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnChainMaxLds));
+#define RAMA_CF_ATTR(DK_, DH_, F_) HIPCHK(hipFuncSetAttribute((const void*)stage_chain_fused_kernel<DK_, DH_, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainFusedMaxLds))
+    RAMA_CF_ATTR(16, 16, true); RAMA_CF_ATTR(16, 16, false); RAMA_CF_ATTR(32, 32, false); RAMA_CF_ATTR(32, 16, false);
+#undef RAMA_CF_ATTR
     HIPCHK(hipFuncSetAttribute((const void*)attn_wo_chain_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAwoMaxLds));
     HIPCHK(hipFuncSetAttribute((const void*)attn_wo_chain_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAwoMaxLds));
     HIPCHK(hipFuncSetAttribute((const void*)attn_wo_chain_solo_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnChainMaxLds));
@@ -1233,6 +1239,50 @@ static int enqueue_stage_ref(rama_ctx* c, const rama_config* cfg, const rama_wei
     return 0;
 }
 
+// [r5] parity mode's whole stage as ONE launch (layer_chain_fused.hpp): narrow models (dim <= 1024, seq_len <= 1024: every position takes the
+// one-workgroup-per-head attention), the chain-order copies given.  *launched = false: the shape is not one it takes.
+static int try_launch_chain_fused(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s, const rama_stage* st,
+                                  const float* cq, const float* ck, const float* cv, const float* co, const float* c13, const float* c2, const float* ccls, bool* launched) {
+    *launched = false;
+    const int dim = cfg->dim, hidden = cfg->hidden_dim, H = cfg->n_heads, hs = dim / H, V = cfg->vocab_size;
+    const int nl = st->layer_end - st->layer_begin;
+    if (!(c->tune_chain_fused < 0 ? dim <= 1024 : c->tune_chain_fused != 0) || c->kp.kernel_id >= 0 || c->tune_chain_d > 0) return 0;
+    if (nl <= 0 && (!st->do_cls || st->do_embed)) return 0;
+    if (dim > kFusedMaxDim || hidden > kFusedMaxHidden || nl > kFusedMaxLayers || dim % 16 || hidden % 16 || hs % 4 || !attn_chain_fits(hs, kPWaves) || cfg->seq_len > 1024 || cfg->seq_len % 4) return 0;
+    if ((double)cfg->seq_len * dim * 4.0 >= 2147483648.0) return 0;
+    if (!s->xb2 || !s->hb2 || !s->k || !s->v || !s->att) return 0;
+    if (!aligned16(s->x) || !aligned16(s->key_cache) || !aligned16(s->value_cache) || !aligned16(w->rms_att_weight) || !aligned16(w->rms_ffn_weight)) return 0;
+    const int kmax = std::max(dim, hidden);
+    const size_t lds = std::max(cf_matvec_lds_floats(kmax, dim), cf_attn_lds_floats(hs, cfg->seq_len)) * sizeof(float) + 16;
+    if (lds > kChainFusedMaxLds) return 0;
+    auto wgs = [](int groups) { return (groups + kPWaves - 1) / kPWaves; };
+    ChainFusedParams a{};
+    a.dim = dim; a.hidden = hidden; a.n_heads = H; a.seq_len = cfg->seq_len; a.vocab = V; a.n_layers = nl; a.do_cls = st->do_cls ? 1 : 0;
+    a.cq = cq; a.ck = ck; a.cv = cv; a.co = co; a.c13 = c13; a.c2 = c2; a.ccls = ccls;
+    a.g_att = w->rms_att_weight; a.g_ffn = w->rms_ffn_weight; a.g_final = w->rms_final_weight;
+    a.emb = st->do_embed ? w->token_embedding_table : nullptr;
+    a.x = s->x; a.xb = s->xb; a.xb2 = s->xb2; a.q = s->q; a.k = s->k; a.v = s->v; a.hb = s->hb; a.hb2 = s->hb2; a.att = s->att; a.logits = s->logits;
+    a.kc = s->key_cache; a.vc = s->value_cache; a.fr = w->freq_cis_real; a.fi = w->freq_cis_imag;
+    a.ctl = c->ctl; a.hand = c->fused_hand; a.epoch = c->fused_epoch; a.err = c->pbar + 1;
+    a.nA = wgs(3 * (dim / 16)); a.nC = wgs(dim / 16); a.nD = wgs(2 * (hidden / 16)); a.nE = a.nC;
+    a.lds_seq = cfg->seq_len;
+    const long grid = (long)nl * (a.nA + H + a.nC + a.nD + a.nE) + (st->do_cls ? wgs((V + 15) / 16) : 0);
+    const int DK = cf_ring(dim / 16), DH = cf_ring(hidden / 16);
+    const bool fast = dim > 320;      // seqsum_fast.hpp for the norms' sums (else lane ripples)
+#define RAMA_CF(DK_, DH_, F_) hipLaunchKernelGGL((stage_chain_fused_kernel<DK_, DH_, F_>), dim3((unsigned)grid), dim3(kPThreads), lds, c->stream, a)
+    if (DK == 16 && DH == 16) { if (fast) RAMA_CF(16, 16, true); else RAMA_CF(16, 16, false); }
+    else if (DK == 32 && !fast) { if (DH == 32) RAMA_CF(32, 32, false); else RAMA_CF(32, 16, false); }
+    else return 0;      // (no instantiation: the separate launches)
+#undef RAMA_CF
+    LAUNCHCHK();
+    *launched = true;
+    c->handoff_dirty = true;
+    if (c->fused_chained) { c->fused_epoch_owed = true; return 0; }      // the sampler that follows advances the epoch
+    hipLaunchKernelGGL(fused_epoch_kernel, dim3(1), dim3(1), 0, c->stream, c->fused_epoch);
+    LAUNCHCHK();
+    return 0;
+}
+
 // the same (every RunState buffer as the CPU path leaves it, bit for bit) on the model's chain-order weight
 // copies: 7 launches per layer.  Returns false when a copy is missing (weights uploaded tensor by tensor,
 // widths that are not whole 16-float blocks, no memory for the copy): the caller takes enqueue_stage_ref.
@@ -1268,6 +1318,11 @@ static int enqueue_stage_chain(rama_ctx* c, const rama_config* cfg, const rama_w
                          st->layer_end - st->layer_begin <= 256 && c->kp.kernel_id != RAMA_K_NORM;
     const int lnorm = tol ? (tol_fold ? CNORM_TREE : CNORM_NONE) : (lead_ok ? CNORM_LEAD : par_norm);      // how the layer norms are folded
     bool led = false;
+    if (!tol) {      // narrow models: the whole stage in one launch
+        bool launched = false;
+        const int rf = try_launch_chain_fused(c, cfg, w, s, st, cq, ck, cv, co, c13, c2, ccls, &launched);
+        if (rf || launched) return rf;
+    }
     const float* w13i = (tol && (mask & 4) && st->layer_end > st->layer_begin && (double)hidden * dim * 8.0 < 2147483648.0) ? rama_internal_w13_lookup(w->w1, w->w3) : nullptr;
     int rc;
     if (st->do_embed) {
@@ -2678,6 +2733,13 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
     if (!strcmp(key, "chain_awo")) {
         REQUIRE(value == 0 || value == 16 || value == 32 || value == 48 || value == 64, RAMA_EINVAL, "set_tuning: chain_awo must be 0, 16, 32, 48 or 64");
         c->tune_chain_awo = value;
+        hipStreamSynchronize(c->stream);
+        drop_graph(c);
+        return 0;
+    }
+    if (!strcmp(key, "chain_fused")) {
+        REQUIRE(value >= -1 && value <= 1, RAMA_EINVAL, "set_tuning: chain_fused must be -1, 0 or 1");
+        c->tune_chain_fused = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
         return 0;

@@ -374,6 +374,46 @@ def test_fast_sequential_sum(dev, n):
                 assert got[1] == 1.0, f"fast sum n={n} list {li} waves {nw}: fell back on ordinary data"
 
 
+@pytest.mark.parametrize("dim,hidden,heads,layers,vocab,seq,steps", [(288, 768, 6, 3, 512, 200, 150), (64, 176, 4, 2, 96, 32, 20), (768, 2048, 12, 2, 333, 160, 40),
+                                                                     (1024, 1024, 8, 2, 160, 64, 10), (48, 80, 3, 2, 50, 40, 12)])
+def test_parity_one_launch_stage_bit_exact(dev, dim, hidden, heads, layers, vocab, seq, steps):
+    """[r5] parity mode's whole stage as ONE launch (layer_chain_fused.hpp, "chain_fused" = 1; opt-in): the phases of every layer and the classifier
+    chained through tagged vectors, chain-order arithmetic in every op -- every RunState buffer the oracle's, bit for bit, at every position
+    (the stories15M / stories110M widths, a head size of 128, ragged row counts), eager and from a hipGraph, and a layer range of a pipeline"""
+    import rama_amd
+    from .helpers import to_rama_cfg
+    cfg = O.Config(dim, hidden, layers, heads, heads, vocab, seq, False)
+    rope = S.rope_tables(seq, dim // heads)
+    w = S.synth_weights(cfg, 13, rope=rope)
+    orc = O.Oracle(cfg, w)
+    model = rama_amd.Model.synth(dev, to_rama_cfg(cfg), 13, rope=rope)
+    eng = rama_amd.Engine(dev, model)
+    sizes = dict(x=dim, xb=dim, xb2=dim, hb=hidden, hb2=hidden, q=dim, k=dim, v=dim, logits=vocab, key_cache=layers * seq * dim, value_cache=layers * seq * dim)
+    try:
+        eng.set_tuning("chain_fused", 1)
+        token = 1
+        for pos in range(steps):
+            lo = orc.forward(token, pos)
+            eng.forward(token, pos)
+            if pos < 6 or pos % 16 == 0 or pos == steps - 1:
+                for buf, n in sizes.items():
+                    assert_bits_equal(eng.buffer(buf, n), orc.s[buf], f"one-launch stage pos {pos} {buf}")
+                att = eng.buffer("att", heads * seq).reshape(heads, seq)[:, :pos + 1]
+                assert_bits_equal(att, orc.s["att"].reshape(heads, seq)[:, :pos + 1], f"one-launch stage pos {pos} att")
+            else:
+                assert_bits_equal(eng.logits(), lo, f"one-launch stage pos {pos} logits")
+            token = O.argmax(lo)
+        # the device-chained loop replays it from a hipGraph
+        eng2 = rama_amd.Engine(dev, model)
+        eng2.set_graph_mode(True)
+        prompt = [5, 9, 2]
+        assert eng2.generate_greedy(prompt, min(steps, 24)) == O.Oracle(cfg, w).generate_greedy(prompt, min(steps, 24))
+        eng2.free()
+    finally:
+        eng.set_tuning("chain_fused", 0)
+        eng.free(); model.free()
+
+
 def _chain_lookup(dev, ptr, rows, K):
     f = dev.lib.rama_internal_chain_lookup
     f.restype = C.c_void_p
