@@ -425,9 +425,11 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *   "chain_resid_d" = -1 | 0 | 100 W + D : [r5] geometry of parity mode's residual products (Wo, W2) alone; -1 (default) = one
  *                   wave with a ring of 32 blocks when a compute unit holds at most one row group (llama2-7B: Wo 15.1 -> 13.5 us,
  *                   W2 33.6 -> 32.1), 0 = like the other products
- *   "chain_awo" = 0|16|32|48|64 : [r5] parity mode below position 128: attention + Wo as ONE launch, the Wo row groups requesting
- *                   4 x this many KiB of their rows while the attention runs.  Bit-identical, measured SLOWER at llama2-7B
- *                   (194 / 186 / 188 / 185 against 200 tok/s: the attention's round trips lengthen under the traffic): default 0
+ *   "chain_awo" = 0|16|48 : [r5] parity mode below position 128: attention + Wo as ONE launch, the Wo row groups requesting
+ *                   4 x this many KiB of their rows while the attention runs (48: one workgroup per CU).  Bit-identical, measured
+ *                   SLOWER at llama2-7B (194 / 188 against 200 tok/s: the attention's round trips lengthen under the traffic): default 0
+ *   "chain_fused" = -1|0|1 : [r5] parity mode, dim <= 1024, seq_len <= 1024: a whole stage as ONE launch (csrc/layer_chain_fused.hpp).
+ *                   Bit-identical, measured SLOWER than the separate launches (stories15M 217 vs 202 us, stories110M 709 vs 426): default 0
  *   "chain_views" = 0|1 : parity mode's rama_matmul makes a chain-order copy of a matrix of no model on first use (default 1) */
 int  rama_set_tuning(rama_ctx *ctx, const char *key, int value);
 

@@ -1172,7 +1172,7 @@ __host__ __device__ constexpr size_t attn_chain_lds_floats(int head_size, int se
     return (size_t)((head_size + 3) & ~3) + (size_t)seq_len + (size_t)(seq_len >> 5) + 4 + (size_t)((seq_len + 3) & ~3) + attn_chain_region_floats(head_size, nw);
 }
 // the value tiles are loaded with 8 x 16 bytes per thread
-__host__ __device__ constexpr bool attn_chain_fits(int head_size, int nw) { return kAttTile * (head_size / 4) <= 8 * 64 * nw; }
+__host__ __device__ constexpr bool attn_chain_fits(int head_size, int nw) { return kAttTile * (head_size / 4) <= (nw >= 16 ? 4 : 8) * 64 * nw; }
 
 // (the body of attention_chain_kernel: head h of token y.  lds_seq = the timesteps the LDS arrays are laid out for (seq_len; a merged launch that
 // only runs below some position passes that bound).  HANDOFF ([r5] attn_wo_chain_kernel): xb leaves with write-through stores and, once they
@@ -1232,7 +1232,9 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
     }
     // xb[i] = sum_t att[t] * v[t][i], t ascending (cpu.rs:43-49).  (Requesting the first value tiles up here, behind a thread's first key
     // rows, was measured: scores 2.4 -> 4.4 us, values 3.2 -> 2.7 at position 70 -- the key rows' wait then covers the value rows too.)
-    constexpr int U = 8;
+    // (16 waves: 1 024 threads cover a tile of head size 256 with four loads each -- and have 128 registers, which eight loads per tile buffer
+    // and a 32-load key batch overran by 56: [r5])
+    constexpr int U = NW >= 16 ? 4 : 8;
     const int tile4 = kAttTile * hs4;                             // f4 elements of a tile
     int er[U], ec[U];                                             // tile element e = tid + u T: its row and 16-byte column (one division each, here)
 #pragma unroll
@@ -1268,14 +1270,15 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
                 d[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.kc + (size_t)t * p.dim + col + pc * kAttPiece) + lc4);
             }
         };
-        f4 na[8], nb[8];
+        constexpr int NB = NW >= 16 ? 1 : 2;                      // staged pieces in flight per wave (16 waves: 128 registers -- one)
+        f4 na[8], nb[NB == 2 ? 8 : 1];
         load_step(0, na);
-        load_step(1, nb);
+        if constexpr (NB == 2) load_step(1, nb);
         float acc = 0.0f;
         auto consume = [&](int st, f4 (&d)[8]) {
 #pragma unroll
             for (int u = 0; u < 8; u++) *reinterpret_cast<f4*>(stage + (u * 8 + lrow) * kAttStride + 4 * lc4) = d[u];
-            load_step(st + 2, d);                                 // this buffer's next use
+            load_step(st + NB, d);                                // this buffer's next use
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the piece is in LDS (a wave's LDS operations finish in order)
             const int pc = st % npiece;
@@ -1296,9 +1299,9 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // rows read before the next piece overwrites them
             __builtin_amdgcn_wave_barrier();
         };
-        for (int st = 0; st < nstep; st += 2) {                   // uniform per wave
+        for (int st = 0; st < nstep; st += NB) {                  // uniform per wave
             consume(st, na);
-            if (st + 1 < nstep) consume(st + 1, nb);
+            if constexpr (NB == 2) { if (st + 1 < nstep) consume(st + 1, nb); }
         }
     } else {
         for (int t = tid; t <= pos; t += T) {                     // a few rounds of timesteps: straight from the cache, a row's loads together
@@ -1323,7 +1326,7 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
                     }
                 }
             };
-            batch(std::integral_constant<int, 32>{});
+            if constexpr (NW < 16) batch(std::integral_constant<int, 32>{});
             batch(std::integral_constant<int, 16>{});
             batch(std::integral_constant<int, 8>{});
             batch(std::integral_constant<int, 4>{});

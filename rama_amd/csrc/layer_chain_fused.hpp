@@ -37,7 +37,7 @@ __host__ __device__ constexpr int cf_pad_floats() { return chain_pad_floats(1, k
 // the ring a row group of nblk blocks gets: ALL of it when it fits a wave's registers (48 blocks: a row of 768 floats) -- the weights of a phase
 // are then there before its input is, and the chain runs out of registers and LDS -- else a rolling ring of 16.  (Measured: the kernel's five
 // phases in one function leave hipcc ~20 free registers beside a ring of 32: 260-330 spilled; profiles/r05_experiments.md section 8.)
-__host__ __device__ constexpr int cf_ring(int nblk) { return nblk <= 16 ? 16 : (nblk <= 32 ? 32 : 16); }      // (48: 192 registers of ring spill wholesale)
+__host__ __device__ constexpr int cf_ring(int) { return 16; }      // (rings of 32 / 48 blocks were measured -- stories15M 220 -> 191 us -- but spill 260-970 registers)
 // dynamic LDS of a matvec phase: the fetched vector | its chain-order copy + the zeros behind it | the squares (scan_slot layout)
 __host__ __device__ constexpr size_t cf_matvec_lds_floats(int kmax, int dim) { return (size_t)kmax + 4 + (size_t)kmax + cf_pad_floats() + (size_t)dim + (dim >> 5) + 8; }
 __host__ __device__ constexpr size_t cf_attn_lds_floats(int hs, int lds_seq) {

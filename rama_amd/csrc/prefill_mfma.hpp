@@ -286,9 +286,12 @@ __global__ __launch_bounds__(kMfThreads) void gemm_mfma_rows(MfParams p) {
             constexpr int UNITS = (PAIR ? PTC : NTC) * 64;      // one unit = 4 consecutive rows of one token
             constexpr int ITER = (UNITS + kMfThreads - 1) / kMfThreads;
             // EPI_QKV: the rotation coefficients and positions of my units are on their way before the barrier
+            // ([r5] with 7 or 8 token tiles the 84 / 96 accumulator registers are still live here and these ten more were spilled (6 / 14 registers of
+            // scratch): those instantiations fetch the coefficients behind the barrier instead)
+            constexpr bool EARLY_ROT = PT < 7;
             float rot[ITER][4];
             int posv[ITER];
-            if (EPI == EPI_QKV) {
+            if (EPI == EPI_QKV && EARLY_ROT) {
 #pragma unroll
                 for (int it = 0; it < ITER; it++) {
                     const int v = tid + it * kMfThreads, ln = v & 63, tile = v >> 6;
@@ -327,6 +330,14 @@ __global__ __launch_bounds__(kMfThreads) void gemm_mfma_rows(MfParams p) {
                     }
                     *reinterpret_cast<acc4*>(p.o + tile_idx(tk, r, p.rows)) = a;
                 } else if (EPI == EPI_QKV) {
+                    if (!EARLY_ROT) {
+                        posv[it] = p.seqs ? p.seqs[tk].pos : p.pos0 + tk;
+                        rot[it][0] = rot[it][1] = rot[it][2] = rot[it][3] = 0.0f;
+                        if (rt < 2) {
+                            const size_t fo = (size_t)posv[it] * (p.head_size >> 1) + ((r % p.head_size) >> 1);
+                            rot[it][0] = p.fr[fo]; rot[it][1] = p.fi[fo]; rot[it][2] = p.fr[fo + 1]; rot[it][3] = p.fi[fo + 1];
+                        }
+                    }
                     const int pos = posv[it];
                     if (rt < 2) {                                                      // cpu.rs:87-96 rotate (q, k)
                         const float c0_ = rot[it][0], s0 = rot[it][1], c1 = rot[it][2], s1 = rot[it][3];

@@ -299,12 +299,10 @@ int rama_ctx_create(int device, void* hip_stream, rama_ctx** out) {
     HIPCHK(hipFuncSetAttribute((const void*)attention_chain_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnChainMaxLds));
     HIPCHK(hipFuncSetAttribute((const void*)attention_chain_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnChainMaxLds));
 #define RAMA_CF_ATTR(DK_, DH_, F_) HIPCHK(hipFuncSetAttribute((const void*)stage_chain_fused_kernel<DK_, DH_, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainFusedMaxLds))
-    RAMA_CF_ATTR(16, 16, true); RAMA_CF_ATTR(16, 16, false); RAMA_CF_ATTR(32, 32, false); RAMA_CF_ATTR(32, 16, false);
+    RAMA_CF_ATTR(16, 16, true); RAMA_CF_ATTR(16, 16, false);
 #undef RAMA_CF_ATTR
     HIPCHK(hipFuncSetAttribute((const void*)attn_wo_chain_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAwoMaxLds));
-    HIPCHK(hipFuncSetAttribute((const void*)attn_wo_chain_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAwoMaxLds));
     HIPCHK(hipFuncSetAttribute((const void*)attn_wo_chain_solo_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnChainMaxLds));
-    HIPCHK(hipFuncSetAttribute((const void*)attn_wo_chain_solo_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnChainMaxLds));
 #define RAMA_GC_ATTR(TPW_) \
     HIPCHK(hipFuncSetAttribute((const void*)gemm_chain_kernel<TPW_, CEPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_chain_lds_bytes(TPW_))); \
     HIPCHK(hipFuncSetAttribute((const void*)gemm_chain_kernel<TPW_, CEPI_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_chain_lds_bytes(TPW_))); \
@@ -730,7 +728,7 @@ static int launch_attention_chain(rama_ctx* c, float* xb, float* att, const floa
 static int try_launch_attn_wo_chain(rama_ctx* c, const rama_config* cfg, rama_run_state* s, size_t li, const float* kc, const float* vc, const float* co_layer, bool* merged) {
     *merged = false;
     const int dim = cfg->dim, hs = dim / cfg->n_heads, D = c->tune_chain_awo, groups = (dim + 15) / 16;
-    if (D <= 0 || c->spread_attn || c->long_attn || c->kp.kernel_id >= 0 || c->tune_chain_d > 0) return 0;
+    if ((D != 16 && D != 48) || c->spread_attn || c->long_attn || c->kp.kernel_id >= 0 || c->tune_chain_d > 0) return 0;
     if (cfg->n_heads > kAwoHeads || li >= (size_t)kAwoLayers || hs % 4 || attn_chain_waves(hs, false) != 4 || dim % 16 || dim / 16 <= 64) return 0;
     const bool solo = D > 32;      // one workgroup per compute unit, the attention workgroups double as Wo groups
     if (solo && (groups > c->cu_count || cfg->n_heads > groups)) return 0;
@@ -744,10 +742,9 @@ static int try_launch_attn_wo_chain(rama_ctx* c, const rama_config* cfg, rama_ru
     p.w[0] = co_layer; p.o[0] = s->xb2; p.resid = s->x; p.x = s->xb; p.K = dim; p.rows = dim; p.nmat = 1;
     p.wait_flags = c->awo_flags + li * kAwoHeads; p.wait_n = cfg->n_heads; p.epoch = c->fused_epoch; p.err = c->pbar + 1;
     const dim3 grid(solo ? groups : cfg->n_heads + groups);
+    // (the 128 KiB two-to-a-CU and the 256 KiB one-to-a-CU variants of the experiment spilled 54 / 122 registers and are gone: profiles/r05_experiments.md)
     if (D == 16) hipLaunchKernelGGL((attn_wo_chain_kernel<16>), grid, dim3(256), lds, c->stream, a, p, cfg->n_heads, lds_seq);
-    else if (D == 32) hipLaunchKernelGGL((attn_wo_chain_kernel<32>), grid, dim3(256), lds, c->stream, a, p, cfg->n_heads, lds_seq);
-    else if (D == 48) hipLaunchKernelGGL((attn_wo_chain_solo_kernel<48>), grid, dim3(256), lds, c->stream, a, p, cfg->n_heads, lds_seq);
-    else hipLaunchKernelGGL((attn_wo_chain_solo_kernel<64>), grid, dim3(256), lds, c->stream, a, p, cfg->n_heads, lds_seq);
+    else hipLaunchKernelGGL((attn_wo_chain_solo_kernel<48>), grid, dim3(256), lds, c->stream, a, p, cfg->n_heads, lds_seq);
     LAUNCHCHK();
     c->handoff_dirty = true;
     *merged = true;
@@ -1267,13 +1264,8 @@ static int try_launch_chain_fused(rama_ctx* c, const rama_config* cfg, const ram
     a.nA = wgs(3 * (dim / 16)); a.nC = wgs(dim / 16); a.nD = wgs(2 * (hidden / 16)); a.nE = a.nC;
     a.lds_seq = cfg->seq_len;
     const long grid = (long)nl * (a.nA + H + a.nC + a.nD + a.nE) + (st->do_cls ? wgs((V + 15) / 16) : 0);
-    const int DK = cf_ring(dim / 16), DH = cf_ring(hidden / 16);
-    const bool fast = dim > 320;      // seqsum_fast.hpp for the norms' sums (else lane ripples)
-#define RAMA_CF(DK_, DH_, F_) hipLaunchKernelGGL((stage_chain_fused_kernel<DK_, DH_, F_>), dim3((unsigned)grid), dim3(kPThreads), lds, c->stream, a)
-    if (DK == 16 && DH == 16) { if (fast) RAMA_CF(16, 16, true); else RAMA_CF(16, 16, false); }
-    else if (DK == 32 && !fast) { if (DH == 32) RAMA_CF(32, 32, false); else RAMA_CF(32, 16, false); }
-    else return 0;      // (no instantiation: the separate launches)
-#undef RAMA_CF
+    if (dim > 320) hipLaunchKernelGGL((stage_chain_fused_kernel<16, 16, true>), dim3((unsigned)grid), dim3(kPThreads), lds, c->stream, a);      // seqsum_fast.hpp for the norms' sums
+    else hipLaunchKernelGGL((stage_chain_fused_kernel<16, 16, false>), dim3((unsigned)grid), dim3(kPThreads), lds, c->stream, a);             // ... lane ripples
     LAUNCHCHK();
     *launched = true;
     c->handoff_dirty = true;
@@ -2731,7 +2723,7 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
         return 0;
     }
     if (!strcmp(key, "chain_awo")) {
-        REQUIRE(value == 0 || value == 16 || value == 32 || value == 48 || value == 64, RAMA_EINVAL, "set_tuning: chain_awo must be 0, 16, 32, 48 or 64");
+        REQUIRE(value == 0 || value == 16 || value == 48, RAMA_EINVAL, "set_tuning: chain_awo must be 0, 16 or 48");
         c->tune_chain_awo = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);

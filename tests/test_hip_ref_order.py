@@ -460,7 +460,7 @@ def test_uploaded_weights_run_the_chain_kernels(dev, dim, hidden, heads, layers,
 
 @pytest.mark.parametrize("dim,hidden,heads,layers,seq,steps", [(4096, 11008, 32, 2, 512, 140), (1296, 1600, 27, 3, 160, 40), (2048, 2048, 16, 2, 300, 270)])
 def test_attention_wo_merged_launch_bit_exact(dev, dim, hidden, heads, layers, seq, steps):
-    """[r5] attention + Wo as ONE launch in parity mode (chain.hpp attn_wo_chain_kernel, "chain_awo" = 32 | 16): the Wo groups request half (a
+    """[r5] attention + Wo as ONE launch in parity mode (chain.hpp attn_wo_chain_kernel, "chain_awo" = 48 | 16): the Wo groups request half (a
     quarter) of their rows' stream while the attention runs, wait for the heads' tagged words and read xb with sc1 loads.  Every position
     -- through the switches to the spread attention (128) and to 256, where the launch is two again -- leaves xb, xb2, x, the probabilities
     and the logits as the oracle's, bit for bit, and as the two-launch form's (llama2-7B's width; a width whose last chunk is ragged with 27
@@ -474,7 +474,7 @@ def test_attention_wo_merged_launch_bit_exact(dev, dim, hidden, heads, layers, s
     model = rama_amd.Model.synth(dev, to_rama_cfg(cfg), 11, rope=rope)
     engs = {}
     try:
-        for awo in (64, 32, 0):
+        for awo in (48, 16, 0):
             engs[awo] = rama_amd.Engine(dev, model)
         token = 1
         for pos in range(steps):
@@ -491,7 +491,7 @@ def test_attention_wo_merged_launch_bit_exact(dev, dim, hidden, heads, layers, s
                 assert_bits_equal(att, orc.s["att"].reshape(heads, seq)[:, :pos + 1], f"awo {awo} pos {pos} att")
             token = O.argmax(lo)
     finally:
-        dev.lib.rama_set_tuning(dev.ctx, b"chain_awo", 32)
+        dev.lib.rama_set_tuning(dev.ctx, b"chain_awo", 0)
         for eng in engs.values():
             eng.free()
         model.free()
