@@ -443,6 +443,9 @@ extern "C" int rama_internal_adopt(rama_ctx* ctx, const rama_config* cfg, const 
 extern "C" const float* rama_internal_chain_view(rama_ctx* ctx, const float* a, int rows, int K, int capturing) {
     if (const float* hit = rama_internal_chain_lookup(a, rows, K)) return hit;
     if (capturing || getenv("RAMA_NO_CHAIN") || K % 16) return nullptr;
+    static std::mutex build_mu;      // one copy per tensor: a second caller waits for the first one's copy instead of making its own
+    std::lock_guard<std::mutex> bl(build_mu);
+    if (const float* hit = rama_internal_chain_lookup(a, rows, K)) return hit;
     const float* base; size_t n;
     if (!alloc_of(a, &base, &n)) return nullptr;
     const size_t per = (size_t)rows * K, off = (size_t)(a - base);

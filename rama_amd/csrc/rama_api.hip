@@ -1307,7 +1307,7 @@ static int enqueue_stage_chain(rama_ctx* c, const rama_config* cfg, const rama_w
     // parity mode, wider models ([r5]): the exact sum by a leader workgroup inside the consuming launch ("chain_lead"; x of <= 4096 floats per wave of the
     // matvec's workgroups, layer ranges of <= 256 layers)
     const bool lead_ok = !tol && par_norm == CNORM_NONE && c->tune_chain_lead && c->tune_chain_d <= 0 && dim % 8 == 0 && dim <= 4096 && dim / 16 > 32 &&
-                         st->layer_end - st->layer_begin <= 256 && c->kp.kernel_id != RAMA_K_NORM;
+                         st->layer_end - st->layer_begin <= 256;      // (per-class timing keeps it: the `norm` class is then the final norm's launch alone, as in the timed step)
     const int lnorm = tol ? (tol_fold ? CNORM_TREE : CNORM_NONE) : (lead_ok ? CNORM_LEAD : par_norm);      // how the layer norms are folded
     bool led = false;
     if (!tol) {      // narrow models: the whole stage in one launch
