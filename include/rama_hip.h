@@ -430,7 +430,10 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *                   SLOWER at llama2-7B (194 / 188 against 200 tok/s: the attention's round trips lengthen under the traffic): default 0
  *   "chain_fused" = -1|0|1 : [r5] parity mode, dim <= 1024, seq_len <= 1024: a whole stage as ONE launch (csrc/layer_chain_fused.hpp).
  *                   Bit-identical, measured SLOWER than the separate launches (stories15M 217 vs 202 us, stories110M 709 vs 426): default 0
- *   "chain_views" = 0|1 : parity mode's rama_matmul makes a chain-order copy of a matrix of no model on first use (default 1) */
+ *   "chain_views" = 0|1 : parity mode's rama_matmul makes a chain-order copy of a matrix of no model on first use (default 1)
+ *   "rope_batch" = 0|1 : [r5] a run of rama_apply_position calls on consecutive heads (q, k advancing by head_size, the same table rows:
+ *                   infer.rs:25-29) is recorded and issued as ONE launch by whatever enters the library next -- same bits, 32 launches per layer
+ *                   fewer (the 1:1 path 131 -> 172 tok/s at llama2-7B); only on a stream the context created itself (default 1) */
 int  rama_set_tuning(rama_ctx *ctx, const char *key, int value);
 
 /* glibc 2.35 expf (the exp the reference's f32::exp calls on Linux) as the reference-order kernels

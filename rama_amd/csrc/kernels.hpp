@@ -841,6 +841,18 @@ __global__ void apply_position_kernel(float* q, float* k, const float* pr, const
     k[2 * i] = k0 * c - k1 * s; k[2 * i + 1] = k0 * s + k1 * c;
 }
 
+// ... for a run of consecutive heads (dim = heads x head_size floats of q and of k; the same table rows for every head: infer.rs:25-29's loop as one launch)
+__global__ void apply_position_heads_kernel(float* q, float* k, const float* pr, const float* pi, int head_size, int dim) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= dim / 2) return;
+    const int i = j % (head_size / 2);
+    float c = pr[i], s = pi[i];
+    float q0 = q[2 * j], q1 = q[2 * j + 1];
+    q[2 * j] = q0 * c - q1 * s; q[2 * j + 1] = q0 * s + q1 * c;
+    float k0 = k[2 * j], k1 = k[2 * j + 1];
+    k[2 * j] = k0 * c - k1 * s; k[2 * j + 1] = k0 * s + k1 * c;
+}
+
 // cpu.rs:119-125, one workgroup
 __global__ __launch_bounds__(1024) void softmax_kernel(float* x, int n) {
     __shared__ float red[16];

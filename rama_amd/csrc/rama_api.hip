@@ -174,6 +174,11 @@ struct rama_ctx {
     int tune_chain_fused = 0;              // parity mode: a whole stage as ONE launch (layer_chain_fused.hpp; opt-in: stories15M +6 %, stories110M -40 %); -1: for dim <= 1024
     int tune_chain_lead_w = 0;             // parity mode: waves per row group of the launches with a leader norm (0: by the number of row groups)
     int tune_chain_resid_d = -1;           // parity mode: 100 W + D for the residual products (Wo, W2) only; 0: by the number of row groups like the others; -1: W = 1, D = 32 when a CU holds one group
+    // [r5] a run of Device::apply_position calls on consecutive heads (infer.rs:25-29: n_heads calls per layer, 1 024 per llama2-7B token, each a launch of
+    // its own) is ISSUED AS ONE LAUNCH: a call only records (q, k, table rows, head size); the next call extends the run when it continues it, and
+    // whatever enters the library next issues it first (RAMA_ENTER).  Only on a stream the context owns ("rope_batch" = 0: every call a launch).
+    struct { float* q = nullptr; float* k = nullptr; const float* pr = nullptr; const float* pi = nullptr; int hs = 0, count = 0; } rope;
+    int tune_rope_batch = 1;
     int tune_chain_views = 1;              // parity mode, Device::matmul on a matrix of no model: a chain-order copy of the tensor is made on first use
     int tune_prefill_chain = 1;            // parity mode: prompt positions go through the chain-order token-batch kernels (32 per weight pass); 0: one forward() each
     size_t pf_floats = 0;
@@ -207,13 +212,18 @@ struct rama_ctx {
 };
 
 static int set_device(rama_ctx* c) { HIPCHK(hipSetDevice(c->device)); return 0; }
+// the pending run of apply_position calls (rama_ctx::rope) is issued by whatever enters the library next: first statement of every entry point
+// that enqueues, synchronises or changes a setting
+static int flush_rope(rama_ctx* c);
+#define RAMA_ENTER(c) do { if ((c) && (c)->rope.count) { const int rf_ = flush_rope(c); if (rf_) return rf_; } } while (0)
 
 // internal accessors for the library's other translation units (pipe.hip); not in the C ABI header
-extern "C" void* rama_internal_stream(rama_ctx* c) { return c ? (void*)c->stream : nullptr; }
+extern "C" void* rama_internal_stream(rama_ctx* c) { if (c && c->rope.count) (void)flush_rope(c); return c ? (void*)c->stream : nullptr; }
 extern "C" int rama_internal_device(rama_ctx* c) { return c ? c->device : 0; }
 // the sampler's device scratch after a rama_sample_topp* call (tests compare the running sums with a
 // sequential fp32 cumsum): sorted probabilities, sorted indices, running sums, candidate count
 extern "C" void rama_internal_topp_scratch(rama_ctx* c, float** keys, int** vals, float** prefix, int** m) {
+    if (c && c->rope.count) (void)flush_rope(c);
     if (keys) *keys = c->topp_keys[1];
     if (vals) *vals = c->topp_vals[1];
     if (prefix) *prefix = c->topp_prefix;
@@ -222,6 +232,7 @@ extern "C" void rama_internal_topp_scratch(rama_ctx* c, float** keys, int** vals
 
 // diagnostics (not in the C ABI header): how often the one-pass exact sum (chain.hpp seq_sum_predict) held / fell back
 extern "C" int rama_internal_pred_stats(rama_ctx* c, unsigned* held, unsigned* fell_back, int reset) {
+    RAMA_ENTER(c);
     unsigned h[2] = {0, 0};
     hipStreamSynchronize(c->stream);
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(rama::g_pred_stats), sizeof h) != hipSuccess) return 1;
@@ -233,6 +244,7 @@ extern "C" int rama_internal_pred_stats(rama_ctx* c, unsigned* held, unsigned* f
 
 // test entry (not in the C ABI header): seqsum_fast.hpp's sum of a_dev[0..n) on nw waves; out_dev[0..3] = sum, held, items, 100 MHz ticks
 extern "C" int rama_internal_seqsum_fast(rama_ctx* c, const float* a_dev, int n, int nw, float* out_dev) {
+    RAMA_ENTER(c);
     REQUIRE(c && a_dev && out_dev && n > 0, RAMA_EINVAL, "seqsum_fast: bad argument");
     const int per = (n + 64 * nw - 1) / (64 * nw);
 #define RAMA_FS(NW_, R_) hipLaunchKernelGGL((seqsum_fast_test_kernel<NW_, R_>), dim3(1), dim3(NW_ * 64), 0, c->stream, a_dev, n, out_dev)
@@ -333,6 +345,7 @@ static void drop_graph(rama_ctx* c) {
 extern "C" void rama_internal_drop_graphs(rama_ctx* c) { if (c) drop_graph(c); }      // model.hip: before a derived weight copy is freed
 
 int rama_ctx_destroy(rama_ctx* c) {
+    if (c && c->rope.count) (void)flush_rope(c);
     if (!c) return 0;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
@@ -371,6 +384,7 @@ static int handoff_check(rama_ctx* c) {
 }
 
 int rama_sync(rama_ctx* c) {
+    RAMA_ENTER(c);
     REQUIRE(c, RAMA_EINVAL, "rama_sync: ctx is NULL");
     HIPCHK(hipStreamSynchronize(c->stream));
     return handoff_check(c);
@@ -379,6 +393,7 @@ int rama_sync(rama_ctx* c) {
 // 0: everything enqueued on the context's stream has run; 1: work is still running; anything else: the stream has failed (the error
 // is also recorded for rama_last_error).  Never blocks -- what a host loop that polls the token rings uses to know when to stop.
 int rama_stream_query(rama_ctx* c) {
+    RAMA_ENTER(c);
     REQUIRE(c, RAMA_EINVAL, "rama_stream_query: ctx is NULL");
     const hipError_t e = hipStreamQuery(c->stream);
     if (e == hipSuccess) return 0;
@@ -387,6 +402,7 @@ int rama_stream_query(rama_ctx* c) {
 }
 
 int rama_device_info(rama_ctx* c, char name[64], int* cus, size_t* hbm) {
+    RAMA_ENTER(c);
     REQUIRE(c, RAMA_EINVAL, "ctx is NULL");
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, c->device));
@@ -402,6 +418,7 @@ int rama_device_info(rama_ctx* c, char name[64], int* cus, size_t* hbm) {
 // ---------------------------------------------------------------- memory
 
 int rama_alloc_f32(rama_ctx* c, size_t n, float** out) {
+    RAMA_ENTER(c);
     REQUIRE(c && out, RAMA_EINVAL, "rama_alloc_f32: NULL argument");
     if (set_device(c)) return 1;
     void* p = nullptr;
@@ -413,6 +430,7 @@ int rama_alloc_f32(rama_ctx* c, size_t n, float** out) {
 }
 
 int rama_copy_h2d_f32(rama_ctx* c, float* dst, const float* host, size_t n) {
+    RAMA_ENTER(c);
     REQUIRE(c && (n == 0 || (dst && host)), RAMA_EINVAL, "rama_copy_h2d_f32: NULL argument");
     if (n == 0) return 0;
     { const int rf = rama_internal_forget_range(c, dst, n, 0); if (rf) return rf; }      // copies derived from what is overwritten here
@@ -422,12 +440,14 @@ int rama_copy_h2d_f32(rama_ctx* c, float* dst, const float* host, size_t n) {
 }
 
 int rama_upload_f32(rama_ctx* c, const float* host, size_t n, float** out) {
+    RAMA_ENTER(c);
     int rc = rama_alloc_f32(c, n, out);
     if (rc) return rc;
     return rama_copy_h2d_f32(c, *out, host, n);
 }
 
 int rama_download_f32(rama_ctx* c, const float* src, size_t n, float* host) {
+    RAMA_ENTER(c);
     REQUIRE(c && (n == 0 || (src && host)), RAMA_EINVAL, "rama_download_f32: NULL argument");
     if (n == 0) return 0;
     HIPCHK(hipMemcpyAsync(host, src, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -436,6 +456,7 @@ int rama_download_f32(rama_ctx* c, const float* src, size_t n, float* host) {
 }
 
 int rama_free(rama_ctx* c, void* p) {
+    RAMA_ENTER(c);
     REQUIRE(c, RAMA_EINVAL, "ctx is NULL");
     if (!p) return 0;
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -491,6 +512,17 @@ struct KTimer {
         }                                                                                                       \
     } while (0)
 
+// the pending run of apply_position calls (rama_ctx::rope) as one launch: `count` consecutive heads are one vector of count x head_size floats
+static int flush_rope(rama_ctx* c) {
+    if (!c->rope.count) return 0;
+    const int hs = c->rope.hs, dim = c->rope.count * hs, n = dim / 2;
+    c->rope.count = 0;
+    if (c->tune_ref_order) hipLaunchKernelGGL(rope_ref_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, c->rope.q, c->rope.k, (const float*)nullptr, c->rope.pr, c->rope.pi, dim, hs,
+                                              (float*)nullptr, (float*)nullptr);
+    else hipLaunchKernelGGL(apply_position_heads_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, c->rope.q, c->rope.k, c->rope.pr, c->rope.pi, hs, dim);
+    LAUNCHCHK();
+    return 0;
+}
 static int check_matvec_shape(size_t width, size_t rows) {
     REQUIRE(width % 4 == 0, RAMA_EINVAL, "matmul: width % 4 != 0 (the reference CPU body panics here, cpu.rs:142-143)");
     REQUIRE(width > 0 && rows > 0, RAMA_EINVAL, "matmul: empty shape");
@@ -754,18 +786,21 @@ static int try_launch_attn_wo_chain(rama_ctx* c, const rama_config* cfg, rama_ru
 // ---------------------------------------------------------------- Device<T> ops, 1:1
 
 int rama_array_add(rama_ctx* c, float* t, const float* s, size_t n) {
+    RAMA_ENTER(c);
     REQUIRE(c && (n == 0 || (t && s)), RAMA_EINVAL, "array_add: NULL argument");
     if (!n) return 0;
     hipLaunchKernelGGL(array_add_kernel, dim3(ew_grid(n)), dim3(256), 0, c->stream, t, s, n);
     LAUNCHCHK(); return 0;
 }
 int rama_array_mult(rama_ctx* c, float* t, const float* s, size_t n) {
+    RAMA_ENTER(c);
     REQUIRE(c && (n == 0 || (t && s)), RAMA_EINVAL, "array_mult: NULL argument");
     if (!n) return 0;
     hipLaunchKernelGGL(array_mult_kernel, dim3(ew_grid(n)), dim3(256), 0, c->stream, t, s, n);
     LAUNCHCHK(); return 0;
 }
 int rama_sinu(rama_ctx* c, float* o, size_t n) {
+    RAMA_ENTER(c);
     REQUIRE(c && (n == 0 || o), RAMA_EINVAL, "sinu: NULL argument");
     if (!n) return 0;
     if (c->tune_ref_order) hipLaunchKernelGGL(sinu_ref_kernel, dim3(ew_grid(n)), dim3(256), 0, c->stream, o, n);
@@ -773,12 +808,14 @@ int rama_sinu(rama_ctx* c, float* o, size_t n) {
     LAUNCHCHK(); return 0;
 }
 int rama_copy_from_slice(rama_ctx* c, float* t, const float* s, size_t n) {
+    RAMA_ENTER(c);
     REQUIRE(c && (n == 0 || (t && s)), RAMA_EINVAL, "copy_from_slice: NULL argument");
     if (!n) return 0;
     hipLaunchKernelGGL(copy_kernel, dim3(ew_grid(n)), dim3(256), 0, c->stream, t, s, n);
     LAUNCHCHK(); return 0;
 }
 int rama_rmsnorm(rama_ctx* c, float* o, const float* x, const float* w, size_t n) {
+    RAMA_ENTER(c);
     REQUIRE(c && o && x && w && n > 0, RAMA_EINVAL, "rmsnorm: bad argument");
     if (c->tune_ref_order) return c->tune_chain && rmsnorm_chain_ok(n) ? launch_rmsnorm_chain(c, o, x, w, (int)n, nullptr) : launch_rmsnorm_ref(c, o, x, w, (int)n);
     hipLaunchKernelGGL(rmsnorm_kernel, dim3(1), dim3(1024), 0, c->stream, o, x, w, (int)n);
@@ -786,6 +823,15 @@ int rama_rmsnorm(rama_ctx* c, float* o, const float* x, const float* w, size_t n
 }
 int rama_apply_position(rama_ctx* c, float* q, float* k, const float* pr, const float* pi, size_t head_size) {
     REQUIRE(c && q && k && pr && pi && head_size >= 2, RAMA_EINVAL, "apply_position: bad argument");
+    if (c->tune_rope_batch && c->own_stream && head_size % 2 == 0 && head_size <= 4096) {
+        auto& r = c->rope;
+        const int hs = (int)head_size;
+        if (r.count && r.count < 4096 && hs == r.hs && pr == r.pr && pi == r.pi && q == r.q + (size_t)r.count * hs && k == r.k + (size_t)r.count * hs) { r.count++; return 0; }
+        const int rf = flush_rope(c); if (rf) return rf;
+        r.q = q; r.k = k; r.pr = pr; r.pi = pi; r.hs = hs; r.count = 1;
+        return 0;
+    }
+    { const int rf = flush_rope(c); if (rf) return rf; }
     int n = (int)(head_size / 2);
     if (c->tune_ref_order) {
         hipLaunchKernelGGL(rope_ref_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, q, k, (const float*)nullptr, pr, pi, (int)head_size, (int)head_size,
@@ -796,6 +842,7 @@ int rama_apply_position(rama_ctx* c, float* q, float* k, const float* pr, const 
     LAUNCHCHK(); return 0;
 }
 int rama_matmul(rama_ctx* c, float* o, const float* a, const float* b, size_t width, size_t o_rows, size_t o_cols) {
+    RAMA_ENTER(c);
     REQUIRE(c && o && a && b, RAMA_EINVAL, "matmul: NULL argument");
     REQUIRE(o_cols >= 1, RAMA_EINVAL, "matmul: o_cols == 0");
     int rc = check_matvec_shape(width, o_rows);
@@ -828,6 +875,7 @@ int rama_matmul(rama_ctx* c, float* o, const float* a, const float* b, size_t wi
     return launch_rows<false, EPI_STORE>(c, o, a, b, nullptr, (int)width, (int)o_rows);
 }
 int rama_softmax(rama_ctx* c, float* x, size_t n) {
+    RAMA_ENTER(c);
     REQUIRE(c && x && n > 0, RAMA_EINVAL, "softmax: bad argument");
     if (c->tune_ref_order && c->tune_chain && rmsnorm_chain_ok(n)) {
         hipLaunchKernelGGL(softmax_chain_kernel, dim3(1), dim3(kNormThreads), (n + (n >> 5) + 2) * sizeof(float), c->stream, x, (int)n);
@@ -976,6 +1024,7 @@ static int launch_attention(rama_ctx* c, float* xb, float* att, const float* q, 
 int rama_multi_head_attention(rama_ctx* c, float* xb, float* att, const float* q, const float* key_cache,
                               const float* value_cache, int layer, int dim, int pos, int head_size,
                               int seq_len, int n_heads) {
+    RAMA_ENTER(c);
     REQUIRE(c && xb && att && q && key_cache && value_cache, RAMA_EINVAL, "multi_head_attention: NULL argument");
     REQUIRE(pos >= 0 && pos < seq_len && layer >= 0 && n_heads > 0 && n_heads * head_size == dim, RAMA_EINVAL, "multi_head_attention: bad shape");
     const size_t lo = (size_t)layer * seq_len * dim;   // cpu.rs:28
@@ -987,6 +1036,7 @@ int rama_multi_head_attention(rama_ctx* c, float* xb, float* att, const float* q
 }
 
 int rama_sample_argmax(rama_ctx* c, const float* logits, size_t n, int32_t* next_host) {
+    RAMA_ENTER(c);
     REQUIRE(c && logits && next_host && n > 0, RAMA_EINVAL, "sample_argmax: bad argument");
     ArgmaxParams ap{};
     ap.logits = logits; ap.n = (int)n; ap.result = c->argmax_result;
@@ -999,6 +1049,7 @@ int rama_sample_argmax(rama_ctx* c, const float* logits, size_t n, int32_t* next
 }
 
 int rama_sample_topp(rama_ctx* c, const float* logits, size_t n, float temperature, float topp, float u, int32_t* next_host) {
+    RAMA_ENTER(c);
     REQUIRE(c && logits && next_host && n > 1, RAMA_EINVAL, "sample_topp: bad argument");
     if (temperature == 0.0f) return rama_sample_argmax(c, logits, n, next_host);
     // Device::sample (cpu.rs:168-178) on the device; only the 4-byte result crosses PCIe (the
@@ -1014,6 +1065,7 @@ int rama_sample_topp(rama_ctx* c, const float* logits, size_t n, float temperatu
 }
 
 int rama_ref_expf(rama_ctx* c, float* o, const float* x, size_t n) {
+    RAMA_ENTER(c);
     REQUIRE(c && (n == 0 || (o && x)), RAMA_EINVAL, "ref_expf: NULL argument");
     if (!n) return 0;
     hipLaunchKernelGGL(expf_glibc_kernel, dim3(ew_grid(n)), dim3(256), 0, c->stream, o, x, n);
@@ -1023,6 +1075,7 @@ int rama_ref_expf(rama_ctx* c, float* o, const float* x, size_t n) {
 // ---------------------------------------------------------------- synthetic fill
 
 int rama_fill_synth(rama_ctx* c, float* dst, size_t n, uint64_t seed, uint64_t tag, uint64_t offset, float scale, float bias) {
+    RAMA_ENTER(c);
     REQUIRE(c && (n == 0 || dst), RAMA_EINVAL, "fill_synth: NULL argument");
     if (!n) return 0;
     const uint64_t base = offset + tag * 0x9E3779B97F4A7C15ULL + seed * 0xD1B54A32D192ED03ULL;
@@ -1509,6 +1562,7 @@ static int ensure_chain_copy(rama_ctx* c, const rama_config* cfg, const rama_wei
 
 int rama_forward_stage(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s,
                        int token, int pos, const rama_stage* st) {
+    RAMA_ENTER(c);
     REQUIRE(c, RAMA_EINVAL, "ctx is NULL");
     if (set_device(c)) return 1;
     int rc = check_cfg(cfg); if (rc) return rc;
@@ -1528,6 +1582,7 @@ int rama_forward_stage(rama_ctx* c, const rama_config* cfg, const rama_weights* 
 // pipeline-stage variants: the token id stays in device memory end to end
 int rama_forward_stage_devtok(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s,
                               const int32_t* token_dev, int pos, const rama_stage* st) {
+    RAMA_ENTER(c);
     REQUIRE(c, RAMA_EINVAL, "ctx is NULL");
     if (set_device(c)) return 1;
     int rc = check_cfg(cfg); if (rc) return rc;
@@ -1576,12 +1631,14 @@ static int topp_dist_check(rama_ctx* c) {
 }
 // test entry (not in the C ABI header): set the word, as a launch whose wait gave up would
 extern "C" int rama_internal_topp_dist_poke(rama_ctx* c, unsigned value) {
+    RAMA_ENTER(c);
     if (!c || !c->topp_dist) return 1;
     hipStreamSynchronize(c->stream);
     return hipMemcpy(topp_dist_params(c).bad, &value, sizeof value, hipMemcpyHostToDevice) != hipSuccess;
 }
 // diagnostics (not in the C ABI header): bit 0 a hand-off wait of topp_pick_dist_kernel timed out, bit 1 a predicted binade did not hold
 extern "C" int rama_internal_topp_dist_bad(rama_ctx* c, unsigned* bad) {
+    RAMA_ENTER(c);
     if (!c || !bad) return 1;
     *bad = 0;
     if (!c->topp_dist) return 0;
@@ -1693,6 +1750,7 @@ static int enqueue_sample_launches(rama_ctx* c, ArgmaxParams fin, float temperat
 }
 
 int rama_sample_topp_dev(rama_ctx* c, const float* logits, size_t n, float temperature, float topp, float u, int32_t* result_dev) {
+    RAMA_ENTER(c);
     REQUIRE(c && logits && result_dev && n > 1 && n < (1u << 30), RAMA_EINVAL, "sample_topp_dev: bad argument");
     int rc = temperature != 0.0f ? ensure_topp_scratch(c, (int)n) : 0;
     if (rc) return rc;
@@ -1702,6 +1760,7 @@ int rama_sample_topp_dev(rama_ctx* c, const float* logits, size_t n, float tempe
 }
 
 int rama_decode_sampler(rama_ctx* c, float temperature, float topp, float u) {
+    RAMA_ENTER(c);
     REQUIRE(c, RAMA_EINVAL, "ctx is NULL");
     REQUIRE(temperature >= 0.0f && topp >= 0.0f && topp <= 1.0f && u >= 0.0f && u < 1.0f, RAMA_EINVAL, "decode_sampler: temperature >= 0, topp in [0,1], u in [0,1)");
     if (temperature != c->samp_T || topp != c->samp_topp || u != c->samp_u) {
@@ -1713,6 +1772,7 @@ int rama_decode_sampler(rama_ctx* c, float temperature, float topp, float u) {
 }
 
 int rama_argmax_dev(rama_ctx* c, const float* logits, size_t n, int32_t* result_dev) {
+    RAMA_ENTER(c);
     REQUIRE(c && logits && result_dev && n > 0, RAMA_EINVAL, "argmax_dev: bad argument");
     ArgmaxParams ap{};
     ap.logits = logits; ap.n = (int)n; ap.result = (int*)result_dev;
@@ -1722,6 +1782,7 @@ int rama_argmax_dev(rama_ctx* c, const float* logits, size_t n, int32_t* result_
 }
 
 int rama_forward(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s, int token, int pos) {
+    RAMA_ENTER(c);
     REQUIRE(cfg, RAMA_EINVAL, "config is NULL");
     rama_stage st{0, cfg->n_layers, 1, 1};
     return rama_forward_stage(c, cfg, w, s, token, pos, &st);
@@ -2090,6 +2151,7 @@ static int decode_batch_chain(rama_ctx* c, const rama_config* cfg, const rama_we
 
 int rama_prefill(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s,
                  const int32_t* tokens_host, int n_tokens, int pos0) {
+    RAMA_ENTER(c);
     REQUIRE(c && tokens_host, RAMA_EINVAL, "prefill: NULL argument");
     int rc = check_cfg(cfg); if (rc) return rc;
     rama_stage st{0, cfg->n_layers, 1, 1};
@@ -2161,6 +2223,7 @@ static int enqueue_batch_pass(rama_ctx* c, const rama_config* cfg, const rama_we
 // contract is "what forward(token_i, pos_i) leaves in state_i, for every i": cache rows + logits.
 int rama_decode_batch(rama_ctx* c, const rama_config* cfg, const rama_weights* w, const rama_run_state* states,
                       const int32_t* tokens_host, const int32_t* pos_host, int n_seq) {
+    RAMA_ENTER(c);
     REQUIRE(c && states && tokens_host && pos_host, RAMA_EINVAL, "decode_batch: NULL argument");
     REQUIRE(n_seq >= 1 && n_seq <= kMfMaxTok, RAMA_EINVAL, "decode_batch: 1..128 sequences per call");
     int rc = check_cfg(cfg); if (rc) return rc;
@@ -2265,6 +2328,7 @@ __global__ __launch_bounds__(1024) void argmax_batch_kernel(BatchArgmaxParams p)
 
 int rama_decode_batch_begin(rama_ctx* c, const rama_config* cfg, const rama_weights* w, const rama_run_state* states,
                             const int32_t* tokens_host, const int32_t* pos_host, int n_seq, int max_steps) {
+    RAMA_ENTER(c);
     REQUIRE(c && states && tokens_host && pos_host, RAMA_EINVAL, "decode_batch_begin: NULL argument");
     REQUIRE(n_seq >= 1 && n_seq <= kMfMaxTok, RAMA_EINVAL, "decode_batch_begin: 1..128 sequences");
     REQUIRE(max_steps >= 1 && max_steps <= (1 << 20), RAMA_EINVAL, "decode_batch_begin: bad max_steps");
@@ -2312,6 +2376,7 @@ int rama_decode_batch_begin(rama_ctx* c, const rama_config* cfg, const rama_weig
 }
 
 int rama_decode_batch_steps(rama_ctx* c, int n_steps) {
+    RAMA_ENTER(c);
     REQUIRE(c && c->bc.n_seq > 0, RAMA_EINVAL, "decode_batch_steps: call rama_decode_batch_begin first");
     REQUIRE(n_steps >= 0 && c->bc.steps_done + n_steps <= c->bc.out_cap, RAMA_EINVAL, "decode_batch_steps: more steps than rama_decode_batch_begin allowed for");
     if (set_device(c)) return 1;
@@ -2350,6 +2415,7 @@ int rama_decode_batch_steps(rama_ctx* c, int n_steps) {
 }
 
 int rama_decode_batch_tokens(rama_ctx* c, int32_t* out_host, int max_per_seq, int* n_per_seq) {
+    RAMA_ENTER(c);
     REQUIRE(c && out_host && n_per_seq && c->bc.n_seq > 0, RAMA_EINVAL, "decode_batch_tokens: bad argument");
     auto& bc = c->bc;
     const int n = std::min(bc.steps_done, max_per_seq);
@@ -2364,6 +2430,7 @@ int rama_decode_batch_tokens(rama_ctx* c, int32_t* out_host, int max_per_seq, in
 // tokens `from`.. sequence `seq` of the chained batch has produced so far, without touching the stream (the host-visible
 // ring of rama_decode_stream_poll, one row per sequence): a server hands each request its tokens as they appear
 int rama_decode_batch_stream_poll(rama_ctx* c, int seq, int from, int32_t* out_host, int max_tokens, int* n_ready) {
+    RAMA_ENTER(c);
     REQUIRE(c && n_ready && c->bc.n_seq > 0 && c->bc.ring && seq >= 0 && seq < c->bc.n_seq && from >= 0 && max_tokens >= 0 && (max_tokens == 0 || out_host),
             RAMA_EINVAL, "decode_batch_stream_poll: bad argument");
     const int* row = c->bc.ring + (size_t)seq * c->bc.out_cap;
@@ -2390,6 +2457,7 @@ static int ring_reset(rama_ctx* c) {
 }
 
 int rama_decode_begin(rama_ctx* c, int token, int pos, const int32_t* forced_host, int n_forced) {
+    RAMA_ENTER(c);
     REQUIRE(c, RAMA_EINVAL, "ctx is NULL");
     { int rr = ring_reset(c); if (rr) return rr; }
     REQUIRE(n_forced >= 0 && n_forced <= c->forced_cap, RAMA_EINVAL, "decode_begin: too many forced tokens");
@@ -2432,6 +2500,7 @@ static bool same_capture(const GraphCache& g, const rama_config* cfg, const rama
 }
 
 int rama_decode_steps(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s, int n_steps) {
+    RAMA_ENTER(c);
     REQUIRE(c, RAMA_EINVAL, "ctx is NULL");
     if (set_device(c)) return 1;
     int rc = check_cfg(cfg); if (rc) return rc;
@@ -2487,6 +2556,7 @@ int rama_decode_steps(rama_ctx* c, const rama_config* cfg, const rama_weights* w
 // sampling launch writes next to its device list (generate_stream's channel, mod.rs:209-248: each token as it is produced).
 // Returns at once; *n_ready may be 0.  Errors of the loop itself are reported by rama_decode_tokens at the end.
 int rama_decode_stream_poll(rama_ctx* c, int from, int32_t* out_host, int max_tokens, int* n_ready) {
+    RAMA_ENTER(c);
     REQUIRE(c && n_ready && from >= 0 && max_tokens >= 0 && (max_tokens == 0 || out_host), RAMA_EINVAL, "decode_stream_poll: bad argument");
     int n = 0;
     while (n < max_tokens && from + n < c->out_cap) {
@@ -2499,6 +2569,7 @@ int rama_decode_stream_poll(rama_ctx* c, int from, int32_t* out_host, int max_to
 }
 
 int rama_decode_tokens(rama_ctx* c, int32_t* out_host, int max_tokens, int* n_out) {
+    RAMA_ENTER(c);
     REQUIRE(c && n_out, RAMA_EINVAL, "decode_tokens: NULL argument");
     Ctl h;
     HIPCHK(hipMemcpyAsync(&h, c->ctl, sizeof h, hipMemcpyDeviceToHost, c->stream));
@@ -2530,6 +2601,7 @@ int rama_decode_tokens(rama_ctx* c, int32_t* out_host, int max_tokens, int* n_ou
 
 int rama_generate_greedy(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s,
                          const int32_t* prompt_host, int n_prompt, int steps, int32_t* out_host) {
+    RAMA_ENTER(c);
     return rama_generate(c, cfg, w, s, prompt_host, n_prompt, steps, 0.0f, 0.9f, 0.0f, out_host);
 }
 
@@ -2587,6 +2659,7 @@ static int generate_enqueue(rama_ctx* c, const rama_config* cfg, const rama_weig
 int rama_generate(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s,
                   const int32_t* prompt_host, int n_prompt, int steps, float temperature, float topp, float u,
                   int32_t* out_host) {
+    RAMA_ENTER(c);
     REQUIRE(out_host, RAMA_EINVAL, "generate_greedy: NULL argument");
     int rc = generate_enqueue(c, cfg, w, s, prompt_host, n_prompt, steps, temperature, topp, u);
     if (rc) return rc;
@@ -2600,6 +2673,7 @@ int rama_generate(rama_ctx* c, const rama_config* cfg, const rama_weights* w, ra
 int rama_generate_stream(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s,
                          const int32_t* prompt_host, int n_prompt, int steps, float temperature, float topp, float u,
                          void (*on_token)(void* user, int index, int32_t token), void* user, int32_t* out_host) {
+    RAMA_ENTER(c);
     REQUIRE(on_token, RAMA_EINVAL, "generate_stream: NULL callback");
     int todo = 0;
     int rc = generate_enqueue(c, cfg, w, s, prompt_host, n_prompt, steps, temperature, topp, u, &todo);
@@ -2643,6 +2717,7 @@ int rama_generate_stream(rama_ctx* c, const rama_config* cfg, const rama_weights
 }
 
 int rama_set_tuning(rama_ctx* c, const char* key, int value) {
+    RAMA_ENTER(c);
     REQUIRE(c && key, RAMA_EINVAL, "set_tuning: NULL argument");
     if (!strcmp(key, "split_pos")) {
         REQUIRE(value >= -1, RAMA_EINVAL, "set_tuning: split_pos must be >= -1");
@@ -2748,6 +2823,11 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
         c->tune_chain_resid_d = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
+        return 0;
+    }
+    if (!strcmp(key, "rope_batch")) {
+        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: rope_batch must be 0 or 1");
+        c->tune_rope_batch = value;
         return 0;
     }
     if (!strcmp(key, "chain_views")) {
@@ -2883,6 +2963,7 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
 }
 
 int rama_set_graph_mode(rama_ctx* c, int enabled) {
+    RAMA_ENTER(c);
     REQUIRE(c, RAMA_EINVAL, "ctx is NULL");
     c->graph_mode = enabled != 0;
     if (!enabled) { hipStreamSynchronize(c->stream); drop_graph(c); }
@@ -2892,11 +2973,13 @@ int rama_set_graph_mode(rama_ctx* c, int enabled) {
 // ---------------------------------------------------------------- measurement
 
 int rama_timer_start(rama_ctx* c) {
+    RAMA_ENTER(c);
     REQUIRE(c, RAMA_EINVAL, "ctx is NULL");
     HIPCHK(hipEventRecord(c->t0, c->stream));
     return 0;
 }
 int rama_timer_stop(rama_ctx* c, float* ms) {
+    RAMA_ENTER(c);
     REQUIRE(c && ms, RAMA_EINVAL, "timer_stop: NULL argument");
     HIPCHK(hipEventRecord(c->t1, c->stream));
     HIPCHK(hipEventSynchronize(c->t1));
@@ -2905,6 +2988,7 @@ int rama_timer_stop(rama_ctx* c, float* ms) {
 }
 
 int rama_kprof_enable(rama_ctx* c, int kernel_id, int max_records) {
+    RAMA_ENTER(c);
     REQUIRE(c && kernel_id >= 0 && kernel_id < RAMA_K_COUNT && max_records > 0, RAMA_EINVAL, "kprof_enable: bad argument");
     KProf& k = c->kp;
     while ((int)k.ev.size() < 2 * max_records) {
@@ -2914,6 +2998,7 @@ int rama_kprof_enable(rama_ctx* c, int kernel_id, int max_records) {
     return 0;
 }
 int rama_kprof_read(rama_ctx* c, int* n_launches, double* total_ms) {
+    RAMA_ENTER(c);
     REQUIRE(c && n_launches && total_ms, RAMA_EINVAL, "kprof_read: NULL argument");
     KProf& k = c->kp;
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -2931,6 +3016,7 @@ int rama_kprof_read(rama_ctx* c, int* n_launches, double* total_ms) {
 // ---------------------------------------------------------------- state
 
 int rama_state_create(rama_ctx* c, const rama_config* cfg, int n_local_layers, rama_run_state* out) {
+    RAMA_ENTER(c);
     REQUIRE(c && out, RAMA_EINVAL, "state_create: NULL argument");
     int rc = check_cfg(cfg); if (rc) return rc;
     REQUIRE(n_local_layers >= 0 && n_local_layers <= cfg->n_layers, RAMA_EINVAL, "state_create: bad layer count");
@@ -2951,6 +3037,7 @@ int rama_state_create(rama_ctx* c, const rama_config* cfg, int n_local_layers, r
 }
 
 int rama_state_free(rama_ctx* c, rama_run_state* s) {
+    RAMA_ENTER(c);
     REQUIRE(c && s, RAMA_EINVAL, "state_free: NULL argument");
     int rc = rama_free(c, s->x);   // x is the blob base
     memset(s, 0, sizeof *s);

@@ -414,6 +414,51 @@ def test_parity_one_launch_stage_bit_exact(dev, dim, hidden, heads, layers, voca
         eng.free(); model.free()
 
 
+@pytest.mark.parametrize("heads,hs", [(32, 128), (6, 48), (3, 2)])
+def test_apply_position_runs_are_one_launch_and_keep_their_order(dev, heads, hs):
+    """[r5] a run of Device::apply_position calls on consecutive heads (infer.rs:25-29) is recorded and issued as ONE launch by whatever enters the
+    library next: bit for bit what one launch per call gives (cpu.rs:87-96's three roundings) -- in call order with other ops in between, out of order,
+    the same head twice, a run followed at once by a download, and with "rope_batch" = 0"""
+    from rama_amd._lib import check
+    dim = heads * hs
+    q0, k0 = rnd(dim, 41, 1.3), rnd(dim, 42, 0.7)
+    ang = np.random.default_rng(43).uniform(0, 6.28, hs // 2)
+    pr, pi = np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32)
+    tpr, tpi = up(dev, pr), up(dev, pi)
+
+    def head(t, h):
+        return t.mut_slice(h * hs)
+
+    def oracle_heads(q, k, order):
+        for h in order:
+            qq, kk = q[h * hs:(h + 1) * hs].copy(), k[h * hs:(h + 1) * hs].copy()
+            O.apply_position(qq, kk, pr, pi, hs)
+            q[h * hs:(h + 1) * hs], k[h * hs:(h + 1) * hs] = qq, kk
+
+    orders = [list(range(heads)), list(reversed(range(heads))), [0, 0, 1] + list(range(1, heads)), [heads - 1]]
+    for batch in (1, 0):
+        check(dev.lib.rama_set_tuning(dev.ctx, b"rope_batch", batch))
+        for order in orders:
+            tq, tk = up(dev, q0), up(dev, k0)
+            eq, ek = q0.copy(), k0.copy()
+            for h in order:
+                dev.apply_position(head(tq, h), head(tk, h), tpr.as_view(), tpi.as_view(), hs)
+            oracle_heads(eq, ek, order)
+            assert_bits_equal(dev.download(tq), eq, f"rope_batch {batch} order {order[:4]} q")      # (the download issues the pending run)
+            assert_bits_equal(dev.download(tk), ek, f"rope_batch {batch} order {order[:4]} k")
+            # an op between two runs sees the first run's result and the second run sees the op's
+            tadd = up(dev, np.full(dim, 0.5, np.float32))
+            for h in range(heads):
+                dev.apply_position(head(tq, h), head(tk, h), tpr.as_view(), tpi.as_view(), hs)
+            dev.array_add(tq, tadd.as_view(), dim)
+            for h in range(heads):
+                dev.apply_position(head(tq, h), head(tk, h), tpr.as_view(), tpi.as_view(), hs)
+            oracle_heads(eq, ek, range(heads)); eq = eq + np.float32(0.5); oracle_heads(eq, ek, range(heads))
+            assert_bits_equal(dev.download(tq), eq, f"rope_batch {batch} runs around an op, q")
+            assert_bits_equal(dev.download(tk), ek, f"rope_batch {batch} runs around an op, k")
+    check(dev.lib.rama_set_tuning(dev.ctx, b"rope_batch", 1))
+
+
 def _chain_lookup(dev, ptr, rows, K):
     f = dev.lib.rama_internal_chain_lookup
     f.restype = C.c_void_p
