@@ -433,7 +433,11 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *   "chain_views" = 0|1 : parity mode's rama_matmul makes a chain-order copy of a matrix of no model on first use (default 1)
  *   "rope_batch" = 0|1 : [r5] a run of rama_apply_position calls on consecutive heads (q, k advancing by head_size, the same table rows:
  *                   infer.rs:25-29) is recorded and issued as ONE launch by whatever enters the library next -- same bits, 32 launches per layer
- *                   fewer (the 1:1 path 131 -> 172 tok/s at llama2-7B); only on a stream the context created itself (default 1) */
+ *                   fewer (the 1:1 path 131 -> 172 tok/s at llama2-7B); only on a stream the context created itself (default 1)
+ *   "matmul_batch" = 0|1, "ew_batch" = 0|1 : [r5] likewise up to three parity-mode rama_matmul calls with the same activations and shape
+ *                   (infer.rs:20-23, :41-42), rama_sinu + the rama_array_mult on the same vector (:44-45) and two rama_copy_from_slice
+ *                   calls in a row (:32-33): recorded, issued as one launch by the next entry into the library, program order kept at
+ *                   every overlap (172 -> 185 tok/s; default 1) */
 int  rama_set_tuning(rama_ctx *ctx, const char *key, int value);
 
 /* glibc 2.35 expf (the exp the reference's f32::exp calls on Linux) as the reference-order kernels

@@ -893,7 +893,7 @@ __device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in)
     const float t2 = v + dpp_mov<0xB1>(v);                       // quad_perm [1,0,3,2]
     const float d = t2 + dpp_mov<0x4E>(t2);                      // quad_perm [2,3,0,1]
     if (EPI == CEPI_STORE) {
-        if (j == 0 && row < p.rows) p.o[0][row] = d;
+        if (j == 0 && row < p.rows) { float* o = m == 0 ? p.o[0] : (m == 1 ? p.o[1] : p.o[2]); o[row] = d; }      // (nmat > 1: a run of Device::matmul calls as one launch)
     } else if (EPI == CEPI_RESID) {
         if (j == 0 && row < p.rows) { p.o[0][row] = d; p.resid[row] = xold + d; }
     } else if (EPI == CEPI_QKV) {

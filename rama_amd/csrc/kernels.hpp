@@ -794,6 +794,20 @@ __global__ void sinu_kernel(float* o, size_t n) {
         o[i] = a * (1.0f / (1.0f + expf(-a)));
     }
 }
+// two Device::copy_from_slice calls as one launch (infer.rs:32-33: the key row and the value row of the cache)
+__global__ void copy2_kernel(float* t1, const float* s1, size_t n1, float* t2, const float* s2, size_t n2) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n1 + n2; i += (size_t)gridDim.x * blockDim.x) {
+        if (i < n1) t1[i] = s1[i]; else t2[i - n1] = s2[i - n1];
+    }
+}
+// Device::sinu followed by Device::array_mult on the same vector (infer.rs:44-45) as one launch, each product rounded as in the two
+__global__ void sinu_mult_kernel(float* o, const float* s, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float a = o[i];
+        a = a * (1.0f / (1.0f + expf(-a)));
+        o[i] = a * s[i];
+    }
+}
 __global__ void copy_kernel(float* t, const float* s, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) t[i] = s[i];
 }

@@ -179,6 +179,14 @@ struct rama_ctx {
     // whatever enters the library next issues it first (RAMA_ENTER).  Only on a stream the context owns ("rope_batch" = 0: every call a launch).
     struct { float* q = nullptr; float* k = nullptr; const float* pr = nullptr; const float* pi = nullptr; int hs = 0, count = 0; } rope;
     int tune_rope_batch = 1;
+    // ... and so is a run of up to three parity-mode Device::matmul calls with the same activations and shape on chain-order copies (infer.rs:20-23: Wq, Wk,
+    // Wv; :41-42: W1, W3): one launch over all their row groups ("matmul_batch")
+    struct { const float* w[3]; float* o[3]; const float* x = nullptr; int K = 0, rows = 0, count = 0; } mm;
+    int tune_matmul_batch = 1;
+    // ... and Device::sinu waits for the Device::array_mult on the same vector (infer.rs:44-45), one Device::copy_from_slice for the next (:32-33): one
+    // launch per pair ("ew_batch").  At most ONE of the three records is pending at any time: whoever records flushes the others first.
+    struct { int kind = 0; float* t = nullptr; const float* s = nullptr; size_t n = 0; } ew;      // 1: sinu(t, n); 2: copy(t, s, n)
+    int tune_ew_batch = 1;
     int tune_chain_views = 1;              // parity mode, Device::matmul on a matrix of no model: a chain-order copy of the tensor is made on first use
     int tune_prefill_chain = 1;            // parity mode: prompt positions go through the chain-order token-batch kernels (32 per weight pass); 0: one forward() each
     size_t pf_floats = 0;
@@ -215,15 +223,18 @@ static int set_device(rama_ctx* c) { HIPCHK(hipSetDevice(c->device)); return 0; 
 // the pending run of apply_position calls (rama_ctx::rope) is issued by whatever enters the library next: first statement of every entry point
 // that enqueues, synchronises or changes a setting
 static int flush_rope(rama_ctx* c);
-#define RAMA_ENTER(c) do { if ((c) && (c)->rope.count) { const int rf_ = flush_rope(c); if (rf_) return rf_; } } while (0)
+static int flush_mm(rama_ctx* c);
+static int flush_ew(rama_ctx* c);
+static int flush_pending(rama_ctx* c) { int rf = flush_rope(c); if (!rf) rf = flush_mm(c); if (!rf) rf = flush_ew(c); return rf; }
+#define RAMA_ENTER(c) do { if ((c) && ((c)->rope.count | (c)->mm.count | (c)->ew.kind)) { const int rf_ = flush_pending(c); if (rf_) return rf_; } } while (0)
 
 // internal accessors for the library's other translation units (pipe.hip); not in the C ABI header
-extern "C" void* rama_internal_stream(rama_ctx* c) { if (c && c->rope.count) (void)flush_rope(c); return c ? (void*)c->stream : nullptr; }
+extern "C" void* rama_internal_stream(rama_ctx* c) { if (c && (c->rope.count | c->mm.count | c->ew.kind)) (void)flush_pending(c); return c ? (void*)c->stream : nullptr; }
 extern "C" int rama_internal_device(rama_ctx* c) { return c ? c->device : 0; }
 // the sampler's device scratch after a rama_sample_topp* call (tests compare the running sums with a
 // sequential fp32 cumsum): sorted probabilities, sorted indices, running sums, candidate count
 extern "C" void rama_internal_topp_scratch(rama_ctx* c, float** keys, int** vals, float** prefix, int** m) {
-    if (c && c->rope.count) (void)flush_rope(c);
+    if (c && (c->rope.count | c->mm.count | c->ew.kind)) (void)flush_pending(c);
     if (keys) *keys = c->topp_keys[1];
     if (vals) *vals = c->topp_vals[1];
     if (prefix) *prefix = c->topp_prefix;
@@ -345,7 +356,7 @@ static void drop_graph(rama_ctx* c) {
 extern "C" void rama_internal_drop_graphs(rama_ctx* c) { if (c) drop_graph(c); }      // model.hip: before a derived weight copy is freed
 
 int rama_ctx_destroy(rama_ctx* c) {
-    if (c && c->rope.count) (void)flush_rope(c);
+    if (c && (c->rope.count | c->mm.count | c->ew.kind)) (void)flush_pending(c);
     if (!c) return 0;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
@@ -523,6 +534,19 @@ static int flush_rope(rama_ctx* c) {
     LAUNCHCHK();
     return 0;
 }
+// the pending elementwise op (rama_ctx::ew) by itself
+static int flush_ew(rama_ctx* c) {
+    if (!c->ew.kind) return 0;
+    const int kind = c->ew.kind;
+    c->ew.kind = 0;
+    const dim3 grid((unsigned)std::min<size_t>((c->ew.n + 255) / 256, 2048));
+    if (kind == 1) {
+        if (c->tune_ref_order) hipLaunchKernelGGL(sinu_ref_kernel, grid, dim3(256), 0, c->stream, c->ew.t, c->ew.n);
+        else hipLaunchKernelGGL(sinu_kernel, grid, dim3(256), 0, c->stream, c->ew.t, c->ew.n);
+    } else hipLaunchKernelGGL(copy_kernel, grid, dim3(256), 0, c->stream, c->ew.t, c->ew.s, c->ew.n);
+    LAUNCHCHK();
+    return 0;
+}
 static int check_matvec_shape(size_t width, size_t rows) {
     REQUIRE(width % 4 == 0, RAMA_EINVAL, "matmul: width % 4 != 0 (the reference CPU body panics here, cpu.rs:142-143)");
     REQUIRE(width > 0 && rows > 0, RAMA_EINVAL, "matmul: empty shape");
@@ -672,6 +696,15 @@ static int launch_chain(rama_ctx* c, ChainParams& p, int norm = CNORM_NONE) {
     LAUNCHCHK();
     return 0;
 }
+// the pending run of parity-mode matmuls (rama_ctx::mm) as one chain-order launch
+static int flush_mm(rama_ctx* c) {
+    if (!c->mm.count) return 0;
+    ChainParams p{};
+    for (int i = 0; i < c->mm.count; i++) { p.w[i] = c->mm.w[i]; p.o[i] = c->mm.o[i]; }
+    p.x = c->mm.x; p.K = c->mm.K; p.rows = c->mm.rows; p.nmat = c->mm.count;
+    c->mm.count = 0;
+    return launch_chain<CEPI_STORE>(c, p);
+}
 static bool rmsnorm_chain_ok(size_t n) { return n <= (size_t)kNormMax && (n + (n >> 5) + 2) * sizeof(float) <= 64 * 1024; }
 static int launch_rmsnorm_chain(rama_ctx* c, float* o, const float* x, const float* w, int n, float* copy_to, int batch = 1, int stride = 0) {
     const size_t lds = ((size_t)n + ((size_t)n >> 5) + 2) * sizeof(float);
@@ -792,9 +825,16 @@ int rama_array_add(rama_ctx* c, float* t, const float* s, size_t n) {
     hipLaunchKernelGGL(array_add_kernel, dim3(ew_grid(n)), dim3(256), 0, c->stream, t, s, n);
     LAUNCHCHK(); return 0;
 }
+static inline bool ranges_overlap(const float* p0, size_t n0, const float* p1, size_t n1) { return p0 < p1 + n1 && p1 < p0 + n0; }
 int rama_array_mult(rama_ctx* c, float* t, const float* s, size_t n) {
-    RAMA_ENTER(c);
     REQUIRE(c && (n == 0 || (t && s)), RAMA_EINVAL, "array_mult: NULL argument");
+    if (c->ew.kind == 1 && !c->rope.count && !c->mm.count && c->ew.t == t && c->ew.n == n && n && !ranges_overlap(s, n, t, n)) {      // the recorded sinu and this product: one launch
+        c->ew.kind = 0;
+        if (c->tune_ref_order) hipLaunchKernelGGL(sinu_mult_ref_kernel, dim3(ew_grid(n)), dim3(256), 0, c->stream, t, s, n);
+        else hipLaunchKernelGGL(sinu_mult_kernel, dim3(ew_grid(n)), dim3(256), 0, c->stream, t, s, n);
+        LAUNCHCHK(); return 0;
+    }
+    RAMA_ENTER(c);
     if (!n) return 0;
     hipLaunchKernelGGL(array_mult_kernel, dim3(ew_grid(n)), dim3(256), 0, c->stream, t, s, n);
     LAUNCHCHK(); return 0;
@@ -803,14 +843,22 @@ int rama_sinu(rama_ctx* c, float* o, size_t n) {
     RAMA_ENTER(c);
     REQUIRE(c && (n == 0 || o), RAMA_EINVAL, "sinu: NULL argument");
     if (!n) return 0;
+    if (c->tune_ew_batch && c->own_stream) { c->ew.kind = 1; c->ew.t = o; c->ew.s = nullptr; c->ew.n = n; return 0; }      // recorded: the product that usually follows takes it along
     if (c->tune_ref_order) hipLaunchKernelGGL(sinu_ref_kernel, dim3(ew_grid(n)), dim3(256), 0, c->stream, o, n);
     else hipLaunchKernelGGL(sinu_kernel, dim3(ew_grid(n)), dim3(256), 0, c->stream, o, n);
     LAUNCHCHK(); return 0;
 }
 int rama_copy_from_slice(rama_ctx* c, float* t, const float* s, size_t n) {
-    RAMA_ENTER(c);
     REQUIRE(c && (n == 0 || (t && s)), RAMA_EINVAL, "copy_from_slice: NULL argument");
+    if (c->ew.kind == 2 && !c->rope.count && !c->mm.count && n && !ranges_overlap(s, n, c->ew.t, c->ew.n) && !ranges_overlap(t, n, c->ew.t, c->ew.n) &&
+        !ranges_overlap(t, n, c->ew.s, c->ew.n) && !ranges_overlap(t, n, s, n)) {      // the recorded copy and this one: one launch
+        c->ew.kind = 0;
+        hipLaunchKernelGGL(copy2_kernel, dim3(ew_grid(n + c->ew.n)), dim3(256), 0, c->stream, c->ew.t, c->ew.s, c->ew.n, t, s, n);
+        LAUNCHCHK(); return 0;
+    }
+    RAMA_ENTER(c);
     if (!n) return 0;
+    if (c->tune_ew_batch && c->own_stream && !ranges_overlap(t, n, s, n)) { c->ew.kind = 2; c->ew.t = t; c->ew.s = s; c->ew.n = n; return 0; }
     hipLaunchKernelGGL(copy_kernel, dim3(ew_grid(n)), dim3(256), 0, c->stream, t, s, n);
     LAUNCHCHK(); return 0;
 }
@@ -823,6 +871,7 @@ int rama_rmsnorm(rama_ctx* c, float* o, const float* x, const float* w, size_t n
 }
 int rama_apply_position(rama_ctx* c, float* q, float* k, const float* pr, const float* pi, size_t head_size) {
     REQUIRE(c && q && k && pr && pi && head_size >= 2, RAMA_EINVAL, "apply_position: bad argument");
+    { int rm = flush_mm(c); if (!rm) rm = flush_ew(c); if (rm) return rm; }      // (whatever was recorded before this call comes first)
     if (c->tune_rope_batch && c->own_stream && head_size % 2 == 0 && head_size <= 4096) {
         auto& r = c->rope;
         const int hs = (int)head_size;
@@ -842,11 +891,13 @@ int rama_apply_position(rama_ctx* c, float* q, float* k, const float* pr, const 
     LAUNCHCHK(); return 0;
 }
 int rama_matmul(rama_ctx* c, float* o, const float* a, const float* b, size_t width, size_t o_rows, size_t o_cols) {
-    RAMA_ENTER(c);
+    if (c && (c->rope.count | c->ew.kind)) { int rf = flush_rope(c); if (!rf) rf = flush_ew(c); if (rf) return rf; }      // (a pending run of matmuls may be extended by this call: below)
     REQUIRE(c && o && a && b, RAMA_EINVAL, "matmul: NULL argument");
     REQUIRE(o_cols >= 1, RAMA_EINVAL, "matmul: o_cols == 0");
     int rc = check_matvec_shape(width, o_rows);
-    if (rc) return rc;
+    if (rc) { (void)flush_mm(c); return rc; }
+    const bool extendable = c->mm.count && c->mm.count < 3 && c->tune_ref_order && o_cols == 1 && c->mm.x == b && c->mm.K == (int)width && c->mm.rows == (int)o_rows;
+    if (!extendable) { rc = flush_mm(c); if (rc) return rc; }
     if (c->tune_ref_order && o_cols == 1) {
         // a layer-aligned view of a resident model's matrix streams the model's chain-order copy
         if (c->tune_chain && width % 16 == 0 && width <= 16000 && aligned16(b)) {
@@ -856,11 +907,25 @@ int rama_matmul(rama_ctx* c, float* o, const float* a, const float* b, size_t wi
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
             const bool capturing = hipStreamIsCapturing(c->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
             if (const float* ch = c->tune_chain_views ? rama_internal_chain_view(c, a, (int)o_rows, (int)width, capturing ? 1 : 0) : rama_internal_chain_lookup(a, (int)o_rows, (int)width)) {
+                auto& mmb = c->mm;
+                // [r5] recorded, not launched: the next call extends the run (same activations, same shape, an output that overlaps nothing of the run) or
+                // issues it.  A run is one launch over all its row groups.
+                auto overlaps = [](const float* p0, size_t n0, const float* p1, size_t n1) { return p0 < p1 + n1 && p1 < p0 + n0; };
+                bool clash = overlaps(o, o_rows, b, width);
+                for (int i = 0; i < mmb.count && !clash; i++) clash = overlaps(o, o_rows, mmb.o[i], o_rows);
+                if (c->tune_matmul_batch && c->own_stream && !capturing && !clash) {
+                    if (!mmb.count) { mmb.x = b; mmb.K = (int)width; mmb.rows = (int)o_rows; }
+                    mmb.w[mmb.count] = ch; mmb.o[mmb.count] = o; mmb.count++;
+                    if (mmb.count == 3) return flush_mm(c);
+                    return 0;
+                }
+                rc = flush_mm(c); if (rc) return rc;
                 ChainParams p{};
                 p.w[0] = ch; p.o[0] = o; p.x = b; p.K = (int)width; p.rows = (int)o_rows; p.nmat = 1;
                 return launch_chain<CEPI_STORE>(c, p);
             }
         }
+        rc = flush_mm(c); if (rc) return rc;
         return launch_matvec_ref1(c, o, a, b, (int)width, (int)o_rows);
     }
     if (o_cols != 1) {   // forward() never takes this path (o_cols is always 1, infer.rs:20-51)
@@ -2823,6 +2888,16 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
         c->tune_chain_resid_d = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
+        return 0;
+    }
+    if (!strcmp(key, "ew_batch")) {
+        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: ew_batch must be 0 or 1");
+        c->tune_ew_batch = value;
+        return 0;
+    }
+    if (!strcmp(key, "matmul_batch")) {
+        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: matmul_batch must be 0 or 1");
+        c->tune_matmul_batch = value;
         return 0;
     }
     if (!strcmp(key, "rope_batch")) {

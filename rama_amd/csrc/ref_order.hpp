@@ -241,6 +241,16 @@ __global__ void sinu_ref_kernel(float* o, size_t n) {
     }
 }
 
+// ... followed by Device::array_mult on the same vector (infer.rs:44-45), one launch: the same two roundings per element (cpu.rs:56, :59-64)
+__global__ void sinu_mult_ref_kernel(float* o, const float* s, size_t n) {
+    RAMA_NO_CONTRACT
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float a = o[i];
+        const float g = a * (1.0f / (1.0f + expf_glibc(-a)));
+        o[i] = g * s[i];
+    }
+}
+
 // cpu.rs:119-125 Device::softmax (whole view)
 __global__ __launch_bounds__(1024) void softmax_ref_kernel(float* x, int n) {
     RAMA_NO_CONTRACT

@@ -459,6 +459,55 @@ def test_apply_position_runs_are_one_launch_and_keep_their_order(dev, heads, hs)
     check(dev.lib.rama_set_tuning(dev.ctx, b"rope_batch", 1))
 
 
+def test_recorded_ops_keep_program_order(dev):
+    """[r5] Device::sinu, Device::copy_from_slice and parity-mode Device::matmul calls are recorded and issued with the call that follows (sinu + array_mult
+    on the same vector, two copies, up to three matmuls with the same activations: one launch each); every hazard must fall back to program order: a
+    copy that reads what the recorded copy writes, a product into another vector, a matmul whose output is the run's input, a download in between"""
+    import rama_amd
+    from rama_amd._lib import check
+    n = 1000
+    a, b, c3 = rnd(n, 51), rnd(n, 52), rnd(n, 53)
+    for batch in (1, 0):
+        for key in (b"ew_batch", b"matmul_batch", b"rope_batch"):
+            check(dev.lib.rama_set_tuning(dev.ctx, key, batch))
+        # sinu then the product on the same vector; then a product into ANOTHER vector
+        ta, tb, tc = up(dev, a), up(dev, b), up(dev, c3)
+        ea = a.copy(); O.sinu(ea, n); ea = (ea * b).astype(np.float32)
+        dev.sinu(ta, n); dev.array_mult(ta, tb.as_view(), n)
+        assert_bits_equal(dev.download(ta), ea, f"batch {batch}: sinu + array_mult")
+        dev.sinu(tb, n); dev.array_mult(tc, tb.as_view(), n)                   # the product reads what the recorded sinu writes
+        eb = b.copy(); O.sinu(eb, n)
+        assert_bits_equal(dev.download(tc), (c3 * eb).astype(np.float32), f"batch {batch}: sinu, then a product that reads it")
+        assert_bits_equal(dev.download(tb), eb, f"batch {batch}: sinu alone")
+        # two independent copies; then a chain of copies (the second reads the first one's target)
+        t1, t2 = up(dev, np.zeros(n, np.float32)), up(dev, np.zeros(n, np.float32))
+        dev.copy_from_slice(t1, ta.as_view(), n); dev.copy_from_slice(t2, tc.as_view(), n)
+        assert_bits_equal(dev.download(t1), ea, f"batch {batch}: copy 1 of 2"); assert_bits_equal(dev.download(t2), (c3 * eb).astype(np.float32), f"batch {batch}: copy 2 of 2")
+        dev.copy_from_slice(t1, tb.as_view(), n); dev.copy_from_slice(t2, t1.as_view(), n)
+        assert_bits_equal(dev.download(t2), eb, f"batch {batch}: a copy that reads the recorded copy's target")
+        # matmul runs on uploaded matrices: three with the same x; then one whose output is the run's x
+        K, rows = 64, 48
+        ws = [rnd(rows * K, 60 + i, 0.3) for i in range(4)]
+        x = rnd(K, 70)
+        tws = [up(dev, w_) for w_ in ws]
+        tx = up(dev, x)
+        outs = [up(dev, np.zeros(rows, np.float32)) for _ in range(3)]
+        for i in range(3):
+            dev.matmul(outs[i], tws[i].as_view(), tx.as_view(), K, rows, 1)
+        for i in range(3):
+            want = np.empty(rows, np.float32); O.matmul(want, ws[i], x, K, rows)
+            assert_bits_equal(dev.download(outs[i]), want, f"batch {batch}: matmul {i} of a run")
+        wsq = rnd(K * K, 80, 0.2); twsq = up(dev, wsq)
+        y = up(dev, np.zeros(rows, np.float32))
+        dev.matmul(y, tws[3].as_view(), tx.as_view(), K, rows, 1)               # recorded ...
+        tx2 = up(dev, x)
+        dev.matmul(tx2, twsq.as_view(), tx2.as_view(), K, K, 1)                # ... and one that overwrites its own input: not part of any run
+        want = np.empty(rows, np.float32); O.matmul(want, ws[3], x, K, rows)
+        assert_bits_equal(dev.download(y), want, f"batch {batch}: a recorded matmul in front of an in-place one")
+    for key in (b"ew_batch", b"matmul_batch", b"rope_batch"):
+        check(dev.lib.rama_set_tuning(dev.ctx, key, 1))
+
+
 def _chain_lookup(dev, ptr, rows, K):
     f = dev.lib.rama_internal_chain_lookup
     f.restype = C.c_void_p
