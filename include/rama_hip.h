@@ -429,7 +429,7 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *                   4 x this many KiB of their rows while the attention runs (48: one workgroup per CU).  Bit-identical, measured
  *                   SLOWER at llama2-7B (194 / 188 against 200 tok/s: the attention's round trips lengthen under the traffic): default 0
  *   "chain_fused" = -1|0|1 : [r5] parity mode, dim <= 1024, seq_len <= 1024: a whole stage as ONE launch (csrc/layer_chain_fused.hpp).
- *                   Bit-identical, measured SLOWER than the separate launches (stories15M 217 vs 202 us, stories110M 709 vs 426): default 0
+ *                   Bit-identical, measured SLOWER than the separate launches (stories15M 217 vs 202 us, stories110M 514 vs 426): default 0
  *   "chain_views" = 0|1 : parity mode's rama_matmul makes a chain-order copy of a matrix of no model on first use (default 1)
  *   "rope_batch" = 0|1 : [r5] a run of rama_apply_position calls on consecutive heads (q, k advancing by head_size, the same table rows:
  *                   infer.rs:25-29) is recorded and issued as ONE launch by whatever enters the library next -- same bits, 32 launches per layer

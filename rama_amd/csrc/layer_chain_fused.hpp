@@ -117,12 +117,51 @@ struct CfUnit {
     }
 };
 
+// A matvec workgroup WORKS on kCfMW waves (the other waves of the 8 leave at once): a phase then has four times the workgroups -- a wave owns 16 rows
+// where the fast path's owns 4, and with 8 row groups per workgroup stories110M's W1|W3 was 32 workgroups on 32 of 256 compute units.
+constexpr int kCfMW = 2, kCfMT = kCfMW * 64;
 struct CfShared {
-    FastSumShared<kPWaves> fs;
-    PredShared<kPWaves> ps;
-    SeqSumShared<kPWaves> sh;
+    FastSumShared<kCfMW> fs;
+    PredShared<kCfMW> ps;
+    SeqSumShared<kCfMW> sh;
     float v;
 };
+
+// fused_fetch (layer_fused.hpp) for the kCfMT working threads of a matvec workgroup
+__device__ __forceinline__ void cf_fetch(const tagged_t* src, const float* plain, int n, const tagged_t* early, unsigned epoch, float* x_s, int* s_ok, unsigned long long* err) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (!src) {
+        for (int i = tid * 4; i < n; i += kCfMT * 4) *reinterpret_cast<f4*>(x_s + i) = *reinterpret_cast<const f4*>(plain + i);
+        __syncthreads();
+        return;
+    }
+    if (early) {
+        if (tid == 0) fused_watch(early, epoch, err);
+        __syncthreads();
+    }
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(src, (unsigned)n * 8u);
+    for (int tries = 0;; tries++) {
+        bool ok = true;
+        for (int i = tid * 2; i < n; i += kCfMT * 2) {
+            const u4 p = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(rs, i * 8, 0, 16));      // sc1: two words
+            ok = ok && p.y == epoch && p.w == epoch;
+            x_s[i] = __uint_as_float(p.x); x_s[i + 1] = __uint_as_float(p.z);
+        }
+        const bool wave_ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
+        int* slot = s_ok + (tries & 1) * kPWaves;
+        if (lane == 0) slot[wave] = wave_ok ? 1 : 0;
+        if (tid == 0) slot[kCfMW] = ((tries & 63) == 63 && (tries >= (1 << 20) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) ? 1 : 0;      // give up?
+        __syncthreads();
+        bool all = true;
+#pragma unroll
+        for (int w = 0; w < kCfMW; w++) all = all && slot[w] != 0;
+        if (all) break;
+        if (slot[kCfMW]) {
+            if (tid == 0) __hip_atomic_store(err, kFusedErr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+}
 
 // The workgroup's input: raw[0..K) was fetched (fused_fetch).  NORM: v = 1 / sqrt(sum(x^2) / K + 1e-5), the sum in index order (cpu.rs:110-113),
 // and xs <- gain * (v * x) (cpu.rs:114-116); else xs <- x.  xs in chain order (xs[16 s + 4 j + t] = x[16 s + 4 t + j]) with zeros behind.
@@ -135,26 +174,26 @@ __device__ __forceinline__ float cf_stage(const float* raw, const float* gain, i
     const int tid = threadIdx.x;
     float v = 1.0f;
     if constexpr (NORM) {
-        for (int i = tid; i < K; i += kPThreads) { const float a = raw[i]; sq[scan_slot(i)] = a * a; }
+        for (int i = tid; i < K; i += kCfMT) { const float a = raw[i]; sq[scan_slot(i)] = a * a; }
         __syncthreads();
         float ss = 0.0f;
         bool ok = false;
-        if constexpr (FAST) { if (K > 320) ok = (seq_sum_fast_prepare<kPWaves>(cs.fs), seq_sum_lds_fast_r<kPWaves, 8>(sq, K, cs.fs, &ss)); }      // (K <= 1024 <= 8 x 512 terms)
+        if constexpr (FAST) { if (K > 320) ok = (seq_sum_fast_prepare<kCfMW>(cs.fs), seq_sum_lds_fast_r<kCfMW, 8>(sq, K, cs.fs, &ss)); }      // (K <= 1024 = 8 x 128 terms)
         if (!ok) {      // (the instantiations of seq_sum_predict for long lists hold 64 terms per thread: only what K <= 1024 on 512 threads can reach is compiled in)
             __syncthreads();
             bool held = true;
-            if (K <= kRippleMax) ss = seq_sum_ripples<kPWaves>(sq, K, cs.ps);
-            else held = seq_sum_predict_r<kPWaves, 4>(sq, K, cs.ps, &ss);
-            if (!held) ss = seq_sum_exact<kPWaves>(sq, K, cs.sh);
+            if (K <= kRippleMax) ss = seq_sum_ripples<kCfMW>(sq, K, cs.ps);
+            else held = seq_sum_predict_r<kCfMW, 16>(sq, K, cs.ps, &ss);
+            if (!held) ss = seq_sum_exact<kCfMW>(sq, K, cs.sh);
         }
         v = 1.0f / sqrtf(ss / (float)K + 1e-5f);
     }
-    for (int i = tid; i < K; i += kPThreads) {
+    for (int i = tid; i < K; i += kCfMT) {
         const float a = raw[i];
         const int s_ = i >> 4, t = (i >> 2) & 3, j = i & 3;
         xs[16 * s_ + 4 * j + t] = NORM ? gain[i] * (v * a) : a;
     }
-    for (int i = K + tid; i < K + cf_pad_floats(); i += kPThreads) xs[i] = 0.0f;
+    for (int i = K + tid; i < K + cf_pad_floats(); i += kCfMT) xs[i] = 0.0f;
     __syncthreads();
     return v;
 }
@@ -180,15 +219,16 @@ __global__ __launch_bounds__(kPThreads) void stage_chain_fused_kernel(ChainFused
     const int gd = dim >> 4, gh = hidden >> 4;          // row groups of a dim-row / hidden-row matrix (host: dim % 16 == hidden % 16 == 0)
     CfUnit<DK> u;
     if (layer >= a.n_layers) {                          // ---- infer.rs:49-51: xb = x; x = rmsnorm(xb); logits = Wcls . x
+        if (wave >= kCfMW) return;
         const int b = blockIdx.x - a.n_layers * per_layer;
-        const int g = b * kPWaves + wave, gv = (a.vocab + 15) >> 4;
+        const int g = b * kCfMW + wave, gv = (a.vocab + 15) >> 4;
         u.request(a.ccls, g, gd, g < gv);
         const unsigned epoch = *a.epoch;
         const tagged_t* hlast = a.hand + (size_t)(a.n_layers ? a.n_layers - 1 : 0) * hw;
-        fused_fetch(a.n_layers ? hlast + 5 * dim + hidden : nullptr, a.x, dim, hlast + 5 * dim + hidden - 1, epoch, raw, s_ok, a.err);
+        cf_fetch(a.n_layers ? hlast + 5 * dim + hidden : nullptr, a.x, dim, hlast + 5 * dim + hidden - 1, epoch, raw, s_ok, a.err);
         const float v = cf_stage<true, FAST>(raw, a.g_final, dim, xs, sq, cs);
         if (b == 0) {                                   // the run state of :49-50, once
-            for (int i = tid; i < dim; i += kPThreads) { const float xv = raw[i]; a.xb[i] = xv; a.x[i] = a.g_final[i] * (v * xv); }
+            for (int i = tid; i < dim; i += kCfMT) { const float xv = raw[i]; a.xb[i] = xv; a.x[i] = a.g_final[i] * (v * xv); }
         }
         const float d = u.run(xs);
         const int row = 16 * g + rr;
@@ -205,7 +245,8 @@ __global__ __launch_bounds__(kPThreads) void stage_chain_fused_kernel(ChainFused
     float* kc = a.kc + (size_t)layer * a.seq_len * dim;
     float* vc = a.vc + (size_t)layer * a.seq_len * dim;
     if (b < a.nA) {                                     // ---- infer.rs:19-33: rmsnorm, Wq | Wk | Wv, RoPE, cache append
-        const int g3 = b * kPWaves + wave, m = g3 / gd, g = g3 - m * gd;
+        if (wave >= kCfMW) return;
+        const int g3 = b * kCfMW + wave, m = g3 / gd, g = g3 - m * gd;
         const bool valid = m < 3;
         u.request((m == 0 ? a.cq : (m == 1 ? a.ck : a.cv)) + layer * dd, g, gd, valid);
         const unsigned epoch = *a.epoch;
@@ -216,7 +257,7 @@ __global__ __launch_bounds__(kPThreads) void stage_chain_fused_kernel(ChainFused
             const int i = ((row & ~1) % hs) >> 1;                       // infer.rs:15-16: table row pos, pair i of the head
             rc = a.fr[(size_t)pos * (hs >> 1) + i]; rs = a.fi[(size_t)pos * (hs >> 1) + i];
         }
-        fused_fetch(t_in, x_in, dim, layer ? hl - dim - 1 : nullptr, epoch, raw, s_ok, a.err);      // early: the last word of hb of the layer before
+        cf_fetch(t_in, x_in, dim, layer ? hl - dim - 1 : nullptr, epoch, raw, s_ok, a.err);      // early: the last word of hb of the layer before
         cf_stage<true, FAST>(raw, a.g_att + (size_t)layer * dim, dim, xs, sq, cs);
         const float d = u.run(xs);
         const float other = __shfl_xor(d, 4);                           // the pair's other row (neighbouring quad)
@@ -245,10 +286,11 @@ __global__ __launch_bounds__(kPThreads) void stage_chain_fused_kernel(ChainFused
     }
     b -= H;
     if (b < a.nC) {                                     // ---- infer.rs:35-37: xb2 = Wo . xb; xc = x + xb2
-        const int g = b * kPWaves + wave;
+        if (wave >= kCfMW) return;
+        const int g = b * kCfMW + wave;
         u.request(a.co + layer * dd, g, gd, g < gd);
         const unsigned epoch = *a.epoch;
-        fused_fetch(t_xb, nullptr, dim, t_qkv + 3 * dim - 1, epoch, raw, s_ok, a.err);
+        cf_fetch(t_xb, nullptr, dim, t_qkv + 3 * dim - 1, epoch, raw, s_ok, a.err);
         const int row = 16 * g + rr;
         const bool mine = j == 0 && g < gd && row < dim;
         float resid = 0.0f;                             // complete since before this layer's first phase
@@ -263,10 +305,11 @@ __global__ __launch_bounds__(kPThreads) void stage_chain_fused_kernel(ChainFused
     }
     b -= a.nC;
     if (b < a.nD) {                                     // ---- infer.rs:39-45: rmsnorm, W1 | W3 (interleaved rows), SiLU * gate
-        const int g = b * kPWaves + wave, g2 = 2 * gh;
+        if (wave >= kCfMW) return;
+        const int g = b * kCfMW + wave, g2 = 2 * gh;
         u.request(a.c13 + layer * 2 * hd, g, gd, g < g2);
         const unsigned epoch = *a.epoch;
-        fused_fetch(t_xc, nullptr, dim, t_xb + dim - 1, epoch, raw, s_ok, a.err);
+        cf_fetch(t_xc, nullptr, dim, t_xb + dim - 1, epoch, raw, s_ok, a.err);
         cf_stage<true, FAST>(raw, a.g_ffn + (size_t)layer * dim, dim, xs, sq, cs);
         const float d = u.run(xs);
         const float h3 = __shfl_xor(d, 4);              // even row = W1 row i, odd row = W3 row i
@@ -281,11 +324,12 @@ __global__ __launch_bounds__(kPThreads) void stage_chain_fused_kernel(ChainFused
     }
     b -= a.nD;
     {                                                   // ---- infer.rs:46-47: xb = W2 . hb; xe = xc + xb
-        const int g = b * kPWaves + wave;
+        if (wave >= kCfMW) return;
+        const int g = b * kCfMW + wave;
         CfUnit<DH> u2;
         u2.request(a.c2 + layer * hd, g, gh, g < gd);
         const unsigned epoch = *a.epoch;
-        fused_fetch(t_hb, nullptr, hidden, t_xc + dim - 1, epoch, raw, s_ok, a.err);
+        cf_fetch(t_hb, nullptr, hidden, t_xc + dim - 1, epoch, raw, s_ok, a.err);
         const int row = 16 * g + rr;
         const bool mine = j == 0 && g < gd && row < dim;
         float resid = 0.0f;                             // complete since before the phase before this one

@@ -1370,7 +1370,7 @@ static int try_launch_chain_fused(rama_ctx* c, const rama_config* cfg, const ram
     const int kmax = std::max(dim, hidden);
     const size_t lds = std::max(cf_matvec_lds_floats(kmax, dim), cf_attn_lds_floats(hs, cfg->seq_len)) * sizeof(float) + 16;
     if (lds > kChainFusedMaxLds) return 0;
-    auto wgs = [](int groups) { return (groups + kPWaves - 1) / kPWaves; };
+    auto wgs = [](int groups) { return (groups + kCfMW - 1) / kCfMW; };
     ChainFusedParams a{};
     a.dim = dim; a.hidden = hidden; a.n_heads = H; a.seq_len = cfg->seq_len; a.vocab = V; a.n_layers = nl; a.do_cls = st->do_cls ? 1 : 0;
     a.cq = cq; a.ck = ck; a.cv = cv; a.co = co; a.c13 = c13; a.c2 = c2; a.ccls = ccls;
