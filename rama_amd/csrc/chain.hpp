@@ -542,6 +542,9 @@ struct ChainParams {
     // producers leaves a tagged word {1, epoch} in wait_flags once its stores have left.  The group requests its ring of weights, then waits, then
     // reads x with sc1 loads only (cdna_hip_programming.md Guideline 16 R1: sc1 payload, drained producer, sc1 flag, one polling wave, barrier)
     const unsigned long long* wait_flags; int wait_n;
+    // OUT ([r5] a producer phase of a merged launch: Wq|Wk|Wv in front of the attention workgroups): q, k, v and the cache rows leave with
+    // write-through stores; once a row group's stores have left, its wave sets the group's tagged word out_flags[matrix * groups + group]
+    unsigned long long* out_flags;
 };
 
 // a descriptor whose inputs the compiler must take as wave-uniform (they are: kernel arguments and blockIdx)
@@ -596,27 +599,32 @@ enum { CNORM_NONE = 0, CNORM_EXACT = 1, CNORM_TREE = 2, CNORM_LEAD = 3 };
 constexpr unsigned long long kLeadErr = 0x3100ull;                // error word: a wait for the leader's word gave up
 constexpr unsigned long long kWaitErr = 0x3200ull;                // error word: a wait for a merged launch's producers gave up
 // (the body of gemv_chain_kernel; `bid_in` = the workgroup's index within its phase -- merged launches run it behind other phases' workgroups)
-template <int W, int D, int XD, int EPI, int NORM = CNORM_NONE, int LR = 64, bool WAIT = false>
+// GPB ([r5]): row groups per workgroup -- W x GPB waves, every W of them one group, the activations staged ONCE for all (a merged launch whose other
+// phase wants 256 threads runs Wq|Wk|Wv as two two-wave groups per workgroup).  The groups of a workgroup walk their chunks in lockstep (one barrier).
+template <int W, int D, int XD, int EPI, int NORM = CNORM_NONE, int LR = 64, bool WAIT = false, int GPB = 1, bool OUT = false>
 __device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in) {
     RAMA_NO_CONTRACT
     CHAIN_STAMP(0);
     static_assert(D % XD == 0, "the x ring must divide the weight ring");
     static_assert(!WAIT || NORM == CNORM_NONE, "a waiting phase takes its activations as they come");
+    static_assert(!OUT || EPI == CEPI_QKV, "only Wq|Wk|Wv hands its output over inside a launch");
     extern __shared__ __attribute__((aligned(16))) float xs[];
-    __shared__ float relay[64];
+    __shared__ float relay[GPB][64];
+    constexpr int WL = W * GPB;                                   // waves of the workgroup
     const int lane = threadIdx.x & 63;
-    const int wave = W == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave_all = WL == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = GPB == 1 ? 0 : wave_all / W, wave = GPB == 1 ? wave_all : wave_all - pair * W;
     const int j = lane & 3, rr = lane >> 2;
     const int groups = (p.rows + 15) >> 4;
     if constexpr (NORM == CNORM_LEAD) {
         if (bid_in == 0) {      // the leader: thread t holds x[t LR .. t LR + LR) (zeros behind K: the descriptor's range check)
-            FastSumShared<W>& fs = *reinterpret_cast<FastSumShared<W>*>(xs);        // (host: the dynamic LDS holds it)
+            FastSumShared<WL>& fs = *reinterpret_cast<FastSumShared<WL>*>(xs);        // (host: the dynamic LDS holds it)
 #ifdef RAMA_CHAIN_STAMPS
             if (threadIdx.x == 0) g_chain_stamps[40] = __builtin_amdgcn_s_memrealtime();
 #endif
             const unsigned ep = *p.epoch;
             const __amdgpu_buffer_rsrc_t rxl = make_rsrc_uniform(p.x, (unsigned)p.K * 4u);
-            seq_sum_fast_prepare<W>(fs);
+            seq_sum_fast_prepare<WL>(fs);
             float a[LR];
 #pragma unroll
             for (int u = 0; u < LR / 4; u++) {
@@ -631,7 +639,7 @@ __device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in)
             if (threadIdx.x == 0) g_chain_stamps[41] = __builtin_amdgcn_s_memrealtime();
 #endif
             float ss;
-            if (!seq_sum_fast<W, LR>(a, fs, &ss)) {      // (uniform) the prediction did not hold: the plain loop over the squares
+            if (!seq_sum_fast<WL, LR>(a, fs, &ss)) {      // (uniform) the prediction did not hold: the plain loop over the squares
                 __syncthreads();
 #pragma unroll
                 for (int k = 0; k < LR; k++) { const int i = (int)threadIdx.x * LR + k; if (i < p.K) xs[i] = a[k]; }
@@ -648,10 +656,14 @@ __device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in)
             return;
         }
     }
-    const int bid = NORM == CNORM_LEAD ? bid_in - 1 : bid_in;
+    const int bid0 = NORM == CNORM_LEAD ? bid_in - 1 : bid_in;
+    // (GPB > 1: a workgroup's last group may lie behind the last row group: it walks the last one again and stores nothing)
+    const int gi_raw = bid0 * GPB + pair;
+    const bool valid = GPB == 1 || gi_raw < p.nmat * groups;
+    const int bid = GPB == 1 ? bid0 : min(gi_raw, p.nmat * groups - 1);
     // (the quotient comes out of the vector ALU: without readfirstlane everything derived from it -- the buffer
     // descriptors above all -- counts as divergent and every load turns into a waterfall loop)
-    const int m = __builtin_amdgcn_readfirstlane(bid / groups), g = bid - m * groups;
+    const int m = __builtin_amdgcn_readfirstlane(bid / groups), g = __builtin_amdgcn_readfirstlane(bid - m * groups);
     const float* Wm = m == 0 ? p.w[0] : (m == 1 ? p.w[1] : p.w[2]);
     const int nblk = p.K >> 4;
     const int nchunk = (nblk + D - 1) / D;
@@ -675,7 +687,7 @@ __device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in)
     const int n4 = p.K >> 2;
     // (a waiting phase folds no norm: whatever of x does not fit the registers follows behind the weights.  [r5] 24 x 16 bytes per thread up front for
     // the residual products -- llama2-7B's W2 reads 11 008 floats on 128 threads, the last 2 816 in a second round trip -- measured: 33.70 against 33.77 us)
-    constexpr int T = W * 64, XU = WAIT ? 16 / W : 16;
+    constexpr int T = WL * 64, XU = WAIT ? 16 / W : 16 / GPB;      // (host: K <= 16 XU T floats where a norm is folded in)
     f4 xa[XU];
     if constexpr (!WAIT) {
 #pragma unroll
@@ -711,7 +723,7 @@ __device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in)
     CHAIN_STAMP(1);
     if constexpr (WAIT) {      // the ring is on its way: now the producers' words (wave 0 polls, lane i < wait_n the word of producer i), then x, sc1
         const unsigned ep = *p.epoch;
-        if (wave == 0) {
+        if (wave_all == 0) {
             long spins = 0;
             while (true) {
                 unsigned long long word = (unsigned long long)ep << 32;
@@ -727,6 +739,7 @@ __device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in)
 #pragma unroll
         for (int u = 0; u < XU; u++) xa[u] = ld4_sc1(rx, ((int)threadIdx.x + T * u) < n4 ? (unsigned)((int)threadIdx.x + T * u) * 16u : kOOB);
     }
+    static_assert(GPB == 1 || NORM == CNORM_NONE || NORM == CNORM_LEAD, "several groups per workgroup: a leader's norm or none");
     if constexpr (NORM == CNORM_TREE) {     // x <- w * (v * x) with the sum of squares as a fixed tree (host: K <= 64 T floats, all of x is in xa)
         float ssl = 0.0f;
 #pragma unroll
@@ -814,7 +827,7 @@ __device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in)
         }
     }
     // zeros behind x: D blocks that may be multiplied (by weights the range check zeroed) + the x ring's read-ahead
-    for (int i = p.K + (int)threadIdx.x; i < p.K + chain_pad_floats(W, D, XD); i += W * 64) xs[i] = 0.0f;
+    for (int i = p.K + (int)threadIdx.x; i < p.K + chain_pad_floats(W, D, XD); i += T) xs[i] = 0.0f;
     __syncthreads();
     // A lone wave issues one instruction per several cycles whatever its kind, and only ONE wave of the group can
     // be adding at any time, so the adding wave's instruction count per block is what bounds a launch with one
@@ -865,7 +878,7 @@ __device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in)
         for (int c = 0; c < nchunk; c++) {
             if ((c % W) == wave) {                                // uniform: my turn
                 if (c < 24) CHAIN_STAMP(8 + 2 * c);
-                if (c > 0) v = relay[lane];
+                if (c > 0) v = relay[pair][lane];
                 __amdgpu_buffer_rsrc_t rn[D / 16];
 #pragma unroll
                 for (int h = 0; h < D / 16; h++) rn[h] = stretch((c + W) * (D / 16) + h);
@@ -879,7 +892,7 @@ __device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in)
                     wr[u] = ld_nt(rn[u >> 4], vo[(u & 15) >> 2] + (unsigned)(u & 3) * 1024u);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (c + 1 < nchunk) relay[lane] = v;
+                if (c + 1 < nchunk) relay[pair][lane] = v;
                 if (c < 24) CHAIN_STAMP(9 + 2 * c);
             } else if (((c + 1) % W) == wave && c + 1 < nchunk) { // my turn is next: the products, while the wave before me adds
                 premultiply(c + 1);
@@ -893,15 +906,25 @@ __device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in)
     const float t2 = v + dpp_mov<0xB1>(v);                       // quad_perm [1,0,3,2]
     const float d = t2 + dpp_mov<0x4E>(t2);                      // quad_perm [2,3,0,1]
     if (EPI == CEPI_STORE) {
-        if (j == 0 && row < p.rows) { float* o = m == 0 ? p.o[0] : (m == 1 ? p.o[1] : p.o[2]); o[row] = d; }      // (nmat > 1: a run of Device::matmul calls as one launch)
+        if (j == 0 && row < p.rows && valid) { float* o = m == 0 ? p.o[0] : (m == 1 ? p.o[1] : p.o[2]); o[row] = d; }      // (nmat > 1: a run of Device::matmul calls as one launch)
     } else if (EPI == CEPI_RESID) {
-        if (j == 0 && row < p.rows) { p.o[0][row] = d; p.resid[row] = xold + d; }
+        if (j == 0 && row < p.rows && valid) { p.o[0][row] = d; p.resid[row] = xold + d; }
     } else if (EPI == CEPI_QKV) {
         const float other = __shfl_xor(d, 4);                    // the pair's other row (neighbouring quad)
         const float a = (rr & 1) ? other : d, b = (rr & 1) ? d : other;
         float out = d;
         if (m < 2) out = (rr & 1) ? a * rs + b * rc : a * rc - b * rs;      // cpu.rs:87-96
-        if (j == 0 && row < p.rows) {
+        if constexpr (OUT) {
+            const unsigned ep = *p.epoch;
+            if (j == 0 && row < p.rows && valid) {
+                float* o = m == 0 ? p.o[0] : (m == 1 ? p.o[1] : p.o[2]);
+                st_sc1(o + row, out);
+                if (m == 1) st_sc1(p.kc + (size_t)pos * p.rows + row, out);  // infer.rs:32
+                else if (m == 2) st_sc1(p.vc + (size_t)pos * p.rows + row, out);     // infer.rs:33
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's stores have left: its group's word may be set
+            if (lane == 0 && valid) put_tagged(p.out_flags + bid, 1.0f, ep);
+        } else if (j == 0 && row < p.rows && valid) {
             float* o = m == 0 ? p.o[0] : (m == 1 ? p.o[1] : p.o[2]);
             o[row] = out;
             if (m == 1) p.kc[(size_t)pos * p.rows + row] = out;              // infer.rs:32
@@ -909,7 +932,7 @@ __device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in)
         }
     } else {   // CEPI_SWIGLU: even row = W1 row i, odd row = W3 row i
         const float h3 = __shfl_xor(d, 4);
-        if (j == 0 && !(rr & 1) && row < p.rows) {
+        if (j == 0 && !(rr & 1) && row < p.rows && valid) {
             const float sl = d * (1.0f / (1.0f + expf_glibc(-d)));           // cpu.rs:56
             p.o[0][row >> 1] = sl * h3;                                        // cpu.rs:59-64
             p.o[1][row >> 1] = h3;
@@ -1182,9 +1205,13 @@ __host__ __device__ constexpr bool attn_chain_fits(int head_size, int nw) { retu
 // producer drains its write-through cache-row stores before it tags, the cache (row `pos` included) is then read with sc1 loads; xb leaves as tagged
 // words (inl.xb_t) and, when p.xb is given, plainly.
 struct AttnInl { const unsigned long long* qkv; const unsigned long long* early; unsigned long long* xb_t; unsigned long long* err; unsigned epoch; int* s_ok; };
-template <int NW, bool HANDOFF = false, bool INL = false>
+// PRE ([r5] qkv_attn_chain_kernel): the head's workgroup sits in the SAME launch as the Wq|Wk|Wv row groups that produce q and this position's cache
+// rows (gemv_chain_body OUT).  It requests its first key rows of EARLIER positions at once (they are an earlier launch's), waits for the tagged
+// words of the 3 head_size / 16 row groups that make its slices, then reads q and the cache with sc1 loads.
+struct AttnPre { const unsigned long long* flags; int groups; unsigned long long* err; const unsigned* epoch; };
+template <int NW, bool HANDOFF = false, bool INL = false, bool PRE = false>
 __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int y, int lds_seq, unsigned long long* flags = nullptr, const unsigned* epoch = nullptr,
-                                                     AttnInl inl = AttnInl{}) {
+                                                     AttnInl inl = AttnInl{}, AttnPre pre = AttnPre{}) {
     RAMA_NO_CONTRACT
     constexpr int T = NW * 64;
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -1207,8 +1234,13 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
     const size_t col = (size_t)h * hs;
     SEQ_STAMP(8);
     const unsigned cache_bytes = (unsigned)p.seq_len * (unsigned)p.dim * 4u;
-    const __amdgpu_buffer_rsrc_t rkc = make_rsrc(p.kc, INL ? cache_bytes : 0u), rvc = make_rsrc(p.vc, INL ? cache_bytes : 0u);
-    if constexpr (INL) {
+    constexpr bool SC1 = INL || PRE;                              // the cache holds a row of THIS launch: every read of it bypasses L1 (and the stale lines in it)
+    const __amdgpu_buffer_rsrc_t rkc = make_rsrc(p.kc, SC1 ? cache_bytes : 0u), rvc = make_rsrc(p.vc, SC1 ? cache_bytes : 0u);
+    constexpr int KP = 32;                                        // PRE, head size 128: a thread's key row of an earlier position, requested before the wait
+    f4 kpre[PRE ? KP : 1];
+    if constexpr (PRE) {
+        // (below, once the value tiles' element map is known)
+    } else if constexpr (INL) {
         if (inl.early) {
             if (tid == 0) fused_watch(inl.early, inl.epoch, inl.err);
             __syncthreads();
@@ -1245,11 +1277,54 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
             // (rows behind pos are clamped: their products are written, never added -- a load under a condition is a branch with
             // `s_waitcnt vmcnt(0)` behind it, one cache round trip per load instruction)
             const int tr = min(t0 + er[u], pos), c4 = ec[u];
-            if constexpr (INL) vr[u] = ld4_sc1(rvc, ((unsigned)tr * (unsigned)p.dim + (unsigned)col + 4u * (unsigned)c4) * 4u);
+            if constexpr (SC1) vr[u] = ld4_sc1(rvc, ((unsigned)tr * (unsigned)p.dim + (unsigned)col + 4u * (unsigned)c4) * 4u);
             else vr[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.vc + (size_t)tr * p.dim + col) + c4);
         }
     };
     f4 va[U], vb[U];                                              // two tiles on their way while a third is added up
+    f4 vpos[PRE ? U : 1];                                         // PRE: this position's value row, every element's 16 bytes of it
+    if constexpr (PRE) {
+        // EARLIER positions' rows are an earlier launch's: the thread's first key row and the first two value tiles go out before the wait
+        // (rows clamped to pos - 1; what an element of row >= pos holds then is replaced by vpos where the product is formed)
+        const int plast = max(pos - 1, 0);
+        {
+            const f4* k4 = reinterpret_cast<const f4*>(p.kc + (size_t)min(tid, plast) * p.dim + col);
+#pragma unroll
+            for (int u = 0; u < KP; u++) kpre[u] = k4[min(u, hs4 - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) va[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.vc + (size_t)min(er[u], plast) * p.dim + col) + ec[u]);
+#pragma unroll
+        for (int u = 0; u < U; u++) vb[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.vc + (size_t)min(kAttTile + er[u], plast) * p.dim + col) + ec[u]);
+        const unsigned ep = *pre.epoch;
+        const int gph = hs >> 4, nflag = 3 * gph;                 // (host: head_size % 16 == 0, 3 head_size / 16 <= 64)
+        if (wave == 0) {
+            const int m_ = lane / gph, gg = h * gph + (lane - m_ * gph);
+            long spins = 0;
+            while (true) {
+                unsigned long long word = (unsigned long long)ep << 32;
+                if (lane < nflag) word = __hip_atomic_load(pre.flags + (size_t)m_ * pre.groups + gg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__builtin_amdgcn_ballot_w64((unsigned)(word >> 32) == ep) == ~0ull) break;
+                __builtin_amdgcn_s_sleep(1);
+                ++spins;
+                if ((spins & 255) == 0 && __hip_atomic_load(pre.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                if (spins > (1L << 22)) { if (lane == 0) __hip_atomic_store(pre.err, kWaitErr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+        __syncthreads();
+        // ONE round trip for everything of THIS position: q, the key row (by the wave that holds timestep pos: its lanes of earlier timesteps
+        // re-read their own rows, the lanes behind read row pos -- a uniform branch, no load under a per-lane condition), the value row
+        float qv = 0.0f;
+        if (tid < hs) qv = ld_sc1(p.q + col + tid);
+        if (wave == (pos >> 6)) {
+#pragma unroll
+            for (int u = 0; u < KP; u++) kpre[u] = ld4_sc1(rkc, ((unsigned)min(tid, pos) * (unsigned)p.dim + (unsigned)col + 4u * (unsigned)min(u, hs4 - 1)) * 4u);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) vpos[u] = ld4_sc1(rvc, ((unsigned)pos * (unsigned)p.dim + (unsigned)col + 4u * (unsigned)ec[u]) * 4u);
+        if (tid < hs) s_q[tid] = qv;
+        for (int i = tid + T; i < hs; i += T) s_q[i] = ld_sc1(p.q + col + i);
+    }
     __syncthreads();
     const float scale_div = sqrtf((float)hs);
     const f4* q4 = reinterpret_cast<const f4*>(s_q);
@@ -1304,7 +1379,20 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
             if constexpr (NB == 2) { if (st + 1 < nstep) consume(st + 1, nb); }
         }
     } else {
-        for (int t = tid; t <= pos; t += T) {                     // a few rounds of timesteps: straight from the cache, a row's loads together
+        int t_first = tid;
+        if constexpr (PRE) {
+            if (hs4 == KP && tid <= pos) {                        // (uniform in hs4) the first round from the rows in registers
+                float acc = 0.0f;
+#pragma unroll
+                for (int u = 0; u < KP; u++) {
+                    const f4 qq = q4[u];
+                    acc = acc + qq.x * kpre[u].x; acc = acc + qq.y * kpre[u].y; acc = acc + qq.z * kpre[u].z; acc = acc + qq.w * kpre[u].w;
+                }
+                s_att[scan_slot(tid)] = acc / scale_div;
+                t_first = tid + T;
+            }
+        }
+        for (int t = t_first; t <= pos; t += T) {                 // a few rounds of timesteps: straight from the cache, a row's loads together
             const f4* k4 = reinterpret_cast<const f4*>(p.kc + (size_t)t * p.dim + col);
             float acc = 0.0f;
             int i = 0;
@@ -1316,7 +1404,7 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
                     f4 kk[NB];
 #pragma unroll
                     for (int u = 0; u < NB; u++) {
-                        if constexpr (INL) kk[u] = ld4_sc1(rkc, ((unsigned)t * (unsigned)p.dim + (unsigned)col + 4u * (unsigned)(i + u)) * 4u);
+                        if constexpr (SC1) kk[u] = ld4_sc1(rkc, ((unsigned)t * (unsigned)p.dim + (unsigned)col + 4u * (unsigned)(i + u)) * 4u);
                         else kk[u] = k4[i + u];
                     }
 #pragma unroll
@@ -1331,7 +1419,7 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
             batch(std::integral_constant<int, 8>{});
             batch(std::integral_constant<int, 4>{});
             for (; i < hs4; i++) {
-                const f4 kk = INL ? ld4_sc1(rkc, ((unsigned)t * (unsigned)p.dim + (unsigned)col + 4u * (unsigned)i) * 4u) : k4[i], qq = q4[i];
+                const f4 kk = SC1 ? ld4_sc1(rkc, ((unsigned)t * (unsigned)p.dim + (unsigned)col + 4u * (unsigned)i) * 4u) : k4[i], qq = q4[i];
                 acc = acc + qq.x * kk.x; acc = acc + qq.y * kk.y; acc = acc + qq.z * kk.z; acc = acc + qq.w * kk.w;
             }
             s_att[scan_slot(t)] = acc / scale_div;
@@ -1356,8 +1444,10 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
     }
     float acc = 0.0f;
     SEQ_STAMP(12);
-    vissue(0, va);
-    vissue(kAttTile, vb);
+    if constexpr (!PRE) {
+        vissue(0, va);
+        vissue(kAttTile, vb);
+    }
     __syncthreads();                                              // the probabilities are final; the staging region is free
     auto vtile = [&](int t0, int buf, f4 (&vr)[U]) {
         float* tile = region + buf * (kAttTile * hs);
@@ -1366,8 +1456,10 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
             const int e = tid + u * T;
             if (e < tile4) {
                 const float a = s_p[min(t0 + er[u], pos)];
+                f4 vv = vr[u];
+                if constexpr (PRE) { if (t0 < 2 * kAttTile && t0 + er[u] >= pos) vv = vpos[u]; }      // (the first two tiles were requested before row pos existed)
                 f4 pr;
-                pr.x = a * vr[u].x; pr.y = a * vr[u].y; pr.z = a * vr[u].z; pr.w = a * vr[u].w;     // cpu.rs:48 `a * vi`, rounded
+                pr.x = a * vv.x; pr.y = a * vv.y; pr.z = a * vv.z; pr.w = a * vv.w;     // cpu.rs:48 `a * vi`, rounded
                 *reinterpret_cast<f4*>(tile + 4 * e) = pr;
             }
         }
@@ -1434,6 +1526,27 @@ template <int D>
 __global__ __launch_bounds__(256) void attn_wo_chain_solo_kernel(RefAttnParams a, ChainParams p, int n_heads, int lds_seq) {
     if ((int)blockIdx.x < n_heads) attention_chain_body<4, true>(a, (int)blockIdx.x, 0, lds_seq, const_cast<unsigned long long*>(p.wait_flags), p.epoch);
     gemv_chain_body<4, D, 4, CEPI_RESID, CNORM_NONE, 64, true>(p, (int)blockIdx.x);
+}
+
+// ---------------------------------------------------------------- [r5] Wq|Wk|Wv + the attention as ONE launch (infer.rs:19-34), parity mode, short contexts
+// The attention is a chain of dependent memory round trips on 32 of 256 compute units; as a launch of its own it also pays a boundary and
+// starts with cold key rows.  Here its 32 workgroups sit BEHIND the Wq|Wk|Wv row groups of the same launch (the norm's leader in front):
+// while the matvec streams they request their key rows of the earlier positions -- 2 MB next to a 201 MB stream: unlike a streaming phase put
+// beside the attention (attn_wo_chain_kernel, measured slower), this costs the stream nothing --, then wait for the tagged words of the 24
+// row groups that make their head's q, k and v slices (gemv_chain_body OUT: write-through stores, drained, then the group's word), read q
+// and the cache with sc1 loads and run attention_chain_body's arithmetic: the same operations in the same order per output.
+// The matvec runs two two-wave row groups per 256-thread workgroup (GPB = 2), its leader on four waves.
+// MEASURED (profiles/r05_experiments.md section 10): 43.7 us against 35.2 + 7.6 as two launches -- the attention's tail shrinks to 6.6 us, but 385 workgroups of
+// two row groups leave half the compute units with four groups and half with two (three each as 769 workgroups of one), and a CU streams ~28 GB/s:
+// the matvec part alone takes 37.1 us.  Opt-in ("chain_qa").
+template <int LR>
+__global__ __launch_bounds__(256, 2) void qkv_attn_chain_kernel(ChainParams p, RefAttnParams a, int nqkv, int lds_seq) {
+    if ((int)blockIdx.x < nqkv) {
+        gemv_chain_body<2, 16, 4, CEPI_QKV, CNORM_LEAD, LR, false, 2, true>(p, (int)blockIdx.x);
+        return;
+    }
+    const AttnPre pre{p.out_flags, (p.rows + 15) >> 4, p.err, p.epoch};
+    attention_chain_body<4, false, false, true>(a, (int)blockIdx.x - nqkv, 0, lds_seq, nullptr, nullptr, AttnInl{}, pre);
 }
 
 // ---------------------------------------------------------------- the same attention spread over the chip (long contexts)

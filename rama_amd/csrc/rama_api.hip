@@ -171,6 +171,8 @@ struct rama_ctx {
     int tune_chain_awo = 0;                // parity mode, short contexts: attention + Wo as one launch, the Wo groups' first 4 x this many KiB requested while the attention runs (0: two launches)
     unsigned long long* awo_flags = nullptr;    // device: [kAwoLayers][kAwoHeads] tagged words
     int tune_chain_norm = 1;               // parity mode, dim <= 512: the layer norms folded into the matvecs that consume them
+    int tune_chain_qa = 0;                 // parity mode, short contexts: Wq|Wk|Wv + the attention as one launch (chain.hpp qkv_attn_chain_kernel; opt-in: measured equal)
+    unsigned long long* qa_flags = nullptr;     // device: [kAwoLayers][3 * 256] tagged words, one per (layer, matrix, row group)
     int tune_chain_fused = 0;              // parity mode: a whole stage as ONE launch (layer_chain_fused.hpp; opt-in: stories15M +6 %, stories110M -40 %); -1: for dim <= 1024
     int tune_chain_lead_w = 0;             // parity mode: waves per row group of the launches with a leader norm (0: by the number of row groups)
     int tune_chain_resid_d = -1;           // parity mode: 100 W + D for the residual products (Wo, W2) only; 0: by the number of row groups like the others; -1: W = 1, D = 32 when a CU holds one group
@@ -303,6 +305,8 @@ int rama_ctx_create(int device, void* hip_stream, rama_ctx** out) {
     { const unsigned one = 1; HIPCHK(hipMemcpy(c->fused_epoch, &one, sizeof one, hipMemcpyHostToDevice)); }      // the zeroed vectors carry tag 0
     HIPCHK(hipMalloc(&c->lead_slots, kLeadSlots * 32 * sizeof(unsigned long long)));
     HIPCHK(hipMemset(c->lead_slots, 0, kLeadSlots * 32 * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&c->qa_flags, (size_t)kAwoLayers * 768 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(c->qa_flags, 0, (size_t)kAwoLayers * 768 * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&c->awo_flags, (size_t)kAwoLayers * kAwoHeads * sizeof(unsigned long long)));
     HIPCHK(hipMemset(c->awo_flags, 0, (size_t)kAwoLayers * kAwoHeads * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&c->pbar, 4 * sizeof(unsigned long long)));
@@ -325,6 +329,8 @@ int rama_ctx_create(int device, void* hip_stream, rama_ctx** out) {
     RAMA_CF_ATTR(16, 16, true); RAMA_CF_ATTR(16, 16, false);
 #undef RAMA_CF_ATTR
     HIPCHK(hipFuncSetAttribute((const void*)attn_wo_chain_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAwoMaxLds));
+    HIPCHK(hipFuncSetAttribute((const void*)qkv_attn_chain_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAwoMaxLds));
+    HIPCHK(hipFuncSetAttribute((const void*)qkv_attn_chain_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAwoMaxLds));
     HIPCHK(hipFuncSetAttribute((const void*)attn_wo_chain_solo_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnChainMaxLds));
 #define RAMA_GC_ATTR(TPW_) \
     HIPCHK(hipFuncSetAttribute((const void*)gemm_chain_kernel<TPW_, CEPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_chain_lds_bytes(TPW_))); \
@@ -362,7 +368,7 @@ int rama_ctx_destroy(rama_ctx* c) {
     hipStreamSynchronize(c->stream);
     drop_graph(c);
     for (auto e : c->kp.ev) hipEventDestroy(e);
-    hipFree(c->ctl); hipFree(c->out); hipFree(c->forced); hipFree(c->argmax_result); hipFree(c->pbar); hipFree(c->attn_counter); hipFree(c->attn_part); hipFree(c->attn_scores); hipFree(c->fused_hand); hipFree(c->fused_epoch); hipFree(c->lead_slots); hipFree(c->awo_flags);
+    hipFree(c->ctl); hipFree(c->out); hipFree(c->forced); hipFree(c->argmax_result); hipFree(c->pbar); hipFree(c->attn_counter); hipFree(c->attn_part); hipFree(c->attn_scores); hipFree(c->fused_hand); hipFree(c->fused_epoch); hipFree(c->lead_slots); hipFree(c->awo_flags); hipFree(c->qa_flags);
     for (int i = 0; i < 2; i++) { hipFree(c->topp_keys[i]); hipFree(c->topp_vals[i]); }
     hipFree(c->topp_prefix); hipFree(c->topp_m); hipFree(c->topp_err); hipFree(c->pf_blob); hipFree(c->pc_blob); if (c->ring) hipHostFree(c->ring);
     hipFree(c->topp_bp); hipFree(c->topp_bi); hipFree(c->topp_bcount); hipFree(c->topp_racc);
@@ -784,6 +790,32 @@ static int launch_attention_chain(rama_ctx* c, float* xb, float* att, const floa
     else RAMA_ATTN_CHAIN(16);
 #undef RAMA_ATTN_CHAIN
     LAUNCHCHK();
+    return 0;
+}
+
+// [r5] infer.rs:19-34 as one launch in parity mode (chain.hpp qkv_attn_chain_kernel): the leader norm's shapes, positions below the spread attention's
+// switch and below 256, head sizes of whole 16-row groups whose 3 hs / 16 words one wave polls, workgroups that fit two to a CU.
+// *merged = false: nothing was enqueued.
+static int try_launch_qkv_attn_chain(rama_ctx* c, const rama_config* cfg, rama_run_state* s, size_t li, ChainParams p, const float* kc, const float* vc, bool* merged) {
+    *merged = false;
+    const int dim = cfg->dim, hs = dim / cfg->n_heads, groups = dim / 16;
+    if (!c->tune_chain_qa || c->spread_attn || c->long_attn || c->kp.kernel_id >= 0 || c->tune_chain_d > 0 || c->tune_chain_lead_w > 0) return 0;
+    if (li >= (size_t)kAwoLayers || hs % 16 || 3 * (hs / 16) > 64 || attn_chain_waves(hs, false) != 4 || dim % 64 || groups > 256 || dim > 4096 || dim <= 1024) return 0;
+    const int lds_seq = std::min(cfg->seq_len, std::max(kLongAttnPos, 1));      // the launch only runs below position 256
+    const size_t lds = std::max({attn_chain_lds_floats_for(hs, lds_seq, 4) * sizeof(float) + 16, (size_t)(dim + chain_pad_floats(2, 16, 4)) * sizeof(float), sizeof(FastSumShared<4>)});
+    if (lds > kAwoMaxLds || !aligned16(s->q) || !aligned16(kc) || !aligned16(vc)) return 0;
+    RefAttnParams a{};
+    a.q = s->q; a.kc = kc; a.vc = vc; a.att = s->att; a.xb = s->xb; a.ctl = c->ctl; a.pos_val = 0;
+    a.dim = dim; a.head_size = hs; a.seq_len = cfg->seq_len;
+    p.out_flags = c->qa_flags + li * 768;
+    const int nqkv = 1 + (3 * groups + 1) / 2;
+    const dim3 grid(nqkv + cfg->n_heads);
+    const int per = (dim + 255) / 256;                           // squares per thread of the four-wave leader
+    if (per <= 8) hipLaunchKernelGGL((qkv_attn_chain_kernel<8>), grid, dim3(256), lds, c->stream, p, a, nqkv, lds_seq);
+    else hipLaunchKernelGGL((qkv_attn_chain_kernel<16>), grid, dim3(256), lds, c->stream, p, a, nqkv, lds_seq);
+    LAUNCHCHK();
+    c->handoff_dirty = true;
+    *merged = true;
     return 0;
 }
 
@@ -1446,6 +1478,7 @@ static int enqueue_stage_chain(rama_ctx* c, const rama_config* cfg, const rama_w
         // narrow models: the two norms of a layer ride in the matvecs that consume them (2 of 7 launches; "chain_norm")
         const bool fold = lnorm != CNORM_NONE;
         if (!fold && !(mask & 1)) { KTimer kt(c, RAMA_K_NORM); rc = launch_rmsnorm_chain(c, s->xb, s->x, w->rms_att_weight + li * dim, dim, nullptr); if (rc) return rc; }      // infer.rs:19
+        bool qa = false;
         if (mask & 1) { rc = launch_fast_qkv(c, cfg, w, s, li, kc, vc); if (rc) return rc; }
         else {   // :20-33: Wq | Wk | Wv, RoPE, cache append
             KTimer kt(c, RAMA_K_QKV);
@@ -1455,11 +1488,12 @@ static int enqueue_stage_chain(rama_ctx* c, const rama_config* cfg, const rama_w
             p.K = dim; p.rows = dim; p.nmat = 3;
             p.ctl = c->ctl; p.fr = w->freq_cis_real; p.fi = w->freq_cis_imag; p.head_size = hs; p.kc = kc; p.vc = vc;
             if (lnorm == CNORM_LEAD) { p.lead = c->lead_slots + 32 * (2 * li); p.epoch = c->fused_epoch; p.err = c->pbar + 1; led = true; }
-            rc = launch_chain<CEPI_QKV>(c, p, fold ? lnorm : CNORM_NONE); if (rc) return rc;
+            if (lnorm == CNORM_LEAD && fold && !c->tune_chain_awo) { rc = try_launch_qkv_attn_chain(c, cfg, s, li, p, kc, vc, &qa); if (rc) return rc; }      // :19-34 as one launch ([r5] "chain_qa")
+            if (!qa) { rc = launch_chain<CEPI_QKV>(c, p, fold ? lnorm : CNORM_NONE); if (rc) return rc; }
         }
         bool awo = false;      // :34-37 as one launch ([r5] "chain_awo")
-        if (!tol && lead_ok) { rc = try_launch_attn_wo_chain(c, cfg, s, li, kc, vc, co + li * dd, &awo); if (rc) return rc; led = led || awo; }
-        if (!awo) {   // :34
+        if (!tol && lead_ok && !qa) { rc = try_launch_attn_wo_chain(c, cfg, s, li, kc, vc, co + li * dd, &awo); if (rc) return rc; led = led || awo; }
+        if (!awo && !qa) {   // :34
             KTimer kt(c, RAMA_K_ATTN);
             if (tol && !(mask & 32)) rc = launch_attention(c, s->xb, s->att, s->q, kc, vc, c->ctl, 0, dim, hs, cfg->seq_len, cfg->n_heads, c->split_attn);
             else rc = launch_attention_chain(c, s->xb, s->att, s->q, kc, vc, c->ctl, 0, dim, hs, cfg->seq_len, cfg->n_heads, c->long_attn, c->spread_attn);
@@ -2865,6 +2899,13 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
     if (!strcmp(key, "chain_awo")) {
         REQUIRE(value == 0 || value == 16 || value == 48, RAMA_EINVAL, "set_tuning: chain_awo must be 0, 16 or 48");
         c->tune_chain_awo = value;
+        hipStreamSynchronize(c->stream);
+        drop_graph(c);
+        return 0;
+    }
+    if (!strcmp(key, "chain_qa")) {
+        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: chain_qa must be 0 or 1");
+        c->tune_chain_qa = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
         return 0;

@@ -568,13 +568,14 @@ def test_attention_wo_merged_launch_bit_exact(dev, dim, hidden, heads, layers, s
     model = rama_amd.Model.synth(dev, to_rama_cfg(cfg), 11, rope=rope)
     engs = {}
     try:
-        for awo in (48, 16, 0):
+        for awo in (48, 16, 0, "qa"):      # "qa": Wq|Wk|Wv + attention as one launch ("chain_qa" = 1) instead
             engs[awo] = rama_amd.Engine(dev, model)
         token = 1
         for pos in range(steps):
             lo = orc.forward(token, pos)
             for awo, eng in engs.items():
-                eng.set_tuning("chain_awo", awo)
+                eng.set_tuning("chain_awo", 0 if awo == "qa" else awo)
+                eng.set_tuning("chain_qa", 1 if awo == "qa" else 0)
                 eng.forward(token, pos)
                 if awo == 0 and pos % 8:
                     continue
@@ -586,6 +587,7 @@ def test_attention_wo_merged_launch_bit_exact(dev, dim, hidden, heads, layers, s
             token = O.argmax(lo)
     finally:
         dev.lib.rama_set_tuning(dev.ctx, b"chain_awo", 0)
+        dev.lib.rama_set_tuning(dev.ctx, b"chain_qa", 0)
         for eng in engs.values():
             eng.free()
         model.free()
