@@ -545,6 +545,11 @@ struct ChainParams {
     // OUT ([r5] a producer phase of a merged launch: Wq|Wk|Wv in front of the attention workgroups): q, k, v and the cache rows leave with
     // write-through stores; once a row group's stores have left, its wave sets the group's tagged word out_flags[matrix * groups + group]
     unsigned long long* out_flags;
+    // half_from > 0 ([r5] one wave per row group): the row groups from this index on are walked as TWO workgroups of 8 rows each (lanes 0..31; the
+    // chain-order block of 16 rows is two halves of 512 bytes).  A compute unit streams ~28 GB/s whatever the rest of the chip does, so a launch whose
+    // row groups do not divide by the compute units ends when the CUs with one group more are through: llama2-7B's W1|W3 is 1 376 groups on 256 CUs,
+    // six on 96 of them and five on the rest; with the last 96 groups as 192 halves it is five and a half at most.
+    int half_from;
 };
 
 // a descriptor whose inputs the compiler must take as wave-uniform (they are: kernel arguments and blockIdx)
@@ -663,11 +668,14 @@ __device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in)
     const int bid = GPB == 1 ? bid0 : min(gi_raw, p.nmat * groups - 1);
     // (the quotient comes out of the vector ALU: without readfirstlane everything derived from it -- the buffer
     // descriptors above all -- counts as divergent and every load turns into a waterfall loop)
-    const int m = __builtin_amdgcn_readfirstlane(bid / groups), g = __builtin_amdgcn_readfirstlane(bid - m * groups);
+    int half = -1, bid_g = bid;
+    if (GPB == 1 && W == 1 && p.half_from > 0 && bid >= p.half_from) { half = (bid - p.half_from) & 1; bid_g = p.half_from + ((bid - p.half_from) >> 1); }      // (uniform)
+    const int m = __builtin_amdgcn_readfirstlane(bid_g / groups), g = __builtin_amdgcn_readfirstlane(bid_g - m * groups);
     const float* Wm = m == 0 ? p.w[0] : (m == 1 ? p.w[1] : p.w[2]);
     const int nblk = p.K >> 4;
     const int nchunk = (nblk + D - 1) / D;
-    const unsigned lane16 = (unsigned)lane * 16u;
+    const bool lane_ok = half < 0 || lane < 32;                   // a half group: 8 rows x 4 chains
+    const unsigned lane16 = half < 0 ? (unsigned)lane * 16u : (lane < 32 ? (unsigned)half * 512u + (unsigned)lane * 16u : kOOB);
     static_assert(D % 16 == 0, "a chunk is made of whole 16-block stretches");
     const int n16 = (nblk + 15) >> 4;
     // the descriptor of stretch q (16 blocks = 16 KiB of the group's stream): as many bytes as the row still has there,
@@ -706,7 +714,7 @@ __device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in)
 #pragma unroll
         for (int u = 0; u < 16; u++) wr[h * 16 + u] = ld_nt(r0, vo[u >> 2] + (unsigned)(u & 3) * 1024u);
     }
-    const int row = 16 * g + rr;
+    const int row = lane_ok ? 16 * g + (half > 0 ? 8 : 0) + rr : p.rows + 16;      // (lanes a half group does not use: behind every matrix)
     // epilogue operands
     float xold = 0.0f, rc = 1.0f, rs = 0.0f;
     int pos = 0;

@@ -171,6 +171,7 @@ struct rama_ctx {
     int tune_chain_awo = 0;                // parity mode, short contexts: attention + Wo as one launch, the Wo groups' first 4 x this many KiB requested while the attention runs (0: two launches)
     unsigned long long* awo_flags = nullptr;    // device: [kAwoLayers][kAwoHeads] tagged words
     int tune_chain_norm = 1;               // parity mode, dim <= 512: the layer norms folded into the matvecs that consume them
+    int tune_chain_split = 1;              // parity mode: the row groups that do not divide by the compute units walked as half groups (chain.hpp half_from)
     int tune_chain_qa = 0;                 // parity mode, short contexts: Wq|Wk|Wv + the attention as one launch (chain.hpp qkv_attn_chain_kernel; opt-in: measured equal)
     unsigned long long* qa_flags = nullptr;     // device: [kAwoLayers][3 * 256] tagged words, one per (layer, matrix, row group)
     int tune_chain_fused = 0;              // parity mode: a whole stage as ONE launch (layer_chain_fused.hpp; opt-in: stories15M +6 %, stories110M -40 %); -1: for dim <= 1024
@@ -654,14 +655,22 @@ static int launch_chain(rama_ctx* c, ChainParams& p, int norm = CNORM_NONE) {
     if ((size_t)(p.K + chain_pad_floats(W, D, 4)) * sizeof(float) > 64 * 1024) { W = 1; D = 16; }
     const size_t lds = (size_t)(p.K + chain_pad_floats(W, D, 4)) * sizeof(float);      // x + the zeros behind it
     REQUIRE(lds <= 64 * 1024, RAMA_EUNSUP, "chain-order matvec: row longer than ~15800 floats");
-    const dim3 grid(groups);
+    // [r5] one wave per row group and more groups than compute units: the groups that do not divide by the CUs as halves (chain.hpp half_from; "chain_split")
+    int nblocks = groups;
+    p.half_from = 0;
+    if (c->tune_chain_split && W == 1 && D == 16 && c->tune_chain_d <= 0 && norm != CNORM_EXACT && norm != CNORM_TREE) {
+        const int cus = std::max(c->cu_count, 1), rem = groups % cus;
+        // (more than half the CUs with a group more -- the classifier's 2 000 groups: the halves would give some CUs two again)
+        if (groups > cus && rem > 0 && 2 * rem <= cus) { p.half_from = groups - rem; nblocks = groups + rem; }
+    }
+    const dim3 grid(nblocks);
     if (norm == CNORM_LEAD) {      // the exact sum by a leader workgroup of this launch (grid + 1); geometry as without a norm
         REQUIRE(D == 16 && (W == 1 || W == 2) && p.K % 8 == 0 && p.K <= 4096 * W && (EPI == CEPI_QKV || EPI == CEPI_SWIGLU || EPI == CEPI_STORE) && p.lead && p.epoch && p.err,
                 RAMA_EUNSUP, "chain-order matvec: no leader-norm instantiation for this shape");
         constexpr int E3 = (EPI == CEPI_QKV || EPI == CEPI_SWIGLU || EPI == CEPI_STORE) ? EPI : CEPI_QKV;
         const int per = (p.K + 64 * W - 1) / (64 * W);
         const size_t ldsl = std::max(lds, W == 1 ? sizeof(FastSumShared<1>) : sizeof(FastSumShared<2>));
-        const dim3 gridl(groups + 1);
+        const dim3 gridl(nblocks + 1);
 #define RAMA_CHAIN_L(W_, LR_) RAMA_LAUNCH(c, (gemv_chain_kernel<W_, 16, 4, E3, CNORM_LEAD, LR_>), gridl, dim3(W_ * 64), ldsl, p)
 #define RAMA_CHAIN_LW(W_) do { if (per <= 8) RAMA_CHAIN_L(W_, 8); else if (per <= 16) RAMA_CHAIN_L(W_, 16); else if (per <= 32) RAMA_CHAIN_L(W_, 32); else RAMA_CHAIN_L(W_, 64); } while (0)
         if (W == 1) RAMA_CHAIN_LW(1); else RAMA_CHAIN_LW(2);
@@ -2899,6 +2908,13 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
     if (!strcmp(key, "chain_awo")) {
         REQUIRE(value == 0 || value == 16 || value == 48, RAMA_EINVAL, "set_tuning: chain_awo must be 0, 16 or 48");
         c->tune_chain_awo = value;
+        hipStreamSynchronize(c->stream);
+        drop_graph(c);
+        return 0;
+    }
+    if (!strcmp(key, "chain_split")) {
+        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: chain_split must be 0 or 1");
+        c->tune_chain_split = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
         return 0;
