@@ -185,7 +185,7 @@ __device__ __forceinline__ float seq_sum_exact(const float* a, int n, SeqSumShar
 //      seq_sum_exact.  The result is the sequential sum bit for bit whenever it is returned.
 // phase time stamps for tools/seqsum_bench.hip only (100 MHz counter, thread 0)
 #ifdef RAMA_SEQ_STAMPS
-__device__ unsigned long long g_seq_stamps[40];
+__device__ unsigned long long g_seq_stamps[64];
 #define SEQ_STAMP(id) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_seq_stamps[id] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define SEQ_STAMP(id) do { } while (0)
@@ -509,11 +509,13 @@ __global__ __launch_bounds__(kNormThreads) void softmax_chain_kernel(float* x, i
     __shared__ PredShared<kNormWaves> ps;
     __shared__ FastSumShared<kNormWaves> fsn;
     __shared__ float red[16];
+    __shared__ unsigned long long s_tab[32];
     const int tid = threadIdx.x;
+    exp_tab_fill(s_tab);
     float mx = -INFINITY;
     for (int i = tid; i < n; i += kNormThreads) mx = fmaxf(mx, x[i]);
     mx = block_max(mx, red);
-    for (int i = tid; i < n; i += kNormThreads) s_e[scan_slot(i)] = expf_glibc(x[i] - mx);
+    for (int i = tid; i < n; i += kNormThreads) s_e[scan_slot(i)] = expf_glibc_tab(x[i] - mx, s_tab);
     __syncthreads();
     float sum;
     if (!seq_sum_lds_fast<kNormWaves>(s_e, n, fsn, &sum)) { __syncthreads(); if (!seq_sum_predict<kNormWaves>(s_e, n, ps, &sum)) sum = seq_sum_exact<kNormWaves>(s_e, n, sh); }
@@ -717,9 +719,12 @@ __device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in)
     const int row = lane_ok ? 16 * g + (half > 0 ? 8 : 0) + rr : p.rows + 16;      // (lanes a half group does not use: behind every matrix)
     // epilogue operands
     float xold = 0.0f, rc = 1.0f, rs = 0.0f;
+    unsigned long long tabv = 0;                                  // SWIGLU: the exponential's table word lane & 31 (requested with the ring, see the epilogue)
     int pos = 0;
     if (EPI == CEPI_RESID) {
         if (j == 0 && row < p.rows) xold = p.resid[row];
+    } else if (EPI == CEPI_SWIGLU) {
+        tabv = kExp2fTab[lane & 31];
     } else if (EPI == CEPI_QKV) {
         pos = p.ctl ? p.ctl->pos : p.pos_val;
         if (m < 2) {
@@ -940,8 +945,13 @@ __device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in)
         }
     } else {   // CEPI_SWIGLU: even row = W1 row i, odd row = W3 row i
         const float h3 = __shfl_xor(d, 4);
+        // the table of expf in LDS, written by every wave for itself from words it asked for in front of the ring (all waves write the same 256 bytes;
+        // a wave's LDS operations keep their order): a lookup in constant memory HERE is a trip to L2 or further at the very end of the workgroup
+        __shared__ unsigned long long s_tab[32];
+        s_tab[lane & 31] = tabv;
+        __builtin_amdgcn_wave_barrier();
         if (j == 0 && !(rr & 1) && row < p.rows && valid) {
-            const float sl = d * (1.0f / (1.0f + expf_glibc(-d)));           // cpu.rs:56
+            const float sl = d * (1.0f / (1.0f + expf_glibc_tab(-d, s_tab)));       // cpu.rs:56
             p.o[0][row >> 1] = sl * h3;                                        // cpu.rs:59-64
             p.o[1][row >> 1] = h3;
         }
@@ -1227,8 +1237,10 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
     __shared__ PredShared<NW> ps;
     __shared__ FastSumShared<NW> fsn;
     __shared__ float red[16];
+    __shared__ unsigned long long s_tab[32];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    exp_tab_fill(s_tab);
     const int pos = p.seqs ? p.seqs[y].pos : (p.ctl ? p.ctl->pos : p.pos_val) + y;
     if (p.seqs) { p.kc = p.seqs[y].kc + p.layer_off; p.vc = p.seqs[y].vc + p.layer_off; }
     p.q += (size_t)y * p.tok_stride; p.xb += (size_t)y * p.tok_stride;
@@ -1439,7 +1451,7 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
     float mx = -INFINITY;
     for (int t = tid; t <= pos; t += T) mx = fmaxf(mx, s_att[scan_slot(t)]);
     mx = block_max(mx, red);
-    for (int t = tid; t <= pos; t += T) s_att[scan_slot(t)] = expf_glibc(s_att[scan_slot(t)] - mx);
+    for (int t = tid; t <= pos; t += T) s_att[scan_slot(t)] = expf_glibc_tab(s_att[scan_slot(t)] - mx, s_tab);
     __syncthreads();
     SEQ_STAMP(10);
     float sum;
@@ -1640,13 +1652,15 @@ __global__ __launch_bounds__(kSoftWaves * 64) void attn_softmax_chain_kernel(Ref
     __shared__ PredShared<kSoftWaves> ps;
     __shared__ FastSumShared<kSoftWaves> fsn;
     __shared__ float red[16];
+    __shared__ unsigned long long s_tab[32];
     const int h = blockIdx.x, tid = threadIdx.x;
+    exp_tab_fill(s_tab);
     const int pos = p.ctl ? p.ctl->pos : p.pos_val;
     float* att = p.att + (size_t)h * p.seq_len;
     float mx = -INFINITY;
     for (int t = tid; t <= pos; t += T) { const float a = att[t]; s_att[scan_slot(t)] = a; mx = fmaxf(mx, a); }
     mx = block_max(mx, red);
-    for (int t = tid; t <= pos; t += T) s_att[scan_slot(t)] = expf_glibc(s_att[scan_slot(t)] - mx);
+    for (int t = tid; t <= pos; t += T) s_att[scan_slot(t)] = expf_glibc_tab(s_att[scan_slot(t)] - mx, s_tab);
     __syncthreads();
     float sum;
     if (!seq_sum_lds_fast<kSoftWaves>(s_att, pos + 1, fsn, &sum)) { __syncthreads(); if (!seq_sum_predict<kSoftWaves>(s_att, pos + 1, ps, &sum)) sum = seq_sum_exact<kSoftWaves>(s_att, pos + 1, sh); }
@@ -1768,6 +1782,8 @@ __global__ __launch_bounds__(kFvWaves * 64) void attn_softmax_values_chain_kerne
     __shared__ PredShared<kFvWaves> ps;
     __shared__ FastSumShared<kFvWaves> fsn;
     __shared__ float red[16];
+    __shared__ unsigned long long s_tab[32];
+    exp_tab_fill(s_tab);
     float* s_att = fv_sm;                                          // [scan_slot(seq_len)] scores -> exponentials
     float* s_p = fv_sm + p.seq_len + (p.seq_len >> 5) + 4;         // [seq_len] the probabilities, unskewed
     const int h = blockIdx.x, sl = blockIdx.y, tid0 = threadIdx.x, tid = (int)threadIdx.x - 64;      // loading threads 0..191; the chain wave: -64..-1
@@ -1792,23 +1808,29 @@ __global__ __launch_bounds__(kFvWaves * 64) void attn_softmax_values_chain_kerne
             vr[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.vc + (size_t)tr * p.dim + col) + c4);
         }
     };
+    SEQ_STAMP(40);
     if (!chain) { vissue(0, v0); vissue(kFvRows, v1); vissue(2 * kFvRows, v2); vissue(3 * kFvRows, v3); }     // uniform per wave
     // softmax_num (cpu.rs:187-192), as attn_softmax_chain_kernel
     float mx = -INFINITY;
 #pragma unroll
     for (int k = 0; k < kSc; k++) { const int t = tid0 + k * TS; if (t <= pos) { s_att[scan_slot(t)] = sc[k]; mx = fmaxf(mx, sc[k]); } }
     for (int t = tid0 + kSc * TS; t <= pos; t += TS) { const float a = scores[t]; s_att[scan_slot(t)] = a; mx = fmaxf(mx, a); }
+    SEQ_STAMP(41);
     mx = block_max(mx, red);
-    for (int t = tid0; t <= pos; t += TS) s_att[scan_slot(t)] = expf_glibc(s_att[scan_slot(t)] - mx);
+    SEQ_STAMP(42);
+    for (int t = tid0; t <= pos; t += TS) s_att[scan_slot(t)] = expf_glibc_tab(s_att[scan_slot(t)] - mx, s_tab);
     __syncthreads();
+    SEQ_STAMP(43);
     float sum;
     if (!seq_sum_lds_fast<kFvWaves>(s_att, pos + 1, fsn, &sum)) { __syncthreads(); if (!seq_sum_predict<kFvWaves>(s_att, pos + 1, ps, &sum)) sum = seq_sum_exact<kFvWaves>(s_att, pos + 1, sh); }
+    SEQ_STAMP(44);
     for (int t = tid0; t <= pos; t += TS) {
         const float a = s_att[scan_slot(t)] / sum;
         s_p[t] = a;
         if (sl == 0) att[t] = a;                                   // the probabilities as the launches before this one left them (tests read them)
     }
     __syncthreads();
+    SEQ_STAMP(45);
     if (chain) {
         const int lane = threadIdx.x;
         float acc = 0.0f;
@@ -1842,8 +1864,10 @@ __global__ __launch_bounds__(kFvWaves * 64) void attn_softmax_values_chain_kerne
                 const float* ts = &tile[buf][lane * kFvStride];
                 for (; r < nt; r++) acc = acc + ts[r];
             }
+            SEQ_STAMP(46 + min(t0 / kFvRows, 12));
         }
         if (lane < kValCols) p.xb[col + lane] = acc;
+        SEQ_STAMP(59);
         return;
     }
     auto vtile = [&](int t0, int buf, f4 (&vr)[U]) {

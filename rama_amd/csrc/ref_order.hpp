@@ -44,7 +44,10 @@ __device__ __constant__ const unsigned long long kExp2fTab[32] = {
     0x3fef5818dcfba487ULL, 0x3fef7c97337b9b5fULL, 0x3fefa4afa2a490daULL, 0x3fefd0765b6e4540ULL,
 };
 
-__device__ __forceinline__ float expf_glibc(float x) {
+// tab: the 32 table words -- kExp2fTab itself, or a workgroup's copy of it in LDS (exp_tab_fill).  A lookup in constant memory is a per-lane load
+// that travels to L2 (and past it once a long context's cache rows have pushed the table out): ~0.2 us in front of EVERY exponential of a loop,
+// 1.5 of the 19 us of the long-context softmax + values launch at position 1 900 ([r5]: an LDS read instead).
+__device__ __forceinline__ float expf_glibc_tab(float x, const unsigned long long* tab) {
     const unsigned ux = __float_as_uint(x);
     const unsigned abstop = (ux >> 20) & 0x7ff;
     if (abstop > 0x42a) {                                   // |x| >= 88 or not finite
@@ -60,7 +63,7 @@ __device__ __forceinline__ float expf_glibc(float x) {
     const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
     kd = __dsub_rn(kd, Shift);
     const double r = __builtin_fma(InvLn2N, xd, -kd);
-    const unsigned long long t = kExp2fTab[ki & 31] + (ki << 47);
+    const unsigned long long t = tab[ki & 31] + (ki << 47);
     const double s = __longlong_as_double((long long)t);
     const double z = __builtin_fma(C0, r, C1);
     const double r2 = __dmul_rn(r, r);
@@ -69,6 +72,9 @@ __device__ __forceinline__ float expf_glibc(float x) {
     y = __dmul_rn(y, s);
     return (float)y;
 }
+__device__ __forceinline__ float expf_glibc(float x) { return expf_glibc_tab(x, kExp2fTab); }
+// the table into LDS: threads 0..31 of the workgroup write it; a barrier of the caller's stands between this and the first expf_glibc_tab
+__device__ __forceinline__ void exp_tab_fill(unsigned long long* s_tab) { if (threadIdx.x < 32) s_tab[threadIdx.x] = kExp2fTab[threadIdx.x]; }
 
 __global__ void expf_glibc_kernel(float* o, const float* x, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) o[i] = expf_glibc(x[i]);
