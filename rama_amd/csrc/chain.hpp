@@ -423,9 +423,12 @@ constexpr int kNormMax = 16384;
 constexpr int kNormWaves = RAMA_NORM_WAVES, kNormThreads = kNormWaves * 64;     // one wave per SIMD: the scan rounds are bound by instruction issue
 
 // [r5] seqsum_fast.hpp's sum (the leader workgroups') for a list that sits in LDS in scan_slot layout: thread t takes terms t R .. t R + R - 1 into
-// registers.  Lists of >= 1024 terms only (below that the ripples of seq_sum_predict are as fast); false: the list is too short or too long,
+// registers.  Lists of >= 256 terms only (below that the ripples of seq_sum_predict are as fast; at 600 terms they take 4.2 us against 2.2 here); false: the list is too short or too long,
 // or a prediction did not hold -- the caller then takes seq_sum_predict / seq_sum_exact as before.  All NW waves call it.
-constexpr int kFastSumMin = 1024;
+#ifndef RAMA_FAST_SUM_MIN
+#define RAMA_FAST_SUM_MIN 256
+#endif
+constexpr int kFastSumMin = RAMA_FAST_SUM_MIN;
 template <int NW, int R>
 __device__ __forceinline__ bool seq_sum_lds_fast_r(const float* a, int n, FastSumShared<NW>& fs, float* out) {
     float v[R];
@@ -1771,16 +1774,20 @@ __global__ __launch_bounds__(kValWaves * 64) void attn_values_chain_kernel(RefAt
 // probabilities through memory and the value launch's 2.8 us until its first tile is there fall away; the weights are read from
 // LDS.  Then as attn_values_chain_kernel: wave 0 adds (lanes 0..15), waves 1..3 load, multiply and store tiles of 192 rows.
 constexpr int kFvRows = 192, kFvStride = kFvRows + 4, kFvWaves = 4;
+#ifndef RAMA_FV_SOFT
+#define RAMA_FV_SOFT 8
+#endif
+constexpr int kFvSoftWaves = RAMA_FV_SOFT;        // [r5] waves of the softmax phase (waves kFvWaves.. leave after it): its loops are a few elements per thread, each with its latency in full
 __host__ __device__ constexpr size_t attn_fused_values_lds_floats(int seq_len) { return (size_t)seq_len + ((size_t)seq_len >> 5) + 4 + (((size_t)seq_len + 3) & ~(size_t)3); }
-__global__ __launch_bounds__(kFvWaves * 64) void attn_softmax_values_chain_kernel(RefAttnParams p) {
+__global__ __launch_bounds__(kFvSoftWaves * 64) void attn_softmax_values_chain_kernel(RefAttnParams p) {
     RAMA_NO_CONTRACT
-    constexpr int TS = kFvWaves * 64;                              // softmax: all four waves
+    constexpr int TS = kFvSoftWaves * 64;                          // softmax: all waves
     constexpr int T = (kFvWaves - 1) * 64, U = kFvRows * (kValCols / 4) / T;      // products: 4 x 16 bytes per loading thread and tile
     extern __shared__ __attribute__((aligned(16))) float fv_sm[];
     __shared__ __attribute__((aligned(16))) float tile[2][kValCols * kFvStride];
-    __shared__ SeqSumShared<kFvWaves> sh;
-    __shared__ PredShared<kFvWaves> ps;
-    __shared__ FastSumShared<kFvWaves> fsn;
+    __shared__ SeqSumShared<kFvSoftWaves> sh;
+    __shared__ PredShared<kFvSoftWaves> ps;
+    __shared__ FastSumShared<kFvSoftWaves> fsn;
     __shared__ float red[16];
     __shared__ unsigned long long s_tab[32];
     exp_tab_fill(s_tab);
@@ -1794,11 +1801,19 @@ __global__ __launch_bounds__(kFvWaves * 64) void attn_softmax_values_chain_kerne
     // head all read the scores, and nothing orders the workgroups of one launch, so none of them may write what the others read
     const float* scores = p.sc + (size_t)h * p.seq_len;
     float* att = p.att + (size_t)h * p.seq_len;
-    // the scores first (their wait then leaves the value rows outstanding), then four tiles of value rows
-    constexpr int kSc = 8;                                         // scores per thread and round
+    // the scores first, staged and their maximum taken BEFORE the value rows are asked for ([r5]; round 4 asked for both at once: behind the join of
+    // `if (loading wave)` the compiler no longer knows how many loads follow the scores in the queue -- 16 or none -- and waited for everything, value
+    // rows included: 2.1 us in front of the first barrier.  The scores are one round trip of 0.4 us, and the rows are not needed for 5 us)
+    constexpr int kSc = 2048 / TS;                                 // scores per thread in flight at once (2 048 positions; a loop for the rest)
     float sc[kSc];
 #pragma unroll
     for (int k = 0; k < kSc; k++) sc[k] = scores[min(tid0 + k * TS, pos)];
+    SEQ_STAMP(40);
+    // softmax_num (cpu.rs:187-192), as attn_softmax_chain_kernel
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < kSc; k++) { const int t = tid0 + k * TS; if (t <= pos) { s_att[scan_slot(t)] = sc[k]; mx = fmaxf(mx, sc[k]); } }
+    for (int t = tid0 + kSc * TS; t <= pos; t += TS) { const float a = scores[t]; s_att[scan_slot(t)] = a; mx = fmaxf(mx, a); }
     f4 v0[U], v1[U], v2[U], v3[U];
     auto vissue = [&](int t0, f4 (&vr)[U]) {
 #pragma unroll
@@ -1808,13 +1823,7 @@ __global__ __launch_bounds__(kFvWaves * 64) void attn_softmax_values_chain_kerne
             vr[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.vc + (size_t)tr * p.dim + col) + c4);
         }
     };
-    SEQ_STAMP(40);
-    if (!chain) { vissue(0, v0); vissue(kFvRows, v1); vissue(2 * kFvRows, v2); vissue(3 * kFvRows, v3); }     // uniform per wave
-    // softmax_num (cpu.rs:187-192), as attn_softmax_chain_kernel
-    float mx = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < kSc; k++) { const int t = tid0 + k * TS; if (t <= pos) { s_att[scan_slot(t)] = sc[k]; mx = fmaxf(mx, sc[k]); } }
-    for (int t = tid0 + kSc * TS; t <= pos; t += TS) { const float a = scores[t]; s_att[scan_slot(t)] = a; mx = fmaxf(mx, a); }
+    if (!chain && tid < T) { vissue(0, v0); vissue(kFvRows, v1); vissue(2 * kFvRows, v2); vissue(3 * kFvRows, v3); }     // uniform per wave
     SEQ_STAMP(41);
     mx = block_max(mx, red);
     SEQ_STAMP(42);
@@ -1822,7 +1831,7 @@ __global__ __launch_bounds__(kFvWaves * 64) void attn_softmax_values_chain_kerne
     __syncthreads();
     SEQ_STAMP(43);
     float sum;
-    if (!seq_sum_lds_fast<kFvWaves>(s_att, pos + 1, fsn, &sum)) { __syncthreads(); if (!seq_sum_predict<kFvWaves>(s_att, pos + 1, ps, &sum)) sum = seq_sum_exact<kFvWaves>(s_att, pos + 1, sh); }
+    if (!seq_sum_lds_fast<kFvSoftWaves>(s_att, pos + 1, fsn, &sum)) { __syncthreads(); if (!seq_sum_predict<kFvSoftWaves>(s_att, pos + 1, ps, &sum)) sum = seq_sum_exact<kFvSoftWaves>(s_att, pos + 1, sh); }
     SEQ_STAMP(44);
     for (int t = tid0; t <= pos; t += TS) {
         const float a = s_att[scan_slot(t)] / sum;
@@ -1831,6 +1840,7 @@ __global__ __launch_bounds__(kFvWaves * 64) void attn_softmax_values_chain_kerne
     }
     __syncthreads();
     SEQ_STAMP(45);
+    if (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) >= kFvWaves) return;      // (a barrier counts the waves that are still there)
     if (chain) {
         const int lane = threadIdx.x;
         float acc = 0.0f;
@@ -1838,31 +1848,101 @@ __global__ __launch_bounds__(kFvWaves * 64) void attn_softmax_values_chain_kerne
         for (int t0 = 0; t0 <= pos; t0 += kFvRows, buf ^= 1) {
             __syncthreads();                                      // tile t0 is written (and the other buffer, read last round, is free again)
             if (lane < kValCols) {
+                // [r5] the chain itself as one block of assembly: a dependent add every ~8 cycles, with the LDS reads of the rows 32 ahead (four
+                // 16-byte reads per 16 rows, three register sets in turn) in the adds' shadows -- compiled C++ keeps reads and adds apart (10.6
+                // cycles an add).  Whole groups of 16 rows: the rows behind pos hold +0 (vtile), which leaves a sum as it is; the reads that run
+                // ahead of the tile's end fetch words that are never added.
                 const int nt = min(kFvRows, pos + 1 - t0);
-                const f4* tb = reinterpret_cast<const f4*>(&tile[buf][lane * kFvStride]);
-                f4 w0[4], w1[4];
-                auto rd = [&](int r, f4 (&w)[4]) {                // (rows behind the tile are clamped: read, never added)
-#pragma unroll
-                    for (int u = 0; u < 4; u++) w[u] = tb[min(r / 4 + u, kFvRows / 4 - 1)];
-                };
-                auto ad = [&](const f4 (&w)[4]) {
-#pragma unroll
-                    for (int u = 0; u < 4; u++) { acc = acc + w[u].x; acc = acc + w[u].y; acc = acc + w[u].z; acc = acc + w[u].w; }
-                };
-                int r = 0;
-                rd(0, w0);
-                for (; r + 32 <= nt; r += 32) {
-                    rd(r + 16, w1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    ad(w0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    rd(r + 32, w0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    ad(w1);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                const float* ts = &tile[buf][lane * kFvStride];
-                for (; r < nt; r++) acc = acc + ts[r];
+                unsigned a = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)&tile[buf][lane * kFvStride];
+                int nb = (nt + 15) >> 4;
+                asm volatile(
+                    "ds_read_b128 v[200:203], %[a] offset:0\n"
+                    "ds_read_b128 v[204:207], %[a] offset:16\n"
+                    "ds_read_b128 v[208:211], %[a] offset:32\n"
+                    "ds_read_b128 v[212:215], %[a] offset:48\n"
+                    "ds_read_b128 v[216:219], %[a] offset:64\n"
+                    "ds_read_b128 v[220:223], %[a] offset:80\n"
+                    "ds_read_b128 v[224:227], %[a] offset:96\n"
+                    "ds_read_b128 v[228:231], %[a] offset:112\n"
+                    "1:\n"
+                    "s_waitcnt lgkmcnt(4)\n"
+                    "v_add_f32 %[acc], %[acc], v200\n"
+                    "ds_read_b128 v[232:235], %[a] offset:128\n"
+                    "v_add_f32 %[acc], %[acc], v201\n"
+                    "v_add_f32 %[acc], %[acc], v202\n"
+                    "s_sub_u32 %[nb], %[nb], 1\n"
+                    "v_add_f32 %[acc], %[acc], v203\n"
+                    "v_add_f32 %[acc], %[acc], v204\n"
+                    "ds_read_b128 v[236:239], %[a] offset:144\n"
+                    "v_add_f32 %[acc], %[acc], v205\n"
+                    "v_add_f32 %[acc], %[acc], v206\n"
+                    "s_cmp_eq_u32 %[nb], 0\n"
+                    "v_add_f32 %[acc], %[acc], v207\n"
+                    "v_add_f32 %[acc], %[acc], v208\n"
+                    "ds_read_b128 v[240:243], %[a] offset:160\n"
+                    "v_add_f32 %[acc], %[acc], v209\n"
+                    "v_add_f32 %[acc], %[acc], v210\n"
+                    "v_add_f32 %[acc], %[acc], v211\n"
+                    "v_add_f32 %[acc], %[acc], v212\n"
+                    "ds_read_b128 v[244:247], %[a] offset:176\n"
+                    "v_add_f32 %[acc], %[acc], v213\n"
+                    "v_add_f32 %[acc], %[acc], v214\n"
+                    "v_add_f32 %[acc], %[acc], v215\n"
+                    "s_cbranch_scc1 2f\n"
+                    "s_waitcnt lgkmcnt(4)\n"
+                    "v_add_f32 %[acc], %[acc], v216\n"
+                    "ds_read_b128 v[200:203], %[a] offset:192\n"
+                    "v_add_f32 %[acc], %[acc], v217\n"
+                    "v_add_f32 %[acc], %[acc], v218\n"
+                    "s_sub_u32 %[nb], %[nb], 1\n"
+                    "v_add_f32 %[acc], %[acc], v219\n"
+                    "v_add_f32 %[acc], %[acc], v220\n"
+                    "ds_read_b128 v[204:207], %[a] offset:208\n"
+                    "v_add_f32 %[acc], %[acc], v221\n"
+                    "v_add_f32 %[acc], %[acc], v222\n"
+                    "s_cmp_eq_u32 %[nb], 0\n"
+                    "v_add_f32 %[acc], %[acc], v223\n"
+                    "v_add_f32 %[acc], %[acc], v224\n"
+                    "ds_read_b128 v[208:211], %[a] offset:224\n"
+                    "v_add_f32 %[acc], %[acc], v225\n"
+                    "v_add_f32 %[acc], %[acc], v226\n"
+                    "v_add_f32 %[acc], %[acc], v227\n"
+                    "v_add_f32 %[acc], %[acc], v228\n"
+                    "ds_read_b128 v[212:215], %[a] offset:240\n"
+                    "v_add_f32 %[acc], %[acc], v229\n"
+                    "v_add_f32 %[acc], %[acc], v230\n"
+                    "v_add_f32 %[acc], %[acc], v231\n"
+                    "s_cbranch_scc1 2f\n"
+                    "s_waitcnt lgkmcnt(4)\n"
+                    "v_add_f32 %[acc], %[acc], v232\n"
+                    "ds_read_b128 v[216:219], %[a] offset:256\n"
+                    "v_add_f32 %[acc], %[acc], v233\n"
+                    "v_add_f32 %[acc], %[acc], v234\n"
+                    "s_sub_u32 %[nb], %[nb], 1\n"
+                    "v_add_f32 %[acc], %[acc], v235\n"
+                    "v_add_f32 %[acc], %[acc], v236\n"
+                    "ds_read_b128 v[220:223], %[a] offset:272\n"
+                    "v_add_f32 %[acc], %[acc], v237\n"
+                    "v_add_f32 %[acc], %[acc], v238\n"
+                    "s_cmp_eq_u32 %[nb], 0\n"
+                    "v_add_f32 %[acc], %[acc], v239\n"
+                    "v_add_f32 %[acc], %[acc], v240\n"
+                    "ds_read_b128 v[224:227], %[a] offset:288\n"
+                    "v_add_f32 %[acc], %[acc], v241\n"
+                    "v_add_f32 %[acc], %[acc], v242\n"
+                    "v_add_f32 %[acc], %[acc], v243\n"
+                    "v_add_f32 %[acc], %[acc], v244\n"
+                    "ds_read_b128 v[228:231], %[a] offset:304\n"
+                    "v_add_f32 %[acc], %[acc], v245\n"
+                    "v_add_u32 %[a], 0xc0, %[a]\n"
+                    "v_add_f32 %[acc], %[acc], v246\n"
+                    "v_add_f32 %[acc], %[acc], v247\n"
+                    "s_cbranch_scc0 1b\n"
+                    "2:\n"
+                    "s_waitcnt lgkmcnt(0)\n"
+                    : [acc] "+v"(acc), [a] "+v"(a), [nb] "+s"(nb)
+                    :
+                    : "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "scc", "memory");
             }
             SEQ_STAMP(46 + min(t0 / kFvRows, 12));
         }
@@ -1874,9 +1954,11 @@ __global__ __launch_bounds__(kFvWaves * 64) void attn_softmax_values_chain_kerne
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int e = tid + u * T, r = e / (kValCols / 4), c4 = e % (kValCols / 4);
-            const float a = t0 + r <= pos ? s_p[min(t0 + r, pos)] : 0.0f;
+            const bool in = t0 + r <= pos;                         // (rows behind pos: +0, whatever the clamped row holds -- the chain adds whole batches of 32 rows)
+            const float a = s_p[min(t0 + r, pos)];
             float* d = &tile[buf][(4 * c4) * kFvStride + r];
-            d[0] = a * vr[u].x; d[kFvStride] = a * vr[u].y; d[2 * kFvStride] = a * vr[u].z; d[3 * kFvStride] = a * vr[u].w;     // cpu.rs:48 `a * vi`, rounded
+            d[0] = in ? a * vr[u].x : 0.0f; d[kFvStride] = in ? a * vr[u].y : 0.0f;      // cpu.rs:48 `a * vi`, rounded
+            d[2 * kFvStride] = in ? a * vr[u].z : 0.0f; d[3 * kFvStride] = in ? a * vr[u].w : 0.0f;
         }
         vissue(t0 + 4 * kFvRows, vr);
         __syncthreads();                                          // this tile is written: the chain wave takes it

@@ -778,8 +778,8 @@ static int launch_attention_chain(rama_ctx* c, float* xb, float* att, const floa
         else hipLaunchKernelGGL(attn_scores_chain_kernel, dim3(n_heads, ngroups), dim3(64), 0, c->stream, p);
         LAUNCHCHK();
         if (fv) {             // the softmax repeated by every slice workgroup, one launch (chain.hpp [r4])
-            if (ev_stop) hipExtLaunchKernelGGL(attn_softmax_values_chain_kernel, dim3(n_heads, head_size / kValCols), dim3(kFvWaves * 64), fv_lds, c->stream, nullptr, ev_stop, 0, p);
-            else hipLaunchKernelGGL(attn_softmax_values_chain_kernel, dim3(n_heads, head_size / kValCols), dim3(kFvWaves * 64), fv_lds, c->stream, p);
+            if (ev_stop) hipExtLaunchKernelGGL(attn_softmax_values_chain_kernel, dim3(n_heads, head_size / kValCols), dim3(kFvSoftWaves * 64), fv_lds, c->stream, nullptr, ev_stop, 0, p);
+            else hipLaunchKernelGGL(attn_softmax_values_chain_kernel, dim3(n_heads, head_size / kValCols), dim3(kFvSoftWaves * 64), fv_lds, c->stream, p);
             LAUNCHCHK();
             return 0;
         }

@@ -22,7 +22,7 @@ int main(int argc, char** argv) {
     const int ngroups = (seq + 63) / 64;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto scores = [&] { hipLaunchKernelGGL(attn_scores_chain_kernel, dim3(H, ngroups), dim3(64), 0, 0, ap); };
-    auto fv = [&] { hipLaunchKernelGGL(attn_softmax_values_chain_kernel, dim3(H, hs / kValCols), dim3(kFvWaves * 64), fv_lds, 0, ap); };
+    auto fv = [&] { hipLaunchKernelGGL(attn_softmax_values_chain_kernel, dim3(H, hs / kValCols), dim3(kFvSoftWaves * 64), fv_lds, 0, ap); };
     for (int what = 0; what < 3; what++) {
         float best = 1e9;
         for (int rep = 0; rep < 4; rep++) {
