@@ -555,6 +555,7 @@ struct ChainParams {
     // row groups do not divide by the compute units ends when the CUs with one group more are through: llama2-7B's W1|W3 is 1 376 groups on 256 CUs,
     // six on 96 of them and five on the rest; with the last 96 groups as 192 halves it is five and a half at most.
     int half_from;
+    float* xout;           // CNORM_LEAD: the leader also stores the normalised vector here (a Device::rmsnorm recorded in front of the run, rama_api.hip flush_mm)
 };
 
 // a descriptor whose inputs the compiler must take as wave-uniform (they are: kernel arguments and blockIdx)
@@ -663,6 +664,9 @@ __device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in)
 #ifdef RAMA_CHAIN_STAMPS
             if (threadIdx.x == 0) g_chain_stamps[42] = __builtin_amdgcn_s_memrealtime();
 #endif
+            if (p.xout) {      // cpu.rs:113-116 o[i] = w[i] * (v * x[i]), as the row groups form it for themselves
+                for (int i = threadIdx.x; i < p.K; i += WL * 64) p.xout[i] = p.nw[i] * (v * p.x[i]);
+            }
             return;
         }
     }

@@ -184,8 +184,15 @@ struct rama_ctx {
     int tune_rope_batch = 1;
     // ... and so is a run of up to three parity-mode Device::matmul calls with the same activations and shape on chain-order copies (infer.rs:20-23: Wq, Wk,
     // Wv; :41-42: W1, W3): one launch over all their row groups ("matmul_batch")
-    struct { const float* w[3]; float* o[3]; const float* x = nullptr; int K = 0, rows = 0, count = 0; } mm;
+    struct { const float* w[3]; float* o[3]; const float* x = nullptr; int K = 0, rows = 0, count = 0; bool norm = false; } mm;
     int tune_matmul_batch = 1;
+    // ... and a parity-mode Device::rmsnorm waits for the run of matmuls on its output (infer.rs:19-23, :40-42): the run's launch then carries the norm as
+    // its leader workgroup (chain.hpp CNORM_LEAD: the exact sum of squares while the row groups' weights are already on their way), and the leader also
+    // stores the normalised vector the call was asked for.  Anything else entering the library issues the norm as its own launch first ("norm_fold").
+    // The leader's tagged words rotate through a range of their own; the epoch advances when the range wraps.
+    struct { float* o = nullptr; const float* x = nullptr; const float* w = nullptr; int n = 0; bool on = false; } nrm;
+    int tune_norm_fold = 1;
+    int op_lead_next = 0;
     // ... and Device::sinu waits for the Device::array_mult on the same vector (infer.rs:44-45), one Device::copy_from_slice for the next (:32-33): one
     // launch per pair ("ew_batch").  At most ONE of the three records is pending at any time: whoever records flushes the others first.
     struct { int kind = 0; float* t = nullptr; const float* s = nullptr; size_t n = 0; } ew;      // 1: sinu(t, n); 2: copy(t, s, n)
@@ -228,16 +235,17 @@ static int set_device(rama_ctx* c) { HIPCHK(hipSetDevice(c->device)); return 0; 
 static int flush_rope(rama_ctx* c);
 static int flush_mm(rama_ctx* c);
 static int flush_ew(rama_ctx* c);
-static int flush_pending(rama_ctx* c) { int rf = flush_rope(c); if (!rf) rf = flush_mm(c); if (!rf) rf = flush_ew(c); return rf; }
-#define RAMA_ENTER(c) do { if ((c) && ((c)->rope.count | (c)->mm.count | (c)->ew.kind)) { const int rf_ = flush_pending(c); if (rf_) return rf_; } } while (0)
+static int flush_pending(rama_ctx* c) { int rf = flush_rope(c); if (!rf) rf = flush_mm(c); if (!rf) rf = flush_ew(c); return rf; }      // (flush_mm issues a recorded norm too)
+#define RAMA_PENDING(c) ((c)->rope.count | (c)->mm.count | (c)->ew.kind | (int)(c)->nrm.on)
+#define RAMA_ENTER(c) do { if ((c) && RAMA_PENDING(c)) { const int rf_ = flush_pending(c); if (rf_) return rf_; } } while (0)
 
 // internal accessors for the library's other translation units (pipe.hip); not in the C ABI header
-extern "C" void* rama_internal_stream(rama_ctx* c) { if (c && (c->rope.count | c->mm.count | c->ew.kind)) (void)flush_pending(c); return c ? (void*)c->stream : nullptr; }
+extern "C" void* rama_internal_stream(rama_ctx* c) { if (c && RAMA_PENDING(c)) (void)flush_pending(c); return c ? (void*)c->stream : nullptr; }
 extern "C" int rama_internal_device(rama_ctx* c) { return c ? c->device : 0; }
 // the sampler's device scratch after a rama_sample_topp* call (tests compare the running sums with a
 // sequential fp32 cumsum): sorted probabilities, sorted indices, running sums, candidate count
 extern "C" void rama_internal_topp_scratch(rama_ctx* c, float** keys, int** vals, float** prefix, int** m) {
-    if (c && (c->rope.count | c->mm.count | c->ew.kind)) (void)flush_pending(c);
+    if (c && RAMA_PENDING(c)) (void)flush_pending(c);
     if (keys) *keys = c->topp_keys[1];
     if (vals) *vals = c->topp_vals[1];
     if (prefix) *prefix = c->topp_prefix;
@@ -304,8 +312,8 @@ int rama_ctx_create(int device, void* hip_stream, rama_ctx** out) {
     HIPCHK(hipMemset(c->fused_hand, 0, (size_t)kFusedMaxLayers * fused_hand_words(kFusedMaxDim, kFusedMaxHidden) * sizeof(tagged_t)));
     HIPCHK(hipMalloc(&c->fused_epoch, sizeof(unsigned)));
     { const unsigned one = 1; HIPCHK(hipMemcpy(c->fused_epoch, &one, sizeof one, hipMemcpyHostToDevice)); }      // the zeroed vectors carry tag 0
-    HIPCHK(hipMalloc(&c->lead_slots, kLeadSlots * 32 * sizeof(unsigned long long)));
-    HIPCHK(hipMemset(c->lead_slots, 0, kLeadSlots * 32 * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&c->lead_slots, 2 * kLeadSlots * 32 * sizeof(unsigned long long)));      // (the second half: the recorded norms of the 1:1 op path)
+    HIPCHK(hipMemset(c->lead_slots, 0, 2 * kLeadSlots * 32 * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&c->qa_flags, (size_t)kAwoLayers * 768 * sizeof(unsigned long long)));
     HIPCHK(hipMemset(c->qa_flags, 0, (size_t)kAwoLayers * 768 * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&c->awo_flags, (size_t)kAwoLayers * kAwoHeads * sizeof(unsigned long long)));
@@ -363,7 +371,7 @@ static void drop_graph(rama_ctx* c) {
 extern "C" void rama_internal_drop_graphs(rama_ctx* c) { if (c) drop_graph(c); }      // model.hip: before a derived weight copy is freed
 
 int rama_ctx_destroy(rama_ctx* c) {
-    if (c && (c->rope.count | c->mm.count | c->ew.kind)) (void)flush_pending(c);
+    if (c && RAMA_PENDING(c)) (void)flush_pending(c);
     if (!c) return 0;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
@@ -712,20 +720,40 @@ static int launch_chain(rama_ctx* c, ChainParams& p, int norm = CNORM_NONE) {
     return 0;
 }
 // the pending run of parity-mode matmuls (rama_ctx::mm) as one chain-order launch
-static int flush_mm(rama_ctx* c) {
-    if (!c->mm.count) return 0;
-    ChainParams p{};
-    for (int i = 0; i < c->mm.count; i++) { p.w[i] = c->mm.w[i]; p.o[i] = c->mm.o[i]; }
-    p.x = c->mm.x; p.K = c->mm.K; p.rows = c->mm.rows; p.nmat = c->mm.count;
-    c->mm.count = 0;
-    return launch_chain<CEPI_STORE>(c, p);
-}
 static bool rmsnorm_chain_ok(size_t n) { return n <= (size_t)kNormMax && (n + (n >> 5) + 2) * sizeof(float) <= 64 * 1024; }
 static int launch_rmsnorm_chain(rama_ctx* c, float* o, const float* x, const float* w, int n, float* copy_to, int batch = 1, int stride = 0) {
     const size_t lds = ((size_t)n + ((size_t)n >> 5) + 2) * sizeof(float);
     RAMA_LAUNCH(c, rmsnorm_chain_kernel, dim3(batch), dim3(kNormThreads), lds, o, x, w, n, copy_to, stride);
     LAUNCHCHK();
     return 0;
+}
+// the recorded norm (rama_ctx::nrm) as a launch of its own: no run of matmuls took it
+static int flush_norm(rama_ctx* c) {
+    if (!c->nrm.on) return 0;
+    c->nrm.on = false;
+    return launch_rmsnorm_chain(c, c->nrm.o, c->nrm.x, c->nrm.w, c->nrm.n, nullptr);
+}
+static int flush_mm(rama_ctx* c) {
+    if (!(c->mm.count && c->mm.norm)) { const int rn = flush_norm(c); if (rn) return rn; }
+    if (!c->mm.count) return 0;
+    ChainParams p{};
+    for (int i = 0; i < c->mm.count; i++) { p.w[i] = c->mm.w[i]; p.o[i] = c->mm.o[i]; }
+    p.x = c->mm.x; p.K = c->mm.K; p.rows = c->mm.rows; p.nmat = c->mm.count;
+    c->mm.count = 0;
+    if (c->mm.norm) {      // the run reads the recorded norm's output: the norm rides in the run's launch, whose leader also stores that output
+        c->mm.norm = false; c->nrm.on = false;
+        p.x = c->nrm.x; p.nw = c->nrm.w; p.xout = c->nrm.o;
+        p.lead = c->lead_slots + 32 * (kLeadSlots + c->op_lead_next); p.epoch = c->fused_epoch; p.err = c->pbar + 1;
+        const int rc = launch_chain<CEPI_STORE>(c, p, CNORM_LEAD);
+        if (rc) return rc;
+        if (++c->op_lead_next == kLeadSlots) {      // every word of the range carries this epoch: the next one
+            c->op_lead_next = 0;
+            hipLaunchKernelGGL(fused_epoch_kernel, dim3(1), dim3(1), 0, c->stream, c->fused_epoch);
+            LAUNCHCHK();
+        }
+        return 0;
+    }
+    return launch_chain<CEPI_STORE>(c, p);
 }
 static int attn_chain_waves(int head_size, bool long_ctx) {
     const int want = long_ctx ? 8 : 4;
@@ -906,6 +934,15 @@ int rama_copy_from_slice(rama_ctx* c, float* t, const float* s, size_t n) {
 int rama_rmsnorm(rama_ctx* c, float* o, const float* x, const float* w, size_t n) {
     RAMA_ENTER(c);
     REQUIRE(c && o && x && w && n > 0, RAMA_EINVAL, "rmsnorm: bad argument");
+    if (c->tune_ref_order && c->tune_chain && rmsnorm_chain_ok(n) && c->tune_norm_fold && c->tune_chain_lead && c->tune_matmul_batch && c->own_stream && c->tune_chain_d <= 0 &&
+        c->tune_chain_lead_w <= 0 && c->kp.kernel_id < 0 && n % 16 == 0 && n <= 4096 && n >= 64 && aligned16(x) && aligned16(w) && aligned16(o) && (o + n <= x || x + n <= o) && c->lead_slots && c->pbar) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(c->stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {      // recorded: the run of matmuls on `o` carries it (flush_mm)
+            c->nrm.o = o; c->nrm.x = x; c->nrm.w = w; c->nrm.n = (int)n; c->nrm.on = true;
+            return 0;
+        }
+        (void)hipGetLastError();
+    }
     if (c->tune_ref_order) return c->tune_chain && rmsnorm_chain_ok(n) ? launch_rmsnorm_chain(c, o, x, w, (int)n, nullptr) : launch_rmsnorm_ref(c, o, x, w, (int)n);
     hipLaunchKernelGGL(rmsnorm_kernel, dim3(1), dim3(1024), 0, c->stream, o, x, w, (int)n);
     LAUNCHCHK(); return 0;
@@ -932,13 +969,13 @@ int rama_apply_position(rama_ctx* c, float* q, float* k, const float* pr, const 
     LAUNCHCHK(); return 0;
 }
 int rama_matmul(rama_ctx* c, float* o, const float* a, const float* b, size_t width, size_t o_rows, size_t o_cols) {
-    if (c && (c->rope.count | c->ew.kind)) { int rf = flush_rope(c); if (!rf) rf = flush_ew(c); if (rf) return rf; }      // (a pending run of matmuls may be extended by this call: below)
+    if (c && (c->rope.count | c->ew.kind)) { int rf = flush_rope(c); if (!rf) rf = flush_ew(c); if (rf) return rf; }      // (a pending run of matmuls may be extended by this call, a recorded norm taken along: below)
     REQUIRE(c && o && a && b, RAMA_EINVAL, "matmul: NULL argument");
     REQUIRE(o_cols >= 1, RAMA_EINVAL, "matmul: o_cols == 0");
     int rc = check_matvec_shape(width, o_rows);
     if (rc) { (void)flush_mm(c); return rc; }
     const bool extendable = c->mm.count && c->mm.count < 3 && c->tune_ref_order && o_cols == 1 && c->mm.x == b && c->mm.K == (int)width && c->mm.rows == (int)o_rows;
-    if (!extendable) { rc = flush_mm(c); if (rc) return rc; }
+    if (!extendable && c->mm.count) { rc = flush_mm(c); if (rc) return rc; }      // (no run pending: a recorded norm stays, this call may open the run that takes it)
     if (c->tune_ref_order && o_cols == 1) {
         // a layer-aligned view of a resident model's matrix streams the model's chain-order copy
         if (c->tune_chain && width % 16 == 0 && width <= 16000 && aligned16(b)) {
@@ -954,8 +991,14 @@ int rama_matmul(rama_ctx* c, float* o, const float* a, const float* b, size_t wi
                 auto overlaps = [](const float* p0, size_t n0, const float* p1, size_t n1) { return p0 < p1 + n1 && p1 < p0 + n0; };
                 bool clash = overlaps(o, o_rows, b, width);
                 for (int i = 0; i < mmb.count && !clash; i++) clash = overlaps(o, o_rows, mmb.o[i], o_rows);
+                // the recorded norm rides with a run on its output; the run then reads the norm's input, which no output of the run may touch
+                const bool takes_norm = c->nrm.on && (mmb.count ? mmb.norm : (b == c->nrm.o && (int)width == c->nrm.n));
+                if (takes_norm && overlaps(o, o_rows, c->nrm.x, (size_t)c->nrm.n)) clash = true;
                 if (c->tune_matmul_batch && c->own_stream && !capturing && !clash) {
-                    if (!mmb.count) { mmb.x = b; mmb.K = (int)width; mmb.rows = (int)o_rows; }
+                    if (!mmb.count) {
+                        mmb.x = b; mmb.K = (int)width; mmb.rows = (int)o_rows; mmb.norm = takes_norm;
+                        if (!takes_norm) { rc = flush_norm(c); if (rc) return rc; }
+                    }
                     mmb.w[mmb.count] = ch; mmb.o[mmb.count] = o; mmb.count++;
                     if (mmb.count == 3) return flush_mm(c);
                     return 0;
@@ -2910,6 +2953,11 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
         c->tune_chain_awo = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
+        return 0;
+    }
+    if (!strcmp(key, "norm_fold")) {
+        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: norm_fold must be 0 or 1");
+        c->tune_norm_fold = value;
         return 0;
     }
     if (!strcmp(key, "chain_split")) {

@@ -508,6 +508,59 @@ def test_recorded_ops_keep_program_order(dev):
         check(dev.lib.rama_set_tuning(dev.ctx, key, 1))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,rows,nmat", [(4096, 4096, 3), (4096, 11008, 2), (288, 288, 3), (768, 2048, 2), (512, 1000, 1), (4096, 32000, 1)])
+def test_recorded_rmsnorm_rides_with_the_matmul_run(dev, K, rows, nmat):
+    """[r5] a parity-mode Device::rmsnorm is recorded; the run of matmuls on its output carries it as the launch's leader workgroup, which also stores
+    the normalised vector (infer.rs:19-23, :40-42, :52-53).  Bit for bit the separate launches' results ("norm_fold" = 0), the oracle's on the small
+    shapes; hazards fall back to program order: an in-place norm, a download in between, a matmul on ANOTHER vector, an output that overlaps the
+    norm's input."""
+    from rama_amd._lib import check
+    x, g = rnd(K, 91, 1.5), (rnd(K, 92, 0.1) + np.float32(1.0)).astype(np.float32)
+    ws = [rnd(rows * K, 93 + i, 0.05) for i in range(nmat)]
+    tws = [up(dev, w_) for w_ in ws]
+    tg = up(dev, g)
+    res = {}
+    for fold in (1, 0):
+        check(dev.lib.rama_set_tuning(dev.ctx, b"norm_fold", fold))
+        tx, txb = up(dev, x), up(dev, np.zeros(K, np.float32))
+        outs = [up(dev, np.zeros(rows, np.float32)) for _ in range(nmat)]
+        dev.rmsnorm(txb, tx.as_view(), tg.as_view(), K)
+        for i in range(nmat):
+            dev.matmul(outs[i], tws[i].as_view(), txb.as_view(), K, rows, 1)
+        res[fold] = [dev.download(o_) for o_ in outs] + [dev.download(txb)]
+        # the norm alone, then a download (nothing takes it along)
+        txc = up(dev, np.zeros(K, np.float32))
+        dev.rmsnorm(txc, tx.as_view(), tg.as_view(), K)
+        assert_bits_equal(dev.download(txc), res[fold][-1], f"fold {fold}: a norm by itself")
+        # a norm, then a matmul on another vector: the norm is issued by itself, in front
+        txd = up(dev, np.zeros(K, np.float32))
+        dev.rmsnorm(txd, tx.as_view(), tg.as_view(), K)
+        dev.matmul(outs[0], tws[0].as_view(), txc.as_view(), K, rows, 1)
+        assert_bits_equal(dev.download(outs[0]), res[fold][0], f"fold {fold}: a matmul on another vector behind a recorded norm")
+        assert_bits_equal(dev.download(txd), res[fold][-1], f"fold {fold}: the norm in front of it")
+        # in place (infer.rs:52): never recorded
+        txe = up(dev, x)
+        dev.rmsnorm(txe, txe.as_view(), tg.as_view(), K)
+        dev.matmul(outs[0], tws[0].as_view(), txe.as_view(), K, rows, 1)
+        assert_bits_equal(dev.download(txe), res[fold][-1], f"fold {fold}: in-place norm")
+        assert_bits_equal(dev.download(outs[0]), res[fold][0], f"fold {fold}: matmul behind an in-place norm")
+        if rows == K:     # an output that IS the norm's input: the run may not read x while it is written
+            txf, txg = up(dev, x), up(dev, np.zeros(K, np.float32))
+            dev.rmsnorm(txg, txf.as_view(), tg.as_view(), K)
+            dev.matmul(txf, tws[0].as_view(), txg.as_view(), K, rows, 1)
+            assert_bits_equal(dev.download(txf), res[fold][0], f"fold {fold}: a matmul into the norm's input")
+    check(dev.lib.rama_set_tuning(dev.ctx, b"norm_fold", 1))
+    for i in range(nmat + 1):
+        assert_bits_equal(res[1][i], res[0][i], f"recorded norm, result {i}")
+    if rows * K <= 4096 * 4096:
+        xb = np.empty(K, np.float32); O.rmsnorm(xb, x, g, K)
+        assert_bits_equal(res[1][-1], xb, "the normalised vector against the oracle")
+        for i in range(nmat):
+            want = np.empty(rows, np.float32); O.matmul(want, ws[i], xb, K, rows)
+            assert_bits_equal(res[1][i], want, f"matmul {i} against the oracle")
+
+
 def _chain_lookup(dev, ptr, rows, K):
     f = dev.lib.rama_internal_chain_lookup
     f.restype = C.c_void_p
