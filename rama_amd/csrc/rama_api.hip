@@ -192,6 +192,7 @@ struct rama_ctx {
     // The leader's tagged words rotate through a range of their own; the epoch advances when the range wraps.
     struct { float* o = nullptr; const float* x = nullptr; const float* w = nullptr; int n = 0; bool on = false; } nrm;
     int tune_norm_fold = 1;
+    int tune_resid_fold = 1;               // ... and a Device::array_add of a recorded matmul's output becomes that launch's residual epilogue
     int op_lead_next = 0;
     // ... and Device::sinu waits for the Device::array_mult on the same vector (infer.rs:44-45), one Device::copy_from_slice for the next (:32-33): one
     // launch per pair ("ew_batch").  At most ONE of the three records is pending at any time: whoever records flushes the others first.
@@ -887,14 +888,22 @@ static int try_launch_attn_wo_chain(rama_ctx* c, const rama_config* cfg, rama_ru
 
 // ---------------------------------------------------------------- Device<T> ops, 1:1
 
+static inline bool ranges_overlap(const float* p0, size_t n0, const float* p1, size_t n1) { return p0 < p1 + n1 && p1 < p0 + n0; }
 int rama_array_add(rama_ctx* c, float* t, const float* s, size_t n) {
-    RAMA_ENTER(c);
     REQUIRE(c && (n == 0 || (t && s)), RAMA_EINVAL, "array_add: NULL argument");
+    // [r5] the recorded matmul whose output this call adds to `t` (infer.rs:35-37, :46-47): ONE launch with the residual epilogue (product stored, t += product)
+    if (c->mm.count == 1 && !c->mm.norm && !c->nrm.on && !c->rope.count && !c->ew.kind && c->tune_ref_order && c->tune_resid_fold && s == c->mm.o[0] && n == (size_t)c->mm.rows &&
+        aligned16(t) && !ranges_overlap(t, n, c->mm.x, (size_t)c->mm.K) && !ranges_overlap(t, n, s, n)) {
+        ChainParams p{};
+        p.w[0] = c->mm.w[0]; p.o[0] = c->mm.o[0]; p.resid = t; p.x = c->mm.x; p.K = c->mm.K; p.rows = c->mm.rows; p.nmat = 1;
+        c->mm.count = 0;
+        return launch_chain<CEPI_RESID>(c, p);
+    }
+    RAMA_ENTER(c);
     if (!n) return 0;
     hipLaunchKernelGGL(array_add_kernel, dim3(ew_grid(n)), dim3(256), 0, c->stream, t, s, n);
     LAUNCHCHK(); return 0;
 }
-static inline bool ranges_overlap(const float* p0, size_t n0, const float* p1, size_t n1) { return p0 < p1 + n1 && p1 < p0 + n0; }
 int rama_array_mult(rama_ctx* c, float* t, const float* s, size_t n) {
     REQUIRE(c && (n == 0 || (t && s)), RAMA_EINVAL, "array_mult: NULL argument");
     if (c->ew.kind == 1 && !c->rope.count && !c->mm.count && c->ew.t == t && c->ew.n == n && n && !ranges_overlap(s, n, t, n)) {      // the recorded sinu and this product: one launch
@@ -2953,6 +2962,11 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
         c->tune_chain_awo = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
+        return 0;
+    }
+    if (!strcmp(key, "resid_fold")) {
+        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: resid_fold must be 0 or 1");
+        c->tune_resid_fold = value;
         return 0;
     }
     if (!strcmp(key, "norm_fold")) {

@@ -561,6 +561,36 @@ def test_recorded_rmsnorm_rides_with_the_matmul_run(dev, K, rows, nmat):
             assert_bits_equal(res[1][i], want, f"matmul {i} against the oracle")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,rows", [(4096, 4096), (11008, 4096), (288, 288), (768, 288), (512, 1000)])
+def test_array_add_of_a_recorded_matmul_is_its_residual_epilogue(dev, K, rows):
+    """[r5] Device::matmul then Device::array_add of its output (infer.rs:35-37, :46-47) is one launch with the residual epilogue: the product stored, the
+    target incremented -- the separate launches' bits ("resid_fold" = 0), the oracle's; an add into the run's own input, or of another vector, stays apart"""
+    from rama_amd._lib import check
+    w, x, t0 = rnd(rows * K, 101, 0.05), rnd(K, 102), rnd(rows, 103)
+    tw = up(dev, w)
+    want = np.empty(rows, np.float32); O.matmul(want, w, x, K, rows)
+    for fold in (1, 0):
+        check(dev.lib.rama_set_tuning(dev.ctx, b"resid_fold", fold))
+        tx, to, tt = up(dev, x), up(dev, np.zeros(rows, np.float32)), up(dev, t0)
+        dev.matmul(to, tw.as_view(), tx.as_view(), K, rows, 1)
+        dev.array_add(tt, to.as_view(), rows)
+        assert_bits_equal(dev.download(to), want, f"fold {fold}: the product")
+        assert_bits_equal(dev.download(tt), (t0 + want).astype(np.float32), f"fold {fold}: the target")
+        # the add of ANOTHER vector behind a recorded matmul
+        to2, tt2 = up(dev, np.zeros(rows, np.float32)), up(dev, t0)
+        dev.matmul(to2, tw.as_view(), tx.as_view(), K, rows, 1)
+        dev.array_add(tt2, to.as_view(), rows)
+        assert_bits_equal(dev.download(tt2), (t0 + want).astype(np.float32), f"fold {fold}: add of another vector")
+        assert_bits_equal(dev.download(to2), want, f"fold {fold}: the matmul in front of it")
+        if rows == K:     # x += W x: the target is the run's input
+            tx3, to3 = up(dev, x), up(dev, np.zeros(rows, np.float32))
+            dev.matmul(to3, tw.as_view(), tx3.as_view(), K, rows, 1)
+            dev.array_add(tx3, to3.as_view(), rows)
+            assert_bits_equal(dev.download(tx3), (x + want).astype(np.float32), f"fold {fold}: add into the matmul's input")
+    check(dev.lib.rama_set_tuning(dev.ctx, b"resid_fold", 1))
+
+
 def _chain_lookup(dev, ptr, rows, K):
     f = dev.lib.rama_internal_chain_lookup
     f.restype = C.c_void_p
