@@ -192,6 +192,8 @@ struct rama_ctx {
     // The leader's tagged words rotate through a range of their own; the epoch advances when the range wraps.
     struct { float* o = nullptr; const float* x = nullptr; const float* w = nullptr; int n = 0; bool on = false; } nrm;
     int tune_norm_fold = 1;
+    int tune_qkv_fold = 1;                 // ... and a run of three matmuls, the apply_position calls over all heads of its first two outputs and the copies of its last two into cache
+                                           // rows (infer.rs:20-33) are ONE launch with the Wq|Wk|Wv epilogue (rotation, cache rows)
     int tune_resid_fold = 1;               // ... and a Device::array_add of a recorded matmul's output becomes that launch's residual epilogue
     int op_lead_next = 0;
     // ... and Device::sinu waits for the Device::array_mult on the same vector (infer.rs:44-45), one Device::copy_from_slice for the next (:32-33): one
@@ -236,7 +238,8 @@ static int set_device(rama_ctx* c) { HIPCHK(hipSetDevice(c->device)); return 0; 
 static int flush_rope(rama_ctx* c);
 static int flush_mm(rama_ctx* c);
 static int flush_ew(rama_ctx* c);
-static int flush_pending(rama_ctx* c) { int rf = flush_rope(c); if (!rf) rf = flush_mm(c); if (!rf) rf = flush_ew(c); return rf; }      // (flush_mm issues a recorded norm too)
+// (in the order they were recorded: a norm and the run of matmuls on it, the rotations of that run's q and k, a copy -- see rama_copy_from_slice)
+static int flush_pending(rama_ctx* c) { int rf = flush_mm(c); if (!rf) rf = flush_rope(c); if (!rf) rf = flush_ew(c); return rf; }      // (flush_mm issues a recorded norm too)
 #define RAMA_PENDING(c) ((c)->rope.count | (c)->mm.count | (c)->ew.kind | (int)(c)->nrm.on)
 #define RAMA_ENTER(c) do { if ((c) && RAMA_PENDING(c)) { const int rf_ = flush_pending(c); if (rf_) return rf_; } } while (0)
 
@@ -928,6 +931,39 @@ int rama_sinu(rama_ctx* c, float* o, size_t n) {
 }
 int rama_copy_from_slice(rama_ctx* c, float* t, const float* s, size_t n) {
     REQUIRE(c && (n == 0 || (t && s)), RAMA_EINVAL, "copy_from_slice: NULL argument");
+    // [r5] infer.rs:20-33 as the fused entry runs it: a pending run of three matmuls (a recorded norm in front, perhaps), every head of its first two outputs
+    // rotated, and now its second and third outputs copied into cache rows -- ONE launch with the Wq|Wk|Wv epilogue.  The first copy is recorded, the second
+    // issues the launch; anything that does not fit issues what is pending in program order.
+    if (c->mm.count == 3 && c->rope.count && c->tune_qkv_fold && c->tune_ref_order && n == (size_t)c->mm.rows && c->rope.count * c->rope.hs == c->mm.rows) {
+        const auto& m = c->mm;
+        const size_t hh = (size_t)c->rope.hs / 2;
+        auto apart = [&](const float* p0, size_t n0) {      // from everything the launch reads or writes besides
+            bool ok = !ranges_overlap(p0, n0, m.o[0], n) && !ranges_overlap(p0, n0, m.o[1], n) && !ranges_overlap(p0, n0, m.o[2], n) && !ranges_overlap(p0, n0, m.x, (size_t)m.K) &&
+                      !ranges_overlap(p0, n0, c->rope.pr, hh) && !ranges_overlap(p0, n0, c->rope.pi, hh);
+            if (ok && m.norm) ok = !ranges_overlap(p0, n0, c->nrm.x, (size_t)c->nrm.n) && !ranges_overlap(p0, n0, c->nrm.w, (size_t)c->nrm.n);
+            return ok;
+        };
+        if (!c->ew.kind && s == m.o[1] && aligned16(t) && apart(t, n) && c->tune_ew_batch) { c->ew.kind = 2; c->ew.t = t; c->ew.s = s; c->ew.n = n; return 0; }
+        if (c->ew.kind == 2 && c->ew.s == m.o[1] && c->ew.n == n && s == m.o[2] && aligned16(t) && apart(t, n) && !ranges_overlap(t, n, c->ew.t, n) &&
+            !ranges_overlap(c->rope.pr, hh, m.o[0], n) && !ranges_overlap(c->rope.pr, hh, m.o[1], n) && !ranges_overlap(c->rope.pr, hh, m.o[2], n) &&
+            !ranges_overlap(c->rope.pi, hh, m.o[0], n) && !ranges_overlap(c->rope.pi, hh, m.o[1], n) && !ranges_overlap(c->rope.pi, hh, m.o[2], n)) {
+            ChainParams p{};
+            for (int i = 0; i < 3; i++) { p.w[i] = m.w[i]; p.o[i] = m.o[i]; }
+            p.x = m.x; p.K = m.K; p.rows = m.rows; p.nmat = 3;
+            p.fr = c->rope.pr; p.fi = c->rope.pi; p.head_size = c->rope.hs; p.kc = c->ew.t; p.vc = t; p.pos_val = 0;      // (the table rows and cache rows of this position themselves)
+            const bool norm = m.norm;
+            c->mm.count = 0; c->mm.norm = false; c->rope.count = 0; c->ew.kind = 0;
+            if (!norm) return launch_chain<CEPI_QKV>(c, p);
+            c->nrm.on = false;
+            p.x = c->nrm.x; p.nw = c->nrm.w; p.xout = c->nrm.o;
+            p.lead = c->lead_slots + 32 * (kLeadSlots + c->op_lead_next); p.epoch = c->fused_epoch; p.err = c->pbar + 1;
+            const int rc = launch_chain<CEPI_QKV>(c, p, CNORM_LEAD);
+            if (rc) return rc;
+            if (++c->op_lead_next == kLeadSlots) { c->op_lead_next = 0; hipLaunchKernelGGL(fused_epoch_kernel, dim3(1), dim3(1), 0, c->stream, c->fused_epoch); LAUNCHCHK(); }
+            return 0;
+        }
+        { const int rf = flush_pending(c); if (rf) return rf; }
+    }
     if (c->ew.kind == 2 && !c->rope.count && !c->mm.count && n && !ranges_overlap(s, n, c->ew.t, c->ew.n) && !ranges_overlap(t, n, c->ew.t, c->ew.n) &&
         !ranges_overlap(t, n, c->ew.s, c->ew.n) && !ranges_overlap(t, n, s, n)) {      // the recorded copy and this one: one launch
         c->ew.kind = 0;
@@ -958,16 +994,20 @@ int rama_rmsnorm(rama_ctx* c, float* o, const float* x, const float* w, size_t n
 }
 int rama_apply_position(rama_ctx* c, float* q, float* k, const float* pr, const float* pi, size_t head_size) {
     REQUIRE(c && q && k && pr && pi && head_size >= 2, RAMA_EINVAL, "apply_position: bad argument");
-    { int rm = flush_mm(c); if (!rm) rm = flush_ew(c); if (rm) return rm; }      // (whatever was recorded before this call comes first)
+    // (whatever was recorded before this call comes first -- except a run of three matmuls whose first two outputs this call starts to rotate, or goes on rotating)
+    const bool on_run = c->mm.count == 3 && c->tune_qkv_fold && !c->ew.kind && c->tune_rope_batch && c->own_stream && head_size % 2 == 0 && c->mm.rows % (int)head_size == 0 &&
+                        (c->rope.count ? true : (q == c->mm.o[0] && k == c->mm.o[1]));
+    if (!on_run && (c->mm.count | c->ew.kind | (int)c->nrm.on)) { const int rm = flush_pending(c); if (rm) return rm; }      // (a run of rotations by itself goes on)
     if (c->tune_rope_batch && c->own_stream && head_size % 2 == 0 && head_size <= 4096) {
         auto& r = c->rope;
         const int hs = (int)head_size;
-        if (r.count && r.count < 4096 && hs == r.hs && pr == r.pr && pi == r.pi && q == r.q + (size_t)r.count * hs && k == r.k + (size_t)r.count * hs) { r.count++; return 0; }
-        const int rf = flush_rope(c); if (rf) return rf;
+        if (r.count && r.count < 4096 && hs == r.hs && pr == r.pr && pi == r.pi && q == r.q + (size_t)r.count * hs && k == r.k + (size_t)r.count * hs &&
+            (!c->mm.count || (r.count + 1) * hs <= c->mm.rows)) { r.count++; return 0; }
+        const int rf = flush_pending(c); if (rf) return rf;
         r.q = q; r.k = k; r.pr = pr; r.pi = pi; r.hs = hs; r.count = 1;
         return 0;
     }
-    { const int rf = flush_rope(c); if (rf) return rf; }
+    { const int rf = flush_pending(c); if (rf) return rf; }
     int n = (int)(head_size / 2);
     if (c->tune_ref_order) {
         hipLaunchKernelGGL(rope_ref_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, q, k, (const float*)nullptr, pr, pi, (int)head_size, (int)head_size,
@@ -978,7 +1018,7 @@ int rama_apply_position(rama_ctx* c, float* q, float* k, const float* pr, const 
     LAUNCHCHK(); return 0;
 }
 int rama_matmul(rama_ctx* c, float* o, const float* a, const float* b, size_t width, size_t o_rows, size_t o_cols) {
-    if (c && (c->rope.count | c->ew.kind)) { int rf = flush_rope(c); if (!rf) rf = flush_ew(c); if (rf) return rf; }      // (a pending run of matmuls may be extended by this call, a recorded norm taken along: below)
+    if (c && (c->rope.count | c->ew.kind)) { const int rf = flush_pending(c); if (rf) return rf; }      // (a pending run of matmuls may be extended by this call, a recorded norm taken along: below)
     REQUIRE(c && o && a && b, RAMA_EINVAL, "matmul: NULL argument");
     REQUIRE(o_cols >= 1, RAMA_EINVAL, "matmul: o_cols == 0");
     int rc = check_matvec_shape(width, o_rows);
@@ -1009,7 +1049,7 @@ int rama_matmul(rama_ctx* c, float* o, const float* a, const float* b, size_t wi
                         if (!takes_norm) { rc = flush_norm(c); if (rc) return rc; }
                     }
                     mmb.w[mmb.count] = ch; mmb.o[mmb.count] = o; mmb.count++;
-                    if (mmb.count == 3) return flush_mm(c);
+                    if (mmb.count == 3 && !(c->tune_qkv_fold && c->tune_rope_batch && c->tune_ew_batch)) return flush_mm(c);      // (else: the rotations and cache copies may follow)
                     return 0;
                 }
                 rc = flush_mm(c); if (rc) return rc;
@@ -2962,6 +3002,11 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
         c->tune_chain_awo = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
+        return 0;
+    }
+    if (!strcmp(key, "qkv_fold")) {
+        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: qkv_fold must be 0 or 1");
+        c->tune_qkv_fold = value;
         return 0;
     }
     if (!strcmp(key, "resid_fold")) {

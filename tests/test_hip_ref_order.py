@@ -591,6 +591,73 @@ def test_array_add_of_a_recorded_matmul_is_its_residual_epilogue(dev, K, rows):
     check(dev.lib.rama_set_tuning(dev.ctx, b"resid_fold", 1))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,heads", [(4096, 32), (288, 6), (512, 8)])
+def test_qkv_run_rotations_and_cache_copies_are_one_launch(dev, dim, heads):
+    """[r5] infer.rs:19-33 op by op -- rmsnorm, three matmuls, apply_position per head, two copies into cache rows -- is recorded and issued as ONE launch
+    with the Wq|Wk|Wv epilogue; the separate launches' bits ("qkv_fold" = 0) and the oracle's.  Sequences that stop short (fewer heads rotated, one
+    copy only, a copy of q) or touch the run's vectors in between are issued in program order."""
+    from rama_amd._lib import check
+    hs = dim // heads
+    x, g = rnd(dim, 111, 1.2), (rnd(dim, 112, 0.1) + np.float32(1.0)).astype(np.float32)
+    ws = [rnd(dim * dim, 113 + i, 0.04) for i in range(3)]
+    tws = [up(dev, w_) for w_ in ws]
+    tg = up(dev, g)
+    fr, fi = np.cos(np.arange(hs // 2, dtype=np.float32) * np.float32(0.37)).astype(np.float32), np.sin(np.arange(hs // 2, dtype=np.float32) * np.float32(0.37)).astype(np.float32)
+    tfr, tfi = up(dev, fr), up(dev, fi)
+    # the oracle
+    xb = np.empty(dim, np.float32); O.rmsnorm(xb, x, g, dim)
+    want = []
+    for i in range(3):
+        o_ = np.empty(dim, np.float32); O.matmul(o_, ws[i], xb, dim, dim); want.append(o_)
+    q_, k_ = want[0].copy(), want[1].copy()
+    for h in range(heads):
+        qh, kh = q_[h * hs:(h + 1) * hs], k_[h * hs:(h + 1) * hs]
+        O.apply_position(qh, kh, fr, fi, hs)
+
+    def run(n_rot, copies, poke=None):
+        tx, txb = up(dev, x), up(dev, np.zeros(dim, np.float32))
+        tq, tk, tv = (up(dev, np.zeros(dim, np.float32)) for _ in range(3))
+        cache = up(dev, np.zeros(4 * dim, np.float32))
+        dev.rmsnorm(txb, tx.as_view(), tg.as_view(), dim)
+        for t_, w_ in zip((tq, tk, tv), tws):
+            dev.matmul(t_, w_.as_view(), txb.as_view(), dim, dim, 1)
+        if poke == "download":
+            dev.download(tq)
+        for h in range(n_rot):
+            dev.apply_position(tq.mut_slice(h * hs, (h + 1) * hs), tk.mut_slice(h * hs, (h + 1) * hs), tfr.as_view(), tfi.as_view(), hs)
+        if poke == "add":
+            dev.array_add(tq, tv.as_view(), dim)
+        srcs = {"k": tk, "v": tv, "q": tq}
+        for j, name in enumerate(copies):
+            dev.copy_from_slice(cache.mut_slice((j + 1) * dim, (j + 2) * dim), srcs[name].as_view(), dim)
+        return [dev.download(t_) for t_ in (tq, tk, tv, cache, txb)]
+
+    for fold in (1, 0):
+        check(dev.lib.rama_set_tuning(dev.ctx, b"qkv_fold", fold))
+        got = run(heads, "kv")
+        assert_bits_equal(got[0], q_, f"fold {fold}: q"); assert_bits_equal(got[1], k_, f"fold {fold}: k"); assert_bits_equal(got[2], want[2], f"fold {fold}: v")
+        assert_bits_equal(got[3][dim:2 * dim], k_, f"fold {fold}: key row"); assert_bits_equal(got[3][2 * dim:3 * dim], want[2], f"fold {fold}: value row")
+        assert not got[3][:dim].any() and not got[3][3 * dim:].any(), f"fold {fold}: the cache around the two rows"
+        assert_bits_equal(got[4], xb, f"fold {fold}: the normalised vector")
+        # fewer heads rotated; one copy; a copy of q in front; something in between
+        got = run(heads - 1, "kv")
+        qp = want[0].copy(); qp[:(heads - 1) * hs] = q_[:(heads - 1) * hs]
+        kp = want[1].copy(); kp[:(heads - 1) * hs] = k_[:(heads - 1) * hs]
+        assert_bits_equal(got[0], qp, f"fold {fold}: q, one head not rotated"); assert_bits_equal(got[3][dim:2 * dim], kp, f"fold {fold}: key row, one head not rotated")
+        got = run(heads, "k")
+        assert_bits_equal(got[3][dim:2 * dim], k_, f"fold {fold}: one copy only"); assert_bits_equal(got[0], q_, f"fold {fold}: q, one copy only")
+        got = run(heads, "qkv")
+        assert_bits_equal(got[3][dim:2 * dim], q_, f"fold {fold}: q copied first"); assert_bits_equal(got[3][2 * dim:3 * dim], k_, f"fold {fold}: then k")
+        assert_bits_equal(got[3][3 * dim:], want[2], f"fold {fold}: then v")
+        got = run(heads, "kv", poke="download")
+        assert_bits_equal(got[3][dim:2 * dim], k_, f"fold {fold}: a download behind the matmuls")
+        got = run(heads, "kv", poke="add")
+        assert_bits_equal(got[0], (q_ + want[2]).astype(np.float32), f"fold {fold}: an add between rotations and copies")
+        assert_bits_equal(got[3][2 * dim:3 * dim], want[2], f"fold {fold}: value row behind it")
+    check(dev.lib.rama_set_tuning(dev.ctx, b"qkv_fold", 1))
+
+
 def _chain_lookup(dev, ptr, rows, K):
     f = dev.lib.rama_internal_chain_lookup
     f.restype = C.c_void_p
