@@ -1585,13 +1585,10 @@ __global__ __launch_bounds__(256, 2) void qkv_attn_chain_kernel(ChainParams p, R
 //   attn_values_chain_kernel   grid (heads x slices of 32 head columns): product tiles of 256 rows x 32 columns, the 32
 //                              chains of the slice add them in row order
 // Same operations in the same order per output as attention_chain_kernel: the same bits.
-__global__ __launch_bounds__(64) void attn_scores_chain_kernel(RefAttnParams p) {
+// one group of 64 timesteps of one head on ONE wave: stage = 64 x kAttStride floats, s_q = head_size floats of this wave's own; emit(t, score) for t <= pos
+template <class Emit>
+__device__ __forceinline__ void attn_scores_group(const RefAttnParams& p, int h, int g, int lane, int pos, float* stage, float* s_q, Emit emit) {
     RAMA_NO_CONTRACT
-    __shared__ __attribute__((aligned(16))) float stage[64 * kAttStride];
-    __shared__ __attribute__((aligned(16))) float s_q[256];
-    const int h = blockIdx.x, g = blockIdx.y, lane = threadIdx.x;
-    const int pos = p.ctl ? p.ctl->pos : p.pos_val;
-    if (g * 64 > pos) return;                                     // uniform
     const int hs = p.head_size, npiece = hs / kAttPiece;
     const size_t col = (size_t)h * hs;
     const int lrow = lane >> 3, lc4 = lane & 7;
@@ -1647,7 +1644,16 @@ __global__ __launch_bounds__(64) void attn_scores_chain_kernel(RefAttnParams p) 
         }
     }
     const int t = g * 64 + lane;
-    if (t <= pos) p.sc[(size_t)h * p.seq_len + t] = acc / scale_div;
+    if (t <= pos) emit(t, acc / scale_div);
+}
+__global__ __launch_bounds__(64) void attn_scores_chain_kernel(RefAttnParams p) {
+    __shared__ __attribute__((aligned(16))) float stage[64 * kAttStride];
+    __shared__ __attribute__((aligned(16))) float s_q[256];
+    const int h = blockIdx.x, g = blockIdx.y, lane = threadIdx.x;
+    const int pos = p.ctl ? p.ctl->pos : p.pos_val;
+    if (g * 64 > pos) return;                                     // uniform
+    float* out = p.sc + (size_t)h * p.seq_len;
+    attn_scores_group(p, h, g, lane, pos, stage, s_q, [&](int t, float v) { out[t] = v; });
 }
 
 constexpr int kSoftWaves = 4;
@@ -1783,7 +1789,14 @@ constexpr int kFvRows = 192, kFvStride = kFvRows + 4, kFvWaves = 4;
 #endif
 constexpr int kFvSoftWaves = RAMA_FV_SOFT;        // [r5] waves of the softmax phase (waves kFvWaves.. leave after it): its loops are a few elements per thread, each with its latency in full
 __host__ __device__ constexpr size_t attn_fused_values_lds_floats(int seq_len) { return (size_t)seq_len + ((size_t)seq_len >> 5) + 4 + (((size_t)seq_len + 3) & ~(size_t)3); }
-__global__ __launch_bounds__(kFvSoftWaves * 64) void attn_softmax_values_chain_kernel(RefAttnParams p) {
+// MERGED ([r5] attn_spread_chain_kernel): the scores too -- waves kFvWaves.. of slice workgroup sl take the groups of 64 timesteps sl NSW + w of the head
+// (NSW = kFvSoftWaves - kFvWaves; host: seq_len <= 64 x slices x NSW and <= 2 048), store them write-through and then tag the group's word of this layer; the
+// chain wave of every slice workgroup of the head polls the head's words (bounded; the error word), then every thread reads its positions' scores (sc1).  All workgroups of the launch must be resident at once (host:
+// heads x slices <= compute units, one workgroup per CU by its LDS): a workgroup waits for words that EVERY slice workgroup of its head writes.
+constexpr int kFvScoreWaves = kFvSoftWaves - kFvWaves;
+__host__ __device__ constexpr size_t attn_spread_extra_lds_floats() { return (size_t)kFvScoreWaves * (64 * kAttStride + 256); }
+template <bool MERGED>
+__device__ __forceinline__ void attn_softmax_values_chain_body(RefAttnParams p) {
     RAMA_NO_CONTRACT
     constexpr int TS = kFvSoftWaves * 64;                          // softmax: all waves
     constexpr int T = (kFvWaves - 1) * 64, U = kFvRows * (kValCols / 4) / T;      // products: 4 x 16 bytes per loading thread and tile
@@ -1810,14 +1823,6 @@ __global__ __launch_bounds__(kFvSoftWaves * 64) void attn_softmax_values_chain_k
     // rows included: 2.1 us in front of the first barrier.  The scores are one round trip of 0.4 us, and the rows are not needed for 5 us)
     constexpr int kSc = 2048 / TS;                                 // scores per thread in flight at once (2 048 positions; a loop for the rest)
     float sc[kSc];
-#pragma unroll
-    for (int k = 0; k < kSc; k++) sc[k] = scores[min(tid0 + k * TS, pos)];
-    SEQ_STAMP(40);
-    // softmax_num (cpu.rs:187-192), as attn_softmax_chain_kernel
-    float mx = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < kSc; k++) { const int t = tid0 + k * TS; if (t <= pos) { s_att[scan_slot(t)] = sc[k]; mx = fmaxf(mx, sc[k]); } }
-    for (int t = tid0 + kSc * TS; t <= pos; t += TS) { const float a = scores[t]; s_att[scan_slot(t)] = a; mx = fmaxf(mx, a); }
     f4 v0[U], v1[U], v2[U], v3[U];
     auto vissue = [&](int t0, f4 (&vr)[U]) {
 #pragma unroll
@@ -1827,7 +1832,49 @@ __global__ __launch_bounds__(kFvSoftWaves * 64) void attn_softmax_values_chain_k
             vr[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.vc + (size_t)tr * p.dim + col) + c4);
         }
     };
-    if (!chain && tid < T) { vissue(0, v0); vissue(kFvRows, v1); vissue(2 * kFvRows, v2); vissue(3 * kFvRows, v3); }     // uniform per wave
+    if constexpr (MERGED) {
+        // (the value rows first: they are on their way while the scores are formed; a loading wave's first look at the words then waits for them -- 2 us,
+        // about what the scores take)
+        if (!chain && tid < T) { vissue(0, v0); vissue(kFvRows, v1); vissue(2 * kFvRows, v2); vissue(3 * kFvRows, v3); }
+        const unsigned ep = *p.epoch;
+        unsigned long long* flags = p.sc_tags + (size_t)h * p.seq_len;      // one word per group of 64 timesteps (the first seq_len / 64 of the head's stretch)
+        float* sco = p.sc + (size_t)h * p.seq_len;
+        const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+        if (wv >= kFvWaves) {                                      // (uniform per wave) the scores of one group: write-through, drained, then the group's word
+            const int wq = wv - kFvWaves, g = sl * kFvScoreWaves + wq;
+            float* s_qw = fv_sm + attn_fused_values_lds_floats(p.seq_len) + (size_t)wq * (64 * kAttStride + 256);
+            if (g * 64 <= pos) {
+                attn_scores_group(p, h, g, (int)threadIdx.x & 63, pos, s_qw + 256, s_qw, [&](int t, float v) { st_sc1(sco + t, v); });
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if ((threadIdx.x & 63) == 0) put_tagged(flags + g, 1.0f, ep);
+            }
+        } else if (wv == 0) {                                      // the chain wave has nothing to do yet: it watches the head's words (lane g: group g), bounded
+            const int ng = (pos >> 6) + 1, lane = threadIdx.x;
+            long spins = 0;
+            while (true) {
+                unsigned long long wd = (unsigned long long)ep << 32;
+                if (lane < ng) wd = __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__builtin_amdgcn_ballot_w64((unsigned)(wd >> 32) == ep) == ~0ull) break;
+                __builtin_amdgcn_s_sleep(2);
+                ++spins;
+                if ((spins & 255) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                if (spins > (1L << 22)) { if (lane == 0) __hip_atomic_store(p.err, kWaitErr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kSc; k++) sc[k] = ld_sc1(sco + min(tid0 + k * TS, pos));
+    } else {
+#pragma unroll
+        for (int k = 0; k < kSc; k++) sc[k] = scores[min(tid0 + k * TS, pos)];
+    }
+    SEQ_STAMP(40);
+    // softmax_num (cpu.rs:187-192), as attn_softmax_chain_kernel
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < kSc; k++) { const int t = tid0 + k * TS; if (t <= pos) { s_att[scan_slot(t)] = sc[k]; mx = fmaxf(mx, sc[k]); } }
+    if constexpr (!MERGED) { for (int t = tid0 + kSc * TS; t <= pos; t += TS) { const float a = scores[t]; s_att[scan_slot(t)] = a; mx = fmaxf(mx, a); } }
+    if constexpr (!MERGED) { if (!chain && tid < T) { vissue(0, v0); vissue(kFvRows, v1); vissue(2 * kFvRows, v2); vissue(3 * kFvRows, v3); } }     // uniform per wave
     SEQ_STAMP(41);
     mx = block_max(mx, red);
     SEQ_STAMP(42);
@@ -1974,5 +2021,8 @@ __global__ __launch_bounds__(kFvSoftWaves * 64) void attn_softmax_values_chain_k
         if (t0 + 3 * kFvRows <= pos) vtile(t0 + 3 * kFvRows, 1, v3);
     }
 }
+
+__global__ __launch_bounds__(kFvSoftWaves * 64) void attn_softmax_values_chain_kernel(RefAttnParams p) { attn_softmax_values_chain_body<false>(p); }
+__global__ __launch_bounds__(kFvSoftWaves * 64) void attn_spread_chain_kernel(RefAttnParams p) { attn_softmax_values_chain_body<true>(p); }
 
 }  // namespace rama

@@ -129,6 +129,9 @@ struct rama_ctx {
     float* topp_approx = nullptr;           // ... the mass in front of every entry of the whole order
     void* topp_dist = nullptr;              // topp_pick_dist_kernel's hand-off words: items | hdr | cross | epoch | bad
     int tune_spread_pos = kSpreadAttnPos;   // parity mode: from this position on the attention is spread over the chip (scores | softmax + values)
+    int tune_attn_merge = 0;                // ... and the scores with them: ONE launch (chain.hpp attn_spread_chain_kernel; opt-in: measured 5-10 us SLOWER, profiles/r05_experiments.md 12)
+    unsigned long long* attn_tags = nullptr;      // device: [layers][n_heads][seq_len] (score, epoch) words of the one-launch form
+    size_t attn_tags_words = 0;
     int tune_attn_fv = 1;                   // parity mode, long contexts: softmax + value chains as one launch (0: two launches)
     int tune_topp_dist = 1;                 // 1: the running sums by up to 32 workgroups in one launch (topp_pick.hpp); 0: one workgroup's scan rounds
     ToppStats* topp_stats = nullptr;        // small-block path: partial softmax statistics, one per 1024 logits
@@ -338,6 +341,7 @@ int rama_ctx_create(int device, void* hip_stream, rama_ctx** out) {
     HIPCHK(hipFuncSetAttribute((const void*)attention_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnChainMaxLds));
     HIPCHK(hipFuncSetAttribute((const void*)attention_chain_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnChainMaxLds));
     HIPCHK(hipFuncSetAttribute((const void*)attention_chain_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnChainMaxLds));
+    HIPCHK(hipFuncSetAttribute((const void*)attn_spread_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
 #define RAMA_CF_ATTR(DK_, DH_, F_) HIPCHK(hipFuncSetAttribute((const void*)stage_chain_fused_kernel<DK_, DH_, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainFusedMaxLds))
     RAMA_CF_ATTR(16, 16, true); RAMA_CF_ATTR(16, 16, false);
 #undef RAMA_CF_ATTR
@@ -381,7 +385,7 @@ int rama_ctx_destroy(rama_ctx* c) {
     hipStreamSynchronize(c->stream);
     drop_graph(c);
     for (auto e : c->kp.ev) hipEventDestroy(e);
-    hipFree(c->ctl); hipFree(c->out); hipFree(c->forced); hipFree(c->argmax_result); hipFree(c->pbar); hipFree(c->attn_counter); hipFree(c->attn_part); hipFree(c->attn_scores); hipFree(c->fused_hand); hipFree(c->fused_epoch); hipFree(c->lead_slots); hipFree(c->awo_flags); hipFree(c->qa_flags);
+    hipFree(c->ctl); hipFree(c->out); hipFree(c->forced); hipFree(c->argmax_result); hipFree(c->pbar); hipFree(c->attn_counter); hipFree(c->attn_part); hipFree(c->attn_scores); hipFree(c->attn_tags); hipFree(c->fused_hand); hipFree(c->fused_epoch); hipFree(c->lead_slots); hipFree(c->awo_flags); hipFree(c->qa_flags);
     for (int i = 0; i < 2; i++) { hipFree(c->topp_keys[i]); hipFree(c->topp_vals[i]); }
     hipFree(c->topp_prefix); hipFree(c->topp_m); hipFree(c->topp_err); hipFree(c->pf_blob); hipFree(c->pc_blob); if (c->ring) hipHostFree(c->ring);
     hipFree(c->topp_bp); hipFree(c->topp_bi); hipFree(c->topp_bcount); hipFree(c->topp_racc);
@@ -780,9 +784,26 @@ static int ensure_attn_scores(rama_ctx* c, int n_heads, int seq_len) {
     return 0;
 }
 
+// the (score, epoch) words of the one-launch spread attention, a region per layer; nothing is allocated inside a stream capture (the caller then keeps two launches)
+static int ensure_attn_tags(rama_ctx* c, int layers, int n_heads, int seq_len) {
+    const size_t need = (size_t)layers * (size_t)n_heads * (size_t)seq_len;
+    if (need <= c->attn_tags_words) return 0;
+    if (need * sizeof(unsigned long long) > ((size_t)256 << 20)) return 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(c->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return 0; }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->attn_tags) { HIPCHK(hipFree(c->attn_tags)); c->attn_tags = nullptr; c->attn_tags_words = 0; }
+    HIPCHK(hipMalloc(&c->attn_tags, need * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(c->attn_tags, 0, need * sizeof(unsigned long long)));      // (tag 0: no epoch)
+    c->attn_tags_words = need;
+    drop_graph(c);
+    return 0;
+}
 // long_ctx: 8 waves per head (twice the timesteps per score round, twice the loaders of the value tiles) -- from position 256 on
+// tags: this layer's region of rama_ctx::attn_tags, or nullptr (*merged_used: the one-launch form ran, the epoch must advance behind the stage)
 static int launch_attention_chain(rama_ctx* c, float* xb, float* att, const float* q, const float* kc_layer, const float* vc_layer,
-                                  const Ctl* ctl, int pos, int dim, int head_size, int seq_len, int n_heads, bool long_ctx = false, bool spread_wanted = false) {
+                                  const Ctl* ctl, int pos, int dim, int head_size, int seq_len, int n_heads, bool long_ctx = false, bool spread_wanted = false,
+                                  unsigned long long* tags = nullptr, bool* merged_used = nullptr) {
     // spread: the three-launch form for long contexts; it needs whole staged pieces and 32-column slices, a score
     // buffer that fits the softmax kernel's LDS, and the att buffer
     const bool spread = spread_wanted && att && head_size % kAttPiece == 0 && head_size % kValCols == 0 && head_size <= 256 &&
@@ -806,6 +827,20 @@ static int launch_attention_chain(rama_ctx* c, float* xb, float* att, const floa
         p.sc = fv ? c->attn_scores : att;
         hipEvent_t ev_start = c->cur_start, ev_stop = c->cur_start ? c->cur_stop : nullptr;
         c->cur_start = nullptr;
+        // [r5] ONE launch: every slice workgroup also forms its share of the head's scores (chain.hpp).  A workgroup waits for words of its head's other
+        // slice workgroups: all of the launch must be resident at once -- one workgroup per CU (its LDS), so no more workgroups than CUs
+        const int slices = head_size / kValCols;
+        if (fv && tags && merged_used && c->tune_attn_merge && c->pbar && seq_len <= 2048 && seq_len <= 64 * slices * kFvScoreWaves && head_size <= 256 &&
+            n_heads * slices <= std::max(c->cu_count, 1) && c->kp.kernel_id < 0) {
+            p.sc_tags = tags; p.epoch = c->fused_epoch; p.err = c->pbar + 1;
+            const size_t lds = fv_lds + attn_spread_extra_lds_floats() * sizeof(float);
+            if (ev_start || ev_stop) hipExtLaunchKernelGGL(attn_spread_chain_kernel, dim3(n_heads, slices), dim3(kFvSoftWaves * 64), lds, c->stream, ev_start, ev_stop, 0, p);
+            else hipLaunchKernelGGL(attn_spread_chain_kernel, dim3(n_heads, slices), dim3(kFvSoftWaves * 64), lds, c->stream, p);
+            LAUNCHCHK();
+            c->handoff_dirty = true;
+            *merged_used = true;
+            return 0;
+        }
         if (ev_start) hipExtLaunchKernelGGL(attn_scores_chain_kernel, dim3(n_heads, ngroups), dim3(64), 0, c->stream, ev_start, nullptr, 0, p);
         else hipLaunchKernelGGL(attn_scores_chain_kernel, dim3(n_heads, ngroups), dim3(64), 0, c->stream, p);
         LAUNCHCHK();
@@ -1100,6 +1135,7 @@ static int ensure_attn_part(rama_ctx* c, const rama_config* cfg) {
         c->attn_part_floats = need;
     }
     if (c->tune_ref_order) { const int rs = ensure_attn_scores(c, cfg->n_heads, cfg->seq_len); if (rs) return rs; }
+    if (c->tune_ref_order && c->tune_attn_merge && cfg->seq_len <= 2048) { const int rs = ensure_attn_tags(c, cfg->n_layers, cfg->n_heads, cfg->seq_len); if (rs) return rs; }
     return 0;
 }
 
@@ -1597,7 +1633,16 @@ static int enqueue_stage_chain(rama_ctx* c, const rama_config* cfg, const rama_w
         if (!awo && !qa) {   // :34
             KTimer kt(c, RAMA_K_ATTN);
             if (tol && !(mask & 32)) rc = launch_attention(c, s->xb, s->att, s->q, kc, vc, c->ctl, 0, dim, hs, cfg->seq_len, cfg->n_heads, c->split_attn);
-            else rc = launch_attention_chain(c, s->xb, s->att, s->q, kc, vc, c->ctl, 0, dim, hs, cfg->seq_len, cfg->n_heads, c->long_attn, c->spread_attn);
+            else {
+                unsigned long long* tags = nullptr;
+                if (c->spread_attn && c->tune_attn_merge && !tol) {
+                    rc = ensure_attn_tags(c, cfg->n_layers, cfg->n_heads, cfg->seq_len); if (rc) return rc;
+                    if (c->attn_tags_words >= (size_t)cfg->n_layers * cfg->n_heads * cfg->seq_len) tags = c->attn_tags + li * (size_t)cfg->n_heads * cfg->seq_len;
+                }
+                bool mg = false;
+                rc = launch_attention_chain(c, s->xb, s->att, s->q, kc, vc, c->ctl, 0, dim, hs, cfg->seq_len, cfg->n_heads, c->long_attn, c->spread_attn, tags, &mg);
+                led = led || mg;
+            }
             if (rc) return rc;
         }
         if (awo) { }
@@ -3136,6 +3181,13 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
     if (!strcmp(key, "spread_pos")) {
         REQUIRE(value >= 64 && value <= (1 << 20), RAMA_EINVAL, "set_tuning: spread_pos must be 64 .. 2^20");
         c->tune_spread_pos = value;
+        hipStreamSynchronize(c->stream);
+        drop_graph(c);
+        return 0;
+    }
+    if (!strcmp(key, "attn_merge")) {
+        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: attn_merge must be 0 or 1");
+        c->tune_attn_merge = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
         return 0;

@@ -763,6 +763,7 @@ def test_model_long_context_bit_exact(dev, n_heads, hs):
     # forms it replaced stay selectable: "attn_fv" = 0 (softmax and value chains as two launches), "spread_pos" (one workgroup per
     # head below it: 4 waves, 8 from position 256 on)
     variants = [({}, (100, 127, 128, 129, 191, 192, 193, 255, 256, 257, 383, 384, 385, 1000, 1023, 1024, 1025, 2047)),
+                ({"attn_merge": 1}, (128, 129, 200, 255, 256, 1000, 1024, 1900, 2047)),      # [r5] scores + softmax + values as ONE launch (opt-in: slower)
                 ({"attn_fv": 0}, (128, 200, 1024, 2047)),
                 ({"spread_pos": 1024}, (255, 256, 257, 1000, 1023, 1024, 1025)),
                 ({"spread_pos": 1 << 20}, (1500, 2047))]
@@ -782,10 +783,10 @@ def test_model_long_context_bit_exact(dev, n_heads, hs):
                     att = eng.buffer("att", n_heads * seq).reshape(n_heads, seq)[:, :pos + 1]
                     assert_bits_equal(att, orc.s["att"].reshape(n_heads, seq)[:, :pos + 1], f"long context pos {pos} att {tune}")
             eng.set_graph_mode(False)
-            eng.set_tuning("attn_fv", 1); eng.set_tuning("spread_pos", 128)
+            eng.set_tuning("attn_fv", 1); eng.set_tuning("spread_pos", 128); eng.set_tuning("attn_merge", 0)
     finally:
         eng.set_graph_mode(False)
-        eng.set_tuning("attn_fv", 1); eng.set_tuning("spread_pos", 128)
+        eng.set_tuning("attn_fv", 1); eng.set_tuning("spread_pos", 128); eng.set_tuning("attn_merge", 0)
     eng.free(); model.free()
 
 
