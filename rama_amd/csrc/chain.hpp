@@ -628,32 +628,40 @@ __device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in)
     const int j = lane & 3, rr = lane >> 2;
     const int groups = (p.rows + 15) >> 4;
     if constexpr (NORM == CNORM_LEAD) {
-        if (bid_in == 0) {      // the leader: thread t holds x[t LR .. t LR + LR) (zeros behind K: the descriptor's range check)
-            FastSumShared<WL>& fs = *reinterpret_cast<FastSumShared<WL>*>(xs);        // (host: the dynamic LDS holds it)
+        if (bid_in == 0) {      // the leader: thread t holds x[t LD .. t LD + LD) (zeros behind K: the descriptor's range check)
+            // [r5] on ONE wave wherever a wave holds the whole vector (LR WL <= 64: llama2-7B's Wq|Wk|Wv launch, two waves per row group): the sum's phases
+            // then need no barrier, and the word is out ~2 us earlier (8.3 -> 6 us after the leader's start)
+#ifndef RAMA_LEAD_SOLO
+#define RAMA_LEAD_SOLO 1
+#endif
+            constexpr bool SOLO = RAMA_LEAD_SOLO && WL > 1 && LR * WL <= 64;
+            constexpr int WD = SOLO ? 1 : WL, LD = SOLO ? LR * WL : LR;
+            if (SOLO && wave_all != 0) return;
+            FastSumShared<WD>& fs = *reinterpret_cast<FastSumShared<WD>*>(xs);        // (host: the dynamic LDS holds it)
 #ifdef RAMA_CHAIN_STAMPS
             if (threadIdx.x == 0) g_chain_stamps[40] = __builtin_amdgcn_s_memrealtime();
 #endif
             const unsigned ep = *p.epoch;
             const __amdgpu_buffer_rsrc_t rxl = make_rsrc_uniform(p.x, (unsigned)p.K * 4u);
-            seq_sum_fast_prepare<WL>(fs);
-            float a[LR];
+            seq_sum_fast_prepare<WD>(fs);
+            float a[LD];
 #pragma unroll
-            for (int u = 0; u < LR / 4; u++) {
-                const f4 xv = ld_c(rxl, ((unsigned)threadIdx.x * (unsigned)LR + 4u * (unsigned)u) * 4u);
+            for (int u = 0; u < LD / 4; u++) {
+                const f4 xv = ld_c(rxl, ((unsigned)threadIdx.x * (unsigned)LD + 4u * (unsigned)u) * 4u);
                 a[4 * u] = xv.x * xv.x; a[4 * u + 1] = xv.y * xv.y; a[4 * u + 2] = xv.z * xv.z; a[4 * u + 3] = xv.w * xv.w;
             }
 #ifdef RAMA_CHAIN_STAMPS
             { float t_ = 0.0f;
 #pragma unroll
-              for (int k = 0; k < LR; k++) t_ += a[k];
+              for (int k = 0; k < LD; k++) t_ += a[k];
               asm volatile("" :: "v"(t_)); }
             if (threadIdx.x == 0) g_chain_stamps[41] = __builtin_amdgcn_s_memrealtime();
 #endif
             float ss;
-            if (!seq_sum_fast<WL, LR>(a, fs, &ss)) {      // (uniform) the prediction did not hold: the plain loop over the squares
+            if (!seq_sum_fast<WD, LD>(a, fs, &ss)) {      // (uniform) the prediction did not hold: the plain loop over the squares
                 __syncthreads();
 #pragma unroll
-                for (int k = 0; k < LR; k++) { const int i = (int)threadIdx.x * LR + k; if (i < p.K) xs[i] = a[k]; }
+                for (int k = 0; k < LD; k++) { const int i = (int)threadIdx.x * LD + k; if (i < p.K) xs[i] = a[k]; }
                 __syncthreads();
                 if (threadIdx.x == 0) { float s_ = 0.0f; for (int i = 0; i < p.K; i++) s_ = s_ + xs[i]; xs[p.K] = s_; }
                 __syncthreads();
@@ -665,7 +673,7 @@ __device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in)
             if (threadIdx.x == 0) g_chain_stamps[42] = __builtin_amdgcn_s_memrealtime();
 #endif
             if (p.xout) {      // cpu.rs:113-116 o[i] = w[i] * (v * x[i]), as the row groups form it for themselves
-                for (int i = threadIdx.x; i < p.K; i += WL * 64) p.xout[i] = p.nw[i] * (v * p.x[i]);
+                for (int i = threadIdx.x; i < p.K; i += WD * 64) p.xout[i] = p.nw[i] * (v * p.x[i]);
             }
             return;
         }
