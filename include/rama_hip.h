@@ -440,7 +440,20 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *   "matmul_batch" = 0|1, "ew_batch" = 0|1 : [r5] likewise up to three parity-mode rama_matmul calls with the same activations and shape
  *                   (infer.rs:20-23, :41-42), rama_sinu + the rama_array_mult on the same vector (:44-45) and two rama_copy_from_slice
  *                   calls in a row (:32-33): recorded, issued as one launch by the next entry into the library, program order kept at
- *                   every overlap (172 -> 185 tok/s; default 1) */
+ *                   every overlap (172 -> 185 tok/s; default 1)
+ *   "norm_fold" = 0|1 : [r5] a parity-mode rama_rmsnorm (dim <= 4096, not in place) is recorded; the run of rama_matmul calls on its output carries it
+ *                   as the launch's LEADER workgroup (the exact sum while the row groups' weights are already on their way), which also stores the
+ *                   normalised vector; anything else issues it as a launch of its own first (the 1:1 path 189 -> 195 tok/s; default 1)
+ *   "resid_fold" = 0|1 : [r5] rama_array_add of a recorded rama_matmul's output (infer.rs:35-37, :46-47) becomes that launch's residual epilogue
+ *                   (195 -> 202 tok/s; default 1)
+ *   "qkv_fold" = 0|1 : [r5] a run of three rama_matmul calls, rama_apply_position over every head of its first two outputs and the rama_copy_from_slice
+ *                   of its last two outputs into cache rows (infer.rs:20-33) are ONE launch with the Wq|Wk|Wv epilogue; a sequence that stops short or
+ *                   touches the run's vectors in between is issued in program order (202 -> 203 tok/s from a Python host, which then is the limit; default 1)
+ *   "chain_split" = 0|1 : [r5] parity matvecs on one wave per row group whose row groups do not divide by the compute units: the remainder as HALF groups
+ *                   (8 rows on 32 lanes), so that no CU carries a whole group more than the others (llama2-7B W1|W3: 1 376 groups on 256 CUs, 59.9 -> 59.0 us;
+ *                   default 1)
+ *   "attn_merge" = 0|1 : [r5] parity mode's long-context attention (scores | softmax + value chains) as ONE launch.  Bit-identical, measured 5-10 us SLOWER
+ *                   per layer (profiles/r05_experiments.md 12): default 0 */
 int  rama_set_tuning(rama_ctx *ctx, const char *key, int value);
 
 /* glibc 2.35 expf (the exp the reference's f32::exp calls on Linux) as the reference-order kernels
