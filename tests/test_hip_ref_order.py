@@ -658,6 +658,29 @@ def test_qkv_run_rotations_and_cache_copies_are_one_launch(dev, dim, heads):
     check(dev.lib.rama_set_tuning(dev.ctx, b"qkv_fold", 1))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,rows", [(128, 4741), (256, 4096 + 16 * 100), (512, 16 * 257), (64, 16 * 300 + 9)])
+def test_half_row_groups_bit_exact(dev, K, rows):
+    """[r5] one wave per row group and a number of row groups that does not divide by the compute units: the remainder runs as half groups (8 rows on 32
+    lanes; "chain_split").  The oracle's bits with and without, a last group of fewer than 16 (or 8) rows included."""
+    from rama_amd._lib import check
+    w, x = rnd(rows * K, 121, 0.1), rnd(K, 122)
+    tw, tx = up(dev, w), up(dev, x)
+    want = np.empty(rows, np.float32); O.matmul(want, w, x, K, rows)
+    for split in (1, 0):
+        check(dev.lib.rama_set_tuning(dev.ctx, b"chain_split", split))
+        to = up(dev, np.full(rows + 32, 7.0, np.float32))
+        dev.matmul(rama_view(to, 0, rows), tw.as_view(), tx.as_view(), K, rows, 1)
+        got = dev.download(to)
+        assert_bits_equal(got[:rows], want, f"split {split}")
+        assert (got[rows:] == 7.0).all(), f"split {split}: floats behind the output were written"
+    check(dev.lib.rama_set_tuning(dev.ctx, b"chain_split", 1))
+
+
+def rama_view(t, a, b):
+    return t.mut_slice(a, b)
+
+
 def _chain_lookup(dev, ptr, rows, K):
     f = dev.lib.rama_internal_chain_lookup
     f.restype = C.c_void_p
