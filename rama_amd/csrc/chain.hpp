@@ -1802,6 +1802,7 @@ __host__ __device__ constexpr size_t attn_fused_values_lds_floats(int seq_len) {
 // chain wave of every slice workgroup of the head polls the head's words (bounded; the error word), then every thread reads its positions' scores (sc1).  All workgroups of the launch must be resident at once (host:
 // heads x slices <= compute units, one workgroup per CU by its LDS): a workgroup waits for words that EVERY slice workgroup of its head writes.
 constexpr int kFvScoreWaves = kFvSoftWaves - kFvWaves;
+static_assert(kFvSoftWaves >= kFvWaves && kFvSoftWaves <= 8, "the value chain's assembly names v200..v247: at most 8 waves per workgroup (256 VGPRs a wave)");
 __host__ __device__ constexpr size_t attn_spread_extra_lds_floats() { return (size_t)kFvScoreWaves * (64 * kAttStride + 256); }
 template <bool MERGED>
 __device__ __forceinline__ void attn_softmax_values_chain_body(RefAttnParams p) {

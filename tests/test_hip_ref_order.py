@@ -681,6 +681,94 @@ def rama_view(t, a, b):
     return t.mut_slice(a, b)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
+def test_recorded_ops_random_sequences(dev, seed):
+    """[r5] the library records parity-mode ops and issues them merged (runs of rotations and matmuls, a norm as the matmuls' leader, an add as the matmul's
+    residual epilogue, Wq|Wk|Wv + rotations + cache copies as one launch).  Random sequences of the trait's ops over a small pool of vectors -- with the
+    reference's own sequence (infer.rs:19-47) mixed in whole and cut short -- must leave every vector bit for bit as with all recording off."""
+    from rama_amd._lib import check
+    rng = np.random.default_rng(seed)
+    dim, heads = 256, 4
+    hs = dim // heads
+    npool = 7
+    init = [rnd(dim, 200 + i) for i in range(npool)]
+    mats = [up(dev, rnd(dim * dim, 300 + i, 0.06)) for i in range(5)]
+    gains = [up(dev, (rnd(dim, 310 + i, 0.1) + np.float32(1.0)).astype(np.float32)) for i in range(2)]
+    tfr = up(dev, np.cos(np.arange(hs // 2, dtype=np.float32) * np.float32(0.3)).astype(np.float32))
+    tfi = up(dev, np.sin(np.arange(hs // 2, dtype=np.float32) * np.float32(0.3)).astype(np.float32))
+    # the program: a list of closures over (pool, cache)
+    prog = []
+    def two(distinct=True):
+        a = int(rng.integers(npool)); b = int(rng.integers(npool))
+        while distinct and b == a:
+            b = int(rng.integers(npool))
+        return a, b
+    def layer_like(cut):
+        x, xb, q, k, v, xb2 = (int(i) for i in rng.permutation(npool)[:6])
+        row = int(rng.integers(3))
+        ops = [("rmsnorm", xb, x, 0), ("matmul", q, 0, xb), ("matmul", k, 1, xb), ("matmul", v, 2, xb)]
+        ops += [("rope", q, k, h) for h in range(heads)]
+        ops += [("tocache", row, k), ("tocache", row + 3, v), ("matmul", xb2, 3, q), ("add", x, xb2), ("rmsnorm", xb, x, 1), ("matmul", q, 4, xb), ("matmul", k, 0, xb),
+                ("sinu", q), ("mult", q, k), ("matmul", xb2, 1, q), ("add", x, xb2)]
+        return ops[:cut]
+    while len(prog) < 260:
+        r = rng.random()
+        if r < 0.25:
+            prog += layer_like(int(rng.integers(1, 24)))
+        elif r < 0.40:
+            a, b = two(); prog.append(("matmul", a, int(rng.integers(5)), b))
+        elif r < 0.50:
+            a, b = two(distinct=rng.random() < 0.8); prog.append(("rmsnorm", a, b, int(rng.integers(2))))
+        elif r < 0.60:
+            a, b = two(); prog.append(("add", a, b))
+        elif r < 0.68:
+            a, b = two(); prog.append(("mult", a, b))
+        elif r < 0.74:
+            prog.append(("sinu", int(rng.integers(npool))))
+        elif r < 0.82:
+            a, b = two(); prog.append(("copy", a, b))
+        elif r < 0.90:
+            a, b = two(); prog.append(("rope", a, b, int(rng.integers(heads))))
+        elif r < 0.96:
+            prog.append(("tocache", int(rng.integers(6)), int(rng.integers(npool))))
+        else:
+            prog.append(("fromcache", int(rng.integers(npool)), int(rng.integers(6))))
+    keys = (b"rope_batch", b"matmul_batch", b"ew_batch", b"norm_fold", b"resid_fold", b"qkv_fold")
+    results = {}
+    for on in (1, 0):
+        for key in keys:
+            check(dev.lib.rama_set_tuning(dev.ctx, key, on))
+        pool = [up(dev, a) for a in init]
+        cache = up(dev, np.zeros(6 * dim, np.float32))
+        for op in prog:
+            if op[0] == "matmul":
+                dev.matmul(pool[op[1]], mats[op[2]].as_view(), pool[op[3]].as_view(), dim, dim, 1)
+            elif op[0] == "rmsnorm":
+                dev.rmsnorm(pool[op[1]], pool[op[2]].as_view(), gains[op[3]].as_view(), dim)
+            elif op[0] == "add":
+                dev.array_add(pool[op[1]], pool[op[2]].as_view(), dim)
+            elif op[0] == "mult":
+                dev.array_mult(pool[op[1]], pool[op[2]].as_view(), dim)
+            elif op[0] == "sinu":
+                dev.sinu(pool[op[1]], dim)
+            elif op[0] == "copy":
+                dev.copy_from_slice(pool[op[1]], pool[op[2]].as_view(), dim)
+            elif op[0] == "rope":
+                h = op[3]
+                dev.apply_position(pool[op[1]].mut_slice(h * hs, (h + 1) * hs), pool[op[2]].mut_slice(h * hs, (h + 1) * hs), tfr.as_view(), tfi.as_view(), hs)
+            elif op[0] == "tocache":
+                dev.copy_from_slice(cache.mut_slice(op[1] * dim, (op[1] + 1) * dim), pool[op[2]].as_view(), dim)
+            elif op[0] == "fromcache":
+                dev.copy_from_slice(pool[op[1]], cache.slice(op[2] * dim, (op[2] + 1) * dim), dim)
+        results[on] = [dev.download(t) for t in pool] + [dev.download(cache)]
+    for key in keys:
+        check(dev.lib.rama_set_tuning(dev.ctx, key, 1))
+    for i, (a, b) in enumerate(zip(results[1], results[0])):
+        assert np.array_equal(bits(a), bits(b)), f"seed {seed}: vector {i} differs between recorded and unrecorded issue"
+    assert sum(bool(np.isfinite(a).all() and np.abs(a).max() > 0) for a in results[1]) >= 5, f"seed {seed}: the program degenerated (inf / nan / zeros): nothing is compared"
+
+
 def _chain_lookup(dev, ptr, rows, K):
     f = dev.lib.rama_internal_chain_lookup
     f.restype = C.c_void_p
