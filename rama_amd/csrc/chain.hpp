@@ -446,6 +446,16 @@ __device__ __forceinline__ bool seq_sum_lds_fast(const float* a, int n, FastSumS
     if (per <= 32) return seq_sum_lds_fast_r<NW, 32>(a, n, fs, out);
     return seq_sum_lds_fast_r<NW, 64>(a, n, fs, out);
 }
+// [r5] the exact sequential sum of a list in LDS (scan_slot layout) by whichever form applies to its length; every thread gets it.  From kFastSumMin terms on
+// seqsum_fast.hpp's form; below it, and wherever a prediction fails, the round-4 forms.  (One thread simply adding a short list in order, sixteen LDS reads
+// ahead of the adds, was measured: 0.35 us + 12 ns a term -- 1.20 us at 71 terms, 1.36 at 121, against 1.12-1.16 here whatever the length: not kept.)
+// The caller has a barrier behind the writes of the list.
+template <int NW>
+__device__ __forceinline__ float seq_sum_cascade(const float* a, int n, FastSumShared<NW>& fsn, PredShared<NW>& ps, SeqSumShared<NW>& sh) {
+    float sum;
+    if (!seq_sum_lds_fast<NW>(a, n, fsn, &sum)) { __syncthreads(); if (!seq_sum_predict<NW>(a, n, ps, &sum)) sum = seq_sum_exact<NW>(a, n, sh); }
+    return sum;
+}
 // (a grid of several workgroups: vector b of a token batch, `stride` floats after the one before it)
 __global__ __launch_bounds__(kNormThreads) void rmsnorm_chain_kernel(float* o, const float* x, const float* w, int n, float* copy_to, int stride = 0) {
     RAMA_NO_CONTRACT
@@ -520,8 +530,7 @@ __global__ __launch_bounds__(kNormThreads) void softmax_chain_kernel(float* x, i
     mx = block_max(mx, red);
     for (int i = tid; i < n; i += kNormThreads) s_e[scan_slot(i)] = expf_glibc_tab(x[i] - mx, s_tab);
     __syncthreads();
-    float sum;
-    if (!seq_sum_lds_fast<kNormWaves>(s_e, n, fsn, &sum)) { __syncthreads(); if (!seq_sum_predict<kNormWaves>(s_e, n, ps, &sum)) sum = seq_sum_exact<kNormWaves>(s_e, n, sh); }
+    const float sum = seq_sum_cascade<kNormWaves>(s_e, n, fsn, ps, sh);
     for (int i = tid; i < n; i += kNormThreads) x[i] = s_e[scan_slot(i)] / sum;
 }
 
@@ -1237,6 +1246,10 @@ __host__ __device__ constexpr bool attn_chain_fits(int head_size, int nw) { retu
 // as tagged words (inl.qkv: [3 dim], layer_fused.hpp's convention) -- the head's three slices are awaited, q goes to LDS from them, and since every
 // producer drains its write-through cache-row stores before it tags, the cache (row `pos` included) is then read with sc1 loads; xb leaves as tagged
 // words (inl.xb_t) and, when p.xb is given, plainly.
+// (a cache base taken from a SeqSlot in memory is a pointer of unknown address space to the compiler: its loads become FLAT loads, which count in lgkmcnt
+// as well -- every wait for an LDS operation then also waits for the cache rows on their way.  The cache is global memory: say so.)
+typedef const __attribute__((address_space(1))) f4* gf4p;
+__device__ __forceinline__ gf4p gptr4(const float* p) { return (gf4p)reinterpret_cast<const f4*>(p); }
 struct AttnInl { const unsigned long long* qkv; const unsigned long long* early; unsigned long long* xb_t; unsigned long long* err; unsigned epoch; int* s_ok; };
 // PRE ([r5] qkv_attn_chain_kernel): the head's workgroup sits in the SAME launch as the Wq|Wk|Wv row groups that produce q and this position's cache
 // rows (gemv_chain_body OUT).  It requests its first key rows of EARLIER positions at once (they are an earlier launch's), waits for the tagged
@@ -1264,15 +1277,31 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
     float* s_q = sm;                                              // [hs]
     float* s_p = sm + ((hs + 3) & ~3);                            // [lds_seq] the probabilities, unskewed (read 4 at a time)
     float* s_att = s_p + ((lds_seq + 3) & ~3);                    // [scan_slot(lds_seq)] scores -> exponentials
-    float* region = s_att + lds_seq + (lds_seq >> 5) + 4;         // score staging, then the product tiles
-    region = reinterpret_cast<float*>(((uintptr_t)region + 15) & ~(uintptr_t)15);
+    // score staging, then the product tiles: the next 16-byte boundary, as an OFFSET into the LDS array (rounding the pointer through an integer made
+    // every access behind it a FLAT load or store -- slower than a ds_ operation, and counted in vmcnt as well: [r5])
+    const int region_off = (((hs + 3) & ~3) + ((lds_seq + 3) & ~3) + lds_seq + (lds_seq >> 5) + 4 + 3) & ~3;
+    float* region = sm + region_off;
     const size_t col = (size_t)h * hs;
     SEQ_STAMP(8);
     const unsigned cache_bytes = (unsigned)p.seq_len * (unsigned)p.dim * 4u;
     constexpr bool SC1 = INL || PRE;                              // the cache holds a row of THIS launch: every read of it bypasses L1 (and the stale lines in it)
     const __amdgpu_buffer_rsrc_t rkc = make_rsrc(p.kc, SC1 ? cache_bytes : 0u), rvc = make_rsrc(p.vc, SC1 ? cache_bytes : 0u);
     constexpr int KP = 32;                                        // PRE, head size 128: a thread's key row of an earlier position, requested before the wait
-    f4 kpre[PRE ? KP : 1];
+    // EARLY ([r5] the plain launch, head size 128, below position 1 024; compiled out: RAMA_ATT_EARLY = 0): a thread's key row of its FIRST timestep and
+    // the first two value tiles requested in one go at the top, q in front of them, all unconditional and in straight-line code, so that the waits are counted
+    // (q: vmcnt(48); the scores: all but the value tiles) and the value rows' round trip lies under the scores and the softmax.  Measured at position 70
+    // (tools/seqsum_bench): values 2.84 -> 2.40 us, but scores 2.20 -> 3.20 -- every thread then requests a row (the ones behind pos the row of pos) and 48
+    // requests per thread stand in front of the first product; the launch 8.72 -> 9.36 us.  Round 4 had tried the same and lost more (scores 2.4 -> 4.4).
+    constexpr bool EARLY = !PRE && !INL && NW <= 4;
+    f4 kpre[(PRE || EARLY) ? KP : 1];
+    bool early = false;
+#ifndef RAMA_ATT_EARLY
+#define RAMA_ATT_EARLY 0
+#endif
+#ifndef RAMA_ATT_STAGE_POS
+#define RAMA_ATT_STAGE_POS 1024
+#endif
+    if constexpr (EARLY) early = RAMA_ATT_EARLY && hs4 == KP && hs <= T && pos < RAMA_ATT_STAGE_POS;      // (uniform)
     if constexpr (PRE) {
         // (below, once the value tiles' element map is known)
     } else if constexpr (INL) {
@@ -1295,10 +1324,9 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
             }
         }
     } else {
-        for (int i = tid; i < hs; i += T) s_q[i] = p.q[col + i];
+        if (!early) { for (int i = tid; i < hs; i += T) s_q[i] = p.q[col + i]; }
     }
-    // xb[i] = sum_t att[t] * v[t][i], t ascending (cpu.rs:43-49).  (Requesting the first value tiles up here, behind a thread's first key
-    // rows, was measured: scores 2.4 -> 4.4 us, values 3.2 -> 2.7 at position 70 -- the key rows' wait then covers the value rows too.)
+    // xb[i] = sum_t att[t] * v[t][i], t ascending (cpu.rs:43-49).
     // (16 waves: 1 024 threads cover a tile of head size 256 with four loads each -- and have 128 registers, which eight loads per tile buffer
     // and a 32-load key batch overran by 56: [r5])
     constexpr int U = NW >= 16 ? 4 : 8;
@@ -1313,24 +1341,38 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
             // `s_waitcnt vmcnt(0)` behind it, one cache round trip per load instruction)
             const int tr = min(t0 + er[u], pos), c4 = ec[u];
             if constexpr (SC1) vr[u] = ld4_sc1(rvc, ((unsigned)tr * (unsigned)p.dim + (unsigned)col + 4u * (unsigned)c4) * 4u);
-            else vr[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.vc + (size_t)tr * p.dim + col) + c4);
+            else vr[u] = __builtin_nontemporal_load(gptr4(p.vc + (size_t)tr * p.dim + col) + c4);
         }
     };
     f4 va[U], vb[U];                                              // two tiles on their way while a third is added up
     f4 vpos[PRE ? U : 1];                                         // PRE: this position's value row, every element's 16 bytes of it
+    if constexpr (EARLY) {
+        if (early) {
+            const float qv = p.q[col + min(tid, hs - 1)];
+            __builtin_amdgcn_sched_barrier(0);                    // (q FIRST in the queue: its wait must not cover the rows; the scheduler would move it behind them)
+            const gf4p k4 = gptr4(p.kc + (size_t)min(tid, pos) * p.dim + col);
+#pragma unroll
+            for (int u = 0; u < KP; u++) kpre[u] = k4[u];
+            __builtin_amdgcn_sched_barrier(0);
+            vissue(0, va);
+            vissue(kAttTile, vb);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tid < hs) s_q[tid] = qv;
+        }
+    }
     if constexpr (PRE) {
         // EARLIER positions' rows are an earlier launch's: the thread's first key row and the first two value tiles go out before the wait
         // (rows clamped to pos - 1; what an element of row >= pos holds then is replaced by vpos where the product is formed)
         const int plast = max(pos - 1, 0);
         {
-            const f4* k4 = reinterpret_cast<const f4*>(p.kc + (size_t)min(tid, plast) * p.dim + col);
+            const gf4p k4 = gptr4(p.kc + (size_t)min(tid, plast) * p.dim + col);
 #pragma unroll
             for (int u = 0; u < KP; u++) kpre[u] = k4[min(u, hs4 - 1)];
         }
 #pragma unroll
-        for (int u = 0; u < U; u++) va[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.vc + (size_t)min(er[u], plast) * p.dim + col) + ec[u]);
+        for (int u = 0; u < U; u++) va[u] = __builtin_nontemporal_load(gptr4(p.vc + (size_t)min(er[u], plast) * p.dim + col) + ec[u]);
 #pragma unroll
-        for (int u = 0; u < U; u++) vb[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.vc + (size_t)min(kAttTile + er[u], plast) * p.dim + col) + ec[u]);
+        for (int u = 0; u < U; u++) vb[u] = __builtin_nontemporal_load(gptr4(p.vc + (size_t)min(kAttTile + er[u], plast) * p.dim + col) + ec[u]);
         const unsigned ep = *pre.epoch;
         const int gph = hs >> 4, nflag = 3 * gph;                 // (host: head_size % 16 == 0, 3 head_size / 16 <= 64)
         if (wave == 0) {
@@ -1363,7 +1405,7 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
     __syncthreads();
     const float scale_div = sqrtf((float)hs);
     const f4* q4 = reinterpret_cast<const f4*>(s_q);
-    if (hs % kAttPiece == 0 && pos >= 1024) {                     // long contexts: staged pieces, two of them in flight per wave
+    if (hs % kAttPiece == 0 && pos >= RAMA_ATT_STAGE_POS) {       // long contexts: staged pieces, two of them in flight per wave
         float* stage = region + wave * (64 * kAttStride);
         const int npiece = hs / kAttPiece;
         const int lrow = lane >> 3, lc4 = lane & 7;               // loader role: row (+ 8 u) and 16-byte column of the piece
@@ -1377,7 +1419,7 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int t = min(g * 64 + u * 8 + lrow, pos);
-                d[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.kc + (size_t)t * p.dim + col + pc * kAttPiece) + lc4);
+                d[u] = __builtin_nontemporal_load(gptr4(p.kc + (size_t)t * p.dim + col + pc * kAttPiece) + lc4);
             }
         };
         constexpr int NB = NW >= 16 ? 1 : 2;                      // staged pieces in flight per wave (16 waves: 128 registers -- one)
@@ -1415,8 +1457,8 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
         }
     } else {
         int t_first = tid;
-        if constexpr (PRE) {
-            if (hs4 == KP && tid <= pos) {                        // (uniform in hs4) the first round from the rows in registers
+        if constexpr (PRE || EARLY) {
+            if ((PRE || early) && hs4 == KP && tid <= pos) {      // (uniform in hs4) the first round from the rows in registers
                 float acc = 0.0f;
 #pragma unroll
                 for (int u = 0; u < KP; u++) {
@@ -1428,7 +1470,7 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
             }
         }
         for (int t = t_first; t <= pos; t += T) {                 // a few rounds of timesteps: straight from the cache, a row's loads together
-            const f4* k4 = reinterpret_cast<const f4*>(p.kc + (size_t)t * p.dim + col);
+            const gf4p k4 = gptr4(p.kc + (size_t)t * p.dim + col);
             float acc = 0.0f;
             int i = 0;
             // batches of 32, 16, 8, 4 x 16 bytes, each requested at once ([r4]: 16 and 8 are new -- head size 64 took four round
@@ -1469,8 +1511,7 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
     for (int t = tid; t <= pos; t += T) s_att[scan_slot(t)] = expf_glibc_tab(s_att[scan_slot(t)] - mx, s_tab);
     __syncthreads();
     SEQ_STAMP(10);
-    float sum;
-    if (!seq_sum_lds_fast<NW>(s_att, pos + 1, fsn, &sum)) { __syncthreads(); if (!seq_sum_predict<NW>(s_att, pos + 1, ps, &sum)) sum = seq_sum_exact<NW>(s_att, pos + 1, sh); }
+    const float sum = seq_sum_cascade<NW>(s_att, pos + 1, fsn, ps, sh);
     SEQ_STAMP(11);
     for (int t = tid; t <= pos; t += T) {
         const float a = s_att[scan_slot(t)] / sum;
@@ -1480,8 +1521,7 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
     float acc = 0.0f;
     SEQ_STAMP(12);
     if constexpr (!PRE) {
-        vissue(0, va);
-        vissue(kAttTile, vb);
+        if (!early) { vissue(0, va); vissue(kAttTile, vb); }
     }
     __syncthreads();                                              // the probabilities are final; the staging region is free
     auto vtile = [&](int t0, int buf, f4 (&vr)[U]) {
@@ -1683,8 +1723,7 @@ __global__ __launch_bounds__(kSoftWaves * 64) void attn_softmax_chain_kernel(Ref
     mx = block_max(mx, red);
     for (int t = tid; t <= pos; t += T) s_att[scan_slot(t)] = expf_glibc_tab(s_att[scan_slot(t)] - mx, s_tab);
     __syncthreads();
-    float sum;
-    if (!seq_sum_lds_fast<kSoftWaves>(s_att, pos + 1, fsn, &sum)) { __syncthreads(); if (!seq_sum_predict<kSoftWaves>(s_att, pos + 1, ps, &sum)) sum = seq_sum_exact<kSoftWaves>(s_att, pos + 1, sh); }
+    const float sum = seq_sum_cascade<kSoftWaves>(s_att, pos + 1, fsn, ps, sh);
     for (int t = tid; t <= pos; t += T) att[t] = s_att[scan_slot(t)] / sum;
 }
 
@@ -1890,8 +1929,7 @@ __device__ __forceinline__ void attn_softmax_values_chain_body(RefAttnParams p) 
     for (int t = tid0; t <= pos; t += TS) s_att[scan_slot(t)] = expf_glibc_tab(s_att[scan_slot(t)] - mx, s_tab);
     __syncthreads();
     SEQ_STAMP(43);
-    float sum;
-    if (!seq_sum_lds_fast<kFvSoftWaves>(s_att, pos + 1, fsn, &sum)) { __syncthreads(); if (!seq_sum_predict<kFvSoftWaves>(s_att, pos + 1, ps, &sum)) sum = seq_sum_exact<kFvSoftWaves>(s_att, pos + 1, sh); }
+    const float sum = seq_sum_cascade<kFvSoftWaves>(s_att, pos + 1, fsn, ps, sh);
     SEQ_STAMP(44);
     for (int t = tid0; t <= pos; t += TS) {
         const float a = s_att[scan_slot(t)] / sum;

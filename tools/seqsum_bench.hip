@@ -37,8 +37,8 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(kc, h.data(), h.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(vc, h.data(), h.size() * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(q, h.data(), dim * 4, hipMemcpyHostToDevice));
         RefAttnParams ap{}; ap.q = q; ap.kc = kc; ap.vc = vc; ap.xb = xb; ap.pos_val = pos; ap.dim = dim; ap.head_size = hs; ap.seq_len = seq;
-        CK(hipFuncSetAttribute((const void*)attention_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-        CK(hipFuncSetAttribute((const void*)attention_chain_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+        CK(hipFuncSetAttribute((const void*)attention_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
+        CK(hipFuncSetAttribute((const void*)attention_chain_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
         for (int nw : {4, 8}) {
             const size_t alds = attn_chain_lds_floats(hs, seq, nw) * 4 + 16;
             for (int rep = 0; rep < 2; rep++) {
