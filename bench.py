@@ -63,6 +63,8 @@ def parse(argv=None):
                          "both: parity + fast; all: the three of them")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="rama_set_tuning(KEY, VALUE) on every engine before timing (A/B runs under the profiler); repeatable")
+    ap.add_argument("--settle-s", type=float, default=3.0,
+                    help="seconds of untimed decoding over the same positions in front of the W warm-up steps (the part's clocks: r05_experiments.md 15); 0: none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kprof", action="store_true")
     ap.add_argument("--no-prefill", action="store_true", help="skip the prompt-ingestion (rama_prefill) figures")
@@ -196,7 +198,7 @@ def cpu_baseline(shape_name, n_tokens, check_engines=None):
     return out, {m: c for m, c in chk.items() if c["checked_positions"]}
 
 
-def time_decode(eng, dev, seq, steps, warmup, pos0, prompt, temperature=0.0):
+def time_decode(eng, dev, seq, steps, warmup, pos0, prompt, temperature=0.0, settle_s=0.0):
     """`warmup` untimed + `steps` timed chained decode steps; a generation that reaches seq_len is followed
     by a new one (BOS + prompt at position 0), so a run may be longer than the model's context.
     temperature != 0: Device::sample's top-p path on the device (topp 0.9, the CPU backend's constant draw)"""
@@ -211,6 +213,15 @@ def time_decode(eng, dev, seq, steps, warmup, pos0, prompt, temperature=0.0):
             n -= m
             pos += m
         return pos
+    # the part's clocks first: a process that has just uploaded a model finds the GPU in a state in which every matvec runs ~2 % slower for the first second
+    # or so of decoding (profiles/r05_experiments.md 15: 204-205 tok/s in some runs, 209 after three or more untimed passes, in every run).  Whole untimed
+    # passes over the SAME positions until `settle_s` seconds of decoding have gone by; the W warm-up steps and the K timed ones then follow as ever.
+    t_settle = time.perf_counter()
+    while settle_s > 0 and time.perf_counter() - t_settle < settle_s:
+        eng.decode_begin(1, pos0, prompt if pos0 == 0 else [])
+        run_steps(warmup + steps, pos0)
+        dev.sync()
+        eng.decode_tokens()
     eng.decode_begin(1, pos0, prompt if pos0 == 0 else [])
     pos = run_steps(warmup, pos0)
     dev.sync()      # N = 1: no other rank to meet; everything runs on the context's stream, which this drains
@@ -352,7 +363,7 @@ MODE_TEXT = {
 }
 
 
-def run_shape(dev, name, steps, warmup, pos0, graph, modes, kprof, sampled=False):
+def run_shape(dev, name, steps, warmup, pos0, graph, modes, kprof, sampled=False, settle_s=0.0):
     """the requested modes of one shape on one resident model -> (cfg, model, bytes, {mode: {...}});
     sampled: also time the head mode with the README's `-r 1` (Device::sample's top-p path, on the device)"""
     import rama_amd
@@ -368,7 +379,7 @@ def run_shape(dev, name, steps, warmup, pos0, graph, modes, kprof, sampled=False
         for k_, v_ in TUNE:
             eng.set_tuning(k_, v_)
         eng.set_graph_mode(bool(graph))
-        wall_ms, ev_ms, pos, tokens = time_decode(eng, dev, seq, steps, warmup, pos0, PROMPT)
+        wall_ms, ev_ms, pos, tokens = time_decode(eng, dev, seq, steps, warmup, pos0, PROMPT, settle_s=settle_s)
         tok_s = steps / (wall_ms * 1e-3)
         r = {"tok_s": round(tok_s, 3), "ms_per_step": round(wall_ms / steps, 4), "event_ms_per_step": round(ev_ms / steps, 4),
              "achieved_GBps": round(bytes_["token"] * tok_s / 1e9, 1),
@@ -437,7 +448,7 @@ def single_gpu(args, local_rank):
     modes = {"all": ["fast", "tol", "parity"], "both": ["fast", "parity"]}.get(args.mode, [args.mode])
     head = "parity" if "parity" in modes else modes[-1]
     cfg, model, bytes_, res = run_shape(dev, args.config, args.steps, args.warmup, args.pos0, args.graph, modes, not args.no_kprof,
-                                        sampled=() if args.no_sampled else (head,))
+                                        sampled=() if args.no_sampled else (head,), settle_s=args.settle_s)
     d, h, L, H, V, seq, shared = SHAPES[args.config]
     for m_ in modes:
         if m_ != "fast" and "fast" in res:
@@ -485,7 +496,7 @@ def single_gpu(args, local_rank):
     r = res[head]
     line = {
         "metric": METRIC_1GPU,
-        "value": r["tok_s"], "unit": "tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "value": r["tok_s"], "unit": "tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "settle_s": args.settle_s,
         "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.config} fp32 decode, weights resident in HBM, greedy, pos {r['positions']}",

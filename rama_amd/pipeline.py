@@ -255,7 +255,7 @@ def _bench_line(args, cfg, world, n_seq, tok_s, dt, roofline, path, hipgraph, rc
     return {
         "metric": f"tokens/sec decode + matvec achieved-HBM-GB/s vs roofline, {args.config} fp32 layer pipeline over {world}xMI355X"
                   if world > 1 else "tokens/sec decode + matvec achieved-HBM-GB/s vs roofline, llama2-7B fp32 1xMI355X",
-        "value": round(tok_s, 3), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(tok_s, 3), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_s": getattr(args, "settle_s", 0.0),
         "ms_per_step": round(dt * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.config} fp32 decode, layer pipeline over {world} GPUs, {n_seq} sequences in flight, greedy",
@@ -342,6 +342,22 @@ def run_pipeline_bench_native(args, cfg, rank: int, world: int, local_rank: int)
     timed = {}
     for mode in modes:
         st.check(st.dev.lib.rama_set_tuning(st.dev.ctx, b"ref_order", REF_ORDER[mode]), "rama_set_tuning")
+        if mode == modes[0] and getattr(args, "settle_s", 0.0) > 0:
+            # the parts' clocks first (bench.py --settle-s): whole untimed generations over the same positions, as many on every rank (the first one's
+            # duration, the maximum over the ranks, says how many more)
+            import math
+            n_more = 0
+            for i in range(21):
+                plan0 = st.plan(n_pos, PROMPT, wrap=cfg.seq_len)
+                ts = time.perf_counter()
+                st.run_ticks(plan0, 0, st.total_ticks(plan0))
+                st.dev.sync(); torch.cuda.synchronize()
+                if i == 0:
+                    d0 = torch.tensor([time.perf_counter() - ts], dtype=torch.float64)
+                    dist.all_reduce(d0, op=dist.ReduceOp.MAX)
+                    n_more = min(20, max(0, math.ceil(args.settle_s / max(float(d0.item()), 1e-3)) - 1))
+                if i >= n_more:
+                    break
         plan = st.plan(n_pos, PROMPT, wrap=cfg.seq_len)
         total = st.total_ticks(plan)
         st.run_ticks(plan, 0, t_warm)
