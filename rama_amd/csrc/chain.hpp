@@ -1521,7 +1521,7 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
     float acc = 0.0f;
     SEQ_STAMP(12);
     if constexpr (!PRE) {
-        if (!early) { vissue(0, va); vissue(kAttTile, vb); }
+        if (!early) { vissue(0, va); if (pos >= kAttTile) vissue(kAttTile, vb); }      // (uniform: 64 KiB of requests a tile cost the CU ~0.25 us wherever they stand)
     }
     __syncthreads();                                              // the probabilities are final; the staging region is free
     auto vtile = [&](int t0, int buf, f4 (&vr)[U]) {
@@ -1538,7 +1538,7 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
                 *reinterpret_cast<f4*>(tile + 4 * e) = pr;
             }
         }
-        vissue(t0 + 2 * kAttTile, vr);
+        if (t0 + 2 * kAttTile <= pos) vissue(t0 + 2 * kAttTile, vr);      // (uniform)
         __syncthreads();                                          // this tile is written; the other one (read last round) is free again
         if (tid < hs) {
             const int nt = min(kAttTile, pos + 1 - t0);
@@ -1922,7 +1922,8 @@ __device__ __forceinline__ void attn_softmax_values_chain_body(RefAttnParams p) 
 #pragma unroll
     for (int k = 0; k < kSc; k++) { const int t = tid0 + k * TS; if (t <= pos) { s_att[scan_slot(t)] = sc[k]; mx = fmaxf(mx, sc[k]); } }
     if constexpr (!MERGED) { for (int t = tid0 + kSc * TS; t <= pos; t += TS) { const float a = scores[t]; s_att[scan_slot(t)] = a; mx = fmaxf(mx, a); } }
-    if constexpr (!MERGED) { if (!chain && tid < T) { vissue(0, v0); vissue(kFvRows, v1); vissue(2 * kFvRows, v2); vissue(3 * kFvRows, v3); } }     // uniform per wave
+    // (tiles behind pos are not asked for -- uniform branches: a tile's requests cost the CU's address unit ~0.2 us wherever they stand)
+    if constexpr (!MERGED) { if (!chain && tid < T) { vissue(0, v0); if (kFvRows <= pos) vissue(kFvRows, v1); if (2 * kFvRows <= pos) vissue(2 * kFvRows, v2); if (3 * kFvRows <= pos) vissue(3 * kFvRows, v3); } }     // uniform per wave
     SEQ_STAMP(41);
     mx = block_max(mx, red);
     SEQ_STAMP(42);
@@ -2058,7 +2059,7 @@ __device__ __forceinline__ void attn_softmax_values_chain_body(RefAttnParams p) 
             d[0] = in ? a * vr[u].x : 0.0f; d[kFvStride] = in ? a * vr[u].y : 0.0f;      // cpu.rs:48 `a * vi`, rounded
             d[2 * kFvStride] = in ? a * vr[u].z : 0.0f; d[3 * kFvStride] = in ? a * vr[u].w : 0.0f;
         }
-        vissue(t0 + 4 * kFvRows, vr);
+        if (t0 + 4 * kFvRows <= pos) vissue(t0 + 4 * kFvRows, vr);      // (uniform)
         __syncthreads();                                          // this tile is written: the chain wave takes it
     };
     for (int t0 = 0; t0 <= pos; t0 += 4 * kFvRows) {
