@@ -452,7 +452,7 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *   "chain_split" = 0|1 : [r5] parity matvecs on one wave per row group whose row groups do not divide by the compute units: the remainder as HALF groups
  *                   (8 rows on 32 lanes), so that no CU carries a whole group more than the others (llama2-7B W1|W3: 1 376 groups on 256 CUs, 59.9 -> 59.0 us;
  *                   default 1)
- *   "attn_merge" = 0|1 : [r5] parity mode's long-context attention (scores | softmax + value chains) as ONE launch.  Bit-identical, measured 5-10 us SLOWER
+ *   "attn_merge" = 0|1 : [r5] parity mode's long-context attention (scores | softmax + value chains) as ONE launch.  Bit-identical, measured 0.3-1.3 us SLOWER
  *                   per layer (profiles/r05_experiments.md 12): default 0 */
 int  rama_set_tuning(rama_ctx *ctx, const char *key, int value);
 

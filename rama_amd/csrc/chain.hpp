@@ -1634,7 +1634,7 @@ __global__ __launch_bounds__(256, 2) void qkv_attn_chain_kernel(ChainParams p, R
 //                              chains of the slice add them in row order
 // Same operations in the same order per output as attention_chain_kernel: the same bits.
 // one group of 64 timesteps of one head on ONE wave: stage = 64 x kAttStride floats, s_q = head_size floats of this wave's own; emit(t, score) for t <= pos
-template <class Emit>
+template <bool ALL4 = true, class Emit>
 __device__ __forceinline__ void attn_scores_group(const RefAttnParams& p, int h, int g, int lane, int pos, float* stage, float* s_q, Emit emit) {
     RAMA_NO_CONTRACT
     const int hs = p.head_size, npiece = hs / kAttPiece;
@@ -1651,11 +1651,11 @@ __device__ __forceinline__ void attn_scores_group(const RefAttnParams& p, int h,
     };
     // [r4] head sizes up to 128: all four pieces (32 KB a wave) are requested at once -- with two in flight the third piece's round
     // trip began only when the first had been consumed, and a launch is little more than round trips (8.9 -> 6 us at 1 900 timesteps)
-    f4 na[8], nb[8], nc[8], nd[8];
+    f4 na[8], nb[8], nc[ALL4 ? 8 : 1], nd[ALL4 ? 8 : 1];          // (ALL4 = false: two pieces in flight -- 64 registers less, for a kernel that is short of them)
     load_piece(0, na);
     load_piece(1, nb);
-    const bool all4 = npiece <= 4;                                // uniform
-    if (all4) { load_piece(2, nc); load_piece(3, nd); }
+    const bool all4 = ALL4 && npiece <= 4;                        // uniform
+    if constexpr (ALL4) { if (all4) { load_piece(2, nc); load_piece(3, nd); } }
     for (int i = lane; i < hs; i += 64) s_q[i] = p.q[col + i];
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1681,10 +1681,12 @@ __device__ __forceinline__ void attn_scores_group(const RefAttnParams& p, int h,
         __builtin_amdgcn_wave_barrier();
     };
     if (all4) {
-        consume(0, na, false);
-        if (npiece > 1) consume(1, nb, false);
-        if (npiece > 2) consume(2, nc, false);
-        if (npiece > 3) consume(3, nd, false);
+        if constexpr (ALL4) {
+            consume(0, na, false);
+            if (npiece > 1) consume(1, nb, false);
+            if (npiece > 2) consume(2, nc, false);
+            if (npiece > 3) consume(3, nd, false);
+        }
     } else {
         for (int pc = 0; pc < npiece; pc += 2) {
             consume(pc, na, true);
@@ -1881,9 +1883,8 @@ __device__ __forceinline__ void attn_softmax_values_chain_body(RefAttnParams p) 
         }
     };
     if constexpr (MERGED) {
-        // (the value rows first: they are on their way while the scores are formed; a loading wave's first look at the words then waits for them -- 2 us,
-        // about what the scores take)
-        if (!chain && tid < T) { vissue(0, v0); vissue(kFvRows, v1); vissue(2 * kFvRows, v2); vissue(3 * kFvRows, v3); }
+        // (the value rows are asked for behind the scores, as in the two-launch form: requested up here they compete with the 31 MB of keys every score
+        // waits for -- measured 2 us slower at position 1 900)
         const unsigned ep = *p.epoch;
         unsigned long long* flags = p.sc_tags + (size_t)h * p.seq_len;      // one word per group of 64 timesteps (the first seq_len / 64 of the head's stretch)
         float* sco = p.sc + (size_t)h * p.seq_len;
@@ -1892,7 +1893,7 @@ __device__ __forceinline__ void attn_softmax_values_chain_body(RefAttnParams p) 
             const int wq = wv - kFvWaves, g = sl * kFvScoreWaves + wq;
             float* s_qw = fv_sm + attn_fused_values_lds_floats(p.seq_len) + (size_t)wq * (64 * kAttStride + 256);
             if (g * 64 <= pos) {
-                attn_scores_group(p, h, g, (int)threadIdx.x & 63, pos, s_qw + 256, s_qw, [&](int t, float v) { st_sc1(sco + t, v); });
+                attn_scores_group<false>(p, h, g, (int)threadIdx.x & 63, pos, s_qw + 256, s_qw, [&](int t, float v) { st_sc1(sco + t, v); });
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if ((threadIdx.x & 63) == 0) put_tagged(flags + g, 1.0f, ep);
             }
@@ -1923,7 +1924,7 @@ __device__ __forceinline__ void attn_softmax_values_chain_body(RefAttnParams p) 
     for (int k = 0; k < kSc; k++) { const int t = tid0 + k * TS; if (t <= pos) { s_att[scan_slot(t)] = sc[k]; mx = fmaxf(mx, sc[k]); } }
     if constexpr (!MERGED) { for (int t = tid0 + kSc * TS; t <= pos; t += TS) { const float a = scores[t]; s_att[scan_slot(t)] = a; mx = fmaxf(mx, a); } }
     // (tiles behind pos are not asked for -- uniform branches: a tile's requests cost the CU's address unit ~0.2 us wherever they stand)
-    if constexpr (!MERGED) { if (!chain && tid < T) { vissue(0, v0); if (kFvRows <= pos) vissue(kFvRows, v1); if (2 * kFvRows <= pos) vissue(2 * kFvRows, v2); if (3 * kFvRows <= pos) vissue(3 * kFvRows, v3); } }     // uniform per wave
+    if (!chain && tid < T) { vissue(0, v0); if (kFvRows <= pos) vissue(kFvRows, v1); if (2 * kFvRows <= pos) vissue(2 * kFvRows, v2); if (3 * kFvRows <= pos) vissue(3 * kFvRows, v3); }     // uniform per wave
     SEQ_STAMP(41);
     mx = block_max(mx, red);
     SEQ_STAMP(42);

@@ -129,7 +129,7 @@ struct rama_ctx {
     float* topp_approx = nullptr;           // ... the mass in front of every entry of the whole order
     void* topp_dist = nullptr;              // topp_pick_dist_kernel's hand-off words: items | hdr | cross | epoch | bad
     int tune_spread_pos = kSpreadAttnPos;   // parity mode: from this position on the attention is spread over the chip (scores | softmax + values)
-    int tune_attn_merge = 0;                // ... and the scores with them: ONE launch (chain.hpp attn_spread_chain_kernel; opt-in: measured 5-10 us SLOWER, profiles/r05_experiments.md 12)
+    int tune_attn_merge = 0;                // ... and the scores with them: ONE launch (chain.hpp attn_spread_chain_kernel; opt-in: measured 0.3-1.3 us slower per layer, profiles/r05_experiments.md 12)
     unsigned long long* attn_tags = nullptr;      // device: [layers][n_heads][seq_len] (score, epoch) words of the one-launch form
     size_t attn_tags_words = 0;
     int tune_attn_fv = 1;                   // parity mode, long contexts: softmax + value chains as one launch (0: two launches)
