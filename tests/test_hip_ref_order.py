@@ -769,6 +769,38 @@ def test_recorded_ops_random_sequences(dev, seed):
     assert sum(bool(np.isfinite(a).all() and np.abs(a).max() > 0) for a in results[1]) >= 5, f"seed {seed}: the program degenerated (inf / nan / zeros): nothing is compared"
 
 
+@pytest.mark.gpu
+def test_op_path_at_long_contexts_matches_the_fused_entry(dev):
+    """[r5] forward() composed op for op from the trait (recorded and merged launches) against the resident model's fused entry at positions around every
+    switch of the parity attention (128: the spread form, 256, 1 000, 1 900), both caches filled with the same rows: logits and the residual stream bit for bit
+    (tools/ops_long_check.py is the same check by hand over more positions)"""
+    import rama_amd
+    from rama_amd._lib import check
+    d, h, L, H, V, seq = 4096, 11008, 2, 32, 640, 2048
+    cfg = rama_amd.Config(d, h, L, H, H, V, seq, False)
+    model = rama_amd.Model.synth(dev, cfg, seed=3)
+    ws = rama_amd.TransformerWeights.synth(cfg, 3, dev)
+    wv = rama_amd.TransformerWeightsView.from_gpu_ws(ws)
+    rs = rama_amd.RunState.from_config(cfg, dev)
+    rsv = rama_amd.RunStateView.from_rs(rs)
+    ref = rama_amd.Engine(dev, model)
+    rng = np.random.default_rng(7)
+    kc = (rng.standard_normal(L * seq * d) * 0.5).astype(np.float32)
+    vc = (rng.standard_normal(L * seq * d) * 0.5).astype(np.float32)
+    try:
+        check(dev.lib.rama_set_tuning(dev.ctx, b"ref_order", 1))
+        for pos in (127, 128, 256, 1000, 1900):
+            ref.set_buffer("key_cache", kc); ref.set_buffer("value_cache", vc)
+            dev.upload_into(rsv.key_cache, kc); dev.upload_into(rsv.value_cache, vc)
+            rama_amd.forward(cfg, wv, rsv, 11, pos, dev)
+            ref.forward(11, pos)
+            assert_bits_equal(dev.download(rsv.logits), ref.logits(), f"op path vs fused entry, logits at position {pos}")
+            assert_bits_equal(dev.download(rsv.x), ref.buffer("x", d), f"op path vs fused entry, x at position {pos}")
+    finally:
+        check(dev.lib.rama_set_tuning(dev.ctx, b"ref_order", 0))
+        ref.free(); rs.free(); ws.free(); model.free()
+
+
 def _chain_lookup(dev, ptr, rows, K):
     f = dev.lib.rama_internal_chain_lookup
     f.restype = C.c_void_p
