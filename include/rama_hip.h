@@ -429,8 +429,9 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *                   4 x this many KiB of their rows while the attention runs (48: one workgroup per CU).  Bit-identical, measured
  *                   SLOWER at llama2-7B (194 / 188 against 200 tok/s: the attention's round trips lengthen under the traffic): default 0
  *   "chain_qa" = 0|1 : [r5] parity mode below position 128: Wq|Wk|Wv + the attention as ONE launch (the attention workgroups behind the row groups,
- *                   their earlier positions' cache rows requested while the matvec streams).  Bit-identical, measured EQUAL (43.7 us against
- *                   35.2 + 7.6: two row groups per workgroup load the compute units unevenly): default 0
+ *                   their earlier positions' cache rows requested while the matvec streams).  Bit-identical, measured equal at first (43.7 us against
+ *                   35.2 + 7.6: two row groups per workgroup load the compute units unevenly) and 1.7 % behind the separate launches as they
+ *                   are now (208.5 against 212.2 tok/s): default 0
  *   "chain_fused" = -1|0|1 : [r5] parity mode, dim <= 1024, seq_len <= 1024: a whole stage as ONE launch (csrc/layer_chain_fused.hpp).
  *                   Bit-identical, measured SLOWER than the separate launches (stories15M 217 vs 202 us, stories110M 514 vs 426): default 0
  *   "chain_views" = 0|1 : parity mode's rama_matmul makes a chain-order copy of a matrix of no model on first use (default 1)
