@@ -1287,21 +1287,10 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
     constexpr bool SC1 = INL || PRE;                              // the cache holds a row of THIS launch: every read of it bypasses L1 (and the stale lines in it)
     const __amdgpu_buffer_rsrc_t rkc = make_rsrc(p.kc, SC1 ? cache_bytes : 0u), rvc = make_rsrc(p.vc, SC1 ? cache_bytes : 0u);
     constexpr int KP = 32;                                        // PRE, head size 128: a thread's key row of an earlier position, requested before the wait
-    // EARLY ([r5] the plain launch, head size 128, below position 1 024; compiled out: RAMA_ATT_EARLY = 0): a thread's key row of its FIRST timestep and
-    // the first two value tiles requested in one go at the top, q in front of them, all unconditional and in straight-line code, so that the waits are counted
-    // (q: vmcnt(48); the scores: all but the value tiles) and the value rows' round trip lies under the scores and the softmax.  Measured at position 70
-    // (tools/seqsum_bench): values 2.84 -> 2.40 us, but scores 2.20 -> 3.20 -- every thread then requests a row (the ones behind pos the row of pos) and 48
-    // requests per thread stand in front of the first product; the launch 8.72 -> 9.36 us.  Round 4 had tried the same and lost more (scores 2.4 -> 4.4).
-    constexpr bool EARLY = !PRE && !INL && NW <= 4;
-    f4 kpre[(PRE || EARLY) ? KP : 1];
-    bool early = false;
-#ifndef RAMA_ATT_EARLY
-#define RAMA_ATT_EARLY 0
-#endif
-#ifndef RAMA_ATT_STAGE_POS
-#define RAMA_ATT_STAGE_POS 1024
-#endif
-    if constexpr (EARLY) early = RAMA_ATT_EARLY && hs4 == KP && hs <= T && pos < RAMA_ATT_STAGE_POS;      // (uniform)
+    // ([r5] measured and removed: q, a thread's first key row and the first two value tiles requested in one go at the top of the PLAIN launch, straight-line
+    // so that the waits are counted (q: vmcnt(48); the scores: all but the value tiles).  At position 70 (tools/seqsum_bench): values 2.84 -> 2.40 us, but
+    // scores 2.20 -> 3.20 -- every thread then requests a row and 48 requests per thread stand in front of the first product; the launch 8.72 -> 9.36 us.)
+    f4 kpre[PRE ? KP : 1];
     if constexpr (PRE) {
         // (below, once the value tiles' element map is known)
     } else if constexpr (INL) {
@@ -1324,7 +1313,7 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
             }
         }
     } else {
-        if (!early) { for (int i = tid; i < hs; i += T) s_q[i] = p.q[col + i]; }
+        for (int i = tid; i < hs; i += T) s_q[i] = p.q[col + i];
     }
     // xb[i] = sum_t att[t] * v[t][i], t ascending (cpu.rs:43-49).
     // (16 waves: 1 024 threads cover a tile of head size 256 with four loads each -- and have 128 registers, which eight loads per tile buffer
@@ -1346,20 +1335,6 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
     };
     f4 va[U], vb[U];                                              // two tiles on their way while a third is added up
     f4 vpos[PRE ? U : 1];                                         // PRE: this position's value row, every element's 16 bytes of it
-    if constexpr (EARLY) {
-        if (early) {
-            const float qv = p.q[col + min(tid, hs - 1)];
-            __builtin_amdgcn_sched_barrier(0);                    // (q FIRST in the queue: its wait must not cover the rows; the scheduler would move it behind them)
-            const gf4p k4 = gptr4(p.kc + (size_t)min(tid, pos) * p.dim + col);
-#pragma unroll
-            for (int u = 0; u < KP; u++) kpre[u] = k4[u];
-            __builtin_amdgcn_sched_barrier(0);
-            vissue(0, va);
-            vissue(kAttTile, vb);
-            __builtin_amdgcn_sched_barrier(0);
-            if (tid < hs) s_q[tid] = qv;
-        }
-    }
     if constexpr (PRE) {
         // EARLIER positions' rows are an earlier launch's: the thread's first key row and the first two value tiles go out before the wait
         // (rows clamped to pos - 1; what an element of row >= pos holds then is replaced by vpos where the product is formed)
@@ -1405,7 +1380,7 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
     __syncthreads();
     const float scale_div = sqrtf((float)hs);
     const f4* q4 = reinterpret_cast<const f4*>(s_q);
-    if (hs % kAttPiece == 0 && pos >= RAMA_ATT_STAGE_POS) {       // long contexts: staged pieces, two of them in flight per wave
+    if (hs % kAttPiece == 0 && pos >= 1024) {       // long contexts: staged pieces, two of them in flight per wave
         float* stage = region + wave * (64 * kAttStride);
         const int npiece = hs / kAttPiece;
         const int lrow = lane >> 3, lc4 = lane & 7;               // loader role: row (+ 8 u) and 16-byte column of the piece
@@ -1457,8 +1432,8 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
         }
     } else {
         int t_first = tid;
-        if constexpr (PRE || EARLY) {
-            if ((PRE || early) && hs4 == KP && tid <= pos) {      // (uniform in hs4) the first round from the rows in registers
+        if constexpr (PRE) {
+            if (hs4 == KP && tid <= pos) {                        // (uniform in hs4) the first round from the rows in registers
                 float acc = 0.0f;
 #pragma unroll
                 for (int u = 0; u < KP; u++) {
@@ -1521,7 +1496,8 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
     float acc = 0.0f;
     SEQ_STAMP(12);
     if constexpr (!PRE) {
-        if (!early) { vissue(0, va); if (pos >= kAttTile) vissue(kAttTile, vb); }      // (uniform: 64 KiB of requests a tile cost the CU ~0.25 us wherever they stand)
+        vissue(0, va);
+        if (pos >= kAttTile) vissue(kAttTile, vb);               // (uniform: 64 KiB of requests a tile cost the CU ~0.25 us wherever they stand)
     }
     __syncthreads();                                              // the probabilities are final; the staging region is free
     auto vtile = [&](int t0, int buf, f4 (&vr)[U]) {
