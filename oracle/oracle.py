@@ -68,6 +68,10 @@ def lib() -> C.CDLL:
     sz = C.c_size_t
     L.oracle_set_threads.argtypes = [C.c_int]
     L.oracle_get_threads.restype = C.c_int
+    L.oracle_set_lane_reduce.argtypes = [C.c_int]
+    L.oracle_get_lane_reduce.restype = C.c_int
+    L.oracle_set_softmax_split.argtypes = [C.c_int]
+    L.oracle_get_softmax_split.restype = C.c_int
     L.oracle_array_add.argtypes = [_f32p, _f32p, sz]
     L.oracle_array_mult.argtypes = [_f32p, _f32p, sz]
     L.oracle_sinu.argtypes = [_f32p, sz]
@@ -103,6 +107,33 @@ def lib() -> C.CDLL:
 def _p(a: np.ndarray):
     assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"], (a.dtype, a.flags)
     return a.ctypes.data_as(_f32p)
+
+
+# ------------------------------------------------------------------ the two orders the reference leaves to its crates (rama_oracle.h)
+LANES = {"pairwise": 0, "strided": 1, "sequential": 2}      # wide::f32x4::reduce_add, cpu.rs:148
+
+
+class orders:
+    """with orders(lane_reduce="strided", softmax_split=3): ...  -- process-wide switches of the C library, restored on exit"""
+
+    def __init__(self, lane_reduce=None, softmax_split=None):
+        self.lr = LANES[lane_reduce] if isinstance(lane_reduce, str) else lane_reduce
+        self.ss = softmax_split
+
+    def __enter__(self):
+        L = lib()
+        self.old = (L.oracle_get_lane_reduce(), L.oracle_get_softmax_split())
+        if self.lr is not None:
+            L.oracle_set_lane_reduce(int(self.lr))
+        if self.ss is not None:
+            L.oracle_set_softmax_split(int(self.ss))
+        return self
+
+    def __exit__(self, *exc):
+        L = lib()
+        L.oracle_set_lane_reduce(self.old[0])
+        L.oracle_set_softmax_split(self.old[1])
+        return False
 
 
 # ------------------------------------------------------------------ ops (1:1 with Device)

@@ -6,8 +6,9 @@
  * Parallel structure follows the reference: matmul is parallel over output rows
  * (rayon par_iter_mut, cpu.rs:137), attention over heads (cpu.rs:32), sinu over
  * elements (cpu.rs:56).  Where the reference uses rayon's order-nondeterministic
- * parallel sum (softmax_num, cpu.rs:190) a sequential fp32 sum is used, which is
- * one of the orders rayon can produce (a single split).
+ * parallel sum (softmax_num, cpu.rs:190) the DEFAULT is one front-to-back fp32 sum
+ * (the order of a producer that is never split); oracle_set_softmax_split(levels)
+ * gives rayon's halving tree with 2^levels leaves instead (rama_oracle.h).
  */
 #include "rama_oracle.h"
 
@@ -19,6 +20,36 @@
 #endif
 
 static int g_threads = 0;
+/* The two places where the reference leaves the order of a sum to a crate (see rama_oracle.h): switchable, so that
+ * the distance between the reference's own admissible executions can be measured (tools/ref_self_spread.py). */
+static int g_lane_reduce = ORACLE_LANES_PAIRWISE;
+static int g_softmax_split = 0;
+
+void oracle_set_lane_reduce(int order) { g_lane_reduce = order; }
+int  oracle_get_lane_reduce(void) { return g_lane_reduce; }
+void oracle_set_softmax_split(int levels) { g_softmax_split = levels < 0 ? 0 : levels; }
+int  oracle_get_softmax_split(void) { return g_softmax_split; }
+
+/* wide::f32x4::reduce_add of the four lane sums, cpu.rs:148 */
+static inline float reduce_add4(float v0, float v1, float v2, float v3, int order) {
+    if (order == ORACLE_LANES_STRIDED) return (v0 + v2) + (v1 + v3);
+    if (order == ORACLE_LANES_SEQUENTIAL) return ((v0 + v1) + v2) + v3;
+    return (v0 + v1) + (v2 + v3);
+}
+
+/* rayon's `par_iter().sum::<f32>()`, cpu.rs:190, with `levels` rounds of halving (the producer is split at len / 2
+ * while both halves keep >= 1 element), every leaf summed front to back, the halves' sums added left + right */
+static float sum_split(const float *x, size_t n, int levels) {
+    if (levels <= 0 || n < 2) {
+        float sum = 0.0f;
+        for (size_t i = 0; i < n; i++) sum += x[i];
+        return sum;
+    }
+    const size_t mid = n / 2;
+    const float left = sum_split(x, mid, levels - 1);
+    const float right = sum_split(x + mid, n - mid, levels - 1);
+    return left + right;
+}
 
 void oracle_set_threads(int n) {
     g_threads = n;
@@ -89,14 +120,17 @@ void oracle_apply_position(float *q, float *k, const float *pos_real,
 
 /* cpu.rs:127-153.  Per output element idx: r = idx / o_cols, c = idx % o_cols;
  * four lane sums over k = j (mod 4) (wide::f32x4 `v += a_wide * b_wide`, separate
- * multiply and add), then reduce_add.  wide 0.7's f32x4::reduce_add sums the lanes
- * pairwise, (l0+l1)+(l2+l3) on the SSE3 hadd path; the lane order of that final
- * 4-term sum is not pinned by the reference (crate version `*`-ish, target-feature
- * dependent) and moves the result by at most 1 ulp. */
+ * multiply and add), then reduce_add.  The order of that final 4-term sum belongs to the
+ * `wide` crate and to the build's target features, not to the reference: pairwise
+ * (l0+l1)+(l2+l3) (an SSE3 hadd pair), strided (l0+l2)+(l1+l3) (movehl + shuffle, the
+ * plain SSE2 idiom) or front to back ((l0+l1)+l2)+l3 (array sum) -- 1 ulp apart at
+ * most.  oracle_set_lane_reduce selects it; the default is pairwise (what rounds 1-5
+ * of this repo compared against). */
 int oracle_matmul(float *o, const float *a, const float *b,
                   size_t width, size_t o_rows, size_t o_cols) {
     if (width % 4 != 0 || o_cols == 0) return -1;
     size_t n_out = o_rows * o_cols;
+    const int order = g_lane_reduce;
     /* tiny products stay on the calling thread (fork/join costs more than the work) */
     const int par = (n_out * width) >= ((size_t)1 << 17);
     if (o_cols == 1) {
@@ -110,7 +144,7 @@ int oracle_matmul(float *o, const float *a, const float *b,
                 v2 += ar[k + 2] * b[k + 2];
                 v3 += ar[k + 3] * b[k + 3];
             }
-            o[r] = (v0 + v1) + (v2 + v3);
+            o[r] = reduce_add4(v0, v1, v2, v3, order);
         }
         return 0;
     }
@@ -125,7 +159,7 @@ int oracle_matmul(float *o, const float *a, const float *b,
             v2 += ar[k + 2] * b[(k + 2) * o_cols + c];
             v3 += ar[k + 3] * b[(k + 3) * o_cols + c];
         }
-        o[idx] = (v0 + v1) + (v2 + v3);
+        o[idx] = reduce_add4(v0, v1, v2, v3, order);
     }
     return 0;
 }
@@ -137,8 +171,7 @@ void oracle_softmax(float *x, size_t n) {
     float mx = x[0];
     for (size_t i = 1; i < n; i++) mx = x[i] > mx ? x[i] : mx;
     for (size_t i = 0; i < n; i++) x[i] = expf(x[i] - mx);
-    float sum = 0.0f;
-    for (size_t i = 0; i < n; i++) sum += x[i];
+    const float sum = sum_split(x, n, g_softmax_split);      /* 0 levels: one front-to-back sum */
     for (size_t i = 0; i < n; i++) x[i] /= sum;
 }
 

@@ -74,6 +74,25 @@ typedef struct {
 void oracle_set_threads(int n);
 int  oracle_get_threads(void);
 
+/* ---- the two orders the reference does not fix itself -------------------------------------------------------------
+ * (1) cpu.rs:148 `v.reduce_add()`: the final sum of the four lane sums belongs to wide 0.7.x (engine/Cargo.toml:18) and
+ *     to the target features of the build: pairwise (l0+l1)+(l2+l3) | strided (l0+l2)+(l1+l3) | sequential
+ *     ((l0+l1)+l2)+l3.  Default: pairwise.
+ * (2) cpu.rs:190 `x.par_iter().sum::<f32>()`: rayon 1.8 (engine/Cargo.toml:14) halves the producer while its splitter
+ *     has splits left -- as this file's author reads rayon's plumbing, `splits` starts at the pool's thread count and is
+ *     halved per level, i.e. floor(log2(threads)) + 1 levels without steals (2 leaves with ONE thread, 32 with 16),
+ *     more when a half is stolen -- sums every leaf front to back and adds the halves left + right.  The reference is
+ *     therefore not bit-reproducible against itself across pool sizes (nor, with steals, run to run).
+ *     oracle_set_softmax_split(levels): 2^levels leaves; default 0 = ONE front-to-back sum, the canonical order every
+ *     round of this repo compared against (a pool whose producer is never split).
+ * tools/ref_self_spread.py measures how far these admissible executions sit from each other at llama2-7B depth
+ * (profiles/r06_reference_self_spread.json): that distance is what "within 1e-4 of the reference" can mean at all. */
+enum { ORACLE_LANES_PAIRWISE = 0, ORACLE_LANES_STRIDED = 1, ORACLE_LANES_SEQUENTIAL = 2 };
+void oracle_set_lane_reduce(int order);
+int  oracle_get_lane_reduce(void);
+void oracle_set_softmax_split(int levels);
+int  oracle_get_softmax_split(void);
+
 /* ---- Device<Vec<f32>> for CPU, engine/src/device/cpu.rs ---- */
 void oracle_array_add(float *target, const float *source, size_t n);          /* cpu.rs:16-21 */
 void oracle_array_mult(float *target, const float *source, size_t n);         /* cpu.rs:59-64 */

@@ -18,7 +18,7 @@ Per position five logit vectors are compared:
              that says how far each fp32 path sits from the exact result
 All four are fed the SAME token sequence (the oracle's greedy choice), so caches stay comparable.
 
-The per-position numbers are written to gpurun_out/r05_parity_llama2_7b_200pos.json (copied to
+The per-position numbers are written to gpurun_out/r06_parity_llama2_7b_200pos.json (copied to
 profiles/ by the builder) whatever the outcome; the assertions come last.
 
 What is asserted, and why not simply "fast path within 1e-4 of the oracle": the reference arithmetic
@@ -133,6 +133,37 @@ def test_llama2_7b_full_depth_200_positions(dev):
         toks_tol.append(int(np.flatnonzero(lt == lt.max())[-1]))
         token = PROMPT[pos] if pos < len(PROMPT) else toks_cpu[-1]
 
+    # [r6] the deep tail: both sides jump to a context of 1 900 positions -- the cache rows n_pos..1 899 of every layer are filled with the same random
+    # rows on both sides (rows 0..n_pos-1 stay what the generation wrote) -- and four more positions are compared at FULL depth: parity mode
+    # bit for bit (the spread attention's slice geometry, the ~1 900-term exact softmax sum, at 32 layers x 32 heads x 128), the fast path recorded
+    tail = []
+    tail_at = int(os.environ.get("RAMA_PARITY_TAIL_AT", "1900"))
+    if tail_at > n_pos and tail_at + 4 <= seq:
+        rng = np.random.default_rng(5)
+        for name in ("key_cache", "value_cache"):
+            full = orc.s[name].reshape(L, seq, d)
+            full[:, n_pos:tail_at, :] = rng.standard_normal((L, tail_at - n_pos, d), dtype=np.float32)
+            for e in (eng, eng_ref):
+                e.set_buffer(name, full)
+        for pos in range(tail_at, tail_at + 4):
+            t1 = time.time()
+            lo = orc.forward(token, pos).copy()
+            t_or = time.time() - t1
+            eng.forward(token, pos)
+            lg = eng.logits()
+            eng_ref.set_tuning("ref_order", 1)
+            try:
+                eng_ref.forward(token, pos)
+                lr = eng_ref.logits()
+            finally:
+                eng_ref.set_tuning("ref_order", 0)
+            tail.append({"pos": pos, "token": int(token), "oracle_s": round(t_or, 3),
+                         "hip_ref_order_vs_oracle": float(np.abs(lr - lo).max()),
+                         "hip_ref_order_bits_equal": bool(np.array_equal(lr.view(np.uint32), lo.view(np.uint32))),
+                         "hip_vs_oracle": float(np.abs(lg - lo).max()),
+                         "greedy_token_equal_ref_order": int(np.flatnonzero(lr == lr.max())[-1]) == int(O.argmax(lo))})
+            token = int(O.argmax(lo))
+
     worst = max(r["hip_vs_oracle"] for r in rows)
     out = {
         "shape": "llama2-7B fp32, 32 layers, synthetic weights seed 0 (bit-identical on both sides)",
@@ -151,9 +182,10 @@ def test_llama2_7b_full_depth_200_positions(dev):
         "first_token_mismatch": next((i for i, (a, b) in enumerate(zip(toks_cpu, toks_hip)) if a != b), None),
         "weights_gen_s": round(t_gen, 1), "oracle_s_per_token": round(t_cpu / n_pos, 3),
         "f64_s_per_token": round(t_f64 / n_pos, 3), "oracle_threads": threads,
+        "deep_tail": tail,
         "per_position": rows,
     }
-    path = Path(os.environ.get("RAMA_PARITY_JSON", REPO / "gpurun_out" / "r05_parity_llama2_7b_200pos.json"))
+    path = Path(os.environ.get("RAMA_PARITY_JSON", REPO / "gpurun_out" / "r06_parity_llama2_7b_200pos.json"))
     try:
         path.parent.mkdir(parents=True, exist_ok=True)
         path.write_text(json.dumps(out, indent=1))
@@ -165,6 +197,9 @@ def test_llama2_7b_full_depth_200_positions(dev):
     eng_ref.free(); eng_tol.free(); model.free()
     # the north_star bar, literally: logits within 1e-4 of the CPU reference path at every position
     assert out["worst_hip_ref_order_vs_oracle"] <= LOGIT_ATOL, out["worst_hip_ref_order_vs_oracle"]
+    assert all(r["hip_ref_order_bits_equal"] for r in rows), [r["pos"] for r in rows if not r["hip_ref_order_bits_equal"]][:8]
+    # ... and deep into the context (positions 1 900..1 903 over a filled cache, all 32 layers): the same bits
+    assert all(t["hip_ref_order_bits_equal"] and t["greedy_token_equal_ref_order"] for t in tail), tail
     # the tolerance-mode experiment: same tokens, the same ~1.4e-4 from the oracle as the fast path (recorded above)
     assert out["worst_hip_tolerance_vs_oracle"] <= 2 * LOGIT_ATOL, out["worst_hip_tolerance_vs_oracle"]
     assert toks_cpu == toks_tol

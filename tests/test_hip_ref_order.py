@@ -931,6 +931,49 @@ def test_model_long_context_bit_exact(dev, n_heads, hs):
     eng.free(); model.free()
 
 
+def test_llama2_7b_width_deep_context_bit_exact(dev):
+    """[r6] the HEADLINE shape's width (dim 4096, hidden 11008, 32 heads of 128, seq_len 2048; 2 of the 32 layers, so that the oracle needs
+    1.6 GB instead of 27) deep into the context: both caches filled with the same random rows on both sides, parity mode with the default
+    tunings, eager and replayed from a hipGraph, at the positions around every switch of the exact attention (128: spread over the chip;
+    256; the 1 024-row tiles) and at its far end (1 900, 2 047: a 2 048-term exact softmax sum, 32 heads x 8 slices of value chains):
+    logits, the residual stream, xb, xb2 and every probability bit for bit the ORACLE's (cpu.rs:23-52 multi_head_attention,
+    cpu.rs:187-192 softmax_num).  Round 5 had this comparison at 2 x 128 / 3 x 64 heads only (test_model_long_context_bit_exact)."""
+    import rama_amd
+    from .helpers import to_rama_cfg
+    dim, hidden, heads, layers, seq, vocab = 4096, 11008, 32, 2, 2048, 640
+    cfg = O.Config(dim, hidden, layers, heads, heads, vocab, seq, False)
+    rope = S.rope_tables(seq, dim // heads)
+    w = S.synth_weights(cfg, 13, rope=rope)
+    rng = np.random.default_rng(13)
+    kc = rng.standard_normal(layers * seq * dim, dtype=np.float32)
+    vc = rng.standard_normal(layers * seq * dim, dtype=np.float32)
+    orc = O.Oracle(cfg, w)
+    model = rama_amd.Model.synth(dev, to_rama_cfg(cfg), 13, rope=rope)
+    eng = rama_amd.Engine(dev, model)
+    positions = (127, 128, 255, 256, 257, 1000, 1023, 1024, 1900, 2047)
+    try:
+        for graph in (False, True):
+            eng.set_graph_mode(graph)
+            for pos in positions:
+                orc.s["key_cache"][:] = kc; orc.s["value_cache"][:] = vc
+                eng.set_buffer("key_cache", kc); eng.set_buffer("value_cache", vc)
+                lo = orc.forward(7, pos).copy()
+                eng.forward(7, pos)
+                what = f"7B width, pos {pos}, graph {graph}"
+                assert_bits_equal(eng.logits(), lo, f"{what}: logits")
+                for buf, n in (("x", dim), ("xb", dim), ("xb2", dim), ("hb", hidden), ("q", dim)):
+                    assert_bits_equal(eng.buffer(buf, n), orc.s[buf], f"{what}: {buf}")
+                # (the probabilities of the LAST layer: att is one [heads, seq] scratch, cpu.rs:29)
+                att = eng.buffer("att", heads * seq).reshape(heads, seq)[:, :pos + 1]
+                assert_bits_equal(att, orc.s["att"].reshape(heads, seq)[:, :pos + 1], f"{what}: att")
+                for buf in ("key_cache", "value_cache"):      # the appended rows of both layers
+                    got = eng.buffer(buf, layers * seq * dim).reshape(layers, seq, dim)[:, pos]
+                    assert_bits_equal(got, orc.s[buf].reshape(layers, seq, dim)[:, pos], f"{what}: {buf} row")
+    finally:
+        eng.set_graph_mode(False)
+        eng.free(); model.free()
+
+
 @pytest.mark.parametrize("shape,n_tokens,pos0", [((64, 176, 2, 4, 96, 48), 2, 0), ((64, 176, 2, 4, 96, 48), 5, 0), ((64, 176, 2, 4, 96, 48), 6, 3),
                                                  ((128, 352, 2, 2, 256, 80), 9, 0), ((128, 352, 2, 2, 256, 80), 17, 0), ((128, 352, 2, 2, 256, 80), 18, 5),
                                                  ((288, 768, 2, 6, 512, 96), 40, 0), ((272, 720, 2, 17, 333, 64), 21, 2),
