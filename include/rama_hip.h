@@ -425,15 +425,6 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *   "chain_resid_d" = -1 | 0 | 100 W + D : [r5] geometry of parity mode's residual products (Wo, W2) alone; -1 (default) = one
  *                   wave with a ring of 32 blocks when a compute unit holds at most one row group (llama2-7B: Wo 15.1 -> 13.5 us,
  *                   W2 33.6 -> 32.1), 0 = like the other products
- *   "chain_awo" = 0|16|48 : [r5] parity mode below position 128: attention + Wo as ONE launch, the Wo row groups requesting
- *                   4 x this many KiB of their rows while the attention runs (48: one workgroup per CU).  Bit-identical, measured
- *                   SLOWER at llama2-7B (194 / 188 against 200 tok/s: the attention's round trips lengthen under the traffic): default 0
- *   "chain_qa" = 0|1 : [r5] parity mode below position 128: Wq|Wk|Wv + the attention as ONE launch (the attention workgroups behind the row groups,
- *                   their earlier positions' cache rows requested while the matvec streams).  Bit-identical, measured equal at first (43.7 us against
- *                   35.2 + 7.6: two row groups per workgroup load the compute units unevenly) and 1.7 % behind the separate launches as they
- *                   are now (208.5 against 212.2 tok/s): default 0
- *   "chain_fused" = -1|0|1 : [r5] parity mode, dim <= 1024, seq_len <= 1024: a whole stage as ONE launch (csrc/layer_chain_fused.hpp).
- *                   Bit-identical, measured SLOWER than the separate launches (stories15M 217 vs 202 us, stories110M 514 vs 426): default 0
  *   "chain_views" = 0|1 : parity mode's rama_matmul makes a chain-order copy of a matrix of no model on first use (default 1)
  *   "rope_batch" = 0|1 : [r5] a run of rama_apply_position calls on consecutive heads (q, k advancing by head_size, the same table rows:
  *                   infer.rs:25-29) is recorded and issued as ONE launch by whatever enters the library next -- same bits, 32 launches per layer
@@ -452,9 +443,7 @@ int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
  *                   touches the run's vectors in between is issued in program order (202 -> 203 tok/s from a Python host, which then is the limit; default 1)
  *   "chain_split" = 0|1 : [r5] parity matvecs on one wave per row group whose row groups do not divide by the compute units: the remainder as HALF groups
  *                   (8 rows on 32 lanes), so that no CU carries a whole group more than the others (llama2-7B W1|W3: 1 376 groups on 256 CUs, 59.9 -> 59.0 us;
- *                   default 1)
- *   "attn_merge" = 0|1 : [r5] parity mode's long-context attention (scores | softmax + value chains) as ONE launch.  Bit-identical, measured 0.3-1.3 us SLOWER
- *                   per layer (profiles/r05_experiments.md 12): default 0 */
+ *                   default 1) */
 int  rama_set_tuning(rama_ctx *ctx, const char *key, int value);
 
 /* glibc 2.35 expf (the exp the reference's f32::exp calls on Linux) as the reference-order kernels

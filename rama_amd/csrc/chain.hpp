@@ -552,13 +552,6 @@ struct ChainParams {
     // ([r5] measured and not kept, profiles/r05_experiments.md: 16 copies of the word on different channels -1.8 %; the leader's compute unit kept free of
     // other workgroups and its waves at priority 3: the word is there 1.1-2 us earlier, the launch no shorter)
     unsigned long long* lead; const unsigned* epoch; unsigned long long* err;
-    // WAIT ([r5] a consumer phase of a merged launch): x is written by OTHER workgroups of this launch (write-through stores); each of the wait_n
-    // producers leaves a tagged word {1, epoch} in wait_flags once its stores have left.  The group requests its ring of weights, then waits, then
-    // reads x with sc1 loads only (cdna_hip_programming.md Guideline 16 R1: sc1 payload, drained producer, sc1 flag, one polling wave, barrier)
-    const unsigned long long* wait_flags; int wait_n;
-    // OUT ([r5] a producer phase of a merged launch: Wq|Wk|Wv in front of the attention workgroups): q, k, v and the cache rows leave with
-    // write-through stores; once a row group's stores have left, its wave sets the group's tagged word out_flags[matrix * groups + group]
-    unsigned long long* out_flags;
     // half_from > 0 ([r5] one wave per row group): the row groups from this index on are walked as TWO workgroups of 8 rows each (lanes 0..31; the
     // chain-order block of 16 rows is two halves of 512 bytes).  A compute unit streams ~28 GB/s whatever the rest of the chip does, so a launch whose
     // row groups do not divide by the compute units ends when the CUs with one group more are through: llama2-7B's W1|W3 is 1 376 groups on 256 CUs,
@@ -617,23 +610,20 @@ __device__ unsigned long long g_chain_all[3 * 4096];
 enum { CNORM_NONE = 0, CNORM_EXACT = 1, CNORM_TREE = 2, CNORM_LEAD = 3 };
 
 constexpr unsigned long long kLeadErr = 0x3100ull;                // error word: a wait for the leader's word gave up
-constexpr unsigned long long kWaitErr = 0x3200ull;                // error word: a wait for a merged launch's producers gave up
-// (the body of gemv_chain_kernel; `bid_in` = the workgroup's index within its phase -- merged launches run it behind other phases' workgroups)
-// GPB ([r5]): row groups per workgroup -- W x GPB waves, every W of them one group, the activations staged ONCE for all (a merged launch whose other
-// phase wants 256 threads runs Wq|Wk|Wv as two two-wave groups per workgroup).  The groups of a workgroup walk their chunks in lockstep (one barrier).
-template <int W, int D, int XD, int EPI, int NORM = CNORM_NONE, int LR = 64, bool WAIT = false, int GPB = 1, bool OUT = false>
+// (the body of gemv_chain_kernel; `bid_in` = the workgroup's index.  [r5] As a PHASE of merged launches -- a consumer waiting for tagged words of
+// other workgroups of its launch, a producer leaving such words, two row groups per workgroup -- it was bit-identical and slower or equal:
+// profiles/r05_experiments.md, profiles/r06_lost_experiments.patch)
+template <int W, int D, int XD, int EPI, int NORM = CNORM_NONE, int LR = 64>
 __device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in) {
     RAMA_NO_CONTRACT
     CHAIN_STAMP(0);
     static_assert(D % XD == 0, "the x ring must divide the weight ring");
-    static_assert(!WAIT || NORM == CNORM_NONE, "a waiting phase takes its activations as they come");
-    static_assert(!OUT || EPI == CEPI_QKV, "only Wq|Wk|Wv hands its output over inside a launch");
     extern __shared__ __attribute__((aligned(16))) float xs[];
-    __shared__ float relay[GPB][64];
-    constexpr int WL = W * GPB;                                   // waves of the workgroup
+    __shared__ float relay[64];
+    constexpr int WL = W;                                         // waves of the workgroup
     const int lane = threadIdx.x & 63;
     const int wave_all = WL == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int pair = GPB == 1 ? 0 : wave_all / W, wave = GPB == 1 ? wave_all : wave_all - pair * W;
+    const int wave = wave_all;
     const int j = lane & 3, rr = lane >> 2;
     const int groups = (p.rows + 15) >> 4;
     if constexpr (NORM == CNORM_LEAD) {
@@ -687,15 +677,11 @@ __device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in)
             return;
         }
     }
-    const int bid0 = NORM == CNORM_LEAD ? bid_in - 1 : bid_in;
-    // (GPB > 1: a workgroup's last group may lie behind the last row group: it walks the last one again and stores nothing)
-    const int gi_raw = bid0 * GPB + pair;
-    const bool valid = GPB == 1 || gi_raw < p.nmat * groups;
-    const int bid = GPB == 1 ? bid0 : min(gi_raw, p.nmat * groups - 1);
+    const int bid = NORM == CNORM_LEAD ? bid_in - 1 : bid_in;
     // (the quotient comes out of the vector ALU: without readfirstlane everything derived from it -- the buffer
     // descriptors above all -- counts as divergent and every load turns into a waterfall loop)
     int half = -1, bid_g = bid;
-    if (GPB == 1 && W == 1 && p.half_from > 0 && bid >= p.half_from) { half = (bid - p.half_from) & 1; bid_g = p.half_from + ((bid - p.half_from) >> 1); }      // (uniform)
+    if (W == 1 && p.half_from > 0 && bid >= p.half_from) { half = (bid - p.half_from) & 1; bid_g = p.half_from + ((bid - p.half_from) >> 1); }      // (uniform)
     const int m = __builtin_amdgcn_readfirstlane(bid_g / groups), g = __builtin_amdgcn_readfirstlane(bid_g - m * groups);
     const float* Wm = m == 0 ? p.w[0] : (m == 1 ? p.w[1] : p.w[2]);
     const int nblk = p.K >> 4;
@@ -719,14 +705,12 @@ __device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in)
     // for the same 32 KiB of x and gain do not keep the leader's own read of x waiting -- measured equal: 39.1 us either way.)
     const __amdgpu_buffer_rsrc_t rx = make_rsrc_uniform(p.x, (unsigned)p.K * 4u);
     const int n4 = p.K >> 2;
-    // (a waiting phase folds no norm: whatever of x does not fit the registers follows behind the weights.  [r5] 24 x 16 bytes per thread up front for
+    // (whatever of x does not fit the registers follows behind the weights.  [r5] 24 x 16 bytes per thread up front for
     // the residual products -- llama2-7B's W2 reads 11 008 floats on 128 threads, the last 2 816 in a second round trip -- measured: 33.70 against 33.77 us)
-    constexpr int T = WL * 64, XU = WAIT ? 16 / W : 16 / GPB;      // (host: K <= 16 XU T floats where a norm is folded in)
+    constexpr int T = WL * 64, XU = 16;                            // (host: K <= 16 XU T floats where a norm is folded in)
     f4 xa[XU];
-    if constexpr (!WAIT) {
 #pragma unroll
-        for (int u = 0; u < XU; u++) xa[u] = ld_c(rx, ((int)threadIdx.x + T * u) < n4 ? (unsigned)((int)threadIdx.x + T * u) * 16u : kOOB);
-    }
+    for (int u = 0; u < XU; u++) xa[u] = ld_c(rx, ((int)threadIdx.x + T * u) < n4 ? (unsigned)((int)threadIdx.x + T * u) * 16u : kOOB);
     f4 ga[NORM != CNORM_NONE ? XU : 1];
     if constexpr (NORM != CNORM_NONE) {
         const __amdgpu_buffer_rsrc_t rg = make_rsrc_uniform(p.nw, (unsigned)p.K * 4u);
@@ -758,25 +742,6 @@ __device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in)
         }
     }
     CHAIN_STAMP(1);
-    if constexpr (WAIT) {      // the ring is on its way: now the producers' words (wave 0 polls, lane i < wait_n the word of producer i), then x, sc1
-        const unsigned ep = *p.epoch;
-        if (wave_all == 0) {
-            long spins = 0;
-            while (true) {
-                unsigned long long word = (unsigned long long)ep << 32;
-                if (lane < p.wait_n) word = __hip_atomic_load(p.wait_flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (__builtin_amdgcn_ballot_w64((unsigned)(word >> 32) == ep) == ~0ull) break;
-                __builtin_amdgcn_s_sleep(2);
-                ++spins;
-                if ((spins & 255) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-                if (spins > (1L << 22)) { if (lane == 0) __hip_atomic_store(p.err, kWaitErr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < XU; u++) xa[u] = ld4_sc1(rx, ((int)threadIdx.x + T * u) < n4 ? (unsigned)((int)threadIdx.x + T * u) * 16u : kOOB);
-    }
-    static_assert(GPB == 1 || NORM == CNORM_NONE || NORM == CNORM_LEAD, "several groups per workgroup: a leader's norm or none");
     if constexpr (NORM == CNORM_TREE) {     // x <- w * (v * x) with the sum of squares as a fixed tree (host: K <= 64 T floats, all of x is in xa)
         float ssl = 0.0f;
 #pragma unroll
@@ -854,7 +819,7 @@ __device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in)
         for (int i0 = (int)threadIdx.x + T * XU; i0 < n4; i0 += T * 8) {      // rows longer than 64 T floats: the rest, behind the weights
             f4 a[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) a[u] = WAIT ? ld4_sc1(rx, (i0 + T * u) < n4 ? (unsigned)(i0 + T * u) * 16u : kOOB) : ld_c(rx, (i0 + T * u) < n4 ? (unsigned)(i0 + T * u) * 16u : kOOB);
+            for (int u = 0; u < 8; u++) a[u] = ld_c(rx, (i0 + T * u) < n4 ? (unsigned)(i0 + T * u) * 16u : kOOB);
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int i = i0 + T * u;
@@ -915,7 +880,7 @@ __device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in)
         for (int c = 0; c < nchunk; c++) {
             if ((c % W) == wave) {                                // uniform: my turn
                 if (c < 24) CHAIN_STAMP(8 + 2 * c);
-                if (c > 0) v = relay[pair][lane];
+                if (c > 0) v = relay[lane];
                 __amdgpu_buffer_rsrc_t rn[D / 16];
 #pragma unroll
                 for (int h = 0; h < D / 16; h++) rn[h] = stretch((c + W) * (D / 16) + h);
@@ -929,7 +894,7 @@ __device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in)
                     wr[u] = ld_nt(rn[u >> 4], vo[(u & 15) >> 2] + (unsigned)(u & 3) * 1024u);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (c + 1 < nchunk) relay[pair][lane] = v;
+                if (c + 1 < nchunk) relay[lane] = v;
                 if (c < 24) CHAIN_STAMP(9 + 2 * c);
             } else if (((c + 1) % W) == wave && c + 1 < nchunk) { // my turn is next: the products, while the wave before me adds
                 premultiply(c + 1);
@@ -943,25 +908,15 @@ __device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in)
     const float t2 = v + dpp_mov<0xB1>(v);                       // quad_perm [1,0,3,2]
     const float d = t2 + dpp_mov<0x4E>(t2);                      // quad_perm [2,3,0,1]
     if (EPI == CEPI_STORE) {
-        if (j == 0 && row < p.rows && valid) { float* o = m == 0 ? p.o[0] : (m == 1 ? p.o[1] : p.o[2]); o[row] = d; }      // (nmat > 1: a run of Device::matmul calls as one launch)
+        if (j == 0 && row < p.rows) { float* o = m == 0 ? p.o[0] : (m == 1 ? p.o[1] : p.o[2]); o[row] = d; }      // (nmat > 1: a run of Device::matmul calls as one launch)
     } else if (EPI == CEPI_RESID) {
-        if (j == 0 && row < p.rows && valid) { p.o[0][row] = d; p.resid[row] = xold + d; }
+        if (j == 0 && row < p.rows) { p.o[0][row] = d; p.resid[row] = xold + d; }
     } else if (EPI == CEPI_QKV) {
         const float other = __shfl_xor(d, 4);                    // the pair's other row (neighbouring quad)
         const float a = (rr & 1) ? other : d, b = (rr & 1) ? d : other;
         float out = d;
         if (m < 2) out = (rr & 1) ? a * rs + b * rc : a * rc - b * rs;      // cpu.rs:87-96
-        if constexpr (OUT) {
-            const unsigned ep = *p.epoch;
-            if (j == 0 && row < p.rows && valid) {
-                float* o = m == 0 ? p.o[0] : (m == 1 ? p.o[1] : p.o[2]);
-                st_sc1(o + row, out);
-                if (m == 1) st_sc1(p.kc + (size_t)pos * p.rows + row, out);  // infer.rs:32
-                else if (m == 2) st_sc1(p.vc + (size_t)pos * p.rows + row, out);     // infer.rs:33
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's stores have left: its group's word may be set
-            if (lane == 0 && valid) put_tagged(p.out_flags + bid, 1.0f, ep);
-        } else if (j == 0 && row < p.rows && valid) {
+        if (j == 0 && row < p.rows) {
             float* o = m == 0 ? p.o[0] : (m == 1 ? p.o[1] : p.o[2]);
             o[row] = out;
             if (m == 1) p.kc[(size_t)pos * p.rows + row] = out;              // infer.rs:32
@@ -974,7 +929,7 @@ __device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in)
         __shared__ unsigned long long s_tab[32];
         s_tab[lane & 31] = tabv;
         __builtin_amdgcn_wave_barrier();
-        if (j == 0 && !(rr & 1) && row < p.rows && valid) {
+        if (j == 0 && !(rr & 1) && row < p.rows) {
             const float sl = d * (1.0f / (1.0f + expf_glibc_tab(-d, s_tab)));       // cpu.rs:56
             p.o[0][row >> 1] = sl * h3;                                        // cpu.rs:59-64
             p.o[1][row >> 1] = h3;
@@ -1239,25 +1194,16 @@ __host__ __device__ constexpr size_t attn_chain_lds_floats(int head_size, int se
 // the value tiles are loaded with 8 x 16 bytes per thread
 __host__ __device__ constexpr bool attn_chain_fits(int head_size, int nw) { return kAttTile * (head_size / 4) <= (nw >= 16 ? 4 : 8) * 64 * nw; }
 
-// (the body of attention_chain_kernel: head h of token y.  lds_seq = the timesteps the LDS arrays are laid out for (seq_len; a merged launch that
-// only runs below some position passes that bound).  HANDOFF ([r5] attn_wo_chain_kernel): xb leaves with write-through stores and, once they
-// have left, the head's tagged word {1, epoch} -- the Wo groups of the same launch wait for the n_heads words)
-// INL ([r5] layer_chain_fused.hpp, the parity-mode one-launch stage): q | k | v of this position were produced by OTHER workgroups of the launch and come
-// as tagged words (inl.qkv: [3 dim], layer_fused.hpp's convention) -- the head's three slices are awaited, q goes to LDS from them, and since every
-// producer drains its write-through cache-row stores before it tags, the cache (row `pos` included) is then read with sc1 loads; xb leaves as tagged
-// words (inl.xb_t) and, when p.xb is given, plainly.
+// (the body of attention_chain_kernel: head h of token y.  lds_seq = the timesteps the LDS arrays are laid out for.
+// [r5] forms of this body that ran inside merged launches -- xb handed to Wo groups of the same launch, q | k | v taken as tagged words from
+// Wq|Wk|Wv groups of the same launch, the whole parity-mode stage as one launch -- were built, are bit-identical and measured slower or equal;
+// they left the product in round 6: profiles/r06_lost_experiments.patch puts them back, profiles/r05_experiments.md holds the measurements)
 // (a cache base taken from a SeqSlot in memory is a pointer of unknown address space to the compiler: its loads become FLAT loads, which count in lgkmcnt
 // as well -- every wait for an LDS operation then also waits for the cache rows on their way.  The cache is global memory: say so.)
 typedef const __attribute__((address_space(1))) f4* gf4p;
 __device__ __forceinline__ gf4p gptr4(const float* p) { return (gf4p)reinterpret_cast<const f4*>(p); }
-struct AttnInl { const unsigned long long* qkv; const unsigned long long* early; unsigned long long* xb_t; unsigned long long* err; unsigned epoch; int* s_ok; };
-// PRE ([r5] qkv_attn_chain_kernel): the head's workgroup sits in the SAME launch as the Wq|Wk|Wv row groups that produce q and this position's cache
-// rows (gemv_chain_body OUT).  It requests its first key rows of EARLIER positions at once (they are an earlier launch's), waits for the tagged
-// words of the 3 head_size / 16 row groups that make its slices, then reads q and the cache with sc1 loads.
-struct AttnPre { const unsigned long long* flags; int groups; unsigned long long* err; const unsigned* epoch; };
-template <int NW, bool HANDOFF = false, bool INL = false, bool PRE = false>
-__device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int y, int lds_seq, unsigned long long* flags = nullptr, const unsigned* epoch = nullptr,
-                                                     AttnInl inl = AttnInl{}, AttnPre pre = AttnPre{}) {
+template <int NW>
+__device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int y, int lds_seq) {
     RAMA_NO_CONTRACT
     constexpr int T = NW * 64;
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -1283,38 +1229,10 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
     float* region = sm + region_off;
     const size_t col = (size_t)h * hs;
     SEQ_STAMP(8);
-    const unsigned cache_bytes = (unsigned)p.seq_len * (unsigned)p.dim * 4u;
-    constexpr bool SC1 = INL || PRE;                              // the cache holds a row of THIS launch: every read of it bypasses L1 (and the stale lines in it)
-    const __amdgpu_buffer_rsrc_t rkc = make_rsrc(p.kc, SC1 ? cache_bytes : 0u), rvc = make_rsrc(p.vc, SC1 ? cache_bytes : 0u);
-    constexpr int KP = 32;                                        // PRE, head size 128: a thread's key row of an earlier position, requested before the wait
     // ([r5] measured and removed: q, a thread's first key row and the first two value tiles requested in one go at the top of the PLAIN launch, straight-line
     // so that the waits are counted (q: vmcnt(48); the scores: all but the value tiles).  At position 70 (tools/seqsum_bench): values 2.84 -> 2.40 us, but
     // scores 2.20 -> 3.20 -- every thread then requests a row and 48 requests per thread stand in front of the first product; the launch 8.72 -> 9.36 us.)
-    f4 kpre[PRE ? KP : 1];
-    if constexpr (PRE) {
-        // (below, once the value tiles' element map is known)
-    } else if constexpr (INL) {
-        if (inl.early) {
-            if (tid == 0) fused_watch(inl.early, inl.epoch, inl.err);
-            __syncthreads();
-        }
-        for (int tries = 0;; tries++) {
-            bool ok = true;
-            for (int i = tid; i < 3 * hs; i += T) {
-                const int m = i / hs, jj = i - m * hs;
-                const unsigned long long w_ = __hip_atomic_load(inl.qkv + (size_t)m * p.dim + col + jj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = ok && (unsigned)(w_ >> 32) == inl.epoch;
-                if (m == 0) s_q[jj] = __uint_as_float((unsigned)w_);
-            }
-            if (fused_all(ok, tries, inl.s_ok)) break;
-            if ((tries & 63) == 63 && __syncthreads_or(tries >= (1 << 20) || __hip_atomic_load(inl.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                if (tid == 0) __hip_atomic_store(inl.err, kFusedErr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-    } else {
-        for (int i = tid; i < hs; i += T) s_q[i] = p.q[col + i];
-    }
+    for (int i = tid; i < hs; i += T) s_q[i] = p.q[col + i];
     // xb[i] = sum_t att[t] * v[t][i], t ascending (cpu.rs:43-49).
     // (16 waves: 1 024 threads cover a tile of head size 256 with four loads each -- and have 128 registers, which eight loads per tile buffer
     // and a 32-load key batch overran by 56: [r5])
@@ -1329,54 +1247,10 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
             // (rows behind pos are clamped: their products are written, never added -- a load under a condition is a branch with
             // `s_waitcnt vmcnt(0)` behind it, one cache round trip per load instruction)
             const int tr = min(t0 + er[u], pos), c4 = ec[u];
-            if constexpr (SC1) vr[u] = ld4_sc1(rvc, ((unsigned)tr * (unsigned)p.dim + (unsigned)col + 4u * (unsigned)c4) * 4u);
-            else vr[u] = __builtin_nontemporal_load(gptr4(p.vc + (size_t)tr * p.dim + col) + c4);
+            vr[u] = __builtin_nontemporal_load(gptr4(p.vc + (size_t)tr * p.dim + col) + c4);
         }
     };
     f4 va[U], vb[U];                                              // two tiles on their way while a third is added up
-    f4 vpos[PRE ? U : 1];                                         // PRE: this position's value row, every element's 16 bytes of it
-    if constexpr (PRE) {
-        // EARLIER positions' rows are an earlier launch's: the thread's first key row and the first two value tiles go out before the wait
-        // (rows clamped to pos - 1; what an element of row >= pos holds then is replaced by vpos where the product is formed)
-        const int plast = max(pos - 1, 0);
-        {
-            const gf4p k4 = gptr4(p.kc + (size_t)min(tid, plast) * p.dim + col);
-#pragma unroll
-            for (int u = 0; u < KP; u++) kpre[u] = k4[min(u, hs4 - 1)];
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) va[u] = __builtin_nontemporal_load(gptr4(p.vc + (size_t)min(er[u], plast) * p.dim + col) + ec[u]);
-#pragma unroll
-        for (int u = 0; u < U; u++) vb[u] = __builtin_nontemporal_load(gptr4(p.vc + (size_t)min(kAttTile + er[u], plast) * p.dim + col) + ec[u]);
-        const unsigned ep = *pre.epoch;
-        const int gph = hs >> 4, nflag = 3 * gph;                 // (host: head_size % 16 == 0, 3 head_size / 16 <= 64)
-        if (wave == 0) {
-            const int m_ = lane / gph, gg = h * gph + (lane - m_ * gph);
-            long spins = 0;
-            while (true) {
-                unsigned long long word = (unsigned long long)ep << 32;
-                if (lane < nflag) word = __hip_atomic_load(pre.flags + (size_t)m_ * pre.groups + gg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (__builtin_amdgcn_ballot_w64((unsigned)(word >> 32) == ep) == ~0ull) break;
-                __builtin_amdgcn_s_sleep(1);
-                ++spins;
-                if ((spins & 255) == 0 && __hip_atomic_load(pre.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-                if (spins > (1L << 22)) { if (lane == 0) __hip_atomic_store(pre.err, kWaitErr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            }
-        }
-        __syncthreads();
-        // ONE round trip for everything of THIS position: q, the key row (by the wave that holds timestep pos: its lanes of earlier timesteps
-        // re-read their own rows, the lanes behind read row pos -- a uniform branch, no load under a per-lane condition), the value row
-        float qv = 0.0f;
-        if (tid < hs) qv = ld_sc1(p.q + col + tid);
-        if (wave == (pos >> 6)) {
-#pragma unroll
-            for (int u = 0; u < KP; u++) kpre[u] = ld4_sc1(rkc, ((unsigned)min(tid, pos) * (unsigned)p.dim + (unsigned)col + 4u * (unsigned)min(u, hs4 - 1)) * 4u);
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) vpos[u] = ld4_sc1(rvc, ((unsigned)pos * (unsigned)p.dim + (unsigned)col + 4u * (unsigned)ec[u]) * 4u);
-        if (tid < hs) s_q[tid] = qv;
-        for (int i = tid + T; i < hs; i += T) s_q[i] = ld_sc1(p.q + col + i);
-    }
     __syncthreads();
     const float scale_div = sqrtf((float)hs);
     const f4* q4 = reinterpret_cast<const f4*>(s_q);
@@ -1431,20 +1305,7 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
             if constexpr (NB == 2) { if (st + 1 < nstep) consume(st + 1, nb); }
         }
     } else {
-        int t_first = tid;
-        if constexpr (PRE) {
-            if (hs4 == KP && tid <= pos) {                        // (uniform in hs4) the first round from the rows in registers
-                float acc = 0.0f;
-#pragma unroll
-                for (int u = 0; u < KP; u++) {
-                    const f4 qq = q4[u];
-                    acc = acc + qq.x * kpre[u].x; acc = acc + qq.y * kpre[u].y; acc = acc + qq.z * kpre[u].z; acc = acc + qq.w * kpre[u].w;
-                }
-                s_att[scan_slot(tid)] = acc / scale_div;
-                t_first = tid + T;
-            }
-        }
-        for (int t = t_first; t <= pos; t += T) {                 // a few rounds of timesteps: straight from the cache, a row's loads together
+        for (int t = tid; t <= pos; t += T) {                     // a few rounds of timesteps: straight from the cache, a row's loads together
             const gf4p k4 = gptr4(p.kc + (size_t)t * p.dim + col);
             float acc = 0.0f;
             int i = 0;
@@ -1455,10 +1316,7 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
                 for (; i + NB <= hs4; i += NB) {
                     f4 kk[NB];
 #pragma unroll
-                    for (int u = 0; u < NB; u++) {
-                        if constexpr (SC1) kk[u] = ld4_sc1(rkc, ((unsigned)t * (unsigned)p.dim + (unsigned)col + 4u * (unsigned)(i + u)) * 4u);
-                        else kk[u] = k4[i + u];
-                    }
+                    for (int u = 0; u < NB; u++) kk[u] = k4[i + u];
 #pragma unroll
                     for (int u = 0; u < NB; u++) {
                         const f4 qq = q4[i + u];
@@ -1471,7 +1329,7 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
             batch(std::integral_constant<int, 8>{});
             batch(std::integral_constant<int, 4>{});
             for (; i < hs4; i++) {
-                const f4 kk = SC1 ? ld4_sc1(rkc, ((unsigned)t * (unsigned)p.dim + (unsigned)col + 4u * (unsigned)i) * 4u) : k4[i], qq = q4[i];
+                const f4 kk = k4[i], qq = q4[i];
                 acc = acc + qq.x * kk.x; acc = acc + qq.y * kk.y; acc = acc + qq.z * kk.z; acc = acc + qq.w * kk.w;
             }
             s_att[scan_slot(t)] = acc / scale_div;
@@ -1495,10 +1353,8 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
     }
     float acc = 0.0f;
     SEQ_STAMP(12);
-    if constexpr (!PRE) {
-        vissue(0, va);
-        if (pos >= kAttTile) vissue(kAttTile, vb);               // (uniform: 64 KiB of requests a tile cost the CU ~0.25 us wherever they stand)
-    }
+    vissue(0, va);
+    if (pos >= kAttTile) vissue(kAttTile, vb);                   // (uniform: 64 KiB of requests a tile cost the CU ~0.25 us wherever they stand)
     __syncthreads();                                              // the probabilities are final; the staging region is free
     auto vtile = [&](int t0, int buf, f4 (&vr)[U]) {
         float* tile = region + buf * (kAttTile * hs);
@@ -1507,8 +1363,7 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
             const int e = tid + u * T;
             if (e < tile4) {
                 const float a = s_p[min(t0 + er[u], pos)];
-                f4 vv = vr[u];
-                if constexpr (PRE) { if (t0 < 2 * kAttTile && t0 + er[u] >= pos) vv = vpos[u]; }      // (the first two tiles were requested before row pos existed)
+                const f4 vv = vr[u];
                 f4 pr;
                 pr.x = a * vv.x; pr.y = a * vv.y; pr.z = a * vv.z; pr.w = a * vv.w;     // cpu.rs:48 `a * vi`, rounded
                 *reinterpret_cast<f4*>(tile + 4 * e) = pr;
@@ -1533,71 +1388,12 @@ __device__ __forceinline__ void attention_chain_body(RefAttnParams p, int h, int
         vtile(t0, 0, va);
         if (t0 + kAttTile <= pos) vtile(t0 + kAttTile, 1, vb);    // uniform
     }
-    if constexpr (INL) {
-        if (tid < hs) { put_tagged(inl.xb_t + col + tid, acc, inl.epoch); if (p.xb) p.xb[col + tid] = acc; }
-    } else if constexpr (HANDOFF) {
-        const unsigned ep = *epoch;
-        if (tid < hs) st_sc1(p.xb + col + tid, acc);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave: its stores have left
-        __syncthreads();
-        if (tid == 0) put_tagged(flags + h, 1.0f, ep);
-    } else {
-        if (tid < hs) p.xb[col + tid] = acc;
-    }
+    if (tid < hs) p.xb[col + tid] = acc;
     SEQ_STAMP(13);
 }
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void attention_chain_kernel(RefAttnParams p) {
     attention_chain_body<NW>(p, (int)blockIdx.x, (int)blockIdx.y, p.seq_len);
-}
-
-// ---------------------------------------------------------------- [r5] attention + the Wo product as ONE launch (infer.rs:34-37), parity mode
-// One workgroup per head keeps 32 of 256 compute units busy for ~8 us while HBM idles, and the Wo launch behind it pays a boundary, a cold
-// first round trip and its tail: 15.1 us for 67 MB.  Here the grid is n_heads attention workgroups followed by Wo's dim / 16 row groups (four
-// waves each, a ring of D blocks per wave): the groups request the first 4 D KiB of their 16 rows' stream -- half of it at D = 32 -- while
-// the attention runs, wait for the n_heads tagged words, read xb with sc1 loads and run the chain as gemv_chain_kernel does: the same
-// operations in the same order per output, the same bits.  A workgroup only waits for workgroups with lower indices (the attention's, which
-// wait for nobody); every wait is bounded (error word, read by the host at its synchronising exits).
-__host__ __device__ constexpr size_t attn_chain_lds_floats_for(int head_size, int lds_seq, int nw) {
-    return (size_t)((head_size + 3) & ~3) + (size_t)lds_seq + (size_t)(lds_seq >> 5) + 4 + (size_t)((lds_seq + 3) & ~3) + attn_chain_region_floats(head_size, nw);
-}
-template <int D>
-__global__ __launch_bounds__(256, 2) void attn_wo_chain_kernel(RefAttnParams a, ChainParams p, int n_heads, int lds_seq) {
-    if ((int)blockIdx.x < n_heads) {
-        attention_chain_body<4, true>(a, (int)blockIdx.x, 0, lds_seq, const_cast<unsigned long long*>(p.wait_flags), p.epoch);
-        return;
-    }
-    gemv_chain_body<4, D, 4, CEPI_RESID, CNORM_NONE, 64, true>(p, (int)blockIdx.x - n_heads);
-}
-// The same with ONE workgroup per compute unit (a grid of dim / 16 <= the CU count; the kernel's > 256 registers per lane see to the placement):
-// workgroup b < n_heads runs head b's attention FIRST (a wave's loads return in order: its cache rows must not queue behind a ring of weights)
-// and requests its ring afterwards; every other workgroup has its whole ring -- at D = 64 all 16 rows of Wo, 256 KiB -- on the way or in
-// registers when the heads' words arrive.
-template <int D>
-__global__ __launch_bounds__(256) void attn_wo_chain_solo_kernel(RefAttnParams a, ChainParams p, int n_heads, int lds_seq) {
-    if ((int)blockIdx.x < n_heads) attention_chain_body<4, true>(a, (int)blockIdx.x, 0, lds_seq, const_cast<unsigned long long*>(p.wait_flags), p.epoch);
-    gemv_chain_body<4, D, 4, CEPI_RESID, CNORM_NONE, 64, true>(p, (int)blockIdx.x);
-}
-
-// ---------------------------------------------------------------- [r5] Wq|Wk|Wv + the attention as ONE launch (infer.rs:19-34), parity mode, short contexts
-// The attention is a chain of dependent memory round trips on 32 of 256 compute units; as a launch of its own it also pays a boundary and
-// starts with cold key rows.  Here its 32 workgroups sit BEHIND the Wq|Wk|Wv row groups of the same launch (the norm's leader in front):
-// while the matvec streams they request their key rows of the earlier positions -- 2 MB next to a 201 MB stream: unlike a streaming phase put
-// beside the attention (attn_wo_chain_kernel, measured slower), this costs the stream nothing --, then wait for the tagged words of the 24
-// row groups that make their head's q, k and v slices (gemv_chain_body OUT: write-through stores, drained, then the group's word), read q
-// and the cache with sc1 loads and run attention_chain_body's arithmetic: the same operations in the same order per output.
-// The matvec runs two two-wave row groups per 256-thread workgroup (GPB = 2), its leader on four waves.
-// MEASURED (profiles/r05_experiments.md section 10): 43.7 us against 35.2 + 7.6 as two launches -- the attention's tail shrinks to 6.6 us, but 385 workgroups of
-// two row groups leave half the compute units with four groups and half with two (three each as 769 workgroups of one), and a CU streams ~28 GB/s:
-// the matvec part alone takes 37.1 us.  Opt-in ("chain_qa").
-template <int LR>
-__global__ __launch_bounds__(256, 2) void qkv_attn_chain_kernel(ChainParams p, RefAttnParams a, int nqkv, int lds_seq) {
-    if ((int)blockIdx.x < nqkv) {
-        gemv_chain_body<2, 16, 4, CEPI_QKV, CNORM_LEAD, LR, false, 2, true>(p, (int)blockIdx.x);
-        return;
-    }
-    const AttnPre pre{p.out_flags, (p.rows + 15) >> 4, p.err, p.epoch};
-    attention_chain_body<4, false, false, true>(a, (int)blockIdx.x - nqkv, 0, lds_seq, nullptr, nullptr, AttnInl{}, pre);
 }
 
 // ---------------------------------------------------------------- the same attention spread over the chip (long contexts)
@@ -1814,14 +1610,9 @@ constexpr int kFvRows = 192, kFvStride = kFvRows + 4, kFvWaves = 4;
 #endif
 constexpr int kFvSoftWaves = RAMA_FV_SOFT;        // [r5] waves of the softmax phase (waves kFvWaves.. leave after it): its loops are a few elements per thread, each with its latency in full
 __host__ __device__ constexpr size_t attn_fused_values_lds_floats(int seq_len) { return (size_t)seq_len + ((size_t)seq_len >> 5) + 4 + (((size_t)seq_len + 3) & ~(size_t)3); }
-// MERGED ([r5] attn_spread_chain_kernel): the scores too -- waves kFvWaves.. of slice workgroup sl take the groups of 64 timesteps sl NSW + w of the head
-// (NSW = kFvSoftWaves - kFvWaves; host: seq_len <= 64 x slices x NSW and <= 2 048), store them write-through and then tag the group's word of this layer; the
-// chain wave of every slice workgroup of the head polls the head's words (bounded; the error word), then every thread reads its positions' scores (sc1).  All workgroups of the launch must be resident at once (host:
-// heads x slices <= compute units, one workgroup per CU by its LDS): a workgroup waits for words that EVERY slice workgroup of its head writes.
-constexpr int kFvScoreWaves = kFvSoftWaves - kFvWaves;
+// ([r5] the scores formed by extra waves of the same launch -- ONE launch for the whole spread attention -- is bit-identical and 0.3-1.3 us slower per
+// layer: profiles/r05_experiments.md section 12, profiles/r06_lost_experiments.patch)
 static_assert(kFvSoftWaves >= kFvWaves && kFvSoftWaves <= 8, "the value chain's assembly names v200..v247: at most 8 waves per workgroup (256 VGPRs a wave)");
-__host__ __device__ constexpr size_t attn_spread_extra_lds_floats() { return (size_t)kFvScoreWaves * (64 * kAttStride + 256); }
-template <bool MERGED>
 __device__ __forceinline__ void attn_softmax_values_chain_body(RefAttnParams p) {
     RAMA_NO_CONTRACT
     constexpr int TS = kFvSoftWaves * 64;                          // softmax: all waves
@@ -1858,47 +1649,14 @@ __device__ __forceinline__ void attn_softmax_values_chain_body(RefAttnParams p) 
             vr[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.vc + (size_t)tr * p.dim + col) + c4);
         }
     };
-    if constexpr (MERGED) {
-        // (the value rows are asked for behind the scores, as in the two-launch form: requested up here they compete with the 31 MB of keys every score
-        // waits for -- measured 2 us slower at position 1 900)
-        const unsigned ep = *p.epoch;
-        unsigned long long* flags = p.sc_tags + (size_t)h * p.seq_len;      // one word per group of 64 timesteps (the first seq_len / 64 of the head's stretch)
-        float* sco = p.sc + (size_t)h * p.seq_len;
-        const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-        if (wv >= kFvWaves) {                                      // (uniform per wave) the scores of one group: write-through, drained, then the group's word
-            const int wq = wv - kFvWaves, g = sl * kFvScoreWaves + wq;
-            float* s_qw = fv_sm + attn_fused_values_lds_floats(p.seq_len) + (size_t)wq * (64 * kAttStride + 256);
-            if (g * 64 <= pos) {
-                attn_scores_group<false>(p, h, g, (int)threadIdx.x & 63, pos, s_qw + 256, s_qw, [&](int t, float v) { st_sc1(sco + t, v); });
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if ((threadIdx.x & 63) == 0) put_tagged(flags + g, 1.0f, ep);
-            }
-        } else if (wv == 0) {                                      // the chain wave has nothing to do yet: it watches the head's words (lane g: group g), bounded
-            const int ng = (pos >> 6) + 1, lane = threadIdx.x;
-            long spins = 0;
-            while (true) {
-                unsigned long long wd = (unsigned long long)ep << 32;
-                if (lane < ng) wd = __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (__builtin_amdgcn_ballot_w64((unsigned)(wd >> 32) == ep) == ~0ull) break;
-                __builtin_amdgcn_s_sleep(2);
-                ++spins;
-                if ((spins & 255) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-                if (spins > (1L << 22)) { if (lane == 0) __hip_atomic_store(p.err, kWaitErr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            }
-        }
-        __syncthreads();
 #pragma unroll
-        for (int k = 0; k < kSc; k++) sc[k] = ld_sc1(sco + min(tid0 + k * TS, pos));
-    } else {
-#pragma unroll
-        for (int k = 0; k < kSc; k++) sc[k] = scores[min(tid0 + k * TS, pos)];
-    }
+    for (int k = 0; k < kSc; k++) sc[k] = scores[min(tid0 + k * TS, pos)];
     SEQ_STAMP(40);
     // softmax_num (cpu.rs:187-192), as attn_softmax_chain_kernel
     float mx = -INFINITY;
 #pragma unroll
     for (int k = 0; k < kSc; k++) { const int t = tid0 + k * TS; if (t <= pos) { s_att[scan_slot(t)] = sc[k]; mx = fmaxf(mx, sc[k]); } }
-    if constexpr (!MERGED) { for (int t = tid0 + kSc * TS; t <= pos; t += TS) { const float a = scores[t]; s_att[scan_slot(t)] = a; mx = fmaxf(mx, a); } }
+    for (int t = tid0 + kSc * TS; t <= pos; t += TS) { const float a = scores[t]; s_att[scan_slot(t)] = a; mx = fmaxf(mx, a); }
     // (tiles behind pos are not asked for -- uniform branches: a tile's requests cost the CU's address unit ~0.2 us wherever they stand)
     if (!chain && tid < T) { vissue(0, v0); if (kFvRows <= pos) vissue(kFvRows, v1); if (2 * kFvRows <= pos) vissue(2 * kFvRows, v2); if (3 * kFvRows <= pos) vissue(3 * kFvRows, v3); }     // uniform per wave
     SEQ_STAMP(41);
@@ -2047,7 +1805,6 @@ __device__ __forceinline__ void attn_softmax_values_chain_body(RefAttnParams p) 
     }
 }
 
-__global__ __launch_bounds__(kFvSoftWaves * 64) void attn_softmax_values_chain_kernel(RefAttnParams p) { attn_softmax_values_chain_body<false>(p); }
-__global__ __launch_bounds__(kFvSoftWaves * 64) void attn_spread_chain_kernel(RefAttnParams p) { attn_softmax_values_chain_body<true>(p); }
+__global__ __launch_bounds__(kFvSoftWaves * 64) void attn_softmax_values_chain_kernel(RefAttnParams p) { attn_softmax_values_chain_body(p); }
 
 }  // namespace rama

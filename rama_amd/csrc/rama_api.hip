@@ -3,7 +3,6 @@
 #include "../../include/rama_hip.h"
 #include "kernels.hpp"
 #include "attn_wo.hpp"
-#include "layer_chain_fused.hpp"
 #include "layer_fused.hpp"
 #include "topp_sort.hpp"
 #include "prefill_attn.hpp"
@@ -59,9 +58,6 @@ constexpr int kSmallAttnPosDefault = 256;
 constexpr size_t kAttnChainMaxLds = 136 * 1024;      // dynamic LDS attention_chain_kernel may ask for (allowed once per device in rama_ctx_create)
 constexpr int kSpreadAttnPos = 128;        // parity mode: from this position on the attention is two launches spread over the chip (chain.hpp; "spread_pos": 187 against 184 tok/s at positions 124..179, 178 against 152 at 800)
 constexpr int kLeadSlots = 2 * 256 + 2;       // tagged words of the leader-workgroup norms: two per layer of a stage (<= 256 layers), one for the final norm
-constexpr int kAwoLayers = 256, kAwoHeads = 64;       // merged attention + Wo launches (chain.hpp attn_wo_chain_kernel): one tagged word per (layer of a stage, head)
-constexpr size_t kChainFusedMaxLds = 120 * 1024;      // dynamic LDS of parity mode's one-launch stage (layer_chain_fused.hpp): one workgroup per CU
-constexpr size_t kAwoMaxLds = 80 * 1024;      // ... whose workgroups must fit two to a compute unit (n_heads + dim / 16 of them on 256 CUs)
 constexpr int kLongAttnPos = 256;          // parity mode: attention_chain_kernel runs 16 waves per head from this position on
 
 struct KProf {
@@ -129,9 +125,6 @@ struct rama_ctx {
     float* topp_approx = nullptr;           // ... the mass in front of every entry of the whole order
     void* topp_dist = nullptr;              // topp_pick_dist_kernel's hand-off words: items | hdr | cross | epoch | bad
     int tune_spread_pos = kSpreadAttnPos;   // parity mode: from this position on the attention is spread over the chip (scores | softmax + values)
-    int tune_attn_merge = 0;                // ... and the scores with them: ONE launch (chain.hpp attn_spread_chain_kernel; opt-in: measured 0.3-1.3 us slower per layer, profiles/r05_experiments.md 12)
-    unsigned long long* attn_tags = nullptr;      // device: [layers][n_heads][seq_len] (score, epoch) words of the one-launch form
-    size_t attn_tags_words = 0;
     int tune_attn_fv = 1;                   // parity mode, long contexts: softmax + value chains as one launch (0: two launches)
     int tune_topp_dist = 1;                 // 1: the running sums by up to 32 workgroups in one launch (topp_pick.hpp); 0: one workgroup's scan rounds
     ToppStats* topp_stats = nullptr;        // small-block path: partial softmax statistics, one per 1024 logits
@@ -171,13 +164,8 @@ struct rama_ctx {
     size_t pc_floats = 0;
     int tune_chain_lead = 1;               // parity mode, dim > 512: the layer norms' exact sums by a leader workgroup INSIDE the consuming matvec's launch (chain.hpp CNORM_LEAD)
     unsigned long long* lead_slots = nullptr;   // device: one tagged word per (layer, norm), 256 bytes apart
-    int tune_chain_awo = 0;                // parity mode, short contexts: attention + Wo as one launch, the Wo groups' first 4 x this many KiB requested while the attention runs (0: two launches)
-    unsigned long long* awo_flags = nullptr;    // device: [kAwoLayers][kAwoHeads] tagged words
     int tune_chain_norm = 1;               // parity mode, dim <= 512: the layer norms folded into the matvecs that consume them
     int tune_chain_split = 1;              // parity mode: the row groups that do not divide by the compute units walked as half groups (chain.hpp half_from)
-    int tune_chain_qa = 0;                 // parity mode, short contexts: Wq|Wk|Wv + the attention as one launch (chain.hpp qkv_attn_chain_kernel; opt-in: measured equal)
-    unsigned long long* qa_flags = nullptr;     // device: [kAwoLayers][3 * 256] tagged words, one per (layer, matrix, row group)
-    int tune_chain_fused = 0;              // parity mode: a whole stage as ONE launch (layer_chain_fused.hpp; opt-in: stories15M +6 %, stories110M -40 %); -1: for dim <= 1024
     int tune_chain_lead_w = 0;             // parity mode: waves per row group of the launches with a leader norm (0: by the number of row groups)
     int tune_chain_resid_d = -1;           // parity mode: 100 W + D for the residual products (Wo, W2) only; 0: by the number of row groups like the others; -1: W = 1, D = 32 when a CU holds one group
     // [r5] a run of Device::apply_position calls on consecutive heads (infer.rs:25-29: n_heads calls per layer, 1 024 per llama2-7B token, each a launch of
@@ -321,10 +309,6 @@ int rama_ctx_create(int device, void* hip_stream, rama_ctx** out) {
     { const unsigned one = 1; HIPCHK(hipMemcpy(c->fused_epoch, &one, sizeof one, hipMemcpyHostToDevice)); }      // the zeroed vectors carry tag 0
     HIPCHK(hipMalloc(&c->lead_slots, 2 * kLeadSlots * 32 * sizeof(unsigned long long)));      // (the second half: the recorded norms of the 1:1 op path)
     HIPCHK(hipMemset(c->lead_slots, 0, 2 * kLeadSlots * 32 * sizeof(unsigned long long)));
-    HIPCHK(hipMalloc(&c->qa_flags, (size_t)kAwoLayers * 768 * sizeof(unsigned long long)));
-    HIPCHK(hipMemset(c->qa_flags, 0, (size_t)kAwoLayers * 768 * sizeof(unsigned long long)));
-    HIPCHK(hipMalloc(&c->awo_flags, (size_t)kAwoLayers * kAwoHeads * sizeof(unsigned long long)));
-    HIPCHK(hipMemset(c->awo_flags, 0, (size_t)kAwoLayers * kAwoHeads * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&c->pbar, 4 * sizeof(unsigned long long)));
     HIPCHK(hipMemset(c->pbar, 0, 4 * sizeof(unsigned long long)));
     HIPCHK(hipHostMalloc(&c->pinned_int, sizeof(int) * 4));
@@ -341,14 +325,6 @@ int rama_ctx_create(int device, void* hip_stream, rama_ctx** out) {
     HIPCHK(hipFuncSetAttribute((const void*)attention_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnChainMaxLds));
     HIPCHK(hipFuncSetAttribute((const void*)attention_chain_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnChainMaxLds));
     HIPCHK(hipFuncSetAttribute((const void*)attention_chain_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnChainMaxLds));
-    HIPCHK(hipFuncSetAttribute((const void*)attn_spread_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-#define RAMA_CF_ATTR(DK_, DH_, F_) HIPCHK(hipFuncSetAttribute((const void*)stage_chain_fused_kernel<DK_, DH_, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainFusedMaxLds))
-    RAMA_CF_ATTR(16, 16, true); RAMA_CF_ATTR(16, 16, false);
-#undef RAMA_CF_ATTR
-    HIPCHK(hipFuncSetAttribute((const void*)attn_wo_chain_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAwoMaxLds));
-    HIPCHK(hipFuncSetAttribute((const void*)qkv_attn_chain_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAwoMaxLds));
-    HIPCHK(hipFuncSetAttribute((const void*)qkv_attn_chain_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAwoMaxLds));
-    HIPCHK(hipFuncSetAttribute((const void*)attn_wo_chain_solo_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnChainMaxLds));
 #define RAMA_GC_ATTR(TPW_) \
     HIPCHK(hipFuncSetAttribute((const void*)gemm_chain_kernel<TPW_, CEPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_chain_lds_bytes(TPW_))); \
     HIPCHK(hipFuncSetAttribute((const void*)gemm_chain_kernel<TPW_, CEPI_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_chain_lds_bytes(TPW_))); \
@@ -385,7 +361,7 @@ int rama_ctx_destroy(rama_ctx* c) {
     hipStreamSynchronize(c->stream);
     drop_graph(c);
     for (auto e : c->kp.ev) hipEventDestroy(e);
-    hipFree(c->ctl); hipFree(c->out); hipFree(c->forced); hipFree(c->argmax_result); hipFree(c->pbar); hipFree(c->attn_counter); hipFree(c->attn_part); hipFree(c->attn_scores); hipFree(c->attn_tags); hipFree(c->fused_hand); hipFree(c->fused_epoch); hipFree(c->lead_slots); hipFree(c->awo_flags); hipFree(c->qa_flags);
+    hipFree(c->ctl); hipFree(c->out); hipFree(c->forced); hipFree(c->argmax_result); hipFree(c->pbar); hipFree(c->attn_counter); hipFree(c->attn_part); hipFree(c->attn_scores); hipFree(c->fused_hand); hipFree(c->fused_epoch); hipFree(c->lead_slots);
     for (int i = 0; i < 2; i++) { hipFree(c->topp_keys[i]); hipFree(c->topp_vals[i]); }
     hipFree(c->topp_prefix); hipFree(c->topp_m); hipFree(c->topp_err); hipFree(c->pf_blob); hipFree(c->pc_blob); if (c->ring) hipHostFree(c->ring);
     hipFree(c->topp_bp); hipFree(c->topp_bi); hipFree(c->topp_bcount); hipFree(c->topp_racc);
@@ -784,26 +760,9 @@ static int ensure_attn_scores(rama_ctx* c, int n_heads, int seq_len) {
     return 0;
 }
 
-// the (score, epoch) words of the one-launch spread attention, a region per layer; nothing is allocated inside a stream capture (the caller then keeps two launches)
-static int ensure_attn_tags(rama_ctx* c, int layers, int n_heads, int seq_len) {
-    const size_t need = (size_t)layers * (size_t)n_heads * (size_t)seq_len;
-    if (need <= c->attn_tags_words) return 0;
-    if (need * sizeof(unsigned long long) > ((size_t)256 << 20)) return 0;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(c->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return 0; }
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->attn_tags) { HIPCHK(hipFree(c->attn_tags)); c->attn_tags = nullptr; c->attn_tags_words = 0; }
-    HIPCHK(hipMalloc(&c->attn_tags, need * sizeof(unsigned long long)));
-    HIPCHK(hipMemset(c->attn_tags, 0, need * sizeof(unsigned long long)));      // (tag 0: no epoch)
-    c->attn_tags_words = need;
-    drop_graph(c);
-    return 0;
-}
 // long_ctx: 8 waves per head (twice the timesteps per score round, twice the loaders of the value tiles) -- from position 256 on
-// tags: this layer's region of rama_ctx::attn_tags, or nullptr (*merged_used: the one-launch form ran, the epoch must advance behind the stage)
 static int launch_attention_chain(rama_ctx* c, float* xb, float* att, const float* q, const float* kc_layer, const float* vc_layer,
-                                  const Ctl* ctl, int pos, int dim, int head_size, int seq_len, int n_heads, bool long_ctx = false, bool spread_wanted = false,
-                                  unsigned long long* tags = nullptr, bool* merged_used = nullptr) {
+                                  const Ctl* ctl, int pos, int dim, int head_size, int seq_len, int n_heads, bool long_ctx = false, bool spread_wanted = false) {
     // spread: the three-launch form for long contexts; it needs whole staged pieces and 32-column slices, a score
     // buffer that fits the softmax kernel's LDS, and the att buffer
     const bool spread = spread_wanted && att && head_size % kAttPiece == 0 && head_size % kValCols == 0 && head_size <= 256 &&
@@ -827,20 +786,6 @@ static int launch_attention_chain(rama_ctx* c, float* xb, float* att, const floa
         p.sc = fv ? c->attn_scores : att;
         hipEvent_t ev_start = c->cur_start, ev_stop = c->cur_start ? c->cur_stop : nullptr;
         c->cur_start = nullptr;
-        // [r5] ONE launch: every slice workgroup also forms its share of the head's scores (chain.hpp).  A workgroup waits for words of its head's other
-        // slice workgroups: all of the launch must be resident at once -- one workgroup per CU (its LDS), so no more workgroups than CUs
-        const int slices = head_size / kValCols;
-        if (fv && tags && merged_used && c->tune_attn_merge && c->pbar && seq_len <= 2048 && seq_len <= 64 * slices * kFvScoreWaves && head_size <= 256 &&
-            n_heads * slices <= std::max(c->cu_count, 1) && c->kp.kernel_id < 0) {
-            p.sc_tags = tags; p.epoch = c->fused_epoch; p.err = c->pbar + 1;
-            const size_t lds = fv_lds + attn_spread_extra_lds_floats() * sizeof(float);
-            if (ev_start || ev_stop) hipExtLaunchKernelGGL(attn_spread_chain_kernel, dim3(n_heads, slices), dim3(kFvSoftWaves * 64), lds, c->stream, ev_start, ev_stop, 0, p);
-            else hipLaunchKernelGGL(attn_spread_chain_kernel, dim3(n_heads, slices), dim3(kFvSoftWaves * 64), lds, c->stream, p);
-            LAUNCHCHK();
-            c->handoff_dirty = true;
-            *merged_used = true;
-            return 0;
-        }
         if (ev_start) hipExtLaunchKernelGGL(attn_scores_chain_kernel, dim3(n_heads, ngroups), dim3(64), 0, c->stream, ev_start, nullptr, 0, p);
         else hipLaunchKernelGGL(attn_scores_chain_kernel, dim3(n_heads, ngroups), dim3(64), 0, c->stream, p);
         LAUNCHCHK();
@@ -866,61 +811,6 @@ static int launch_attention_chain(rama_ctx* c, float* xb, float* att, const floa
     else RAMA_ATTN_CHAIN(16);
 #undef RAMA_ATTN_CHAIN
     LAUNCHCHK();
-    return 0;
-}
-
-// [r5] infer.rs:19-34 as one launch in parity mode (chain.hpp qkv_attn_chain_kernel): the leader norm's shapes, positions below the spread attention's
-// switch and below 256, head sizes of whole 16-row groups whose 3 hs / 16 words one wave polls, workgroups that fit two to a CU.
-// *merged = false: nothing was enqueued.
-static int try_launch_qkv_attn_chain(rama_ctx* c, const rama_config* cfg, rama_run_state* s, size_t li, ChainParams p, const float* kc, const float* vc, bool* merged) {
-    *merged = false;
-    const int dim = cfg->dim, hs = dim / cfg->n_heads, groups = dim / 16;
-    if (!c->tune_chain_qa || c->spread_attn || c->long_attn || c->kp.kernel_id >= 0 || c->tune_chain_d > 0 || c->tune_chain_lead_w > 0) return 0;
-    if (li >= (size_t)kAwoLayers || hs % 16 || 3 * (hs / 16) > 64 || attn_chain_waves(hs, false) != 4 || dim % 64 || groups > 256 || dim > 4096 || dim <= 1024) return 0;
-    const int lds_seq = std::min(cfg->seq_len, std::max(kLongAttnPos, 1));      // the launch only runs below position 256
-    const size_t lds = std::max({attn_chain_lds_floats_for(hs, lds_seq, 4) * sizeof(float) + 16, (size_t)(dim + chain_pad_floats(2, 16, 4)) * sizeof(float), sizeof(FastSumShared<4>)});
-    if (lds > kAwoMaxLds || !aligned16(s->q) || !aligned16(kc) || !aligned16(vc)) return 0;
-    RefAttnParams a{};
-    a.q = s->q; a.kc = kc; a.vc = vc; a.att = s->att; a.xb = s->xb; a.ctl = c->ctl; a.pos_val = 0;
-    a.dim = dim; a.head_size = hs; a.seq_len = cfg->seq_len;
-    p.out_flags = c->qa_flags + li * 768;
-    const int nqkv = 1 + (3 * groups + 1) / 2;
-    const dim3 grid(nqkv + cfg->n_heads);
-    const int per = (dim + 255) / 256;                           // squares per thread of the four-wave leader
-    if (per <= 8) hipLaunchKernelGGL((qkv_attn_chain_kernel<8>), grid, dim3(256), lds, c->stream, p, a, nqkv, lds_seq);
-    else hipLaunchKernelGGL((qkv_attn_chain_kernel<16>), grid, dim3(256), lds, c->stream, p, a, nqkv, lds_seq);
-    LAUNCHCHK();
-    c->handoff_dirty = true;
-    *merged = true;
-    return 0;
-}
-
-// [r5] infer.rs:34-37 as one launch in parity mode (chain.hpp attn_wo_chain_kernel): positions below the spread attention's switch and below 256 (the
-// four-wave attention), head sizes whose value tiles four waves can load, <= 64 heads, <= 256 layers per stage, workgroups that fit two to a CU.
-// *merged = false: nothing was enqueued, the caller launches the two kernels.
-static int try_launch_attn_wo_chain(rama_ctx* c, const rama_config* cfg, rama_run_state* s, size_t li, const float* kc, const float* vc, const float* co_layer, bool* merged) {
-    *merged = false;
-    const int dim = cfg->dim, hs = dim / cfg->n_heads, D = c->tune_chain_awo, groups = (dim + 15) / 16;
-    if ((D != 16 && D != 48) || c->spread_attn || c->long_attn || c->kp.kernel_id >= 0 || c->tune_chain_d > 0) return 0;
-    if (cfg->n_heads > kAwoHeads || li >= (size_t)kAwoLayers || hs % 4 || attn_chain_waves(hs, false) != 4 || dim % 16 || dim / 16 <= 64) return 0;
-    const bool solo = D > 32;      // one workgroup per compute unit, the attention workgroups double as Wo groups
-    if (solo && (groups > c->cu_count || cfg->n_heads > groups)) return 0;
-    const int lds_seq = solo ? cfg->seq_len : std::min(cfg->seq_len, std::max(kLongAttnPos, 1));      // the launch only runs below position 256
-    const size_t lds = std::max(attn_chain_lds_floats_for(hs, lds_seq, 4) * sizeof(float) + 16, (size_t)(dim + chain_pad_floats(4, D, 4)) * sizeof(float));
-    if (lds > (solo ? kAttnChainMaxLds : kAwoMaxLds) || !aligned16(s->q) || !aligned16(kc) || !aligned16(vc) || !aligned16(s->xb)) return 0;
-    RefAttnParams a{};
-    a.q = s->q; a.kc = kc; a.vc = vc; a.att = s->att; a.xb = s->xb; a.ctl = c->ctl; a.pos_val = 0;
-    a.dim = dim; a.head_size = hs; a.seq_len = cfg->seq_len;
-    ChainParams p{};
-    p.w[0] = co_layer; p.o[0] = s->xb2; p.resid = s->x; p.x = s->xb; p.K = dim; p.rows = dim; p.nmat = 1;
-    p.wait_flags = c->awo_flags + li * kAwoHeads; p.wait_n = cfg->n_heads; p.epoch = c->fused_epoch; p.err = c->pbar + 1;
-    const dim3 grid(solo ? groups : cfg->n_heads + groups);
-    // (the 128 KiB two-to-a-CU and the 256 KiB one-to-a-CU variants of the experiment spilled 54 / 122 registers and are gone: profiles/r05_experiments.md)
-    if (D == 16) hipLaunchKernelGGL((attn_wo_chain_kernel<16>), grid, dim3(256), lds, c->stream, a, p, cfg->n_heads, lds_seq);
-    else hipLaunchKernelGGL((attn_wo_chain_solo_kernel<48>), grid, dim3(256), lds, c->stream, a, p, cfg->n_heads, lds_seq);
-    LAUNCHCHK();
-    c->handoff_dirty = true;
-    *merged = true;
     return 0;
 }
 
@@ -1135,7 +1025,6 @@ static int ensure_attn_part(rama_ctx* c, const rama_config* cfg) {
         c->attn_part_floats = need;
     }
     if (c->tune_ref_order) { const int rs = ensure_attn_scores(c, cfg->n_heads, cfg->seq_len); if (rs) return rs; }
-    if (c->tune_ref_order && c->tune_attn_merge && cfg->seq_len <= 2048) { const int rs = ensure_attn_tags(c, cfg->n_layers, cfg->n_heads, cfg->seq_len); if (rs) return rs; }
     return 0;
 }
 
@@ -1523,45 +1412,6 @@ static int enqueue_stage_ref(rama_ctx* c, const rama_config* cfg, const rama_wei
     return 0;
 }
 
-// [r5] parity mode's whole stage as ONE launch (layer_chain_fused.hpp): narrow models (dim <= 1024, seq_len <= 1024: every position takes the
-// one-workgroup-per-head attention), the chain-order copies given.  *launched = false: the shape is not one it takes.
-static int try_launch_chain_fused(rama_ctx* c, const rama_config* cfg, const rama_weights* w, rama_run_state* s, const rama_stage* st,
-                                  const float* cq, const float* ck, const float* cv, const float* co, const float* c13, const float* c2, const float* ccls, bool* launched) {
-    *launched = false;
-    const int dim = cfg->dim, hidden = cfg->hidden_dim, H = cfg->n_heads, hs = dim / H, V = cfg->vocab_size;
-    const int nl = st->layer_end - st->layer_begin;
-    if (!(c->tune_chain_fused < 0 ? dim <= 1024 : c->tune_chain_fused != 0) || c->kp.kernel_id >= 0 || c->tune_chain_d > 0) return 0;
-    if (nl <= 0 && (!st->do_cls || st->do_embed)) return 0;
-    if (dim > kFusedMaxDim || hidden > kFusedMaxHidden || nl > kFusedMaxLayers || dim % 16 || hidden % 16 || hs % 4 || !attn_chain_fits(hs, kPWaves) || cfg->seq_len > 1024 || cfg->seq_len % 4) return 0;
-    if ((double)cfg->seq_len * dim * 4.0 >= 2147483648.0) return 0;
-    if (!s->xb2 || !s->hb2 || !s->k || !s->v || !s->att) return 0;
-    if (!aligned16(s->x) || !aligned16(s->key_cache) || !aligned16(s->value_cache) || !aligned16(w->rms_att_weight) || !aligned16(w->rms_ffn_weight)) return 0;
-    const int kmax = std::max(dim, hidden);
-    const size_t lds = std::max(cf_matvec_lds_floats(kmax, dim), cf_attn_lds_floats(hs, cfg->seq_len)) * sizeof(float) + 16;
-    if (lds > kChainFusedMaxLds) return 0;
-    auto wgs = [](int groups) { return (groups + kCfMW - 1) / kCfMW; };
-    ChainFusedParams a{};
-    a.dim = dim; a.hidden = hidden; a.n_heads = H; a.seq_len = cfg->seq_len; a.vocab = V; a.n_layers = nl; a.do_cls = st->do_cls ? 1 : 0;
-    a.cq = cq; a.ck = ck; a.cv = cv; a.co = co; a.c13 = c13; a.c2 = c2; a.ccls = ccls;
-    a.g_att = w->rms_att_weight; a.g_ffn = w->rms_ffn_weight; a.g_final = w->rms_final_weight;
-    a.emb = st->do_embed ? w->token_embedding_table : nullptr;
-    a.x = s->x; a.xb = s->xb; a.xb2 = s->xb2; a.q = s->q; a.k = s->k; a.v = s->v; a.hb = s->hb; a.hb2 = s->hb2; a.att = s->att; a.logits = s->logits;
-    a.kc = s->key_cache; a.vc = s->value_cache; a.fr = w->freq_cis_real; a.fi = w->freq_cis_imag;
-    a.ctl = c->ctl; a.hand = c->fused_hand; a.epoch = c->fused_epoch; a.err = c->pbar + 1;
-    a.nA = wgs(3 * (dim / 16)); a.nC = wgs(dim / 16); a.nD = wgs(2 * (hidden / 16)); a.nE = a.nC;
-    a.lds_seq = cfg->seq_len;
-    const long grid = (long)nl * (a.nA + H + a.nC + a.nD + a.nE) + (st->do_cls ? wgs((V + 15) / 16) : 0);
-    if (dim > 320) hipLaunchKernelGGL((stage_chain_fused_kernel<16, 16, true>), dim3((unsigned)grid), dim3(kPThreads), lds, c->stream, a);      // seqsum_fast.hpp for the norms' sums
-    else hipLaunchKernelGGL((stage_chain_fused_kernel<16, 16, false>), dim3((unsigned)grid), dim3(kPThreads), lds, c->stream, a);             // ... lane ripples
-    LAUNCHCHK();
-    *launched = true;
-    c->handoff_dirty = true;
-    if (c->fused_chained) { c->fused_epoch_owed = true; return 0; }      // the sampler that follows advances the epoch
-    hipLaunchKernelGGL(fused_epoch_kernel, dim3(1), dim3(1), 0, c->stream, c->fused_epoch);
-    LAUNCHCHK();
-    return 0;
-}
-
 // the same (every RunState buffer as the CPU path leaves it, bit for bit) on the model's chain-order weight
 // copies: 7 launches per layer.  Returns false when a copy is missing (weights uploaded tensor by tensor,
 // widths that are not whole 16-float blocks, no memory for the copy): the caller takes enqueue_stage_ref.
@@ -1597,11 +1447,6 @@ static int enqueue_stage_chain(rama_ctx* c, const rama_config* cfg, const rama_w
                          st->layer_end - st->layer_begin <= 256;      // (per-class timing keeps it: the `norm` class is then the final norm's launch alone, as in the timed step)
     const int lnorm = tol ? (tol_fold ? CNORM_TREE : CNORM_NONE) : (lead_ok ? CNORM_LEAD : par_norm);      // how the layer norms are folded
     bool led = false;
-    if (!tol) {      // narrow models: the whole stage in one launch
-        bool launched = false;
-        const int rf = try_launch_chain_fused(c, cfg, w, s, st, cq, ck, cv, co, c13, c2, ccls, &launched);
-        if (rf || launched) return rf;
-    }
     const float* w13i = (tol && (mask & 4) && st->layer_end > st->layer_begin && (double)hidden * dim * 8.0 < 2147483648.0) ? rama_internal_w13_lookup(w->w1, w->w3) : nullptr;
     int rc;
     if (st->do_embed) {
@@ -1615,7 +1460,6 @@ static int enqueue_stage_chain(rama_ctx* c, const rama_config* cfg, const rama_w
         // narrow models: the two norms of a layer ride in the matvecs that consume them (2 of 7 launches; "chain_norm")
         const bool fold = lnorm != CNORM_NONE;
         if (!fold && !(mask & 1)) { KTimer kt(c, RAMA_K_NORM); rc = launch_rmsnorm_chain(c, s->xb, s->x, w->rms_att_weight + li * dim, dim, nullptr); if (rc) return rc; }      // infer.rs:19
-        bool qa = false;
         if (mask & 1) { rc = launch_fast_qkv(c, cfg, w, s, li, kc, vc); if (rc) return rc; }
         else {   // :20-33: Wq | Wk | Wv, RoPE, cache append
             KTimer kt(c, RAMA_K_QKV);
@@ -1625,28 +1469,15 @@ static int enqueue_stage_chain(rama_ctx* c, const rama_config* cfg, const rama_w
             p.K = dim; p.rows = dim; p.nmat = 3;
             p.ctl = c->ctl; p.fr = w->freq_cis_real; p.fi = w->freq_cis_imag; p.head_size = hs; p.kc = kc; p.vc = vc;
             if (lnorm == CNORM_LEAD) { p.lead = c->lead_slots + 32 * (2 * li); p.epoch = c->fused_epoch; p.err = c->pbar + 1; led = true; }
-            if (lnorm == CNORM_LEAD && fold && !c->tune_chain_awo) { rc = try_launch_qkv_attn_chain(c, cfg, s, li, p, kc, vc, &qa); if (rc) return rc; }      // :19-34 as one launch ([r5] "chain_qa")
-            if (!qa) { rc = launch_chain<CEPI_QKV>(c, p, fold ? lnorm : CNORM_NONE); if (rc) return rc; }
+            rc = launch_chain<CEPI_QKV>(c, p, fold ? lnorm : CNORM_NONE); if (rc) return rc;
         }
-        bool awo = false;      // :34-37 as one launch ([r5] "chain_awo")
-        if (!tol && lead_ok && !qa) { rc = try_launch_attn_wo_chain(c, cfg, s, li, kc, vc, co + li * dd, &awo); if (rc) return rc; led = led || awo; }
-        if (!awo && !qa) {   // :34
+        {   // :34
             KTimer kt(c, RAMA_K_ATTN);
             if (tol && !(mask & 32)) rc = launch_attention(c, s->xb, s->att, s->q, kc, vc, c->ctl, 0, dim, hs, cfg->seq_len, cfg->n_heads, c->split_attn);
-            else {
-                unsigned long long* tags = nullptr;
-                if (c->spread_attn && c->tune_attn_merge && !tol) {
-                    rc = ensure_attn_tags(c, cfg->n_layers, cfg->n_heads, cfg->seq_len); if (rc) return rc;
-                    if (c->attn_tags_words >= (size_t)cfg->n_layers * cfg->n_heads * cfg->seq_len) tags = c->attn_tags + li * (size_t)cfg->n_heads * cfg->seq_len;
-                }
-                bool mg = false;
-                rc = launch_attention_chain(c, s->xb, s->att, s->q, kc, vc, c->ctl, 0, dim, hs, cfg->seq_len, cfg->n_heads, c->long_attn, c->spread_attn, tags, &mg);
-                led = led || mg;
-            }
+            else rc = launch_attention_chain(c, s->xb, s->att, s->q, kc, vc, c->ctl, 0, dim, hs, cfg->seq_len, cfg->n_heads, c->long_attn, c->spread_attn);
             if (rc) return rc;
         }
-        if (awo) { }
-        else if (mask & 2) { KTimer kt(c, RAMA_K_WO); rc = launch_rows<false, EPI_RESID>(c, s->x, w->wo + li * dd, s->xb, nullptr, dim, dim); if (rc) return rc; }
+        if (mask & 2) { KTimer kt(c, RAMA_K_WO); rc = launch_rows<false, EPI_RESID>(c, s->x, w->wo + li * dd, s->xb, nullptr, dim, dim); if (rc) return rc; }
         else {   // :35-37: xb2 = Wo . xb; x += xb2
             KTimer kt(c, RAMA_K_WO);
             ChainParams p{};
@@ -3042,13 +2873,6 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
         drop_graph(c);
         return 0;
     }
-    if (!strcmp(key, "chain_awo")) {
-        REQUIRE(value == 0 || value == 16 || value == 48, RAMA_EINVAL, "set_tuning: chain_awo must be 0, 16 or 48");
-        c->tune_chain_awo = value;
-        hipStreamSynchronize(c->stream);
-        drop_graph(c);
-        return 0;
-    }
     if (!strcmp(key, "qkv_fold")) {
         REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: qkv_fold must be 0 or 1");
         c->tune_qkv_fold = value;
@@ -3067,20 +2891,6 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
     if (!strcmp(key, "chain_split")) {
         REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: chain_split must be 0 or 1");
         c->tune_chain_split = value;
-        hipStreamSynchronize(c->stream);
-        drop_graph(c);
-        return 0;
-    }
-    if (!strcmp(key, "chain_qa")) {
-        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: chain_qa must be 0 or 1");
-        c->tune_chain_qa = value;
-        hipStreamSynchronize(c->stream);
-        drop_graph(c);
-        return 0;
-    }
-    if (!strcmp(key, "chain_fused")) {
-        REQUIRE(value >= -1 && value <= 1, RAMA_EINVAL, "set_tuning: chain_fused must be -1, 0 or 1");
-        c->tune_chain_fused = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
         return 0;
@@ -3181,13 +2991,6 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
     if (!strcmp(key, "spread_pos")) {
         REQUIRE(value >= 64 && value <= (1 << 20), RAMA_EINVAL, "set_tuning: spread_pos must be 64 .. 2^20");
         c->tune_spread_pos = value;
-        hipStreamSynchronize(c->stream);
-        drop_graph(c);
-        return 0;
-    }
-    if (!strcmp(key, "attn_merge")) {
-        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: attn_merge must be 0 or 1");
-        c->tune_attn_merge = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
         return 0;

@@ -186,8 +186,6 @@ struct RefAttnParams {
     const Ctl* ctl; int pos_val;
     int dim, head_size, seq_len;
     float* sc = nullptr;      // spread attention (chain.hpp): where the scores launch leaves the raw scores ([n_heads, seq_len]; == att for the three-launch form)
-    // ... as ONE launch (chain.hpp attn_spread_chain_kernel): the scores travel as (value, epoch) words [n_heads, seq_len] of this layer
-    unsigned long long* sc_tags = nullptr; const unsigned* epoch = nullptr; unsigned long long* err = nullptr;
     // a grid of (heads, tokens) -- the parity-mode prefill pass, chain.hpp: token y sits at position pos + y, its q / xb
     // rows are y * tok_stride floats further on, its att rows y * att_stride.  (0, 0 and gridDim.y = 1: one token.)
     int tok_stride, att_stride;

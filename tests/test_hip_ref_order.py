@@ -374,46 +374,6 @@ def test_fast_sequential_sum(dev, n):
                 assert got[1] == 1.0, f"fast sum n={n} list {li} waves {nw}: fell back on ordinary data"
 
 
-@pytest.mark.parametrize("dim,hidden,heads,layers,vocab,seq,steps", [(288, 768, 6, 3, 512, 200, 150), (64, 176, 4, 2, 96, 32, 20), (768, 2048, 12, 2, 333, 160, 40),
-                                                                     (1024, 1024, 8, 2, 160, 64, 10), (48, 80, 3, 2, 50, 40, 12)])
-def test_parity_one_launch_stage_bit_exact(dev, dim, hidden, heads, layers, vocab, seq, steps):
-    """[r5] parity mode's whole stage as ONE launch (layer_chain_fused.hpp, "chain_fused" = 1; opt-in): the phases of every layer and the classifier
-    chained through tagged vectors, chain-order arithmetic in every op -- every RunState buffer the oracle's, bit for bit, at every position
-    (the stories15M / stories110M widths, a head size of 128, ragged row counts), eager and from a hipGraph, and a layer range of a pipeline"""
-    import rama_amd
-    from .helpers import to_rama_cfg
-    cfg = O.Config(dim, hidden, layers, heads, heads, vocab, seq, False)
-    rope = S.rope_tables(seq, dim // heads)
-    w = S.synth_weights(cfg, 13, rope=rope)
-    orc = O.Oracle(cfg, w)
-    model = rama_amd.Model.synth(dev, to_rama_cfg(cfg), 13, rope=rope)
-    eng = rama_amd.Engine(dev, model)
-    sizes = dict(x=dim, xb=dim, xb2=dim, hb=hidden, hb2=hidden, q=dim, k=dim, v=dim, logits=vocab, key_cache=layers * seq * dim, value_cache=layers * seq * dim)
-    try:
-        eng.set_tuning("chain_fused", 1)
-        token = 1
-        for pos in range(steps):
-            lo = orc.forward(token, pos)
-            eng.forward(token, pos)
-            if pos < 6 or pos % 16 == 0 or pos == steps - 1:
-                for buf, n in sizes.items():
-                    assert_bits_equal(eng.buffer(buf, n), orc.s[buf], f"one-launch stage pos {pos} {buf}")
-                att = eng.buffer("att", heads * seq).reshape(heads, seq)[:, :pos + 1]
-                assert_bits_equal(att, orc.s["att"].reshape(heads, seq)[:, :pos + 1], f"one-launch stage pos {pos} att")
-            else:
-                assert_bits_equal(eng.logits(), lo, f"one-launch stage pos {pos} logits")
-            token = O.argmax(lo)
-        # the device-chained loop replays it from a hipGraph
-        eng2 = rama_amd.Engine(dev, model)
-        eng2.set_graph_mode(True)
-        prompt = [5, 9, 2]
-        assert eng2.generate_greedy(prompt, min(steps, 24)) == O.Oracle(cfg, w).generate_greedy(prompt, min(steps, 24))
-        eng2.free()
-    finally:
-        eng.set_tuning("chain_fused", 0)
-        eng.free(); model.free()
-
-
 @pytest.mark.parametrize("heads,hs", [(32, 128), (6, 48), (3, 2)])
 def test_apply_position_runs_are_one_launch_and_keep_their_order(dev, heads, hs):
     """[r5] a run of Device::apply_position calls on consecutive heads (infer.rs:25-29) is recorded and issued as ONE launch by whatever enters the
@@ -843,47 +803,6 @@ def test_uploaded_weights_run_the_chain_kernels(dev, dim, hidden, heads, layers,
         assert not _chain_lookup(dev, wq_ptr, dim, dim), "a chain-order copy outlived its tensor"
 
 
-@pytest.mark.parametrize("dim,hidden,heads,layers,seq,steps", [(4096, 11008, 32, 2, 512, 140), (1296, 1600, 27, 3, 160, 40), (2048, 2048, 16, 2, 300, 270)])
-def test_attention_wo_merged_launch_bit_exact(dev, dim, hidden, heads, layers, seq, steps):
-    """[r5] attention + Wo as ONE launch in parity mode (chain.hpp attn_wo_chain_kernel, "chain_awo" = 48 | 16): the Wo groups request half (a
-    quarter) of their rows' stream while the attention runs, wait for the heads' tagged words and read xb with sc1 loads.  Every position
-    -- through the switches to the spread attention (128) and to 256, where the launch is two again -- leaves xb, xb2, x, the probabilities
-    and the logits as the oracle's, bit for bit, and as the two-launch form's (llama2-7B's width; a width whose last chunk is ragged with 27
-    heads of 48; 16 heads of 128 across both switches)"""
-    import rama_amd
-    from .helpers import to_rama_cfg
-    cfg = O.Config(dim, hidden, layers, heads, heads, 320, seq, False)
-    rope = S.rope_tables(seq, dim // heads)
-    w = S.synth_weights(cfg, 11, rope=rope)
-    orc = O.Oracle(cfg, w)
-    model = rama_amd.Model.synth(dev, to_rama_cfg(cfg), 11, rope=rope)
-    engs = {}
-    try:
-        for awo in (48, 16, 0, "qa"):      # "qa": Wq|Wk|Wv + attention as one launch ("chain_qa" = 1) instead
-            engs[awo] = rama_amd.Engine(dev, model)
-        token = 1
-        for pos in range(steps):
-            lo = orc.forward(token, pos)
-            for awo, eng in engs.items():
-                eng.set_tuning("chain_awo", 0 if awo == "qa" else awo)
-                eng.set_tuning("chain_qa", 1 if awo == "qa" else 0)
-                eng.forward(token, pos)
-                if awo == 0 and pos % 8:
-                    continue
-                assert_bits_equal(eng.logits(), lo, f"awo {awo} pos {pos} logits")
-                for buf, n in (("x", dim), ("xb", dim), ("xb2", dim)):
-                    assert_bits_equal(eng.buffer(buf, n), orc.s[buf], f"awo {awo} pos {pos} {buf}")
-                att = eng.buffer("att", heads * seq).reshape(heads, seq)[:, :pos + 1]
-                assert_bits_equal(att, orc.s["att"].reshape(heads, seq)[:, :pos + 1], f"awo {awo} pos {pos} att")
-            token = O.argmax(lo)
-    finally:
-        dev.lib.rama_set_tuning(dev.ctx, b"chain_awo", 0)
-        dev.lib.rama_set_tuning(dev.ctx, b"chain_qa", 0)
-        for eng in engs.values():
-            eng.free()
-        model.free()
-
-
 @pytest.mark.parametrize("n_heads,hs", [(2, 128), (3, 64)])
 def test_model_long_context_bit_exact(dev, n_heads, hs):
     """parity mode over a pre-filled cache at positions around the 4-wave / 16-wave switch (256) and deep into the
@@ -904,7 +823,6 @@ def test_model_long_context_bit_exact(dev, n_heads, hs):
     # forms it replaced stay selectable: "attn_fv" = 0 (softmax and value chains as two launches), "spread_pos" (one workgroup per
     # head below it: 4 waves, 8 from position 256 on)
     variants = [({}, (100, 127, 128, 129, 191, 192, 193, 255, 256, 257, 383, 384, 385, 1000, 1023, 1024, 1025, 2047)),
-                ({"attn_merge": 1}, (128, 129, 200, 255, 256, 1000, 1024, 1900, 2047)),      # [r5] scores + softmax + values as ONE launch (opt-in: slower)
                 ({"attn_fv": 0}, (128, 200, 1024, 2047)),
                 ({"spread_pos": 1024}, (255, 256, 257, 1000, 1023, 1024, 1025)),
                 ({"spread_pos": 1 << 20}, (1500, 2047))]
@@ -924,10 +842,10 @@ def test_model_long_context_bit_exact(dev, n_heads, hs):
                     att = eng.buffer("att", n_heads * seq).reshape(n_heads, seq)[:, :pos + 1]
                     assert_bits_equal(att, orc.s["att"].reshape(n_heads, seq)[:, :pos + 1], f"long context pos {pos} att {tune}")
             eng.set_graph_mode(False)
-            eng.set_tuning("attn_fv", 1); eng.set_tuning("spread_pos", 128); eng.set_tuning("attn_merge", 0)
+            eng.set_tuning("attn_fv", 1); eng.set_tuning("spread_pos", 128)
     finally:
         eng.set_graph_mode(False)
-        eng.set_tuning("attn_fv", 1); eng.set_tuning("spread_pos", 128); eng.set_tuning("attn_merge", 0)
+        eng.set_tuning("attn_fv", 1); eng.set_tuning("spread_pos", 128)
     eng.free(); model.free()
 
 

@@ -24,31 +24,6 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto scores = [&] { hipLaunchKernelGGL(attn_scores_chain_kernel, dim3(H, ngroups), dim3(64), 0, 0, ap); };
     auto fv = [&] { hipLaunchKernelGGL(attn_softmax_values_chain_kernel, dim3(H, hs / kValCols), dim3(kFvSoftWaves * 64), fv_lds, 0, ap); };
-    {   // [r5] the one-launch form: a region of (score, epoch) words per launch of the timed loop (the product: per layer, the epoch advancing per token)
-        unsigned long long *tags, *err; unsigned* epoch; float* sc2; CK(hipMalloc(&sc2, (size_t)H * seq * 4));
-        CK(hipMalloc(&tags, (size_t)50 * H * seq * 8)); CK(hipMalloc(&err, 8)); CK(hipMemset(err, 0, 8)); CK(hipMalloc(&epoch, 4));
-        CK(hipFuncSetAttribute((const void*)attn_spread_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        const size_t lds = fv_lds + attn_spread_extra_lds_floats() * 4;
-        float best = 1e9;
-        for (unsigned rep = 0; rep < 4; rep++) {
-            const unsigned e = rep + 1; CK(hipMemcpy(epoch, &e, 4, hipMemcpyHostToDevice));
-            CK(hipEventRecord(e0, 0));
-            for (int i = 0; i < 50; i++) {
-                RefAttnParams mp = ap; mp.sc_tags = tags + (size_t)i * H * seq; mp.epoch = epoch; mp.err = err; mp.sc = sc2;
-                hipLaunchKernelGGL(attn_spread_chain_kernel, dim3(H, hs / kValCols), dim3(kFvSoftWaves * 64), lds, 0, mp);
-            }
-            CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
-            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = ms < best ? ms : best;
-        }
-        unsigned long long ew; CK(hipMemcpy(&ew, err, 8, hipMemcpyDeviceToHost));
-        std::vector<float> x1(dim), x2(dim);
-        CK(hipMemcpy(x1.data(), xb, dim * 4, hipMemcpyDeviceToHost));
-        hipLaunchKernelGGL(attn_scores_chain_kernel, dim3(H, ngroups), dim3(64), 0, 0, ap);
-        hipLaunchKernelGGL(attn_softmax_values_chain_kernel, dim3(H, hs / kValCols), dim3(kFvSoftWaves * 64), fv_lds, 0, ap);
-        CK(hipMemcpy(x2.data(), xb, dim * 4, hipMemcpyDeviceToHost));
-        int bad = 0; for (int i = 0; i < dim; i++) bad += memcmp(&x1[i], &x2[i], 4) != 0;
-        printf("pos %d ONE launch (scores + softmax + values): %.2f us; error word %llx; outputs that differ from the two launches': %d\n", pos, best * 1e3 / 50, ew, bad);
-    }
     for (int what = 0; what < 3; what++) {
         float best = 1e9;
         for (int rep = 0; rep < 4; rep++) {
