@@ -557,7 +557,10 @@ struct ChainParams {
     // row groups do not divide by the compute units ends when the CUs with one group more are through: llama2-7B's W1|W3 is 1 376 groups on 256 CUs,
     // six on 96 of them and five on the rest; with the last 96 groups as 192 halves it is five and a half at most.
     int half_from;
+    int half_all;          // [r6] 1: EVERY row group is walked as two half groups (grid = 2 x groups; "chain_resid_half": an experiment on Wo's 256 groups -- two waves per
+                           // CU on different SIMDs instead of one)
     float* xout;           // CNORM_LEAD: the leader also stores the normalised vector here (a Device::rmsnorm recorded in front of the run, rama_api.hip flush_mm)
+    int lane_reduce;       // [r6] the order of cpu.rs:148 `v.reduce_add()`: LANES_PAIRWISE | LANES_STRIDED | LANES_SEQUENTIAL (ref_order.hpp; "lane_reduce")
 };
 
 // a descriptor whose inputs the compiler must take as wave-uniform (they are: kernel arguments and blockIdx)
@@ -681,7 +684,8 @@ __device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in)
     // (the quotient comes out of the vector ALU: without readfirstlane everything derived from it -- the buffer
     // descriptors above all -- counts as divergent and every load turns into a waterfall loop)
     int half = -1, bid_g = bid;
-    if (W == 1 && p.half_from > 0 && bid >= p.half_from) { half = (bid - p.half_from) & 1; bid_g = p.half_from + ((bid - p.half_from) >> 1); }      // (uniform)
+    if (W == 1 && p.half_all) { half = bid & 1; bid_g = bid >> 1; }                                                                                   // (uniform)
+    else if (W == 1 && p.half_from > 0 && bid >= p.half_from) { half = (bid - p.half_from) & 1; bid_g = p.half_from + ((bid - p.half_from) >> 1); }      // (uniform)
     const int m = __builtin_amdgcn_readfirstlane(bid_g / groups), g = __builtin_amdgcn_readfirstlane(bid_g - m * groups);
     const float* Wm = m == 0 ? p.w[0] : (m == 1 ? p.w[1] : p.w[2]);
     const int nblk = p.K >> 4;
@@ -904,9 +908,18 @@ __device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in)
     }
     CHAIN_STAMP(4);
     if (W > 1 && ((nchunk - 1) % W) != wave) return;             // the wave that summed the last chunk finishes the rows
-    // (v0 + v1) + (v2 + v3): both adds are commutative, so every lane of the quad ends with the row's bits
-    const float t2 = v + dpp_mov<0xB1>(v);                       // quad_perm [1,0,3,2]
-    const float d = t2 + dpp_mov<0x4E>(t2);                      // quad_perm [2,3,0,1]
+    // cpu.rs:148 reduce_add of the quad's four chains, in the order the host selected: every lane of the quad ends with the row's bits
+    // (a uniform branch at the very end of the launch)
+    float d;
+    if (p.lane_reduce == LANES_STRIDED) {                         // (v0 + v2) + (v1 + v3): both adds are commutative
+        const float t2 = v + dpp_mov<0x4E>(v);                    // quad_perm [2,3,0,1]
+        d = t2 + dpp_mov<0xB1>(t2);                               // quad_perm [1,0,3,2]
+    } else if (p.lane_reduce == LANES_SEQUENTIAL) {               // ((v0 + v1) + v2) + v3: every lane walks the quad front to back
+        d = ((dpp_mov<0x00>(v) + dpp_mov<0x55>(v)) + dpp_mov<0xAA>(v)) + dpp_mov<0xFF>(v);      // quad_perm [0,0,0,0] .. [3,3,3,3]
+    } else {                                                      // (v0 + v1) + (v2 + v3)
+        const float t2 = v + dpp_mov<0xB1>(v);                    // quad_perm [1,0,3,2]
+        d = t2 + dpp_mov<0x4E>(t2);                               // quad_perm [2,3,0,1]
+    }
     if (EPI == CEPI_STORE) {
         if (j == 0 && row < p.rows) { float* o = m == 0 ? p.o[0] : (m == 1 ? p.o[1] : p.o[2]); o[row] = d; }      // (nmat > 1: a run of Device::matmul calls as one launch)
     } else if (EPI == CEPI_RESID) {
@@ -937,7 +950,9 @@ __device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in)
     }
 }
 
-template <int W, int D, int XD, int EPI, int NORM = CNORM_NONE, int LR = 64>
+// TAG: nothing but a name -- the same body under another symbol, so that a kernel trace tells two uses of one geometry apart ([r6] TAG 1 = the SQUARE
+// residual product, Wo; round 5's traces showed Wo and W2 as one row with their mean)
+template <int W, int D, int XD, int EPI, int NORM = CNORM_NONE, int LR = 64, int TAG = 0>
 __global__ __launch_bounds__(W * 64) void gemv_chain_kernel(ChainParams p) {
     gemv_chain_body<W, D, XD, EPI, NORM, LR>(p, (int)blockIdx.x);
 }
@@ -965,6 +980,7 @@ struct GemmChainParams {
     int n_tok;
     int pos0; const float* fr; const float* fi; int head_size; float* kc; float* vc;      // QKV: token t sits at pos0 + t; this layer's cache slabs
     const SeqSlot* seqs; size_t layer_off;   // QKV, independent sequences: token t at seqs[t].pos, its caches at seqs[t].kc / .vc + layer_off
+    int lane_reduce;        // [r6] as ChainParams::lane_reduce
 };
 constexpr int kGcWaves = 4, kGcThreads = kGcWaves * 64;
 constexpr int kGcBlocks = 8;             // blocks of 16 floats per chunk (8 KiB of weights; 32 KiB of LDS per workgroup at 16 tokens: four workgroups per CU)
@@ -1124,8 +1140,18 @@ __global__ __launch_bounds__(kGcThreads) void gemm_chain_kernel(GemmChainParams 
     for (int tt = 0; tt < TPW; tt++) {
         const int t = wave * TPW + tt;
         const float v = TPW == 1 ? acc1 : acc2[tt / 2][tt & 1];
-        const float t2 = v + __shfl_xor(v, 16);                  // (v0 + v1) + (v2 + v3)
-        const float d = t2 + __shfl_xor(t2, 32);
+        // cpu.rs:148 reduce_add: the four chains of a row sit 16 lanes apart (chain j on lanes 16 j ..)
+        float d;
+        if (p.lane_reduce == LANES_STRIDED) {                     // (v0 + v2) + (v1 + v3)
+            const float t2 = v + __shfl_xor(v, 32);
+            d = t2 + __shfl_xor(t2, 16);
+        } else if (p.lane_reduce == LANES_SEQUENTIAL) {           // ((v0 + v1) + v2) + v3
+            const int l16 = (int)(threadIdx.x & 15);
+            d = ((__shfl(v, l16) + __shfl(v, l16 + 16)) + __shfl(v, l16 + 32)) + __shfl(v, l16 + 48);
+        } else {                                                  // (v0 + v1) + (v2 + v3)
+            const float t2 = v + __shfl_xor(v, 16);
+            d = t2 + __shfl_xor(t2, 32);
+        }
         const float other = __shfl_xor(d, 1);                    // the neighbouring row (RoPE pair / W3 row)
         if (t >= p.n_tok) continue;                              // uniform per wave
         if (EPI == CEPI_STORE) {

@@ -295,8 +295,11 @@ void drop_tiled(rama_ctx* ctx, rama_model* m) {
 
 // the live model that owns these weights (matched on its first layer tensor, or the classifier of a layerless stage)
 rama_model* model_of(const rama_weights* w) {
-    for (rama_model* m : g_models)
+    for (rama_model* m : g_models) {
+        // (an ADOPTED model is the caller's tensors: another rama_weights that shares wq but not the rest is another model)
+        if (m->adopted && (m->w.wk != w->wk || m->w.wv != w->wv || m->w.wo != w->wo || m->w.w1 != w->w1 || m->w.w2 != w->w2 || m->w.w3 != w->w3)) continue;
         if ((w->wq && m->w.wq == w->wq) || (!w->wq && w->wcls && m->w.wcls == w->wcls && !m->w.wq)) return m;
+    }
     return nullptr;
 }
 
@@ -384,6 +387,17 @@ extern "C" void rama_internal_note_alloc(const float* base, size_t n) {
     g_allocs[base] = n;
 }
 extern "C" void rama_internal_drop_graphs(rama_ctx* ctx);      // rama_api.hip: captured graphs hold the copies' addresses
+// [r6] the union interval of every CALLER-OWNED range a copy was derived from (an adopted model's tensors, a view's tensor); it only grows.  A library entry
+// that writes device memory asks rama_internal_note_write first: outside the interval (the run state of a host whose weights lie elsewhere; every write while
+// nothing was derived) that is two atomic loads, inside it the registries are searched like rama_copy_h2d_f32 does.
+std::atomic<uintptr_t> g_derived_lo{UINTPTR_MAX}, g_derived_hi{0};
+static void note_derived(const float* p, size_t n) {
+    const uintptr_t a = (uintptr_t)p, b = a + n * sizeof(float);
+    uintptr_t lo = g_derived_lo.load(std::memory_order_relaxed);
+    while (a < lo && !g_derived_lo.compare_exchange_weak(lo, a, std::memory_order_relaxed)) { }
+    uintptr_t hi = g_derived_hi.load(std::memory_order_relaxed);
+    while (b > hi && !g_derived_hi.compare_exchange_weak(hi, b, std::memory_order_relaxed)) { }
+}
 // internal: [base, base + n) is about to be freed or overwritten -- every derived copy made from it goes (an adopted model that holds a tensor
 // in the range is dissolved, a view's chain-order copy is freed); `freed`: the allocation itself leaves the table.  Cheap when nothing was derived.
 extern "C" int rama_internal_forget_range(rama_ctx* ctx, const float* base, size_t n, int freed) {
@@ -410,10 +424,19 @@ extern "C" int rama_internal_forget_range(rama_ctx* ctx, const float* base, size
     g_copies_gen++;
     int rc = ctx ? rama_sync(ctx) : 0;
     if (ctx) rama_internal_drop_graphs(ctx);
-    for (rama_model* m : gone) { drop_chain(ctx, m); drop_tiled(ctx, m); delete m; }
+    for (rama_model* m : gone) {
+        { std::lock_guard<std::mutex> bl(m->build_mu); }      // whoever found it before it left the list and is making a copy right now has finished (as rama_model_free)
+        drop_chain(ctx, m); drop_tiled(ctx, m); delete m;
+    }
     for (float* v : views) { std::lock_guard<std::mutex> lk(g_allocs_mu); g_allocs.erase(v); }
     for (float* v : views) if (hipFree(v) != hipSuccess && !rc) rc = RAMA_EIO;
     return rc;
+}
+
+extern "C" int rama_internal_note_write(rama_ctx* ctx, const float* dst, size_t n) {
+    const uintptr_t a = (uintptr_t)dst, b = a + n * sizeof(float);
+    if (b <= g_derived_lo.load(std::memory_order_relaxed) || a >= g_derived_hi.load(std::memory_order_relaxed)) return 0;
+    return rama_internal_forget_range(ctx, dst, n, 0);
 }
 
 // internal: weights that belong to no model (uploaded tensor by tensor and passed to rama_forward* as a rama_weights) are ADOPTED -- a model
@@ -432,6 +455,7 @@ extern "C" int rama_internal_adopt(rama_ctx* ctx, const rama_config* cfg, const 
         const float* base; size_t n;
         if (!t.first || !alloc_of(t.first, &base, &n) || t.first + t.second > base + n) { delete m; return 0; }
     }
+    for (auto& t : model_tensors(m)) note_derived(t.first, t.second);
     g_models.push_back(m);
     return 0;
 }
@@ -460,6 +484,7 @@ extern "C" const float* rama_internal_chain_view(rama_ctx* ctx, const float* a, 
     rama_sync(ctx);
     hipLaunchKernelGGL(chain_weights_kernel<false>, dim3(4096), dim3(256), 0, 0, dst, src, (const float*)nullptr, nmat, rows, K);
     if (hipDeviceSynchronize() != hipSuccess) { rama_free(ctx, dst); return nullptr; }
+    note_derived(src, nmat * per);
     { std::lock_guard<std::mutex> lk(g_chain_mu); g_chain.push_back({src, nullptr, per, nmat, rows, K, dst, dst}); }
     return rama_internal_chain_lookup(a, rows, K);
 }

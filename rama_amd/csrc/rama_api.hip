@@ -32,6 +32,11 @@ extern "C" void rama_internal_note_alloc(const float* base, size_t n);          
 extern "C" int rama_internal_forget_range(rama_ctx* ctx, const float* base, size_t n, int freed);      // ... the copies derived from a range go
 extern "C" int rama_internal_adopt(rama_ctx* ctx, const rama_config* cfg, const rama_stage* st, const rama_weights* w);
 extern "C" const float* rama_internal_chain_view(rama_ctx* ctx, const float* a, int rows, int K, int capturing);
+extern "C" int rama_internal_note_write(rama_ctx* ctx, const float* dst, size_t n);                    // model.hip: an entry is about to write [dst, dst + n) on the device
+// every entry that writes device memory the caller names says so first: a chain-order copy DERIVED from a tensor uploaded by the caller (an adopted model's, a
+// view's) must not outlive a device-side write into that tensor (rama_fill_synth re-seeding it, an op's output landing in it).  Two atomic loads when the
+// range lies outside everything copies were derived from.
+#define RAMA_WRITES(c, p, n) do { if ((p) && (n)) { const int rw_ = rama_internal_note_write((c), (p), (size_t)(n)); if (rw_) return rw_; } } while (0)
 
 // ---------------------------------------------------------------- error plumbing
 
@@ -99,7 +104,7 @@ struct rama_ctx {
     struct StageGraph { GraphCache g; rama_stage st{}; int variant = 0; unsigned long long used = 0; };
     std::vector<StageGraph> sg;        // rama_forward / rama_forward_stage* in graph mode: one graph per (state, stage, attention variant)
     unsigned long long sg_clock = 0;
-    GraphCache gc[6];                  // [0..2] one step per graph, [3..5] tune_graph_steps steps per graph; by attention variant: [0] one 16-wave workgroup per head, [1] split-T (long contexts), [2] one 4-wave workgroup per head (short contexts)
+    GraphCache gc[8];                  // [0..3] one step per graph, [4..7] tune_graph_steps steps per graph; by attention variant (attn_variant)
     KProf kp;
     int cu_count = 0;
     hipEvent_t cur_start = nullptr, cur_stop = nullptr;   // events the next profiled launch carries
@@ -110,6 +115,14 @@ struct rama_ctx {
     int tune_tol = 0;                      // "ref_order" = 2, the tolerance-mode experiment: the chain-order matvecs (the reference's rounding sequence) with the layer
                                            // norms folded into them as tree-shaped sums and the fast attention -- 0.72 of the roofline, but 1.4e-4 from the CPU path at
                                            // llama2-7B x 200 positions, no closer than the fast path; kept as the per-op A/B instrument
+    int tune_bar = 0;                      // [r6] "ref_order" = 3, BAR mode: parity mode's launches (chain-order matvecs, exact norms, the exact attention) up to position
+                                           // "bar_pos", the FAST path's attention from there on -- not bit-identical, but measured <= 1e-4 from the CPU path over the WHOLE
+                                           // 2 048-position context at llama2-7B depth (profiles/r06_tolerance_sweep_7b_2048pos.jsonl: fast attention at every position 9.75e-5;
+                                           // every other single swap >= 1.3e-4 already at 200 positions), where the exact attention costs 25 us a layer at position 1 900
+    int tune_bar_pos = kSpreadAttnPos;     // ... the first position that takes the fast attention (clamped to the spread attention's switch and to 256: below it one exact variant)
+    bool bar_fast = false;                 // ... the steps being enqueued / captured are at or behind it
+    int tune_lane_reduce = 0;              // [r6] parity mode: the order of the final 4-lane sum of cpu.rs:148 `v.reduce_add()` (wide::f32x4 leaves it to the build's target
+                                           // features): 0 pairwise (l0+l1)+(l2+l3), 1 strided (l0+l2)+(l1+l3), 2 sequential ((l0+l1)+l2)+l3 -- the oracle's switch of the same name
     int tune_tol_mask = 0;                 // tolerance mode, A/B: ops swapped for the fast path's (1 qkv, 2 wo, 4 w13, 8 w2, 16 cls) or parity mode's (32 attention, 64 norms)
     int tune_chain = 1;                    // parity mode streams the model's chain-order weight copy (chain.hpp); 0: ref_order.hpp's one-thread-per-row kernels
     int tune_chain_d = 0;                  // chain-order matvec geometry: 0 = by row groups per CU, else 100 W + D (waves per group, blocks per wave in flight)
@@ -124,6 +137,7 @@ struct rama_ctx {
     unsigned long long* topp_bm = nullptr;  // ... the blocks' running masses
     float* topp_approx = nullptr;           // ... the mass in front of every entry of the whole order
     void* topp_dist = nullptr;              // topp_pick_dist_kernel's hand-off words: items | hdr | cross | epoch | bad
+    bool topp_dist_dirty = false;           // ... a distributed pick has been enqueued since its error word was last read (else a synchronising exit need not read it)
     int tune_spread_pos = kSpreadAttnPos;   // parity mode: from this position on the attention is spread over the chip (scores | softmax + values)
     int tune_attn_fv = 1;                   // parity mode, long contexts: softmax + value chains as one launch (0: two launches)
     int tune_topp_dist = 1;                 // 1: the running sums by up to 32 workgroups in one launch (topp_pick.hpp); 0: one workgroup's scan rounds
@@ -167,6 +181,7 @@ struct rama_ctx {
     int tune_chain_norm = 1;               // parity mode, dim <= 512: the layer norms folded into the matvecs that consume them
     int tune_chain_split = 1;              // parity mode: the row groups that do not divide by the compute units walked as half groups (chain.hpp half_from)
     int tune_chain_lead_w = 0;             // parity mode: waves per row group of the launches with a leader norm (0: by the number of row groups)
+    int tune_chain_resid_half = 0;         // [r6] experiment: Wo's row groups as half groups throughout (chain.hpp half_all)
     int tune_chain_resid_d = -1;           // parity mode: 100 W + D for the residual products (Wo, W2) only; 0: by the number of row groups like the others; -1: W = 1, D = 32 when a CU holds one group
     // [r5] a run of Device::apply_position calls on consecutive heads (infer.rs:25-29: n_heads calls per layer, 1 024 per llama2-7B token, each a launch of
     // its own) is ISSUED AS ONE LAUNCH: a call only records (q, k, table rows, head size); the next call extends the run when it continues it, and
@@ -590,7 +605,7 @@ static int launch_matvec_ref(rama_ctx* c, int nmat, float* const o[3], const flo
     REQUIRE(K % 4 == 0 && K > 0 && rows > 0, RAMA_EINVAL, "matmul: width % 4 != 0 (the reference CPU body panics here, cpu.rs:142-143)");
     RefMatParams p{};
     for (int m = 0; m < nmat; m++) { p.w[m] = W[m]; p.o[m] = o[m]; }
-    p.x = x; p.K = K; p.rows = rows;
+    p.x = x; p.K = K; p.rows = rows; p.lane_reduce = c->tune_lane_reduce;
     hipLaunchKernelGGL(matvec_ref_kernel, dim3((rows + 63) / 64, nmat), dim3(64), 0, c->stream, p);
     LAUNCHCHK();
     return 0;
@@ -629,6 +644,7 @@ static int launch_chain(rama_ctx* c, ChainParams& p, int norm = CNORM_NONE) {
     REQUIRE(p.K % 16 == 0 && p.K > 0 && p.rows > 0, RAMA_EINVAL, "chain-order matvec: width must be a multiple of 16");
     REQUIRE((p.nw != nullptr) == (norm != CNORM_NONE), RAMA_EINVAL, "chain-order matvec: a folded norm needs its gain vector");
     const int groups = p.nmat * ((p.rows + 15) / 16);
+    p.lane_reduce = c->tune_lane_reduce;
     int W, D;
     if (c->tune_chain_d > 0) { W = c->tune_chain_d / 100; D = c->tune_chain_d % 100; }
     else if (EPI == CEPI_RESID && norm == CNORM_NONE && c->tune_chain_resid_d > 0) { W = c->tune_chain_resid_d / 100; D = c->tune_chain_resid_d % 100; }
@@ -649,12 +665,16 @@ static int launch_chain(rama_ctx* c, ChainParams& p, int norm = CNORM_NONE) {
     REQUIRE(lds <= 64 * 1024, RAMA_EUNSUP, "chain-order matvec: row longer than ~15800 floats");
     // [r5] one wave per row group and more groups than compute units: the groups that do not divide by the CUs as halves (chain.hpp half_from; "chain_split")
     int nblocks = groups;
-    p.half_from = 0;
+    p.half_from = 0; p.half_all = 0;
     if (c->tune_chain_split && W == 1 && D == 16 && c->tune_chain_d <= 0 && norm != CNORM_EXACT && norm != CNORM_TREE) {
         const int cus = std::max(c->cu_count, 1), rem = groups % cus;
         // (more than half the CUs with a group more -- the classifier's 2 000 groups: the halves would give some CUs two again)
         if (groups > cus && rem > 0 && 2 * rem <= cus) { p.half_from = groups - rem; nblocks = groups + rem; }
     }
+    // [r6] "chain_resid_half" (an experiment, default 0): the square residual product (Wo) with at most one row group per compute unit as HALF groups throughout --
+    // two one-wave workgroups per CU, each with its own ring of 32 half blocks
+    const bool wo_like = EPI == CEPI_RESID && norm == CNORM_NONE && p.K == p.rows;
+    if (c->tune_chain_resid_half && wo_like && W == 1 && D == 32 && c->tune_chain_d <= 0) { p.half_all = 1; nblocks = 2 * groups; }
     const dim3 grid(nblocks);
     if (norm == CNORM_LEAD) {      // the exact sum by a leader workgroup of this launch (grid + 1); geometry as without a norm
         REQUIRE(D == 16 && (W == 1 || W == 2) && p.K % 8 == 0 && p.K <= 4096 * W && (EPI == CEPI_QKV || EPI == CEPI_SWIGLU || EPI == CEPI_STORE) && p.lead && p.epoch && p.err,
@@ -692,6 +712,7 @@ static int launch_chain(rama_ctx* c, ChainParams& p, int norm = CNORM_NONE) {
     }
 #define RAMA_CHAIN(W_, D_) RAMA_LAUNCH(c, (gemv_chain_kernel<W_, D_, 4, EPI>), grid, dim3(W_ * 64), lds, p)
     if (W == 1 && D == 16) RAMA_CHAIN(1, 16);
+    else if (W == 1 && D == 32 && wo_like) RAMA_LAUNCH(c, (gemv_chain_kernel<1, 32, 4, EPI, CNORM_NONE, 64, 1>), grid, dim3(64), lds, p);      // (Wo under a name of its own)
     else if (W == 1 && D == 32) RAMA_CHAIN(1, 32);
     else if (W == 2 && D == 16) RAMA_CHAIN(2, 16);
     else if (W == 2 && D == 32) RAMA_CHAIN(2, 32);
@@ -754,7 +775,7 @@ static int ensure_attn_scores(rama_ctx* c, int n_heads, int seq_len) {
     if (need <= c->attn_scores_floats) return 0;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(c->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return 0; }
-    if (c->attn_scores) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->attn_scores)); c->attn_scores = nullptr; c->attn_scores_floats = 0; }
+    if (c->attn_scores) { HIPCHK(hipStreamSynchronize(c->stream)); drop_graph(c); HIPCHK(hipFree(c->attn_scores)); c->attn_scores = nullptr; c->attn_scores_floats = 0; }      // (graphs captured for a smaller model hold the old address)
     HIPCHK(hipMalloc(&c->attn_scores, need * sizeof(float)));
     c->attn_scores_floats = need;
     return 0;
@@ -819,6 +840,7 @@ static int launch_attention_chain(rama_ctx* c, float* xb, float* att, const floa
 static inline bool ranges_overlap(const float* p0, size_t n0, const float* p1, size_t n1) { return p0 < p1 + n1 && p1 < p0 + n0; }
 int rama_array_add(rama_ctx* c, float* t, const float* s, size_t n) {
     REQUIRE(c && (n == 0 || (t && s)), RAMA_EINVAL, "array_add: NULL argument");
+    RAMA_WRITES(c, t, n);
     // [r5] the recorded matmul whose output this call adds to `t` (infer.rs:35-37, :46-47): ONE launch with the residual epilogue (product stored, t += product)
     if (c->mm.count == 1 && !c->mm.norm && !c->nrm.on && !c->rope.count && !c->ew.kind && c->tune_ref_order && c->tune_resid_fold && s == c->mm.o[0] && n == (size_t)c->mm.rows &&
         aligned16(t) && !ranges_overlap(t, n, c->mm.x, (size_t)c->mm.K) && !ranges_overlap(t, n, s, n)) {
@@ -834,6 +856,7 @@ int rama_array_add(rama_ctx* c, float* t, const float* s, size_t n) {
 }
 int rama_array_mult(rama_ctx* c, float* t, const float* s, size_t n) {
     REQUIRE(c && (n == 0 || (t && s)), RAMA_EINVAL, "array_mult: NULL argument");
+    RAMA_WRITES(c, t, n);
     if (c->ew.kind == 1 && !c->rope.count && !c->mm.count && c->ew.t == t && c->ew.n == n && n && !ranges_overlap(s, n, t, n)) {      // the recorded sinu and this product: one launch
         c->ew.kind = 0;
         if (c->tune_ref_order) hipLaunchKernelGGL(sinu_mult_ref_kernel, dim3(ew_grid(n)), dim3(256), 0, c->stream, t, s, n);
@@ -848,6 +871,7 @@ int rama_array_mult(rama_ctx* c, float* t, const float* s, size_t n) {
 int rama_sinu(rama_ctx* c, float* o, size_t n) {
     RAMA_ENTER(c);
     REQUIRE(c && (n == 0 || o), RAMA_EINVAL, "sinu: NULL argument");
+    RAMA_WRITES(c, o, n);
     if (!n) return 0;
     if (c->tune_ew_batch && c->own_stream) { c->ew.kind = 1; c->ew.t = o; c->ew.s = nullptr; c->ew.n = n; return 0; }      // recorded: the product that usually follows takes it along
     if (c->tune_ref_order) hipLaunchKernelGGL(sinu_ref_kernel, dim3(ew_grid(n)), dim3(256), 0, c->stream, o, n);
@@ -856,6 +880,7 @@ int rama_sinu(rama_ctx* c, float* o, size_t n) {
 }
 int rama_copy_from_slice(rama_ctx* c, float* t, const float* s, size_t n) {
     REQUIRE(c && (n == 0 || (t && s)), RAMA_EINVAL, "copy_from_slice: NULL argument");
+    RAMA_WRITES(c, t, n);
     // [r5] infer.rs:20-33 as the fused entry runs it: a pending run of three matmuls (a recorded norm in front, perhaps), every head of its first two outputs
     // rotated, and now its second and third outputs copied into cache rows -- ONE launch with the Wq|Wk|Wv epilogue.  The first copy is recorded, the second
     // issues the launch; anything that does not fit issues what is pending in program order.
@@ -904,6 +929,7 @@ int rama_copy_from_slice(rama_ctx* c, float* t, const float* s, size_t n) {
 int rama_rmsnorm(rama_ctx* c, float* o, const float* x, const float* w, size_t n) {
     RAMA_ENTER(c);
     REQUIRE(c && o && x && w && n > 0, RAMA_EINVAL, "rmsnorm: bad argument");
+    RAMA_WRITES(c, o, n);
     if (c->tune_ref_order && c->tune_chain && rmsnorm_chain_ok(n) && c->tune_norm_fold && c->tune_chain_lead && c->tune_matmul_batch && c->own_stream && c->tune_chain_d <= 0 &&
         c->tune_chain_lead_w <= 0 && c->kp.kernel_id < 0 && n % 16 == 0 && n <= 4096 && n >= 64 && aligned16(x) && aligned16(w) && aligned16(o) && (o + n <= x || x + n <= o) && c->lead_slots && c->pbar) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -919,6 +945,7 @@ int rama_rmsnorm(rama_ctx* c, float* o, const float* x, const float* w, size_t n
 }
 int rama_apply_position(rama_ctx* c, float* q, float* k, const float* pr, const float* pi, size_t head_size) {
     REQUIRE(c && q && k && pr && pi && head_size >= 2, RAMA_EINVAL, "apply_position: bad argument");
+    RAMA_WRITES(c, q, head_size); RAMA_WRITES(c, k, head_size);
     // (whatever was recorded before this call comes first -- except a run of three matmuls whose first two outputs this call starts to rotate, or goes on rotating)
     const bool on_run = c->mm.count == 3 && c->tune_qkv_fold && !c->ew.kind && c->tune_rope_batch && c->own_stream && head_size % 2 == 0 && c->mm.rows % (int)head_size == 0 &&
                         (c->rope.count ? true : (q == c->mm.o[0] && k == c->mm.o[1]));
@@ -946,6 +973,7 @@ int rama_matmul(rama_ctx* c, float* o, const float* a, const float* b, size_t wi
     if (c && (c->rope.count | c->ew.kind)) { const int rf = flush_pending(c); if (rf) return rf; }      // (a pending run of matmuls may be extended by this call, a recorded norm taken along: below)
     REQUIRE(c && o && a && b, RAMA_EINVAL, "matmul: NULL argument");
     REQUIRE(o_cols >= 1, RAMA_EINVAL, "matmul: o_cols == 0");
+    RAMA_WRITES(c, o, o_rows * o_cols);
     int rc = check_matvec_shape(width, o_rows);
     if (rc) { (void)flush_mm(c); return rc; }
     const bool extendable = c->mm.count && c->mm.count < 3 && c->tune_ref_order && o_cols == 1 && c->mm.x == b && c->mm.K == (int)width && c->mm.rows == (int)o_rows;
@@ -986,8 +1014,15 @@ int rama_matmul(rama_ctx* c, float* o, const float* a, const float* b, size_t wi
         rc = flush_mm(c); if (rc) return rc;
         return launch_matvec_ref1(c, o, a, b, (int)width, (int)o_rows);
     }
+    // (none of the paths below records: whatever is pending -- a parity-mode Device::rmsnorm whose output this call may read -- is issued first)
+    rc = flush_mm(c); if (rc) return rc;
     if (o_cols != 1) {   // forward() never takes this path (o_cols is always 1, infer.rs:20-51)
         size_t n = o_rows * o_cols;
+        if (c->tune_ref_order) {      // the reference's rounding order for this shape too (cpu.rs:137-151)
+            REQUIRE(width % 4 == 0, RAMA_EINVAL, "matmul: width % 4 != 0 (the reference CPU body panics here, cpu.rs:142-143)");
+            hipLaunchKernelGGL(matmul_cols_ref_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, o, a, b, (int)width, (int)o_rows, (int)o_cols, c->tune_lane_reduce);
+            LAUNCHCHK(); return 0;
+        }
         hipLaunchKernelGGL(matmul_generic, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, o, a, b, (int)width, (int)o_rows, (int)o_cols);
         LAUNCHCHK(); return 0;
     }
@@ -1000,6 +1035,7 @@ int rama_matmul(rama_ctx* c, float* o, const float* a, const float* b, size_t wi
 int rama_softmax(rama_ctx* c, float* x, size_t n) {
     RAMA_ENTER(c);
     REQUIRE(c && x && n > 0, RAMA_EINVAL, "softmax: bad argument");
+    RAMA_WRITES(c, x, n);
     if (c->tune_ref_order && c->tune_chain && rmsnorm_chain_ok(n)) {
         hipLaunchKernelGGL(softmax_chain_kernel, dim3(1), dim3(kNormThreads), (n + (n >> 5) + 2) * sizeof(float), c->stream, x, (int)n);
         LAUNCHCHK(); return 0;
@@ -1020,7 +1056,7 @@ static int ensure_attn_part(rama_ctx* c, const rama_config* cfg) {
     const int hs = cfg->dim / cfg->n_heads;
     const size_t need = (size_t)cfg->n_heads * attn_nsplit(c, cfg->n_heads) * (hs + 4);
     if (need > c->attn_part_floats) {
-        if (c->attn_part) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->attn_part)); c->attn_part = nullptr; }
+        if (c->attn_part) { HIPCHK(hipStreamSynchronize(c->stream)); drop_graph(c); HIPCHK(hipFree(c->attn_part)); c->attn_part = nullptr; }      // (graphs captured for a smaller model hold the old address)
         HIPCHK(hipMalloc(&c->attn_part, need * sizeof(float)));
         c->attn_part_floats = need;
     }
@@ -1060,17 +1096,21 @@ static bool small_attn_at(const rama_ctx* c, int pos, bool split, int dim) {
 
 // Which launches a step at `pos` consists of (one hipGraph per variant): fast mode 0 = one 16-wave workgroup per head,
 // 1 = split-T (long contexts), 2 = fewer waves per head (short contexts); parity mode 0 = 4 waves per head, 1 = 8 (pos >= 256),
-// 2 = launches spread over the chip (pos >= tune_spread_pos)
+// 2 = launches spread over the chip (pos >= tune_spread_pos); bar mode 0 = parity mode's 4 waves per head below bar_pos_eff, from there on the fast
+// mode's variants as 1 = split-T, 2 = fewer waves per head, 3 = one 16-wave workgroup per head
+static int bar_pos_eff(const rama_ctx* c) { return std::max(0, std::min(std::min(c->tune_bar_pos, c->tune_spread_pos), kLongAttnPos)); }
 static int attn_variant(const rama_ctx* c, const rama_config* cfg, int pos) {
-    if (c->tune_ref_order && !c->tune_tol) return pos >= c->tune_spread_pos ? 2 : (pos >= kLongAttnPos ? 1 : 0);
+    if (c->tune_ref_order && !c->tune_tol && !(c->tune_bar && pos >= bar_pos_eff(c))) return pos >= c->tune_spread_pos ? 2 : (pos >= kLongAttnPos ? 1 : 0);
     const bool split = pos >= split_threshold(c, cfg);
-    return split ? 1 : (small_attn_at(c, pos, split, cfg->dim) ? 2 : 0);
+    const int v = split ? 1 : (small_attn_at(c, pos, split, cfg->dim) ? 2 : 0);
+    return (c->tune_ref_order && c->tune_bar && v == 0) ? 3 : v;
 }
 static int apply_attn_variant(rama_ctx* c, const rama_config* cfg, int pos) {
     c->split_attn = pos >= split_threshold(c, cfg);
     c->small_attn = small_attn_at(c, pos, c->split_attn, cfg->dim);
     c->long_attn = pos >= kLongAttnPos;
     c->spread_attn = pos >= c->tune_spread_pos;
+    c->bar_fast = c->tune_ref_order && !c->tune_tol && c->tune_bar && pos >= bar_pos_eff(c);
     return c->variant = attn_variant(c, cfg, pos);
 }
 
@@ -1150,7 +1190,12 @@ int rama_multi_head_attention(rama_ctx* c, float* xb, float* att, const float* q
     RAMA_ENTER(c);
     REQUIRE(c && xb && att && q && key_cache && value_cache, RAMA_EINVAL, "multi_head_attention: NULL argument");
     REQUIRE(pos >= 0 && pos < seq_len && layer >= 0 && n_heads > 0 && n_heads * head_size == dim, RAMA_EINVAL, "multi_head_attention: bad shape");
+    RAMA_WRITES(c, xb, dim); RAMA_WRITES(c, att, (size_t)n_heads * seq_len);
     const size_t lo = (size_t)layer * seq_len * dim;   // cpu.rs:28
+    if (c->tune_ref_order && c->tune_bar && !c->tune_tol && pos >= bar_pos_eff(c)) {      // bar mode behind its switch: the fast path's single-workgroup kernel (the 1:1 path prepares no split-T scratch)
+        c->small_attn = small_attn_at(c, pos, false, dim);
+        return launch_attention(c, xb, att, q, key_cache + lo, value_cache + lo, nullptr, pos, dim, head_size, seq_len, n_heads);
+    }
     if (c->tune_ref_order && c->tune_chain && attn_chain_ok(head_size, seq_len) && aligned16(q) && aligned16(key_cache + lo) && aligned16(value_cache + lo) && dim % 4 == 0)
         return launch_attention_chain(c, xb, att, q, key_cache + lo, value_cache + lo, nullptr, pos, dim, head_size, seq_len, n_heads, pos >= kLongAttnPos, pos >= c->tune_spread_pos);
     if (c->tune_ref_order) return launch_attention_ref(c, xb, att, q, key_cache + lo, value_cache + lo, nullptr, pos, dim, head_size, seq_len, n_heads);
@@ -1200,6 +1245,7 @@ int rama_ref_expf(rama_ctx* c, float* o, const float* x, size_t n) {
 int rama_fill_synth(rama_ctx* c, float* dst, size_t n, uint64_t seed, uint64_t tag, uint64_t offset, float scale, float bias) {
     RAMA_ENTER(c);
     REQUIRE(c && (n == 0 || dst), RAMA_EINVAL, "fill_synth: NULL argument");
+    RAMA_WRITES(c, dst, n);
     if (!n) return 0;
     const uint64_t base = offset + tag * 0x9E3779B97F4A7C15ULL + seed * 0xD1B54A32D192ED03ULL;
     int grid = (int)std::min<size_t>((n + 255) / 256, 1 << 16);
@@ -1473,7 +1519,7 @@ static int enqueue_stage_chain(rama_ctx* c, const rama_config* cfg, const rama_w
         }
         {   // :34
             KTimer kt(c, RAMA_K_ATTN);
-            if (tol && !(mask & 32)) rc = launch_attention(c, s->xb, s->att, s->q, kc, vc, c->ctl, 0, dim, hs, cfg->seq_len, cfg->n_heads, c->split_attn);
+            if ((tol && !(mask & 32)) || c->bar_fast) rc = launch_attention(c, s->xb, s->att, s->q, kc, vc, c->ctl, 0, dim, hs, cfg->seq_len, cfg->n_heads, c->split_attn);
             else rc = launch_attention_chain(c, s->xb, s->att, s->q, kc, vc, c->ctl, 0, dim, hs, cfg->seq_len, cfg->n_heads, c->long_attn, c->spread_attn);
             if (rc) return rc;
         }
@@ -1696,7 +1742,8 @@ static ToppDistParams topp_dist_params(rama_ctx* c) {
 // synchronising exit like the hand-off word above: the call fails and the word is cleared, so that one hiccup neither leaves with rc 0 nor
 // makes every later launch give up its waits after 1 024 spins (bit 0 is what the waiting workgroups watch).  The stream is idle when this runs.
 static int topp_dist_check(rama_ctx* c) {
-    if (!c->topp_dist) return 0;
+    if (!c->topp_dist || !c->topp_dist_dirty) return 0;      // (gated like handoff_dirty: no device round trip per rama_sync of a host-driven loop)
+    c->topp_dist_dirty = false;
     unsigned bad = 0;
     unsigned* word = topp_dist_params(c).bad;
     HIPCHK(hipMemcpy(&bad, word, sizeof bad, hipMemcpyDeviceToHost));
@@ -1710,6 +1757,7 @@ extern "C" int rama_internal_topp_dist_poke(rama_ctx* c, unsigned value) {
     RAMA_ENTER(c);
     if (!c || !c->topp_dist) return 1;
     hipStreamSynchronize(c->stream);
+    c->topp_dist_dirty = true;
     return hipMemcpy(topp_dist_params(c).bad, &value, sizeof value, hipMemcpyHostToDevice) != hipSuccess;
 }
 // diagnostics (not in the C ABI header): bit 0 a hand-off wait of topp_pick_dist_kernel timed out, bit 1 a predicted binade did not hold
@@ -1818,7 +1866,7 @@ static int enqueue_sample_launches(rama_ctx* c, ArgmaxParams fin, float temperat
     }
     if (lds_path && !c->tune_topp_keep_sums) tp.prefix = nullptr;
     // the running sums: the exact parallel scan with the list in LDS, or (longer lists) the staged lane ripple
-    if (dist) hipLaunchKernelGGL(topp_pick_dist_kernel, dim3(kPickMaxChunks), dim3(1024), 0, c->stream, tp, topp_dist_params(c), fin);
+    if (dist) { c->topp_dist_dirty = true; hipLaunchKernelGGL(topp_pick_dist_kernel, dim3(kPickMaxChunks), dim3(1024), 0, c->stream, tp, topp_dist_params(c), fin); }
     else if (lds_path) hipLaunchKernelGGL(topp_pick_scan_kernel, dim3(1), dim3(1024), 0, c->stream, tp, fin);
     else hipLaunchKernelGGL(topp_pick_kernel, dim3(1), dim3(1024), 0, c->stream, tp, fin);
     LAUNCHCHK();
@@ -2066,6 +2114,7 @@ static int run_layers_batched(rama_ctx* c, const rama_config* cfg, const rama_we
 // does (mod.rs:187-194).  *done = false: shape or copies not available, nothing was enqueued.
 template <int EPI>
 static int launch_gemm_chain(rama_ctx* c, GemmChainParams& p) {
+    p.lane_reduce = c->tune_lane_reduce;
     const dim3 grid(p.nmat * ((p.rows + 15) / 16)), block(kGcThreads);
     if (p.n_tok <= 4) hipLaunchKernelGGL((gemm_chain_kernel<1, EPI>), grid, block, gemm_chain_lds_bytes(1), c->stream, p);
     else if (p.n_tok <= 8) hipLaunchKernelGGL((gemm_chain_kernel<2, EPI>), grid, block, gemm_chain_lds_bytes(2), c->stream, p);
@@ -2592,7 +2641,7 @@ int rama_decode_steps(rama_ctx* c, const rama_config* cfg, const rama_weights* w
     REQUIRE(c->host_pos >= 0, RAMA_EINVAL, "decode_steps: call rama_decode_begin first");
     rc = ensure_attn_part(c, cfg); if (rc) return rc;
     if (c->tune_ref_order && c->tune_chain) { rc = ensure_chain_copy(c, cfg, w, nullptr); if (rc) return rc; }
-    if (c->samp_T != 0.0f) { rc = ensure_topp_scratch(c, cfg->vocab_size); if (rc) return rc; }
+    if (c->samp_T != 0.0f) { rc = ensure_topp_scratch(c, cfg->vocab_size); if (rc) return rc; c->topp_dist_dirty = true; }      // (a replayed graph enqueues the pick without passing enqueue_sample)
     REQUIRE(c->host_pos + n_steps <= cfg->seq_len, RAMA_EINVAL, "decode_steps: would run past seq_len");
     const bool graphs = c->graph_mode && c->kp.kernel_id < 0;
     auto variant_at = [&](int pos) { return attn_variant(c, cfg, pos); };
@@ -2603,7 +2652,7 @@ int rama_decode_steps(rama_ctx* c, const rama_config* cfg, const rama_weights* w
         if (graphs) {
             const int M = c->tune_graph_steps > 0 ? c->tune_graph_steps : (cfg->dim <= 1024 ? 4 : 1);
             if (M > 1 && n_steps - i >= M && variant_at(c->host_pos + M - 1) == v) take = M;   // the variant changes at most once, monotonically
-            GraphCache& g = c->gc[v + (take > 1 ? 3 : 0)];
+            GraphCache& g = c->gc[v + (take > 1 ? 4 : 0)];
             if (!same_capture(g, cfg, w, s) || g.steps != take) {
                 if (g.exec) hipGraphExecDestroy(g.exec);
                 if (g.graph) hipGraphDestroy(g.graph);
@@ -2902,6 +2951,13 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
         drop_graph(c);
         return 0;
     }
+    if (!strcmp(key, "chain_resid_half")) {
+        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: chain_resid_half must be 0 or 1");
+        c->tune_chain_resid_half = value;
+        hipStreamSynchronize(c->stream);
+        drop_graph(c);
+        return 0;
+    }
     if (!strcmp(key, "chain_resid_d")) {
         REQUIRE(value == 0 || value == -1 || ((value / 100 == 1 || value / 100 == 2 || value / 100 == 4) && (value % 100 == 16 || value % 100 == 32)), RAMA_EINVAL, "set_tuning: chain_resid_d must be -1, 0 or 100 W + D, W in {1, 2, 4}, D in {16, 32}");
         c->tune_chain_resid_d = value;
@@ -3025,8 +3081,22 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
         return 0;
     }
     if (!strcmp(key, "ref_order")) {
-        REQUIRE(value >= 0 && value <= 2, RAMA_EINVAL, "set_tuning: ref_order must be 0, 1 or 2");
-        c->tune_ref_order = value != 0; c->tune_tol = value == 2;
+        REQUIRE(value >= 0 && value <= 3, RAMA_EINVAL, "set_tuning: ref_order must be 0, 1, 2 or 3");
+        c->tune_ref_order = value != 0; c->tune_tol = value == 2; c->tune_bar = value == 3;
+        hipStreamSynchronize(c->stream);
+        drop_graph(c);
+        return 0;
+    }
+    if (!strcmp(key, "bar_pos")) {
+        REQUIRE(value >= 0, RAMA_EINVAL, "set_tuning: bar_pos must be >= 0");
+        c->tune_bar_pos = value;
+        hipStreamSynchronize(c->stream);
+        drop_graph(c);
+        return 0;
+    }
+    if (!strcmp(key, "lane_reduce")) {
+        REQUIRE(value >= 0 && value <= 2, RAMA_EINVAL, "set_tuning: lane_reduce must be 0 (pairwise), 1 (strided) or 2 (sequential)");
+        c->tune_lane_reduce = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
         return 0;

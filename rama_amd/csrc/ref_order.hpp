@@ -83,7 +83,10 @@ __global__ void expf_glibc_kernel(float* o, const float* x, size_t n) {
 // ---------------------------------------------------------------- cpu.rs:127-153 matmul, o_cols == 1
 // One thread per output row: v_j += a[r][4i + j] * b[4i + j] for i ascending, four chains, then
 // (v0 + v1) + (v2 + v3).  Up to 3 matrices per launch (blockIdx.y), all [rows, K].
-struct RefMatParams { const float* w[3]; float* o[3]; const float* x; int K, rows; };
+// lane_reduce: the order of the final sum of the four chains, cpu.rs:148 `v.reduce_add()` -- wide::f32x4 leaves it to the build's target features (an SSE3
+// hadd pair, the SSE2 movehl + shuffle idiom, or an array sum), the oracle has the same switch (oracle_set_lane_reduce), "lane_reduce" sets it
+enum { LANES_PAIRWISE = 0, LANES_STRIDED = 1, LANES_SEQUENTIAL = 2 };
+struct RefMatParams { const float* w[3]; float* o[3]; const float* x; int K, rows; int lane_reduce; };
 
 __global__ __launch_bounds__(64) void matvec_ref_kernel(RefMatParams p) {
     RAMA_NO_CONTRACT
@@ -119,7 +122,25 @@ __global__ __launch_bounds__(64) void matvec_ref_kernel(RefMatParams p) {
             v2 = v2 + W[k + 2] * p.x[k + 2]; v3 = v3 + W[k + 3] * p.x[k + 3];
         }
     }
-    o[r] = (v0 + v1) + (v2 + v3);
+    o[r] = p.lane_reduce == LANES_STRIDED ? (v0 + v2) + (v1 + v3) : (p.lane_reduce == LANES_SEQUENTIAL ? ((v0 + v1) + v2) + v3 : (v0 + v1) + (v2 + v3));
+}
+
+// the trait's o_cols > 1 product (cpu.rs:137-151 as written: output idx = r * o_cols + c, b strided by o_cols; forward() never calls it): one thread per
+// output, the same four chains and the same final order
+__global__ __launch_bounds__(256) void matmul_cols_ref_kernel(float* o, const float* a, const float* b, int width, int o_rows, int o_cols, int lane_reduce) {
+    RAMA_NO_CONTRACT
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)o_rows * (size_t)o_cols) return;
+    const size_t r = idx / (size_t)o_cols, cc = idx % (size_t)o_cols;
+    const float* ar = a + r * (size_t)width;
+    float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
+    for (int k = 0; k < width; k += 4) {
+        v0 = v0 + ar[k] * b[(size_t)k * o_cols + cc];
+        v1 = v1 + ar[k + 1] * b[(size_t)(k + 1) * o_cols + cc];
+        v2 = v2 + ar[k + 2] * b[(size_t)(k + 2) * o_cols + cc];
+        v3 = v3 + ar[k + 3] * b[(size_t)(k + 3) * o_cols + cc];
+    }
+    o[idx] = lane_reduce == LANES_STRIDED ? (v0 + v2) + (v1 + v3) : (lane_reduce == LANES_SEQUENTIAL ? ((v0 + v1) + v2) + v3 : (v0 + v1) + (v2 + v3));
 }
 
 // ---------------------------------------------------------------- cpu.rs:99-117 rmsnorm

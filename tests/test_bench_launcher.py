@@ -67,12 +67,16 @@ def test_spawn_ranks_timeout(tmp_path):
 
 
 def test_bench_gpus_n_without_launcher_spawns_before_touching_a_gpu(tmp_path):
-    """`python bench.py --gpus 2` with no RANK in the environment must go through spawn_ranks (here: the children fail
-    loudly because this container has no GPU, and the parent reports it with a non-zero code instead of hanging)"""
+    """`python bench.py --gpus 2` with no RANK in the environment: [r6] on a node that shows fewer than 2 devices it says "needs 2 visible devices" and
+    exits 3 BEFORE anything touches a GPU; with the device check waived it goes through spawn_ranks (here: the children fail loudly because this
+    container has no GPU, and the parent reports it with a non-zero code instead of hanging)"""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--rank-timeout", "120"],
-                       env=env, capture_output=True, text=True, timeout=300)
     import torch
+    cmd = [sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--rank-timeout", "120"]
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 3 and "needs 2 visible devices" in r.stderr and r.stdout.strip() == ""
     if not torch.cuda.is_available():
+        r = subprocess.run(cmd, env=dict(env, RAMA_BENCH_SKIP_DEVICE_CHECK="1"), capture_output=True, text=True, timeout=300)
         assert r.returncode != 0 and "rank" in r.stderr
         assert r.stdout.strip() == ""

@@ -65,6 +65,13 @@ def dev():
     d.close()
 
 
+def _library_stamp():
+    import sys
+    sys.path.insert(0, str(REPO))
+    from bench import library_stamp
+    return library_stamp()
+
+
 def _host_mem_gb() -> float:
     try:
         with open("/proc/meminfo") as f:
@@ -94,8 +101,9 @@ def test_llama2_7b_full_depth_200_positions(dev):
     eng = rama_amd.Engine(dev, model)
     eng_ref = rama_amd.Engine(dev, model)
     eng_tol = rama_amd.Engine(dev, model)
+    eng_bar = rama_amd.Engine(dev, model)      # [r6] "ref_order" = 3: parity mode up to position 127, the fast path's attention from 128 on
 
-    rows, toks_cpu, toks_hip, toks_tol = [], [], [], []
+    rows, toks_cpu, toks_hip, toks_tol, toks_bar = [], [], [], [], []
     token = 1
     t_cpu = t_f64 = 0.0
     for pos in range(n_pos):
@@ -120,7 +128,16 @@ def test_llama2_7b_full_depth_200_positions(dev):
             lt = eng_tol.logits()
         finally:
             eng_tol.set_tuning("ref_order", 0)
+        eng_bar.set_tuning("ref_order", 3)
+        try:
+            eng_bar.forward(token, pos)
+            lb = eng_bar.logits()
+        finally:
+            eng_bar.set_tuning("ref_order", 0)
+        toks_bar.append(int(np.flatnonzero(lb == lb.max())[-1]))
         rows.append({"pos": pos, "token": int(token),
+                     "hip_bar_vs_oracle": float(np.abs(lb - lo).max()),
+                     "hip_bar_bits_equal": bool(np.array_equal(lb.view(np.uint32), lo.view(np.uint32))),
                      "hip_tolerance_vs_oracle": float(np.abs(lt - lo).max()),
                      "hip_tolerance_vs_f64": float(np.abs(lt - l64).max()),
                      "hip_ref_order_vs_oracle": float(np.abs(lr - lo).max()),
@@ -143,7 +160,7 @@ def test_llama2_7b_full_depth_200_positions(dev):
         for name in ("key_cache", "value_cache"):
             full = orc.s[name].reshape(L, seq, d)
             full[:, n_pos:tail_at, :] = rng.standard_normal((L, tail_at - n_pos, d), dtype=np.float32)
-            for e in (eng, eng_ref):
+            for e in (eng, eng_ref, eng_bar):
                 e.set_buffer(name, full)
         for pos in range(tail_at, tail_at + 4):
             t1 = time.time()
@@ -157,7 +174,15 @@ def test_llama2_7b_full_depth_200_positions(dev):
                 lr = eng_ref.logits()
             finally:
                 eng_ref.set_tuning("ref_order", 0)
+            eng_bar.set_tuning("ref_order", 3)
+            try:
+                eng_bar.forward(token, pos)
+                lb = eng_bar.logits()
+            finally:
+                eng_bar.set_tuning("ref_order", 0)
             tail.append({"pos": pos, "token": int(token), "oracle_s": round(t_or, 3),
+                         "hip_bar_vs_oracle": float(np.abs(lb - lo).max()),
+                         "greedy_token_equal_bar": int(np.flatnonzero(lb == lb.max())[-1]) == int(O.argmax(lo)),
                          "hip_ref_order_vs_oracle": float(np.abs(lr - lo).max()),
                          "hip_ref_order_bits_equal": bool(np.array_equal(lr.view(np.uint32), lo.view(np.uint32))),
                          "hip_vs_oracle": float(np.abs(lg - lo).max()),
@@ -171,6 +196,9 @@ def test_llama2_7b_full_depth_200_positions(dev):
         "positions": n_pos, "bar": LOGIT_ATOL,
         "worst_hip_ref_order_vs_oracle": max(r["hip_ref_order_vs_oracle"] for r in rows),
         "positions_ref_order_bit_identical": sum(r["hip_ref_order_bits_equal"] for r in rows),
+        "worst_hip_bar_vs_oracle": max([r["hip_bar_vs_oracle"] for r in rows] + [t["hip_bar_vs_oracle"] for t in tail]),
+        "positions_bar_bit_identical": sum(r["hip_bar_bits_equal"] for r in rows),
+        "greedy_tokens_equal_bar": toks_cpu == toks_bar,
         "worst_hip_tolerance_vs_oracle": max(r["hip_tolerance_vs_oracle"] for r in rows),
         "positions_tolerance_over_bar": [r["pos"] for r in rows if r["hip_tolerance_vs_oracle"] > LOGIT_ATOL],
         "greedy_tokens_equal_tolerance": toks_cpu == toks_tol,
@@ -182,6 +210,7 @@ def test_llama2_7b_full_depth_200_positions(dev):
         "first_token_mismatch": next((i for i, (a, b) in enumerate(zip(toks_cpu, toks_hip)) if a != b), None),
         "weights_gen_s": round(t_gen, 1), "oracle_s_per_token": round(t_cpu / n_pos, 3),
         "f64_s_per_token": round(t_f64 / n_pos, 3), "oracle_threads": threads,
+        "library": _library_stamp(),
         "deep_tail": tail,
         "per_position": rows,
     }
@@ -194,12 +223,17 @@ def test_llama2_7b_full_depth_200_positions(dev):
     print(json.dumps({k: v for k, v in out.items() if k != "per_position"}))
     eng.free()
 
-    eng_ref.free(); eng_tol.free(); model.free()
+    eng_ref.free(); eng_tol.free(); eng_bar.free(); model.free()
     # the north_star bar, literally: logits within 1e-4 of the CPU reference path at every position
     assert out["worst_hip_ref_order_vs_oracle"] <= LOGIT_ATOL, out["worst_hip_ref_order_vs_oracle"]
     assert all(r["hip_ref_order_bits_equal"] for r in rows), [r["pos"] for r in rows if not r["hip_ref_order_bits_equal"]][:8]
     # ... and deep into the context (positions 1 900..1 903 over a filled cache, all 32 layers): the same bits
     assert all(t["hip_ref_order_bits_equal"] and t["greedy_token_equal_ref_order"] for t in tail), tail
+    # [r6] bar mode: parity mode's bits below its switch (position 128), <= 1e-4 from the oracle behind it -- here over 72 + 4 positions; over the whole
+    # 2 048-position context: profiles/r06_tolerance_sweep_7b_2048pos_bar.jsonl (tools/tol_sweep.py) -- and the oracle's tokens
+    assert all(r["hip_bar_bits_equal"] for r in rows if r["pos"] < 128), [r["pos"] for r in rows if r["pos"] < 128 and not r["hip_bar_bits_equal"]][:8]
+    assert out["worst_hip_bar_vs_oracle"] <= LOGIT_ATOL, out["worst_hip_bar_vs_oracle"]
+    assert toks_cpu == toks_bar and all(t["greedy_token_equal_bar"] for t in tail)
     # the tolerance-mode experiment: same tokens, the same ~1.4e-4 from the oracle as the fast path (recorded above)
     assert out["worst_hip_tolerance_vs_oracle"] <= 2 * LOGIT_ATOL, out["worst_hip_tolerance_vs_oracle"]
     assert toks_cpu == toks_tol

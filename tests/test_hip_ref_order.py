@@ -87,6 +87,161 @@ def test_matmul_bit_exact(dev, rows, width):
     assert_bits_equal(dev.download(to), want, "matmul")
 
 
+@pytest.mark.parametrize("order", ["strided", "sequential"])
+def test_lane_reduce_orders_bit_exact(dev, order):
+    """[r6] cpu.rs:148 `v.reduce_add()`: the order of the final 4-lane sum belongs to the `wide` crate and the build's target features, not to the
+    reference.  "lane_reduce" = 1 (strided, (l0+l2)+(l1+l3)) | 2 (sequential, ((l0+l1)+l2)+l3) against the oracle switched the same way
+    (oracle_set_lane_reduce): Device::matmul on a model-less matrix (the chain-order view, one and two waves per row group, half groups, the
+    one-thread-per-row kernel of an unaligned view, o_cols = 2), forward() through the fused entry and through the 1:1 ops with every RunState
+    buffer, a prompt through the chain-order token-batch kernels -- bit for bit; and the orders do differ from the default on the same inputs"""
+    import rama_amd
+    from rama_amd._lib import check
+    from .helpers import to_rama_cfg
+    code = O.LANES[order]
+    check(dev.lib.rama_set_tuning(dev.ctx, b"lane_reduce", code))
+    try:
+        differs = 0
+        with O.orders(lane_reduce=order):
+            for rows, width in [(7, 8), (288, 288), (333, 772), (4096, 4096), (64, 11008), (22016, 4096), (1000, 4100)]:
+                w, x = rnd(rows * width, rows + width, 0.05), rnd(width, 5, 1.5)
+                want = np.empty(rows, np.float32)
+                O.matmul(want, w, x, width, rows)
+                tw = up(dev, w); tx = up(dev, x); to = up(dev, np.zeros(rows, np.float32))
+                dev.matmul(to, tw.as_view(), tx.as_view(), width, rows, 1)
+                assert_bits_equal(dev.download(to), want, f"matmul {rows}x{width} lanes {order}")
+                with O.orders(lane_reduce="pairwise"):
+                    base = np.empty(rows, np.float32); O.matmul(base, w, x, width, rows)
+                differs += int((bits(base) != bits(want)).sum())
+            assert differs > 0, "the lane orders never differed from the default: nothing was tested"
+            # an unaligned view (the one-thread-per-row kernel) and the trait's o_cols = 2 shape
+            rows, width = 50, 64
+            w, x = rnd(rows * width + 3, 1, 0.1), rnd(width + 1, 2)
+            want = np.empty(rows, np.float32)
+            O.matmul(want, np.ascontiguousarray(w[3:]), np.ascontiguousarray(x[1:]), width, rows)
+            sw = dev.allocate(w); sx = dev.allocate(x); to = up(dev, np.zeros(rows, np.float32))
+            dev.matmul(to, rama_amd.View(sw).slice(3), rama_amd.View(sx).slice(1), width, rows, 1)
+            assert_bits_equal(dev.download(to), want, f"matmul (unaligned view) lanes {order}")
+            b2 = rnd(width * 2, 9)
+            want2 = np.empty(rows * 2, np.float32)
+            O.matmul(want2, np.ascontiguousarray(w[3:]), b2, width, rows, 2)
+            tb2 = up(dev, b2); to2 = up(dev, np.zeros(rows * 2, np.float32))
+            dev.matmul(to2, rama_amd.View(sw).slice(3), tb2.as_view(), width, rows, 2)
+            assert_bits_equal(dev.download(to2), want2, f"matmul o_cols=2 lanes {order}")
+            # forward(): fused entry + 1:1 ops on a small golden case, and llama2-7B's width (leader norms, two waves per row group, W1|W3's half groups)
+            cfg, wts, g = load_case("synth_d288_h6")
+            toks = g["tokens"].tolist()[:6]
+            orc = O.Oracle(cfg, wts)
+            rcfg, ws, wv, rs, rsv = gpu_views(dev, cfg, wts)
+            model = rama_amd.Model.synth(dev, to_rama_cfg(cfg), int(g["seed"]), rope=(g["freq_cis_real"], g["freq_cis_imag"]))
+            eng = rama_amd.Engine(dev, model)
+            for pos, t in enumerate(toks):
+                lo = orc.forward(t, pos)
+                eng.forward(t, pos)
+                rama_amd.forward(rcfg, wv, rsv, t, pos, dev)
+                assert_bits_equal(eng.logits(), lo, f"fused entry lanes {order} pos {pos}")
+                for buf in ("logits", "x", "xb", "xb2", "hb", "q", "key_cache"):
+                    assert_bits_equal(dev.download(getattr(rsv, buf)), orc.s[buf], f"1:1 ops lanes {order} pos {pos} {buf}")
+            eng.free(); model.free(); rs.free(); ws.free()
+            d, h, L, H, V, seq = 4096, 11008, 1, 32, 320, 64
+            cfg7 = O.Config(d, h, L, H, H, V, seq, False)
+            rope = S.rope_tables(seq, d // H)
+            w7 = S.synth_weights(cfg7, 17, rope=rope)
+            orc7 = O.Oracle(cfg7, w7)
+            model7 = rama_amd.Model.synth(dev, to_rama_cfg(cfg7), 17, rope=rope)
+            eng7 = rama_amd.Engine(dev, model7)
+            token = 1
+            for pos in range(4):
+                lo = orc7.forward(token, pos)
+                eng7.forward(token, pos)
+                assert_bits_equal(eng7.logits(), lo, f"7B width lanes {order} pos {pos}")
+                for buf, n in (("x", d), ("hb", h), ("q", d)):
+                    assert_bits_equal(eng7.buffer(buf, n), orc7.s[buf], f"7B width lanes {order} pos {pos} {buf}")
+                token = O.argmax(lo)
+            # a prompt through the chain-order token-batch kernels (gemm_chain_kernel)
+            toks = [1] + [int(t) for t in np.random.default_rng(3).integers(0, V, 20)]
+            orc8 = O.Oracle(cfg7, w7)
+            for pos, t in enumerate(toks):
+                lo = orc8.forward(t, pos)
+            eng8 = rama_amd.Engine(dev, model7)
+            arr = (C.c_int32 * len(toks))(*toks)
+            check(dev.lib.rama_prefill(dev.ctx, C.byref(model7.ccfg), C.byref(model7.weights), C.byref(eng8.state), arr, len(toks), 0), "rama_prefill")
+            assert_bits_equal(eng8.logits(), lo, f"prefill lanes {order}: logits")
+            assert_bits_equal(eng8.buffer("key_cache", L * seq * d), orc8.s["key_cache"], f"prefill lanes {order}: key_cache")
+            eng7.free(); eng8.free(); model7.free()
+    finally:
+        check(dev.lib.rama_set_tuning(dev.ctx, b"lane_reduce", 0))
+    with pytest.raises(rama_amd.RamaError):
+        check(dev.lib.rama_set_tuning(dev.ctx, b"lane_reduce", 3))
+
+
+def test_rmsnorm_then_matmul_with_columns_reads_the_norm(dev):
+    """[r6] (round 5's advisor) a parity-mode Device::rmsnorm is RECORDED (it may ride in the launch of the matmuls on its output); a Device::matmul with
+    o_cols = 2 reading that output records nothing and used to run before the norm had been issued.  Now everything pending is issued first, and
+    the o_cols > 1 product follows the reference's order too (cpu.rs:137-151)"""
+    n, rows = 256, 24
+    x, g = rnd(n, 1, 2.0), rnd(n, 2)
+    a = rnd(rows * (n // 2), 3, 0.1)
+    normed = np.empty(n, np.float32)
+    O.rmsnorm(normed, x, g, n)
+    want = np.empty(rows * 2, np.float32)
+    O.matmul(want, a, normed, n // 2, rows, 2)          # b = the normalised vector read as [n / 2, 2]
+    tx = up(dev, x); tg = up(dev, g); tn = up(dev, np.full(n, 7.0, np.float32)); ta = up(dev, a); to = up(dev, np.zeros(rows * 2, np.float32))
+    dev.rmsnorm(tn, tx.as_view(), tg.as_view(), n)
+    dev.matmul(to, ta.as_view(), tn.as_view(), n // 2, rows, 2)
+    assert_bits_equal(dev.download(to), want, "matmul (o_cols = 2) behind a recorded rmsnorm")
+    assert_bits_equal(dev.download(tn), normed, "the recorded rmsnorm's output")
+
+
+def test_device_side_writes_dissolve_derived_copies(dev):
+    """[r6] (round 5's advisor) chain-order copies derived from tensors the caller uploaded are dropped by rama_free / rama_copy_h2d_f32 -- and now by every
+    entry that WRITES device memory: TransformerWeights re-seeded in place with rama_fill_synth, an op's output landing in a matrix.  The next
+    parity-mode call derives them again from the live tensor: logits bit for bit the oracle's for the NEW weights"""
+    import rama_amd
+    from rama_amd._lib import check
+    from .helpers import to_rama_cfg
+    cfg = O.Config(128, 352, 2, 2, 2, 96, 32, False)
+    rcfg = to_rama_cfg(cfg)
+    ws = rama_amd.TransformerWeights.synth(rcfg, 31, dev)
+    wv = rama_amd.TransformerWeightsView.from_gpu_ws(ws)
+    rs = rama_amd.RunState.from_config(rcfg, dev); rsv = rama_amd.RunStateView.from_rs(rs)
+    fr = dev.download(wv.freq_cis_real).reshape(cfg.seq_len, -1); fi = dev.download(wv.freq_cis_imag).reshape(cfg.seq_len, -1)
+
+    def check_seed(seed, what):
+        w = S.synth_weights(cfg, seed, rope=(fr, fi))
+        orc = O.Oracle(cfg, w)
+        token = 1
+        for pos in range(3):
+            lo = orc.forward(token, pos)
+            rama_amd.forward_fused(rcfg, wv, rsv, token, pos, dev)
+            assert_bits_equal(dev.download(rsv.logits), lo, f"{what}: fused entry pos {pos}")
+            rama_amd.forward(rcfg, wv, rsv, token, pos, dev)
+            assert_bits_equal(dev.download(rsv.logits), lo, f"{what}: 1:1 ops pos {pos}")
+            token = O.argmax(lo)
+
+    check_seed(31, "first upload")
+    assert _chain_lookup(dev, wv.wq.ptr, cfg.dim, cfg.dim), "no chain-order copy was derived: nothing is tested"
+    # the same tensors re-seeded ON THE DEVICE (what TransformerWeights.synth does per tensor): the copies must go
+    spec = S.synth_spec(cfg)
+    for name in ("wq", "wk", "wv", "wo", "w1", "w2", "w3", "token_embedding_table", "wcls", "rms_att_weight", "rms_ffn_weight", "rms_final_weight"):
+        view = getattr(wv, name)
+        tag, scale, bias = spec[name]
+        n = int(np.prod(dict(O.weight_shapes(cfg))[name]))
+        check(dev.lib.rama_fill_synth(dev.ctx, view.ptr, n, 32, tag, 0, float(scale), float(bias)), "rama_fill_synth")
+    assert not _chain_lookup(dev, wv.wq.ptr, cfg.dim, cfg.dim), "a chain-order copy survived a device-side write into its tensor"
+    check_seed(32, "re-seeded in place")
+    # an op's output landing in a matrix (array_add of the matrix onto itself: every element doubles)
+    assert _chain_lookup(dev, wv.wo.ptr, cfg.dim, cfg.dim)
+    dev.array_add(rama_amd.MutView(ws.wo), wv.wo, cfg.n_layers * cfg.dim * cfg.dim)
+    assert not _chain_lookup(dev, wv.wo.ptr, cfg.dim, cfg.dim), "a chain-order copy survived an op that wrote its tensor"
+    w = S.synth_weights(cfg, 32, rope=(fr, fi))
+    w["wo"] = (w["wo"] + w["wo"]).astype(np.float32)
+    orc = O.Oracle(cfg, w)
+    lo = orc.forward(5, 0)
+    rama_amd.forward_fused(rcfg, wv, rsv, 5, 0, dev)
+    assert_bits_equal(dev.download(rsv.logits), lo, "after an op wrote wo")
+    rs.free(); ws.free()
+
+
 def test_matmul_unaligned_view_bit_exact(dev):
     import rama_amd
     rows, width = 50, 64
@@ -847,6 +1002,73 @@ def test_model_long_context_bit_exact(dev, n_heads, hs):
         eng.set_graph_mode(False)
         eng.set_tuning("attn_fv", 1); eng.set_tuning("spread_pos", 128)
     eng.free(); model.free()
+
+
+@pytest.mark.parametrize("dim,hidden,heads,layers,seq,bar_pos", [(256, 512, 2, 2, 512, None), (4096, 11008, 32, 2, 2048, None), (288, 768, 6, 2, 256, 16)])
+def test_bar_mode_is_parity_until_its_switch_then_the_fast_attention(dev, dim, hidden, heads, layers, seq, bar_pos):
+    """[r6] "ref_order" = 3, bar mode: every launch parity mode's -- the oracle's bits -- up to position "bar_pos" (default 128, the spread attention's
+    switch), the fast path's attention from there on (one workgroup per head, split-T from 256 at llama2-7B's width) while matvecs and norms stay exact.
+    Over a pre-filled cache: below the switch every buffer bit for bit, behind it logits within 2e-6 of the oracle at this depth (2 layers) and the
+    greedy token the same; eager and from a hipGraph; the 1:1 Device ops take the same switch.  (Full depth, whole context: tools/tol_sweep.py,
+    profiles/r06_*; tests/test_hip_parity_7b.py asserts <= 1e-4 per position there.)"""
+    import rama_amd
+    from rama_amd._lib import check
+    from .helpers import to_rama_cfg
+    vocab = 320
+    cfg = O.Config(dim, hidden, layers, heads, heads, vocab, seq, False)
+    rope = S.rope_tables(seq, dim // heads)
+    w = S.synth_weights(cfg, 19, rope=rope)
+    rng = np.random.default_rng(19)
+    kc = rng.standard_normal(layers * seq * dim, dtype=np.float32)
+    vc = rng.standard_normal(layers * seq * dim, dtype=np.float32)
+    orc = O.Oracle(cfg, w)
+    model = rama_amd.Model.synth(dev, to_rama_cfg(cfg), 19, rope=rope)
+    eng = rama_amd.Engine(dev, model)
+    switch = bar_pos if bar_pos is not None else 128
+    positions = sorted({0, 5, switch - 1, switch, switch + 1, min(seq - 1, 255), min(seq - 1, 256), min(seq - 1, 300), seq - 1})
+    check(dev.lib.rama_set_tuning(dev.ctx, b"ref_order", 3))
+    if bar_pos is not None:
+        check(dev.lib.rama_set_tuning(dev.ctx, b"bar_pos", bar_pos))
+    try:
+        for graph in (False, True):
+            eng.set_graph_mode(graph)
+            for pos in positions:
+                orc.s["key_cache"][:] = kc; orc.s["value_cache"][:] = vc
+                eng.set_buffer("key_cache", kc); eng.set_buffer("value_cache", vc)
+                lo = orc.forward(9, pos).copy()
+                eng.forward(9, pos)
+                lg = eng.logits()
+                what = f"bar mode pos {pos} graph {graph}"
+                if pos < switch:
+                    assert_bits_equal(lg, lo, f"{what}: logits (below the switch: parity mode's bits)")
+                    assert_bits_equal(eng.buffer("xb2", dim), orc.s["xb2"], f"{what}: xb2")
+                else:
+                    assert float(np.abs(lg - lo).max()) <= 2e-6, (what, float(np.abs(lg - lo).max()))
+                    assert int(np.flatnonzero(lg == lg.max())[-1]) == O.argmax(lo), what
+                for buf in ("key_cache", "value_cache"):      # the appended rows come from the exact matvecs in either regime... of layer 0 (layer 1's input has passed an attention)
+                    got = eng.buffer(buf, seq * dim).reshape(seq, dim)[pos]
+                    assert_bits_equal(got, orc.s[buf].reshape(layers, seq, dim)[0, pos], f"{what}: {buf} row of layer 0")
+        eng.set_graph_mode(False)
+        # the 1:1 op: Device::multi_head_attention behind the switch = the fast kernel (close, not bit-identical by contract), below it the exact one
+        rcfg = to_rama_cfg(cfg)
+        rs = rama_amd.RunState.from_config(rcfg, dev); rsv = rama_amd.RunStateView.from_rs(rs)
+        q = rnd(dim, 5, 1.5)
+        dev.upload_into(rsv.key_cache, kc); dev.upload_into(rsv.value_cache, vc); dev.upload_into(rsv.q, q)
+        for pos in (switch - 1, switch + 3):
+            orc.s["key_cache"][:] = kc; orc.s["value_cache"][:] = vc; orc.s["q"][:] = q
+            orc.multi_head_attention(1, pos)
+            dev.multi_head_attention(rsv, rcfg, 1, pos)
+            got = dev.download(rsv.xb)
+            if pos < switch:
+                assert_bits_equal(got, orc.s["xb"], f"op path, bar mode, pos {pos}")
+            else:
+                assert float(np.abs(got - orc.s["xb"]).max()) <= 1e-5
+        rs.free()
+    finally:
+        eng.set_graph_mode(False)
+        check(dev.lib.rama_set_tuning(dev.ctx, b"bar_pos", 128))
+        check(dev.lib.rama_set_tuning(dev.ctx, b"ref_order", 1))
+        eng.free(); model.free()
 
 
 def test_llama2_7b_width_deep_context_bit_exact(dev):

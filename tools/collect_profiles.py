@@ -39,6 +39,11 @@ env = dict(os.environ, TMPDIR="/tmp")
 bench = str(REPO / "bench.py")
 
 
+sys.path.insert(0, str(REPO))
+from bench import library_stamp  # noqa: E402   (hashes rama_amd/librama_hip.so; touches no GPU)
+LIBRARY = library_stamp()
+
+
 def run(cmd, workdir):
     print("+", " ".join(cmd), flush=True)
     subprocess.run(cmd, cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -54,6 +59,7 @@ run(cmd1, d1)
 stats = glob.glob(str(d1 / "**" / "*kernel_stats.csv"), recursive=True)
 assert stats, "rocprofv3 wrote no kernel_stats.csv"
 shutil.copy(stats[0], out / f"{tag}_bench_{short}{suffix}_kernel_stats.csv")
+(out / f"{tag}_bench_{short}{suffix}_kernel_stats.meta.json").write_text(json.dumps({"library": LIBRARY, "command": " ".join(cmd1[:9]) + " -- python3 bench.py " + " ".join(cmd1[cmd1.index(bench) + 1:])}) + "\n")
 
 # 2. counters, in a pass of their own
 d2 = out / "_pmc"
@@ -79,7 +85,7 @@ tokens = sum(n for name, (n, tot) in acc.items() if "argmax_kernel" in name)
 per_token = int(round(sum(tot for name, (n, tot) in acc.items() if not any(k in name for k in setup)) * 1024 * 2 / tokens)) if tokens else None
 with open(out / f"{tag}_bench_{short}{suffix}_pmc_fetch_size.json", "w") as f:
     json.dump({"command": " ".join(cmd2[:5]) + f" -- python bench.py --steps 16 --warmup 2 --no-cpu-baseline --no-kprof --graph 0 --mode {a.mode} --config {a.config}",
-               "tokens": tokens, "hbm_read_bytes_per_token_corrected": per_token,
+               "library": LIBRARY, "tokens": tokens, "hbm_read_bytes_per_token_corrected": per_token,
                "note": "FETCH_SIZE is reported in KB; on gfx950 it counts 128-B requests at 64 B, i.e. exactly half of a wide "
                        "coalesced read (MI355X_MICROARCH.md, HBM section): hbm_read_bytes_corrected = value * 1024 * 2",
                "rows": rows}, f, indent=1)

@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Which op carries how much of the distance to the CPU path?  Full-depth shape (default llama2-7B, 27 GB of
 synthetic weights on both sides), the generate() loop on 'once upon a time' with the ORACLE's greedy tokens;
-the oracle's logits are computed once, then every mode / "tol_mask" runs the same positions on the GPU:
+every mode / "tol_mask" runs the same positions on the GPU, the oracle beside it:
 
     fast            the fast path (fused multiply-adds, tree sums)
     parity          every op in the reference's rounding order (bit-identical)
     tol             tolerance mode ("ref_order" = 2): chain-order matvecs + tree-summed norms folded in + fast attention
+    bar             bar mode ("ref_order" = 3): parity mode up to position 127, the fast attention from 128 on (exact matvecs and norms)
     tol+<mask>      tolerance mode with ops swapped: 1 / 2 / 4 / 8 / 16 = the FAST qkv / wo / w13 / w2 / cls launch,
                     32 = parity mode's attention, 64 = parity mode's exact-sum norm launches
 
@@ -14,7 +15,7 @@ Prints one JSON line per configuration: worst |dlogit| vs the oracle, positions 
 every 64 positions, and the per-position curves are written to RAMA_TOL_JSON (default gpurun_out/r06_tol_curve.json) as they
 grow -- a run over the whole 2 048-position context is ~8 minutes of oracle and leaves its curve even when cut short.
 Usage: python tools/tol_sweep.py [n_positions] [shape] [mask,mask,...] [modes]     (test infrastructure: uses oracle/)
-       modes: comma list of fast,parity,tol (default all three) run beside the tol+<mask> configurations"""
+       modes: comma list of fast,parity,tol,bar (default fast,parity,tol) run beside the tol+<mask> configurations"""
 import json
 import os
 import sys
@@ -28,6 +29,8 @@ import rama_amd  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 from oracle import synth as S  # noqa: E402
 
+from bench import library_stamp  # noqa: E402
+LIBRARY = library_stamp()
 SHAPES = {"llama2-7B": (4096, 11008, 32, 32, 32000, 2048, False),
           "stories110M": (768, 2048, 12, 12, 32000, 1024, True),
           "stories15M": (288, 768, 6, 6, 32000, 256, True)}
@@ -50,7 +53,7 @@ prompt = [10646, 2501, 263, 931]
 dev = rama_amd.Hip(0)
 rcfg = rama_amd.Config(d, h, L, H, H, V, seq, shared)
 model = rama_amd.Model.synth(dev, rcfg, 0, rope=rope)
-configs = [(m, {"fast": 0, "parity": 1, "tol": 2}[m], 0) for m in base] + [(f"tol+{m}", 2, m) for m in masks]
+configs = [(m, {"fast": 0, "parity": 1, "tol": 2, "bar": 3}[m], 0) for m in base] + [(f"tol+{m}", 2, m) for m in masks]
 engines = {name: rama_amd.Engine(dev, model) for name, _, _ in configs}
 curves = {name: [] for name, _, _ in configs}
 same = {name: True for name, _, _ in configs}
@@ -68,7 +71,7 @@ def summary(name):
 
 
 def dump():
-    out_path.write_text(json.dumps({"shape": shape, "positions_done": len(next(iter(curves.values()))), "oracle_threads": threads,
+    out_path.write_text(json.dumps({"library": LIBRARY, "shape": shape, "positions_done": len(next(iter(curves.values()))), "oracle_threads": threads,
                                     "what": "max |logit - oracle logit| per position, the oracle's greedy tokens fed to every configuration",
                                     "summaries": [summary(n) for n in curves], "per_position": curves}))
 
