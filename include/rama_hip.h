@@ -263,6 +263,20 @@ typedef struct {
 /* the schedule alone (no GPU): 1 + (*seq, *pos) if `rank` of `world` computes an item at `tick`, 0 if idle */
 int  rama_pipe_item(const rama_pipe_plan *plan, int world, int rank, int tick, int *seq, int *pos);
 int  rama_pipe_total_ticks(const rama_pipe *pipe, const rama_pipe_plan *plan);   /* S * n_pos + world - 1 */
+int  rama_pipe_plan_ticks(const rama_pipe_plan *plan, int world);                 /* the same without a communicator */
+/* [r6] EVERYTHING one tick of one rank consists of, as pure arithmetic (no GPU, no communicator): rama_pipe_run_ticks is a loop over this function
+ * and executes exactly what it says -- so a CPU test that lets gloo ranks compute and exchange by it (tests/test_pipeline_gloo.py) validates the
+ * native loop's own bookkeeping.  kinds: RAMA_PIPE_NONE | RAMA_PIPE_X (float[dim]) | RAMA_PIPE_TOKEN (one int32).
+ * token_kind: 0 = BOS (mod.rs:182), 1 = forced prompt token `token` (mod.rs:190-191), 2 = the sequence's device token word (rank 0: what the last
+ * rank sampled; other ranks take no token).  recv_pos: the position the received token was sampled AFTER (rank 0's history row). */
+enum { RAMA_PIPE_NONE = 0, RAMA_PIPE_X = 1, RAMA_PIPE_TOKEN = 2 };
+typedef struct {
+    int32_t on, seq, pos, pos_wrapped, token_kind, token;
+    int32_t samples;                                   /* this rank runs Device::sample behind the item (the last rank) */
+    int32_t send_kind, send_seq, send_peer;
+    int32_t recv_kind, recv_seq, recv_peer, recv_pos;
+} rama_pipe_tick;
+int  rama_pipe_tick_plan(const rama_pipe_plan *plan, int world, int rank, int tick, rama_pipe_tick *out);
 /* Runs ticks [tick_from, tick_to) of this rank: states[s] is sequence s's run state for this stage
  * (its x is the hand-off buffer), tok_dev[s] its device token word.  Asynchronous on the context's
  * stream; after the last tick of the last rank tok_dev[s] holds sequence s's newest token. */

@@ -106,6 +106,8 @@ extern "C" {
                               recv_x: *mut f32, n_recv_x: usize, recv_x_peer: c_int,
                               send_tok: *const i32, send_tok_peer: c_int, recv_tok: *mut i32, recv_tok_peer: c_int) -> c_int;
     pub fn rama_pipe_item(plan: *const rama_pipe_plan, world: c_int, rank: c_int, tick: c_int, seq: *mut c_int, pos: *mut c_int) -> c_int;
+    pub fn rama_pipe_plan_ticks(plan: *const rama_pipe_plan, world: c_int) -> c_int;
+    pub fn rama_pipe_tick_plan(plan: *const rama_pipe_plan, world: c_int, rank: c_int, tick: c_int, out: *mut rama_pipe_tick) -> c_int;
     pub fn rama_pipe_last_error() -> *const c_char;
 
     // the rest of include/rama_hip.h, for hosts that want more than the trait: stage-wise forwards
@@ -155,4 +157,14 @@ pub struct rama_pipe_plan {
     pub prompt: *const i32, pub n_prompt: i32,
     pub temperature: f32, pub topp: f32, pub u: f32,
     pub out_tokens_dev: *mut i32,
+}
+
+/// one tick of one rank of the layer pipeline, decided (include/rama_hip.h rama_pipe_tick): what rama_pipe_run_ticks executes
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct rama_pipe_tick {
+    pub on: i32, pub seq: i32, pub pos: i32, pub pos_wrapped: i32, pub token_kind: i32, pub token: i32,
+    pub samples: i32,
+    pub send_kind: i32, pub send_seq: i32, pub send_peer: i32,
+    pub recv_kind: i32, pub recv_seq: i32, pub recv_peer: i32, pub recv_pos: i32,
 }

@@ -52,6 +52,11 @@ class rama_pipe_plan(C.Structure):
                 ("temperature", C.c_float), ("topp", C.c_float), ("u", C.c_float), ("out_tokens_dev", C.c_void_p)]
 
 
+class rama_pipe_tick(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("on", "seq", "pos", "pos_wrapped", "token_kind", "token", "samples", "send_kind", "send_seq", "send_peer",
+                                         "recv_kind", "recv_seq", "recv_peer", "recv_pos")]
+
+
 # name -> (restype, argtypes); every symbol include/rama_hip.h declares
 _vp, _sz, _int = C.c_void_p, C.c_size_t, C.c_int
 _cfgp, _wp, _sp, _stp = C.POINTER(rama_config), C.POINTER(rama_weights), C.POINTER(rama_run_state), C.POINTER(rama_stage)
@@ -119,6 +124,8 @@ SIGNATURES = {
     "rama_pipe_exchange": (_int, [_vp, _vp, _sz, _int, _vp, _sz, _int, _vp, _int, _vp, _int]),
     "rama_pipe_item": (_int, [_vp, _int, _int, _int, C.POINTER(_int), C.POINTER(_int)]),
     "rama_pipe_total_ticks": (_int, [_vp, _vp]),
+    "rama_pipe_plan_ticks": (_int, [_vp, _int]),
+    "rama_pipe_tick_plan": (_int, [_vp, _int, _int, _int, C.POINTER(rama_pipe_tick)]),
     "rama_pipe_comm_info": (_int, [_vp, C.POINTER(_int), C.POINTER(_int)]),
     "rama_pipe_run_ticks": (_int, [_vp, _cfgp, _wp, _sp, C.POINTER(_vp), _stp, _vp, _int, _int]),
     "rama_pipe_last_error": (C.c_char_p, []),

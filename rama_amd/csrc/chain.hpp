@@ -557,8 +557,6 @@ struct ChainParams {
     // row groups do not divide by the compute units ends when the CUs with one group more are through: llama2-7B's W1|W3 is 1 376 groups on 256 CUs,
     // six on 96 of them and five on the rest; with the last 96 groups as 192 halves it is five and a half at most.
     int half_from;
-    int half_all;          // [r6] 1: EVERY row group is walked as two half groups (grid = 2 x groups; "chain_resid_half": an experiment on Wo's 256 groups -- two waves per
-                           // CU on different SIMDs instead of one)
     float* xout;           // CNORM_LEAD: the leader also stores the normalised vector here (a Device::rmsnorm recorded in front of the run, rama_api.hip flush_mm)
     int lane_reduce;       // [r6] the order of cpu.rs:148 `v.reduce_add()`: LANES_PAIRWISE | LANES_STRIDED | LANES_SEQUENTIAL (ref_order.hpp; "lane_reduce")
 };
@@ -684,8 +682,9 @@ __device__ __forceinline__ void gemv_chain_body(const ChainParams p, int bid_in)
     // (the quotient comes out of the vector ALU: without readfirstlane everything derived from it -- the buffer
     // descriptors above all -- counts as divergent and every load turns into a waterfall loop)
     int half = -1, bid_g = bid;
-    if (W == 1 && p.half_all) { half = bid & 1; bid_g = bid >> 1; }                                                                                   // (uniform)
-    else if (W == 1 && p.half_from > 0 && bid >= p.half_from) { half = (bid - p.half_from) & 1; bid_g = p.half_from + ((bid - p.half_from) >> 1); }      // (uniform)
+    // ([r6] measured and removed: EVERY group of Wo as two half groups -- two one-wave workgroups per compute unit on different SIMDs, a ring of 32 half
+    // blocks each: 14.10 against 13.89 us per launch, 209.0 against 209.8 tok/s; profiles/r06_experiments.md 1)
+    if (W == 1 && p.half_from > 0 && bid >= p.half_from) { half = (bid - p.half_from) & 1; bid_g = p.half_from + ((bid - p.half_from) >> 1); }      // (uniform)
     const int m = __builtin_amdgcn_readfirstlane(bid_g / groups), g = __builtin_amdgcn_readfirstlane(bid_g - m * groups);
     const float* Wm = m == 0 ? p.w[0] : (m == 1 ? p.w[1] : p.w[2]);
     const int nblk = p.K >> 4;

@@ -191,6 +191,37 @@ extern "C" int rama_pipe_total_ticks(const rama_pipe* p, const rama_pipe_plan* p
     if (!p || !plan) return -1;
     return slots_of(*plan, p->world) * plan->n_pos + p->world - 1;
 }
+extern "C" int rama_pipe_plan_ticks(const rama_pipe_plan* plan, int world) {
+    if (!plan || world < 1 || plan->n_seq < 1 || plan->n_pos < 1) return -1;
+    return slots_of(*plan, world) * plan->n_pos + world - 1;
+}
+
+// one tick of one rank, decided: what it computes, with which token, whether it samples, what it sends and what it receives.  The ONLY place the
+// native loop's decisions are made -- rama_pipe_run_ticks below executes this, tests/test_pipeline_gloo.py lets gloo ranks execute it on the CPU.
+extern "C" int rama_pipe_tick_plan(const rama_pipe_plan* plan, int world, int rank, int tick, rama_pipe_tick* out) {
+    if (!plan || !out || world < 1 || rank < 0 || rank >= world || plan->n_seq < 1 || plan->n_pos < 1 || plan->n_prompt < 0 || (plan->n_prompt && !plan->prompt)) return -1;
+    const int last = world - 1;
+    rama_pipe_tick t{};
+    const Item it = item_of(*plan, world, rank, tick);
+    t.on = it.on ? 1 : 0; t.seq = it.seq; t.pos = it.pos; t.token_kind = 2;
+    if (it.on) {
+        t.pos_wrapped = plan->wrap > 0 ? it.pos % plan->wrap : it.pos;
+        if (rank == 0 && t.pos_wrapped == 0) { t.token_kind = 0; t.token = 1; }                                                        // BOS, mod.rs:182
+        else if (rank == 0 && t.pos_wrapped <= plan->n_prompt) { t.token_kind = 1; t.token = plan->prompt[t.pos_wrapped - 1]; }       // mod.rs:190-191
+        t.samples = rank == last ? 1 : 0;
+        if (world > 1) {      // what I send after computing
+            if (rank < last) { t.send_kind = RAMA_PIPE_X; t.send_seq = it.seq; t.send_peer = rank + 1; }
+            else { t.send_kind = RAMA_PIPE_TOKEN; t.send_seq = it.seq; t.send_peer = 0; }
+        }
+    }
+    if (world > 1) {          // what my upstream neighbour sends me this tick
+        const int src = rank > 0 ? rank - 1 : last;
+        const Item up = item_of(*plan, world, src, tick);
+        if (up.on) { t.recv_kind = rank > 0 ? RAMA_PIPE_X : RAMA_PIPE_TOKEN; t.recv_seq = up.seq; t.recv_peer = src; t.recv_pos = up.pos; }
+    }
+    *out = t;
+    return 0;
+}
 
 extern "C" int rama_pipe_run_ticks(rama_pipe* p, const rama_config* cfg, const rama_weights* w, rama_run_state* states,
                                    int32_t* const* tok_dev, const rama_stage* stage, const rama_pipe_plan* plan,
@@ -198,47 +229,36 @@ extern "C" int rama_pipe_run_ticks(rama_pipe* p, const rama_config* cfg, const r
     if (!p || !cfg || !w || !states || !tok_dev || !stage || !plan) return bad(RAMA_EINVAL, "rama_pipe_run_ticks: NULL argument");
     if (plan->n_seq < 1 || plan->n_pos < 1) return bad(RAMA_EINVAL, "rama_pipe_run_ticks: n_seq and n_pos must be positive");
     if (plan->n_prompt < 0 || (plan->n_prompt && !plan->prompt)) return bad(RAMA_EINVAL, "rama_pipe_run_ticks: bad prompt");
-    const int rank = p->rank, world = p->world, last = world - 1;
+    const int rank = p->rank, world = p->world;
+    hipStream_t stream = (hipStream_t)rama_internal_stream(p->ctx);
     for (int tick = tick_from; tick < tick_to; tick++) {
-        const Item it = item_of(*plan, world, rank, tick);
-        if (it.on) {
-            const int pos = plan->wrap > 0 ? it.pos % plan->wrap : it.pos;
-            rama_run_state* st = &states[it.seq];
+        rama_pipe_tick t;
+        if (rama_pipe_tick_plan(plan, world, rank, tick, &t)) return bad(RAMA_EINVAL, "rama_pipe_run_ticks: bad plan");
+        if (t.on) {
+            rama_run_state* st = &states[t.seq];
             int rc;
-            if (rank == 0 && pos == 0) rc = rama_forward_stage(p->ctx, cfg, w, st, /*BOS, mod.rs:182*/ 1, pos, stage);
-            else if (rank == 0 && pos <= plan->n_prompt) rc = rama_forward_stage(p->ctx, cfg, w, st, plan->prompt[pos - 1], pos, stage);   // mod.rs:190-191
-            else rc = rama_forward_stage_devtok(p->ctx, cfg, w, st, rank == 0 ? tok_dev[it.seq] : nullptr, pos, stage);
+            if (t.token_kind != 2) rc = rama_forward_stage(p->ctx, cfg, w, st, t.token, t.pos_wrapped, stage);
+            else rc = rama_forward_stage_devtok(p->ctx, cfg, w, st, rank == 0 ? tok_dev[t.seq] : nullptr, t.pos_wrapped, stage);
             if (rc) return rc;
-            if (rank == last) {      // Device::sample (cpu.rs:155-179), result stays on the device
-                rc = plan->temperature == 0.0f ? rama_argmax_dev(p->ctx, st->logits, (size_t)cfg->vocab_size, tok_dev[it.seq])
-                                               : rama_sample_topp_dev(p->ctx, st->logits, (size_t)cfg->vocab_size, plan->temperature, plan->topp, plan->u, tok_dev[it.seq]);
+            if (t.samples) {      // Device::sample (cpu.rs:155-179), result stays on the device
+                rc = plan->temperature == 0.0f ? rama_argmax_dev(p->ctx, st->logits, (size_t)cfg->vocab_size, tok_dev[t.seq])
+                                               : rama_sample_topp_dev(p->ctx, st->logits, (size_t)cfg->vocab_size, plan->temperature, plan->topp, plan->u, tok_dev[t.seq]);
                 if (rc) return rc;
                 if (world == 1 && plan->out_tokens_dev &&
-                    hipMemcpyAsync(plan->out_tokens_dev + (size_t)it.seq * plan->n_pos + it.pos, tok_dev[it.seq], sizeof(int32_t),
-                                   hipMemcpyDeviceToDevice, (hipStream_t)rama_internal_stream(p->ctx)) != hipSuccess)
+                    hipMemcpyAsync(plan->out_tokens_dev + (size_t)t.seq * plan->n_pos + t.pos, tok_dev[t.seq], sizeof(int32_t), hipMemcpyDeviceToDevice, stream) != hipSuccess)
                     return bad(RAMA_EIO, "rama_pipe_run_ticks: token copy failed");
             }
         }
         if (world == 1) continue;
-        // what I send after computing, and what my upstream neighbour sends me this tick
-        const float* sx = nullptr; const int32_t* stok = nullptr; float* rx = nullptr; int32_t* rtok = nullptr;
-        int sx_peer = 0, stok_peer = 0, rx_peer = 0, rtok_peer = 0;
-        if (it.on) {
-            if (rank < last) { sx = states[it.seq].x; sx_peer = rank + 1; }
-            else { stok = tok_dev[it.seq]; stok_peer = 0; }
-        }
-        const int src = rank > 0 ? rank - 1 : last;
-        const Item up = item_of(*plan, world, src, tick);
-        if (up.on) {
-            if (rank > 0) { rx = states[up.seq].x; rx_peer = src; }
-            else { rtok = tok_dev[up.seq]; rtok_peer = src; }
-        }
-        int rc = rama_pipe_exchange(p, sx, (size_t)cfg->dim, sx_peer, rx, (size_t)cfg->dim, rx_peer, stok, stok_peer, rtok, rtok_peer);
+        const float* sx = t.send_kind == RAMA_PIPE_X ? states[t.send_seq].x : nullptr;
+        const int32_t* stok = t.send_kind == RAMA_PIPE_TOKEN ? tok_dev[t.send_seq] : nullptr;
+        float* rx = t.recv_kind == RAMA_PIPE_X ? states[t.recv_seq].x : nullptr;
+        int32_t* rtok = t.recv_kind == RAMA_PIPE_TOKEN ? tok_dev[t.recv_seq] : nullptr;
+        int rc = rama_pipe_exchange(p, sx, (size_t)cfg->dim, t.send_peer, rx, (size_t)cfg->dim, t.recv_peer, stok, t.send_peer, rtok, t.recv_peer);
         if (rc) return rc;
         // rank 0 keeps the history of sampled ids (generate() prints every `next`, mod.rs:196-200)
         if (rtok && plan->out_tokens_dev &&
-            hipMemcpyAsync(plan->out_tokens_dev + (size_t)up.seq * plan->n_pos + up.pos, rtok, sizeof(int32_t), hipMemcpyDeviceToDevice,
-                           (hipStream_t)rama_internal_stream(p->ctx)) != hipSuccess)
+            hipMemcpyAsync(plan->out_tokens_dev + (size_t)t.recv_seq * plan->n_pos + t.recv_pos, rtok, sizeof(int32_t), hipMemcpyDeviceToDevice, stream) != hipSuccess)
             return bad(RAMA_EIO, "rama_pipe_run_ticks: token copy failed");
     }
     return 0;

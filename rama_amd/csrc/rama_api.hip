@@ -181,7 +181,6 @@ struct rama_ctx {
     int tune_chain_norm = 1;               // parity mode, dim <= 512: the layer norms folded into the matvecs that consume them
     int tune_chain_split = 1;              // parity mode: the row groups that do not divide by the compute units walked as half groups (chain.hpp half_from)
     int tune_chain_lead_w = 0;             // parity mode: waves per row group of the launches with a leader norm (0: by the number of row groups)
-    int tune_chain_resid_half = 0;         // [r6] experiment: Wo's row groups as half groups throughout (chain.hpp half_all)
     int tune_chain_resid_d = -1;           // parity mode: 100 W + D for the residual products (Wo, W2) only; 0: by the number of row groups like the others; -1: W = 1, D = 32 when a CU holds one group
     // [r5] a run of Device::apply_position calls on consecutive heads (infer.rs:25-29: n_heads calls per layer, 1 024 per llama2-7B token, each a launch of
     // its own) is ISSUED AS ONE LAUNCH: a call only records (q, k, table rows, head size); the next call extends the run when it continues it, and
@@ -665,16 +664,13 @@ static int launch_chain(rama_ctx* c, ChainParams& p, int norm = CNORM_NONE) {
     REQUIRE(lds <= 64 * 1024, RAMA_EUNSUP, "chain-order matvec: row longer than ~15800 floats");
     // [r5] one wave per row group and more groups than compute units: the groups that do not divide by the CUs as halves (chain.hpp half_from; "chain_split")
     int nblocks = groups;
-    p.half_from = 0; p.half_all = 0;
+    p.half_from = 0;
     if (c->tune_chain_split && W == 1 && D == 16 && c->tune_chain_d <= 0 && norm != CNORM_EXACT && norm != CNORM_TREE) {
         const int cus = std::max(c->cu_count, 1), rem = groups % cus;
         // (more than half the CUs with a group more -- the classifier's 2 000 groups: the halves would give some CUs two again)
         if (groups > cus && rem > 0 && 2 * rem <= cus) { p.half_from = groups - rem; nblocks = groups + rem; }
     }
-    // [r6] "chain_resid_half" (an experiment, default 0): the square residual product (Wo) with at most one row group per compute unit as HALF groups throughout --
-    // two one-wave workgroups per CU, each with its own ring of 32 half blocks
-    const bool wo_like = EPI == CEPI_RESID && norm == CNORM_NONE && p.K == p.rows;
-    if (c->tune_chain_resid_half && wo_like && W == 1 && D == 32 && c->tune_chain_d <= 0) { p.half_all = 1; nblocks = 2 * groups; }
+    const bool wo_like = EPI == CEPI_RESID && norm == CNORM_NONE && p.K == p.rows;      // the square residual product: Wo
     const dim3 grid(nblocks);
     if (norm == CNORM_LEAD) {      // the exact sum by a leader workgroup of this launch (grid + 1); geometry as without a norm
         REQUIRE(D == 16 && (W == 1 || W == 2) && p.K % 8 == 0 && p.K <= 4096 * W && (EPI == CEPI_QKV || EPI == CEPI_SWIGLU || EPI == CEPI_STORE) && p.lead && p.epoch && p.err,
@@ -2947,13 +2943,6 @@ int rama_set_tuning(rama_ctx* c, const char* key, int value) {
     if (!strcmp(key, "chain_lead_w")) {
         REQUIRE(value >= 0 && value <= 2, RAMA_EINVAL, "set_tuning: chain_lead_w must be 0, 1 or 2");
         c->tune_chain_lead_w = value;
-        hipStreamSynchronize(c->stream);
-        drop_graph(c);
-        return 0;
-    }
-    if (!strcmp(key, "chain_resid_half")) {
-        REQUIRE(value == 0 || value == 1, RAMA_EINVAL, "set_tuning: chain_resid_half must be 0 or 1");
-        c->tune_chain_resid_half = value;
         hipStreamSynchronize(c->stream);
         drop_graph(c);
         return 0;

@@ -1008,7 +1008,7 @@ def test_model_long_context_bit_exact(dev, n_heads, hs):
 def test_bar_mode_is_parity_until_its_switch_then_the_fast_attention(dev, dim, hidden, heads, layers, seq, bar_pos):
     """[r6] "ref_order" = 3, bar mode: every launch parity mode's -- the oracle's bits -- up to position "bar_pos" (default 128, the spread attention's
     switch), the fast path's attention from there on (one workgroup per head, split-T from 256 at llama2-7B's width) while matvecs and norms stay exact.
-    Over a pre-filled cache: below the switch every buffer bit for bit, behind it logits within 2e-6 of the oracle at this depth (2 layers) and the
+    Over a pre-filled cache: below the switch every buffer bit for bit, behind it logits within 5e-5 of the oracle at this depth (2 layers) and the
     greedy token the same; eager and from a hipGraph; the 1:1 Device ops take the same switch.  (Full depth, whole context: tools/tol_sweep.py,
     profiles/r06_*; tests/test_hip_parity_7b.py asserts <= 1e-4 per position there.)"""
     import rama_amd
@@ -1043,7 +1043,7 @@ def test_bar_mode_is_parity_until_its_switch_then_the_fast_attention(dev, dim, h
                     assert_bits_equal(lg, lo, f"{what}: logits (below the switch: parity mode's bits)")
                     assert_bits_equal(eng.buffer("xb2", dim), orc.s["xb2"], f"{what}: xb2")
                 else:
-                    assert float(np.abs(lg - lo).max()) <= 2e-6, (what, float(np.abs(lg - lo).max()))
+                    assert float(np.abs(lg - lo).max()) <= 5e-5, (what, float(np.abs(lg - lo).max()))      # (random cache rows: logits of magnitude ~2, 2 layers)
                     assert int(np.flatnonzero(lg == lg.max())[-1]) == O.argmax(lo), what
                 for buf in ("key_cache", "value_cache"):      # the appended rows come from the exact matvecs in either regime... of layer 0 (layer 1's input has passed an attention)
                     got = eng.buffer(buf, seq * dim).reshape(seq, dim)[pos]
