@@ -333,131 +333,47 @@ int  rama_generate_stream(rama_ctx *ctx, const rama_config *cfg, const rama_weig
  * trait-level host or a pipeline stage issues one cursor write and one graph launch per token.  Setting 0
  * synchronises and drops every captured graph; free a run state only after that (or after rama_ctx_destroy). */
 int  rama_set_graph_mode(rama_ctx *ctx, int enabled);
-/* Performance knobs (results are unaffected up to fp32 summation order).  Keys:
- *   "geom" = 0..3 : matvec workgroup geometry (rows per workgroup, waves, chunks per step);
- *                   3 is the shipping choice, see rama_api.hip DISPATCH_GEOM
- *   "split_pos" = -1 | N : attention switches from one workgroup per head to the split-T variant
- *                   (n_heads x nsplit workgroups + a combine launch) at position N; -1 (default)
- *                   chooses by model size: 256 when one head's whole K+V cache exceeds 1 MiB
- *                   (llama2-7B), never below that (stories15M / 110M), as measured
- *   "resid_r2" = 0..3 : geometry of the two residual matvecs (Wo, W2) under geometry 3: 0 = 4-row
- *                   workgroups like the rest; 1 = 2 rows x 8 waves (+0.45 % tokens/s at llama2-7B);
- *                   2 (default) = as 1, and rows wider than 8192 floats (W2) spread over 16 waves,
- *                   one chunk each per step (+1.15 % more); 3 = 16 waves x 4 chunks
- *   "prefill" = 0|1 : 1 (default) lets rama_generate_greedy push the forced prompt positions through
- *                   rama_prefill (up to 128 positions per weight pass) instead of one forward per token
- *   "chain_norm" = 0|1 : parity mode, dim <= 512: the two rmsnorms of a layer folded into the chain-order matvecs that
- *                   consume them (every workgroup forms the exact sum itself; default 1: +6.6 % at the stories15M shape)
- *   "prefill_chain" = 0|1 : parity mode's rama_prefill through the chain-order token-batch kernels (default 1)
- *   "prefill_tok" = 64|128 : positions per weight pass of rama_prefill (default 128; 64 = round 2's kernels)
- *   "fused" = -1|0|1 : 1 runs a whole stage of rama_forward* / the chained decode loop -- every layer and the classifier --
- *                   as ONE launch (csrc/layer_fused.hpp: the phases wait for each other's output vectors, whose floats
- *                   carry their own tags; weights are requested before the wait); -1 (default) = for dim <= 1024:
- *                   12 315 vs 9 640 tok/s at the stories15M shape, 5 299 vs 3 700 at stories110M.  Same results within
- *                   the fast path's bar; long contexts that split attention, per-kernel timing and wider models take
- *                   the separate launches.  "fused_solo" = -1|0|1: its workgroups alone on their CU (-1 = for dim > 512)
- *   "merge" = -1|0|1 : 1 runs attention and the Wo matvec as one launch when the occupancy API says
- *                   its whole grid is resident (Wo's weights stream while attention runs); -1
- *                   (default) turns it on for dim <= 1024 only: measured +4.2 % / +7.7 % tokens/s at
- *                   the stories110M / stories15M shapes, +0.9 % short and -2.5 % at 1000-token
- *                   contexts at llama2-7B
- *   "attn_nsplit" = 0..32, "attn_waves" = 16|8|4, "attn_nt" = 0|1 : geometry of the split-T attention of long
- *                   contexts: slices per head (0 = #CUs / n_heads, at most 16), waves per workgroup (default 8)
- *                   and non-temporal cache-row loads (default 1); tools/attn_sweep.py
- *   "attn_u" = 8|16 : cache rows of K and of V a lane requests per round there; 16 (at <= 8 waves) makes a round 256
- *                   timesteps at head size 128 -- a whole slice of a 2048-token context in one round trip; measured
- *                   no faster (14.9 vs 14.1 us per launch at 1900 tokens), default 8
- *   "small_attn" = -1|0|1, "small_attn_waves" = 4|8, "small_attn_pos" = N : fewer-wave attention workgroups in the
- *                   decode step; -1 (default): 8 waves per head below position 256 where attention is not
- *                   merged with Wo (+0.7 % tokens/s at llama2-7B, positions 8..135)
- *   "solo" = -1|0|1 : matvecs with one wave per row group and no LDS turn; -1 (default) = for rows of <= 2048
- *                   floats (the stories15M / 110M widths), where launches are latency-bound
- *   "norm_in_gemm" = 0|1 : token-batch passes: 1 (default) = an rmsnorm is one launch (fold the pending K-slices,
- *                   X * gain, partial sums of squares) and the GEMM that consumes it scales its outputs per token,
- *                   as the decode matvecs do; 0 = a second launch writes the normalised activations
- *   "tiled" = 0|1 : 1 (default) lets rama_prefill / rama_decode_batch read the tile-order copy of the weights a
- *                   rama_model keeps (csrc/model.hip make_tiled; +27 GB at llama2-7B, RAMA_NO_TILED=1 skips it):
- *                   contiguous 1-KiB weight reads -- 16-token passes 6.4 -> 4.7 ms at llama2-7B; 0 = row-major weights
- *   "prefill_attn" = 0|1 : 1 (default) runs the attention of a prefill pass as fp32 MFMA tiles, 16 queries of a head
- *                   per workgroup sharing every cache row (csrc/prefill_attn.hpp; head sizes 16, 32, 48, 64, 128); 0 = one
- *                   decode-attention workgroup per (head, query)
- *   "graph_steps" = -1|1..32 : decode steps captured per hipGraph in rama_decode_steps / rama_generate (the cursor
- *                   lives on the device, so consecutive steps are the same launches).  A graph launch costs ~7 us on
- *                   top of its kernels; 4 steps per graph: +5.3 % tokens/s at stories15M, +1.4 % at 110M, +0.1 % at
- *                   llama2-7B; 8 and more are slower again.  -1 (default): 4 for dim <= 1024, else 1
- *   "spread_pos" = 64..2^20 : parity mode: the position from which the exact attention runs spread over the chip (scores over
- *                   heads x groups of 64 timesteps, then softmax + value chains over heads x 16-column slices) instead of one
- *                   workgroup per head.  Default 128 (round 3: 1024): llama2-7B 187 against 184 tok/s at positions 124..179,
- *                   178 against 152 at 800.  Head sizes that are no multiple of 32 always take one workgroup per head
- *   "attn_fv" = 0|1 : parity mode from "spread_pos" on (the attention spread over the chip): 1 (default) = the softmax and the value
- *                   chains as ONE launch, every 16-column slice workgroup of a head repeating the head's softmax while its value rows
- *                   are on their way (22.2 us at 1 900 timesteps); 0 = two launches (9.5 + 16.0 us).  Same bits.
- *   "topp_sort" = 0|1 : ordering step of the top-p sampler for vocabularies <= 32768: 1 (default) = block sorts in
- *                   LDS + ranks by binary searches in the other sorted blocks staged in LDS (csrc/topp_sort.hpp);
- *                   0 = the ranks through global memory (topp_rank_global_kernel) and the staged lane ripple for the
- *                   sums -- what larger vocabularies always take.  Same token either way; no library kernel in either.
- *   "topp_pairs" = 0|1 : how the sorted blocks are merged into one order (vocabularies <= 32768): 1 (default) = one workgroup
- *                   per (block, blocks) pair, every entry of a block does ONE binary search in each other block and adds the
- *                   count (and the mass in front of that place) to its accumulator, then a scatter launch; 0 = round 3's
- *                   launch, every workgroup searching all 15 other blocks in its own LDS (23.1 us: 32 CUs, LDS-conflict-bound)
- *   "topp_block" = 1024|512|2048 : entries per sorted block on the pair-ranking path.  1024 (default) / 512: the softmax
- *                   statistics once (a launch of its own, one partial per 1024 logits), block sorts on 8 / 4 waves with the
- *                   in-wave stages by DPP moves and lane swaps, every block's running mass as a 48-bit fixed-point sum;
- *                   2048 = round 3's block sort (every workgroup repeats the statistics), without masses
- *   "topp_dist" = 0|1 : the running sums of the sorted probabilities (blocks of 1024 / 512 only): 1 (default) = by up to 32
- *                   workgroups in one launch (csrc/topp_pick.hpp: binades predicted from the exact mass in front of every
- *                   entry, integer maps, a lane ripple over the chunks' items; lists up to 8192 entries are left to one
- *                   workgroup); 0 = one workgroup's scan rounds, one per binade (round 2).  Same sums bit for bit.
- *                   32 000 flat logits: 36 us per token (r3: 81), 109 kept entries: 17.6 us (26) -- profiles/r04_sampler_bench.json
- *   "topp_keep_sums" = 0|1 : 1 makes the top-p sampler also store its running sums in device scratch (tests)
- *   "ref_order" = 0|1|2 : 0 (default) = the fast path (fused multiply-adds, tree-shaped sums), which differs from the
- *                   CPU path by the CPU path's own rounding error (1.5e-4 in llama2-7B logits over 200 positions).
- *                   1 = PARITY MODE: every op in the REFERENCE'S OWN rounding order (4-lane sequential matvec sums with
- *                   separate multiply and add, sequential rmsnorm / softmax sums, glibc's expf restated), results
- *                   bit-identical to the reference CPU path.  A resident model streams its chain-order weight copy
- *                   (csrc/chain.hpp; made on first use, +27 GB at llama2-7B): 4.8 ms per llama2-7B token, the dominant
- *                   matvec at 0.80 of the HBM roofline.  [r5] Weights uploaded tensor by tensor (hbm.rs:55-90) run the same
- *                   kernels: the fused entries (rama_forward*, rama_decode_*, rama_generate*, rama_prefill) ADOPT a
- *                   rama_weights whose matrices lie in rama_alloc_f32 / rama_upload_f32 allocations -- the same chain-order
- *                   copies as a resident model's -- and rama_matmul makes a chain-order copy of a matrix that belongs to no
- *                   model on first use ("chain_views").  Freeing (rama_free) or overwriting (rama_copy_h2d_f32) a tensor
- *                   drops what was derived from it.  The host mirrors (C++ CLI, Rust shim) select this mode by default
- *                   (RAMA_REF_ORDER=0 for the fast path); the library's own default stays 0.
- *                   2 = the tolerance-mode EXPERIMENT: parity mode's chain-order matvecs with the rmsnorm sums
- *                   tree-shaped and folded into them and the fast path's attention: 218 tok/s at llama2-7B, but 1.4e-4
- *                   from the CPU path, no closer than the fast path (profiles/r04_tolerance_sweep_7b_200pos.jsonl).
- *   "tol_mask" = 0..127 : with "ref_order" = 2, ops swapped for A/B runs: 1 / 2 / 4 / 8 / 16 = the FAST Wq|Wk|Wv / Wo /
- *                   W1|W3 / W2 / classifier launch, 32 = parity mode's attention, 64 = its exact-sum norm launches
- *                   (tools/tol_sweep.py: which op carries how much of the distance to the CPU path)
- *   "chain" = 0|1, "chain_d" = 0 | 100 W + D, "chain_norm" = 0|1, "prefill_chain" = 0|1 : parity mode's kernels -- the
- *                   chain-order copy on/off, the matvec geometry (waves per 16 rows, blocks in flight), the exact norms
- *                   folded into the matvecs (dim <= 512), prompt positions through the chain-order token-batch kernels
- *   "chain_lead" = 0|1 : [r5] parity mode, 512 < dim <= 4096: the layer norms' exact sums by a LEADER workgroup inside the
- *                   consuming matvec's launch (it publishes 1 / sqrt(mean(x^2) + eps) as one tagged word; the others request
- *                   their weights, then wait for it) instead of a launch of their own: 193 -> 204 tok/s at llama2-7B (default 1)
- *   "chain_lead_w" = 0|1|2 : waves per row group of those launches (0 = by the number of row groups)
- *   "chain_resid_d" = -1 | 0 | 100 W + D : [r5] geometry of parity mode's residual products (Wo, W2) alone; -1 (default) = one
- *                   wave with a ring of 32 blocks when a compute unit holds at most one row group (llama2-7B: Wo 15.1 -> 13.5 us,
- *                   W2 33.6 -> 32.1), 0 = like the other products
- *   "chain_views" = 0|1 : parity mode's rama_matmul makes a chain-order copy of a matrix of no model on first use (default 1)
- *   "rope_batch" = 0|1 : [r5] a run of rama_apply_position calls on consecutive heads (q, k advancing by head_size, the same table rows:
- *                   infer.rs:25-29) is recorded and issued as ONE launch by whatever enters the library next -- same bits, 32 launches per layer
- *                   fewer (the 1:1 path 131 -> 172 tok/s at llama2-7B); only on a stream the context created itself (default 1)
- *   "matmul_batch" = 0|1, "ew_batch" = 0|1 : [r5] likewise up to three parity-mode rama_matmul calls with the same activations and shape
- *                   (infer.rs:20-23, :41-42), rama_sinu + the rama_array_mult on the same vector (:44-45) and two rama_copy_from_slice
- *                   calls in a row (:32-33): recorded, issued as one launch by the next entry into the library, program order kept at
- *                   every overlap (172 -> 185 tok/s; default 1)
- *   "norm_fold" = 0|1 : [r5] a parity-mode rama_rmsnorm (dim <= 4096, not in place) is recorded; the run of rama_matmul calls on its output carries it
- *                   as the launch's LEADER workgroup (the exact sum while the row groups' weights are already on their way), which also stores the
- *                   normalised vector; anything else issues it as a launch of its own first (the 1:1 path 189 -> 195 tok/s; default 1)
- *   "resid_fold" = 0|1 : [r5] rama_array_add of a recorded rama_matmul's output (infer.rs:35-37, :46-47) becomes that launch's residual epilogue
- *                   (195 -> 202 tok/s; default 1)
- *   "qkv_fold" = 0|1 : [r5] a run of three rama_matmul calls, rama_apply_position over every head of its first two outputs and the rama_copy_from_slice
- *                   of its last two outputs into cache rows (infer.rs:20-33) are ONE launch with the Wq|Wk|Wv epilogue; a sequence that stops short or
- *                   touches the run's vectors in between is issued in program order (202 -> 203 tok/s from a Python host, which then is the limit; default 1)
- *   "chain_split" = 0|1 : [r5] parity matvecs on one wave per row group whose row groups do not divide by the compute units: the remainder as HALF groups
- *                   (8 rows on 32 lanes), so that no CU carries a whole group more than the others (llama2-7B W1|W3: 1 376 groups on 256 CUs, 59.9 -> 59.0 us;
- *                   default 1) */
+/* Modes and performance knobs.  The MODE keys change which of the reference's admissible roundings is reproduced; every other key leaves results
+ * unchanged (parity mode: the same bits; fast mode: up to fp32 summation order).  Changing a key synchronises and drops captured graphs.
+ * Measurements and history of every key: DESIGN.md appendix A.
+ *
+ * MODE
+ *   "ref_order" = 0|1|2|3
+ *        0 (library default) FAST: fused multiply-adds, tree-shaped sums -- closer to the exact logits than the CPU path, ~1.5e-4 from it at llama2-7B depth.
+ *        1 PARITY (the default of every host mirror: C++ CLI, Rust shim, bench.py's `value`): every op in the reference CPU path's own rounding order
+ *          (cpu.rs: 4-lane strided matvec sums with separate multiply and add, front-to-back rmsnorm / softmax / attention sums, glibc's expf restated) on
+ *          chain-order weight copies (csrc/chain.hpp; made on first use, +27 GB at llama2-7B).  Bit-identical to oracle/rama_oracle.c -- i.e. to cpu.rs with
+ *          the two orders it leaves to its crates fixed: "lane_reduce" below, and rayon's softmax sum taken as ONE front-to-back sum.  Weights uploaded
+ *          tensor by tensor (hbm.rs:55-90) run the same kernels: the fused entries ADOPT them, rama_matmul makes a chain-order copy of a model-less matrix
+ *          on first use; rama_free, rama_copy_h2d_f32 and every entry that WRITES a tensor (an op's output, rama_fill_synth) drop what was derived from it.
+ *          A resident model's own tensors (rama_model_weights) are immutable by contract.
+ *        2 TOLERANCE experiment: chain-order matvecs, tree-summed norms folded in, fast attention (1.4e-4 from the CPU path: the instrument of "tol_mask").
+ *        3 BAR: parity up to position "bar_pos" - 1, the fast path's attention from there on (matvecs and norms stay exact).  Not bit-identical behind the
+ *          switch; measured <= 1e-4 from the oracle over the whole 2 048-position context at llama2-7B depth, +7 % tokens/s at position 1 900.
+ *   "lane_reduce" = 0|1|2 : parity / bar mode: the order of cpu.rs:148 `v.reduce_add()` -- 0 pairwise (l0+l1)+(l2+l3) (default), 1 strided (l0+l2)+(l1+l3),
+ *        2 sequential ((l0+l1)+l2)+l3.  wide::f32x4 leaves it to the build's target features; the Rust shim asks the crate at start-up and sets this.
+ *   "bar_pos" = N : first position of bar mode's fast attention (default 128; clamped to "spread_pos" and 256)
+ *   "tol_mask" = 0..127 : with "ref_order" = 2, ops swapped for A/B runs (1 / 2 / 4 / 8 / 16 = the FAST Wq|Wk|Wv / Wo / W1|W3 / W2 / classifier launch,
+ *        32 = parity mode's attention, 64 = its exact norms; tools/tol_sweep.py)
+ *
+ * FAST MODE  (default in brackets)
+ *   "geom" 0..3 [3] matvec workgroup geometry | "resid_r2" 0..3 [2] geometry of Wo / W2 | "solo" -1|0|1 [-1: rows <= 2048 floats] one wave per row group
+ *   "w13i" 0|1 [1] W1|W3 from the row-interleaved copy | "fused" / "fused_solo" -1|0|1 [-1: dim <= 1024 / dim > 512] a whole stage as ONE launch (layer_fused.hpp)
+ *   "merge" -1|0|1 [-1: dim <= 1024] attention + Wo as one launch | "split_pos" -1|N [-1: 256 when a head's K+V cache exceeds 1 MiB] split-T attention from N
+ *   "attn_nsplit" 0..32 [0], "attn_waves" 16|8|4 [8], "attn_nt" 0|1 [1], "attn_u" 8|16 [8], "combine_v" 0|1 [1] : split-T geometry
+ *   "small_attn" -1|0|1 [-1], "small_attn_waves" 4|8 [8], "small_attn_pos" N [256] : fewer-wave attention at short contexts
+ *   "graph_steps" -1|1..32 [-1: 4 for dim <= 1024, else 1] decode steps per captured graph | "prefill" 0|1 [1] rama_generate_greedy's prompt through rama_prefill
+ *   "prefill_tok" 64|128 [128], "prefill_attn" 0|1 [1], "tiled" 0|1 [1], "norm_in_gemm" 0|1 [1] : the token-batch passes (prefill_mfma.hpp, prefill_attn.hpp)
+ *   "topp_sort", "topp_pairs", "topp_dist" 0|1 [1], "topp_block" 512|1024|2048 [1024], "topp_keep_sums" 0|1 [0] : the device top-p sampler's phases
+ *
+ * PARITY MODE  (same bits whatever the setting)
+ *   "chain" 0|1 [1] chain-order copies (0: one thread per row) | "chain_d" 0|100 W + D [0], "chain_resid_d" -1|0|100 W + D [-1], "chain_lead_w" 0|1|2 [0] : geometry
+ *   "chain_norm" 0|1 [1] exact norms folded into the matvecs (dim <= 512) | "chain_lead" 0|1 [1] the norms' exact sums by a leader workgroup of the consuming launch
+ *   "chain_split" 0|1 [1] remainder row groups as half groups | "chain_views" 0|1 [1] chain-order copies of model-less matrices
+ *   "spread_pos" 64..2^20 [128] exact attention spread over the chip from this position | "attn_fv" 0|1 [1] its softmax + value chains as one launch
+ *   "prefill_chain" 0|1 [1] prompt positions through the chain-order token-batch kernels
+ *   "rope_batch", "matmul_batch", "ew_batch", "norm_fold", "resid_fold", "qkv_fold" 0|1 [1] : the 1:1 Device ops are RECORDED and issued merged (49 -> 6 launches
+ *        per layer; every hazard falls back to program order) */
 int  rama_set_tuning(rama_ctx *ctx, const char *key, int value);
 
 /* glibc 2.35 expf (the exp the reference's f32::exp calls on Linux) as the reference-order kernels

@@ -43,14 +43,39 @@ fn ck(rc: i32) {
     }
 }
 
+/// Which order does `wide::f32x4::reduce_add` of THIS build sum its lanes in?  [1, 2^-24, -1, 1.5 * 2^-24] gives three different fp32 results:
+/// pairwise (l0+l1)+(l2+l3) = 2^-23, strided (l0+l2)+(l1+l3) = 1.25 * 2^-23, sequential ((l0+l1)+l2)+l3 = 1.5 * 2^-24
+/// (tests/test_oracle_golden.py::test_lane_reduce_probe_vector pins the three values against the oracle's switch).
+fn probe_lane_reduce() -> c_int {
+    use wide::f32x4;
+    let e = f32::from_bits(0x3380_0000);                       // 2^-24
+    let v = f32x4::from(std::hint::black_box([1.0f32, e, -1.0f32, 1.5 * e])).reduce_add();
+    match v.to_bits() {
+        0x3400_0000 => 0,                                      // 2^-23: pairwise
+        0x3420_0000 => 1,                                      // 1.25 * 2^-23: strided
+        0x33C0_0000 => 2,                                      // 1.5 * 2^-24: sequential
+        other => panic!("wide::f32x4::reduce_add sums its lanes in an order this backend does not know (probe gave {other:#x})"),
+    }
+}
+
 impl Hip {
     pub fn new() -> Self {
         let mut ctx = ptr::null_mut();
         ck(unsafe { rama_ctx_create(0, ptr::null_mut(), &mut ctx) });
         // parity mode unless RAMA_REF_ORDER says otherwise (0 = fast, 2 = tolerance experiment): the reference CPU path's rounding order in
         // every op, logits bit-identical to cpu.rs (mirrors rama_amd/csrc/host/engine.hpp Hip::Hip)
-        let mode: c_int = std::env::var("RAMA_REF_ORDER").ok().and_then(|v| v.parse().ok()).unwrap_or(1);
+        let mode: c_int = match std::env::var("RAMA_REF_ORDER") {
+            Err(_) => 1,
+            Ok(v) => match v.parse::<c_int>() { Ok(k) if (0..=3).contains(&k) => k, _ => panic!("RAMA_REF_ORDER must be 0 (fast), 1 (parity), 2 (tolerance experiment) or 3 (bar), got '{v}'") },
+        };
         ck(unsafe { rama_set_tuning(ctx, b"ref_order\0".as_ptr() as *const c_char, mode) });
+        // cpu.rs:148 `v.reduce_add()`: the order of wide::f32x4's final 4-lane sum depends on the crate version and on the target features THIS binary was
+        // built with.  Ask the crate itself, and tell the library ("lane_reduce"), so that parity mode reproduces the CPU path of the same build.
+        let lanes: c_int = match std::env::var("RAMA_LANE_REDUCE") {
+            Ok(v) => v.parse().expect("RAMA_LANE_REDUCE must be 0 (pairwise), 1 (strided) or 2 (sequential)"),
+            Err(_) => probe_lane_reduce(),
+        };
+        ck(unsafe { rama_set_tuning(ctx, b"lane_reduce\0".as_ptr() as *const c_char, lanes) });
         Hip { ctx }
     }
     /// htod_sync_copy (hbm.rs:14-16)

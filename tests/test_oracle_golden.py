@@ -1,6 +1,8 @@
 """The oracle (CPU restatement of cpu.rs + infer.rs) against fixtures produced by the
 reference's own PyTorch model definition (tools/make_goldens.py) and against the one
 known-answer vector the reference's test suite holds (gpu.rs:249-288)."""
+from pathlib import Path
+
 import numpy as np
 import pytest
 
@@ -148,3 +150,63 @@ def test_v1_ak42_fixture_is_not_a_v0_file(golden_dir):
     assert int.from_bytes(raw[8:12], "little") == 32                    # dim of the tiny model
     with pytest.raises(ValueError, match="ak42"):
         O.read_checkpoint(golden_dir / "ckpt_v1_ak42.bin")
+
+
+# ------------------------------------------------------------------ [r6] the two orders the reference leaves to its crates
+
+def test_lane_reduce_probe_vector():
+    """cpu.rs:148 `v.reduce_add()`: the oracle's three lane orders on the probe vector the Rust shim asks `wide` with at start-up
+    (integration/rust/hip.rs probe_lane_reduce): three DIFFERENT fp32 results, the bit patterns the shim matches on"""
+    e = np.float32(2.0 ** -24)
+    probe = np.array([1.0, e, -1.0, np.float32(1.5) * e], np.float32)
+    ones = np.ones(4, np.float32)
+    want = {"pairwise": 0x34000000, "strided": 0x34200000, "sequential": 0x33C00000}
+    text = (Path(__file__).resolve().parent.parent / "integration" / "rust" / "hip.rs").read_text()
+    for order, bits_ in want.items():
+        with O.orders(lane_reduce=order):
+            o = np.zeros(1, np.float32)
+            O.matmul(o, probe, ones, 4, 1)
+        assert int(o.view(np.uint32)[0]) == bits_, (order, hex(int(o.view(np.uint32)[0])))
+        assert f"{bits_:08x}" in text.replace("_", "").lower(), f"hip.rs does not match on {bits_:#x}"
+    assert O.lib().oracle_get_lane_reduce() == 0          # the context manager restored the default
+
+
+def test_lane_reduce_and_softmax_split_orders():
+    """the oracle's switches against plain numpy restatements: the final 4-lane sum in each order (cpu.rs:141-148), rayon's halving tree over the
+    softmax's exponentials (cpu.rs:190) with 2^levels leaves -- and level 0 / pairwise are the defaults every golden fixture was checked with"""
+    rng = np.random.default_rng(5)
+    rows, width = 37, 260
+    a = rng.standard_normal((rows, width)).astype(np.float32)
+    b = rng.standard_normal(width).astype(np.float32)
+    lanes = []
+    for j in range(4):
+        acc = np.zeros(rows, np.float32)
+        for k in range(j, width, 4):
+            acc = acc + a[:, k] * b[k]
+        lanes.append(acc)
+    want = {"pairwise": (lanes[0] + lanes[1]) + (lanes[2] + lanes[3]), "strided": (lanes[0] + lanes[2]) + (lanes[1] + lanes[3]),
+            "sequential": ((lanes[0] + lanes[1]) + lanes[2]) + lanes[3]}
+    for order, w_ in want.items():
+        with O.orders(lane_reduce=order):
+            o = np.zeros(rows, np.float32)
+            O.matmul(o, a, b, width, rows)
+        assert np.array_equal(o.view(np.uint32), w_.astype(np.float32).view(np.uint32)), order
+
+    def tree(x, levels):
+        if levels <= 0 or x.size < 2:
+            s = np.float32(0.0)
+            for v in x:
+                s = np.float32(s + v)
+            return s
+        mid = x.size // 2
+        return np.float32(tree(x[:mid], levels - 1) + tree(x[mid:], levels - 1))
+
+    for n in (1, 2, 3, 33, 200, 1901):
+        x = (rng.standard_normal(n) * 3).astype(np.float32)
+        ex = O.expf(x - x.max())
+        for levels in (0, 1, 2, 5, 12):
+            with O.orders(softmax_split=levels):
+                y = x.copy()
+                O.softmax(y, n)
+            assert np.array_equal(y.view(np.uint32), (ex / tree(ex, levels)).astype(np.float32).view(np.uint32)), (n, levels)
+    assert O.lib().oracle_get_softmax_split() == 0

@@ -33,7 +33,7 @@ out = Path(a.out).resolve()
 out.mkdir(parents=True, exist_ok=True)
 tag = f"r{a.round:02d}"
 suffix = {"parity": "_parity", "tol": "_tol"}.get(a.mode, "")
-mode_args = ["--mode", a.mode, "--no-other-configs", "--no-prefill", "--no-by-position", "--no-trait-ops", "--config", a.config]
+mode_args = ["--mode", a.mode, "--no-other-configs", "--no-prefill", "--no-by-position", "--no-trait-ops", "--no-generation-200", "--config", a.config]
 short = "7b" if a.config == "llama2-7B" else a.config
 env = dict(os.environ, TMPDIR="/tmp")
 bench = str(REPO / "bench.py")
@@ -65,7 +65,7 @@ shutil.copy(stats[0], out / f"{tag}_bench_{short}{suffix}_kernel_stats.csv")
 d2 = out / "_pmc"
 shutil.rmtree(d2, ignore_errors=True)
 cmd2 = ["rocprofv3", "--kernel-trace", "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", str(d2), "-o", "pmc", "--",
-        "python3", bench, "--steps", "16", "--warmup", "2", "--no-cpu-baseline", "--no-kprof", "--no-sampled", "--graph", "0"] + mode_args
+        "python3", bench, "--steps", "16", "--warmup", "2", "--settle-s", "0", "--no-cpu-baseline", "--no-kprof", "--no-sampled", "--graph", "0"] + mode_args      # (counters serialise the launches: no untimed settle passes under them)
 run(cmd2, d2)
 cc = glob.glob(str(d2 / "**" / "*counter_collection.csv"), recursive=True)
 assert cc, "rocprofv3 wrote no counter_collection.csv"
