@@ -163,7 +163,7 @@ struct Hip final : Device {
     // path (fused multiply-adds, tree-shaped sums: ~20 % faster, ~1.5e-4 from the CPU path at 32 layers x 200 positions), 2 the tolerance experiment,
     // 3 bar mode (parity up to position 127, the fast path's attention from 128 on: <= 1e-4 measured over the whole 2 048-position context, not bit-identical).
     explicit Hip(int device = 0) {
-        ck(rama_ctx_create(device, nullptr, &ctx), "rama_ctx_create");
+        // (the environment is read BEFORE anything touches a GPU: a bad value exits 2 on any machine)
         // (strtol with an end-pointer check: "parity", "" or "1x" are refused instead of silently meaning 0 = fast mode)
         auto env_int = [](const char* name, long fallback, long lo, long hi, const char* what) {
             const char* v = std::getenv(name);
@@ -174,9 +174,10 @@ struct Hip final : Device {
             return k;
         };
         const int mode = (int)env_int("RAMA_REF_ORDER", 1, 0, 3, "0 (fast), 1 (parity, the default), 2 (tolerance experiment) or 3 (bar: parity with the fast attention from position 128 on)");
-        ck(rama_set_tuning(ctx, "ref_order", mode), "rama_set_tuning(ref_order)");
         // the order of wide::f32x4::reduce_add in the reference build this host stands in for (cpu.rs:148): 0 pairwise (the default), 1 strided, 2 sequential
         const int lanes = (int)env_int("RAMA_LANE_REDUCE", 0, 0, 2, "0 (pairwise), 1 (strided) or 2 (sequential)");
+        ck(rama_ctx_create(device, nullptr, &ctx), "rama_ctx_create");
+        ck(rama_set_tuning(ctx, "ref_order", mode), "rama_set_tuning(ref_order)");
         if (lanes) ck(rama_set_tuning(ctx, "lane_reduce", lanes), "rama_set_tuning(lane_reduce)");
     }
     ~Hip() override { rama_ctx_destroy(ctx); }

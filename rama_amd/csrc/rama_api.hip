@@ -82,6 +82,8 @@ struct GraphCache {
     bool valid = false;
     int steps = 1;                     // decode steps in the captured graph
     unsigned long long copies_gen = 0; // model.hip's generation of derived weight copies at capture: a graph holds their addresses, and ANOTHER context may free them
+    bool handoff = false;              // [r6] the captured launches hand data over inside a kernel (a leader norm, attention+Wo, the one-launch stage): a REPLAY must mark
+                                       // the error word as worth reading too (rama_ctx::handoff_dirty is otherwise only set where such a launch is enqueued)
 };
 
 struct rama_ctx {
@@ -1643,9 +1645,13 @@ static int run_stage(rama_ctx* c, const rama_config* cfg, const rama_weights* w,
             c->sg.erase(c->sg.begin() + (long)old);
         }
         rama_ctx::StageGraph e;
+        const bool dirty_before = c->handoff_dirty;
+        c->handoff_dirty = false;
         HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
         const int rc = enqueue_stage(c, cfg, w, s, st);
         const hipError_t err = hipStreamEndCapture(c->stream, &e.g.graph);
+        e.g.handoff = c->handoff_dirty;
+        c->handoff_dirty = dirty_before;
         if (rc) { if (e.g.graph) hipGraphDestroy(e.g.graph); return rc; }
         HIPCHK(err);
         HIPCHK(hipGraphInstantiate(&e.g.exec, e.g.graph, nullptr, nullptr, 0));
@@ -1655,6 +1661,7 @@ static int run_stage(rama_ctx* c, const rama_config* cfg, const rama_weights* w,
     }
     hit->used = ++c->sg_clock;
     HIPCHK(hipGraphLaunch(hit->g.exec, c->stream));
+    if (hit->g.handoff) c->handoff_dirty = true;
     return 0;
 }
 
@@ -2653,15 +2660,20 @@ int rama_decode_steps(rama_ctx* c, const rama_config* cfg, const rama_weights* w
                 if (g.exec) hipGraphExecDestroy(g.exec);
                 if (g.graph) hipGraphDestroy(g.graph);
                 g = GraphCache();
+                const bool dirty_before = c->handoff_dirty;
+                c->handoff_dirty = false;
                 HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
                 for (int k = 0; k < take && !rc; k++) rc = enqueue_decode_step(c, cfg, w, s);
                 hipError_t e = hipStreamEndCapture(c->stream, &g.graph);
+                g.handoff = c->handoff_dirty;
+                c->handoff_dirty = dirty_before;
                 if (rc) return rc;
                 HIPCHK(e);
                 HIPCHK(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
                 g.cfg = *cfg; g.w = *w; g.s = *s; g.valid = true; g.copies_gen = rama_internal_copies_generation(); g.steps = take;
             }
             HIPCHK(hipGraphLaunch(g.exec, c->stream));
+            if (g.handoff) c->handoff_dirty = true;
         } else {
             rc = enqueue_decode_step(c, cfg, w, s);
             if (rc) return rc;

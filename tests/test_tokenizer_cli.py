@@ -1,6 +1,7 @@
 """Host-side string code: the C++ tokenizer (rama_amd/csrc/host/tokenizer.hpp)
 against the Python restatement of bpe.rs (oracle/tokenizer.py) on synthetic vocabularies (CPU),
 and -- marked gpu -- the engine CLI's printed text against oracle generate() + decode."""
+import os
 import random
 import struct
 import subprocess
@@ -225,3 +226,14 @@ def test_engine_cli_rejects_too_many_steps(tmp_path):
     r = subprocess.run([str(ENGINE), "-m", str(GOLDEN / "ckpt_tied.bin"), "-t", str(tokp), "-s", "17", "-r", "0"],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "seq_len" in r.stderr
+
+
+@pytest.mark.parametrize("var,value", [("RAMA_REF_ORDER", "parity"), ("RAMA_REF_ORDER", ""), ("RAMA_REF_ORDER", "1x"), ("RAMA_REF_ORDER", "4"), ("RAMA_LANE_REDUCE", "pairwise"), ("RAMA_LANE_REDUCE", "3")])
+def test_cli_refuses_garbage_mode_variables(var, value):
+    """[r6] (round 5's advisor) `atoi` turned RAMA_REF_ORDER=parity into 0 -- FAST mode, silently, although the default is parity.  The C++ host now parses with
+    an end-pointer check BEFORE anything touches a GPU: garbage or an out-of-range value exits 2 with a message naming the variable (runs without a GPU)"""
+    if not ENGINE.exists():
+        pytest.skip("engine binary not built")
+    r = subprocess.run([str(ENGINE), "-m", str(GOLDEN / "ckpt_tied.bin"), "-t", str(REPO / "tests" / "golden" / "nonexistent_tokenizer.bin"), "-s", "3", "-r", "0"],
+                       capture_output=True, text=True, env=dict(os.environ, **{var: value}), timeout=60)
+    assert r.returncode == 2 and var in r.stderr, (r.returncode, r.stderr[-300:])
