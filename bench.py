@@ -82,40 +82,49 @@ def parse(argv=None):
     return ap.parse_args(argv)
 
 
-def library_stamp():
-    """what is being run: the first 16 hex digits of the SHA-256 of rama_amd/librama_hip.so (content, not history: the GPU box has no .git) and the git
-    head recorded when it was built (rama_amd/BUILD_INFO.json, written by __graft_entry__.build(); informational)"""
+LIB_SOURCES = ("rama_amd/csrc/*.hip", "rama_amd/csrc/*.hpp", "include/rama_hip.h")      # what librama_hip.so is compiled from
+
+
+def source_hash():
+    """first 16 hex digits of the SHA-256 over (relative path, contents) of every source file of librama_hip.so, in sorted order: the identity of a build that
+    survives a rebuild (hipcc's output is not bit-reproducible: two builds of the same sources hash differently) and a fresh checkout"""
+    import glob
     import hashlib
-    lib = REPO / "rama_amd" / "librama_hip.so"
-    out = {"lib_sha16": None, "git_head_at_build": None}
-    try:
-        h = hashlib.sha256()
-        with open(lib, "rb") as f:
-            for blk in iter(lambda: f.read(1 << 20), b""):
-                h.update(blk)
-        out["lib_sha16"] = h.hexdigest()[:16]
-    except OSError:
-        pass
+    h = hashlib.sha256()
+    files = sorted(f for pat in LIB_SOURCES for f in glob.glob(str(REPO / pat)))
+    for f in files:
+        h.update(str(Path(f).relative_to(REPO)).encode() + b"\0")
+        h.update(Path(f).read_bytes())
+        h.update(b"\0")
+    return h.hexdigest()[:16] if files else None
+
+
+def library_stamp():
+    """what is being run: `src_sha16` = source_hash() of the tree, `built_from_src_sha16` = the same as __graft_entry__.build() recorded it when it compiled
+    the library that is loaded (rama_amd/BUILD_INFO.json; `stale_build` when the two differ: sources edited without a rebuild), the git head at that build
+    (informational: the GPU box has no .git)"""
+    out = {"src_sha16": source_hash(), "built_from_src_sha16": None, "git_head_at_build": None}
     try:
         info = json.loads((REPO / "rama_amd" / "BUILD_INFO.json").read_text())
+        out["built_from_src_sha16"] = info.get("src_sha16")
         out["git_head_at_build"] = info.get("git_head")
-        if info.get("lib_sha16") and out["lib_sha16"] and info["lib_sha16"] != out["lib_sha16"]:
-            out["build_info_stale"] = True
     except (OSError, ValueError):
         pass
+    if out["built_from_src_sha16"] != out["src_sha16"]:
+        out["stale_build"] = True
     return out
 
 
 def profile_stamp(path):
     """the library a committed profile was collected on (tools/collect_profiles.py and the parity test write `library` into their JSON; a CSV has a
-    .meta.json beside it): -> lib_sha16 or None (profiles of rounds 1-5 carry no stamp)"""
+    .meta.json beside it): -> src_sha16 or None (profiles of rounds 1-5 carry no stamp)"""
     try:
         pth = Path(path)
         if pth.suffix == ".json":
             j = json.loads(pth.read_text())
         else:
             j = json.loads(pth.with_suffix(".meta.json").read_text())
-        return (j.get("library") or {}).get("lib_sha16")
+        return (j.get("library") or {}).get("src_sha16")
     except (OSError, ValueError, AttributeError):
         return None
 
@@ -584,7 +593,7 @@ def bar_whole_context():
             for sm in j["summaries"]:
                 if sm["config"] == "bar":
                     return {"source": f"profiles/{Path(f).name}", "positions": sm["positions"], "worst_vs_oracle": sm["worst_vs_oracle"], "positions_over_1e-4": sm["positions_over_1e-4"],
-                            "greedy_tokens_equal": sm["greedy_tokens_equal"], "worst_by_512": sm["worst_by_512"], "library": (j.get("library") or {}).get("lib_sha16")}
+                            "greedy_tokens_equal": sm["greedy_tokens_equal"], "worst_by_512": sm["worst_by_512"], "library": (j.get("library") or {}).get("src_sha16")}
         except (OSError, ValueError, KeyError):
             continue
     return None
@@ -744,7 +753,7 @@ def single_gpu(args, local_rank):
     if bw:
         quoted[bw["source"]] = bw.get("library")
     line["profiles_quoted"] = quoted
-    line["profile_matches_build"] = bool(quoted) and all(v is not None and v == lib["lib_sha16"] for v in quoted.values())
+    line["profile_matches_build"] = bool(quoted) and not lib.get("stale_build") and all(v is not None and v == lib["src_sha16"] for v in quoted.values())
     print(json.dumps(line), flush=True)
     dev.close()
 
