@@ -77,7 +77,7 @@ def parse(argv=None):
     ap.add_argument("--pos0", type=int, default=0,
                     help="start the timed generation at this position over a pre-filled (zero) cache: long-context timing, "
                          "N = 1 only; the default 0 is generate()'s own start (BOS + prompt)")
-    ap.add_argument("--cpu-tokens", type=int, default=4, help="tokens of the CPU baseline's sample (the first one warms up)")
+    ap.add_argument("--cpu-tokens", type=int, default=16, help="tokens of the CPU baseline's sample (the first one warms up); every mode's logits are compared with the oracle's at each of them")
     ap.add_argument("--rank-timeout", type=float, default=900.0, help="seconds the self-started ranks of --gpus N may take")
     return ap.parse_args(argv)
 

@@ -1071,6 +1071,35 @@ def test_bar_mode_is_parity_until_its_switch_then_the_fast_attention(dev, dim, h
         eng.free(); model.free()
 
 
+@pytest.mark.parametrize("dim,hidden,heads,layers,seq,steps", [(288, 768, 6, 3, 256, 200), (2048, 2048, 16, 2, 1100, 300)])
+def test_bar_mode_chained_decode_crosses_its_switches(dev, dim, hidden, heads, layers, seq, steps):
+    """[r6] the device-chained generate() loop in bar mode, replayed from hipGraphs (four steps per graph at dim <= 1024), straight through position 128 --
+    where the graph variant changes from parity mode's exact attention to the fast path's -- and through 256 (the wider shape: a head's K + V cache
+    exceeds 1 MiB there, so the fast attention turns split-T): the oracle's greedy tokens at every step, the positions below 128 from parity mode's bits"""
+    import rama_amd
+    from rama_amd._lib import check
+    from .helpers import to_rama_cfg
+    cfg = O.Config(dim, hidden, layers, heads, heads, 512, seq, True)
+    rope = S.rope_tables(seq, dim // heads)
+    w = S.synth_weights(cfg, 23, rope=rope)
+    prompt = [17, 4, 99]
+    want = O.Oracle(cfg, w).generate_greedy(prompt, steps)
+    model = rama_amd.Model.synth(dev, to_rama_cfg(cfg), 23, rope=rope)
+    check(dev.lib.rama_set_tuning(dev.ctx, b"ref_order", 3))
+    try:
+        for graph in (True, False):
+            eng = rama_amd.Engine(dev, model)
+            eng.set_graph_mode(graph)
+            got = eng.generate_greedy(prompt, steps)
+            eng.set_graph_mode(False)
+            first_bad = next((i for i, (a_, b_) in enumerate(zip(got, want)) if a_ != b_), None)
+            assert got == want, (graph, first_bad, got[first_bad - 2:first_bad + 3], want[first_bad - 2:first_bad + 3])
+            eng.free()
+    finally:
+        check(dev.lib.rama_set_tuning(dev.ctx, b"ref_order", 1))
+        model.free()
+
+
 def test_llama2_7b_width_deep_context_bit_exact(dev):
     """[r6] the HEADLINE shape's width (dim 4096, hidden 11008, 32 heads of 128, seq_len 2048; 2 of the 32 layers, so that the oracle needs
     1.6 GB instead of 27) deep into the context: both caches filled with the same random rows on both sides, parity mode with the default
