@@ -556,7 +556,7 @@ def roofline_of(kernels, bytes_, mode, d):
     elif mode == "parity":
         kname = "gemv_chain_kernel<W,D,XD,CEPI_SWIGLU> (chain-order W1|W3 matvec in the reference's rounding order + SiLU*gate)"
         kname = "gemv_chain_kernel<W,D,XD,CEPI_SWIGLU,CNORM_LEAD> (the FFN norm's exact sum by a leader workgroup of the launch + chain-order W1|W3 matvec in the reference's rounding order + SiLU*gate)"
-        traffic, traffic_src = pmc_traffic("gemv_chain_kernel<1, 16, 4, 3, 3, 64>") if d == 4096 else (None, None)      # [r5] the leader-norm instantiation
+        traffic, traffic_src = pmc_traffic("gemv_chain_kernel<1, 16, 4, 3, 3, 64") if d == 4096 else (None, None)      # [r5] the leader-norm instantiation
         if traffic is None and d == 4096:
             kname = "gemv_chain_kernel<W,D,XD,CEPI_SWIGLU> (chain-order W1|W3 matvec in the reference's rounding order + SiLU*gate)"
             traffic, traffic_src = pmc_traffic("gemv_chain_kernel<1, 16, 4, 3, 0>")
