@@ -2,7 +2,7 @@
 """The C++ CLI (rama_amd/bin/engine, the mirror of engine/src/main.rs) at the llama2-7B shape: a synthetic v0 checkpoint written to a scratch
 directory by rama_model_save, a 32 000-entry tokenizer file, then the CLI on its three paths -- RAMA_PATH=ops (forward() composed from the 1:1
 Device ops on tensor-by-tensor uploads: the reference's own structure, compiled host), fused, chained -- in parity mode (the default) and in
-fast mode.  Prints one JSON line per run.  Usage: python tools/cli_7b_bench.py [scratch dir] [steps]"""
+fast mode, [r6] and in bar mode (RAMA_REF_ORDER=3).  Prints one JSON line per run.  RAMA_CLI_PATHS=chained restricts the paths.  Usage: python tools/cli_7b_bench.py [scratch dir] [steps]"""
 import json, os, re, struct, subprocess, sys, time
 from pathlib import Path
 REPO = Path(__file__).resolve().parent.parent
@@ -25,8 +25,10 @@ with open(tokp, "wb") as f:
     f.write(struct.pack("<I", max(len(s.encode()) for s, _ in entries)))
     for s, score in entries:
         b = s.encode(); f.write(struct.pack("<fi", score, len(b))); f.write(b)
-for mode, ro in (("parity", None), ("fast", "0")):
-    for path in ("ops", "fused", "chained"):
+modes = (("parity", None), ("bar", "3"), ("fast", "0"))      # [r6] bar: RAMA_REF_ORDER=3
+paths = tuple(os.environ.get("RAMA_CLI_PATHS", "ops,fused,chained").split(","))
+for mode, ro in modes:
+    for path in paths:
         env = dict(os.environ, RAMA_PATH=path)
         env.pop("RAMA_REF_ORDER", None)
         if ro is not None:
