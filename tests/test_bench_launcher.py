@@ -80,3 +80,26 @@ def test_bench_gpus_n_without_launcher_spawns_before_touching_a_gpu(tmp_path):
         r = subprocess.run(cmd, env=dict(env, RAMA_BENCH_SKIP_DEVICE_CHECK="1"), capture_output=True, text=True, timeout=300)
         assert r.returncode != 0 and "rank" in r.stderr
         assert r.stdout.strip() == ""
+
+
+def test_provenance_stamps(tmp_path):
+    """[r6] bench.py stamps what it prints, and the collectors what they write, with the hash of the SOURCES librama_hip.so is built from (hipcc's output
+    is not bit-reproducible, so the binary's own hash would not survive a rebuild): the hash is stable, __graft_entry__.build() records it, a stale build
+    is flagged, and a profile's stamp is read from its JSON or from the .meta.json beside a CSV"""
+    h = bench.source_hash()
+    assert isinstance(h, str) and len(h) == 16 and h == bench.source_hash()
+    info = REPO / "rama_amd" / "BUILD_INFO.json"
+    if info.exists():          # written by build(); the driver builds before it tests
+        st = bench.library_stamp()
+        recorded = json.loads(info.read_text()).get("src_sha16")
+        assert st["src_sha16"] == h and st["built_from_src_sha16"] == recorded
+        assert ("stale_build" in st) == (recorded != h)
+    j = tmp_path / "r99_x.json"
+    j.write_text(json.dumps({"library": {"src_sha16": "0123456789abcdef"}, "rows": []}))
+    assert bench.profile_stamp(j) == "0123456789abcdef"
+    c = tmp_path / "r99_kernel_stats.csv"
+    c.write_text("Name,Calls\n")
+    assert bench.profile_stamp(c) is None                      # no sidecar: rounds 1-5
+    c.with_suffix(".meta.json").write_text(json.dumps({"library": {"src_sha16": "fedcba9876543210"}}))
+    assert bench.profile_stamp(c) == "fedcba9876543210"
+    assert bench.profile_stamp(tmp_path / "missing.json") is None
